@@ -1,0 +1,118 @@
+"""Seeded synthetic inputs of the shapes BASELINE.md names.
+
+No demo clouds or checkpoints exist in the reference tree (LFS stubs), so bench.py and the tests use these
+generators.  Units are centimetres (reference README.md:82).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .gnn_data import FeaturedPoints
+from .params import HeadConfig
+from .so3 import irreps_dim
+
+
+def score_head_kwargs(lmax: int = 2, radii=(5., 10., 20., None)) -> dict:
+    """The `score_head_kwargs` block of reference configs/panda_mug/pick_lowres/score_model_configs.yaml:3-25
+    (+ the keys multiscale_score_model.py:79-85 injects), with irreps truncated at `lmax`."""
+    irr = '+'.join(['64x0e', '32x1e', '16x2e', '8x3e'][:lmax + 1])
+    sh = '+'.join(['1x0e', '1x1e', '1x2e', '1x3e'][:lmax + 1])
+    return dict(
+        max_time=1., time_emb_mlp=[256, 128, 64], ang_mult=2.5, lin_mult=15.,
+        edge_time_encoding=True, query_time_encoding=False,
+        key_tensor_field_kwargs=dict(
+            irreps_input=irr, irreps_output=irr, irreps_sh=sh, num_heads=4, fc_neurons=[-1, 128, 64],
+            length_emb_dim=64, r_cluster_multiscale=list(radii), n_layers=1, irreps_mlp_mid=3,
+            cutoff_method='edge_attn', r_mincut_nonscalar_sh=0.3,
+            length_enc_max_r=100. if radii[-1] is None else None, use_src_point_attn=False),
+        irreps_query_edf=irr)
+
+
+def fps(x: np.ndarray, ratio: float) -> np.ndarray:
+    """Farthest point sampling, start index 0, ceil(ratio*N) points (torch_cluster.fps with
+    random_start=False, as reference connectivity.py:62)."""
+    N = x.shape[0]
+    k = int(math.ceil(ratio * N))
+    idx = np.zeros(k, dtype=np.int64)
+    d = np.full(N, np.inf)
+    cur = 0
+    for i in range(k):
+        idx[i] = cur
+        d = np.minimum(d, ((x - x[cur]) ** 2).sum(-1))
+        cur = int(np.argmax(d))
+    return idx
+
+
+def make_scene(n_points: int, seed: int = 0) -> np.ndarray:
+    """60 % plane patch [-25,25]^2 x {0}, 40 % vertical cylinder surface (r=4, h=10, centre (0,0,5))."""
+    rng = np.random.default_rng(seed)
+    n_plane = int(round(0.6 * n_points))
+    n_cyl = n_points - n_plane
+    plane = np.stack([rng.uniform(-25, 25, n_plane), rng.uniform(-25, 25, n_plane), np.zeros(n_plane)], -1)
+    th = rng.uniform(0, 2 * np.pi, n_cyl)
+    cyl = np.stack([4 * np.cos(th), 4 * np.sin(th), rng.uniform(0, 10, n_cyl)], -1)
+    return np.concatenate([plane, cyl], 0)
+
+
+def make_grasp(n_points: int, seed: int = 0) -> np.ndarray:
+    """uniform on the surface of a 6x6x10 cm box centred (0,0,8) in the gripper frame."""
+    rng = np.random.default_rng(seed + 1000)
+    ext = np.array([6., 6., 10.])
+    areas = np.array([ext[1] * ext[2], ext[0] * ext[2], ext[0] * ext[1]])
+    face = rng.choice(3, size=n_points, p=areas / areas.sum())
+    p = rng.uniform(-0.5, 0.5, size=(n_points, 3)) * ext
+    sign = rng.choice([-0.5, 0.5], size=n_points)
+    p[np.arange(n_points), face] = sign * ext[face]
+    return p + np.array([0., 0., 8.])
+
+
+def make_key_clouds(cfg: HeadConfig, n_scene: int, seed: int = 0, ratio: float = 0.2,
+                    dtype=torch.float32) -> List[FeaturedPoints]:
+    """FPS cascade (ratio 0.2, n_scales times) of the synthetic scene; features ~ N(0,1) per component."""
+    x = make_scene(n_scene, seed)
+    g = torch.Generator().manual_seed(seed + 17)
+    out = []
+    for n in range(cfg.n_scales):
+        x = x[fps(x, ratio)]
+        f = torch.randn(x.shape[0], cfg.dim, generator=g, dtype=torch.float64)
+        out.append(FeaturedPoints(x=torch.tensor(x, dtype=dtype), f=f.to(dtype),
+                                  b=torch.zeros(x.shape[0], dtype=torch.long)))
+    return out
+
+
+def make_query(cfg: HeadConfig, n_grasp: int, seed: int = 0, ratio: float = 0.1, static_keypoints: bool = False,
+               dtype=torch.float32) -> FeaturedPoints:
+    g = torch.Generator().manual_seed(seed + 29)
+    if static_keypoints:      # reference configs/panda_mug/pick_lowres/score_model_configs.yaml:76-80
+        x = np.array([[0.5, 0.5, 10.5], [-0.5, -0.5, 10.5]])
+    else:
+        x = make_grasp(n_grasp, seed)
+        x = x[fps(x, ratio)]
+    f = torch.randn(x.shape[0], cfg.dim, generator=g, dtype=torch.float64)
+    w = torch.sigmoid(torch.randn(x.shape[0], generator=g, dtype=torch.float64))
+    return FeaturedPoints(x=torch.tensor(x, dtype=dtype), f=f.to(dtype), b=torch.zeros(x.shape[0], dtype=torch.long),
+                          w=w.to(dtype))
+
+
+def make_poses(n: int, seed: int = 1, first_pose_index: int = 0, near_object: bool = False,
+               dtype=torch.float64) -> torch.Tensor:
+    """(n,7) [qw,qx,qy,qz,x,y,z]; q = normalised N(0,1)^4 standardised to w>=0 (reference
+    transforms.py:349-355), x ~ U([-20,20]^2 x [0,25]).  Each pose is drawn from its own generator keyed by
+    (seed, global pose index) so that a pose-sharded run sees exactly the poses of the single-GPU run."""
+    out = np.zeros((n, 7))
+    for i in range(n):
+        rng = np.random.default_rng([seed, first_pose_index + i])
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        if q[0] < 0:
+            q = -q
+        if near_object:
+            p = np.array([rng.uniform(-8, 8), rng.uniform(-8, 8), rng.uniform(0, 15)])
+        else:
+            p = np.array([rng.uniform(-20, 20), rng.uniform(-20, 20), rng.uniform(0, 25)])
+        out[i, :4], out[i, 4:] = q, p
+    return torch.tensor(out, dtype=dtype)
