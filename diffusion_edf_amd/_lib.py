@@ -1,0 +1,135 @@
+"""ctypes binding of libdedf.so (C ABI in include/dedf.h).  There is NO fallback: if the HIP library is missing or
+no gfx950 device is present the product raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .params import HeadConfig
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libdedf.so")
+MAX_SCALES = 8
+
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_RUNTIME = 0, 1, 2, 3
+
+SYMBOLS = [
+    "dedf_version", "dedf_param_count", "dedf_param_name", "dedf_param_numel", "dedf_create", "dedf_destroy",
+    "dedf_last_error", "dedf_set_key_clouds", "dedf_set_query", "dedf_score", "dedf_sample", "dedf_get_stats",
+    "dedf_debug_enable", "dedf_debug_copy", "dedf_debug_packed",
+]
+
+
+class DedfConfig(C.Structure):
+    _fields_ = [
+        ("lmax", C.c_int), ("mul", C.c_int * 4), ("num_heads", C.c_int), ("fc_neurons", C.c_int * 3),
+        ("length_emb_dim", C.c_int), ("time_emb_mlp", C.c_int * 3), ("irreps_mlp_mid", C.c_int), ("n_scales", C.c_int),
+        ("radii", C.c_float * MAX_SCALES), ("r_mincut_nonscalar_sh", C.c_float), ("length_enc_max_r", C.c_float),
+        ("max_time", C.c_float), ("time_enc_n", C.c_float), ("lin_mult", C.c_float), ("ang_mult", C.c_float),
+        ("max_neighbors", C.c_int), ("device", C.c_int), ("max_edges", C.c_int64),
+    ]
+
+
+class DedfSchedule(C.Structure):
+    _fields_ = [("n_steps", C.c_int), ("t", C.POINTER(C.c_double)), ("alpha_ang", C.POINTER(C.c_double)),
+                ("alpha_lin", C.POINTER(C.c_double)), ("temperature", C.POINTER(C.c_double))]
+
+
+class DedfStats(C.Structure):
+    _fields_ = [("n_dst", C.c_int64), ("n_edges", C.c_int64 * MAX_SCALES), ("n_edges_total", C.c_int64), ("overflow", C.c_int)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load libdedf.so and declare the prototypes.  Raises (no CPU path) if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950). diffusion_edf_amd has no CPU fallback.")
+    lib = C.CDLL(_LIB_PATH)
+    P = C.POINTER
+    lib.dedf_version.restype = C.c_char_p
+    lib.dedf_param_count.argtypes = [P(DedfConfig)]; lib.dedf_param_count.restype = C.c_int
+    lib.dedf_param_name.argtypes = [P(DedfConfig), C.c_int]; lib.dedf_param_name.restype = C.c_char_p
+    lib.dedf_param_numel.argtypes = [P(DedfConfig), C.c_int]; lib.dedf_param_numel.restype = C.c_size_t
+    lib.dedf_create.argtypes = [P(DedfConfig), P(C.c_float), C.c_size_t, P(C.c_void_p)]; lib.dedf_create.restype = C.c_int
+    lib.dedf_destroy.argtypes = [C.c_void_p]; lib.dedf_destroy.restype = None
+    lib.dedf_last_error.argtypes = [C.c_void_p]; lib.dedf_last_error.restype = C.c_char_p
+    lib.dedf_set_key_clouds.argtypes = [C.c_void_p, C.c_int, P(C.c_int), P(C.c_void_p), P(C.c_void_p), C.c_void_p]
+    lib.dedf_set_key_clouds.restype = C.c_int
+    lib.dedf_set_query.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]; lib.dedf_set_query.restype = C.c_int
+    lib.dedf_score.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]; lib.dedf_score.restype = C.c_int
+    lib.dedf_sample.argtypes = [C.c_void_p, C.c_int, C.c_void_p, P(DedfSchedule), C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.dedf_sample.restype = C.c_int
+    lib.dedf_get_stats.argtypes = [C.c_void_p, P(DedfStats)]; lib.dedf_get_stats.restype = C.c_int
+    lib.dedf_debug_enable.argtypes = [C.c_void_p, C.c_int]; lib.dedf_debug_enable.restype = C.c_int
+    lib.dedf_debug_copy.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, P(C.c_size_t)]; lib.dedf_debug_copy.restype = C.c_int
+    lib.dedf_debug_packed.argtypes = [C.c_void_p, C.c_char_p, P(P(C.c_float)), P(C.c_size_t)]; lib.dedf_debug_packed.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def make_config(cfg: HeadConfig, device: int, max_edges: int = 0) -> DedfConfig:
+    c = DedfConfig()
+    c.lmax = cfg.lmax
+    for i, m in enumerate(cfg.muls):
+        c.mul[i] = m
+    c.num_heads = cfg.num_heads
+    for i in range(3):
+        c.fc_neurons[i] = cfg.fc_neurons[i]
+        c.time_emb_mlp[i] = cfg.time_emb_mlp[i]
+    c.length_emb_dim = cfg.length_emb_dim
+    c.irreps_mlp_mid = cfg.irreps_mlp_mid
+    c.n_scales = cfg.n_scales
+    for i, r in enumerate(cfg.radii):
+        c.radii[i] = -1.0 if r is None else float(r)
+    c.r_mincut_nonscalar_sh = cfg.r_mincut_nonscalar_sh
+    c.length_enc_max_r = cfg.length_enc_max_r
+    c.max_time, c.time_enc_n = cfg.max_time, cfg.time_enc_n
+    c.lin_mult, c.ang_mult = cfg.lin_mult, cfg.ang_mult
+    c.max_neighbors = cfg.max_neighbors
+    c.device = device
+    c.max_edges = max_edges
+    return c
+
+
+def param_names(ccfg: DedfConfig):
+    lib = load()
+    n = lib.dedf_param_count(C.byref(ccfg))
+    if n < 0:
+        raise ValueError("configuration rejected by libdedf")
+    return [(lib.dedf_param_name(C.byref(ccfg), i).decode(), int(lib.dedf_param_numel(C.byref(ccfg), i))) for i in range(n)]
+
+
+def raise_for(lib, handle, rc: int, what: str):
+    if rc == OK:
+        return
+    msg = lib.dedf_last_error(handle).decode() if handle else ""
+    if rc == ERR_INVALID:
+        raise ValueError(f"{what}: {msg}")
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(f"{what}: {msg}")
+    raise RuntimeError(f"{what}: {msg}")
+
+
+def pack_params(ccfg: DedfConfig, state: dict) -> np.ndarray:
+    """Concatenate `state` (reference state_dict names below `score_head.`) in the library's canonical order."""
+    chunks = []
+    for name, numel in param_names(ccfg):
+        if name not in state:
+            raise KeyError(f"missing parameter {name}")
+        a = state[name].detach().cpu().to(dtype=__import__('torch').float32).reshape(-1).numpy()
+        if a.size != numel:
+            raise ValueError(f"{name}: expected {numel} elements, got {a.size}")
+        chunks.append(a)
+    return np.ascontiguousarray(np.concatenate(chunks), dtype=np.float32)

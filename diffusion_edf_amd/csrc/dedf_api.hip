@@ -1,0 +1,539 @@
+// libdedf.so — host side of the C ABI declared in include/dedf.h (see there for the reference interfaces replaced).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++20 -shared -fPIC dedf_api.hip -o libdedf.so   (gfx950 only, no fallbacks)
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+#include "../../include/dedf.h"
+#include "dedf_edge.h"
+#include "dedf_misc.h"
+#include "dedf_node.h"
+#include "dedf_pack.h"
+
+using namespace dedf;
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// the two fused kernels: persistent waves striding over tiles (tile count lives on the device: no host round trip)
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int L> __global__ __launch_bounds__(64, 1) void k_edge(EdgeParams P) {
+    const int* ti = P.tile_info;
+    const int ntiles = ti[P.n_scales];
+    const Wave wv = make_wave(P.W, P.W_bytes);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int scale = 0;
+        while (t >= ti[scale + 1]) ++scale;
+        const int k = t - ti[scale];
+        const int ebase = ti[16 + scale], En = ti[16 + scale + 1] - ebase;
+        edge_tile<L>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k));
+    }
+}
+template <int L> __global__ __launch_bounds__(64, 1) void k_node(NodeParams P) {
+    const Wave wv = make_wave(P.W, P.W_bytes);
+    const int ntiles = (P.n_nodes + 31) / 32;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) node_tile<L>(P, wv, t * 32);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool ensure(size_t n) {
+        if (n <= bytes) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        if (hipMalloc(&p, n) != hipSuccess) return false;
+        bytes = n;
+        return true;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct dedf_handle {
+    dedf_config cfg{};
+    std::string err;
+    bool host_only = false;
+    int L = 2;
+    ParamSpec spec;
+    std::vector<float> params;
+    Image edge_img, node_img;
+    EdgeOffsets eo{};
+    NodeOffsets no{};
+    int n_cu = 256;
+    // device: weights
+    DevBuf d_edge_w, d_node_w, d_nat;     // d_nat: natural-layout weights for the small kernels
+    size_t nat_tw1 = 0, nat_tb1 = 0, nat_tw2 = 0, nat_tb2 = 0, nat_wpre = 0, nat_bpre = 0, nat_lnw = 0, nat_lnb = 0, nat_wsrc = 0, nat_bsrc = 0, nat_tfreq = 0;
+    // device: scene / query
+    DevBuf d_key_x, d_key_f, d_msg, d_qx, d_qf, d_qw;
+    int n_keys = 0, nQ = 0;
+    int scale_start[kMaxScales + 1] = {0};
+    bool have_keys = false, have_query = false;
+    // device: per call
+    DevBuf d_Ts, d_time, d_tb, d_pose, d_qpos, d_cnt, d_off, d_tile, d_esrc, d_edst, d_eout, d_z, d_nout, d_ang, d_lin, d_T64, d_dbgw;
+    int64_t edge_cap = 0;
+    int last_nT = 0;
+    bool debug = false;
+    hipStream_t last_stream = nullptr;
+};
+
+namespace {
+
+int fail(dedf_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+#define HIPCK(h, call)                                                                                          \
+    do {                                                                                                        \
+        hipError_t e__ = (call);                                                                                \
+        if (e__ != hipSuccess) return fail(h, DEDF_ERR_RUNTIME, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+int check_config(const dedf_config* c, std::string& why) {
+    if (!c) { why = "null config"; return DEDF_ERR_INVALID; }
+    if (c->lmax != 1 && c->lmax != 2) { why = "lmax must be 1 or 2 (lmax 3 is a next-row item)"; return DEDF_ERR_UNSUPPORTED; }
+    for (int l = 0; l <= c->lmax; ++l)
+        if (c->mul[l] != mul_of(l)) { why = "irreps must be 64x0e+32x1e(+16x2e)"; return DEDF_ERR_UNSUPPORTED; }
+    if (c->num_heads != kHeads) { why = "num_heads must be 4"; return DEDF_ERR_UNSUPPORTED; }
+    if (c->fc_neurons[0] != kFc0 || c->fc_neurons[1] != kFc1 || c->fc_neurons[2] != kFc2) { why = "fc_neurons must resolve to [128,128,64]"; return DEDF_ERR_UNSUPPORTED; }
+    if (c->length_emb_dim != kLenEmb) { why = "length_emb_dim must be 64"; return DEDF_ERR_UNSUPPORTED; }
+    if (c->time_emb_mlp[0] != kTimeEnc || c->time_emb_mlp[1] != kTimeHid || c->time_emb_mlp[2] != kTimeEmb) { why = "time_emb_mlp must be [256,128,64]"; return DEDF_ERR_UNSUPPORTED; }
+    if (c->irreps_mlp_mid != kMlpMid) { why = "irreps_mlp_mid must be 3"; return DEDF_ERR_UNSUPPORTED; }
+    if (c->n_scales < 1 || c->n_scales > kMaxScales) { why = "n_scales out of range"; return DEDF_ERR_INVALID; }
+    bool inf = false;
+    for (int n = 0; n < c->n_scales; ++n) {
+        if (c->radii[n] <= 0) inf = true;
+        else if (inf) { why = "Finite cluster radius cannot come after infinite cluster radius"; return DEDF_ERR_INVALID; }
+    }
+    if (c->max_neighbors <= 0) { why = "max_neighbors must be positive"; return DEDF_ERR_INVALID; }
+    return DEDF_OK;
+}
+
+template <int L> void build_all(dedf_handle* h) {
+    h->spec = build_spec<L>(h->cfg);
+}
+template <int L> void pack_all(dedf_handle* h) {
+    pack_edge<L>(h->cfg, h->spec, h->params.data(), h->edge_img, h->eo);
+    pack_node<L>(h->cfg, h->spec, h->params.data(), h->node_img, h->no);
+}
+
+ParamSpec spec_for(const dedf_config* c) {
+    return c->lmax == 1 ? build_spec<1>(*c) : build_spec<2>(*c);
+}
+
+int upload_weights(dedf_handle* h) {
+    const dedf_config& c = h->cfg;
+    const ParamSpec& S = h->spec;
+    const float* B = h->params.data();
+    if (!h->d_edge_w.ensure(h->edge_img.data.size() * 4) || !h->d_node_w.ensure(h->node_img.data.size() * 4))
+        return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(weights) failed");
+    HIPCK(h, hipMemcpy(h->d_edge_w.p, h->edge_img.data.data(), h->edge_img.data.size() * 4, hipMemcpyHostToDevice));
+    HIPCK(h, hipMemcpy(h->d_node_w.p, h->node_img.data.data(), h->node_img.data.size() * 4, hipMemcpyHostToDevice));
+    // natural-layout weights for the small kernels
+    std::vector<float> nat;
+    auto put = [&](const float* p, size_t n) { size_t o = nat.size(); nat.insert(nat.end(), p, p + n); return o; };
+    const int ns = c.n_scales;
+    h->nat_tw1 = nat.size();
+    for (int n = 0; n < ns; ++n) put(S.get(B, "time_mlps_multiscale." + std::to_string(n) + ".0.weight"), 128 * 256);
+    h->nat_tb1 = nat.size();
+    for (int n = 0; n < ns; ++n) put(S.get(B, "time_mlps_multiscale." + std::to_string(n) + ".0.bias"), 128);
+    h->nat_tw2 = nat.size();
+    for (int n = 0; n < ns; ++n) put(S.get(B, "time_mlps_multiscale." + std::to_string(n) + ".2.weight"), 64 * 128);
+    h->nat_tb2 = nat.size();
+    for (int n = 0; n < ns; ++n) put(S.get(B, "time_mlps_multiscale." + std::to_string(n) + ".2.bias"), 64);
+    h->nat_wpre = nat.size();
+    for (int n = 0; n < ns; ++n) put(S.get(B, "key_tensor_field.edge_scalars_pre_linears." + std::to_string(n) + ".0.weight"), 128 * 128);
+    h->nat_bpre = nat.size();
+    for (int n = 0; n < ns; ++n) put(S.get(B, "key_tensor_field.edge_scalars_pre_linears." + std::to_string(n) + ".0.bias"), 128);
+    const std::string blk = "key_tensor_field.gnn_block_init";
+    const size_t nirr = h->L == 1 ? sum_mul<1>() : sum_mul<2>();
+    size_t sq = 0;
+    for (int l = 0; l <= h->L; ++l) sq += (size_t)mul_of(l) * mul_of(l);
+    h->nat_lnw = put(S.get(B, blk + ".prenorm_src.affine_weight"), nirr);
+    h->nat_lnb = put(S.get(B, blk + ".prenorm_src.affine_bias"), mul_of(0));
+    h->nat_wsrc = put(S.get(B, blk + ".linear_src.tp.weight"), sq);
+    h->nat_bsrc = put(S.get(B, blk + ".linear_src.bias.0"), mul_of(0));
+    {   // time-encoding frequencies, evaluated like torch: exp(float(k) * float(-ln(n)/127)) in float32
+        std::vector<float> fr(128);
+        const double step = std::log((double)c.time_enc_n) / (kTimeEnc / 2 - 1);
+        for (int k = 0; k < 128; ++k) fr[k] = std::exp((float)k * (float)(-step));
+        h->nat_tfreq = put(fr.data(), 128);
+    }
+    if (!h->d_nat.ensure(nat.size() * 4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(nat) failed");
+    HIPCK(h, hipMemcpy(h->d_nat.p, nat.data(), nat.size() * 4, hipMemcpyHostToDevice));
+    return DEDF_OK;
+}
+
+int ensure_workspace(dedf_handle* h, int nT) {
+    const int L = h->L;
+    const size_t D = L == 1 ? feat_dim<1>() : feat_dim<2>();
+    const size_t REC = L == 1 ? edge_rec<1>() : edge_rec<2>();
+    const size_t WN = L == 1 ? dtp_wn<1>() : dtp_wn<2>();
+    const size_t Nd = (size_t)nT * h->nQ;
+    const int ns = h->cfg.n_scales;
+    // worst case: every key of every scale is a neighbour (capped per scale by max_neighbors for finite scales)
+    int64_t per_dst = 0;
+    for (int n = 0; n < ns; ++n) {
+        const int64_t k = h->scale_start[n + 1] - h->scale_start[n];
+        per_dst += h->cfg.radii[n] > 0 ? std::min<int64_t>(k, h->cfg.max_neighbors) : k;
+    }
+    int64_t cap = (int64_t)Nd * per_dst;
+    if (h->cfg.max_edges > 0) cap = std::min(cap, h->cfg.max_edges);
+    else cap = std::min(cap, std::max<int64_t>((int64_t)Nd * 96, 1 << 20));    // auto: 96 edges per destination node
+    cap = std::min<int64_t>(cap, 0x7fffffff - 64);
+    cap = std::max<int64_t>(cap, 64);
+    h->edge_cap = cap;
+    bool ok = h->d_Ts.ensure((size_t)nT * 7 * 4) && h->d_time.ensure((size_t)nT * 4) && h->d_tb.ensure((size_t)nT * ns * 128 * 4) &&
+              h->d_pose.ensure((size_t)nT * kPoseRec * 4) && h->d_qpos.ensure(Nd * 3 * 4) && h->d_cnt.ensure(Nd * ns * 4) &&
+              h->d_off.ensure(Nd * ns * 4) && h->d_tile.ensure(64 * 4) && h->d_esrc.ensure((size_t)cap * 4) &&
+              h->d_edst.ensure((size_t)cap * 4) && h->d_eout.ensure((size_t)cap * REC * 4) && h->d_z.ensure(Nd * D * 4) &&
+              h->d_nout.ensure(Nd * 8 * 4) && h->d_ang.ensure((size_t)nT * 3 * 4) && h->d_lin.ensure((size_t)nT * 3 * 4) &&
+              h->d_T64.ensure((size_t)nT * 7 * 8);
+    if (ok && h->debug) ok = h->d_dbgw.ensure((size_t)cap * WN * 4);
+    if (!ok) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(workspace) failed");
+    if (h->d_eout.bytes >= (1ull << 32) || h->d_z.bytes >= (1ull << 32))
+        ;   // buffer descriptors address 4 GiB: z is read through one (see launch), eout is written with flat stores
+    return DEDF_OK;
+}
+
+// one evaluation of the score head on poses already in h->d_Ts (f32) with times in h->d_time
+template <int L>
+int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, hipStream_t st) {
+    const dedf_config& c = h->cfg;
+    const int ns = c.n_scales, nQ = h->nQ;
+    const int Nd = nT * nQ;
+    constexpr int D = feat_dim<L>();
+    const float* nat = h->d_nat.as<float>();
+    if ((size_t)Nd * D * 4 >= (1ull << 32)) return fail(h, DEDF_ERR_INVALID, "nT*nQ too large for one call (z buffer > 4 GiB); split the pose batch");
+    // 1. poses: Wigner-D + transformed query positions
+    hipLaunchKernelGGL(k_pose_prep<L>, dim3(nT), dim3(64), 0, st, h->d_Ts.as<float>(), h->d_qx.as<float>(), nQ, h->d_pose.as<float>(), h->d_qpos.as<float>());
+    // 2. time embedding -> pre-linear bias rows
+    {
+        TimeParams tp{};
+        tp.time = h->d_time.as<float>(); tp.time_stride = time_stride;
+        tp.w1 = nat + h->nat_tw1; tp.b1 = nat + h->nat_tb1; tp.w2 = nat + h->nat_tw2; tp.b2 = nat + h->nat_tb2;
+        tp.wpre = nat + h->nat_wpre; tp.bpre = nat + h->nat_bpre; tp.tfreq = nat + h->nat_tfreq;
+        tp.max_time = c.max_time; tp.time_enc_n = c.time_enc_n; tp.tb = h->d_tb.as<float>();
+        hipLaunchKernelGGL(k_time_bias, dim3(time_stride ? nT : 1, ns), dim3(128), 0, st, tp);
+    }
+    // 3. neighbour search
+    NbrParams np{};
+    np.key_x = h->d_key_x.as<float>(); np.n_keys = h->n_keys; np.n_scales = ns; np.max_neighbors = c.max_neighbors;
+    for (int n = 0; n <= ns; ++n) np.scale_start[n] = h->scale_start[n];
+    for (int n = 0; n < ns; ++n) np.r2[n] = c.radii[n] > 0 ? c.radii[n] * c.radii[n] : -1.0f;
+    np.qpos = h->d_qpos.as<float>(); np.n_dst = Nd; np.cnt = h->d_cnt.as<int>(); np.off = h->d_off.as<int>();
+    np.tile_info = h->d_tile.as<int>(); np.edge_src = h->d_esrc.as<int>(); np.edge_dst = h->d_edst.as<int>(); np.cap = h->edge_cap;
+    hipLaunchKernelGGL(k_neighbors<false>, dim3((Nd + 255) / 256), dim3(256), 0, st, np);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, h->d_cnt.as<int>(), h->d_off.as<int>(), Nd, ns, h->d_tile.as<int>(), h->edge_cap);
+    hipLaunchKernelGGL(k_neighbors<true>, dim3((Nd + 255) / 256), dim3(256), 0, st, np);
+    // 4. fused edge pipeline
+    {
+        EdgeParams P{};
+        P.key_x = h->d_key_x.as<float>(); P.qpos = h->d_qpos.as<float>(); P.edge_src = h->d_esrc.as<int>(); P.edge_dst = h->d_edst.as<int>();
+        P.tile_info = h->d_tile.as<int>(); P.msg = h->d_msg.as<float>(); P.msg_bytes = (uint32_t)((size_t)h->n_keys * D * 4);
+        P.tb = h->d_tb.as<float>(); P.tb_bytes = (uint32_t)((size_t)(time_stride ? nT : 1) * ns * 128 * 4);
+        P.tb_pose_stride = time_stride ? ns * 128 : 0;
+        P.nQ = nQ; P.n_scales = ns;
+        for (int n = 0; n < ns; ++n) {
+            P.radius[n] = c.radii[n] > 0 ? c.radii[n] : -1.0f;
+            P.cut_begin[n] = (float)(0.8 * (double)c.radii[n]);
+            P.cut_div[n] = (float)(1.0 * (double)c.radii[n] - 0.8 * (double)c.radii[n]);
+        }
+        P.ns_lo = (float)(0.2 * (double)c.r_mincut_nonscalar_sh);
+        P.ns_div = (float)(1.0 * (double)c.r_mincut_nonscalar_sh - 0.2 * (double)c.r_mincut_nonscalar_sh);
+        P.len_enc_max_r = c.length_enc_max_r;
+        P.W = h->d_edge_w.as<float>(); P.W_bytes = (uint32_t)h->d_edge_w.bytes;
+        const EdgeOffsets& o = h->eo;
+        P.o_enc = o.o_enc; P.o_A_pre = o.o_A_pre; P.o_A_r1 = o.o_A_r1; P.o_b_r1 = o.o_b_r1; P.o_g_r1 = o.o_g_r1; P.o_be_r1 = o.o_be_r1;
+        P.o_A_r2 = o.o_A_r2; P.o_b_r2 = o.o_b_r2; P.o_g_r2 = o.o_g_r2; P.o_be_r2 = o.o_be_r2; P.o_A_r3 = o.o_A_r3; P.o_off_r3 = o.o_off_r3;
+        for (int l = 0; l < 4; ++l) { P.o_A_lin[l] = o.o_A_lin[l]; P.o_A_val[l] = o.o_A_val[l]; }
+        P.o_b_r0 = o.o_b_r0; P.o_b_val0 = o.o_b_val0; P.o_alpha_dot = o.o_alpha_dot;
+        P.out = h->d_eout.as<float>();
+        P.dbg_w = h->debug ? h->d_dbgw.as<float>() : nullptr;
+        hipLaunchKernelGGL(k_edge<L>, dim3(h->n_cu * 4), dim3(64), 0, st, P);
+    }
+    // 5. joint softmax + aggregation
+    hipLaunchKernelGGL(k_aggregate<L>, dim3((Nd + 3) / 4), dim3(256), 0, st, h->d_eout.as<float>(), h->d_cnt.as<int>(), h->d_off.as<int>(),
+                       h->d_tile.as<int>(), Nd, ns, h->d_z.as<float>());
+    // 6. node epilogue + score tensor products
+    {
+        NodeParams P{};
+        P.z = h->d_z.as<float>(); P.z_bytes = (uint32_t)((size_t)Nd * D * 4);
+        P.qf = h->d_qf.as<float>(); P.qf_bytes = (uint32_t)((size_t)nQ * D * 4);
+        P.pose = h->d_pose.as<float>(); P.pose_bytes = (uint32_t)((size_t)nT * kPoseRec * 4);
+        P.qx = h->d_qx.as<float>(); P.qw = h->d_qw.as<float>(); P.nQ = nQ; P.n_nodes = Nd; P.lin_mult = c.lin_mult;
+        P.W = h->d_node_w.as<float>(); P.W_bytes = (uint32_t)h->d_node_w.bytes;
+        const NodeOffsets& o = h->no;
+        for (int l = 0; l < 4; ++l) { P.o_A_proj[l] = o.o_A_proj[l]; P.o_ln_w[l] = o.o_ln_w[l]; P.o_A_f1[l] = o.o_A_f1[l]; P.o_A_f2[l] = o.o_A_f2[l]; }
+        P.o_b_proj0 = o.o_b_proj0; P.o_ln_b0 = o.o_ln_b0; P.o_b_f1 = o.o_b_f1; P.o_b_f2 = o.o_b_f2;
+        for (int t = 0; t < 2; ++t) {
+            for (int p = 0; p < 16; ++p) P.o_A_s[t][p] = o.o_A_s[t][p];
+            P.o_A_sl[t][0] = o.o_A_sl[t][0]; P.o_A_sl[t][1] = o.o_A_sl[t][1]; P.o_b_sl[t] = o.o_b_sl[t];
+        }
+        P.node_out = h->d_nout.as<float>();
+        const int ntiles = (Nd + 31) / 32;
+        hipLaunchKernelGGL(k_node<L>, dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
+    }
+    // 7. per-pose reduction
+    hipLaunchKernelGGL(k_pose_reduce, dim3((nT + 127) / 128), dim3(128), 0, st, h->d_nout.as<float>(), nT, nQ, ang, lin);
+    if (hipGetLastError() != hipSuccess) return fail(h, DEDF_ERR_RUNTIME, "kernel launch failed");
+    h->last_nT = nT;
+    h->last_stream = st;
+    return DEDF_OK;
+}
+
+int score_dispatch(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, hipStream_t st) {
+    return h->L == 1 ? score_impl<1>(h, nT, time_stride, ang, lin, st) : score_impl<2>(h, nT, time_stride, ang, lin, st);
+}
+
+}  // namespace
+
+// ===========================================================================================================================
+extern "C" {
+
+const char* dedf_version(void) { return "dedf 0.1.0 (gfx950)"; }
+
+int dedf_param_count(const dedf_config* cfg) {
+    std::string why;
+    if (check_config(cfg, why) != DEDF_OK) return -1;
+    return (int)spec_for(cfg).entries.size();
+}
+const char* dedf_param_name(const dedf_config* cfg, int i) {
+    static thread_local std::string s;
+    std::string why;
+    if (check_config(cfg, why) != DEDF_OK) return nullptr;
+    const ParamSpec S = spec_for(cfg);
+    if (i < 0 || i >= (int)S.entries.size()) return nullptr;
+    s = S.entries[i].name;
+    return s.c_str();
+}
+size_t dedf_param_numel(const dedf_config* cfg, int i) {
+    std::string why;
+    if (check_config(cfg, why) != DEDF_OK) return 0;
+    const ParamSpec S = spec_for(cfg);
+    if (i < 0 || i >= (int)S.entries.size()) return 0;
+    return S.entries[i].numel;
+}
+
+int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, dedf_handle** out) {
+    if (!out) return DEDF_ERR_INVALID;
+    *out = nullptr;
+    auto h = std::make_unique<dedf_handle>();
+    std::string why;
+    int rc = check_config(cfg, why);
+    if (rc != DEDF_OK) { fprintf(stderr, "dedf_create: %s\n", why.c_str()); return rc; }
+    h->cfg = *cfg;
+    h->L = cfg->lmax;
+    h->host_only = cfg->device < 0;
+    if (h->L == 1) build_all<1>(h.get()); else build_all<2>(h.get());
+    if (!params || n_params != h->spec.total) {
+        fprintf(stderr, "dedf_create: expected %zu parameters, got %zu\n", h->spec.total, n_params);
+        return DEDF_ERR_INVALID;
+    }
+    h->params.assign(params, params + n_params);
+    try {
+        if (h->L == 1) pack_all<1>(h.get()); else pack_all<2>(h.get());
+    } catch (const std::exception& e) {
+        fprintf(stderr, "dedf_create: %s\n", e.what());
+        return DEDF_ERR_INVALID;
+    }
+    if (!h->host_only) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device) {
+            fprintf(stderr, "dedf_create: HIP device %d not available (this library has no CPU path)\n", cfg->device);
+            return DEDF_ERR_RUNTIME;
+        }
+        if (hipSetDevice(cfg->device) != hipSuccess) return DEDF_ERR_RUNTIME;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) {
+            h->n_cu = prop.multiProcessorCount;
+            if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+                fprintf(stderr, "dedf_create: device is %s; this library is built for gfx950 only\n", prop.gcnArchName);
+                return DEDF_ERR_UNSUPPORTED;
+            }
+        }
+        rc = upload_weights(h.get());
+        if (rc != DEDF_OK) { fprintf(stderr, "dedf_create: %s\n", h->err.c_str()); return rc; }
+    }
+    *out = h.release();
+    return DEDF_OK;
+}
+
+void dedf_destroy(dedf_handle* h) { delete h; }
+
+const char* dedf_last_error(const dedf_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int dedf_set_key_clouds(dedf_handle* h, int n_scales, const int* n_pts, const float* const* x, const float* const* f, void* stream) {
+    if (!h) return DEDF_ERR_INVALID;
+    if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
+    if (n_scales != h->cfg.n_scales) return fail(h, DEDF_ERR_INVALID, "len(key_pcd_multiscale) != n_scales");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCK(h, hipSetDevice(h->cfg.device));
+    const size_t D = h->L == 1 ? feat_dim<1>() : feat_dim<2>();
+    int total = 0;
+    for (int n = 0; n < n_scales; ++n) {
+        if (n_pts[n] < 0 || (n_pts[n] > 0 && (!x[n] || !f[n]))) return fail(h, DEDF_ERR_INVALID, "bad key cloud");
+        h->scale_start[n] = total;
+        total += n_pts[n];
+    }
+    h->scale_start[n_scales] = total;
+    if (total <= 0) return fail(h, DEDF_ERR_INVALID, "empty key clouds");
+    if ((size_t)total * D * 4 >= (1ull << 32)) return fail(h, DEDF_ERR_INVALID, "key clouds too large");
+    h->n_keys = total;
+    if (!h->d_key_x.ensure((size_t)total * 3 * 4) || !h->d_key_f.ensure((size_t)total * D * 4) || !h->d_msg.ensure((size_t)total * D * 4))
+        return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(key clouds) failed");
+    for (int n = 0; n < n_scales; ++n) {
+        if (n_pts[n] == 0) continue;
+        HIPCK(h, hipMemcpyAsync(h->d_key_x.as<float>() + (size_t)h->scale_start[n] * 3, x[n], (size_t)n_pts[n] * 3 * 4, hipMemcpyDeviceToDevice, st));
+        HIPCK(h, hipMemcpyAsync(h->d_key_f.as<float>() + (size_t)h->scale_start[n] * D, f[n], (size_t)n_pts[n] * D * 4, hipMemcpyDeviceToDevice, st));
+    }
+    const float* nat = h->d_nat.as<float>();
+    if (h->L == 1)
+        hipLaunchKernelGGL(k_src_message<1>, dim3(total), dim3(64), 0, st, h->d_key_f.as<float>(), total, nat + h->nat_lnw, nat + h->nat_lnb,
+                           nat + h->nat_wsrc, nat + h->nat_bsrc, h->d_msg.as<float>());
+    else
+        hipLaunchKernelGGL(k_src_message<2>, dim3(total), dim3(64), 0, st, h->d_key_f.as<float>(), total, nat + h->nat_lnw, nat + h->nat_lnb,
+                           nat + h->nat_wsrc, nat + h->nat_bsrc, h->d_msg.as<float>());
+    HIPCK(h, hipStreamSynchronize(st));
+    h->have_keys = true;
+    return DEDF_OK;
+}
+
+int dedf_set_query(dedf_handle* h, int nQ, const float* x, const float* f, const float* w, void* stream) {
+    if (!h) return DEDF_ERR_INVALID;
+    if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
+    if (nQ <= 0 || !x || !f) return fail(h, DEDF_ERR_INVALID, "bad query cloud");
+    if (!w) return fail(h, DEDF_ERR_INVALID, "query_pcd.w is required (score_head.py:156-157)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCK(h, hipSetDevice(h->cfg.device));
+    const size_t D = h->L == 1 ? feat_dim<1>() : feat_dim<2>();
+    if (!h->d_qx.ensure((size_t)nQ * 3 * 4) || !h->d_qf.ensure((size_t)nQ * D * 4) || !h->d_qw.ensure((size_t)nQ * 4))
+        return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(query) failed");
+    HIPCK(h, hipMemcpyAsync(h->d_qx.p, x, (size_t)nQ * 3 * 4, hipMemcpyDeviceToDevice, st));
+    HIPCK(h, hipMemcpyAsync(h->d_qf.p, f, (size_t)nQ * D * 4, hipMemcpyDeviceToDevice, st));
+    HIPCK(h, hipMemcpyAsync(h->d_qw.p, w, (size_t)nQ * 4, hipMemcpyDeviceToDevice, st));
+    HIPCK(h, hipStreamSynchronize(st));
+    h->nQ = nQ;
+    h->have_query = true;
+    return DEDF_OK;
+}
+
+int dedf_score(dedf_handle* h, int nT, const float* Ts, const float* time, float* ang, float* lin, void* stream) {
+    if (!h) return DEDF_ERR_INVALID;
+    if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
+    if (!h->have_keys || !h->have_query) return fail(h, DEDF_ERR_INVALID, "set_key_clouds / set_query must be called first");
+    if (nT <= 0 || !Ts || !time || !ang || !lin) return fail(h, DEDF_ERR_INVALID, "bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCK(h, hipSetDevice(h->cfg.device));
+    int rc = ensure_workspace(h, nT);
+    if (rc != DEDF_OK) return rc;
+    HIPCK(h, hipMemcpyAsync(h->d_Ts.p, Ts, (size_t)nT * 7 * 4, hipMemcpyDeviceToDevice, st));
+    HIPCK(h, hipMemcpyAsync(h->d_time.p, time, (size_t)nT * 4, hipMemcpyDeviceToDevice, st));
+    return score_dispatch(h, nT, 1, ang, lin, st);
+}
+
+int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedule* sched, uint64_t seed, int64_t first_pose_index,
+                const double* noise, double* Ts_out, void* stream) {
+    if (!h) return DEDF_ERR_INVALID;
+    if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
+    if (!h->have_keys || !h->have_query) return fail(h, DEDF_ERR_INVALID, "set_key_clouds / set_query must be called first");
+    if (nT <= 0 || !T_seed || !sched || sched->n_steps < 0 || !Ts_out) return fail(h, DEDF_ERR_INVALID, "bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCK(h, hipSetDevice(h->cfg.device));
+    int rc = ensure_workspace(h, nT);
+    if (rc != DEDF_OK) return rc;
+    const size_t row = (size_t)nT * 7;
+    HIPCK(h, hipMemcpyAsync(h->d_T64.p, T_seed, row * 8, hipMemcpyDeviceToDevice, st));
+    HIPCK(h, hipMemcpyAsync(Ts_out, T_seed, row * 8, hipMemcpyDeviceToDevice, st));
+    for (int s = 0; s < sched->n_steps; ++s) {
+        hipLaunchKernelGGL(k_cast_pose, dim3((unsigned)((row + 255) / 256)), dim3(256), 0, st, h->d_T64.as<double>(), h->d_Ts.as<float>(), (int)row);
+        const float tf = (float)sched->t[s];
+        HIPCK(h, hipMemcpyAsync(h->d_time.p, &tf, 4, hipMemcpyHostToDevice, st));   // pageable 4-byte copy: staged by the runtime
+        rc = score_dispatch(h, nT, 0, h->d_ang.as<float>(), h->d_lin.as<float>(), st);
+        if (rc != DEDF_OK) return rc;
+        LangevinParams lp{};
+        lp.T = h->d_T64.as<double>(); lp.ang = h->d_ang.as<float>(); lp.lin = h->d_lin.as<float>();
+        lp.t = sched->t[s]; lp.alpha_ang = sched->alpha_ang[s]; lp.alpha_lin = sched->alpha_lin[s]; lp.temperature = sched->temperature[s];
+        lp.ang_mult = h->cfg.ang_mult; lp.lin_mult = h->cfg.lin_mult;
+        lp.noise = noise ? noise + (size_t)s * 2 * nT * 3 : nullptr;
+        lp.seed = seed; lp.first_pose = first_pose_index; lp.step = s;
+        lp.traj_out = Ts_out + (size_t)(s + 1) * row; lp.nT = nT;
+        hipLaunchKernelGGL(k_langevin, dim3((nT + 127) / 128), dim3(128), 0, st, lp);
+    }
+    HIPCK(h, hipMemcpyAsync(Ts_out + (size_t)(sched->n_steps + 1) * row, h->d_T64.p, row * 8, hipMemcpyDeviceToDevice, st));
+    HIPCK(h, hipStreamSynchronize(st));
+    int ovf = 0;
+    if (sched->n_steps > 0) HIPCK(h, hipMemcpy(&ovf, h->d_tile.as<int>() + 40, 4, hipMemcpyDeviceToHost));
+    if (ovf) return fail(h, DEDF_ERR_RUNTIME, "edge workspace overflow: raise dedf_config.max_edges");
+    return DEDF_OK;
+}
+
+int dedf_get_stats(dedf_handle* h, dedf_stats* out) {
+    if (!h || !out) return DEDF_ERR_INVALID;
+    if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
+    memset(out, 0, sizeof(*out));
+    if (h->last_nT == 0) return DEDF_OK;
+    HIPCK(h, hipStreamSynchronize(h->last_stream));
+    int ti[64];
+    HIPCK(h, hipMemcpy(ti, h->d_tile.p, sizeof(ti), hipMemcpyDeviceToHost));
+    out->n_dst = (int64_t)h->last_nT * h->nQ;
+    for (int n = 0; n < h->cfg.n_scales; ++n) { out->n_edges[n] = ti[16 + n + 1] - ti[16 + n]; out->n_edges_total += out->n_edges[n]; }
+    out->overflow = ti[40];
+    return DEDF_OK;
+}
+
+int dedf_debug_enable(dedf_handle* h, int on) {
+    if (!h) return DEDF_ERR_INVALID;
+    h->debug = on != 0;
+    return DEDF_OK;
+}
+
+int dedf_debug_copy(dedf_handle* h, const char* name, void* host_dst, size_t max_bytes, size_t* actual_bytes) {
+    if (!h || !name) return DEDF_ERR_INVALID;
+    if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
+    const std::string nm(name);
+    const size_t D = h->L == 1 ? feat_dim<1>() : feat_dim<2>();
+    const size_t REC = h->L == 1 ? edge_rec<1>() : edge_rec<2>();
+    const size_t WN = h->L == 1 ? dtp_wn<1>() : dtp_wn<2>();
+    const size_t Nd = (size_t)h->last_nT * h->nQ;
+    HIPCK(h, hipDeviceSynchronize());
+    int ti[64] = {0};
+    if (h->d_tile.p) HIPCK(h, hipMemcpy(ti, h->d_tile.p, sizeof(ti), hipMemcpyDeviceToHost));
+    const size_t E = (size_t)ti[16 + h->cfg.n_scales];
+    const void* src = nullptr;
+    size_t n = 0;
+    if (nm == "msg") { src = h->d_msg.p; n = (size_t)h->n_keys * D * 4; }
+    else if (nm == "qpos") { src = h->d_qpos.p; n = Nd * 3 * 4; }
+    else if (nm == "pose") { src = h->d_pose.p; n = (size_t)h->last_nT * kPoseRec * 4; }
+    else if (nm == "tb") { src = h->d_tb.p; n = (size_t)h->last_nT * h->cfg.n_scales * 128 * 4; }
+    else if (nm == "edge_src") { src = h->d_esrc.p; n = E * 4; }
+    else if (nm == "edge_dst") { src = h->d_edst.p; n = E * 4; }
+    else if (nm == "edge_out") { src = h->d_eout.p; n = E * REC * 4; }
+    else if (nm == "z") { src = h->d_z.p; n = Nd * D * 4; }
+    else if (nm == "node_out") { src = h->d_nout.p; n = Nd * 8 * 4; }
+    else if (nm == "tile_info") { src = h->d_tile.p; n = 64 * 4; }
+    else if (nm == "dbg_w") { src = h->d_dbgw.p; n = h->d_dbgw.p ? E * WN * 4 : 0; }
+    else return fail(h, DEDF_ERR_INVALID, "unknown debug buffer " + nm);
+    if (actual_bytes) *actual_bytes = n;
+    if (!host_dst) return DEDF_OK;
+    if (n > max_bytes) return fail(h, DEDF_ERR_INVALID, "destination too small");
+    if (n && src) HIPCK(h, hipMemcpy(host_dst, src, n, hipMemcpyDeviceToHost));
+    return DEDF_OK;
+}
+
+int dedf_debug_packed(dedf_handle* h, const char* which, const float** ptr, size_t* n_floats) {
+    if (!h || !which || !ptr || !n_floats) return DEDF_ERR_INVALID;
+    const std::string w(which);
+    const Image& im = w == "edge" ? h->edge_img : h->node_img;
+    *ptr = im.data.data();
+    *n_floats = im.data.size();
+    return DEDF_OK;
+}
+
+}  // extern "C"

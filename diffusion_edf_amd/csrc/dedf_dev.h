@@ -1,0 +1,178 @@
+// Device-side building blocks (gfx950).  Kernel bodies are written as __host__ __device__ templates so that the
+// same source can be driven lane-by-lane by the CPU wave emulator in tests/emu (test infrastructure); the product
+// only ever launches the __device__ side.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <utility>
+#include "dedf_layout.h"
+
+#define DEDF_DEV __host__ __device__ __forceinline__
+#include "dedf_tables.h"
+
+namespace dedf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+// host side of the wave emulator (defined in tests/emu/wave_emu.h; never linked into the product)
+namespace emu {
+int lane();
+f32x16 mfma32(float a, float b, f32x16 c);
+float xor32(float v);
+}  // namespace emu
+#endif
+
+DEDF_DEV int lane_id() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)(threadIdx.x & 63);
+#else
+    return emu::lane();
+#endif
+}
+
+// D(32x32) += A(32x2) * B(2x32), exact f32 (v_mfma_f32_32x32x2_f32, 64 cycles per SIMD)
+DEDF_DEV f32x16 mfma32(float a, float b, f32x16 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+#else
+    return emu::mfma32(a, b, c);
+#endif
+}
+
+// exchange with the lane holding the other half of this item's channel rows
+DEDF_DEV float xor32(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __shfl_xor(v, 32, 64);
+#else
+    return emu::xor32(v);
+#endif
+}
+
+template <class F, int... I>
+DEDF_DEV void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f.template operator()<I>(), ...);
+}
+template <int N, class F>
+DEDF_DEV void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// scheduling-region fence: keeps hipcc from hoisting hundreds of weight loads to the top of a fully unrolled phase
+DEDF_DEV void sched_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+// ---- buffer-descriptor loads: base in 4 SGPRs, ONE per-lane byte offset VGPR, everything else scalar ----------------
+// (a fully unrolled kernel otherwise materialises one 64-bit VGPR address per weight load and spills hundreds of them)
+struct Buf {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __amdgpu_buffer_rsrc_t r;
+#else
+    const char* p;
+#endif
+};
+DEDF_DEV Buf make_buf(const void* p, uint32_t bytes) {
+    Buf b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+#else
+    (void)bytes;
+    b.p = static_cast<const char*>(p);
+#endif
+    return b;
+}
+DEDF_DEV f32x4 bld4(const Buf& b, int voff_bytes, int soff_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, voff_bytes, soff_bytes, 0));
+#else
+    return *reinterpret_cast<const f32x4*>(b.p + voff_bytes + soff_bytes);
+#endif
+}
+
+struct Wave {            // per-lane constants of the transposed-GEMM layout
+    int lane, col, hi;
+    int lane16;          // byte offset of this lane inside a packed-A group (64 lanes x 16 B)
+    int hi64;            // byte offset of this lane's half inside a row-packed tile (2 x 16 floats)
+    Buf w;               // all packed weights / row vectors of the launch
+};
+DEDF_DEV Wave make_wave(const void* wbuf, uint32_t wbytes) {
+    Wave wv;
+    wv.lane = lane_id(); wv.col = wv.lane & 31; wv.hi = wv.lane >> 5;
+    wv.lane16 = wv.lane * 16; wv.hi64 = wv.hi * 64;
+    wv.w = make_buf(wbuf, wbytes);
+    return wv;
+}
+// A operands of 4 consecutive K-steps (group g) of out tile To; matrix at float offset `off`, nG groups per tile
+DEDF_DEV f32x4 lda(const Wave& wv, int off, int nG, int To, int g) {
+    return bld4(wv.w, wv.lane16, (off + (To * nG + g) * 256) * 4);
+}
+// acc tile <- 16 per-row values stored [tile][hi][r] at float offset `off`
+DEDF_DEV f32x16 ldrows(const Buf& b, int voff_hi64, int off, int tile) {
+    f32x16 v;
+    static_for<4>([&]<int G>() {
+        const f32x4 t = bld4(b, voff_hi64, (off + tile * 32 + 4 * G) * 4);
+        v[4 * G + 0] = t[0]; v[4 * G + 1] = t[1]; v[4 * G + 2] = t[2]; v[4 * G + 3] = t[3];
+    });
+    return v;
+}
+DEDF_DEV f32x16 ldrows(const Wave& wv, int off, int tile) { return ldrows(wv.w, wv.hi64, off, tile); }
+
+// One packed-A group = 4 K-steps of one 32-row output tile: acc += A[:, 4 steps] * B[4 steps, :]
+DEDF_DEV void mfma_group(f32x16& acc, const f32x4 a, float b0, float b1, float b2, float b3) {
+    acc = mfma32(a[0], b0, acc);
+    acc = mfma32(a[1], b1, acc);
+    acc = mfma32(a[2], b2, acc);
+    acc = mfma32(a[3], b3, acc);
+}
+
+// ---- scalar math ---------------------------------------------------------------------------------------------------
+DEDF_DEV float rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+DEDF_DEV float sigmoidf(float x) { return rcp(1.0f + expf(-x)); }
+DEDF_DEV float siluf(float x) { return x * sigmoidf(x); }
+// normalize2mom-wrapped activations (reference equiformer/fast_activation.py:69)
+DEDF_DEV float silu_n(float x) { return siluf(x) * kNormSilu; }
+DEDF_DEV float sigmoid_n(float x) { return sigmoidf(x) * kNormSigmoid; }
+// SmoothLeakyReLU(0.2) (reference fast_activation.py:14-23) x normalize2mom
+DEDF_DEV float slrelu_n(float x) {
+    const float x1 = 0.6f * x;
+    const float x2 = 0.4f * x * (2.0f * sigmoidf(x) - 1.0f);
+    return (x1 + x2) * kNormSlrelu;
+}
+// soft_step (reference radial_func.py:15-17, n = 3)
+DEDF_DEV float soft_step(float x) {
+    if (!(x > 0.0f)) return 0.0f;
+    if (x >= 1.0f) return 1.0f;
+    const float x3 = x * x * x;
+    return 4.0f * x3 - 3.0f * x3 * x;
+}
+// sin(x) (want_cos = 0) or cos(x) (want_cos = 1): 3-term Cody-Waite reduction by pi/2 with FMA + cephes
+// minimax polynomials on [-pi/4, pi/4]; ~1 ulp for |x| < 1e5, branch-free (arguments here are <= ~1e3 rad).
+DEDF_DEV float sin_or_cos(float x, int want_cos) {
+    const float fn = rintf(x * 0.636619772367581343f);
+    const int n = (int)fn + want_cos;
+    float r = fmaf(fn, -1.5707963705062866f, x);
+    r = fmaf(fn, 4.371138828673793e-08f, r);
+    r = fmaf(fn, 1.7151245100058819e-15f, r);
+    const float r2 = r * r;
+    const float s = fmaf(r * r2, fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f), r);
+    const float c = fmaf(r2 * r2, fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f),
+                         fmaf(-0.5f, r2, 1.0f));
+    const float v = (n & 1) ? c : s;
+    return (n & 2) ? -v : v;
+}
+
+DEDF_DEV f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+DEDF_DEV void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+}  // namespace dedf

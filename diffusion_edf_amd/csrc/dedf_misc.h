@@ -1,0 +1,422 @@
+// The small kernels around the two fused ones: pose preparation (Wigner-D, transformed query positions), time
+// embedding -> pre-linear bias rows, pose-independent source message, radius neighbour search (count / scan / fill),
+// joint softmax + aggregation over all scales, per-pose reduction and the float64 Langevin update.
+#pragma once
+#include "dedf_dev.h"
+#include "dedf_net.h"
+#include "dedf_node.h"
+
+namespace dedf {
+
+// ------------------------------------------------------------------------------------------------------------------------
+// T (f64, sampler state) -> f32 poses + shared time
+__global__ void k_cast_pose(const double* __restrict__ T, float* __restrict__ Ts, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) Ts[i] = (float)T[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Pose preparation: one block per pose.
+//   pose record: raw q, D^1(q), D^2(q)   with  q_n = standardize(q/|q|), R = quaternion_to_matrix(q_n),
+//   (a,b,c) = matrix_to_euler_angles(R, "YXY"), D^l = X(a) J X(b) J X(c)            (wigner.py:44-81, 257-283;
+//   transforms.py:83-110, 198-208, 271-308 — including the signed-zero behaviour at q = identity)
+//   qpos[pose][q] = quaternion_apply(q_raw, x_q) + t                                  (gnn_data.py:95)
+template <int LD>
+__device__ inline void wigner_from_angles(float a, float b, float c, float* D /* (2l+1)^2 row-major */) {
+    constexpr int n = 2 * LD + 1;
+    float X[3][n][n];
+    const float ang[3] = {a, b, c};
+    for (int t = 0; t < 3; ++t) {
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) X[t][i][j] = 0.0f;
+        for (int i = 0; i < n; ++i) {                      // wigner.py:21-42 (sin first, cos overwrites the centre)
+            const float f = (float)(LD - i);
+            X[t][i][n - 1 - i] = sinf(f * ang[t]);
+            X[t][i][i] = cosf(f * ang[t]);
+        }
+    }
+    float A[n][n], Bm[n][n];
+    auto Jl = [](int i, int j) { if constexpr (LD == 1) return kJ1[i][j]; else return kJ2[i][j]; };
+    // ((((Xa J) Xb) J) Xc)
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { float s = 0; for (int k = 0; k < n; ++k) s += X[0][i][k] * Jl(k, j); A[i][j] = s; }
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { float s = 0; for (int k = 0; k < n; ++k) s += A[i][k] * X[1][k][j]; Bm[i][j] = s; }
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { float s = 0; for (int k = 0; k < n; ++k) s += Bm[i][k] * Jl(k, j); A[i][j] = s; }
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { float s = 0; for (int k = 0; k < n; ++k) s += A[i][k] * X[2][k][j]; D[i * n + j] = s; }
+}
+
+template <int L>
+__global__ void k_pose_prep(const float* __restrict__ Ts, const float* __restrict__ qx, int nQ,
+                            float* __restrict__ pose, float* __restrict__ qpos) {
+    const int t = blockIdx.x;
+    const float* T = Ts + 7 * t;
+    const float qw = T[0], qi = T[1], qj = T[2], qk = T[3];
+    if (threadIdx.x == 0) {
+        float* rec = pose + (size_t)t * kPoseRec;
+        rec[0] = qw; rec[1] = qi; rec[2] = qj; rec[3] = qk;
+        const float nrm = sqrtf(qw * qw + qi * qi + qj * qj + qk * qk);       // torch.norm
+        float r = qw / nrm, i = qi / nrm, j = qj / nrm, k = qk / nrm;
+        if (r < 0.0f) { r = -r; i = -i; j = -j; k = -k; }                      // standardize_quaternion
+        const float two_s = 2.0f / (r * r + i * i + j * j + k * k);
+        // rows of R (transforms.py:96-108); only row 1 / column 1 are needed for YXY
+        const float R01 = two_s * (i * j - k * r);
+        const float R10 = two_s * (i * j + k * r);
+        const float R11 = 1.0f - two_s * (i * i + k * k);
+        const float R12 = two_s * (j * k - i * r);
+        const float R21 = two_s * (j * k + i * r);
+        const float a = atan2f(R01, R21);              // _angle_from_tan("Y","X", R[:,1], horizontal=False)
+        const float b = acosf(R11);
+        const float c = atan2f(R10, -R12);             // _angle_from_tan("Y","X", R[1,:], horizontal=True)
+        wigner_from_angles<1>(a, b, c, rec + 4);
+        if constexpr (L >= 2) wigner_from_angles<2>(a, b, c, rec + 16);
+    }
+    for (int q = threadIdx.x; q < nQ; q += blockDim.x) {
+        // quaternion_apply(q, p) = (q * (0,p)) * conj(q)   with the reference's raw products (transforms.py:113-165)
+        const float px = qx[3 * q], py = qx[3 * q + 1], pz = qx[3 * q + 2];
+        const float aw = qw, ax = qi, ay = qj, az = qk;
+        const float bw = 0.0f, bx = px, by = py, bz = pz;
+        const float ow = aw * bw - ax * bx - ay * by - az * bz;
+        const float ox = aw * bx + ax * bw + ay * bz - az * by;
+        const float oy = aw * by - ax * bz + ay * bw + az * bx;
+        const float oz = aw * bz + ax * by - ay * bx + az * bw;
+        const float cw = qw, cx = -qi, cy = -qj, cz = -qk;
+        const float rx = ow * cx + ox * cw + oy * cz - oz * cy;
+        const float ry = ow * cy - ox * cz + oy * cw + oz * cx;
+        const float rz = ow * cz + ox * cy - oy * cx + oz * cw;
+        float* o = qpos + ((size_t)t * nQ + q) * 3;
+        o[0] = rx + T[4]; o[1] = ry + T[5]; o[2] = rz + T[6];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Time embedding (score_head.py:159-164) folded into the pre-linear (multiscale_tensor_field.py:225-234):
+//   tb[p][n][row-packed 128] = W_pre[n][:, 64:] . MLP_n(sinusoid(time_p)) + b_pre[n]
+// grid (nTb, n_scales), block 128.
+struct TimeParams {
+    const float* time; int time_stride;             // stride 0: one shared time
+    const float *w1, *b1, *w2, *b2;                 // [n_scales][128][256], [128], [64][128], [64]
+    const float *wpre, *bpre;                       // [n_scales][128][128], [128]
+    const float* tfreq;                             // [128] exp(k * -(ln n / 127)) evaluated on the host like torch does
+    float max_time, time_enc_n;
+    float* tb;
+};
+__global__ void k_time_bias(TimeParams P) {
+    __shared__ float enc[kTimeEnc], hid[kTimeHid], emb[kTimeEmb];
+    const int p = blockIdx.x, n = blockIdx.y, n_scales = gridDim.y, tid = threadIdx.x;
+    const float t = P.time[p * P.time_stride];
+    // SinusoidalPositionEmbeddings(dim 256, max_val, n) — radial_func.py:305-316
+    const float x = t / P.max_time * P.time_enc_n;
+    {
+        const float fr = P.tfreq[tid];
+        enc[tid] = sinf(x * fr);
+        enc[tid + 128] = cosf(x * fr);
+    }
+    __syncthreads();
+    {
+        const float* w = P.w1 + ((size_t)n * kTimeHid + tid) * kTimeEnc;
+        float s = P.b1[n * kTimeHid + tid];
+        for (int k = 0; k < kTimeEnc; ++k) s += w[k] * enc[k];
+        hid[tid] = s / (1.0f + expf(-s));
+    }
+    __syncthreads();
+    if (tid < kTimeEmb) {
+        const float* w = P.w2 + ((size_t)n * kTimeEmb + tid) * kTimeHid;
+        float s = P.b2[n * kTimeEmb + tid];
+        for (int k = 0; k < kTimeHid; ++k) s += w[k] * hid[k];
+        emb[tid] = s;
+    }
+    __syncthreads();
+    {
+        const float* w = P.wpre + ((size_t)n * 128 + tid) * 128 + kLenEmb;
+        float s = P.bpre[n * 128 + tid];
+        for (int k = 0; k < kTimeEmb; ++k) s += w[k] * emb[k];
+        const int tile = tid >> 5, row = tid & 31;
+        P.tb[((size_t)p * n_scales + n) * 128 + (tile * 2 + row_hi(row)) * 16 + row_reg(row)] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Source message (pose independent): EquivariantLayerNormV2 + LinearRS(bias) on every key point
+// (gnn_block.py:170-171, layer_norm.py:91-156, tensor_product_rescale.py:176-185).  One block (64 threads) per point.
+template <int L>
+__global__ void k_src_message(const float* __restrict__ f, int n_pts, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                              const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ msg) {
+    constexpr int D = feat_dim<L>();
+    __shared__ float x[D], red[2];
+    const int pt = blockIdx.x, tid = threadIdx.x;
+    const float* fi = f + (size_t)pt * D;
+    for (int i = tid; i < D; i += 64) x[i] = fi[i];
+    __syncthreads();
+    int woff = 0, chan = 0;
+    for (int l = 0; l <= L; ++l) {
+        const int m = mul_of(l), d = 2 * l + 1, off = blk_off(l);
+        // statistics of block l (serial in thread 0: 240 values, runs once per scene)
+        if (tid == 0) {
+            float mean = 0.0f;
+            if (l == 0) { for (int c = 0; c < m; ++c) mean += x[off + c]; mean /= m; }
+            float v = 0.0f;
+            for (int c = 0; c < m; ++c) {
+                float s = 0.0f;
+                for (int k = 0; k < d; ++k) { const float t = x[off + c * d + k] - mean; s += t * t; }
+                v += s / d;
+            }
+            red[0] = mean; red[1] = 1.0f / sqrtf(v / m + 1e-5f);
+        }
+        __syncthreads();
+        const float mean = red[0], rs = red[1];
+        __syncthreads();
+        for (int i = tid; i < m * d; i += 64) {
+            const int c = i / d;
+            float t = (x[off + i] - mean) * (rs * ln_w[chan + c]);
+            if (l == 0) t += ln_b[c];
+            x[off + i] = t;
+        }
+        __syncthreads();
+        woff += m * m; chan += m;
+    }
+    woff = 0;
+    float* o = msg + (size_t)pt * D;
+    for (int l = 0; l <= L; ++l) {
+        const int m = mul_of(l), d = 2 * l + 1, off = blk_off(l);
+        for (int i = tid; i < m * d; i += 64) {
+            const int w = i / d, k = i % d;
+            float s = (l == 0) ? bias[w] : 0.0f;
+            for (int u = 0; u < m; ++u) s += W[woff + u * m + w] * x[off + u * d + k];
+            o[off + i] = s;
+        }
+        woff += m * m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Radius neighbour search (torch_cluster.radius as used at graph_parser.py:339; all pairs for the infinite scale,
+// graph_parser.py:279-281).  Keys are tiny (<= a few thousand points) and static, queries move every step: brute force with
+// the key cloud streamed through LDS, one thread per destination node.  Edge order: scale, then dst, then src ascending.
+struct NbrParams {
+    const float* key_x; int n_keys;
+    int scale_start[kMaxScales + 1];
+    float r2[kMaxScales];                 // squared radius, <= 0: infinite
+    int n_scales, max_neighbors;
+    const float* qpos; int n_dst;
+    int* cnt;                             // [n_scales][n_dst]
+    const int* off;                       // [n_scales][n_dst]  exclusive prefix inside the scale
+    const int* tile_info;                 // edge base per scale at [16 + n]
+    int* edge_src; int* edge_dst;
+    int64_t cap;
+};
+constexpr int kNbrChunk = 1024;
+template <bool FILL>
+__global__ void k_neighbors(NbrParams P) {
+    __shared__ float kx[kNbrChunk * 3];
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = d < P.n_dst;
+    float px = 0, py = 0, pz = 0;
+    if (act) { px = P.qpos[3 * d]; py = P.qpos[3 * d + 1]; pz = P.qpos[3 * d + 2]; }
+    for (int n = 0; n < P.n_scales; ++n) {
+        const int s0 = P.scale_start[n], s1 = P.scale_start[n + 1];
+        const float r2 = P.r2[n];
+        int c = 0;
+        int64_t base = 0;
+        if (FILL && act) base = (int64_t)P.tile_info[16 + n] + P.off[(size_t)n * P.n_dst + d];
+        for (int c0 = s0; c0 < s1; c0 += kNbrChunk) {
+            const int nc = min(kNbrChunk, s1 - c0);
+            __syncthreads();
+            for (int i = threadIdx.x; i < nc * 3; i += blockDim.x) kx[i] = P.key_x[(size_t)c0 * 3 + i];
+            __syncthreads();
+            if (!act) continue;
+            for (int i = 0; i < nc; ++i) {
+                const float dx = kx[3 * i] - px, dy = kx[3 * i + 1] - py, dz = kx[3 * i + 2] - pz;
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                const bool in = (r2 <= 0.0f) || (d2 < r2);
+                if (in && (r2 <= 0.0f || c < P.max_neighbors)) {
+                    if (FILL && base + c < P.cap) { P.edge_src[base + c] = c0 + i; P.edge_dst[base + c] = d; }
+                    ++c;
+                }
+            }
+        }
+        if (!FILL && act) P.cnt[(size_t)n * P.n_dst + d] = c;
+    }
+}
+
+// exclusive scan of cnt[n][*] per scale + tile table.  One block of 1024 threads.
+// tile_info: [0..n_scales] tile prefix, [16..16+n_scales] edge prefix, [40] overflow flag
+__global__ void k_scan(const int* __restrict__ cnt, int* __restrict__ off, int n_dst, int n_scales, int* __restrict__ tile_info, int64_t cap) {
+    __shared__ int part[1024];
+    __shared__ int carry;
+    const int tid = threadIdx.x;
+    int tiles = 0;
+    int64_t edges = 0;
+    if (tid == 0) { tile_info[0] = 0; tile_info[16] = 0; }
+    for (int n = 0; n < n_scales; ++n) {
+        if (tid == 0) carry = 0;
+        __syncthreads();
+        const int per = (n_dst + 1023) / 1024;
+        const int i0 = tid * per, i1 = min(n_dst, i0 + per);
+        int s = 0;
+        for (int i = i0; i < i1; ++i) s += cnt[(size_t)n * n_dst + i];
+        part[tid] = s;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {          // Hillis-Steele inclusive scan
+            int v = (tid >= o) ? part[tid - o] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        int run = part[tid] - s;
+        for (int i = i0; i < i1; ++i) { off[(size_t)n * n_dst + i] = run; run += cnt[(size_t)n * n_dst + i]; }
+        const int total = part[1023];
+        __syncthreads();
+        edges += total;
+        tiles += (total + 31) / 32;
+        if (tid == 0) { tile_info[n + 1] = tiles; tile_info[16 + n + 1] = (int)min(edges, (int64_t)0x7fffffff); }
+    }
+    if (tid == 0) {
+        const int ovf = edges > cap ? 1 : 0;
+        tile_info[40] = ovf;
+        if (ovf) for (int n = 0; n <= n_scales; ++n) tile_info[n] = 0;     // no tiles: downstream kernels do nothing
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Joint softmax over ALL scales' edges of one destination node + weighted aggregation (graph_attention.py:253-266;
+// scatter_logsumexp / scatter restated: max-shifted, empty segments give 0).  One wave per destination, lane = float4 of
+// the value record; deterministic (fixed edge order, no atomics).
+template <int L>
+__global__ void k_aggregate(const float* __restrict__ edge_out, const int* __restrict__ cnt, const int* __restrict__ off,
+                            const int* __restrict__ tile_info, int n_dst, int n_scales, float* __restrict__ z) {
+    constexpr int D = feat_dim<L>(), REC = edge_rec<L>(), NV = D / 4;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= n_dst) return;
+    const int d = wave;
+    if (tile_info[40]) return;
+    const int ci = 4 * lane;
+    int head = 0;
+    if (ci < blk_off(1)) head = ci / (mul_of(0) / kHeads);
+    else if (L >= 1 && ci < blk_off(2)) head = ((ci - blk_off(1)) % mul_of(1)) / (mul_of(1) / kHeads);
+    else if (L >= 2) head = ((ci - blk_off(2)) % mul_of(2)) / (mul_of(2) / kHeads);
+    float mx[kHeads];
+    for (int h = 0; h < kHeads; ++h) mx[h] = -INFINITY;
+    for (int n = 0; n < n_scales; ++n) {
+        const int c = cnt[(size_t)n * n_dst + d];
+        const size_t e0 = (size_t)tile_info[16 + n] + off[(size_t)n * n_dst + d];
+        for (int j = 0; j < c; ++j) {
+            const f32x4 lg = ld4(edge_out + (e0 + j) * REC + D);
+            for (int h = 0; h < kHeads; ++h) mx[h] = fmaxf(mx[h], lg[h]);
+        }
+    }
+    float sum[kHeads] = {0, 0, 0, 0};
+    f32x4 acc = {0, 0, 0, 0};
+    for (int n = 0; n < n_scales; ++n) {
+        const int c = cnt[(size_t)n * n_dst + d];
+        const size_t e0 = (size_t)tile_info[16 + n] + off[(size_t)n * n_dst + d];
+        for (int j = 0; j < c; ++j) {
+            const float* rec = edge_out + (e0 + j) * REC;
+            const f32x4 lg = ld4(rec + D);
+            float p[kHeads];
+            for (int h = 0; h < kHeads; ++h) { p[h] = expf(lg[h] - mx[h]); sum[h] += p[h]; }
+            if (lane < NV) {
+                const f32x4 v = ld4(rec + ci);
+                const float ph = head == 0 ? p[0] : (head == 1 ? p[1] : (head == 2 ? p[2] : p[3]));
+                acc += v * ph;
+            }
+        }
+    }
+    if (lane < NV) {
+        const float s = head == 0 ? sum[0] : (head == 1 ? sum[1] : (head == 2 ? sum[2] : sum[3]));
+        const float inv = s > 0.0f ? 1.0f / s : 0.0f;
+        st4(z + (size_t)d * D + ci, acc * inv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Sum over the query points of one pose (score_head.py:207-209), fixed order.
+__global__ void k_pose_reduce(const float* __restrict__ node_out, int nT, int nQ, float* __restrict__ ang, float* __restrict__ lin) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nT) return;
+    float s[6] = {0, 0, 0, 0, 0, 0};
+    for (int q = 0; q < nQ; ++q) {
+        const float* o = node_out + ((size_t)t * nQ + q) * 8;
+        for (int i = 0; i < 6; ++i) s[i] += o[i];
+    }
+    lin[3 * t] = s[0]; lin[3 * t + 1] = s[1]; lin[3 * t + 2] = s[2];
+    ang[3 * t] = s[3]; ang[3 * t + 1] = s[4]; ang[3 * t + 2] = s[5];
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Langevin step on SE(3) in float64 (score_model_base.py:178-193).  Noise: caller-provided standard normals or
+// Philox4x32-10 keyed by (seed, global pose index, step) + Box-Muller, so results do not depend on how poses are sharded.
+__device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ inline double u01(uint32_t hi, uint32_t lo) {      // (0,1]
+    const uint64_t v = ((uint64_t)hi << 21) ^ (uint64_t)(lo >> 11);   // 53 bits
+    return ((double)(v & ((1ull << 53) - 1)) + 1.0) * (1.0 / 9007199254740992.0);
+}
+struct LangevinParams {
+    double* T;                 // [nT][7] state, updated in place
+    const float* ang; const float* lin;
+    double t, alpha_ang, alpha_lin, temperature, ang_mult, lin_mult;
+    const double* noise;       // [2][nT][3] for this step or nullptr
+    uint64_t seed; int64_t first_pose; int step;
+    double* traj_out;          // [nT][7] slot of this step
+    int nT;
+};
+__global__ void k_langevin(LangevinParams P) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.nT) return;
+    double* T = P.T + 7 * (size_t)i;
+    double na[3], nl[3];
+    if (P.noise) {
+        for (int k = 0; k < 3; ++k) { na[k] = P.noise[(size_t)i * 3 + k]; nl[k] = P.noise[(size_t)(P.nT + i) * 3 + k]; }
+    } else {
+        const uint64_t gp = (uint64_t)(P.first_pose + i);
+        double g[8];
+        for (int b = 0; b < 2; ++b) {
+            uint32_t r[8];
+            philox4x32_10((uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)P.step, (uint32_t)(2 * b), (uint32_t)P.seed, (uint32_t)(P.seed >> 32), r);
+            philox4x32_10((uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)P.step, (uint32_t)(2 * b + 1), (uint32_t)P.seed, (uint32_t)(P.seed >> 32), r + 4);
+            for (int p = 0; p < 2; ++p) {              // Box-Muller on two uniform pairs
+                const double u1 = u01(r[4 * p], r[4 * p + 1]), u2 = u01(r[4 * p + 2], r[4 * p + 3]);
+                const double rad = sqrt(-2.0 * log(u1)), th = 6.283185307179586476925 * u2;
+                g[4 * b + 2 * p] = rad * cos(th); g[4 * b + 2 * p + 1] = rad * sin(th);
+            }
+        }
+        for (int k = 0; k < 3; ++k) { na[k] = g[k]; nl[k] = g[3 + k]; }
+    }
+    const double st = sqrt(P.t);
+    double da[3], dl[3];
+    for (int k = 0; k < 3; ++k) {
+        const double sa = (double)P.ang[3 * i + k] / (P.ang_mult * st);
+        const double sl = (double)P.lin[3 * i + k] / (P.lin_mult * st);
+        da[k] = (P.alpha_ang / 2) * sa + sqrt(P.temperature * P.alpha_ang) * na[k];
+        dl[k] = (P.alpha_lin / 2) * sl + sqrt(P.temperature * P.alpha_lin) * nl[k];
+    }
+    const double q0 = T[0], q1 = T[1], q2 = T[2], q3 = T[3];
+    // dq = L da,  L = T[q_indices] * q_factor  (score_model_base.py:31-32, 188-190)
+    double dq[4];
+    dq[0] = -0.5 * q1 * da[0] - 0.5 * q2 * da[1] - 0.5 * q3 * da[2];
+    dq[1] = 0.5 * q0 * da[0] - 0.5 * q3 * da[1] + 0.5 * q2 * da[2];
+    dq[2] = 0.5 * q3 * da[0] + 0.5 * q0 * da[1] - 0.5 * q1 * da[2];
+    dq[3] = -0.5 * q2 * da[0] + 0.5 * q1 * da[1] + 0.5 * q0 * da[2];
+    // dx = quaternion_apply(q, dl) with the pre-update q
+    const double ow = -q1 * dl[0] - q2 * dl[1] - q3 * dl[2];
+    const double ox = q0 * dl[0] + q2 * dl[2] - q3 * dl[1];
+    const double oy = q0 * dl[1] - q1 * dl[2] + q3 * dl[0];
+    const double oz = q0 * dl[2] + q1 * dl[1] - q2 * dl[0];
+    const double rx = -ow * q1 + ox * q0 - oy * q3 + oz * q2;
+    const double ry = -ow * q2 + ox * q3 + oy * q0 - oz * q1;
+    const double rz = -ow * q3 - ox * q2 + oy * q1 + oz * q0;
+    double n0 = q0 + dq[0], n1 = q1 + dq[1], n2 = q2 + dq[2], n3 = q3 + dq[3];
+    const double nn = sqrt(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
+    T[0] = n0 / nn; T[1] = n1 / nn; T[2] = n2 / nn; T[3] = n3 / nn;
+    T[4] += rx; T[5] += ry; T[6] += rz;
+    double* o = P.traj_out + 7 * (size_t)i;
+    for (int k = 0; k < 7; ++k) o[k] = T[k];
+}
+
+}  // namespace dedf

@@ -1,0 +1,156 @@
+// Compile-time description of the score-head network for irreps  64x0e + 32x1e (+ 16x2e (+ 8x3e)),  SH 0..L.
+// Everything here is constexpr and shared by the host weight packers and the device kernels, so the order in which a
+// kernel walks K-steps and the order in which the host lays out the A operands cannot drift apart.
+//
+// Path / weight ordering restates the reference's instruction construction:
+//   DepthwiseTensorProduct   equiformer/tensor_product_rescale.py:352-382  (creation order in1 -> in2 -> l_out,
+//                            outputs re-sorted by l with a stable sort; weight blocks stay in creation order)
+//   LinearRS / FCTP          equiformer/tensor_product_rescale.py:155-185
+#pragma once
+#include "dedf_layout.h"
+
+namespace dedf {
+
+constexpr int kHeads = 4;
+constexpr int kFc0 = 128, kFc1 = 128, kFc2 = 64;     // fc_neurons of every shipped config (resolved)
+constexpr int kLenEmb = 64, kTimeEmb = 64, kTimeEnc = 256, kTimeHid = 128;
+constexpr int kMaxScales = 8;
+
+DEDF_HD constexpr int mul_of(int l) { return 64 >> l; }
+DEDF_HD constexpr int iabs(int a) { return a < 0 ? -a : a; }
+DEDF_HD constexpr int imin(int a, int b) { return a < b ? a : b; }
+DEDF_HD constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+DEDF_HD constexpr int rup(int a, int b) { return cdiv(a, b) * b; }
+
+template <int L> DEDF_HD constexpr int feat_dim() { int d = 0; for (int l = 0; l <= L; ++l) d += mul_of(l) * (2 * l + 1); return d; }
+// offset of irreps block l (same in the reference layout [mul][m] and in the internal layout [m][mul])
+DEDF_HD constexpr int blk_off(int l) { int d = 0; for (int i = 0; i < l; ++i) d += mul_of(i) * (2 * i + 1); return d; }
+template <int L> DEDF_HD constexpr int sum_mul() { int d = 0; for (int l = 0; l <= L; ++l) d += mul_of(l); return d; }
+
+struct PathInfo {
+    int l1, l2, l3;
+    int mul1, mul2;   // multiplicities of in1 / in2 (mul2 == 1 for the SH depth-wise TP)
+    int wstart;       // offset of this path's weight block in the flat e3nn weight vector
+    int kofs;         // offset of this path's channels inside the l3 block of the (sorted) DTP output
+};
+
+// ---- depth-wise TP  features (x) SH(0..L), outputs l3 <= L ------------------------------------------------------
+template <int L> DEDF_HD constexpr int dtp_num_paths() {
+    int n = 0;
+    for (int l1 = 0; l1 <= L; ++l1) for (int l2 = 0; l2 <= L; ++l2)
+        for (int l3 = iabs(l1 - l2); l3 <= imin(L, l1 + l2); ++l3) ++n;
+    return n;
+}
+template <int L> DEDF_HD constexpr PathInfo dtp_path(int p) {
+    int n = 0, w = 0;
+    int kc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int l1 = 0; l1 <= L; ++l1) for (int l2 = 0; l2 <= L; ++l2)
+        for (int l3 = iabs(l1 - l2); l3 <= imin(L, l1 + l2); ++l3) {
+            if (n == p) return PathInfo{l1, l2, l3, mul_of(l1), 1, w, kc[l3]};
+            w += mul_of(l1); kc[l3] += mul_of(l1); ++n;
+        }
+    return PathInfo{-1, -1, -1, 0, 0, w, 0};
+}
+template <int L> DEDF_HD constexpr int dtp_wn() { return dtp_path<L>(dtp_num_paths<L>()).wstart; }   // 480 (L=2), 224 (L=1)
+template <int L> DEDF_HD constexpr int dtp_k(int l3) {       // channels of the l3 block of the DTP output: 112/192/176
+    int k = 0;
+    for (int p = 0; p < dtp_num_paths<L>(); ++p) if (dtp_path<L>(p).l3 == l3) k += dtp_path<L>(p).mul1;
+    return k;
+}
+template <int L> DEDF_HD constexpr int dtp_out_dim() { int d = 0; for (int l = 0; l <= L; ++l) d += dtp_k<L>(l) * (2 * l + 1); return d; }
+template <int L> DEDF_HD constexpr int dtp_path_of_row(int wrow) {
+    for (int p = 0; p < dtp_num_paths<L>(); ++p) {
+        const PathInfo pi = dtp_path<L>(p);
+        if (wrow >= pi.wstart && wrow < pi.wstart + pi.mul1) return p;
+    }
+    return -1;
+}
+// A "group" = 8 consecutive weight rows = 4 accumulator registers x 2 half-waves = 4 MFMA K-steps.
+// Index of w-group `wg` (= wrow / 8) among the groups that feed the same l3 (their K-steps follow w order).
+template <int L> DEDF_HD constexpr int dtp_group_index(int wg) {
+    const int l3 = dtp_path<L>(dtp_path_of_row<L>(wg * 8)).l3;
+    int n = 0;
+    for (int g = 0; g < wg; ++g) if (dtp_path<L>(dtp_path_of_row<L>(g * 8)).l3 == l3) ++n;
+    return n;
+}
+// K-steps (as indices into the l3 block of the sorted DTP output) in the order the kernels walk them
+template <int L> inline std::vector<KStep> dtp_steps(int l3) {
+    std::vector<KStep> s;
+    for (int wg = 0; wg < dtp_wn<L>() / 8; ++wg) {
+        const PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(wg * 8));
+        if (pi.l3 != l3) continue;
+        const int u0 = wg * 8 - pi.wstart;
+        for (int j = 0; j < 4; ++j) s.push_back({pi.kofs + u0 + j, pi.kofs + u0 + 4 + j});
+    }
+    return s;
+}
+
+// ---- score tensor products: in1 = rotated query feature, in2 = field, outputs l3 in {0, 1} ------------------------
+template <int L> DEDF_HD constexpr int stp_num_paths() {
+    int n = 0;
+    for (int l1 = 0; l1 <= L; ++l1) for (int l2 = 0; l2 <= L; ++l2)
+        for (int l3 = iabs(l1 - l2); l3 <= imin(1, l1 + l2); ++l3) ++n;
+    return n;
+}
+template <int L> DEDF_HD constexpr PathInfo stp_path(int p) {
+    int n = 0, w = 0;
+    int kc[2] = {0, 0};
+    for (int l1 = 0; l1 <= L; ++l1) for (int l2 = 0; l2 <= L; ++l2)
+        for (int l3 = iabs(l1 - l2); l3 <= imin(1, l1 + l2); ++l3) {
+            if (n == p) return PathInfo{l1, l2, l3, mul_of(l1), mul_of(l2), w, kc[l3]};
+            w += mul_of(l1) * mul_of(l2); kc[l3] += mul_of(l1); ++n;
+        }
+    return PathInfo{-1, -1, -1, 0, 0, w, 0};
+}
+template <int L> DEDF_HD constexpr int stp_wn() { return stp_path<L>(stp_num_paths<L>()).wstart; }    // 11776 (L=2)
+template <int L> DEDF_HD constexpr int stp_k(int l3) {
+    int k = 0;
+    for (int p = 0; p < stp_num_paths<L>(); ++p) if (stp_path<L>(p).l3 == l3) k += stp_path<L>(p).mul1;
+    return k;
+}
+// group index (4 K-steps each) of (path p, u-group gu) among the groups feeding l3, walking paths in creation order
+template <int L> DEDF_HD constexpr int stp_group_index(int p, int gu) {
+    const int l3 = stp_path<L>(p).l3;
+    int n = 0;
+    for (int q = 0; q < p; ++q) if (stp_path<L>(q).l3 == l3) n += stp_path<L>(q).mul1 / 8;
+    return n + gu;
+}
+template <int L> inline std::vector<KStep> stp_steps(int l3) {
+    std::vector<KStep> s;
+    for (int p = 0; p < stp_num_paths<L>(); ++p) {
+        const PathInfo pi = stp_path<L>(p);
+        if (pi.l3 != l3) continue;
+        for (int gu = 0; gu < pi.mul1 / 8; ++gu)
+            for (int j = 0; j < 4; ++j) s.push_back({pi.kofs + gu * 8 + j, pi.kofs + gu * 8 + 4 + j});
+    }
+    return s;
+}
+// same walk for the second depth-wise TP of the attention value (shared weights; paths in creation order)
+template <int L> DEDF_HD constexpr int dtp2_group_index(int p, int gu) {
+    const int l3 = dtp_path<L>(p).l3;
+    int n = 0;
+    for (int q = 0; q < p; ++q) if (dtp_path<L>(q).l3 == l3) n += dtp_path<L>(q).mul1 / 8;
+    return n + gu;
+}
+
+// ---- row spaces of the edge kernel ---------------------------------------------------------------------------------
+// l3 = 0 GEMM of sep_act.lin and sep_alpha share their K-steps:  rows [0, lin0) = lin scalars+gates, padded to a tile,
+// then 64 alpha rows.
+template <int L> DEDF_HD constexpr int gates_total() { int g = 0; for (int l = 1; l <= L; ++l) g += mul_of(l); return g; }
+template <int L> DEDF_HD constexpr int lin0_rows() { return mul_of(0) + gates_total<L>(); }          // 112 / 96
+template <int L> DEDF_HD constexpr int alpha_row0() { return rup(lin0_rows<L>(), 32); }                // 128 / 96
+template <int L> DEDF_HD constexpr int r0_tiles() { return (alpha_row0<L>() + mul_of(0)) / 32; }       // 6 / 5
+DEDF_HD constexpr int gate_row(int l, int c) { int r = mul_of(0); for (int i = 1; i < l; ++i) r += mul_of(i); return r + c; }
+// per-edge record written by the edge kernel: value in internal layout + one logit per head
+template <int L> DEDF_HD constexpr int edge_rec() { return feat_dim<L>() + kHeads; }                   // 244 / 164
+
+// ---- FFN row spaces (node kernel) ------------------------------------------------------------------------------------
+constexpr int kMlpMid = 3;
+template <int L> DEDF_HD constexpr int f1_rows0() { int r = kMlpMid * mul_of(0); for (int l = 1; l <= L; ++l) r += kMlpMid * mul_of(l); return r; }  // 336 / 288
+DEDF_HD constexpr int f1_gate_row(int l, int c) { int r = kMlpMid * mul_of(0); for (int i = 1; i < l; ++i) r += kMlpMid * mul_of(i); return r + c; }
+
+// internal feature layout: block l at blk_off(l), stored [m][mul]  (reference stores [mul][m])
+DEDF_HD constexpr int int_idx(int l, int c, int m) { return blk_off(l) + m * mul_of(l) + c; }
+DEDF_HD constexpr int ref_idx(int l, int c, int m) { return blk_off(l) + c * (2 * l + 1) + m; }
+
+}  // namespace dedf

@@ -1,0 +1,321 @@
+// Per-query-node epilogue (one wave = 32 (pose, query) nodes):
+//   attention output -> proj (graph_attention.py:268) -> post-norm + FFN + residual (gnn_block.py:210-216) ->
+//   lin/ang score tensor products with the Wigner-rotated query feature (score_head.py:192-199) -> rotate back to the
+//   body frame, orbital term, query weights (score_head.py:201-209).
+// Same transposed-GEMM register layout as the edge kernel (dedf_layout.h): lane = (node column, row half).
+//
+// The score TP `uvu` with mul(in2) > 1 is evaluated factorised:  T_p[u][j] = sum_v W_p[u,v] field[v,j]  (MFMA),
+// then the Clebsch-Gordan contraction with the query feature row u is lane-local and its result row is directly the
+// K-step operand of the final LinearRS — 25 088 MAC per TP instead of the 171 632 of the materialised (u,v,i,j) form.
+#pragma once
+#include "dedf_dev.h"
+#include "dedf_net.h"
+
+namespace dedf {
+
+constexpr int kPoseRec = 64;      // floats per pose: [0:4] raw q, [4:13] D^1 row-major, [16:41] D^2 row-major
+
+struct NodeParams {
+    const float* z;  uint32_t z_bytes;        // [N_d][D] softmax-aggregated values, internal layout
+    const float* qf; uint32_t qf_bytes;       // [nQ][D] query features, reference layout
+    const float* pose; uint32_t pose_bytes;   // [nT][kPoseRec]
+    const float* qx;                          // [nQ][3] query positions (gripper frame)
+    const float* qw;                          // [nQ] query weights
+    int nQ, n_nodes;
+    float lin_mult;
+    const float* W; uint32_t W_bytes;
+    int o_A_proj[4], o_b_proj0;
+    int o_ln_w[4], o_ln_b0;
+    int o_A_f1[4], o_b_f1;
+    int o_A_f2[4], o_b_f2;
+    int o_A_s[2][16];                          // [tp][path]  W_p (rows u, K = v)
+    int o_A_sl[2][2];                          // [tp][l3]    final LinearRS (l3 = 0: the 32 gate rows; l3 = 1: 32 rows)
+    int o_b_sl[2];                             // [tp]        gate bias rows
+    float* node_out;                           // [N_d][8]: w*lin_vel (3), w*(ang_orbital + ang_spin) (3), 0, 0
+};
+
+template <int L> struct Feat {                 // one node's features in row layout: row = channel
+    f32x16 s[2];                               // 64 scalars
+    float v1[3][16];                           // 32x1e, [m][reg]
+    float v2[5][8];                            // 16x2e, [m][reg]
+};
+// B operand for K-group g (4 regs) of block l, component m
+template <int L, int l, int m, int g, int j> DEDF_DEV float feat_b(const Feat<L>& f) {
+    if constexpr (l == 0) return f.s[g / 4][4 * (g % 4) + j];
+    else if constexpr (l == 1) return f.v1[m][4 * g + j];
+    else return f.v2[m][4 * g + j];
+}
+
+template <int L>
+DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
+    constexpr int D = feat_dim<L>();
+    const int hi = wv.hi;
+    const bool valid = n0 + wv.col < P.n_nodes;
+    const int n = valid ? n0 + wv.col : n0;
+    const int pose = n / P.nQ, q = n - pose * P.nQ;
+
+    // ---- load aggregated attention values (internal layout [l][m][channel]) ---------------------------------------------
+    Feat<L> z;
+    {
+        const Buf zb = make_buf(P.z, P.z_bytes);
+        const int zv = n * (D * 4) + hi * 16;
+        static_for<2>([&]<int T>() { static_for<4>([&]<int g>() {
+            const f32x4 t = bld4(zb, zv, (T * 32 + 8 * g) * 4);
+            z.s[T][4 * g] = t[0]; z.s[T][4 * g + 1] = t[1]; z.s[T][4 * g + 2] = t[2]; z.s[T][4 * g + 3] = t[3];
+        }); });
+        if constexpr (L >= 1) static_for<3>([&]<int m>() { static_for<4>([&]<int g>() {
+            const f32x4 t = bld4(zb, zv, (blk_off(1) + m * 32 + 8 * g) * 4);
+            z.v1[m][4 * g] = t[0]; z.v1[m][4 * g + 1] = t[1]; z.v1[m][4 * g + 2] = t[2]; z.v1[m][4 * g + 3] = t[3];
+        }); });
+        if constexpr (L >= 2) static_for<5>([&]<int m>() { static_for<2>([&]<int g>() {
+            const f32x4 t = bld4(zb, zv, (blk_off(2) + m * 16 + 8 * g) * 4);
+            z.v2[m][4 * g] = t[0]; z.v2[m][4 * g + 1] = t[1]; z.v2[m][4 * g + 2] = t[2]; z.v2[m][4 * g + 3] = t[3];
+        }); });
+    }
+
+    // ---- proj: per-l dense matrix (+ bias on 0e) ---------------------------------------------------------------------------
+    Feat<L> emb;
+    static_for<2>([&]<int To>() {
+        emb.s[To] = ldrows(wv, P.o_b_proj0, To);
+        static_for<8>([&]<int g>() {
+            mfma_group(emb.s[To], lda(wv, P.o_A_proj[0], 8, To, g), feat_b<L, 0, 0, g, 0>(z), feat_b<L, 0, 0, g, 1>(z),
+                       feat_b<L, 0, 0, g, 2>(z), feat_b<L, 0, 0, g, 3>(z));
+        });
+    });
+    sched_fence();
+    if constexpr (L >= 1) static_for<3>([&]<int m>() {
+        f32x16 a = {0};
+        static_for<4>([&]<int g>() {
+            mfma_group(a, lda(wv, P.o_A_proj[1], 4, 0, g), z.v1[m][4 * g], z.v1[m][4 * g + 1], z.v1[m][4 * g + 2], z.v1[m][4 * g + 3]);
+        });
+        static_for<16>([&]<int R>() { emb.v1[m][R] = a[R]; });
+    });
+    if constexpr (L >= 2) static_for<5>([&]<int m>() {
+        f32x16 a = {0};
+        static_for<2>([&]<int g>() {
+            mfma_group(a, lda(wv, P.o_A_proj[2], 2, 0, g), z.v2[m][4 * g], z.v2[m][4 * g + 1], z.v2[m][4 * g + 2], z.v2[m][4 * g + 3]);
+        });
+        static_for<8>([&]<int R>() { emb.v2[m][R] = a[R]; });
+    });
+    sched_fence();
+
+    // ---- EquivariantLayerNormV2 (equiformer/layer_norm.py:91-156) ----------------------------------------------------------
+    Feat<L> nrm;
+    {
+        float s = 0.0f;
+        static_for<2>([&]<int T>() { static_for<16>([&]<int R>() { s += emb.s[T][R]; }); });
+        s += xor32(s);
+        const float mean = s * (1.0f / 64);
+        float v = 0.0f;
+        static_for<2>([&]<int T>() { static_for<16>([&]<int R>() { const float d = emb.s[T][R] - mean; v += d * d; }); });
+        v += xor32(v);
+        const float rs = 1.0f / sqrtf(v * (1.0f / 64) + 1e-5f);
+        static_for<2>([&]<int T>() {
+            const f32x16 w = ldrows(wv, P.o_ln_w[0], T), b = ldrows(wv, P.o_ln_b0, T);
+            static_for<16>([&]<int R>() { nrm.s[T][R] = (emb.s[T][R] - mean) * (rs * w[R]) + b[R]; });
+        });
+    }
+    if constexpr (L >= 1) {
+        float v = 0.0f;
+        static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { v += emb.v1[m][R] * emb.v1[m][R]; }); });
+        v += xor32(v);
+        const float rs = 1.0f / sqrtf(v * (1.0f / (3 * 32)) + 1e-5f);
+        const f32x16 w = ldrows(wv, P.o_ln_w[1], 0);
+        static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { nrm.v1[m][R] = emb.v1[m][R] * (rs * w[R]); }); });
+    }
+    if constexpr (L >= 2) {
+        float v = 0.0f;
+        static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { v += emb.v2[m][R] * emb.v2[m][R]; }); });
+        v += xor32(v);
+        const float rs = 1.0f / sqrtf(v * (1.0f / (5 * 16)) + 1e-5f);
+        const f32x16 w = ldrows(wv, P.o_ln_w[2], 0);
+        static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { nrm.v2[m][R] = emb.v2[m][R] * (rs * w[R]); }); });
+    }
+
+    // ---- FFN: FCTP+SwishGate (D -> 336x0e+96x1e+48x2e) -> Gate -> FCTP (-> D), + residual (gnn_block.py:51-57, 210-216) ----
+    Feat<L> fld;
+    {   // l = 0: 6 scalar tiles stream through SiLU straight into fctp_2's K-steps
+        f32x16 o0[2];
+        static_for<2>([&]<int T>() { o0[T] = ldrows(wv, P.o_b_f2, T); });
+        static_for<6>([&]<int To>() {
+            f32x16 a = ldrows(wv, P.o_b_f1, To);
+            static_for<8>([&]<int g>() {
+                mfma_group(a, lda(wv, P.o_A_f1[0], 8, To, g), feat_b<L, 0, 0, g, 0>(nrm), feat_b<L, 0, 0, g, 1>(nrm),
+                           feat_b<L, 0, 0, g, 2>(nrm), feat_b<L, 0, 0, g, 3>(nrm));
+            });
+            static_for<16>([&]<int R>() { a[R] = silu_n(a[R]); });
+            static_for<2>([&]<int T2>() { static_for<4>([&]<int g>() {
+                mfma_group(o0[T2], lda(wv, P.o_A_f2[0], 24, T2, To * 4 + g), a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+            }); });
+            sched_fence();
+        });
+        static_for<2>([&]<int T>() { static_for<16>([&]<int R>() { fld.s[T][R] = o0[T][R] + emb.s[T][R]; }); });
+    }
+    if constexpr (L >= 1) {   // l = 1: gate rows 192..287 (tiles 6..8); hidden 96x1e
+        f32x16 gt[3];
+        static_for<3>([&]<int t>() {
+            gt[t] = ldrows(wv, P.o_b_f1, 6 + t);
+            static_for<8>([&]<int g>() {
+                mfma_group(gt[t], lda(wv, P.o_A_f1[0], 8, 6 + t, g), feat_b<L, 0, 0, g, 0>(nrm), feat_b<L, 0, 0, g, 1>(nrm),
+                           feat_b<L, 0, 0, g, 2>(nrm), feat_b<L, 0, 0, g, 3>(nrm));
+            });
+            static_for<16>([&]<int R>() { gt[t][R] = sigmoid_n(gt[t][R]); });
+        });
+        sched_fence();
+        static_for<3>([&]<int m>() {
+            f32x16 o = {0};
+            static_for<3>([&]<int t>() {
+                f32x16 hh = {0};
+                static_for<4>([&]<int g>() {
+                    mfma_group(hh, lda(wv, P.o_A_f1[1], 4, t, g), nrm.v1[m][4 * g], nrm.v1[m][4 * g + 1], nrm.v1[m][4 * g + 2], nrm.v1[m][4 * g + 3]);
+                });
+                static_for<16>([&]<int R>() { hh[R] *= gt[t][R]; });
+                static_for<4>([&]<int g>() {
+                    mfma_group(o, lda(wv, P.o_A_f2[1], 12, 0, t * 4 + g), hh[4 * g], hh[4 * g + 1], hh[4 * g + 2], hh[4 * g + 3]);
+                });
+            });
+            static_for<16>([&]<int R>() { fld.v1[m][R] = o[R] + emb.v1[m][R]; });
+            sched_fence();
+        });
+    }
+    if constexpr (L >= 2) {   // l = 2: gate rows 288..335 (tile 9, tile 10 rows 0..15); hidden 48x2e (tile 0 full, tile 1 half)
+        constexpr int GT0 = f1_gate_row(2, 0) / 32;
+        f32x16 gt[2];
+        static_for<2>([&]<int t>() {
+            gt[t] = ldrows(wv, P.o_b_f1, GT0 + t);
+            static_for<8>([&]<int g>() {
+                mfma_group(gt[t], lda(wv, P.o_A_f1[0], 8, GT0 + t, g), feat_b<L, 0, 0, g, 0>(nrm), feat_b<L, 0, 0, g, 1>(nrm),
+                           feat_b<L, 0, 0, g, 2>(nrm), feat_b<L, 0, 0, g, 3>(nrm));
+            });
+            static_for<16>([&]<int R>() { gt[t][R] = sigmoid_n(gt[t][R]); });
+        });
+        sched_fence();
+        static_for<5>([&]<int m>() {
+            f32x16 o = {0};
+            static_for<2>([&]<int t>() {
+                f32x16 hh = {0};
+                static_for<2>([&]<int g>() {
+                    mfma_group(hh, lda(wv, P.o_A_f1[2], 2, t, g), nrm.v2[m][4 * g], nrm.v2[m][4 * g + 1], nrm.v2[m][4 * g + 2], nrm.v2[m][4 * g + 3]);
+                });
+                static_for<16>([&]<int R>() { hh[R] *= gt[t][R]; });
+                static_for<(t == 0 ? 4 : 2)>([&]<int g>() {
+                    mfma_group(o, lda(wv, P.o_A_f2[2], 6, 0, t * 4 + g), hh[4 * g], hh[4 * g + 1], hh[4 * g + 2], hh[4 * g + 3]);
+                });
+            });
+            static_for<8>([&]<int R>() { fld.v2[m][R] = o[R] + emb.v2[m][R]; });
+            sched_fence();
+        });
+    }
+
+    // ---- score tensor products ------------------------------------------------------------------------------------------------
+    const Buf qfb = make_buf(P.qf, P.qf_bytes);
+    const Buf pb = make_buf(P.pose, P.pose_bytes);
+    float qraw[4], D1[9], D2[25];
+    {
+        const int pv = pose * (kPoseRec * 4);
+        const f32x4 t = bld4(pb, pv, 0);
+        qraw[0] = t[0]; qraw[1] = t[1]; qraw[2] = t[2]; qraw[3] = t[3];
+        static_for<3>([&]<int Q>() {
+            const f32x4 d = bld4(pb, pv, (4 + 4 * Q) * 4);
+            static_for<4>([&]<int J>() { if constexpr (4 * Q + J < 9) D1[4 * Q + J] = d[J]; });
+        });
+        if constexpr (L >= 2) static_for<7>([&]<int Q>() {
+            const f32x4 d = bld4(pb, pv, (16 + 4 * Q) * 4);
+            static_for<4>([&]<int J>() { if constexpr (4 * Q + J < 25) D2[4 * Q + J] = d[J]; });
+        });
+    }
+    const int qv0 = q * (D * 4) + hi * 16, qv1 = q * (D * 4) + hi * 48, qv2 = q * (D * 4) + hi * 80;
+    float res[2][3];                         // per TP: mean over the 32 gated 1e channels
+    static_for<2>([&]<int tp>() {
+        f32x16 gacc = ldrows(wv, P.o_b_sl[tp], 0);
+        f32x16 vacc[3];
+        static_for<3>([&]<int K>() { static_for<16>([&]<int R>() { vacc[K][R] = 0.0f; }); });
+        static_for<stp_num_paths<L>()>([&]<int p>() {
+            constexpr PathInfo pi = stp_path<L>(p);
+            constexpr int l1 = pi.l1, l2 = pi.l2, l3 = pi.l3;
+            constexpr int d1 = 2 * l1 + 1, d2 = 2 * l2 + 1, d3 = 2 * l3 + 1;
+            constexpr int NGK = pi.mul2 / 8;              // K groups over v
+            using C = CG<l1, l2, l3>;
+            static_for<cdiv(pi.mul1, 32)>([&]<int To>() {
+                f32x16 T[d2];
+                static_for<d2>([&]<int j>() {
+                    static_for<16>([&]<int R>() { T[j][R] = 0.0f; });
+                    static_for<NGK>([&]<int g>() {
+                        mfma_group(T[j], lda(wv, P.o_A_s[tp][p], NGK, To, g), feat_b<L, l2, j, g, 0>(fld), feat_b<L, l2, j, g, 1>(fld),
+                                   feat_b<L, l2, j, g, 2>(fld), feat_b<L, l2, j, g, 3>(fld));
+                    });
+                });
+                static_for<imin(4, (pi.mul1 - 32 * To) / 8)>([&]<int g>() {
+                    constexpr int u0 = 32 * To + 8 * g;
+                    constexpr int gi = stp_group_index<L>(p, u0 / 8);
+                    // query feature rows u0 + 4 hi + j (reference layout), rotated by D^{l1}(q)
+                    float xr[4 * d1];
+                    const int qv = l1 == 0 ? qv0 : (l1 == 1 ? qv1 : qv2);
+                    static_for<d1>([&]<int Q>() {
+                        const f32x4 t = bld4(qfb, qv, (blk_off(l1) + u0 * d1 + 4 * Q) * 4);
+                        xr[4 * Q] = t[0]; xr[4 * Q + 1] = t[1]; xr[4 * Q + 2] = t[2]; xr[4 * Q + 3] = t[3];
+                    });
+                    float a[4][d3];
+                    static_for<4>([&]<int j>() {
+                        float x[d1], y[d2], m[C::NM], o[d3];
+                        if constexpr (l1 == 0) x[0] = xr[j];
+                        else if constexpr (l1 == 1) static_for<3>([&]<int I>() {
+                            x[I] = D1[3 * I] * xr[3 * j] + D1[3 * I + 1] * xr[3 * j + 1] + D1[3 * I + 2] * xr[3 * j + 2]; });
+                        else static_for<5>([&]<int I>() {
+                            x[I] = D2[5 * I] * xr[5 * j] + D2[5 * I + 1] * xr[5 * j + 1] + D2[5 * I + 2] * xr[5 * j + 2] +
+                                   D2[5 * I + 3] * xr[5 * j + 3] + D2[5 * I + 4] * xr[5 * j + 4]; });
+                        static_for<d2>([&]<int J>() { y[J] = T[J][4 * g + j]; });
+                        C::make(y, m);
+                        C::apply(x, m, o);
+                        static_for<d3>([&]<int K>() { a[j][K] = o[K]; });
+                    });
+                    constexpr int NG = stp_k<L>(l3) / 8;
+                    if constexpr (l3 == 0) {
+                        mfma_group(gacc, lda(wv, P.o_A_sl[tp][0], NG, 0, gi), a[0][0], a[1][0], a[2][0], a[3][0]);
+                    } else {
+                        const f32x4 av = lda(wv, P.o_A_sl[tp][1], NG, 0, gi);
+                        static_for<3>([&]<int K>() { mfma_group(vacc[K], av, a[0][K], a[1][K], a[2][K], a[3][K]); });
+                    }
+                });
+                sched_fence();
+            });
+        });
+        // Gate (sigmoid on the 32 gates) and mean over the 32 1e channels (score_head.py:196-199)
+        static_for<3>([&]<int K>() {
+            float s = 0.0f;
+            static_for<16>([&]<int R>() { s += vacc[K][R] * sigmoid_n(gacc[R]); });
+            s += xor32(s);
+            res[tp][K] = s * (1.0f / 32);
+        });
+    });
+
+    // ---- back to the body frame, orbital term, query weight (score_head.py:201-209) ------------------------------------------
+    if (valid && hi == 0) {
+        auto qmul = [](const float (&a)[4], const float (&b)[4], float (&o)[4]) {     // transforms.py:113-129
+            o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+            o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+            o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+            o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+        };
+        const float qi[4] = {qraw[0], -qraw[1], -qraw[2], -qraw[3]};
+        const float qc[4] = {qraw[0], qraw[1], qraw[2], qraw[3]};          // invert(qinv)
+        float rot[2][3];
+        static_for<2>([&]<int tp>() {
+            const float pq[4] = {0.0f, res[tp][0], res[tp][1], res[tp][2]};
+            float t1[4], t2[4];
+            qmul(qi, pq, t1);
+            qmul(t1, qc, t2);
+            rot[tp][0] = t2[1]; rot[tp][1] = t2[2]; rot[tp][2] = t2[3];
+        });
+        const float x0 = P.qx[3 * q] / P.lin_mult, x1 = P.qx[3 * q + 1] / P.lin_mult, x2 = P.qx[3 * q + 2] / P.lin_mult;
+        const float w = P.qw[q];
+        const float o0 = x1 * rot[0][2] - x2 * rot[0][1];
+        const float o1 = x2 * rot[0][0] - x0 * rot[0][2];
+        const float o2 = x0 * rot[0][1] - x1 * rot[0][0];
+        float* out = P.node_out + (size_t)n * 8;
+        st4(out, f32x4{w * rot[0][0], w * rot[0][1], w * rot[0][2], w * o0 + w * rot[1][0]});
+        st4(out + 4, f32x4{w * o1 + w * rot[1][1], w * o2 + w * rot[1][2], 0.0f, 0.0f});
+    }
+}
+
+}  // namespace dedf

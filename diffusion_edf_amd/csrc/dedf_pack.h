@@ -1,0 +1,253 @@
+// Host side: canonical parameter schema (mirror of diffusion_edf_amd/params.py::param_spec, i.e. the reference
+// state_dict below `score_head.`) and the packers that turn e3nn-layout weights into the lane-ordered A operands the
+// kernels consume (dedf_layout.h / dedf_net.h).
+#pragma once
+#include <cmath>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/dedf.h"
+#include "dedf_net.h"
+
+namespace dedf {
+
+struct ParamEntry { std::string name; size_t numel; size_t offset; };
+
+struct ParamSpec {
+    std::vector<ParamEntry> entries;
+    std::map<std::string, size_t> index;
+    size_t total = 0;
+    void add(const std::string& n, size_t numel) {
+        index[n] = entries.size();
+        entries.push_back({n, numel, total});
+        total += numel;
+    }
+    const float* get(const float* blob, const std::string& n) const {
+        auto it = index.find(n);
+        if (it == index.end()) throw std::runtime_error("missing parameter " + n);
+        return blob + entries[it->second].offset;
+    }
+};
+
+template <int L>
+inline ParamSpec build_spec(const dedf_config& c) {
+    ParamSpec S;
+    const int* te = c.time_emb_mlp;
+    for (int n = 0; n < c.n_scales; ++n) {
+        const std::string p = "time_mlps_multiscale." + std::to_string(n) + ".";
+        S.add(p + "0.weight", (size_t)te[1] * te[0]); S.add(p + "0.bias", te[1]);
+        S.add(p + "2.weight", (size_t)te[2] * te[1]); S.add(p + "2.bias", te[2]);
+    }
+    const std::string ktf = "key_tensor_field";
+    const int F0 = c.fc_neurons[0], dimL = c.length_emb_dim;
+    for (int n = 0; n < c.n_scales; ++n) {
+        if (c.radii[n] > 0) {
+            const std::string pm = ktf + ".graph_parsers." + std::to_string(n) + ".length_enc.param_module.";
+            S.add(pm + "std_logit", dimL); S.add(pm + "weight_logit", dimL); S.add(pm + "mean", dimL);
+        }
+        const std::string pl = ktf + ".edge_scalars_pre_linears." + std::to_string(n) + ".0.";
+        S.add(pl + "weight", (size_t)F0 * F0); S.add(pl + "bias", F0);
+    }
+    const std::string blk = ktf + ".gnn_block_init";
+    size_t sq = 0;
+    for (int l = 0; l <= L; ++l) sq += (size_t)mul_of(l) * mul_of(l);
+    S.add(blk + ".prenorm_src.affine_weight", sum_mul<L>()); S.add(blk + ".prenorm_src.affine_bias", mul_of(0));
+    S.add(blk + ".linear_src.tp.weight", sq); S.add(blk + ".linear_src.bias.0", mul_of(0));
+    const std::string ga = blk + ".ga";
+    const int ch[4] = {c.fc_neurons[0], c.fc_neurons[1], c.fc_neurons[2], dtp_wn<L>()};
+    const std::string rad = ga + ".sep_act.dtp_rad.";
+    S.add(rad + "net.0.weight", (size_t)ch[1] * ch[0]); S.add(rad + "net.0.bias", ch[1]);
+    S.add(rad + "net.1.weight", ch[1]); S.add(rad + "net.1.bias", ch[1]);
+    S.add(rad + "net.3.weight", (size_t)ch[2] * ch[1]); S.add(rad + "net.3.bias", ch[2]);
+    S.add(rad + "net.4.weight", ch[2]); S.add(rad + "net.4.bias", ch[2]);
+    S.add(rad + "net.6.weight", (size_t)ch[3] * ch[2]);
+    S.add(rad + "offset", ch[3]);
+    size_t lin_n = 0, val_n = 0;
+    for (int l = 0; l <= L; ++l) {
+        lin_n += (size_t)dtp_k<L>(l) * (l == 0 ? lin0_rows<L>() : mul_of(l));
+        val_n += (size_t)dtp_k<L>(l) * mul_of(l);
+    }
+    S.add(ga + ".sep_act.lin.tp.weight", lin_n); S.add(ga + ".sep_act.lin.bias.0", lin0_rows<L>());
+    S.add(ga + ".sep_alpha.tp.weight", (size_t)dtp_k<L>(0) * mul_of(0)); S.add(ga + ".sep_alpha.bias.0", mul_of(0));
+    S.add(ga + ".sep_value.dtp.tp.weight", dtp_wn<L>());
+    S.add(ga + ".sep_value.lin.tp.weight", val_n); S.add(ga + ".sep_value.lin.bias.0", mul_of(0));
+    S.add(ga + ".alpha_dot", mul_of(0));
+    S.add(ga + ".proj.tp.weight", sq); S.add(ga + ".proj.bias.0", mul_of(0));
+    S.add(blk + ".post_norm.affine_weight", sum_mul<L>()); S.add(blk + ".post_norm.affine_bias", mul_of(0));
+    size_t f1 = 0, f2 = 0;
+    for (int l = 0; l <= L; ++l) {
+        f1 += (size_t)mul_of(l) * (l == 0 ? f1_rows0<L>() : kMlpMid * mul_of(l));
+        f2 += (size_t)kMlpMid * mul_of(l) * mul_of(l);
+    }
+    S.add(blk + ".ffn.fctp_1.tp.weight", f1); S.add(blk + ".ffn.fctp_1.bias.0", f1_rows0<L>());
+    S.add(blk + ".ffn.fctp_2.tp.weight", f2); S.add(blk + ".ffn.fctp_2.bias.0", mul_of(0));
+    for (const char* nm : {"lin_vel_tp", "ang_vel_tp"}) {
+        const std::string p = std::string(nm);
+        S.add(p + ".dtp.tp.weight", stp_wn<L>());
+        S.add(p + ".lin.tp.weight", (size_t)stp_k<L>(0) * (1 + mul_of(1)) + (size_t)stp_k<L>(1) * mul_of(1));
+        S.add(p + ".lin.bias.0", 1 + mul_of(1));
+    }
+    return S;
+}
+
+// ---- growing image of packed weights: every block is 16-byte aligned, offsets are in floats --------------------------------
+struct Image {
+    std::vector<float> data;
+    int push(const std::vector<float>& v) {
+        while (data.size() % 4) data.push_back(0.0f);
+        const int off = (int)data.size();
+        data.insert(data.end(), v.begin(), v.end());
+        return off;
+    }
+};
+
+struct EdgeOffsets {
+    int o_enc, o_A_pre, o_A_r1, o_b_r1, o_g_r1, o_be_r1, o_A_r2, o_b_r2, o_g_r2, o_be_r2, o_A_r3, o_off_r3;
+    int o_A_lin[4], o_b_r0, o_A_val[4], o_b_val0, o_alpha_dot;
+};
+struct NodeOffsets {
+    int o_A_proj[4], o_b_proj0, o_ln_w[4], o_ln_b0, o_A_f1[4], o_b_f1, o_A_f2[4], o_b_f2;
+    int o_A_s[2][16], o_A_sl[2][2], o_b_sl[2];
+};
+
+inline float softplusf(float x) { return x > 20.0f ? x : std::log1p(std::exp(x)); }
+
+template <int L>
+inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, Image& im, EdgeOffsets& o) {
+    const std::string ktf = "key_tensor_field", blk = ktf + ".gnn_block_init", ga = blk + ".ga", rad = ga + ".sep_act.dtp_rad.";
+    // length encoders (reference radial_func.py:168-227, 291-316)
+    {
+        std::vector<float> enc((size_t)c.n_scales * 192, 0.0f);
+        for (int n = 0; n < c.n_scales; ++n) {
+            float* e = enc.data() + (size_t)n * 192;
+            if (c.radii[n] > 0) {
+                const std::string pm = ktf + ".graph_parsers." + std::to_string(n) + ".length_enc.param_module.";
+                const float *sl = S.get(B, pm + "std_logit"), *wl = S.get(B, pm + "weight_logit"), *mu = S.get(B, pm + "mean");
+                for (int k = 0; k < 64; ++k) {
+                    const int hi = k / 32, s = k % 32;
+                    const float sd = softplusf(sl[k]) + 1e-5f;
+                    e[0 + hi * 32 + s] = mu[k] + 0.0f;
+                    e[64 + hi * 32 + s] = 1.0f / sd;
+                    e[128 + hi * 32 + s] = (1.0f / (1.0f + std::exp(-wl[k]))) * (4.0f * std::sqrt((float)c.length_emb_dim));
+                }
+            } else {
+                const double step = std::log(1000.0) / (32 - 1);
+                for (int k = 0; k < 32; ++k) e[k] = std::exp((float)k * (float)(-step));
+            }
+        }
+        o.o_enc = im.push(enc);
+    }
+    {   // pre-linear: length-embedding half of the weight (multiscale_tensor_field.py:141-146)
+        std::vector<KStep> st;
+        for (int s = 0; s < 32; ++s) st.push_back({s, s + 32});
+        std::vector<float> all;
+        for (int n = 0; n < c.n_scales; ++n) {
+            const float* W = S.get(B, ktf + ".edge_scalars_pre_linears." + std::to_string(n) + ".0.weight");
+            auto a = pack_A(128, st, [&](int oo, int k) { return W[oo * 128 + k]; });
+            all.insert(all.end(), a.begin(), a.end());
+        }
+        o.o_A_pre = im.push(all);
+    }
+    auto rows = [&](int O, const float* v) { return pack_rows(O, [&](int i) { return v[i]; }); };
+    {
+        const float* W = S.get(B, rad + "net.0.weight");
+        o.o_A_r1 = im.push(pack_A(128, chain_steps(128), [&](int oo, int k) { return W[oo * 128 + k]; }));
+        o.o_b_r1 = im.push(rows(128, S.get(B, rad + "net.0.bias")));
+        o.o_g_r1 = im.push(rows(128, S.get(B, rad + "net.1.weight")));
+        o.o_be_r1 = im.push(rows(128, S.get(B, rad + "net.1.bias")));
+        const float* W2 = S.get(B, rad + "net.3.weight");
+        o.o_A_r2 = im.push(pack_A(64, chain_steps(128), [&](int oo, int k) { return W2[oo * 128 + k]; }));
+        o.o_b_r2 = im.push(rows(64, S.get(B, rad + "net.3.bias")));
+        o.o_g_r2 = im.push(rows(64, S.get(B, rad + "net.4.weight")));
+        o.o_be_r2 = im.push(rows(64, S.get(B, rad + "net.4.bias")));
+        const float* W3 = S.get(B, rad + "net.6.weight");
+        o.o_A_r3 = im.push(pack_A(dtp_wn<L>(), chain_steps(64), [&](int oo, int k) { return W3[oo * 64 + k]; }));
+        o.o_off_r3 = im.push(rows(dtp_wn<L>(), S.get(B, rad + "offset")));
+    }
+    {   // sep_act.lin (+ sep_alpha on the l3 = 0 K-steps) and sep_value.lin (shared DTP weights folded in)
+        const float* lw = S.get(B, ga + ".sep_act.lin.tp.weight");
+        const float* aw = S.get(B, ga + ".sep_alpha.tp.weight");
+        const float* vw = S.get(B, ga + ".sep_value.lin.tp.weight");
+        const float* w2 = S.get(B, ga + ".sep_value.dtp.tp.weight");
+        // flat DTP weight index of sorted channel k of block l
+        auto wflat = [&](int l, int k) {
+            for (int p = 0; p < dtp_num_paths<L>(); ++p) {
+                const PathInfo pi = dtp_path<L>(p);
+                if (pi.l3 == l && k >= pi.kofs && k < pi.kofs + pi.mul1) return pi.wstart + (k - pi.kofs);
+            }
+            return -1;
+        };
+        size_t lo = 0, vo = 0;
+        for (int l = 0; l <= L; ++l) {
+            const int K = dtp_k<L>(l), Ol = (l == 0 ? lin0_rows<L>() : mul_of(l));
+            const float* Wl = lw + lo;
+            const float* Vl = vw + vo;
+            if (l == 0) {
+                const int a0 = alpha_row0<L>();
+                o.o_A_lin[0] = im.push(pack_A(a0 + mul_of(0), dtp_steps<L>(0), [&](int oo, int k) {
+                    if (oo < Ol) return Wl[k * Ol + oo];
+                    if (oo >= a0) return aw[k * mul_of(0) + (oo - a0)];
+                    return 0.0f;
+                }));
+                const float* lb = S.get(B, ga + ".sep_act.lin.bias.0");
+                const float* ab = S.get(B, ga + ".sep_alpha.bias.0");
+                o.o_b_r0 = im.push(pack_rows(a0 + mul_of(0), [&](int i) { return i < Ol ? lb[i] : (i >= a0 ? ab[i - a0] : 0.0f); }));
+            } else {
+                o.o_A_lin[l] = im.push(pack_A(Ol, dtp_steps<L>(l), [&](int oo, int k) { return Wl[k * Ol + oo]; }));
+            }
+            o.o_A_val[l] = im.push(pack_A(mul_of(l), dtp_steps<L>(l), [&](int oo, int k) { return Vl[k * mul_of(l) + oo] * w2[wflat(l, k)]; }));
+            lo += (size_t)K * Ol;
+            vo += (size_t)K * mul_of(l);
+        }
+        o.o_b_val0 = im.push(rows(mul_of(0), S.get(B, ga + ".sep_value.lin.bias.0")));
+        o.o_alpha_dot = im.push(rows(mul_of(0), S.get(B, ga + ".alpha_dot")));
+    }
+}
+
+template <int L>
+inline void pack_node(const dedf_config&, const ParamSpec& S, const float* B, Image& im, NodeOffsets& o) {
+    const std::string blk = "key_tensor_field.gnn_block_init", ga = blk + ".ga";
+    auto rows = [&](int O, const float* v) { return pack_rows(O, [&](int i) { return v[i]; }); };
+    const float* pw = S.get(B, ga + ".proj.tp.weight");
+    const float* lnw = S.get(B, blk + ".post_norm.affine_weight");
+    const float* f1w = S.get(B, blk + ".ffn.fctp_1.tp.weight");
+    const float* f2w = S.get(B, blk + ".ffn.fctp_2.tp.weight");
+    size_t po = 0, lo = 0, f1o = 0, f2o = 0;
+    for (int l = 0; l <= L; ++l) {
+        const int m = mul_of(l), O1 = (l == 0 ? f1_rows0<L>() : kMlpMid * m), Kh = kMlpMid * m;
+        const float* Wp = pw + po;
+        o.o_A_proj[l] = im.push(pack_A(m, chain_steps(m), [&](int oo, int k) { return Wp[k * m + oo]; }));
+        o.o_ln_w[l] = im.push(pack_rows(m, [&](int i) { return lnw[lo + i]; }));
+        const float* W1 = f1w + f1o;
+        o.o_A_f1[l] = im.push(pack_A(O1, chain_steps(m), [&](int oo, int k) { return W1[k * O1 + oo]; }));
+        const float* W2 = f2w + f2o;
+        o.o_A_f2[l] = im.push(pack_A(m, chain_steps(Kh), [&](int oo, int k) { return W2[k * m + oo]; }));
+        po += (size_t)m * m; lo += m; f1o += (size_t)m * O1; f2o += (size_t)Kh * m;
+    }
+    o.o_b_proj0 = im.push(rows(mul_of(0), S.get(B, ga + ".proj.bias.0")));
+    o.o_ln_b0 = im.push(rows(mul_of(0), S.get(B, blk + ".post_norm.affine_bias")));
+    o.o_b_f1 = im.push(rows(f1_rows0<L>(), S.get(B, blk + ".ffn.fctp_1.bias.0")));
+    o.o_b_f2 = im.push(rows(mul_of(0), S.get(B, blk + ".ffn.fctp_2.bias.0")));
+    int tp = 0;
+    for (const char* nm : {"lin_vel_tp", "ang_vel_tp"}) {
+        const std::string p = std::string(nm);
+        const float* dw = S.get(B, p + ".dtp.tp.weight");
+        for (int q = 0; q < stp_num_paths<L>(); ++q) {
+            const PathInfo pi = stp_path<L>(q);
+            const float* W = dw + pi.wstart;
+            o.o_A_s[tp][q] = im.push(pack_A(pi.mul1, chain_steps(pi.mul2), [&](int u, int v) { return W[u * pi.mul2 + v]; }));
+        }
+        const float* lw = S.get(B, p + ".lin.tp.weight");
+        const int n1 = mul_of(1), O0 = 1 + n1;
+        const float* W0 = lw;
+        const float* W1 = lw + (size_t)stp_k<L>(0) * O0;
+        o.o_A_sl[tp][0] = im.push(pack_A(n1, stp_steps<L>(0), [&](int oo, int k) { return W0[k * O0 + 1 + oo]; }));   // row 0 (the unused 1x0e) is dropped
+        o.o_A_sl[tp][1] = im.push(pack_A(n1, stp_steps<L>(1), [&](int oo, int k) { return W1[k * n1 + oo]; }));
+        const float* lb = S.get(B, p + ".lin.bias.0");
+        o.o_b_sl[tp] = im.push(pack_rows(n1, [&](int i) { return lb[1 + i]; }));
+        ++tp;
+    }
+}
+
+}  // namespace dedf

@@ -1,0 +1,206 @@
+"""``ScoreModelHead`` — drop-in for reference ``diffusion_edf/score_head.py:18-252`` on MI355X.
+
+Same constructor keywords (the ``score_head_kwargs`` block of the reference YAML configs), same parameter names
+(``state_dict`` keys equal the reference's below ``score_head.``), same ``forward(Ts, key_pcd_multiscale, query_pcd,
+time) -> (ang_vel, lin_vel)`` contract, ``warmup``, ``lin_mult`` / ``ang_mult`` / ``n_scales`` attributes and
+``jittable = False`` so that reference ``agent.py:53-55`` skips TorchScript.  The arithmetic runs in libdedf.so
+(hand-written HIP for gfx950); there is no PyTorch/CPU fallback — construction fails loudly without the library/GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import _lib
+from .gnn_data import FeaturedPoints
+from .params import HeadConfig, init_params, param_spec
+
+
+class _Node(torch.nn.Module):
+    """anonymous container so that parameter names follow the reference module tree"""
+
+
+def _register(root: torch.nn.Module, dotted: str, value: torch.Tensor):
+    parts = dotted.split('.')
+    mod = root
+    for p in parts[:-1]:
+        if not hasattr(mod, p):
+            mod.add_module(p, _Node())
+        mod = getattr(mod, p)
+    mod.register_parameter(parts[-1], torch.nn.Parameter(value, requires_grad=False))
+
+
+class ScoreModelHead(torch.nn.Module):
+    jittable: bool = False
+
+    def __init__(self,
+                 max_time: float,
+                 time_emb_mlp: List[int],
+                 key_tensor_field_kwargs: Dict,
+                 irreps_query_edf,
+                 lin_mult: float,
+                 ang_mult: float,
+                 time_enc_n: float = 10000.,
+                 edge_time_encoding: bool = False,
+                 query_time_encoding: bool = True,
+                 device: Union[str, torch.device, None] = None,
+                 init_seed: int = 2,
+                 max_edges: int = 0):
+        super().__init__()
+        kw = dict(max_time=max_time, time_emb_mlp=list(time_emb_mlp), key_tensor_field_kwargs=dict(key_tensor_field_kwargs),
+                  irreps_query_edf=irreps_query_edf, lin_mult=lin_mult, ang_mult=ang_mult, time_enc_n=time_enc_n,
+                  edge_time_encoding=edge_time_encoding, query_time_encoding=query_time_encoding)
+        if not edge_time_encoding and not query_time_encoding:
+            raise NotImplementedError("No time encoding! Are you sure?")          # reference score_head.py:72-73
+        self.cfg = HeadConfig.from_kwargs(kw)
+        self.lin_mult, self.ang_mult = float(lin_mult), float(ang_mult)
+        self.n_scales = self.cfg.n_scales
+        self.max_time = float(max_time)
+        self.time_emb_mlp = list(time_emb_mlp)
+        self.key_edf_dim = self.query_edf_dim = self.cfg.dim
+        self.n_irreps_prescore = self.cfg.muls[1]
+        self.edge_time_encoding, self.query_time_encoding = edge_time_encoding, query_time_encoding
+        self.irreps_key_edf = '+'.join(f"{m}x{l}e" for m, l in self.cfg.irreps)
+        self._max_edges = int(max_edges)
+        for name, t in init_params(self.cfg, seed=init_seed).items():
+            _register(self, name, t)
+        self._handle = None
+        self._handle_device: Optional[torch.device] = None
+        self._scene_key = None
+        self._query_key = None
+        if device is not None:
+            self.to(device)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _state(self) -> Dict[str, torch.Tensor]:
+        return {k: v for k, v in self.state_dict().items()}
+
+    def _ensure_handle(self, device: torch.device):
+        if self._handle is not None and self._handle_device == device:
+            return
+        self._release()
+        if device.type != 'cuda':
+            raise RuntimeError("diffusion_edf_amd.ScoreModelHead runs on an MI355X (torch device 'cuda') only; "
+                               "there is no CPU path (the CPU restatement lives under oracle/ and is test infrastructure).")
+        lib = _lib.load()
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        ccfg = _lib.make_config(self.cfg, idx, self._max_edges)
+        blob = _lib.pack_params(ccfg, self._state())
+        h = C.c_void_p()
+        rc = lib.dedf_create(C.byref(ccfg), blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, C.byref(h))
+        if rc != _lib.OK:
+            _lib.raise_for(lib, None, rc, "dedf_create failed (see stderr)")
+        self._handle, self._handle_device = h, device
+        self._scene_key = self._query_key = None
+
+    def _release(self):
+        if self._handle is not None:
+            _lib.load().dedf_destroy(self._handle)
+            self._handle = None
+
+    def refresh_weights(self):
+        """call after load_state_dict(): the packed device image is rebuilt on next use"""
+        self._release()
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.refresh_weights()
+        return r
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _stream() -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def set_key_clouds(self, key_pcd_multiscale: Sequence[FeaturedPoints]):
+        assert len(key_pcd_multiscale) == self.n_scales
+        dev = key_pcd_multiscale[0].x.device
+        self._ensure_handle(dev)
+        lib = _lib.load()
+        xs = [p.x.detach().to(torch.float32).contiguous() for p in key_pcd_multiscale]
+        fs = [p.f.detach().to(torch.float32).contiguous() for p in key_pcd_multiscale]
+        for x, f in zip(xs, fs):
+            assert x.ndim == 2 and x.shape[-1] == 3, f"{x.shape}"
+            assert f.ndim == 2 and f.shape[-1] == self.key_edf_dim and len(f) == len(x), f"{f.shape}"
+        n = len(xs)
+        npts = (C.c_int * n)(*[len(x) for x in xs])
+        xp = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+        fp = (C.c_void_p * n)(*[f.data_ptr() for f in fs])
+        rc = lib.dedf_set_key_clouds(self._handle, n, npts, xp, fp, self._stream())
+        _lib.raise_for(lib, self._handle, rc, "dedf_set_key_clouds")
+        self._scene_key = tuple((p.x.data_ptr(), p.f.data_ptr(), p.x._version, p.f._version, len(p.x)) for p in key_pcd_multiscale)
+
+    def set_query(self, query_pcd: FeaturedPoints):
+        dev = query_pcd.x.device
+        self._ensure_handle(dev)
+        lib = _lib.load()
+        assert query_pcd.f.ndim == 2 and query_pcd.f.shape[-1] == self.query_edf_dim, f"{query_pcd.f.shape}"
+        w = query_pcd.w
+        assert isinstance(w, torch.Tensor)
+        x = query_pcd.x.detach().to(torch.float32).contiguous()
+        f = query_pcd.f.detach().to(torch.float32).contiguous()
+        w = w.detach().to(torch.float32).contiguous()
+        rc = lib.dedf_set_query(self._handle, len(x), x.data_ptr(), f.data_ptr(), w.data_ptr(), self._stream())
+        _lib.raise_for(lib, self._handle, rc, "dedf_set_query")
+        self._query_key = (query_pcd.x.data_ptr(), query_pcd.f.data_ptr(), query_pcd.w.data_ptr(), query_pcd.x._version,
+                           query_pcd.f._version, query_pcd.w._version, len(x))
+
+    def _sync_inputs(self, key_pcd_multiscale, query_pcd):
+        sk = tuple((p.x.data_ptr(), p.f.data_ptr(), p.x._version, p.f._version, len(p.x)) for p in key_pcd_multiscale)
+        if self._handle is None or sk != self._scene_key:
+            self.set_key_clouds(key_pcd_multiscale)
+        qk = (query_pcd.x.data_ptr(), query_pcd.f.data_ptr(), query_pcd.w.data_ptr(), query_pcd.x._version,
+              query_pcd.f._version, query_pcd.w._version, len(query_pcd.x))
+        if qk != self._query_key:
+            self.set_query(query_pcd)
+
+    @torch.no_grad()
+    def forward(self, Ts: torch.Tensor, key_pcd_multiscale: List[FeaturedPoints], query_pcd: FeaturedPoints,
+                time: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        assert Ts.ndim == 2 and Ts.shape[-1] == 7, f"{Ts.shape}"                      # reference score_head.py:149
+        assert time.ndim == 1 and len(time) == len(Ts), f"{time.shape}"               # :150
+        assert query_pcd.f.ndim == 2 and query_pcd.f.shape[-1] == self.query_edf_dim, f"{query_pcd.f.shape}"   # :151
+        self._sync_inputs(key_pcd_multiscale, query_pcd)
+        lib = _lib.load()
+        nT = len(Ts)
+        Ts32 = Ts.detach().to(torch.float32).contiguous()
+        t32 = time.detach().to(torch.float32).contiguous()
+        ang = torch.empty(nT, 3, device=Ts.device, dtype=torch.float32)
+        lin = torch.empty(nT, 3, device=Ts.device, dtype=torch.float32)
+        rc = lib.dedf_score(self._handle, nT, Ts32.data_ptr(), t32.data_ptr(), ang.data_ptr(), lin.data_ptr(), self._stream())
+        _lib.raise_for(lib, self._handle, rc, "dedf_score")
+        return ang.to(Ts.dtype), lin.to(Ts.dtype)
+
+    def warmup(self, Ts, key_pcd_multiscale, query_pcd, time):                         # reference score_head.py:213-218
+        return self.forward(Ts=Ts, key_pcd_multiscale=key_pcd_multiscale, query_pcd=query_pcd, time=time)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def stats(self) -> dict:
+        lib = _lib.load()
+        st = _lib.DedfStats()
+        rc = lib.dedf_get_stats(self._handle, C.byref(st))
+        _lib.raise_for(lib, self._handle, rc, "dedf_get_stats")
+        return dict(n_dst=st.n_dst, n_edges=[st.n_edges[i] for i in range(self.n_scales)], n_edges_total=st.n_edges_total,
+                    overflow=bool(st.overflow))
+
+    def debug_enable(self, on: bool = True):
+        _lib.load().dedf_debug_enable(self._handle, int(on))
+
+    def debug_buffer(self, name: str, dtype=torch.float32) -> torch.Tensor:
+        lib = _lib.load()
+        n = C.c_size_t(0)
+        rc = lib.dedf_debug_copy(self._handle, name.encode(), None, 0, C.byref(n))
+        _lib.raise_for(lib, self._handle, rc, "dedf_debug_copy")
+        out = torch.empty(n.value // 4, dtype=torch.float32 if dtype == torch.float32 else torch.int32)
+        if n.value:
+            rc = lib.dedf_debug_copy(self._handle, name.encode(), out.data_ptr(), n.value, C.byref(n))
+            _lib.raise_for(lib, self._handle, rc, "dedf_debug_copy")
+        return out

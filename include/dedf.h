@@ -1,0 +1,120 @@
+/*
+ * dedf.h — C ABI of the MI355X-native Diffusion-EDF score-head hot path (libdedf.so, gfx950).
+ *
+ * The reference (tomato1mule/diffusion_edf) is pure Python: it has no FFI/operator registry, and the boundary
+ * of this path is the torch.nn.Module contract of ScoreModelHead / ScoreModelBase.  Each entry point below
+ * replaces one piece of that contract (file:line under /root/reference) so that a maintainer can bind it with
+ * ctypes (diffusion_edf_amd/_lib.py is that binding):
+ *
+ *   dedf_create          ScoreModelHead.__init__                 diffusion_edf/score_head.py:32-140
+ *                        (+ MultiscaleTensorField.__init__       diffusion_edf/multiscale_tensor_field.py:22-190,
+ *                           EquiformerBlock.__init__             diffusion_edf/gnn_block.py:71-162,
+ *                           GraphAttentionMLP2.__init__          diffusion_edf/graph_attention.py:139-214)
+ *   dedf_set_key_clouds  the `key_pcd_multiscale` argument        score_head.py:143; also hoists the pose-independent
+ *                        prenorm_src + linear_src                 gnn_block.py:170-171
+ *   dedf_set_query       the `query_pcd` argument                 score_head.py:144,151-157
+ *   dedf_score           ScoreModelHead.forward                   score_head.py:142-211
+ *   dedf_sample          ScoreModelBase.sample (inner loop)       score_model_base.py:110-204
+ *   dedf_destroy         module deletion
+ *
+ * Conventions: all tensor arguments are DEVICE pointers owned by the caller (the library never frees or mutates
+ * inputs); row-major; poses are (nT,7) = [qw,qx,qy,qz,x,y,z] in centimetres (reference README.md:77-82); features
+ * are (N, sum_l mul_l (2l+1)) with irreps blocks 0e|1e|2e, mul-major, m fastest (reference layer_norm.py:111).
+ * Every call enqueues work on `stream` (a hipStream_t; NULL = default stream) and returns without synchronising,
+ * except where stated.  A handle is not thread-safe; use one handle per (device, stream).  Functions return 0 on
+ * success or a DEDF_ERR_* code; dedf_last_error() gives the message.
+ */
+#ifndef DEDF_H
+#define DEDF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEDF_OK 0
+#define DEDF_ERR_INVALID 1      /* bad argument / shape (the reference raises AssertionError / ValueError) */
+#define DEDF_ERR_UNSUPPORTED 2  /* configuration outside the accelerated path */
+#define DEDF_ERR_RUNTIME 3      /* HIP failure, workspace overflow */
+#define DEDF_MAX_SCALES 8
+
+typedef struct dedf_handle dedf_handle;
+
+typedef struct dedf_config {
+    int lmax;                            /* irreps = 64x0e + 32x1e (+ 16x2e); SH 0..lmax.  Supported: 1, 2 */
+    int mul[4];                          /* must equal {64,32,16,8}[0..lmax] (every reference config) */
+    int num_heads;                       /* 4 */
+    int fc_neurons[3];                   /* {128,128,64}: fc_neurons after the -1 is resolved (multiscale_tensor_field.py:63-67) */
+    int length_emb_dim;                  /* 64 */
+    int time_emb_mlp[3];                 /* {256,128,64} */
+    int irreps_mlp_mid;                  /* 3 */
+    int n_scales;                        /* len(r_cluster_multiscale) */
+    float radii[DEDF_MAX_SCALES];        /* r_cluster_multiscale; <= 0 means None (all-pairs scale) */
+    float r_mincut_nonscalar_sh;         /* 0.3 */
+    float length_enc_max_r;              /* 100 */
+    float max_time;                      /* 1 */
+    float time_enc_n;                    /* 10000 */
+    float lin_mult, ang_mult;            /* 15, 2.5 */
+    int max_neighbors;                   /* 1000 (multiscale_tensor_field.py:195) */
+    int device;                          /* HIP device ordinal; -1 = host-only handle (packing tests, no GPU calls) */
+    int64_t max_edges;                   /* edge workspace capacity per call; 0 = auto */
+} dedf_config;
+
+typedef struct dedf_schedule {           /* host arrays, one entry per denoising step (score_model_base.py:146-171) */
+    int n_steps;
+    const double* t;                     /* diffusion time of the step */
+    const double* alpha_ang;             /* ang_mult^2 * t^e_alpha * dt */
+    const double* alpha_lin;             /* lin_mult^2 * t^e_alpha * dt */
+    const double* temperature;           /* T_base * t^e_T */
+} dedf_schedule;
+
+typedef struct dedf_stats {
+    int64_t n_dst;                       /* nT * nQ of the last call */
+    int64_t n_edges[DEDF_MAX_SCALES];    /* edges per scale of the last score evaluation */
+    int64_t n_edges_total;
+    int overflow;                        /* 1 if the edge workspace was too small (results invalid) */
+} dedf_stats;
+
+const char* dedf_version(void);
+
+/* canonical parameter order = order of the flat `params` blob of dedf_create; names are the reference state_dict keys
+ * below `score_head.` (reference trainer.py:141-147) */
+int dedf_param_count(const dedf_config* cfg);
+const char* dedf_param_name(const dedf_config* cfg, int i);
+size_t dedf_param_numel(const dedf_config* cfg, int i);
+
+/* `params`: HOST pointer, concatenation of all tensors in canonical order, n_params floats in total. */
+int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, dedf_handle** out);
+void dedf_destroy(dedf_handle* h);
+const char* dedf_last_error(const dedf_handle* h);
+
+/* x[s]: (n_pts[s],3), f[s]: (n_pts[s],D) device pointers; host arrays of pointers.  Copies the clouds and precomputes
+ * the source message.  Synchronises `stream` before returning. */
+int dedf_set_key_clouds(dedf_handle* h, int n_scales, const int* n_pts, const float* const* x, const float* const* f, void* stream);
+/* x: (nQ,3), f: (nQ,D), w: (nQ,) device pointers (copied). */
+int dedf_set_query(dedf_handle* h, int nQ, const float* x, const float* f, const float* w, void* stream);
+
+/* Ts: (nT,7) f32, time: (nT,) f32 -> ang: (nT,3), lin: (nT,3) f32 ("ang first", score_head.py:211). */
+int dedf_score(dedf_handle* h, int nT, const float* Ts, const float* time, float* ang, float* lin, void* stream);
+
+/* T_seed: (nT,7) f64; noise: NULL (counter-based Philox keyed by (seed, first_pose_index + pose, step)) or
+ * (n_steps,2,nT,3) f64 standard normals [ang, lin]; Ts_out: (n_steps + 2, nT, 7) f64 = [seed, after each step, final again]
+ * (score_model_base.py:199-201).  Synchronises `stream` before returning (overflow check). */
+int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedule* sched, uint64_t seed,
+                int64_t first_pose_index, const double* noise, double* Ts_out, void* stream);
+
+int dedf_get_stats(dedf_handle* h, dedf_stats* out);   /* synchronises the last used stream */
+
+/* Test hooks: copy an internal device buffer of the last dedf_score call to HOST memory.  Names: "msg", "qpos", "pose",
+ * "tb", "edge_src", "edge_dst", "edge_out", "z", "node_out", "tile_info", "dbg_w" (enable with dedf_debug_enable). */
+int dedf_debug_enable(dedf_handle* h, int on);
+int dedf_debug_copy(dedf_handle* h, const char* name, void* host_dst, size_t max_bytes, size_t* actual_bytes);
+/* Packed weight images (host-only handles too): "edge" | "node"; for layout tests. */
+int dedf_debug_packed(dedf_handle* h, const char* which, const float** ptr, size_t* n_floats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEDF_H */
