@@ -1,0 +1,163 @@
+"""Pins the CPU oracle: (i) golden vectors produced by the two importable reference modules (tests/golden/make_golden.py),
+(ii) the invariants the reference is designed around: SE(3) bi-equivariance of the score, softmax
+normalisation, continuity at the cut-offs, and the YXY signed-zero quirk."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from diffusion_edf_amd import params, synthetic
+from oracle import restatement as R
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def gt():
+    return np.load(os.path.join(G, "transforms.npz"))
+
+
+@pytest.fixture(scope="module")
+def gr():
+    return np.load(os.path.join(G, "radial_func.npz"))
+
+
+def T(a, dt=torch.float64):
+    return torch.tensor(a, dtype=dt)
+
+
+def test_transforms_golden(gt):
+    q, p = T(gt["q"]), T(gt["p"])
+    assert torch.equal(R.standardize_quaternion(q), T(gt["standardize"]))
+    assert torch.allclose(R.quaternion_to_matrix(q), T(gt["to_matrix"]), atol=0, rtol=0)
+    assert torch.equal(R.quaternion_apply(q, p), T(gt["apply"]))
+    assert torch.equal(R.quaternion_invert(q), T(gt["invert"]))
+    assert torch.equal(R.quaternion_raw_multiply(q, q.flip(0)), T(gt["raw_multiply"]))
+    e64 = R.matrix_to_euler_yxy(R.quaternion_to_matrix(R.standardize_quaternion(q)))
+    assert torch.equal(e64, T(gt["euler_yxy_f64"]))
+    q32 = q.float()
+    e32 = R.matrix_to_euler_yxy(R.quaternion_to_matrix(R.standardize_quaternion(q32)))
+    assert torch.equal(e32, T(gt["euler_yxy_f32"], torch.float32))
+    # the quirk of SURVEY §0: identity -> (0, 0, pi)
+    assert gt["euler_yxy_f64"][0].tolist() == [0.0, 0.0, np.pi]
+
+
+def test_radial_func_golden(gr):
+    x = T(gr["ssc2_x"], torch.float32)
+    assert torch.equal(R.soft_square_cutoff_2(x, (None, None, 4., 5.)), T(gr["ssc2_right"], torch.float32))
+    assert gr["ssc2_right"].tolist() == [1.0] * 9 + [0.6875, 0.0, 0.0, 0.0]
+    x2 = T(gr["ssc2_x2"], torch.float32)
+    assert torch.equal(R.soft_square_cutoff_2(x2, (0.2 * 0.3, 0.3, None, None)), T(gr["ssc2_left"], torch.float32))
+    x3 = T(gr["ssc2_x3"], torch.float32)
+    assert torch.equal(R.soft_square_cutoff_2(x3, (None, None, 0.8 * 20., 20.)), T(gr["ssc2_r20"], torch.float32))
+    assert torch.equal(R.soft_step(torch.linspace(-0.5, 1.5, 41)), T(gr["soft_step"], torch.float32))
+    d = T(gr["dist"], torch.float32)
+    cfg = params.HeadConfig.from_kwargs(synthetic.score_head_kwargs(2))
+    P = params.init_params(cfg, seed=2)
+    for n, r in enumerate((5., 10., 20.)):
+        out = R.gaussian_radial_basis(d, P, f"key_tensor_field.graph_parsers.{n}.length_enc", 64, r)
+        assert torch.allclose(out, T(gr[f"grb_{int(r)}"], torch.float32), rtol=2e-6, atol=1e-7)
+    assert torch.equal(R.sinusoidal_embedding(d * 3.0, 64, 100., 1000.), T(gr["sinus_len"], torch.float32))
+    tt = T(gr["time"], torch.float32)
+    assert torch.equal(R.sinusoidal_embedding(tt, 256, 1., 10000.), T(gr["sinus_time"], torch.float32))
+    assert torch.equal(R.sinusoidal_embedding(tt.double(), 256, 1., 10000.), T(gr["sinus_time_f64"]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _case(lmax, nT=5, n_scene=400, n_grasp=80, radii=(5., 10., 20., None)):
+    kw = synthetic.score_head_kwargs(lmax, radii=radii)
+    cfgp = params.HeadConfig.from_kwargs(kw)
+    cfg = R.config_from_kwargs(kw)
+    P = params.init_params(cfgp, seed=2, randomize_all=True, dtype=torch.float64)
+    keys = [R.FeaturedPoints(*k) for k in synthetic.make_key_clouds(cfgp, n_scene, dtype=torch.float64)]
+    q = R.FeaturedPoints(*synthetic.make_query(cfgp, n_grasp, dtype=torch.float64))
+    Ts = synthetic.make_poses(nT, near_object=True)
+    time = torch.linspace(0.2, 0.9, nT, dtype=torch.float64)
+    return cfg, P, keys, q, Ts, time
+
+
+def _rand_q(seed):
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(4, generator=g, dtype=torch.float64)
+    return q / q.norm()
+
+
+@pytest.mark.parametrize("lmax", [1, 2])
+def test_left_equivariance(lmax):
+    """rotating/translating scene and poses together leaves the body-frame scores unchanged"""
+    cfg, P, keys, q, Ts, time = _case(lmax)
+    ang, lin = R.score_head_forward(cfg, P, Ts, keys, q, time)
+    g, gt = _rand_q(3), torch.tensor([1., -2., 0.5], dtype=torch.float64)
+    keys2 = [R.FeaturedPoints(x=R.quaternion_apply(g, k.x) + gt, f=R.transform_feature_quaternion(cfg.irreps, k.f, g[None])[0], b=k.b) for k in keys]
+    Ts2 = torch.cat([R.quaternion_raw_multiply(g.expand(len(Ts), 4), Ts[:, :4]), R.quaternion_apply(g, Ts[:, 4:]) + gt], -1)
+    ang2, lin2 = R.score_head_forward(cfg, P, Ts2, keys2, q, time)
+    assert (ang2 - ang).abs().max() < 1e-11 and (lin2 - lin).abs().max() < 1e-11
+    assert ang.abs().max() > 1e-3 and lin.abs().max() > 1e-3
+
+
+@pytest.mark.parametrize("lmax", [1, 2])
+def test_right_equivariance(lmax):
+    """re-expressing the grasp cloud in a rotated gripper frame (x -> h^-1 x, f -> D(h^-1) f, T -> T h) rotates the
+    body-frame scores by h^-1 (pure rotation h, so the orbital term transforms consistently)"""
+    cfg, P, keys, q, Ts, time = _case(lmax)
+    ang, lin = R.score_head_forward(cfg, P, Ts, keys, q, time)
+    h = _rand_q(11)
+    hinv = R.quaternion_invert(h)
+    q2 = R.FeaturedPoints(x=R.quaternion_apply(hinv, q.x), f=R.transform_feature_quaternion(cfg.irreps, q.f, hinv[None])[0], b=q.b, w=q.w)
+    Ts2 = torch.cat([R.quaternion_raw_multiply(Ts[:, :4], h.expand(len(Ts), 4)), Ts[:, 4:]], -1)
+    ang2, lin2 = R.score_head_forward(cfg, P, Ts2, keys, q2, time)
+    assert (ang2 - R.quaternion_apply(hinv, ang)).abs().max() < 1e-11
+    assert (lin2 - R.quaternion_apply(hinv, lin)).abs().max() < 1e-11
+
+
+def test_softmax_normalisation_and_empty_segments():
+    cfg, P, keys, q, Ts, time = _case(2, radii=(3.5, 5., 6.5, 8.))      # high-res radii: far poses have no edges at all
+    Ts = torch.cat([Ts, torch.tensor([[1., 0, 0, 0, 100., 100., 100.]], dtype=torch.float64)])
+    time = torch.cat([time, time[-1:]])
+    dbg = R.Debug()
+    ang, lin = R.score_head_forward(cfg, P, Ts, keys, q, time, dbg)
+    assert torch.isfinite(ang).all() and torch.isfinite(lin).all()
+    Nd = len(Ts) * len(q.x)
+    deg = torch.bincount(dbg['edge_dst'], minlength=Nd)
+    assert (deg[-len(q.x):] == 0).all()                                   # the far pose has zero edges
+    # attention output of edge-less nodes is exactly zero (scatter-sum of nothing)
+    assert (dbg['attn'][-len(q.x):] == 0).all()
+
+
+def test_continuity_at_cutoffs():
+    """outputs are continuous when a key point crosses d = 0.8 r and d = r (soft cut-off acting on the logits)"""
+    kw = synthetic.score_head_kwargs(2, radii=(5.,))
+    cfgp = params.HeadConfig.from_kwargs(kw)
+    cfg = R.config_from_kwargs(kw)
+    P = params.init_params(cfgp, seed=2, randomize_all=True, dtype=torch.float64)
+    g = torch.Generator().manual_seed(0)
+    f = torch.randn(3, cfgp.dim, generator=g, dtype=torch.float64)
+    qq = R.FeaturedPoints(x=torch.zeros(1, 3, dtype=torch.float64), f=torch.randn(1, cfgp.dim, generator=g, dtype=torch.float64),
+                          b=torch.zeros(1, dtype=torch.long), w=torch.ones(1, dtype=torch.float64))
+    Ts = torch.tensor([[1., 0, 0, 0, 0, 0, 0]], dtype=torch.float64)
+    t = torch.tensor([0.5], dtype=torch.float64)
+
+    def run(d):
+        x = torch.tensor([[1.0, 0.5, 0.2], [0.3, -2.0, 1.0], [d, 0., 0.]], dtype=torch.float64)
+        return torch.cat(R.score_head_forward(cfg, P, Ts, [R.FeaturedPoints(x, f, torch.zeros(3, dtype=torch.long))], qq, t))
+    for d0 in (4.0, 5.0):
+        a, b = run(d0 - 1e-7), run(d0 + 1e-7)
+        assert (a - b).abs().max() < 1e-5
+    # beyond the radius the point has no influence at all
+    assert torch.equal(run(5.5), run(7.0))
+
+
+def test_sampler_matches_manual_loop_and_appends_final_pose_twice():
+    cfg, P, keys, q, Ts, time = _case(1, nT=3, n_scene=200, n_grasp=40)
+    P32 = R.cast_params(P, torch.float32)
+    keys32 = [R.FeaturedPoints(k.x.float(), k.f.float(), k.b) for k in keys]
+    q32 = R.FeaturedPoints(q.x.float(), q.f.float(), q.b, q.w.float())
+    g = torch.Generator().manual_seed(5)
+    noise = torch.randn(3, 2, 3, 3, generator=g, dtype=torch.float64)
+    traj = R.sample(cfg, P32, Ts, keys32, q32, [[1.0, 0.5]], [3], [0.04], temperatures=1.0, noise=noise)
+    assert traj.shape == (5, 3, 7) and torch.equal(traj[-1], traj[-2]) and torch.equal(traj[0], Ts)
+    assert torch.allclose(traj[..., :4].norm(dim=-1), torch.ones(5, 3, dtype=torch.float64), atol=1e-14)
+    ts = R.t_schedule((1.0, 0.5), 3)
+    assert abs(float(ts[0]) - 1.0) < 1e-15 and abs(float(ts[-1]) - 0.5) < 1e-15 and abs(float(ts[1]) - 0.5 ** 0.5) < 1e-15
