@@ -1,0 +1,135 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+Tolerance (BASELINE.json north_star): score within 1e-4 relative error, measured as max|gpu - oracle_fp64| / max|oracle|."""
+import numpy as np
+import pytest
+import torch
+
+import stage_check as SC
+from diffusion_edf_amd import params, synthetic
+from diffusion_edf_amd.gnn_data import FeaturedPoints
+from diffusion_edf_amd.score_head import ScoreModelHead
+from diffusion_edf_amd.score_model_base import ScoreModelBase
+from oracle import restatement as R
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _check(rep, stages=True):
+    assert rep['edges_gpu'] == rep['edges_oracle']
+    assert rep['edge_set_equal']
+    assert rep['final_ang'] < TOL and rep['final_lin'] < TOL, rep
+    if stages:
+        for k in ('msg', 'qpos', 'dtp_weight', 'value', 'attn', 'node_lin'):
+            assert rep[k] < 2e-4, (k, rep[k])
+
+
+@pytest.mark.parametrize("lmax", [1, 2])
+def test_score_parity_fake_input_style(lmax):
+    """sizes of ScoreModelHead._get_fake_input (reference score_head.py:220-246): a few poses, ~100 key points"""
+    _check(SC.stage_report(lmax=lmax, nT=5, n_scene=512, n_grasp=100, verbose=False))
+
+
+def test_score_parity_c0_plumbing():
+    """BASELINE config C0: 4096-pt scene stand-in (820/164/33/7 key points), 2 static keypoints, 4 poses incl. the
+    identity quaternion (YXY signed-zero quirk)"""
+    rep = SC.stage_report(lmax=2, nT=4, n_scene=4096, n_grasp=0, static_kp=True, verbose=False, near=False)
+    _check(rep)
+
+
+def test_score_parity_ragged_and_empty_neighbourhoods():
+    """high-res radii [3.5,5,6.5,8] (no infinite scale): poses far from the scene have zero edges at every scale"""
+    kw, cfg, P, keys, query, Ts, time = SC.build_case(2, 6, 1024, 100, radii=(3.5, 5., 6.5, 8.), near=False)
+    Ts[1, 4:] = torch.tensor([200., 200., 200.], dtype=torch.float64)
+    ang64, lin64, d64, _ = SC.oracle_run(kw, P, keys, query, Ts, time, torch.float64)
+    head, ang, lin = SC.gpu_run(kw, P, keys, query, Ts, time, debug=False)
+    assert head.stats()['n_edges'] == d64['n_edges_per_scale']
+    deg = torch.bincount(d64['edge_dst'], minlength=len(Ts) * len(query.x))
+    assert (deg == 0).any() and (deg > 0).any()
+    scale = float(max(ang64.abs().max(), lin64.abs().max()))
+    assert float((ang.double() - ang64).abs().max()) / scale < TOL
+    assert float((lin.double() - lin64).abs().max()) / scale < TOL
+
+
+def test_score_parity_medium_batch():
+    """a few hundred destination nodes per scale boundary: exercises partial tiles and multi-tile scales"""
+    _check(SC.stage_report(lmax=2, nT=37, n_scene=2048, n_grasp=330, verbose=False), stages=False)
+
+
+def test_sampler_parity_injected_noise():
+    """ScoreModelBase.sample with injected noise vs the oracle's float64 Langevin loop (score in f32 on both sides)"""
+    kw, cfg, P, keys, query, Ts, time = SC.build_case(2, 8, 512, 100, identity_pose=True)
+    ocfg = R.config_from_kwargs(kw)
+    g = torch.Generator().manual_seed(9)
+    n_steps = [3, 2]
+    noise = torch.randn(sum(n_steps), 2, len(Ts), 3, generator=g, dtype=torch.float64)
+    sched = [[1.0, 0.5], [0.5, 0.2]]
+    ok = [R.FeaturedPoints(k.x, k.f, k.b) for k in keys]
+    oq = R.FeaturedPoints(query.x, query.f, query.b, query.w)
+    ref = R.sample(ocfg, P, Ts, ok, oq, sched, n_steps, [0.04, 0.02], temperatures=[1.0, 0.5], noise=noise)
+    dev = torch.device('cuda:0')
+    head = ScoreModelHead(**kw)
+    head.load_state_dict(P)
+    head.to(dev)
+    model = ScoreModelBase(head)
+    gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
+    gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
+    out = model.sample(Ts.to(dev), gk, gq, sched, n_steps, [0.04, 0.02], temperatures=[1.0, 0.5], noise=noise).cpu()
+    assert out.shape == ref.shape == (sum(n_steps) + 2, len(Ts), 7)
+    assert torch.equal(out[0], Ts) and torch.equal(out[-1], out[-2])
+    # poses move by O(1) cm per step; agreement is limited by the f32 score (1e-5 relative), not by the f64 update
+    assert float((out - ref).abs().max()) < 2e-4, float((out - ref).abs().max())
+    assert torch.allclose(out[..., :4].norm(dim=-1), torch.ones(out.shape[:2], dtype=torch.float64), atol=1e-12)
+
+
+def test_sampler_langevin_update_is_float64_exact_given_scores():
+    """temperature 0, one step: pose update from the library's own score equals the oracle's update formula to 1e-12"""
+    kw, cfg, P, keys, query, Ts, time = SC.build_case(2, 5, 512, 60)
+    ocfg = R.config_from_kwargs(kw)
+    dev = torch.device('cuda:0')
+    head = ScoreModelHead(**kw)
+    head.load_state_dict(P)
+    head.to(dev)
+    gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
+    gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
+    t = 0.7
+    ang, lin = head(Ts.to(dev).float(), gk, gq, torch.full((len(Ts),), t, device=dev))
+    out = ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[t, t]], [1], [0.04], temperatures=0.0).cpu()
+    z = torch.zeros(len(Ts), 3, dtype=torch.float64)
+    ref = R.langevin_step(ocfg, Ts, ang.cpu(), lin.cpu(), float(torch.tensor(t, dtype=torch.float32)), 0.04, 0.0, 0.5, 0.5, z, z)
+    assert float((out[1] - ref).abs().max()) < 1e-12
+
+
+def test_philox_noise_is_shard_invariant_and_standard_normal():
+    """poses sharded as [0:5] + [5:8] with first_pose_index draw the same noise as the unsharded run"""
+    kw, cfg, P, keys, query, Ts, time = SC.build_case(1, 8, 256, 40)
+    dev = torch.device('cuda:0')
+    head = ScoreModelHead(**kw)
+    head.load_state_dict(P)
+    head.to(dev)
+    m = ScoreModelBase(head)
+    gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
+    gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
+    args = dict(diffusion_schedules=[[1.0, 0.6]], N_steps=[3], timesteps=[0.04], temperatures=1.0, seed=1234)
+    full = m.sample(Ts.to(dev), gk, gq, **args).cpu()
+    a = m.sample(Ts[:5].to(dev), gk, gq, first_pose_index=0, **args).cpu()
+    b = m.sample(Ts[5:].to(dev), gk, gq, first_pose_index=5, **args).cpu()
+    assert torch.equal(torch.cat([a, b], 1), full)
+    other = m.sample(Ts.to(dev), gk, gq, **{**args, 'seed': 99}).cpu()
+    assert not torch.equal(other, full)
+
+
+def test_argument_errors_match_reference_types():
+    kw, cfg, P, keys, query, Ts, time = SC.build_case(1, 3, 128, 30)
+    dev = torch.device('cuda:0')
+    head = ScoreModelHead(**kw).to(dev)
+    gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
+    gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
+    with pytest.raises(AssertionError):
+        head(Ts[:, :6].to(dev).float(), gk, gq, time.to(dev).float())
+    with pytest.raises(AssertionError):
+        head(Ts.to(dev).float(), gk, gq, time[:2].to(dev).float())
+    with pytest.raises(AssertionError):
+        head(Ts.to(dev).float(), gk[:2], gq, time.to(dev).float())
+    with pytest.raises(RuntimeError):
+        ScoreModelHead(**kw)(Ts.float(), keys, query, time.float())      # CPU tensors: no CPU path
