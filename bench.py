@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""bench.py — the headline benchmark of BASELINE.json on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+
+Workload (config C2 of BASELINE.md, the one the metric is quoted on): synthetic 4096-pt scene -> key clouds 820/164/33/7,
+1024-pt grasp -> 103 query points, lmax 2 (64x0e+32x1e+16x2e, full irreps TP + graph attention), 1000 poses PER GPU
+(weak scaling: config C3 = 8 x 1000 poses), random-init weights of the reference architecture, inputs resident in HBM.
+A "step" is one denoising step of the fused sampler over the rank's pose batch: neighbour search + score forward (f32) +
+Langevin update (f64).  value = (poses on all ranks) x K / max-over-ranks wall time  [pose-steps/s].
+One RCCL all-gather of the final poses closes the timed region.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (fused per-edge pipeline): achieved = 2 * E * 193 344 FLOP per launch / its HIP-event duration
+                against the 157.3 TFLOP/s dense fp32 MFMA peak (MI355X_MICROARCH.md); traffic from profiles/*pmc*.json if present.
+  cpu_baseline  the CPU restatement oracle ("port", fp32, same inputs) timed on this host on a bounded pose sample.
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+M_EDGE = {1: 105_536, 2: 193_344}          # algorithmic MAC per edge (dense-CG convention)
+M_NODE = {1: 56_320 + 186_560, 2: 68_352 + 343_264}
+PEAK_FP32_MFMA_TFLOPS = 157.3
+
+
+def build_inputs(lmax, n_scene, n_grasp, n_poses, first_pose, device):
+    from diffusion_edf_amd import params, synthetic
+    from diffusion_edf_amd.gnn_data import FeaturedPoints
+    kw = synthetic.score_head_kwargs(lmax)
+    cfg = params.HeadConfig.from_kwargs(kw)
+    P = params.init_params(cfg, seed=2)
+    keys = synthetic.make_key_clouds(cfg, n_scene, seed=0)
+    query = synthetic.make_query(cfg, n_grasp, seed=0)
+    Ts = synthetic.make_poses(n_poses, seed=1, first_pose_index=first_pose)
+    if device is not None:
+        keys = [FeaturedPoints(k.x.to(device), k.f.to(device), k.b.to(device)) for k in keys]
+        query = FeaturedPoints(query.x.to(device), query.f.to(device), query.b.to(device), query.w.to(device))
+        Ts = Ts.to(device)
+    return kw, cfg, P, keys, query, Ts
+
+
+def cpu_baseline(lmax, n_scene, n_grasp, n_sample_poses=8, t=0.5):
+    """oracle (kind 'port'): one score evaluation + Langevin step on a bounded pose sample, fp32, all host threads torch picks"""
+    from oracle import restatement as R
+    kw, cfg, P, keys, query, Ts = build_inputs(lmax, n_scene, n_grasp, n_sample_poses, 0, None)
+    ocfg = R.config_from_kwargs(kw)
+    ok = [R.FeaturedPoints(k.x, k.f, k.b) for k in keys]
+    oq = R.FeaturedPoints(query.x, query.f, query.b, query.w)
+    cores = torch.get_num_threads()
+    noise = torch.zeros(1, 2, n_sample_poses, 3, dtype=torch.float64)
+    R.sample(ocfg, P, Ts[:2], ok, oq, [[t, t]], [1], [0.04], noise=noise[:, :, :2])          # warm-up (builds caches)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        R.sample(ocfg, P, Ts, ok, oq, [[t, t]], [1], [0.04], noise=noise)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or reps >= 20:
+            break
+    return dict(value=n_sample_poses * reps / el, unit="pose-steps/s", cores=cores, kind="port",
+                sample=f"{reps} x (1 denoise step, {n_sample_poses} poses) of the same C2 inputs, fp32 CPU restatement (oracle/restatement.py), {el:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--poses-per-gpu", type=int, default=1000)
+    ap.add_argument("--lmax", type=int, default=2)
+    ap.add_argument("--scene", type=int, default=4096)
+    ap.add_argument("--grasp", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from diffusion_edf_amd import dist as ddist
+    from diffusion_edf_amd.score_head import ScoreModelHead
+    from diffusion_edf_amd.score_model_base import ScoreModelBase
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+
+    n_total = args.poses_per_gpu * world
+    first, _ = ddist.shard_range(n_total, world, rank)
+    kw, cfg, P, keys, query, Ts = build_inputs(args.lmax, args.scene, args.grasp, args.poses_per_gpu, first, device)
+    head = ScoreModelHead(**kw)
+    head.load_state_dict(P)
+    head.to(device)
+    model = ScoreModelBase(head)
+    head.set_key_clouds(keys)
+    head.set_query(query)
+
+    def run(T0, n_steps, first_idx):
+        # t: 1 -> 0.15 log-spaced, dt 0.04, temperature 1 (configs C1/C2 of BASELINE.md)
+        return model.sample(T0, keys, query, [[1.0, 0.15]], [n_steps], [0.04], temperatures=1.0, seed=3, first_pose_index=first_idx)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    T = Ts
+    if args.warmup > 0:
+        T = run(T, args.warmup, first)[-1]
+        if world > 1:
+            ddist.gather_poses(T, n_total)
+    head.profile_enable(True)
+    head.profile_read()
+    barrier()
+    t0 = time.perf_counter()
+    traj = run(T, args.steps, first)
+    final = ddist.gather_poses(traj[-1], n_total) if world > 1 else traj[-1]
+    barrier()
+    el = time.perf_counter() - t0
+    prof = head.profile_read()
+    head.profile_enable(False)
+    if world > 1:
+        tt = torch.tensor([el], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    assert torch.isfinite(final).all()
+
+    if rank == 0:
+        n_ev = max(1, prof["n_evals"])
+        edge_ms = prof["ms"]["edge"] / n_ev
+        e_per_launch = prof["n_edges"] / n_ev
+        flops = 2.0 * e_per_launch * M_EDGE[args.lmax]
+        achieved = flops / (edge_ms * 1e-3) / 1e12 if edge_ms > 0 else 0.0
+        traffic = None
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json"))):
+            try:
+                traffic = json.load(open(f)).get("edge_kernel_hbm_bytes_per_launch", traffic)
+            except Exception:
+                pass
+        out = {
+            "metric": "denoised SE(3) poses/sec (pose-steps/s, 4k-pt scene / 1k-pt grasp, lmax=2)",
+            "value": n_total * args.steps / el,
+            "unit": "pose-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (score network, exact-f32 MFMA) + f64 (SE(3) Langevin state)",
+            "data": "synthetic (seeded scene/grasp clouds of the named sizes, random-init weights of the reference architecture)",
+            "config": {"workload": f"C2: {args.scene}-pt scene -> key clouds {'/'.join(str(len(k.x)) for k in keys)}, {args.grasp}-pt grasp -> "
+                                   f"{len(query.x)} query pts, lmax={args.lmax}, {args.poses_per_gpu} poses per GPU, t 1->0.15 log-spaced, dt 0.04",
+                       "poses_total": n_total, "parallelism": f"pose-parallel dp{world}, one RCCL all-gather at the end",
+                       "edges_per_step_rank0": e_per_launch, "full_trajectories_per_s_at_50_steps": n_total * args.steps / el / 50.0},
+            "roofline": {"kernel": "k_edge (fused per-edge pipeline)", "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                         "avg_launch_ms": edge_ms, "algorithmic_flop_per_launch": flops,
+                         "kernel_ms_per_step": {k: v / n_ev for k, v in prof["ms"].items()}},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.lmax, args.scene, args.grasp)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

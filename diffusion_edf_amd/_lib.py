@@ -18,7 +18,7 @@ OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_RUNTIME = 0, 1, 2, 3
 SYMBOLS = [
     "dedf_version", "dedf_param_count", "dedf_param_name", "dedf_param_numel", "dedf_create", "dedf_destroy",
     "dedf_last_error", "dedf_set_key_clouds", "dedf_set_query", "dedf_score", "dedf_sample", "dedf_get_stats",
-    "dedf_debug_enable", "dedf_debug_copy", "dedf_debug_packed",
+    "dedf_debug_enable", "dedf_debug_copy", "dedf_debug_packed", "dedf_profile_enable", "dedf_profile_read",
 ]
 
 
@@ -40,6 +40,12 @@ class DedfSchedule(C.Structure):
 class DedfStats(C.Structure):
     _fields_ = [("n_dst", C.c_int64), ("n_edges", C.c_int64 * MAX_SCALES), ("n_edges_total", C.c_int64), ("overflow", C.c_int)]
 
+
+class DedfProfile(C.Structure):
+    _fields_ = [("n_evals", C.c_int64), ("n_edges", C.c_int64), ("n_dst", C.c_int64), ("ms", C.c_double * 6)]
+
+
+PROF_CLASSES = ["pose_time", "neighbors", "edge", "aggregate", "node", "reduce"]
 
 _lib: Optional[C.CDLL] = None
 
@@ -75,6 +81,8 @@ def load() -> C.CDLL:
     lib.dedf_debug_enable.argtypes = [C.c_void_p, C.c_int]; lib.dedf_debug_enable.restype = C.c_int
     lib.dedf_debug_copy.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, P(C.c_size_t)]; lib.dedf_debug_copy.restype = C.c_int
     lib.dedf_debug_packed.argtypes = [C.c_void_p, C.c_char_p, P(P(C.c_float)), P(C.c_size_t)]; lib.dedf_debug_packed.restype = C.c_int
+    lib.dedf_profile_enable.argtypes = [C.c_void_p, C.c_int]; lib.dedf_profile_enable.restype = C.c_int
+    lib.dedf_profile_read.argtypes = [C.c_void_p, P(DedfProfile)]; lib.dedf_profile_read.restype = C.c_int
     _lib = lib
     return lib
 

@@ -81,6 +81,13 @@ struct dedf_handle {
     int last_nT = 0;
     bool debug = false;
     hipStream_t last_stream = nullptr;
+    // live profiling (bench.py roofline)
+    bool profile = false;
+    std::vector<hipEvent_t> ev;           // 7 events per evaluation
+    size_t ev_used = 0;
+    int64_t prof_evals = 0, prof_dst = 0;
+    DevBuf d_hist;
+    ~dedf_handle() { for (auto e : ev) (void)hipEventDestroy(e); }
 };
 
 namespace {
@@ -210,7 +217,13 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     const int Nd = nT * nQ;
     constexpr int D = feat_dim<L>();
     const float* nat = h->d_nat.as<float>();
+    auto mark = [&]() {
+        if (!h->profile) return;
+        if (h->ev_used == h->ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; h->ev.push_back(e); }
+        (void)hipEventRecord(h->ev[h->ev_used++], st);
+    };
     if ((size_t)Nd * D * 4 >= (1ull << 32)) return fail(h, DEDF_ERR_INVALID, "nT*nQ too large for one call (z buffer > 4 GiB); split the pose batch");
+    mark();
     // 1. poses: Wigner-D + transformed query positions
     hipLaunchKernelGGL(k_pose_prep<L>, dim3(nT), dim3(64), 0, st, h->d_Ts.as<float>(), h->d_qx.as<float>(), nQ, h->d_pose.as<float>(), h->d_qpos.as<float>());
     // 2. time embedding -> pre-linear bias rows
@@ -222,6 +235,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         tp.max_time = c.max_time; tp.time_enc_n = c.time_enc_n; tp.tb = h->d_tb.as<float>();
         hipLaunchKernelGGL(k_time_bias, dim3(time_stride ? nT : 1, ns), dim3(128), 0, st, tp);
     }
+    mark();
     // 3. neighbour search
     NbrParams np{};
     np.key_x = h->d_key_x.as<float>(); np.n_keys = h->n_keys; np.n_scales = ns; np.max_neighbors = c.max_neighbors;
@@ -230,8 +244,10 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     np.qpos = h->d_qpos.as<float>(); np.n_dst = Nd; np.cnt = h->d_cnt.as<int>(); np.off = h->d_off.as<int>();
     np.tile_info = h->d_tile.as<int>(); np.edge_src = h->d_esrc.as<int>(); np.edge_dst = h->d_edst.as<int>(); np.cap = h->edge_cap;
     hipLaunchKernelGGL(k_neighbors<false>, dim3((Nd + 255) / 256), dim3(256), 0, st, np);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, h->d_cnt.as<int>(), h->d_off.as<int>(), Nd, ns, h->d_tile.as<int>(), h->edge_cap);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, h->d_cnt.as<int>(), h->d_off.as<int>(), Nd, ns, h->d_tile.as<int>(), h->edge_cap,
+                       h->profile ? h->d_hist.as<long long>() : nullptr);
     hipLaunchKernelGGL(k_neighbors<true>, dim3((Nd + 255) / 256), dim3(256), 0, st, np);
+    mark();
     // 4. fused edge pipeline
     {
         EdgeParams P{};
@@ -258,9 +274,11 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         P.dbg_w = h->debug ? h->d_dbgw.as<float>() : nullptr;
         hipLaunchKernelGGL(k_edge<L>, dim3(h->n_cu * 4), dim3(64), 0, st, P);
     }
+    mark();
     // 5. joint softmax + aggregation
     hipLaunchKernelGGL(k_aggregate<L>, dim3((Nd + 3) / 4), dim3(256), 0, st, h->d_eout.as<float>(), h->d_cnt.as<int>(), h->d_off.as<int>(),
                        h->d_tile.as<int>(), Nd, ns, h->d_z.as<float>());
+    mark();
     // 6. node epilogue + score tensor products
     {
         NodeParams P{};
@@ -280,8 +298,11 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         const int ntiles = (Nd + 31) / 32;
         hipLaunchKernelGGL(k_node<L>, dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
     }
+    mark();
     // 7. per-pose reduction
     hipLaunchKernelGGL(k_pose_reduce, dim3((nT + 127) / 128), dim3(128), 0, st, h->d_nout.as<float>(), nT, nQ, ang, lin);
+    mark();
+    if (h->profile) { h->prof_evals += 1; h->prof_dst += Nd; }
     if (hipGetLastError() != hipSuccess) return fail(h, DEDF_ERR_RUNTIME, "kernel launch failed");
     h->last_nT = nT;
     h->last_stream = st;
@@ -485,6 +506,40 @@ int dedf_get_stats(dedf_handle* h, dedf_stats* out) {
     out->n_dst = (int64_t)h->last_nT * h->nQ;
     for (int n = 0; n < h->cfg.n_scales; ++n) { out->n_edges[n] = ti[16 + n + 1] - ti[16 + n]; out->n_edges_total += out->n_edges[n]; }
     out->overflow = ti[40];
+    return DEDF_OK;
+}
+
+int dedf_profile_enable(dedf_handle* h, int on) {
+    if (!h) return DEDF_ERR_INVALID;
+    if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
+    HIPCK(h, hipSetDevice(h->cfg.device));
+    if (on && !h->d_hist.p) {
+        if (!h->d_hist.ensure(8)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc failed");
+        HIPCK(h, hipMemset(h->d_hist.p, 0, 8));
+    }
+    h->profile = on != 0;
+    return DEDF_OK;
+}
+
+int dedf_profile_read(dedf_handle* h, dedf_profile* out) {
+    if (!h || !out) return DEDF_ERR_INVALID;
+    if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
+    memset(out, 0, sizeof(*out));
+    HIPCK(h, hipDeviceSynchronize());
+    for (size_t i = 0; i + 6 < h->ev_used; i += 7)
+        for (int c = 0; c < DEDF_PROF_CLASSES; ++c) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, h->ev[i + c], h->ev[i + c + 1]) == hipSuccess) out->ms[c] += ms;
+        }
+    out->n_evals = h->prof_evals;
+    out->n_dst = h->prof_dst;
+    if (h->d_hist.p) {
+        long long e = 0;
+        HIPCK(h, hipMemcpy(&e, h->d_hist.p, 8, hipMemcpyDeviceToHost));
+        out->n_edges = e;
+        HIPCK(h, hipMemset(h->d_hist.p, 0, 8));
+    }
+    h->ev_used = 0; h->prof_evals = 0; h->prof_dst = 0;
     return DEDF_OK;
 }
 

@@ -238,7 +238,8 @@ __global__ void k_neighbors(NbrParams P) {
 
 // exclusive scan of cnt[n][*] per scale + tile table.  One block of 1024 threads.
 // tile_info: [0..n_scales] tile prefix, [16..16+n_scales] edge prefix, [40] overflow flag
-__global__ void k_scan(const int* __restrict__ cnt, int* __restrict__ off, int n_dst, int n_scales, int* __restrict__ tile_info, int64_t cap) {
+__global__ void k_scan(const int* __restrict__ cnt, int* __restrict__ off, int n_dst, int n_scales, int* __restrict__ tile_info, int64_t cap,
+                       long long* __restrict__ edge_hist) {
     __shared__ int part[1024];
     __shared__ int carry;
     const int tid = threadIdx.x;
@@ -271,6 +272,7 @@ __global__ void k_scan(const int* __restrict__ cnt, int* __restrict__ off, int n
     if (tid == 0) {
         const int ovf = edges > cap ? 1 : 0;
         tile_info[40] = ovf;
+        if (edge_hist) *edge_hist += edges;
         if (ovf) for (int n = 0; n <= n_scales; ++n) tile_info[n] = 0;     // no tiles: downstream kernels do nothing
     }
 }

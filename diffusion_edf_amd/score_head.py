@@ -191,6 +191,17 @@ class ScoreModelHead(torch.nn.Module):
         return dict(n_dst=st.n_dst, n_edges=[st.n_edges[i] for i in range(self.n_scales)], n_edges_total=st.n_edges_total,
                     overflow=bool(st.overflow))
 
+    def profile_enable(self, on: bool = True):
+        lib = _lib.load()
+        _lib.raise_for(lib, self._handle, lib.dedf_profile_enable(self._handle, int(on)), "dedf_profile_enable")
+
+    def profile_read(self) -> dict:
+        """summed HIP-event kernel times [ms] per kernel class since the last read (resets the counters)"""
+        lib = _lib.load()
+        pr = _lib.DedfProfile()
+        _lib.raise_for(lib, self._handle, lib.dedf_profile_read(self._handle, C.byref(pr)), "dedf_profile_read")
+        return dict(n_evals=pr.n_evals, n_edges=pr.n_edges, n_dst=pr.n_dst, ms={k: pr.ms[i] for i, k in enumerate(_lib.PROF_CLASSES)})
+
     def debug_enable(self, on: bool = True):
         _lib.load().dedf_debug_enable(self._handle, int(on))
 

@@ -107,6 +107,18 @@ int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedul
 
 int dedf_get_stats(dedf_handle* h, dedf_stats* out);   /* synchronises the last used stream */
 
+/* Live kernel timing for bench.py's roofline: when enabled, HIP events are recorded on the launch stream around every
+ * kernel class of every score evaluation.  dedf_profile_read synchronises, returns the totals since the last reset and resets. */
+#define DEDF_PROF_CLASSES 6   /* 0 pose+time, 1 neighbour search, 2 fused edge kernel, 3 softmax-aggregate, 4 node kernel, 5 reduce */
+typedef struct dedf_profile {
+    int64_t n_evals;                       /* score evaluations covered */
+    int64_t n_edges;                       /* sum of edge counts over those evaluations */
+    int64_t n_dst;                         /* sum of destination-node counts */
+    double ms[DEDF_PROF_CLASSES];          /* summed kernel time per class [ms] */
+} dedf_profile;
+int dedf_profile_enable(dedf_handle* h, int on);
+int dedf_profile_read(dedf_handle* h, dedf_profile* out);
+
 /* Test hooks: copy an internal device buffer of the last dedf_score call to HOST memory.  Names: "msg", "qpos", "pose",
  * "tb", "edge_src", "edge_dst", "edge_out", "z", "node_out", "tile_info", "dbg_w" (enable with dedf_debug_enable). */
 int dedf_debug_enable(dedf_handle* h, int on);
