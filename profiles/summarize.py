@@ -1,0 +1,68 @@
+"""Turn rocprofv3 (ROCm 7.2, rocpd sqlite output) result DBs under gpurun_out/ into the committed text / JSON summaries.
+
+  python profiles/summarize.py r01        # reads gpurun_out/r01_trace, r01_pmc_*  ->  profiles/r01_*.txt|json
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are collected in SEPARATE --pmc
+passes, are reported in KiB, and on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced streams, so the read
+side is doubled ("fetch_x2"); WRITE_SIZE is taken as reported (uncalibrated).
+"""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def db(path_glob):
+    f = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", path_glob, "*", "*_results.db")))
+    return sqlite3.connect(f[-1]) if f else None
+
+
+def main(tag):
+    out_txt = []
+    con = db(f"{tag}_trace")
+    if con:
+        out_txt.append(f"# rocprofv3 --kernel-trace --stats  ({tag})   name | calls | total_us | avg_us | pct")
+        for r in con.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
+            out_txt.append(f"{r[0][:100]:100s} {r[1]:6d} {r[2]:14.1f} {r[3]:12.2f} {r[4]:6.2f}")
+        out_txt.append("")
+        out_txt.append("# per-kernel resources: name | vgpr | accum_vgpr | sgpr | lds | scratch | grid | wg")
+        seen = set()
+        for r in con.execute("select name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x from kernels"):
+            if r[0] in seen:
+                continue
+            seen.add(r[0])
+            out_txt.append(" | ".join(str(x) for x in r)[:200])
+    pmc = {}
+    for kind in ("fetch", "write", "sq"):
+        con = db(f"{tag}_pmc_{kind}")
+        if not con:
+            continue
+        q = ("select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection "
+             "group by kernel_name, counter_name")
+        for name, cname, n, avg, tot in con.execute(q):
+            pmc.setdefault(name, {})[cname] = {"launches": n, "avg": avg, "sum": tot}
+    summary = {"tag": tag, "per_kernel": pmc}
+    for name, c in pmc.items():
+        if name.startswith("void k_edge"):
+            f = c.get("FETCH_SIZE", {}).get("avg")
+            w = c.get("WRITE_SIZE", {}).get("avg")
+            if f is not None and w is not None:
+                summary["edge_kernel_fetch_KiB_per_launch_raw"] = f
+                summary["edge_kernel_write_KiB_per_launch_raw"] = w
+                summary["edge_kernel_hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0
+    with open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.txt"), "w") as fh:
+        fh.write("\n".join(out_txt) + "\n")
+    with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w") as fh:
+        json.dump(summary, fh, indent=1)
+    print("\n".join(out_txt[:20]))
+    print(json.dumps({k: v for k, v in summary.items() if k != "per_kernel"}, indent=1))
+    for name, c in pmc.items():
+        if "k_edge" in name or "k_node" in name or "k_aggregate" in name:
+            print(name[:60], {k: round(v["avg"], 1) for k, v in c.items()})
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
