@@ -10,7 +10,7 @@ import numpy as np
 
 from .params import HeadConfig
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libdedf.so")
+_LIB_PATH = os.environ.get("DEDF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libdedf.so")
 MAX_SCALES = 8
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_RUNTIME = 0, 1, 2, 3

@@ -61,8 +61,11 @@ DEDF_DEV void static_for(F&& f) {
 }
 
 // scheduling-region fence: keeps hipcc from hoisting hundreds of weight loads to the top of a fully unrolled phase
+#ifndef DEDF_FENCE
+#define DEDF_FENCE 1
+#endif
 DEDF_DEV void sched_fence() {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && DEDF_FENCE
     __builtin_amdgcn_sched_barrier(0);
 #endif
 }
@@ -121,6 +124,23 @@ DEDF_DEV f32x16 ldrows(const Buf& b, int voff_hi64, int off, int tile) {
     return v;
 }
 DEDF_DEV f32x16 ldrows(const Wave& wv, int off, int tile) { return ldrows(wv.w, wv.hi64, off, tile); }
+
+// Software-pipelined stream of packed-A groups: the operand of item I+PD is requested before item I is consumed, and
+// scheduling fences keep hipcc from sinking the request back next to its use (it otherwise emits load -> vmcnt(0) -> MFMA
+// for every group and exposes the full L2 latency ~180 times per tile at one wave per SIMD).
+//   soff.operator()<I>() -> byte offset (wave-uniform) of item I;   body.operator()<I>(f32x4 a)
+template <int N, int PD, class SoffF, class BodyF>
+DEDF_DEV void a_stream(const Wave& wv, SoffF&& soff, BodyF&& body) {
+    f32x4 ring[PD];
+    static_for<PD>([&]<int I>() { if constexpr (I < N) ring[I] = bld4(wv.w, wv.lane16, soff.template operator()<I>()); });
+    static_for<N>([&]<int I>() {
+        const f32x4 a = ring[I % PD];
+        if constexpr (I + PD < N) ring[I % PD] = bld4(wv.w, wv.lane16, soff.template operator()<I + PD>());
+        sched_fence();
+        body.template operator()<I>(a);
+        sched_fence();
+    });
+}
 
 // One packed-A group = 4 K-steps of one 32-row output tile: acc += A[:, 4 steps] * B[4 steps, :]
 DEDF_DEV void mfma_group(f32x16& acc, const f32x4 a, float b0, float b1, float b2, float b3) {

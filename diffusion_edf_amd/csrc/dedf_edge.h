@@ -151,32 +151,26 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         const Buf tbb = make_buf(P.tb, P.tb_bytes);
         const int tvoff = (pose * P.tb_pose_stride) * 4 + wv.hi64;
         const int oA = P.o_A_pre + scale * (4 * 8 * 256);
-        static_for<4>([&]<int To>() {
-            h[To] = ldrows(tbb, tvoff, scale * 128, To);
-            static_for<8>([&]<int g>() {
-                mfma_group(h[To], lda(wv, oA, 8, To, g), eb[4 * g], eb[4 * g + 1], eb[4 * g + 2], eb[4 * g + 3]);
-            });
-            static_for<16>([&]<int R>() { h[To][R] = siluf(h[To][R]); });
-            sched_fence();
+        static_for<4>([&]<int To>() { h[To] = ldrows(tbb, tvoff, scale * 128, To); });
+        a_stream<32, 4>(wv, [&]<int I>() { return (oA + I * 256) * 4; }, [&]<int I>(f32x4 a) {
+            constexpr int To = I / 8, g = I % 8;
+            mfma_group(h[To], a, eb[4 * g], eb[4 * g + 1], eb[4 * g + 2], eb[4 * g + 3]);
         });
+        static_for<4>([&]<int To>() { static_for<16>([&]<int R>() { h[To][R] = siluf(h[To][R]); }); });
     }
     // ---- RadialProfile layers 1, 2 (equiformer/radial_func.py:11-60) ---------------------------------------------------
     f32x16 r1[4];
-    static_for<4>([&]<int To>() {
-        r1[To] = ldrows(wv, P.o_b_r1, To);
-        static_for<4>([&]<int T>() { static_for<4>([&]<int g>() {
-            mfma_group(r1[To], lda(wv, P.o_A_r1, 16, To, T * 4 + g), h[T][4 * g], h[T][4 * g + 1], h[T][4 * g + 2], h[T][4 * g + 3]);
-        }); });
-        sched_fence();
+    static_for<4>([&]<int To>() { r1[To] = ldrows(wv, P.o_b_r1, To); });
+    a_stream<64, 4>(wv, [&]<int I>() { return (P.o_A_r1 + I * 256) * 4; }, [&]<int I>(f32x4 a) {
+        constexpr int To = I / 16, T = (I % 16) / 4, g = I % 4;
+        mfma_group(r1[To], a, h[T][4 * g], h[T][4 * g + 1], h[T][4 * g + 2], h[T][4 * g + 3]);
     });
     ln_silu<4>(r1, wv, P.o_g_r1, P.o_be_r1);
     f32x16 r2[2];
-    static_for<2>([&]<int To>() {
-        r2[To] = ldrows(wv, P.o_b_r2, To);
-        static_for<4>([&]<int T>() { static_for<4>([&]<int g>() {
-            mfma_group(r2[To], lda(wv, P.o_A_r2, 16, To, T * 4 + g), r1[T][4 * g], r1[T][4 * g + 1], r1[T][4 * g + 2], r1[T][4 * g + 3]);
-        }); });
-        sched_fence();
+    static_for<2>([&]<int To>() { r2[To] = ldrows(wv, P.o_b_r2, To); });
+    a_stream<32, 4>(wv, [&]<int I>() { return (P.o_A_r2 + I * 256) * 4; }, [&]<int I>(f32x4 a) {
+        constexpr int To = I / 16, T = (I % 16) / 4, g = I % 4;
+        mfma_group(r2[To], a, r1[T][4 * g], r1[T][4 * g + 1], r1[T][4 * g + 2], r1[T][4 * g + 3]);
     });
     ln_silu<2>(r2, wv, P.o_g_r2, P.o_be_r2);
 
@@ -191,30 +185,54 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // per-l1 lane offsets of the 4 message rows this lane owns inside an 8-row group
     const int mv0 = src * (D * 4) + hi * 16, mv1 = src * (D * 4) + hi * 48, mv2 = src * (D * 4) + hi * 80;
 
+    // operands of one DTP group (8 weight rows): A operands of the lin GEMM(s) it feeds + this lane's 4 source-message rows
+    struct GroupOps { f32x4 a[NR0]; f32x4 x[2 * L + 1]; };
+    auto load_group = [&]<int G>() {
+        GroupOps o;
+        if constexpr (G < WN / 8) {
+            constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(G * 8));
+            constexpr int l1 = pi.l1, l3 = pi.l3, d1 = 2 * l1 + 1, u0 = G * 8 - pi.wstart;
+            constexpr int gi = dtp_group_index<L>(G), NG = dtp_k<L>(l3) / 8;
+            if constexpr (l3 == 0) static_for<NR0>([&]<int To>() { o.a[To] = lda(wv, P.o_A_lin[0], NG, To, gi); });
+            else o.a[0] = lda(wv, P.o_A_lin[l3], NG, 0, gi);
+            const int mv = l1 == 0 ? mv0 : (l1 == 1 ? mv1 : mv2);
+            static_for<d1>([&]<int Q>() { o.x[Q] = bld4(msgb, mv, (blk_off(l1) + u0 * d1 + 4 * Q) * 4); });
+        }
+        return o;
+    };
+    // layer-3 A operands: one global stream over all tiles, 4 groups (>= 1000 cycles of MFMA work) ahead
+    constexpr int NL3 = NWT * 8, PD3 = 4;
+    f32x4 l3ring[PD3];
+    static_for<PD3>([&]<int I>() { l3ring[I] = bld4(wv.w, wv.lane16, (P.o_A_r3 + I * 256) * 4); });
+    GroupOps gcur = load_group.template operator()<0>();
+    f32x16 wt = ldrows(wv, P.o_off_r3, 0);
     static_for<NWT>([&]<int Tw>() {
-        f32x16 wt = ldrows(wv, P.o_off_r3, Tw);
-        static_for<2>([&]<int T>() { static_for<4>([&]<int g>() {
-            mfma_group(wt, lda(wv, P.o_A_r3, 8, Tw, T * 4 + g), r2[T][4 * g], r2[T][4 * g + 1], r2[T][4 * g + 2], r2[T][4 * g + 3]);
-        }); });
-        sched_fence();
+        static_for<8>([&]<int gg>() {
+            constexpr int I = Tw * 8 + gg, T = gg / 4, g = gg % 4;
+            const f32x4 a = l3ring[I % PD3];
+            if constexpr (I + PD3 < NL3) l3ring[I % PD3] = bld4(wv.w, wv.lane16, (P.o_A_r3 + (I + PD3) * 256) * 4);
+            sched_fence();
+            mfma_group(wt, a, r2[T][4 * g], r2[T][4 * g + 1], r2[T][4 * g + 2], r2[T][4 * g + 3]);
+            sched_fence();
+        });
         if (P.dbg_w != nullptr && valid)
             static_for<16>([&]<int R>() { P.dbg_w[(size_t)e * WN + Tw * 32 + rowmap(R, hi)] = wt[R]; });
+        f32x16 wt_next = wt;
+        if constexpr (Tw + 1 < NWT) wt_next = ldrows(wv, P.o_off_r3, Tw + 1);
         static_for<4>([&]<int g>() {
-            constexpr int wrow0 = Tw * 32 + 8 * g;
+            constexpr int G = Tw * 4 + g;
+            constexpr int wrow0 = G * 8;
             constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(wrow0));
             constexpr int l1 = pi.l1, l2 = pi.l2, l3 = pi.l3;
             constexpr int d1 = 2 * l1 + 1, d3 = 2 * l3 + 1;
-            constexpr int u0 = wrow0 - pi.wstart;
-            constexpr int gi = dtp_group_index<L>(wrow0 / 8);
+            const GroupOps gnext = load_group.template operator()<G + 1>();
+            sched_fence();
             using C = CG<l1, l2, l3>;
             float m[C::NM];
             C::make(Y.template get<l2>(), m);
-            // 4 source-message rows (u0 + 4 hi + j), d1 components each, contiguous in the reference layout
             float xr[4 * d1];
-            const int mv = l1 == 0 ? mv0 : (l1 == 1 ? mv1 : mv2);
             static_for<d1>([&]<int Q>() {
-                const f32x4 t = bld4(msgb, mv, (blk_off(l1) + u0 * d1 + 4 * Q) * 4);
-                xr[4 * Q] = t[0]; xr[4 * Q + 1] = t[1]; xr[4 * Q + 2] = t[2]; xr[4 * Q + 3] = t[3];
+                xr[4 * Q] = gcur.x[Q][0]; xr[4 * Q + 1] = gcur.x[Q][1]; xr[4 * Q + 2] = gcur.x[Q][2]; xr[4 * Q + 3] = gcur.x[Q][3];
             });
             float a[4][d3];
             static_for<4>([&]<int j>() {
@@ -222,19 +240,17 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 C::apply(&xr[j * d1], m, o);
                 static_for<d3>([&]<int K>() { a[j][K] = o[K] * wt[4 * g + j]; });
             });
-            constexpr int NG = dtp_k<L>(l3) / 8;
             if constexpr (l3 == 0) {
-                static_for<NR0>([&]<int To>() {
-                    mfma_group(acc[To], lda(wv, P.o_A_lin[0], NG, To, gi), a[0][0], a[1][0], a[2][0], a[3][0]);
-                });
+                static_for<NR0>([&]<int To>() { mfma_group(acc[To], gcur.a[To], a[0][0], a[1][0], a[2][0], a[3][0]); });
             } else {
-                const f32x4 av = lda(wv, P.o_A_lin[l3], NG, 0, gi);
                 static_for<d3>([&]<int K>() {
-                    mfma_group(acc[(l3 == 1 ? AB1 : AB2) + K], av, a[0][K], a[1][K], a[2][K], a[3][K]);
+                    mfma_group(acc[(l3 == 1 ? AB1 : AB2) + K], gcur.a[0], a[0][K], a[1][K], a[2][K], a[3][K]);
                 });
             }
             sched_fence();
+            gcur = gnext;
         });
+        wt = wt_next;
     });
 
     // ---- attention logits (graph_attention.py:233-246): heads of sep_alpha -> SmoothLeakyReLU -> . alpha_dot + log cut-off
@@ -279,37 +295,45 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     f32x16 val[NV];
     static_for<2>([&]<int T>() { val[T] = ldrows(wv, P.o_b_val0, T); });
     static_for<NV - 2>([&]<int T>() { static_for<16>([&]<int R>() { val[2 + T][R] = 0.0f; }); });
-    static_for<dtp_num_paths<L>()>([&]<int p>() {
-        constexpr PathInfo pi = dtp_path<L>(p);
+    // groups are walked in weight order (= path creation order, u ascending); A operands two groups ahead
+    struct ValOps { f32x4 a[2]; };
+    auto load_val = [&]<int G>() {
+        ValOps o;
+        if constexpr (G < WN / 8) {
+            constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(G * 8));
+            constexpr int l3 = pi.l3, gi = dtp_group_index<L>(G), NG = dtp_k<L>(l3) / 8;
+            o.a[0] = lda(wv, P.o_A_val[l3], NG, 0, gi);
+            if constexpr (l3 == 0) o.a[1] = lda(wv, P.o_A_val[0], NG, 1, gi);
+        }
+        return o;
+    };
+    ValOps v0 = load_val.template operator()<0>(), v1 = load_val.template operator()<1>();
+    static_for<WN / 8>([&]<int G>() {
+        constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(G * 8));
         constexpr int l1 = pi.l1, l2 = pi.l2, l3 = pi.l3;
         constexpr int d1 = 2 * l1 + 1, d3 = 2 * l3 + 1;
+        constexpr int gu = (G * 8 - pi.wstart) / 8;
+        const ValOps v2 = load_val.template operator()<G + 2>();
+        sched_fence();
         using C = CG<l1, l2, l3>;
         float m[C::NM];
         C::make(Y.template get<l2>(), m);
-        static_for<pi.mul1 / 8>([&]<int gu>() {
-            constexpr int gi = dtp2_group_index<L>(p, gu);
-            float a[4][d3];
-            static_for<4>([&]<int j>() {
-                float x[d1], o[d3];
-                if constexpr (l1 == 0) x[0] = u0[gu / 4][4 * (gu % 4) + j];
-                else if constexpr (l1 == 1) { static_for<3>([&]<int I>() { x[I] = u1[I][4 * gu + j]; }); }
-                else { static_for<5>([&]<int I>() { x[I] = u2[I][4 * gu + j]; }); }
-                C::apply(x, m, o);
-                static_for<d3>([&]<int K>() { a[j][K] = o[K]; });
-            });
-            constexpr int NG = dtp_k<L>(l3) / 8;
-            if constexpr (l3 == 0) {
-                static_for<2>([&]<int To>() {
-                    mfma_group(val[To], lda(wv, P.o_A_val[0], NG, To, gi), a[0][0], a[1][0], a[2][0], a[3][0]);
-                });
-            } else {
-                const f32x4 av = lda(wv, P.o_A_val[l3], NG, 0, gi);
-                static_for<d3>([&]<int K>() {
-                    mfma_group(val[(l3 == 1 ? 2 : 5) + K], av, a[0][K], a[1][K], a[2][K], a[3][K]);
-                });
-            }
-            sched_fence();
+        float a[4][d3];
+        static_for<4>([&]<int j>() {
+            float x[d1], o[d3];
+            if constexpr (l1 == 0) x[0] = u0[gu / 4][4 * (gu % 4) + j];
+            else if constexpr (l1 == 1) { static_for<3>([&]<int I>() { x[I] = u1[I][4 * gu + j]; }); }
+            else { static_for<5>([&]<int I>() { x[I] = u2[I][4 * gu + j]; }); }
+            C::apply(x, m, o);
+            static_for<d3>([&]<int K>() { a[j][K] = o[K]; });
         });
+        if constexpr (l3 == 0) {
+            static_for<2>([&]<int To>() { mfma_group(val[To], v0.a[To], a[0][0], a[1][0], a[2][0], a[3][0]); });
+        } else {
+            static_for<d3>([&]<int K>() { mfma_group(val[(l3 == 1 ? 2 : 5) + K], v0.a[0], a[0][K], a[1][K], a[2][K], a[3][K]); });
+        }
+        sched_fence();
+        v0 = v1; v1 = v2;
     });
 
     // ---- store the edge record: value in internal layout [l][m][channel] + one logit per head ----------------------------
