@@ -76,7 +76,7 @@ struct dedf_handle {
     int scale_start[kMaxScales + 1] = {0};
     bool have_keys = false, have_query = false;
     // device: per call
-    DevBuf d_Ts, d_time, d_tb, d_pose, d_qpos, d_cnt, d_off, d_tile, d_esrc, d_edst, d_eout, d_z, d_nout, d_ang, d_lin, d_T64, d_dbgw;
+    DevBuf d_Ts, d_time, d_tb, d_pose, d_qpos, d_cnt, d_off, d_blk, d_tile, d_esrc, d_edst, d_eout, d_z, d_nout, d_ang, d_lin, d_T64, d_dbgw;
     int64_t edge_cap = 0;
     int last_nT = 0;
     bool debug = false;
@@ -198,7 +198,7 @@ int ensure_workspace(dedf_handle* h, int nT) {
     h->edge_cap = cap;
     bool ok = h->d_Ts.ensure((size_t)nT * 7 * 4) && h->d_time.ensure((size_t)nT * 4) && h->d_tb.ensure((size_t)nT * ns * 128 * 4) &&
               h->d_pose.ensure((size_t)nT * kPoseRec * 4) && h->d_qpos.ensure(Nd * 3 * 4) && h->d_cnt.ensure(Nd * ns * 4) &&
-              h->d_off.ensure(Nd * ns * 4) && h->d_tile.ensure(64 * 4) && h->d_esrc.ensure((size_t)cap * 4) &&
+              h->d_off.ensure(Nd * ns * 4) && h->d_blk.ensure(((Nd + kNbrBlock - 1) / kNbrBlock) * ns * 4 + 64) && h->d_tile.ensure(64 * 4) && h->d_esrc.ensure((size_t)cap * 4) &&
               h->d_edst.ensure((size_t)cap * 4) && h->d_eout.ensure((size_t)cap * REC * 4) && h->d_z.ensure(Nd * D * 4) &&
               h->d_nout.ensure(Nd * 8 * 4) && h->d_ang.ensure((size_t)nT * 3 * 4) && h->d_lin.ensure((size_t)nT * 3 * 4) &&
               h->d_T64.ensure((size_t)nT * 7 * 8);
@@ -241,12 +241,13 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     np.key_x = h->d_key_x.as<float>(); np.n_keys = h->n_keys; np.n_scales = ns; np.max_neighbors = c.max_neighbors;
     for (int n = 0; n <= ns; ++n) np.scale_start[n] = h->scale_start[n];
     for (int n = 0; n < ns; ++n) np.r2[n] = c.radii[n] > 0 ? c.radii[n] * c.radii[n] : -1.0f;
-    np.qpos = h->d_qpos.as<float>(); np.n_dst = Nd; np.cnt = h->d_cnt.as<int>(); np.off = h->d_off.as<int>();
+    np.qpos = h->d_qpos.as<float>(); np.n_dst = Nd; np.cnt = h->d_cnt.as<int>(); np.off = h->d_off.as<int>(); np.blk = h->d_blk.as<int>();
     np.tile_info = h->d_tile.as<int>(); np.edge_src = h->d_esrc.as<int>(); np.edge_dst = h->d_edst.as<int>(); np.cap = h->edge_cap;
-    hipLaunchKernelGGL(k_neighbors<false>, dim3((Nd + 255) / 256), dim3(256), 0, st, np);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, h->d_cnt.as<int>(), h->d_off.as<int>(), Nd, ns, h->d_tile.as<int>(), h->edge_cap,
+    const int nblk = (Nd + kNbrBlock - 1) / kNbrBlock;
+    hipLaunchKernelGGL(k_neighbors<false>, dim3(nblk), dim3(kNbrBlock), 0, st, np);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, h->d_blk.as<int>(), nblk, ns, h->d_tile.as<int>(), h->edge_cap,
                        h->profile ? h->d_hist.as<long long>() : nullptr);
-    hipLaunchKernelGGL(k_neighbors<true>, dim3((Nd + 255) / 256), dim3(256), 0, st, np);
+    hipLaunchKernelGGL(k_neighbors<true>, dim3(nblk), dim3(kNbrBlock), 0, st, np);
     mark();
     // 4. fused edge pipeline
     {

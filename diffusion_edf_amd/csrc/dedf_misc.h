@@ -190,6 +190,8 @@ __global__ void k_src_message(const float* __restrict__ f, int n_pts, const floa
 // Radius neighbour search (torch_cluster.radius as used at graph_parser.py:339; all pairs for the infinite scale,
 // graph_parser.py:279-281).  Keys are tiny (<= a few thousand points) and static, queries move every step: brute force with
 // the key cloud streamed through LDS, one thread per destination node.  Edge order: scale, then dst, then src ascending.
+//   pass 1 (count):  cnt[n][d] and per-block totals;   k_scan: exclusive scan of the block totals + tile table;
+//   pass 2 (fill):   block-local exclusive scan of cnt + block offset -> off[n][d], then the edge lists.
 struct NbrParams {
     const float* key_x; int n_keys;
     int scale_start[kMaxScales + 1];
@@ -197,16 +199,34 @@ struct NbrParams {
     int n_scales, max_neighbors;
     const float* qpos; int n_dst;
     int* cnt;                             // [n_scales][n_dst]
-    const int* off;                       // [n_scales][n_dst]  exclusive prefix inside the scale
+    int* off;                             // [n_scales][n_dst]  exclusive prefix inside the scale
+    int* blk;                             // [n_scales][n_blocks] block totals (count) -> block offsets (after k_scan)
     const int* tile_info;                 // edge base per scale at [16 + n]
     int* edge_src; int* edge_dst;
     int64_t cap;
 };
 constexpr int kNbrChunk = 1024;
+constexpr int kNbrBlock = 256;
+
+// exclusive scan of one int per thread over a 256-thread block; returns the exclusive prefix, total in *total
+__device__ inline int block_exclusive_scan_256(int v, int* total) {
+    __shared__ int wsum[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int x = v;
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    __syncthreads();
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < w; ++i) base += wsum[i];
+    *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    return base + x - v;
+}
+
 template <bool FILL>
-__global__ void k_neighbors(NbrParams P) {
+__global__ __launch_bounds__(kNbrBlock) void k_neighbors(NbrParams P) {
     __shared__ float kx[kNbrChunk * 3];
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    const int d = blockIdx.x * kNbrBlock + threadIdx.x;
     const bool act = d < P.n_dst;
     float px = 0, py = 0, pz = 0;
     if (act) { px = P.qpos[3 * d]; py = P.qpos[3 * d + 1]; pz = P.qpos[3 * d + 2]; }
@@ -215,11 +235,18 @@ __global__ void k_neighbors(NbrParams P) {
         const float r2 = P.r2[n];
         int c = 0;
         int64_t base = 0;
-        if (FILL && act) base = (int64_t)P.tile_info[16 + n] + P.off[(size_t)n * P.n_dst + d];
+        if (FILL) {
+            const int mine = act ? P.cnt[(size_t)n * P.n_dst + d] : 0;
+            int total;
+            const int ex = block_exclusive_scan_256(mine, &total);
+            const int o = P.blk[(size_t)n * gridDim.x + blockIdx.x] + ex;
+            if (act) P.off[(size_t)n * P.n_dst + d] = o;
+            base = (int64_t)P.tile_info[16 + n] + o;
+        }
         for (int c0 = s0; c0 < s1; c0 += kNbrChunk) {
             const int nc = min(kNbrChunk, s1 - c0);
             __syncthreads();
-            for (int i = threadIdx.x; i < nc * 3; i += blockDim.x) kx[i] = P.key_x[(size_t)c0 * 3 + i];
+            for (int i = threadIdx.x; i < nc * 3; i += kNbrBlock) kx[i] = P.key_x[(size_t)c0 * 3 + i];
             __syncthreads();
             if (!act) continue;
             for (int i = 0; i < nc; ++i) {
@@ -232,27 +259,30 @@ __global__ void k_neighbors(NbrParams P) {
                 }
             }
         }
-        if (!FILL && act) P.cnt[(size_t)n * P.n_dst + d] = c;
+        if (!FILL) {
+            if (act) P.cnt[(size_t)n * P.n_dst + d] = c;
+            int total;
+            (void)block_exclusive_scan_256(act ? c : 0, &total);
+            if (threadIdx.x == 0) P.blk[(size_t)n * gridDim.x + blockIdx.x] = total;
+        }
     }
 }
 
-// exclusive scan of cnt[n][*] per scale + tile table.  One block of 1024 threads.
+// exclusive scan of the per-block totals of every scale (in place) + tile table.  One block of 1024 threads.
 // tile_info: [0..n_scales] tile prefix, [16..16+n_scales] edge prefix, [40] overflow flag
-__global__ void k_scan(const int* __restrict__ cnt, int* __restrict__ off, int n_dst, int n_scales, int* __restrict__ tile_info, int64_t cap,
+__global__ void k_scan(int* __restrict__ blk, int n_blocks, int n_scales, int* __restrict__ tile_info, int64_t cap,
                        long long* __restrict__ edge_hist) {
     __shared__ int part[1024];
-    __shared__ int carry;
     const int tid = threadIdx.x;
     int tiles = 0;
     int64_t edges = 0;
     if (tid == 0) { tile_info[0] = 0; tile_info[16] = 0; }
     for (int n = 0; n < n_scales; ++n) {
-        if (tid == 0) carry = 0;
-        __syncthreads();
-        const int per = (n_dst + 1023) / 1024;
-        const int i0 = tid * per, i1 = min(n_dst, i0 + per);
+        const int per = (n_blocks + 1023) / 1024;
+        const int i0 = min(n_blocks, tid * per), i1 = min(n_blocks, i0 + per);
         int s = 0;
-        for (int i = i0; i < i1; ++i) s += cnt[(size_t)n * n_dst + i];
+        for (int i = i0; i < i1; ++i) s += blk[(size_t)n * n_blocks + i];
+        __syncthreads();
         part[tid] = s;
         __syncthreads();
         for (int o = 1; o < 1024; o <<= 1) {          // Hillis-Steele inclusive scan
@@ -262,9 +292,8 @@ __global__ void k_scan(const int* __restrict__ cnt, int* __restrict__ off, int n
             __syncthreads();
         }
         int run = part[tid] - s;
-        for (int i = i0; i < i1; ++i) { off[(size_t)n * n_dst + i] = run; run += cnt[(size_t)n * n_dst + i]; }
+        for (int i = i0; i < i1; ++i) { const int c = blk[(size_t)n * n_blocks + i]; blk[(size_t)n * n_blocks + i] = run; run += c; }
         const int total = part[1023];
-        __syncthreads();
         edges += total;
         tiles += (total + 31) / 32;
         if (tid == 0) { tile_info[n + 1] = tiles; tile_info[16 + n + 1] = (int)min(edges, (int64_t)0x7fffffff); }
