@@ -22,13 +22,23 @@ template <int L> __global__ __launch_bounds__(64, 1) void k_edge(EdgeParams P) {
     const int* ti = P.tile_info;
     const int ntiles = ti[P.n_scales];
     const Wave wv = make_wave(P.W, P.W_bytes);
+#if defined(DEDF_PHASE_PROF)
+    unsigned long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         int scale = 0;
         while (t >= ti[scale + 1]) ++scale;
         const int k = t - ti[scale];
         const int ebase = ti[16 + scale], En = ti[16 + scale + 1] - ebase;
+#if defined(DEDF_PHASE_PROF)
+        edge_tile<L>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k), pacc);
+#else
         edge_tile<L>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k));
+#endif
     }
+#if defined(DEDF_PHASE_PROF)
+    if (P.phase_prof && wv.lane == 0) for (int i = 0; i < 12; ++i) P.phase_prof[blockIdx.x * 16 + i] += pacc[i];
+#endif
 }
 template <int L> __global__ __launch_bounds__(64, 1) void k_node(NodeParams P) {
     const Wave wv = make_wave(P.W, P.W_bytes);
@@ -86,7 +96,7 @@ struct dedf_handle {
     std::vector<hipEvent_t> ev;           // 7 events per evaluation
     size_t ev_used = 0;
     int64_t prof_evals = 0, prof_dst = 0;
-    DevBuf d_hist;
+    DevBuf d_hist, d_phase;
     ~dedf_handle() { for (auto e : ev) (void)hipEventDestroy(e); }
 };
 
@@ -273,6 +283,10 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         P.o_b_r0 = o.o_b_r0; P.o_b_val0 = o.o_b_val0; P.o_alpha_dot = o.o_alpha_dot;
         P.out = h->d_eout.as<float>();
         P.dbg_w = h->debug ? h->d_dbgw.as<float>() : nullptr;
+        P.phase_prof = nullptr;
+#if defined(DEDF_PHASE_PROF)
+        if (h->d_phase.ensure((size_t)h->n_cu * 4 * 16 * 8)) P.phase_prof = h->d_phase.as<unsigned long long>();
+#endif
         hipLaunchKernelGGL(k_edge<L>, dim3(h->n_cu * 4), dim3(64), 0, st, P);
     }
     mark();
@@ -575,6 +589,7 @@ int dedf_debug_copy(dedf_handle* h, const char* name, void* host_dst, size_t max
     else if (nm == "node_out") { src = h->d_nout.p; n = Nd * 8 * 4; }
     else if (nm == "tile_info") { src = h->d_tile.p; n = 64 * 4; }
     else if (nm == "dbg_w") { src = h->d_dbgw.p; n = h->d_dbgw.p ? E * WN * 4 : 0; }
+    else if (nm == "phase_prof") { src = h->d_phase.p; n = h->d_phase.bytes; }
     else return fail(h, DEDF_ERR_INVALID, "unknown debug buffer " + nm);
     if (actual_bytes) *actual_bytes = n;
     if (!host_dst) return DEDF_OK;

@@ -125,6 +125,36 @@ DEDF_DEV f32x16 ldrows(const Buf& b, int voff_hi64, int off, int tile) {
 }
 DEDF_DEV f32x16 ldrows(const Wave& wv, int off, int tile) { return ldrows(wv.w, wv.hi64, off, tile); }
 
+// Make a wave-uniform scalar opaque to the optimiser at this point.  Used on weight-image offsets at the top of every
+// tile: otherwise LICM hoists ~600 `offset + constant` values out of the persistent tile loop, spills them to VGPR lanes
+// and pays `v_readlane; s_nop 4` between MFMAs for every weight load.
+DEDF_DEV int opaque_s(int x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(x));
+#endif
+    return x;
+}
+
+// Dense layer  out[NTO tiles] += W * act  with the NTO accumulators rotated inside every K-group (consecutive MFMAs hit
+// different accumulators: an instruction between two MFMAs on the SAME accumulator costs a ~43-cycle bubble on gfx950).
+//   bop.operator()<kg, j>() -> B operand of K-step 4*kg + j;   A operands prefetched one K-group (NTO float4) ahead.
+template <int NTO, int NKG, int PD = 2, class BopF>
+DEDF_DEV void dense_rot(const Wave& wv, int off, f32x16 (&acc)[NTO], BopF&& bop) {
+    f32x4 ring[PD][NTO];
+    static_for<PD>([&]<int k>() { if constexpr (k < NKG) static_for<NTO>([&]<int To>() { ring[k][To] = lda(wv, off, NKG, To, k); }); });
+    static_for<NKG>([&]<int kg>() {
+        f32x4 cur[NTO];
+        static_for<NTO>([&]<int To>() { cur[To] = ring[kg % PD][To]; });
+        if constexpr (kg + PD < NKG) static_for<NTO>([&]<int To>() { ring[kg % PD][To] = lda(wv, off, NKG, To, kg + PD); });
+        sched_fence();
+        static_for<4>([&]<int j>() {
+            const float b = bop.template operator()<kg, j>();
+            static_for<NTO>([&]<int To>() { acc[To] = mfma32(cur[To][j], b, acc[To]); });
+        });
+        sched_fence();
+    });
+}
+
 // Software-pipelined stream of packed-A groups: the operand of item I+PD is requested before item I is consumed, and
 // scheduling fences keep hipcc from sinking the request back next to its use (it otherwise emits load -> vmcnt(0) -> MFMA
 // for every group and exposes the full L2 latency ~180 times per tile at one wave per SIMD).
@@ -158,7 +188,16 @@ DEDF_DEV float rcp(float x) {
     return 1.0f / x;
 #endif
 }
-DEDF_DEV float sigmoidf(float x) { return rcp(1.0f + expf(-x)); }
+// exp(x) as one v_exp_f32 on x*log2(e): relative error ~(1 + |x|) * 1e-7 (the argument product is rounded once),
+// 5x fewer instructions than libm expf; arguments here are activations of O(10).  Flushes to 0 / inf like exp2f.
+DEDF_DEV float fexp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+#else
+    return exp2f(x * 1.44269504088896340736f);
+#endif
+}
+DEDF_DEV float sigmoidf(float x) { return rcp(1.0f + fexp(-x)); }
 DEDF_DEV float siluf(float x) { return x * sigmoidf(x); }
 // normalize2mom-wrapped activations (reference equiformer/fast_activation.py:69)
 DEDF_DEV float silu_n(float x) { return siluf(x) * kNormSilu; }

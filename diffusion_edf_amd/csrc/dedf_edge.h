@@ -50,6 +50,7 @@ struct EdgeParams {
     int o_alpha_dot;          // row-packed over the two alpha tiles
     float* out;               // [E][edge_rec]
     float* dbg_w;             // optional [E][WN] dump of the radial weights (tests)
+    unsigned long long* phase_prof;   // optional [grid][16] per-wave phase cycle sums (built with -DDEDF_PHASE_PROF)
 };
 
 template <int L> struct SH {           // spherical harmonics of one edge, non-scalar blocks already cut off
@@ -77,14 +78,42 @@ DEDF_DEV void ln_silu(f32x16 (&x)[NT], const Wave& wv, int o_gamma, int o_beta) 
     });
 }
 
+#if defined(DEDF_PHASE_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define DEDF_STAMP(i)                                                  \
+    do {                                                               \
+        sched_fence();                                                 \
+        const unsigned long long t_now = __builtin_readcyclecounter(); \
+        pacc[i] += t_now - t_last;                                     \
+        t_last = t_now;                                                \
+        sched_fence();                                                 \
+    } while (0)
+#else
+#define DEDF_STAMP(i) do { } while (0)
+#endif
+#if defined(DEDF_PHASE_PROF)
+#define DEDF_PROF_ARG , unsigned long long (&pacc)[12]
+#else
+#define DEDF_PROF_ARG
+#endif
+
 template <int L>
-DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, int n_valid) {
+DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, int n_valid DEDF_PROF_ARG) {
+#if defined(DEDF_PHASE_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long t_last = __builtin_readcyclecounter();
+#endif
     constexpr int D = feat_dim<L>();
     constexpr int REC = edge_rec<L>();
     constexpr int WN = dtp_wn<L>();
     constexpr int NWT = WN / 32;
     constexpr int NR0 = r0_tiles<L>();
     const int hi = wv.hi;
+    // weight-image offsets, re-materialised per tile (see opaque_s)
+    const int o_A_r1 = opaque_s(P.o_A_r1), o_b_r1 = opaque_s(P.o_b_r1), o_g_r1 = opaque_s(P.o_g_r1), o_be_r1 = opaque_s(P.o_be_r1);
+    const int o_A_r2 = opaque_s(P.o_A_r2), o_b_r2 = opaque_s(P.o_b_r2), o_g_r2 = opaque_s(P.o_g_r2), o_be_r2 = opaque_s(P.o_be_r2);
+    const int o_A_r3 = opaque_s(P.o_A_r3), o_off_r3 = opaque_s(P.o_off_r3), o_b_r0 = opaque_s(P.o_b_r0);
+    const int o_b_val0 = opaque_s(P.o_b_val0), o_alpha_dot = opaque_s(P.o_alpha_dot);
+    int o_A_lin[L + 1], o_A_val[L + 1];
+    static_for<L + 1>([&]<int l>() { o_A_lin[l] = opaque_s(P.o_A_lin[l]); o_A_val[l] = opaque_s(P.o_A_val[l]); });
     const bool valid = wv.col < n_valid;
     const int e = e0 + (valid ? wv.col : 0);
     const int src = P.edge_src[e], dst = P.edge_dst[e];
@@ -133,7 +162,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 const f32x4 w = bld4(wv.w, hi128, (o_enc + 128 + 4 * G) * 4);
                 static_for<4>([&]<int J>() {
                     const float z = (t - mu[J]) * is[J];
-                    eb[4 * G + J] = expf(-0.5f * (z * z)) * w[J];
+                    eb[4 * G + J] = fexp(-0.5f * (z * z)) * w[J];
                 });
             });
         } else {                       // SinusoidalPositionEmbeddings(n = 1000), radial_func.py:305-316
@@ -145,122 +174,159 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         }
     }
 
+    DEDF_STAMP(0);
     // ---- edge pre-linear + SiLU (multiscale_tensor_field.py:225-234); time part + bias arrive as per-pose rows --------
     f32x16 h[4];
     {
         const Buf tbb = make_buf(P.tb, P.tb_bytes);
         const int tvoff = (pose * P.tb_pose_stride) * 4 + wv.hi64;
-        const int oA = P.o_A_pre + scale * (4 * 8 * 256);
+        const int oA = opaque_s(P.o_A_pre + scale * (4 * 8 * 256));
         static_for<4>([&]<int To>() { h[To] = ldrows(tbb, tvoff, scale * 128, To); });
-        a_stream<32, 4>(wv, [&]<int I>() { return (oA + I * 256) * 4; }, [&]<int I>(f32x4 a) {
-            constexpr int To = I / 8, g = I % 8;
-            mfma_group(h[To], a, eb[4 * g], eb[4 * g + 1], eb[4 * g + 2], eb[4 * g + 3]);
-        });
+        dense_rot<4, 8, 2>(wv, oA, h, [&]<int kg, int j>() { return eb[4 * kg + j]; });
         static_for<4>([&]<int To>() { static_for<16>([&]<int R>() { h[To][R] = siluf(h[To][R]); }); });
     }
+    DEDF_STAMP(1);
     // ---- RadialProfile layers 1, 2 (equiformer/radial_func.py:11-60) ---------------------------------------------------
     f32x16 r1[4];
-    static_for<4>([&]<int To>() { r1[To] = ldrows(wv, P.o_b_r1, To); });
-    a_stream<64, 4>(wv, [&]<int I>() { return (P.o_A_r1 + I * 256) * 4; }, [&]<int I>(f32x4 a) {
-        constexpr int To = I / 16, T = (I % 16) / 4, g = I % 4;
-        mfma_group(r1[To], a, h[T][4 * g], h[T][4 * g + 1], h[T][4 * g + 2], h[T][4 * g + 3]);
-    });
-    ln_silu<4>(r1, wv, P.o_g_r1, P.o_be_r1);
+    static_for<4>([&]<int To>() { r1[To] = ldrows(wv, o_b_r1, To); });
+    dense_rot<4, 16, 2>(wv, o_A_r1, r1, [&]<int kg, int j>() { return h[kg / 4][4 * (kg % 4) + j]; });
+    DEDF_STAMP(2);
+    ln_silu<4>(r1, wv, o_g_r1, o_be_r1);
+    DEDF_STAMP(3);
     f32x16 r2[2];
-    static_for<2>([&]<int To>() { r2[To] = ldrows(wv, P.o_b_r2, To); });
-    a_stream<32, 4>(wv, [&]<int I>() { return (P.o_A_r2 + I * 256) * 4; }, [&]<int I>(f32x4 a) {
-        constexpr int To = I / 16, T = (I % 16) / 4, g = I % 4;
-        mfma_group(r2[To], a, r1[T][4 * g], r1[T][4 * g + 1], r1[T][4 * g + 2], r1[T][4 * g + 3]);
-    });
-    ln_silu<2>(r2, wv, P.o_g_r2, P.o_be_r2);
+    static_for<2>([&]<int To>() { r2[To] = ldrows(wv, o_b_r2, To); });
+    dense_rot<2, 16, 4>(wv, o_A_r2, r2, [&]<int kg, int j>() { return r1[kg / 4][4 * (kg % 4) + j]; });
+    DEDF_STAMP(4);
+    ln_silu<2>(r2, wv, o_g_r2, o_be_r2);
+    DEDF_STAMP(5);
 
     // ---- layer 3 (-> per-edge TP weights, one 32-row tile at a time) fused with DTP #1 and the lin / sep_alpha GEMMs ----
     // accumulators: l3 = 0 -> NR0 tiles (lin scalars+gates | alpha), l3 >= 1 -> one tile per m
     constexpr int NACC = NR0 + (L >= 1 ? 3 : 0) + (L >= 2 ? 5 : 0);
     constexpr int AB1 = NR0, AB2 = NR0 + 3;   // first accumulator tile of the l3 = 1 / l3 = 2 outputs
     f32x16 acc[NACC];
-    static_for<NR0>([&]<int T>() { acc[T] = ldrows(wv, P.o_b_r0, T); });
+    static_for<NR0>([&]<int T>() { acc[T] = ldrows(wv, o_b_r0, T); });
     static_for<NACC - NR0>([&]<int T>() { static_for<16>([&]<int R>() { acc[NR0 + T][R] = 0.0f; }); });
     const Buf msgb = make_buf(P.msg, P.msg_bytes);
     // per-l1 lane offsets of the 4 message rows this lane owns inside an 8-row group
     const int mv0 = src * (D * 4) + hi * 16, mv1 = src * (D * 4) + hi * 48, mv2 = src * (D * 4) + hi * 80;
 
-    // operands of one DTP group (8 weight rows): A operands of the lin GEMM(s) it feeds + this lane's 4 source-message rows
-    struct GroupOps { f32x4 a[NR0]; f32x4 x[2 * L + 1]; };
-    auto load_group = [&]<int G>() {
-        GroupOps o;
-        if constexpr (G < WN / 8) {
+    // Software pipeline over the WN/8 depth-wise-TP groups (8 weight rows = 4 K-steps each).  Region G issues, in one
+    // scheduling region so that hipcc interleaves them:  loads for G+1 / G+2,  the layer-3 MFMAs of the NEXT weight tile,
+    // the lane-local Clebsch-Gordan VALU work of group G+1 (-> its B operands),  and the lin / sep_alpha MFMAs of group G.
+    constexpr int NGRP = WN / 8;
+    struct AOps { f32x4 a[NR0]; };
+    struct XOps { f32x4 x[2 * L + 1]; };
+    struct BOps { float b[4][2 * L + 1]; };
+    auto load_A = [&]<int G>() {
+        AOps o;
+        if constexpr (G < NGRP) {
             constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(G * 8));
-            constexpr int l1 = pi.l1, l3 = pi.l3, d1 = 2 * l1 + 1, u0 = G * 8 - pi.wstart;
-            constexpr int gi = dtp_group_index<L>(G), NG = dtp_k<L>(l3) / 8;
-            if constexpr (l3 == 0) static_for<NR0>([&]<int To>() { o.a[To] = lda(wv, P.o_A_lin[0], NG, To, gi); });
-            else o.a[0] = lda(wv, P.o_A_lin[l3], NG, 0, gi);
+            constexpr int l3 = pi.l3, gi = dtp_group_index<L>(G), NG = dtp_k<L>(l3) / 8;
+            if constexpr (l3 == 0) static_for<NR0>([&]<int To>() { o.a[To] = lda(wv, o_A_lin[0], NG, To, gi); });
+            else o.a[0] = lda(wv, o_A_lin[l3], NG, 0, gi);
+        }
+        return o;
+    };
+    auto load_X = [&]<int G>() {      // this lane's 4 source-message rows of the group (contiguous in the reference layout)
+        XOps o;
+        if constexpr (G < NGRP) {
+            constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(G * 8));
+            constexpr int l1 = pi.l1, d1 = 2 * l1 + 1, u0 = G * 8 - pi.wstart;
             const int mv = l1 == 0 ? mv0 : (l1 == 1 ? mv1 : mv2);
             static_for<d1>([&]<int Q>() { o.x[Q] = bld4(msgb, mv, (blk_off(l1) + u0 * d1 + 4 * Q) * 4); });
         }
         return o;
     };
-    // layer-3 A operands: one global stream over all tiles, 4 groups (>= 1000 cycles of MFMA work) ahead
-    constexpr int NL3 = NWT * 8, PD3 = 4;
-    f32x4 l3ring[PD3];
-    static_for<PD3>([&]<int I>() { l3ring[I] = bld4(wv.w, wv.lane16, (P.o_A_r3 + I * 256) * 4); });
-    GroupOps gcur = load_group.template operator()<0>();
-    f32x16 wt = ldrows(wv, P.o_off_r3, 0);
-    static_for<NWT>([&]<int Tw>() {
-        static_for<8>([&]<int gg>() {
-            constexpr int I = Tw * 8 + gg, T = gg / 4, g = gg % 4;
-            const f32x4 a = l3ring[I % PD3];
-            if constexpr (I + PD3 < NL3) l3ring[I % PD3] = bld4(wv.w, wv.lane16, (P.o_A_r3 + (I + PD3) * 256) * 4);
-            sched_fence();
-            mfma_group(wt, a, r2[T][4 * g], r2[T][4 * g + 1], r2[T][4 * g + 2], r2[T][4 * g + 3]);
-            sched_fence();
-        });
-        if (P.dbg_w != nullptr && valid)
-            static_for<16>([&]<int R>() { P.dbg_w[(size_t)e * WN + Tw * 32 + rowmap(R, hi)] = wt[R]; });
-        f32x16 wt_next = wt;
-        if constexpr (Tw + 1 < NWT) wt_next = ldrows(wv, P.o_off_r3, Tw + 1);
-        static_for<4>([&]<int g>() {
-            constexpr int G = Tw * 4 + g;
-            constexpr int wrow0 = G * 8;
-            constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(wrow0));
-            constexpr int l1 = pi.l1, l2 = pi.l2, l3 = pi.l3;
-            constexpr int d1 = 2 * l1 + 1, d3 = 2 * l3 + 1;
-            const GroupOps gnext = load_group.template operator()<G + 1>();
-            sched_fence();
+    auto valu_group = [&]<int G>(const XOps& xo, const f32x16& wtile) {
+        BOps o;
+        if constexpr (G < NGRP) {
+            constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(G * 8));
+            constexpr int l1 = pi.l1, l2 = pi.l2, l3 = pi.l3, d1 = 2 * l1 + 1, d3 = 2 * l3 + 1, g = G % 4;
             using C = CG<l1, l2, l3>;
             float m[C::NM];
             C::make(Y.template get<l2>(), m);
             float xr[4 * d1];
             static_for<d1>([&]<int Q>() {
-                xr[4 * Q] = gcur.x[Q][0]; xr[4 * Q + 1] = gcur.x[Q][1]; xr[4 * Q + 2] = gcur.x[Q][2]; xr[4 * Q + 3] = gcur.x[Q][3];
+                xr[4 * Q] = xo.x[Q][0]; xr[4 * Q + 1] = xo.x[Q][1]; xr[4 * Q + 2] = xo.x[Q][2]; xr[4 * Q + 3] = xo.x[Q][3];
             });
-            float a[4][d3];
             static_for<4>([&]<int j>() {
-                float o[d3];
-                C::apply(&xr[j * d1], m, o);
-                static_for<d3>([&]<int K>() { a[j][K] = o[K] * wt[4 * g + j]; });
+                float t[d3];
+                C::apply(&xr[j * d1], m, t);
+                static_for<d3>([&]<int K>() { o.b[j][K] = t[K] * wtile[4 * g + j]; });
             });
-            if constexpr (l3 == 0) {
-                static_for<NR0>([&]<int To>() { mfma_group(acc[To], gcur.a[To], a[0][0], a[1][0], a[2][0], a[3][0]); });
-            } else {
-                static_for<d3>([&]<int K>() {
-                    mfma_group(acc[(l3 == 1 ? AB1 : AB2) + K], gcur.a[0], a[0][K], a[1][K], a[2][K], a[3][K]);
-                });
-            }
+        }
+        return o;
+    };
+    auto mfma_dtp = [&]<int G>(const AOps& ao, const BOps& bo) {
+        constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(G * 8));
+        constexpr int l3 = pi.l3, d3 = 2 * l3 + 1;
+        if constexpr (l3 == 0) {
+            static_for<NR0>([&]<int To>() { mfma_group(acc[To], ao.a[To], bo.b[0][0], bo.b[1][0], bo.b[2][0], bo.b[3][0]); });
+        } else {
+            static_for<d3>([&]<int K>() {
+                mfma_group(acc[(l3 == 1 ? AB1 : AB2) + K], ao.a[0], bo.b[0][K], bo.b[1][K], bo.b[2][K], bo.b[3][K]);
+            });
+        }
+    };
+    // layer-3 A operands: one global stream over all tiles, PD3 groups ahead
+    constexpr int NL3 = NWT * 8, PD3 = 4;
+    f32x4 l3ring[PD3];
+    static_for<PD3>([&]<int I>() { l3ring[I] = bld4(wv.w, wv.lane16, (o_A_r3 + I * 256) * 4); });
+    auto l3_group = [&]<int I>(f32x16& w) {
+        constexpr int gg = I % 8, T = gg / 4, g = gg % 4;
+        const f32x4 a = l3ring[I % PD3];
+        if constexpr (I + PD3 < NL3) l3ring[I % PD3] = bld4(wv.w, wv.lane16, (o_A_r3 + (I + PD3) * 256) * 4);
+        mfma_group(w, a, r2[T][4 * g], r2[T][4 * g + 1], r2[T][4 * g + 2], r2[T][4 * g + 3]);
+    };
+    auto dump_w = [&]<int Tw>(const f32x16& w) {
+        if (P.dbg_w != nullptr && valid)
+            static_for<16>([&]<int R>() { P.dbg_w[(size_t)e * WN + Tw * 32 + rowmap(R, hi)] = w[R]; });
+    };
+    DEDF_STAMP(6);
+    // prologue: weight tile 0, operands of groups 0 / 1, B operands of group 0
+    AOps a_cur = load_A.template operator()<0>();
+    XOps x_nxt = load_X.template operator()<1>();
+    f32x16 wt = ldrows(wv, o_off_r3, 0);
+    BOps b_cur;
+    {
+        const XOps x0 = load_X.template operator()<0>();
+        static_for<8>([&]<int gg>() { sched_fence(); l3_group.template operator()<gg>(wt); });
+        sched_fence();
+        dump_w.template operator()<0>(wt);
+        b_cur = valu_group.template operator()<0>(x0, wt);
+    }
+    DEDF_STAMP(7);
+    static_for<NWT>([&]<int Tw>() {
+        f32x16 wt_next = wt;
+        if constexpr (Tw + 1 < NWT) wt_next = ldrows(wv, o_off_r3, Tw + 1);
+        static_for<4>([&]<int g>() {
+            constexpr int G = Tw * 4 + g;
+            const AOps a_nxt = load_A.template operator()<G + 1>();
+            const XOps x_nn = load_X.template operator()<G + 2>();
             sched_fence();
-            gcur = gnext;
+            if constexpr (Tw + 1 < NWT) {       // layer 3 of the next tile: groups {0,1,2 | 3,4,5 | 6,7 | -}
+                constexpr int first = g * 3, cnt = g == 0 || g == 1 ? 3 : (g == 2 ? 2 : 0);
+                static_for<cnt>([&]<int k>() { l3_group.template operator()<(Tw + 1) * 8 + first + k>(wt_next); });
+            }
+            const BOps b_nxt = valu_group.template operator()<G + 1>(x_nxt, g == 3 ? wt_next : wt);
+            mfma_dtp.template operator()<G>(a_cur, b_cur);
+            sched_fence();
+            if constexpr (g == 2 && Tw + 1 < NWT) dump_w.template operator()<Tw + 1>(wt_next);
+            a_cur = a_nxt; x_nxt = x_nn; b_cur = b_nxt;
         });
         wt = wt_next;
     });
 
+    DEDF_STAMP(8);
     // ---- attention logits (graph_attention.py:233-246): heads of sep_alpha -> SmoothLeakyReLU -> . alpha_dot + log cut-off
     float logit[kHeads];
     {
         constexpr int AT = alpha_row0<L>() / 32;
         static_for<kHeads>([&]<int hd>() {
             constexpr int T = AT + (hd >> 1), r0 = 8 * (hd & 1);
-            const f32x4 d0 = bld4(wv.w, wv.hi64, (P.o_alpha_dot + (hd >> 1) * 32 + r0) * 4);
-            const f32x4 d1v = bld4(wv.w, wv.hi64, (P.o_alpha_dot + (hd >> 1) * 32 + r0 + 4) * 4);
+            const f32x4 d0 = bld4(wv.w, wv.hi64, (o_alpha_dot + (hd >> 1) * 32 + r0) * 4);
+            const f32x4 d1v = bld4(wv.w, wv.hi64, (o_alpha_dot + (hd >> 1) * 32 + r0 + 4) * 4);
             float s = 0.0f;
             static_for<4>([&]<int R>() { s += slrelu_n(acc[T][r0 + R]) * d0[R]; });
             static_for<4>([&]<int R>() { s += slrelu_n(acc[T][r0 + 4 + R]) * d1v[R]; });
@@ -290,52 +356,64 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     }
     sched_fence();
 
+    DEDF_STAMP(9);
     // ---- sep_value: depth-wise TP #2 (shared weights folded into A_val) + LinearRS -> value --------------------------------
     constexpr int NV = 2 + (L >= 1 ? 3 : 0) + (L >= 2 ? 5 : 0);
     f32x16 val[NV];
-    static_for<2>([&]<int T>() { val[T] = ldrows(wv, P.o_b_val0, T); });
+    static_for<2>([&]<int T>() { val[T] = ldrows(wv, o_b_val0, T); });
     static_for<NV - 2>([&]<int T>() { static_for<16>([&]<int R>() { val[2 + T][R] = 0.0f; }); });
-    // groups are walked in weight order (= path creation order, u ascending); A operands two groups ahead
+    // groups are walked in weight order (= path creation order, u ascending); region G = loads(G+2), VALU(G+1), MFMA(G)
     struct ValOps { f32x4 a[2]; };
     auto load_val = [&]<int G>() {
         ValOps o;
-        if constexpr (G < WN / 8) {
+        if constexpr (G < NGRP) {
             constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(G * 8));
             constexpr int l3 = pi.l3, gi = dtp_group_index<L>(G), NG = dtp_k<L>(l3) / 8;
-            o.a[0] = lda(wv, P.o_A_val[l3], NG, 0, gi);
-            if constexpr (l3 == 0) o.a[1] = lda(wv, P.o_A_val[0], NG, 1, gi);
+            o.a[0] = lda(wv, o_A_val[l3], NG, 0, gi);
+            if constexpr (l3 == 0) o.a[1] = lda(wv, o_A_val[0], NG, 1, gi);
+        }
+        return o;
+    };
+    auto valu_val = [&]<int G>() {
+        BOps o;
+        if constexpr (G < NGRP) {
+            constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(G * 8));
+            constexpr int l1 = pi.l1, l2 = pi.l2, l3 = pi.l3, d1 = 2 * l1 + 1, d3 = 2 * l3 + 1;
+            constexpr int gu = (G * 8 - pi.wstart) / 8;
+            using C = CG<l1, l2, l3>;
+            float m[C::NM];
+            C::make(Y.template get<l2>(), m);
+            static_for<4>([&]<int j>() {
+                float x[d1], t[d3];
+                if constexpr (l1 == 0) x[0] = u0[gu / 4][4 * (gu % 4) + j];
+                else if constexpr (l1 == 1) { static_for<3>([&]<int I>() { x[I] = u1[I][4 * gu + j]; }); }
+                else { static_for<5>([&]<int I>() { x[I] = u2[I][4 * gu + j]; }); }
+                C::apply(x, m, t);
+                static_for<d3>([&]<int K>() { o.b[j][K] = t[K]; });
+            });
         }
         return o;
     };
     ValOps v0 = load_val.template operator()<0>(), v1 = load_val.template operator()<1>();
-    static_for<WN / 8>([&]<int G>() {
+    BOps vb_cur = valu_val.template operator()<0>();
+    static_for<NGRP>([&]<int G>() {
         constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(G * 8));
-        constexpr int l1 = pi.l1, l2 = pi.l2, l3 = pi.l3;
-        constexpr int d1 = 2 * l1 + 1, d3 = 2 * l3 + 1;
-        constexpr int gu = (G * 8 - pi.wstart) / 8;
+        constexpr int l3 = pi.l3, d3 = 2 * l3 + 1;
         const ValOps v2 = load_val.template operator()<G + 2>();
         sched_fence();
-        using C = CG<l1, l2, l3>;
-        float m[C::NM];
-        C::make(Y.template get<l2>(), m);
-        float a[4][d3];
-        static_for<4>([&]<int j>() {
-            float x[d1], o[d3];
-            if constexpr (l1 == 0) x[0] = u0[gu / 4][4 * (gu % 4) + j];
-            else if constexpr (l1 == 1) { static_for<3>([&]<int I>() { x[I] = u1[I][4 * gu + j]; }); }
-            else { static_for<5>([&]<int I>() { x[I] = u2[I][4 * gu + j]; }); }
-            C::apply(x, m, o);
-            static_for<d3>([&]<int K>() { a[j][K] = o[K]; });
-        });
+        const BOps vb_nxt = valu_val.template operator()<G + 1>();
         if constexpr (l3 == 0) {
-            static_for<2>([&]<int To>() { mfma_group(val[To], v0.a[To], a[0][0], a[1][0], a[2][0], a[3][0]); });
+            static_for<2>([&]<int To>() { mfma_group(val[To], v0.a[To], vb_cur.b[0][0], vb_cur.b[1][0], vb_cur.b[2][0], vb_cur.b[3][0]); });
         } else {
-            static_for<d3>([&]<int K>() { mfma_group(val[(l3 == 1 ? 2 : 5) + K], v0.a[0], a[0][K], a[1][K], a[2][K], a[3][K]); });
+            static_for<d3>([&]<int K>() {
+                mfma_group(val[(l3 == 1 ? 2 : 5) + K], v0.a[0], vb_cur.b[0][K], vb_cur.b[1][K], vb_cur.b[2][K], vb_cur.b[3][K]);
+            });
         }
         sched_fence();
-        v0 = v1; v1 = v2;
+        v0 = v1; v1 = v2; vb_cur = vb_nxt;
     });
 
+    DEDF_STAMP(10);
     // ---- store the edge record: value in internal layout [l][m][channel] + one logit per head ----------------------------
     if (valid) {
         float* o = P.out + (size_t)e * REC;
@@ -352,6 +430,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         }); });
         if (hi == 0) st4(o + D, f32x4{logit[0], logit[1], logit[2], logit[3]});
     }
+    DEDF_STAMP(11);
 }
 
 }  // namespace dedf

@@ -1,0 +1,25 @@
+import os, sys, torch, numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import bench
+from diffusion_edf_amd.score_head import ScoreModelHead
+dev = torch.device('cuda:0')
+kw, cfg, P, keys, query, Ts = bench.build_inputs(2, 4096, 1024, 1000, 0, dev)
+head = ScoreModelHead(**kw); head.load_state_dict(P); head.to(dev)
+t = torch.full((1000,), 0.5, device=dev)
+for _ in range(3): head(Ts.float(), keys, query, t)
+torch.cuda.synchronize()
+# zero prof
+import ctypes as C
+from diffusion_edf_amd import _lib
+buf = head.debug_buffer('phase_prof')   # float32 view of u64 data
+raw0 = buf.numpy().view(np.uint64).reshape(-1, 16).copy()
+head(Ts.float(), keys, query, t); torch.cuda.synchronize()
+raw1 = head.debug_buffer('phase_prof').numpy().view(np.uint64).reshape(-1, 16)
+d = (raw1 - raw0).astype(np.float64)
+names = ["geom+enc", "prelin+silu", "L1 mfma", "L1 LN+silu", "L2 mfma", "L2 LN+silu", "accinit", "E prologue(wt0)", "E main", "logits+gate", "F main", "stores"]
+tot = d[:, :12].sum(1).mean()
+E = head.stats()['n_edges_total']; tiles = sum((e + 31)//32 for e in head.stats()['n_edges'])
+print("edges", E, "tiles", tiles, "tiles/wave", tiles / d.shape[0])
+for i, n in enumerate(names):
+    print(f"{n:18s} {d[:, i].mean() / (tiles / d.shape[0]):10.0f} cycles/tile  {100 * d[:, i].mean() / tot:5.1f}%")
+print("total cycles/tile", tot / (tiles / d.shape[0]))
