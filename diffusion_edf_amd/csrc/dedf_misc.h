@@ -323,31 +323,30 @@ __global__ void k_aggregate(const float* __restrict__ edge_out, const int* __res
     if (ci < blk_off(1)) head = ci / (mul_of(0) / kHeads);
     else if (L >= 1 && ci < blk_off(2)) head = ((ci - blk_off(1)) % mul_of(1)) / (mul_of(1) / kHeads);
     else if (L >= 2) head = ((ci - blk_off(2)) % mul_of(2)) / (mul_of(2) / kHeads);
-    float mx[kHeads];
+    // single pass, online softmax: running max / sum per head, accumulator rescaled when a head's max grows
+    float mx[kHeads], sum[kHeads] = {0, 0, 0, 0};
     for (int h = 0; h < kHeads; ++h) mx[h] = -INFINITY;
-    for (int n = 0; n < n_scales; ++n) {
-        const int c = cnt[(size_t)n * n_dst + d];
-        const size_t e0 = (size_t)tile_info[16 + n] + off[(size_t)n * n_dst + d];
-        for (int j = 0; j < c; ++j) {
-            const f32x4 lg = ld4(edge_out + (e0 + j) * REC + D);
-            for (int h = 0; h < kHeads; ++h) mx[h] = fmaxf(mx[h], lg[h]);
-        }
-    }
-    float sum[kHeads] = {0, 0, 0, 0};
     f32x4 acc = {0, 0, 0, 0};
     for (int n = 0; n < n_scales; ++n) {
         const int c = cnt[(size_t)n * n_dst + d];
         const size_t e0 = (size_t)tile_info[16 + n] + off[(size_t)n * n_dst + d];
+        const float* rec = edge_out + e0 * REC;
+        f32x4 v_nxt = {0, 0, 0, 0}, lg_nxt = {0, 0, 0, 0};
+        if (c > 0) { lg_nxt = ld4(rec + D); if (lane < NV) v_nxt = ld4(rec + ci); }
         for (int j = 0; j < c; ++j) {
-            const float* rec = edge_out + (e0 + j) * REC;
-            const f32x4 lg = ld4(rec + D);
-            float p[kHeads];
-            for (int h = 0; h < kHeads; ++h) { p[h] = expf(lg[h] - mx[h]); sum[h] += p[h]; }
-            if (lane < NV) {
-                const f32x4 v = ld4(rec + ci);
-                const float ph = head == 0 ? p[0] : (head == 1 ? p[1] : (head == 2 ? p[2] : p[3]));
-                acc += v * ph;
+            const f32x4 lg = lg_nxt, v = v_nxt;
+            if (j + 1 < c) { lg_nxt = ld4(rec + (size_t)(j + 1) * REC + D); if (lane < NV) v_nxt = ld4(rec + (size_t)(j + 1) * REC + ci); }
+            float p[kHeads], sc[kHeads];
+            for (int h = 0; h < kHeads; ++h) {
+                const float m_new = fmaxf(mx[h], lg[h]);
+                sc[h] = expf(mx[h] - m_new);            // exp(-inf) = 0 on the first edge
+                p[h] = expf(lg[h] - m_new);
+                sum[h] = sum[h] * sc[h] + p[h];
+                mx[h] = m_new;
             }
+            const float ph = head == 0 ? p[0] : (head == 1 ? p[1] : (head == 2 ? p[2] : p[3]));
+            const float sh = head == 0 ? sc[0] : (head == 1 ? sc[1] : (head == 2 ? sc[2] : sc[3]));
+            acc = acc * sh + v * ph;
         }
     }
     if (lane < NV) {
