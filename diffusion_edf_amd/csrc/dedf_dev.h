@@ -155,6 +155,23 @@ DEDF_DEV void dense_rot(const Wave& wv, int off, f32x16 (&acc)[NTO], BopF&& bop)
     });
 }
 
+// One output tile (To) applied to NM independent right-hand sides that share the A operands (e.g. the 2l+1 components of
+// an l-block): NM accumulators rotate, A operands prefetched PD groups ahead.   bop<m, kg, j>() -> B operand.
+template <int NM, int NKG, int PD = 2, class BopF>
+DEDF_DEV void dense_shared(const Wave& wv, int off, int nG, int To, int g0, f32x16 (&acc)[NM], BopF&& bop) {
+    f32x4 ring[PD];
+    static_for<PD>([&]<int k>() { if constexpr (k < NKG) ring[k] = lda(wv, off, nG, To, g0 + k); });
+    static_for<NKG>([&]<int kg>() {
+        const f32x4 cur = ring[kg % PD];
+        if constexpr (kg + PD < NKG) ring[kg % PD] = lda(wv, off, nG, To, g0 + kg + PD);
+        sched_fence();
+        static_for<4>([&]<int j>() {
+            static_for<NM>([&]<int m>() { acc[m] = mfma32(cur[j], bop.template operator()<m, kg, j>(), acc[m]); });
+        });
+        sched_fence();
+    });
+}
+
 // Software-pipelined stream of packed-A groups: the operand of item I+PD is requested before item I is consumed, and
 // scheduling fences keep hipcc from sinking the request back next to its use (it otherwise emits load -> vmcnt(0) -> MFMA
 // for every group and exposes the full L2 latency ~180 times per tile at one wave per SIMD).

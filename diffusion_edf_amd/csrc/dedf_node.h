@@ -50,6 +50,20 @@ template <int L>
 DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     constexpr int D = feat_dim<L>();
     const int hi = wv.hi;
+    // weight-image offsets, re-materialised per tile (see opaque_s)
+    struct Off {
+        int A_proj[L + 1], b_proj0, ln_w[L + 1], ln_b0, A_f1[L + 1], b_f1, A_f2[L + 1], b_f2;
+        int A_s[2][stp_num_paths<L>()], A_sl[2][2], b_sl[2];
+    } O;
+    static_for<L + 1>([&]<int l>() {
+        O.A_proj[l] = opaque_s(P.o_A_proj[l]); O.ln_w[l] = opaque_s(P.o_ln_w[l]);
+        O.A_f1[l] = opaque_s(P.o_A_f1[l]); O.A_f2[l] = opaque_s(P.o_A_f2[l]);
+    });
+    O.b_proj0 = opaque_s(P.o_b_proj0); O.ln_b0 = opaque_s(P.o_ln_b0); O.b_f1 = opaque_s(P.o_b_f1); O.b_f2 = opaque_s(P.o_b_f2);
+    static_for<2>([&]<int t>() {
+        static_for<stp_num_paths<L>()>([&]<int p>() { O.A_s[t][p] = opaque_s(P.o_A_s[t][p]); });
+        O.A_sl[t][0] = opaque_s(P.o_A_sl[t][0]); O.A_sl[t][1] = opaque_s(P.o_A_sl[t][1]); O.b_sl[t] = opaque_s(P.o_b_sl[t]);
+    });
     const bool valid = n0 + wv.col < P.n_nodes;
     const int n = valid ? n0 + wv.col : n0;
     const int pose = n / P.nQ, q = n - pose * P.nQ;
@@ -75,29 +89,18 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
 
     // ---- proj: per-l dense matrix (+ bias on 0e) ---------------------------------------------------------------------------
     Feat<L> emb;
-    static_for<2>([&]<int To>() {
-        emb.s[To] = ldrows(wv, P.o_b_proj0, To);
-        static_for<8>([&]<int g>() {
-            mfma_group(emb.s[To], lda(wv, P.o_A_proj[0], 8, To, g), feat_b<L, 0, 0, g, 0>(z), feat_b<L, 0, 0, g, 1>(z),
-                       feat_b<L, 0, 0, g, 2>(z), feat_b<L, 0, 0, g, 3>(z));
-        });
-    });
-    sched_fence();
-    if constexpr (L >= 1) static_for<3>([&]<int m>() {
-        f32x16 a = {0};
-        static_for<4>([&]<int g>() {
-            mfma_group(a, lda(wv, P.o_A_proj[1], 4, 0, g), z.v1[m][4 * g], z.v1[m][4 * g + 1], z.v1[m][4 * g + 2], z.v1[m][4 * g + 3]);
-        });
-        static_for<16>([&]<int R>() { emb.v1[m][R] = a[R]; });
-    });
-    if constexpr (L >= 2) static_for<5>([&]<int m>() {
-        f32x16 a = {0};
-        static_for<2>([&]<int g>() {
-            mfma_group(a, lda(wv, P.o_A_proj[2], 2, 0, g), z.v2[m][4 * g], z.v2[m][4 * g + 1], z.v2[m][4 * g + 2], z.v2[m][4 * g + 3]);
-        });
-        static_for<8>([&]<int R>() { emb.v2[m][R] = a[R]; });
-    });
-    sched_fence();
+    static_for<2>([&]<int To>() { emb.s[To] = ldrows(wv, O.b_proj0, To); });
+    dense_rot<2, 8>(wv, O.A_proj[0], emb.s, [&]<int kg, int j>() { return z.s[kg / 4][4 * (kg % 4) + j]; });
+    if constexpr (L >= 1) {
+        f32x16 a[3] = {{0}, {0}, {0}};
+        dense_shared<3, 4>(wv, O.A_proj[1], 4, 0, 0, a, [&]<int m, int kg, int j>() { return z.v1[m][4 * kg + j]; });
+        static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { emb.v1[m][R] = a[m][R]; }); });
+    }
+    if constexpr (L >= 2) {
+        f32x16 a[5] = {{0}, {0}, {0}, {0}, {0}};
+        dense_shared<5, 2>(wv, O.A_proj[2], 2, 0, 0, a, [&]<int m, int kg, int j>() { return z.v2[m][4 * kg + j]; });
+        static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { emb.v2[m][R] = a[m][R]; }); });
+    }
 
     // ---- EquivariantLayerNormV2 (equiformer/layer_norm.py:91-156) ----------------------------------------------------------
     Feat<L> nrm;
@@ -111,7 +114,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         v += xor32(v);
         const float rs = 1.0f / sqrtf(v * (1.0f / 64) + 1e-5f);
         static_for<2>([&]<int T>() {
-            const f32x16 w = ldrows(wv, P.o_ln_w[0], T), b = ldrows(wv, P.o_ln_b0, T);
+            const f32x16 w = ldrows(wv, O.ln_w[0], T), b = ldrows(wv, O.ln_b0, T);
             static_for<16>([&]<int R>() { nrm.s[T][R] = (emb.s[T][R] - mean) * (rs * w[R]) + b[R]; });
         });
     }
@@ -120,7 +123,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { v += emb.v1[m][R] * emb.v1[m][R]; }); });
         v += xor32(v);
         const float rs = 1.0f / sqrtf(v * (1.0f / (3 * 32)) + 1e-5f);
-        const f32x16 w = ldrows(wv, P.o_ln_w[1], 0);
+        const f32x16 w = ldrows(wv, O.ln_w[1], 0);
         static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { nrm.v1[m][R] = emb.v1[m][R] * (rs * w[R]); }); });
     }
     if constexpr (L >= 2) {
@@ -128,84 +131,57 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { v += emb.v2[m][R] * emb.v2[m][R]; }); });
         v += xor32(v);
         const float rs = 1.0f / sqrtf(v * (1.0f / (5 * 16)) + 1e-5f);
-        const f32x16 w = ldrows(wv, P.o_ln_w[2], 0);
+        const f32x16 w = ldrows(wv, O.ln_w[2], 0);
         static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { nrm.v2[m][R] = emb.v2[m][R] * (rs * w[R]); }); });
     }
 
     // ---- FFN: FCTP+SwishGate (D -> 336x0e+96x1e+48x2e) -> Gate -> FCTP (-> D), + residual (gnn_block.py:51-57, 210-216) ----
     Feat<L> fld;
-    {   // l = 0: 6 scalar tiles stream through SiLU straight into fctp_2's K-steps
+    constexpr int NF1 = f1_rows0<L>() / 32 + (f1_rows0<L>() % 32 ? 1 : 0);     // 11 (L=2) / 9 (L=1) tiles of fctp_1's 0e rows
+    {   // l = 0: 192 hidden scalars (6 tiles) -> SiLU -> fctp_2
+        f32x16 hs[6];
+        static_for<6>([&]<int To>() { hs[To] = ldrows(wv, O.b_f1, To); });
+        dense_rot<6, 8>(wv, O.A_f1[0], hs, [&]<int kg, int j>() { return nrm.s[kg / 4][4 * (kg % 4) + j]; });
+        static_for<6>([&]<int To>() { static_for<16>([&]<int R>() { hs[To][R] = silu_n(hs[To][R]); }); });
         f32x16 o0[2];
-        static_for<2>([&]<int T>() { o0[T] = ldrows(wv, P.o_b_f2, T); });
-        static_for<6>([&]<int To>() {
-            f32x16 a = ldrows(wv, P.o_b_f1, To);
-            static_for<8>([&]<int g>() {
-                mfma_group(a, lda(wv, P.o_A_f1[0], 8, To, g), feat_b<L, 0, 0, g, 0>(nrm), feat_b<L, 0, 0, g, 1>(nrm),
-                           feat_b<L, 0, 0, g, 2>(nrm), feat_b<L, 0, 0, g, 3>(nrm));
-            });
-            static_for<16>([&]<int R>() { a[R] = silu_n(a[R]); });
-            static_for<2>([&]<int T2>() { static_for<4>([&]<int g>() {
-                mfma_group(o0[T2], lda(wv, P.o_A_f2[0], 24, T2, To * 4 + g), a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
-            }); });
-            sched_fence();
-        });
+        static_for<2>([&]<int T>() { o0[T] = ldrows(wv, O.b_f2, T); });
+        dense_rot<2, 24>(wv, O.A_f2[0], o0, [&]<int kg, int j>() { return hs[kg / 4][4 * (kg % 4) + j]; });
         static_for<2>([&]<int T>() { static_for<16>([&]<int R>() { fld.s[T][R] = o0[T][R] + emb.s[T][R]; }); });
     }
-    if constexpr (L >= 1) {   // l = 1: gate rows 192..287 (tiles 6..8); hidden 96x1e
-        f32x16 gt[3];
+    // gate rows of fctp_1 (tiles 6 .. NF1-1 of the 0e row space): 96 gates for the 1e hidden, 48 for the 2e hidden
+    constexpr int NGT = NF1 - 6;
+    f32x16 gt[NGT];
+    static_for<NGT>([&]<int t>() { gt[t] = ldrows(wv, O.b_f1, 6 + t); });
+    {
+        // dense_rot walks tiles 0..NTO-1 of one matrix; the gate tiles start at tile 6 -> shift the matrix offset
+        const int off = O.A_f1[0] + 6 * 8 * 256;
+        dense_rot<NGT, 8>(wv, off, gt, [&]<int kg, int j>() { return nrm.s[kg / 4][4 * (kg % 4) + j]; });
+        static_for<NGT>([&]<int t>() { static_for<16>([&]<int R>() { gt[t][R] = sigmoid_n(gt[t][R]); }); });
+    }
+    if constexpr (L >= 1) {   // l = 1: hidden 96x1e (3 tiles) per component, gated, then fctp_2 (K = 96) shared over the 3 components
+        f32x16 hh[3][3];      // [tile][m]
         static_for<3>([&]<int t>() {
-            gt[t] = ldrows(wv, P.o_b_f1, 6 + t);
-            static_for<8>([&]<int g>() {
-                mfma_group(gt[t], lda(wv, P.o_A_f1[0], 8, 6 + t, g), feat_b<L, 0, 0, g, 0>(nrm), feat_b<L, 0, 0, g, 1>(nrm),
-                           feat_b<L, 0, 0, g, 2>(nrm), feat_b<L, 0, 0, g, 3>(nrm));
-            });
-            static_for<16>([&]<int R>() { gt[t][R] = sigmoid_n(gt[t][R]); });
+            static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] = 0.0f; }); });
+            dense_shared<3, 4>(wv, O.A_f1[1], 4, t, 0, hh[t], [&]<int m, int kg, int j>() { return nrm.v1[m][4 * kg + j]; });
+            static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] *= gt[t][R]; }); });
         });
-        sched_fence();
-        static_for<3>([&]<int m>() {
-            f32x16 o = {0};
-            static_for<3>([&]<int t>() {
-                f32x16 hh = {0};
-                static_for<4>([&]<int g>() {
-                    mfma_group(hh, lda(wv, P.o_A_f1[1], 4, t, g), nrm.v1[m][4 * g], nrm.v1[m][4 * g + 1], nrm.v1[m][4 * g + 2], nrm.v1[m][4 * g + 3]);
-                });
-                static_for<16>([&]<int R>() { hh[R] *= gt[t][R]; });
-                static_for<4>([&]<int g>() {
-                    mfma_group(o, lda(wv, P.o_A_f2[1], 12, 0, t * 4 + g), hh[4 * g], hh[4 * g + 1], hh[4 * g + 2], hh[4 * g + 3]);
-                });
-            });
-            static_for<16>([&]<int R>() { fld.v1[m][R] = o[R] + emb.v1[m][R]; });
-            sched_fence();
-        });
+        f32x16 o[3] = {{0}, {0}, {0}};
+        dense_shared<3, 12>(wv, O.A_f2[1], 12, 0, 0, o, [&]<int m, int kg, int j>() { return hh[kg / 4][m][4 * (kg % 4) + j]; });
+        static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { fld.v1[m][R] = o[m][R] + emb.v1[m][R]; }); });
     }
-    if constexpr (L >= 2) {   // l = 2: gate rows 288..335 (tile 9, tile 10 rows 0..15); hidden 48x2e (tile 0 full, tile 1 half)
-        constexpr int GT0 = f1_gate_row(2, 0) / 32;
-        f32x16 gt[2];
+    if constexpr (L >= 2) {   // l = 2: hidden 48x2e (tile 0 full, tile 1 rows 0..15); gates = 0e rows 288..335 (gate tile 3, tile 4 low half)
+        f32x16 hh[2][5];
         static_for<2>([&]<int t>() {
-            gt[t] = ldrows(wv, P.o_b_f1, GT0 + t);
-            static_for<8>([&]<int g>() {
-                mfma_group(gt[t], lda(wv, P.o_A_f1[0], 8, GT0 + t, g), feat_b<L, 0, 0, g, 0>(nrm), feat_b<L, 0, 0, g, 1>(nrm),
-                           feat_b<L, 0, 0, g, 2>(nrm), feat_b<L, 0, 0, g, 3>(nrm));
-            });
-            static_for<16>([&]<int R>() { gt[t][R] = sigmoid_n(gt[t][R]); });
+            static_for<5>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] = 0.0f; }); });
+            dense_shared<5, 2>(wv, O.A_f1[2], 2, t, 0, hh[t], [&]<int m, int kg, int j>() { return nrm.v2[m][4 * kg + j]; });
+            static_for<5>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] *= gt[3 + t][R]; }); });
         });
-        sched_fence();
-        static_for<5>([&]<int m>() {
-            f32x16 o = {0};
-            static_for<2>([&]<int t>() {
-                f32x16 hh = {0};
-                static_for<2>([&]<int g>() {
-                    mfma_group(hh, lda(wv, P.o_A_f1[2], 2, t, g), nrm.v2[m][4 * g], nrm.v2[m][4 * g + 1], nrm.v2[m][4 * g + 2], nrm.v2[m][4 * g + 3]);
-                });
-                static_for<16>([&]<int R>() { hh[R] *= gt[t][R]; });
-                static_for<(t == 0 ? 4 : 2)>([&]<int g>() {
-                    mfma_group(o, lda(wv, P.o_A_f2[2], 6, 0, t * 4 + g), hh[4 * g], hh[4 * g + 1], hh[4 * g + 2], hh[4 * g + 3]);
-                });
-            });
-            static_for<8>([&]<int R>() { fld.v2[m][R] = o[R] + emb.v2[m][R]; });
-            sched_fence();
-        });
+        f32x16 o[5] = {{0}, {0}, {0}, {0}, {0}};
+        // K = 48: groups 0..3 read hidden tile 0, groups 4..5 the valid half of tile 1
+        dense_shared<5, 6>(wv, O.A_f2[2], 6, 0, 0, o, [&]<int m, int kg, int j>() { return hh[kg / 4][m][4 * (kg % 4) + j]; });
+        static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { fld.v2[m][R] = o[m][R] + emb.v2[m][R]; }); });
     }
+    sched_fence();
 
     // ---- score tensor products ------------------------------------------------------------------------------------------------
     const Buf qfb = make_buf(P.qf, P.qf_bytes);
@@ -227,7 +203,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     const int qv0 = q * (D * 4) + hi * 16, qv1 = q * (D * 4) + hi * 48, qv2 = q * (D * 4) + hi * 80;
     float res[2][3];                         // per TP: mean over the 32 gated 1e channels
     static_for<2>([&]<int tp>() {
-        f32x16 gacc = ldrows(wv, P.o_b_sl[tp], 0);
+        f32x16 gacc = ldrows(wv, O.b_sl[tp], 0);
         f32x16 vacc[3];
         static_for<3>([&]<int K>() { static_for<16>([&]<int R>() { vacc[K][R] = 0.0f; }); });
         static_for<stp_num_paths<L>()>([&]<int p>() {
@@ -238,12 +214,11 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
             using C = CG<l1, l2, l3>;
             static_for<cdiv(pi.mul1, 32)>([&]<int To>() {
                 f32x16 T[d2];
-                static_for<d2>([&]<int j>() {
-                    static_for<16>([&]<int R>() { T[j][R] = 0.0f; });
-                    static_for<NGK>([&]<int g>() {
-                        mfma_group(T[j], lda(wv, P.o_A_s[tp][p], NGK, To, g), feat_b<L, l2, j, g, 0>(fld), feat_b<L, l2, j, g, 1>(fld),
-                                   feat_b<L, l2, j, g, 2>(fld), feat_b<L, l2, j, g, 3>(fld));
-                    });
+                static_for<d2>([&]<int j>() { static_for<16>([&]<int R>() { T[j][R] = 0.0f; }); });
+                dense_shared<d2, NGK>(wv, O.A_s[tp][p], NGK, To, 0, T, [&]<int j, int kg, int jj>() {
+                    if constexpr (l2 == 0) return fld.s[kg / 4][4 * (kg % 4) + jj];
+                    else if constexpr (l2 == 1) return fld.v1[j][4 * kg + jj];
+                    else return fld.v2[j][4 * kg + jj];
                 });
                 static_for<imin(4, (pi.mul1 - 32 * To) / 8)>([&]<int g>() {
                     constexpr int u0 = 32 * To + 8 * g;
@@ -271,9 +246,9 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
                     });
                     constexpr int NG = stp_k<L>(l3) / 8;
                     if constexpr (l3 == 0) {
-                        mfma_group(gacc, lda(wv, P.o_A_sl[tp][0], NG, 0, gi), a[0][0], a[1][0], a[2][0], a[3][0]);
+                        mfma_group(gacc, lda(wv, O.A_sl[tp][0], NG, 0, gi), a[0][0], a[1][0], a[2][0], a[3][0]);
                     } else {
-                        const f32x4 av = lda(wv, P.o_A_sl[tp][1], NG, 0, gi);
+                        const f32x4 av = lda(wv, O.A_sl[tp][1], NG, 0, gi);
                         static_for<3>([&]<int K>() { mfma_group(vacc[K], av, a[0][K], a[1][K], a[2][K], a[3][K]); });
                     }
                 });
