@@ -97,8 +97,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # under torch.distributed.run always go through RCCL
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
 
     n_total = args.poses_per_gpu * world
@@ -116,26 +118,26 @@ def main():
         return model.sample(T0, keys, query, [[1.0, 0.15]], [n_steps], [0.04], temperatures=1.0, seed=3, first_pose_index=first_idx)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     T = Ts
     if args.warmup > 0:
         T = run(T, args.warmup, first)[-1]
-        if world > 1:
+        if use_dist:
             ddist.gather_poses(T, n_total)
     head.profile_enable(True)
     head.profile_read()
     barrier()
     t0 = time.perf_counter()
     traj = run(T, args.steps, first)
-    final = ddist.gather_poses(traj[-1], n_total) if world > 1 else traj[-1]
+    final = ddist.gather_poses(traj[-1], n_total) if use_dist else traj[-1]
     barrier()
     el = time.perf_counter() - t0
     prof = head.profile_read()
     head.profile_enable(False)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([el], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
@@ -147,14 +149,16 @@ def main():
         e_per_launch = prof["n_edges"] / n_ev
         flops = 2.0 * e_per_launch * M_EDGE[args.lmax]
         achieved = flops / (edge_ms * 1e-3) / 1e12 if edge_ms > 0 else 0.0
+        default_workload = (args.lmax, args.scene, args.grasp, args.poses_per_gpu) == (2, 4096, 1024, 1000)
+        wname = "C2" if default_workload else ("C1" if (args.lmax, args.scene, args.grasp) == (1, 2048, 512) else "custom")
         traffic = None
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json"))):
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json"))) if default_workload else []:
             try:
                 traffic = json.load(open(f)).get("edge_kernel_hbm_bytes_per_launch", traffic)
             except Exception:
                 pass
         out = {
-            "metric": "denoised SE(3) poses/sec (pose-steps/s, 4k-pt scene / 1k-pt grasp, lmax=2)",
+            "metric": f"denoised SE(3) poses/sec (pose-steps/s, {args.scene // 1024}k-pt scene / {args.grasp}-pt grasp, lmax={args.lmax})",
             "value": n_total * args.steps / el,
             "unit": "pose-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -162,7 +166,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (score network, exact-f32 MFMA) + f64 (SE(3) Langevin state)",
             "data": "synthetic (seeded scene/grasp clouds of the named sizes, random-init weights of the reference architecture)",
-            "config": {"workload": f"C2: {args.scene}-pt scene -> key clouds {'/'.join(str(len(k.x)) for k in keys)}, {args.grasp}-pt grasp -> "
+            "config": {"workload": f"{wname}: {args.scene}-pt scene -> key clouds {'/'.join(str(len(k.x)) for k in keys)}, {args.grasp}-pt grasp -> "
                                    f"{len(query.x)} query pts, lmax={args.lmax}, {args.poses_per_gpu} poses per GPU, t 1->0.15 log-spaced, dt 0.04",
                        "poses_total": n_total, "parallelism": f"pose-parallel dp{world}, one RCCL all-gather at the end",
                        "edges_per_step_rank0": e_per_launch, "full_trajectories_per_s_at_50_steps": n_total * args.steps / el / 50.0},
@@ -174,7 +178,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.lmax, args.scene, args.grasp)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

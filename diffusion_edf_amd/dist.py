@@ -34,8 +34,6 @@ def gather_poses(local: torch.Tensor, n_total: int, dim: int = 0, group=None) ->
     """All-gather pose blocks of (possibly) unequal length along `dim` into the full batch, identical on every rank.
     Uses one all_gather on blocks padded to the largest shard (a single RCCL collective)."""
     ws = dist.get_world_size(group)
-    if ws == 1:
-        return local
     sizes = [shard_range(n_total, ws, r) for r in range(ws)]
     mx = max(e - s for s, e in sizes)
     x = local.movedim(dim, 0).contiguous()
