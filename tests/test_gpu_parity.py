@@ -133,3 +133,124 @@ def test_argument_errors_match_reference_types():
         head(Ts.to(dev).float(), gk[:2], gq, time.to(dev).float())
     with pytest.raises(RuntimeError):
         ScoreModelHead(**kw)(Ts.float(), keys, query, time.float())      # CPU tensors: no CPU path
+
+
+# ---- edge cases ----------------------------------------------------------------------------------------------------------
+
+def _gpu_head(kw, P, dev, **kwargs):
+    head = ScoreModelHead(**kw, **kwargs)
+    head.load_state_dict(P)
+    head.to(dev)
+    return head
+
+
+def _to_dev(keys, query, dev):
+    gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
+    gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
+    return gk, gq
+
+
+@pytest.mark.parametrize("nT,n_grasp,static_kp", [(1, 10, False), (3, 0, True), (33, 10, False)])
+def test_tiny_batches(nT, n_grasp, static_kp):
+    """single pose / single query point / batch sizes around the 32-column tile"""
+    kw, cfg, P, keys, query, Ts, time = SC.build_case(2, nT, 256, n_grasp, static_kp=static_kp, identity_pose=False)
+    if n_grasp == 10:
+        query = FeaturedPoints(query.x[:1], query.f[:1], query.b[:1], query.w[:1])
+    ang64, lin64, d64, _ = SC.oracle_run(kw, P, keys, query, Ts, time, torch.float64)
+    head, ang, lin = SC.gpu_run(kw, P, keys, query, Ts, time, debug=False)
+    assert head.stats()['n_edges'] == d64['n_edges_per_scale']
+    scale = float(max(ang64.abs().max(), lin64.abs().max()))
+    assert float((ang.double() - ang64).abs().max()) / scale < TOL and float((lin.double() - lin64).abs().max()) / scale < TOL
+
+
+@pytest.mark.parametrize("radii", [(6.,), (4., None), (3., 6., 9., 12., None)])
+def test_other_scale_counts(radii):
+    kw, cfg, P, keys, query, Ts, time = SC.build_case(2, 5, 700, 60, radii=radii)
+    ang64, lin64, d64, _ = SC.oracle_run(kw, P, keys, query, Ts, time, torch.float64)
+    head, ang, lin = SC.gpu_run(kw, P, keys, query, Ts, time, debug=False)
+    assert head.stats()['n_edges'] == d64['n_edges_per_scale']
+    scale = float(max(ang64.abs().max(), lin64.abs().max()))
+    assert float((ang.double() - ang64).abs().max()) / scale < TOL and float((lin.double() - lin64).abs().max()) / scale < TOL
+
+
+def test_max_neighbors_cap_binds():
+    """a dense blob: more than max_neighbors keys inside the radius; torch_cluster.radius keeps the first ones in src order"""
+    kw, cfg, P, keys, query, Ts, time = SC.build_case(1, 3, 256, 30, radii=(50.,), identity_pose=False)
+    from diffusion_edf_amd import params as PP
+    okw = dict(kw)
+    ang_o = None
+    for cap in (1000, 20):
+        ocfg = R.config_from_kwargs(kw)._replace(max_neighbors=cap)
+        ok = [R.FeaturedPoints(k.x.double(), k.f.double(), k.b) for k in keys]
+        oq = R.FeaturedPoints(query.x.double(), query.f.double(), query.b, query.w.double())
+        dbg = R.Debug()
+        ang64, lin64 = R.score_head_forward(ocfg, R.cast_params(P, torch.float64), Ts, ok, oq, time, dbg)
+        head = ScoreModelHead(**kw)
+        head.cfg.max_neighbors = cap
+        head.load_state_dict(P)
+        dev = torch.device('cuda:0')
+        head.to(dev)
+        gk, gq = _to_dev(keys, query, dev)
+        ang, lin = head(Ts.to(dev).float(), gk, gq, time.to(dev).float())
+        assert head.stats()['n_edges'] == dbg['n_edges_per_scale']
+        if cap == 20:
+            assert dbg['n_edges_per_scale'][0] == 20 * len(Ts) * len(query.x)      # the cap binds for every destination
+        scale = float(max(ang64.abs().max(), lin64.abs().max()))
+        assert float((ang.cpu().double() - ang64).abs().max()) / scale < TOL
+
+
+def test_edge_workspace_overflow_is_reported():
+    kw, cfg, P, keys, query, Ts, time = SC.build_case(1, 8, 1024, 100)
+    dev = torch.device('cuda:0')
+    head = _gpu_head(kw, P, dev, max_edges=64)
+    gk, gq = _to_dev(keys, query, dev)
+    head(Ts.to(dev).float(), gk, gq, time.to(dev).float())
+    assert head.stats()['overflow'] is True
+    with pytest.raises(RuntimeError, match="overflow"):
+        ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[1.0, 0.5]], [2], [0.04])
+
+
+def test_weights_reload_and_input_change_are_picked_up():
+    kw, cfg, P, keys, query, Ts, time = SC.build_case(1, 4, 256, 30)
+    dev = torch.device('cuda:0')
+    head = _gpu_head(kw, P, dev)
+    gk, gq = _to_dev(keys, query, dev)
+    a1, l1 = head(Ts.to(dev).float(), gk, gq, time.to(dev).float())
+    a1b, _ = head(Ts.to(dev).float(), gk, gq, time.to(dev).float())
+    assert torch.equal(a1, a1b)                                  # deterministic: no atomics anywhere
+    P2 = params.init_params(cfg, seed=77, randomize_all=True)
+    head.load_state_dict(P2)
+    a2, _ = head(Ts.to(dev).float(), gk, gq, time.to(dev).float())
+    assert not torch.allclose(a1, a2)
+    gk[0].f.mul_(0.5)                                            # in-place change of a key cloud is detected (tensor version)
+    a3, _ = head(Ts.to(dev).float(), gk, gq, time.to(dev).float())
+    assert not torch.allclose(a2, a3)
+
+
+# ---- full BASELINE size through size-independent properties -------------------------------------------------------------
+
+def test_full_size_c2_bi_equivariance_and_determinism():
+    """C2 sizes (820/164/33/7 keys, 103 queries, 1000 poses, ~2 M edges): the oracle is too slow here, so check what the
+    domain guarantees — rotating/translating scene AND poses leaves the body-frame scores unchanged (left equivariance),
+    and two runs agree bit for bit."""
+    import bench
+    dev = torch.device('cuda:0')
+    kw, cfg, P, keys, query, Ts = bench.build_inputs(2, 4096, 1024, 1000, 0, dev)
+    head = _gpu_head(kw, P, dev)
+    t = torch.full((1000,), 0.5, device=dev)
+    ang, lin = head(Ts.float(), keys, query, t)
+    assert head.stats()['n_edges_total'] > 1_500_000 and not head.stats()['overflow']
+    ang_b, lin_b = head(Ts.float(), keys, query, t)
+    assert torch.equal(ang, ang_b) and torch.equal(lin, lin_b)
+    g = torch.tensor([0.3, -0.5, 0.7, 0.41], dtype=torch.float64)
+    g = g / g.norm()
+    gt = torch.tensor([3., -2., 1.], dtype=torch.float64)
+    ocfg = R.config_from_kwargs(kw)
+    keys2 = [FeaturedPoints((R.quaternion_apply(g, k.x.cpu().double()) + gt).float().to(dev),
+                            R.transform_feature_quaternion(ocfg.irreps, k.f.cpu().double(), g[None])[0].float().to(dev), k.b) for k in keys]
+    Tc = Ts.cpu()
+    Ts2 = torch.cat([R.quaternion_raw_multiply(g.expand(len(Tc), 4), Tc[:, :4]), R.quaternion_apply(g, Tc[:, 4:]) + gt], -1).to(dev)
+    ang2, lin2 = head(Ts2.float(), keys2, query, t)
+    scale = float(max(ang.abs().max(), lin.abs().max()))
+    assert float((ang2 - ang).abs().max()) / scale < 2e-4, float((ang2 - ang).abs().max()) / scale
+    assert float((lin2 - lin).abs().max()) / scale < 2e-4
