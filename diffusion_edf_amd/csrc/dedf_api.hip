@@ -18,7 +18,7 @@ using namespace dedf;
 // ---------------------------------------------------------------------------------------------------------------------------
 // the two fused kernels: persistent waves striding over tiles (tile count lives on the device: no host round trip)
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int L> __global__ __launch_bounds__(64, 1) void k_edge(EdgeParams P) {
+template <int L, int F0> __global__ __launch_bounds__(64, 1) void k_edge(EdgeParams P) {
     const int* ti = P.tile_info;
     const int ntiles = ti[P.n_scales];
     const Wave wv = make_wave(P.W, P.W_bytes);
@@ -31,19 +31,26 @@ template <int L> __global__ __launch_bounds__(64, 1) void k_edge(EdgeParams P) {
         const int k = t - ti[scale];
         const int ebase = ti[16 + scale], En = ti[16 + scale + 1] - ebase;
 #if defined(DEDF_PHASE_PROF)
-        edge_tile<L>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k), pacc);
+        edge_tile<L, F0>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k), pacc);
 #else
-        edge_tile<L>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k));
+        edge_tile<L, F0>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k));
 #endif
     }
 #if defined(DEDF_PHASE_PROF)
     if (P.phase_prof && wv.lane == 0) for (int i = 0; i < 12; ++i) P.phase_prof[blockIdx.x * 16 + i] += pacc[i];
 #endif
 }
-template <int L> __global__ __launch_bounds__(64, 1) void k_node(NodeParams P) {
+template <int L, bool EBM> __global__ __launch_bounds__(64, 1) void k_node(NodeParams P) {
     const Wave wv = make_wave(P.W, P.W_bytes);
     const int ntiles = (P.n_nodes + 31) / 32;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) node_tile<L>(P, wv, t * 32);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) node_tile<L, EBM>(P, wv, t * 32);
+}
+__global__ void k_energy_reduce(const float* __restrict__ node_out, int nT, int nQ, float* __restrict__ energy) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nT) return;
+    float s = 0.0f;
+    for (int q = 0; q < nQ; ++q) s += node_out[((size_t)t * nQ + q) * 8];
+    energy[t] = s;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -79,7 +86,7 @@ struct dedf_handle {
     int n_cu = 256;
     // device: weights
     DevBuf d_edge_w, d_node_w, d_nat;     // d_nat: natural-layout weights for the small kernels
-    size_t nat_tw1 = 0, nat_tb1 = 0, nat_tw2 = 0, nat_tb2 = 0, nat_wpre = 0, nat_bpre = 0, nat_lnw = 0, nat_lnb = 0, nat_wsrc = 0, nat_bsrc = 0, nat_tfreq = 0;
+    size_t nat_tw1 = 0, nat_tb1 = 0, nat_tw2 = 0, nat_tb2 = 0, nat_wpre = 0, nat_bpre = 0, nat_lnw = 0, nat_lnb = 0, nat_wsrc = 0, nat_bsrc = 0, nat_tfreq = 0, nat_brows = 0;
     // device: scene / query
     DevBuf d_key_x, d_key_f, d_msg, d_qx, d_qf, d_qw;
     int n_keys = 0, nQ = 0;
@@ -118,7 +125,8 @@ int check_config(const dedf_config* c, std::string& why) {
     for (int l = 0; l <= c->lmax; ++l)
         if (c->mul[l] != mul_of(l)) { why = "irreps must be 64x0e+32x1e(+16x2e)"; return DEDF_ERR_UNSUPPORTED; }
     if (c->num_heads != kHeads) { why = "num_heads must be 4"; return DEDF_ERR_UNSUPPORTED; }
-    if (c->fc_neurons[0] != kFc0 || c->fc_neurons[1] != kFc1 || c->fc_neurons[2] != kFc2) { why = "fc_neurons must resolve to [128,128,64]"; return DEDF_ERR_UNSUPPORTED; }
+    if (c->fc_neurons[0] != (c->ebm ? kLenEmb : kFc0) || c->fc_neurons[1] != kFc1 || c->fc_neurons[2] != kFc2) {
+        why = "fc_neurons must resolve to [128,128,64] (score head) or [64,128,64] (EBM head without time encoding)"; return DEDF_ERR_UNSUPPORTED; }
     if (c->length_emb_dim != kLenEmb) { why = "length_emb_dim must be 64"; return DEDF_ERR_UNSUPPORTED; }
     if (c->time_emb_mlp[0] != kTimeEnc || c->time_emb_mlp[1] != kTimeHid || c->time_emb_mlp[2] != kTimeEmb) { why = "time_emb_mlp must be [256,128,64]"; return DEDF_ERR_UNSUPPORTED; }
     if (c->irreps_mlp_mid != kMlpMid) { why = "irreps_mlp_mid must be 3"; return DEDF_ERR_UNSUPPORTED; }
@@ -182,6 +190,15 @@ int upload_weights(dedf_handle* h) {
         for (int k = 0; k < 128; ++k) fr[k] = std::exp((float)k * (float)(-step));
         h->nat_tfreq = put(fr.data(), 128);
     }
+    if (c.ebm) {   // no time encoding: the pre-linear "time rows" are just its bias, row-packed once
+        std::vector<float> rows;
+        for (int n = 0; n < ns; ++n) {
+            const float* b = S.get(B, "key_tensor_field.edge_scalars_pre_linears." + std::to_string(n) + ".0.bias");
+            auto r = pack_rows(c.fc_neurons[0], [&](int i) { return b[i]; });
+            rows.insert(rows.end(), r.begin(), r.end());
+        }
+        h->nat_brows = put(rows.data(), rows.size());
+    }
     if (!h->d_nat.ensure(nat.size() * 4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(nat) failed");
     HIPCK(h, hipMemcpy(h->d_nat.p, nat.data(), nat.size() * 4, hipMemcpyHostToDevice));
     return DEDF_OK;
@@ -220,8 +237,9 @@ int ensure_workspace(dedf_handle* h, int nT) {
 }
 
 // one evaluation of the score head on poses already in h->d_Ts (f32) with times in h->d_time
-template <int L>
+template <int L, bool EBM>
 int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, hipStream_t st) {
+    constexpr int F0 = EBM ? kLenEmb : kFc0;
     const dedf_config& c = h->cfg;
     const int ns = c.n_scales, nQ = h->nQ;
     const int Nd = nT * nQ;
@@ -236,8 +254,8 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     mark();
     // 1. poses: Wigner-D + transformed query positions
     hipLaunchKernelGGL(k_pose_prep<L>, dim3(nT), dim3(64), 0, st, h->d_Ts.as<float>(), h->d_qx.as<float>(), nQ, h->d_pose.as<float>(), h->d_qpos.as<float>());
-    // 2. time embedding -> pre-linear bias rows
-    {
+    // 2. time embedding -> pre-linear bias rows (EBM head: constant bias rows, uploaded once)
+    if constexpr (!EBM) {
         TimeParams tp{};
         tp.time = h->d_time.as<float>(); tp.time_stride = time_stride;
         tp.w1 = nat + h->nat_tw1; tp.b1 = nat + h->nat_tb1; tp.w2 = nat + h->nat_tw2; tp.b2 = nat + h->nat_tb2;
@@ -264,8 +282,12 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         EdgeParams P{};
         P.key_x = h->d_key_x.as<float>(); P.qpos = h->d_qpos.as<float>(); P.edge_src = h->d_esrc.as<int>(); P.edge_dst = h->d_edst.as<int>();
         P.tile_info = h->d_tile.as<int>(); P.msg = h->d_msg.as<float>(); P.msg_bytes = (uint32_t)((size_t)h->n_keys * D * 4);
-        P.tb = h->d_tb.as<float>(); P.tb_bytes = (uint32_t)((size_t)(time_stride ? nT : 1) * ns * 128 * 4);
-        P.tb_pose_stride = time_stride ? ns * 128 : 0;
+        if constexpr (EBM) {
+            P.tb = nat + h->nat_brows; P.tb_bytes = (uint32_t)((size_t)ns * F0 * 4); P.tb_pose_stride = 0;
+        } else {
+            P.tb = h->d_tb.as<float>(); P.tb_bytes = (uint32_t)((size_t)(time_stride ? nT : 1) * ns * F0 * 4);
+            P.tb_pose_stride = time_stride ? ns * F0 : 0;
+        }
         P.nQ = nQ; P.n_scales = ns;
         for (int n = 0; n < ns; ++n) {
             P.radius[n] = c.radii[n] > 0 ? c.radii[n] : -1.0f;
@@ -287,7 +309,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
 #if defined(DEDF_PHASE_PROF)
         if (h->d_phase.ensure((size_t)h->n_cu * 4 * 16 * 8)) P.phase_prof = h->d_phase.as<unsigned long long>();
 #endif
-        hipLaunchKernelGGL(k_edge<L>, dim3(h->n_cu * 4), dim3(64), 0, st, P);
+        hipLaunchKernelGGL((k_edge<L, F0>), dim3(h->n_cu * 4), dim3(64), 0, st, P);
     }
     mark();
     // 5. joint softmax + aggregation
@@ -305,17 +327,18 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         const NodeOffsets& o = h->no;
         for (int l = 0; l < 4; ++l) { P.o_A_proj[l] = o.o_A_proj[l]; P.o_ln_w[l] = o.o_ln_w[l]; P.o_A_f1[l] = o.o_A_f1[l]; P.o_A_f2[l] = o.o_A_f2[l]; }
         P.o_b_proj0 = o.o_b_proj0; P.o_ln_b0 = o.o_ln_b0; P.o_b_f1 = o.o_b_f1; P.o_b_f2 = o.o_b_f2;
-        for (int t = 0; t < 2; ++t) {
+        if constexpr (!EBM) for (int t = 0; t < 2; ++t) {
             for (int p = 0; p < 16; ++p) P.o_A_s[t][p] = o.o_A_s[t][p];
             P.o_A_sl[t][0] = o.o_A_sl[t][0]; P.o_A_sl[t][1] = o.o_A_sl[t][1]; P.o_b_sl[t] = o.o_b_sl[t];
         }
         P.node_out = h->d_nout.as<float>();
         const int ntiles = (Nd + 31) / 32;
-        hipLaunchKernelGGL(k_node<L>, dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
+        hipLaunchKernelGGL((k_node<L, EBM>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
     }
     mark();
     // 7. per-pose reduction
-    hipLaunchKernelGGL(k_pose_reduce, dim3((nT + 127) / 128), dim3(128), 0, st, h->d_nout.as<float>(), nT, nQ, ang, lin);
+    if constexpr (EBM) hipLaunchKernelGGL(k_energy_reduce, dim3((nT + 127) / 128), dim3(128), 0, st, h->d_nout.as<float>(), nT, nQ, ang);
+    else hipLaunchKernelGGL(k_pose_reduce, dim3((nT + 127) / 128), dim3(128), 0, st, h->d_nout.as<float>(), nT, nQ, ang, lin);
     mark();
     if (h->profile) { h->prof_evals += 1; h->prof_dst += Nd; }
     if (hipGetLastError() != hipSuccess) return fail(h, DEDF_ERR_RUNTIME, "kernel launch failed");
@@ -325,7 +348,8 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
 }
 
 int score_dispatch(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, hipStream_t st) {
-    return h->L == 1 ? score_impl<1>(h, nT, time_stride, ang, lin, st) : score_impl<2>(h, nT, time_stride, ang, lin, st);
+    if (h->cfg.ebm) return h->L == 1 ? score_impl<1, true>(h, nT, time_stride, ang, lin, st) : score_impl<2, true>(h, nT, time_stride, ang, lin, st);
+    return h->L == 1 ? score_impl<1, false>(h, nT, time_stride, ang, lin, st) : score_impl<2, false>(h, nT, time_stride, ang, lin, st);
 }
 
 }  // namespace
@@ -465,6 +489,8 @@ int dedf_score(dedf_handle* h, int nT, const float* Ts, const float* time, float
     if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
     if (!h->have_keys || !h->have_query) return fail(h, DEDF_ERR_INVALID, "set_key_clouds / set_query must be called first");
     if (nT <= 0 || !Ts || !time || !ang || !lin) return fail(h, DEDF_ERR_INVALID, "bad arguments");
+    if (h->cfg.ebm) return fail(h, DEDF_ERR_UNSUPPORTED, "EBM head: the score is the autograd of the energy (score_head_ebm.py:203-217), "
+                                                          "which needs a backward pass and is not on the accelerated path; use dedf_energy");
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCK(h, hipSetDevice(h->cfg.device));
     int rc = ensure_workspace(h, nT);
@@ -474,12 +500,28 @@ int dedf_score(dedf_handle* h, int nT, const float* Ts, const float* time, float
     return score_dispatch(h, nT, 1, ang, lin, st);
 }
 
+int dedf_energy(dedf_handle* h, int nT, const float* Ts, const float* time, float* energy, void* stream) {
+    if (!h) return DEDF_ERR_INVALID;
+    if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
+    if (!h->cfg.ebm) return fail(h, DEDF_ERR_UNSUPPORTED, "dedf_energy needs a handle created with dedf_config.ebm = 1");
+    if (!h->have_keys || !h->have_query) return fail(h, DEDF_ERR_INVALID, "set_key_clouds / set_query must be called first");
+    if (nT <= 0 || !Ts || !energy) return fail(h, DEDF_ERR_INVALID, "bad arguments");
+    (void)time;   // the critic has no time encoding (configs/*/pick_ebm/score_model_configs.yaml:8-9; agent.py:170)
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCK(h, hipSetDevice(h->cfg.device));
+    int rc = ensure_workspace(h, nT);
+    if (rc != DEDF_OK) return rc;
+    HIPCK(h, hipMemcpyAsync(h->d_Ts.p, Ts, (size_t)nT * 7 * 4, hipMemcpyDeviceToDevice, st));
+    return score_dispatch(h, nT, 0, energy, nullptr, st);
+}
+
 int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedule* sched, uint64_t seed, int64_t first_pose_index,
                 const double* noise, double* Ts_out, void* stream) {
     if (!h) return DEDF_ERR_INVALID;
     if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
     if (!h->have_keys || !h->have_query) return fail(h, DEDF_ERR_INVALID, "set_key_clouds / set_query must be called first");
     if (nT <= 0 || !T_seed || !sched || sched->n_steps < 0 || !Ts_out) return fail(h, DEDF_ERR_INVALID, "bad arguments");
+    if (h->cfg.ebm) return fail(h, DEDF_ERR_UNSUPPORTED, "EBM head: sampling needs the energy gradient (backward pass); use dedf_energy");
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCK(h, hipSetDevice(h->cfg.device));
     int rc = ensure_workspace(h, nT);

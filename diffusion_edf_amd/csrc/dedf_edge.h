@@ -25,7 +25,7 @@ struct EdgeParams {
     const int* tile_info;     // [0..n_scales] tile prefix, [16..16+n_scales] edge prefix
     const float* msg;         // [sum N_s][D]  source message (LN + LinearRS of key features), reference layout
     uint32_t msg_bytes;
-    const float* tb;          // [(nT|1)][n_scales][128] row-packed: W_pre[:,64:] c_t + b_pre
+    const float* tb;          // [(nT|1)][n_scales][F0] row-packed: W_pre[:,64:] c_t + b_pre  (b_pre alone when F0 = 64)
     uint32_t tb_bytes;
     int tb_pose_stride;       // floats; 0 when every pose shares the time (sampler)
     int nQ, n_scales;
@@ -39,7 +39,7 @@ struct EdgeParams {
     const float* W;
     uint32_t W_bytes;
     int o_enc;                // [n_scales][3][2][32]  mean | 1/std | weight in (hi, s) order; infinite: freq[32] first
-    int o_A_pre;              // [n_scales][4 tiles][8 groups][64][4]
+    int o_A_pre;              // [n_scales][F0/32 tiles][8 groups][64][4]
     int o_A_r1, o_b_r1, o_g_r1, o_be_r1;
     int o_A_r2, o_b_r2, o_g_r2, o_be_r2;
     int o_A_r3, o_off_r3;
@@ -96,7 +96,7 @@ DEDF_DEV void ln_silu(f32x16 (&x)[NT], const Wave& wv, int o_gamma, int o_beta) 
 #define DEDF_PROF_ARG
 #endif
 
-template <int L>
+template <int L, int F0>
 DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, int n_valid DEDF_PROF_ARG) {
 #if defined(DEDF_PHASE_PROF) && defined(__HIP_DEVICE_COMPILE__)
     unsigned long long t_last = __builtin_readcyclecounter();
@@ -176,20 +176,21 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
 
     DEDF_STAMP(0);
     // ---- edge pre-linear + SiLU (multiscale_tensor_field.py:225-234); time part + bias arrive as per-pose rows --------
-    f32x16 h[4];
+    constexpr int NH = F0 / 32;      // pre-linear width: 128 (length + time embedding) or 64 (EBM critic: length only)
+    f32x16 h[NH];
     {
         const Buf tbb = make_buf(P.tb, P.tb_bytes);
         const int tvoff = (pose * P.tb_pose_stride) * 4 + wv.hi64;
-        const int oA = opaque_s(P.o_A_pre + scale * (4 * 8 * 256));
-        static_for<4>([&]<int To>() { h[To] = ldrows(tbb, tvoff, scale * 128, To); });
-        dense_rot<4, 8, 2>(wv, oA, h, [&]<int kg, int j>() { return eb[4 * kg + j]; });
-        static_for<4>([&]<int To>() { static_for<16>([&]<int R>() { h[To][R] = siluf(h[To][R]); }); });
+        const int oA = opaque_s(P.o_A_pre + scale * (NH * 8 * 256));
+        static_for<NH>([&]<int To>() { h[To] = ldrows(tbb, tvoff, scale * F0, To); });
+        dense_rot<NH, 8, 2>(wv, oA, h, [&]<int kg, int j>() { return eb[4 * kg + j]; });
+        static_for<NH>([&]<int To>() { static_for<16>([&]<int R>() { h[To][R] = siluf(h[To][R]); }); });
     }
     DEDF_STAMP(1);
     // ---- RadialProfile layers 1, 2 (equiformer/radial_func.py:11-60) ---------------------------------------------------
     f32x16 r1[4];
     static_for<4>([&]<int To>() { r1[To] = ldrows(wv, o_b_r1, To); });
-    dense_rot<4, 16, 2>(wv, o_A_r1, r1, [&]<int kg, int j>() { return h[kg / 4][4 * (kg % 4) + j]; });
+    dense_rot<4, F0 / 8, 2>(wv, o_A_r1, r1, [&]<int kg, int j>() { return h[kg / 4][4 * (kg % 4) + j]; });
     DEDF_STAMP(2);
     ln_silu<4>(r1, wv, o_g_r1, o_be_r1);
     DEDF_STAMP(3);

@@ -46,7 +46,7 @@ template <int L, int l, int m, int g, int j> DEDF_DEV float feat_b(const Feat<L>
     else return f.v2[m][4 * g + j];
 }
 
-template <int L>
+template <int L, bool EBM>
 DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     constexpr int D = feat_dim<L>();
     const int hi = wv.hi;
@@ -60,7 +60,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         O.A_f1[l] = opaque_s(P.o_A_f1[l]); O.A_f2[l] = opaque_s(P.o_A_f2[l]);
     });
     O.b_proj0 = opaque_s(P.o_b_proj0); O.ln_b0 = opaque_s(P.o_ln_b0); O.b_f1 = opaque_s(P.o_b_f1); O.b_f2 = opaque_s(P.o_b_f2);
-    static_for<2>([&]<int t>() {
+    if constexpr (!EBM) static_for<2>([&]<int t>() {
         static_for<stp_num_paths<L>()>([&]<int p>() { O.A_s[t][p] = opaque_s(P.o_A_s[t][p]); });
         O.A_sl[t][0] = opaque_s(P.o_A_sl[t][0]); O.A_sl[t][1] = opaque_s(P.o_A_sl[t][1]); O.b_sl[t] = opaque_s(P.o_b_sl[t]);
     });
@@ -201,6 +201,43 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         });
     }
     const int qv0 = q * (D * 4) + hi * 16, qv1 = q * (D * 4) + hi * 48, qv2 = q * (D * 4) + hi * 80;
+    if constexpr (EBM) {
+        // ---- EbmScoreModelHead.compute_energy (score_head_ebm.py:171-172): |field - D(q) f_query|^2 / dim, weighted by w_q ----
+        float esum = 0.0f;
+        static_for<L + 1>([&]<int l>() {
+            constexpr int d = 2 * l + 1;
+            static_for<mul_of(l) / 8>([&]<int gu>() {
+                float xr[4 * d];
+                const int qv = l == 0 ? qv0 : (l == 1 ? qv1 : qv2);
+                static_for<d>([&]<int Q>() {
+                    const f32x4 t = bld4(qfb, qv, (blk_off(l) + gu * 8 * d + 4 * Q) * 4);
+                    xr[4 * Q] = t[0]; xr[4 * Q + 1] = t[1]; xr[4 * Q + 2] = t[2]; xr[4 * Q + 3] = t[3];
+                });
+                static_for<4>([&]<int j>() {
+                    static_for<d>([&]<int I>() {
+                        float g, f;
+                        if constexpr (l == 0) { g = xr[j]; f = fld.s[gu / 4][4 * (gu % 4) + j]; }
+                        else if constexpr (l == 1) {
+                            g = D1[3 * I] * xr[3 * j] + D1[3 * I + 1] * xr[3 * j + 1] + D1[3 * I + 2] * xr[3 * j + 2];
+                            f = fld.v1[I][4 * gu + j];
+                        } else {
+                            g = D2[5 * I] * xr[5 * j] + D2[5 * I + 1] * xr[5 * j + 1] + D2[5 * I + 2] * xr[5 * j + 2] +
+                                D2[5 * I + 3] * xr[5 * j + 3] + D2[5 * I + 4] * xr[5 * j + 4];
+                            f = fld.v2[I][4 * gu + j];
+                        }
+                        esum += (f - g) * (f - g);
+                    });
+                });
+            });
+        });
+        esum += xor32(esum);
+        if (valid && hi == 0) {
+            float* out = P.node_out + (size_t)n * 8;
+            st4(out, f32x4{P.qw[q] * (esum * (1.0f / D)), 0.0f, 0.0f, 0.0f});
+            st4(out + 4, f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+        }
+        return;
+    }
     float res[2][3];                         // per TP: mean over the 32 gated 1e channels
     static_for<2>([&]<int tp>() {
         f32x16 gacc = ldrows(wv, O.b_sl[tp], 0);

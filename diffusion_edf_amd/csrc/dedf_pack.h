@@ -82,7 +82,7 @@ inline ParamSpec build_spec(const dedf_config& c) {
     }
     S.add(blk + ".ffn.fctp_1.tp.weight", f1); S.add(blk + ".ffn.fctp_1.bias.0", f1_rows0<L>());
     S.add(blk + ".ffn.fctp_2.tp.weight", f2); S.add(blk + ".ffn.fctp_2.bias.0", mul_of(0));
-    for (const char* nm : {"lin_vel_tp", "ang_vel_tp"}) {
+    if (!c.ebm) for (const char* nm : {"lin_vel_tp", "ang_vel_tp"}) {
         const std::string p = std::string(nm);
         S.add(p + ".dtp.tp.weight", stp_wn<L>());
         S.add(p + ".lin.tp.weight", (size_t)stp_k<L>(0) * (1 + mul_of(1)) + (size_t)stp_k<L>(1) * mul_of(1));
@@ -144,7 +144,8 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
         std::vector<float> all;
         for (int n = 0; n < c.n_scales; ++n) {
             const float* W = S.get(B, ktf + ".edge_scalars_pre_linears." + std::to_string(n) + ".0.weight");
-            auto a = pack_A(128, st, [&](int oo, int k) { return W[oo * 128 + k]; });
+            const int F0 = c.fc_neurons[0];      // 128 = length emb (64) + time emb (64); 64 for the EBM head (no time)
+            auto a = pack_A(F0, st, [&](int oo, int k) { return W[oo * F0 + k]; });
             all.insert(all.end(), a.begin(), a.end());
         }
         o.o_A_pre = im.push(all);
@@ -152,7 +153,8 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
     auto rows = [&](int O, const float* v) { return pack_rows(O, [&](int i) { return v[i]; }); };
     {
         const float* W = S.get(B, rad + "net.0.weight");
-        o.o_A_r1 = im.push(pack_A(128, chain_steps(128), [&](int oo, int k) { return W[oo * 128 + k]; }));
+        const int F0 = c.fc_neurons[0];
+        o.o_A_r1 = im.push(pack_A(128, chain_steps(F0), [&](int oo, int k) { return W[oo * F0 + k]; }));
         o.o_b_r1 = im.push(rows(128, S.get(B, rad + "net.0.bias")));
         o.o_g_r1 = im.push(rows(128, S.get(B, rad + "net.1.weight")));
         o.o_be_r1 = im.push(rows(128, S.get(B, rad + "net.1.bias")));
@@ -206,7 +208,7 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
 }
 
 template <int L>
-inline void pack_node(const dedf_config&, const ParamSpec& S, const float* B, Image& im, NodeOffsets& o) {
+inline void pack_node(const dedf_config& c, const ParamSpec& S, const float* B, Image& im, NodeOffsets& o) {
     const std::string blk = "key_tensor_field.gnn_block_init", ga = blk + ".ga";
     auto rows = [&](int O, const float* v) { return pack_rows(O, [&](int i) { return v[i]; }); };
     const float* pw = S.get(B, ga + ".proj.tp.weight");
@@ -230,7 +232,7 @@ inline void pack_node(const dedf_config&, const ParamSpec& S, const float* B, Im
     o.o_b_f1 = im.push(rows(f1_rows0<L>(), S.get(B, blk + ".ffn.fctp_1.bias.0")));
     o.o_b_f2 = im.push(rows(mul_of(0), S.get(B, blk + ".ffn.fctp_2.bias.0")));
     int tp = 0;
-    for (const char* nm : {"lin_vel_tp", "ang_vel_tp"}) {
+    if (!c.ebm) for (const char* nm : {"lin_vel_tp", "ang_vel_tp"}) {
         const std::string p = std::string(nm);
         const float* dw = S.get(B, p + ".dtp.tp.weight");
         for (int q = 0; q < stp_num_paths<L>(); ++q) {

@@ -40,6 +40,7 @@ class HeadConfig:
     ang_mult: float
     irreps_mlp_mid: int = 3
     max_neighbors: int = 1000
+    ebm: bool = False                    # EbmScoreModelHead (reference score_head_ebm.py): energy critic, no time encoding
 
     @property
     def n_scales(self) -> int:
@@ -69,9 +70,11 @@ class HeadConfig:
         for i, (m, l) in enumerate(irreps):
             if l != i:
                 raise NotImplementedError(f"irreps must be mul_0 x0e + mul_1 x1e + ...: {irreps}")
-        if not k.get('edge_time_encoding', False) or k.get('query_time_encoding', True):
-            raise NotImplementedError("only edge_time_encoding=True, query_time_encoding=False (all shipped "
-                                      "MultiscaleScoreModel configs) is on the accelerated path")
+        ebm = bool(k.get('ebm', False))
+        ete, qte = bool(k.get('edge_time_encoding', False)), bool(k.get('query_time_encoding', True))
+        if qte or (ebm and ete) or (not ebm and not ete):
+            raise NotImplementedError("accelerated path: score head with edge_time_encoding=True / query_time_encoding=False, "
+                                      "or EBM critic head with both False (the only combinations in the shipped configs)")
         if tf.get('n_layers', 1) != 1:
             raise NotImplementedError("n_layers != 1")
         if tf.get('cutoff_method', 'edge_attn') != 'edge_attn':
@@ -83,8 +86,8 @@ class HeadConfig:
         fc = list(tf['fc_neurons'])
         temb = list(k['time_emb_mlp'])
         if fc[0] == -1:
-            fc[0] = tf['length_emb_dim'] + temb[-1]
-        assert fc[0] == tf['length_emb_dim'] + temb[-1]
+            fc[0] = tf['length_emb_dim'] + (temb[-1] if ete else 0)
+        assert fc[0] == tf['length_emb_dim'] + (temb[-1] if ete else 0)
         radii = [None if r is None else float(r) for r in tf['r_cluster_multiscale']]
         if 'n_scales' in tf and tf['n_scales'] is not None:
             assert tf['n_scales'] == len(radii)
@@ -100,12 +103,14 @@ class HeadConfig:
         lmr = tf.get('length_enc_max_r', None)
         if radii[-1] is None:
             assert lmr is not None
+        elif lmr is not None:
+            raise AssertionError("You don't need to provide length_enc_max_r")      # multiscale_tensor_field.py:100
         return cls(irreps=irreps, lmax_sh=len(sh) - 1, num_heads=int(tf['num_heads']), fc_neurons=fc,
                    length_emb_dim=int(tf['length_emb_dim']), radii=radii, r_mincut_nonscalar_sh=float(rmin),
                    length_enc_max_r=float(lmr) if lmr is not None else 0.0, time_emb_mlp=temb,
                    max_time=float(k['max_time']), time_enc_n=float(k.get('time_enc_n', 10000.)),
                    lin_mult=float(k['lin_mult']), ang_mult=float(k['ang_mult']),
-                   irreps_mlp_mid=int(tf.get('irreps_mlp_mid', 3)))
+                   irreps_mlp_mid=int(tf.get('irreps_mlp_mid', 3)), ebm=ebm)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -217,7 +222,7 @@ def param_spec(cfg: HeadConfig) -> List[Tuple[str, Tuple[int, ...], str, float]]
     sby = dtp_sorted_out(spaths)
     n_pre = muls[1]
     smul = [sum(spaths[p][3] for p in sby.get(l, [])) for l in (0, 1)]
-    for name in ("lin_vel_tp", "ang_vel_tp"):
+    for name in (() if cfg.ebm else ("lin_vel_tp", "ang_vel_tp")):
         S.append((f"{name}.dtp.tp.weight", (sum(p[3] * p[4] for p in spaths),),
                   'tp_w:' + ','.join(f"{p[3]*p[4]}:{p[4]}" for p in spaths), 0))
         lo = [1 + n_pre, n_pre]

@@ -47,12 +47,13 @@ class ScoreModelHead(torch.nn.Module):
                  query_time_encoding: bool = True,
                  device: Union[str, torch.device, None] = None,
                  init_seed: int = 2,
-                 max_edges: int = 0):
+                 max_edges: int = 0,
+                 ebm: bool = False):
         super().__init__()
-        kw = dict(max_time=max_time, time_emb_mlp=list(time_emb_mlp), key_tensor_field_kwargs=dict(key_tensor_field_kwargs),
+        kw = dict(ebm=ebm, max_time=max_time, time_emb_mlp=list(time_emb_mlp), key_tensor_field_kwargs=dict(key_tensor_field_kwargs),
                   irreps_query_edf=irreps_query_edf, lin_mult=lin_mult, ang_mult=ang_mult, time_enc_n=time_enc_n,
                   edge_time_encoding=edge_time_encoding, query_time_encoding=query_time_encoding)
-        if not edge_time_encoding and not query_time_encoding:
+        if not edge_time_encoding and not query_time_encoding and not ebm:
             raise NotImplementedError("No time encoding! Are you sure?")          # reference score_head.py:72-73
         self.cfg = HeadConfig.from_kwargs(kw)
         self.lin_mult, self.ang_mult = float(lin_mult), float(ang_mult)
@@ -215,3 +216,43 @@ class ScoreModelHead(torch.nn.Module):
             rc = lib.dedf_debug_copy(self._handle, name.encode(), out.data_ptr(), n.value, C.byref(n))
             _lib.raise_for(lib, self._handle, rc, "dedf_debug_copy")
         return out
+
+
+class EbmScoreModelHead(ScoreModelHead):
+    """Energy-based critic head — drop-in for ``compute_energy`` of reference ``diffusion_edf/score_head_ebm.py:18-255``
+    (what ``agent.py:163-174`` calls to rank the sampled poses).  Same constructor keywords and parameter names (no
+    ``lin_vel_tp`` / ``ang_vel_tp``); ``forward`` (score = autograd of the energy, ``score_head_ebm.py:192-222``) needs a
+    backward pass and is not on the accelerated path."""
+    jittable: bool = False
+
+    def __init__(self, max_time: float, time_emb_mlp: List[int], key_tensor_field_kwargs: Dict, irreps_query_edf,
+                 lin_mult: float, ang_mult: float, time_enc_n: float = 10000., edge_time_encoding: bool = False,
+                 query_time_encoding: bool = True, **kw):
+        kw.pop('ebm', None)
+        super().__init__(max_time=max_time, time_emb_mlp=time_emb_mlp, key_tensor_field_kwargs=key_tensor_field_kwargs,
+                         irreps_query_edf=irreps_query_edf, lin_mult=lin_mult, ang_mult=ang_mult, time_enc_n=time_enc_n,
+                         edge_time_encoding=edge_time_encoding, query_time_encoding=query_time_encoding, ebm=True, **kw)
+        self.energy_rescale_factor = 1. / float(self.key_edf_dim)
+
+    @torch.no_grad()
+    def compute_energy(self, Ts: torch.Tensor, key_pcd_multiscale: List[FeaturedPoints], query_pcd: FeaturedPoints,
+                       time: torch.Tensor) -> torch.Tensor:
+        assert Ts.ndim == 2 and Ts.shape[-1] == 7, f"{Ts.shape}"                      # reference score_head_ebm.py:129
+        assert time.ndim == 1 and len(time) == len(Ts), f"{time.shape}"               # :130
+        assert query_pcd.f.ndim == 2 and query_pcd.f.shape[-1] == self.query_edf_dim, f"{query_pcd.f.shape}"   # :131
+        self._sync_inputs(key_pcd_multiscale, query_pcd)
+        lib = _lib.load()
+        nT = len(Ts)
+        Ts32 = Ts.detach().to(torch.float32).contiguous()
+        t32 = time.detach().to(torch.float32).contiguous()
+        energy = torch.empty(nT, device=Ts.device, dtype=torch.float32)
+        rc = lib.dedf_energy(self._handle, nT, Ts32.data_ptr(), t32.data_ptr(), energy.data_ptr(), self._stream())
+        _lib.raise_for(lib, self._handle, rc, "dedf_energy")
+        return energy.to(Ts.dtype)
+
+    def warmup(self, Ts, key_pcd_multiscale, query_pcd, time):                         # reference score_head_ebm.py:176-181
+        return self.compute_energy(Ts=Ts, key_pcd_multiscale=key_pcd_multiscale, query_pcd=query_pcd, time=time)
+
+    def forward(self, Ts, key_pcd_multiscale, query_pcd, time):
+        raise NotImplementedError("EbmScoreModelHead.forward is the autograd of compute_energy (reference score_head_ebm.py:"
+                                  "203-217); only compute_energy (the inference-time critic) is on the accelerated path")

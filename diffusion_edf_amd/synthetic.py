@@ -16,6 +16,13 @@ from .params import HeadConfig
 from .so3 import irreps_dim
 
 
+def ebm_head_kwargs(lmax: int = 2, radii=(3.5, 5., 6.5, 8.)) -> dict:
+    """`score_head_kwargs` of the critic: reference configs/panda_mug/pick_ebm/score_model_configs.yaml:3-26 (no time encoding)"""
+    kw = score_head_kwargs(lmax, radii)
+    kw.update(ebm=True, edge_time_encoding=False, query_time_encoding=False)
+    return kw
+
+
 def score_head_kwargs(lmax: int = 2, radii=(5., 10., 20., None)) -> dict:
     """The `score_head_kwargs` block of reference configs/panda_mug/pick_lowres/score_model_configs.yaml:3-25
     (+ the keys multiscale_score_model.py:79-85 injects), with irreps truncated at `lmax`."""

@@ -15,6 +15,7 @@
  *   dedf_set_query       the `query_pcd` argument                 score_head.py:144,151-157
  *   dedf_score           ScoreModelHead.forward                   score_head.py:142-211
  *   dedf_sample          ScoreModelBase.sample (inner loop)       score_model_base.py:110-204
+ *   dedf_energy          EbmScoreModelHead.compute_energy         score_head_ebm.py:122-174
  *   dedf_destroy         module deletion
  *
  * Conventions: all tensor arguments are DEVICE pointers owned by the caller (the library never frees or mutates
@@ -46,7 +47,7 @@ typedef struct dedf_config {
     int lmax;                            /* irreps = 64x0e + 32x1e (+ 16x2e); SH 0..lmax.  Supported: 1, 2 */
     int mul[4];                          /* must equal {64,32,16,8}[0..lmax] (every reference config) */
     int num_heads;                       /* 4 */
-    int fc_neurons[3];                   /* {128,128,64}: fc_neurons after the -1 is resolved (multiscale_tensor_field.py:63-67) */
+    int fc_neurons[3];                   /* {128,128,64} ({64,128,64} for the EBM head): fc_neurons after the -1 is resolved (multiscale_tensor_field.py:63-67) */
     int length_emb_dim;                  /* 64 */
     int time_emb_mlp[3];                 /* {256,128,64} */
     int irreps_mlp_mid;                  /* 3 */
@@ -60,6 +61,8 @@ typedef struct dedf_config {
     int max_neighbors;                   /* 1000 (multiscale_tensor_field.py:195) */
     int device;                          /* HIP device ordinal; -1 = host-only handle (packing tests, no GPU calls) */
     int64_t max_edges;                   /* edge workspace capacity per call; 0 = auto */
+    int ebm;                             /* 1: EbmScoreModelHead (score_head_ebm.py): energy critic, no time encoding, fc_neurons[0] = 64,
+                                            no lin/ang_vel_tp parameters; only dedf_energy is available.  0: ScoreModelHead */
 } dedf_config;
 
 typedef struct dedf_schedule {           /* host arrays, one entry per denoising step (score_model_base.py:146-171) */
@@ -98,6 +101,10 @@ int dedf_set_query(dedf_handle* h, int nQ, const float* x, const float* f, const
 
 /* Ts: (nT,7) f32, time: (nT,) f32 -> ang: (nT,3), lin: (nT,3) f32 ("ang first", score_head.py:211). */
 int dedf_score(dedf_handle* h, int nT, const float* Ts, const float* time, float* ang, float* lin, void* stream);
+
+/* EbmScoreModelHead.compute_energy (score_head_ebm.py:122-174; used by agent.py:163-174 to rank the sampled poses):
+ * Ts (nT,7) f32, time (nT,) f32 (ignored by the shipped critic configs: no time encoding) -> energy (nT,) f32.  EBM handles only. */
+int dedf_energy(dedf_handle* h, int nT, const float* Ts, const float* time, float* energy, void* stream);
 
 /* T_seed: (nT,7) f64; noise: NULL (counter-based Philox keyed by (seed, first_pose_index + pose, step)) or
  * (n_steps,2,nT,3) f64 standard normals [ang, lin]; Ts_out: (n_steps + 2, nT, 7) f64 = [seed, after each step, final again]

@@ -523,6 +523,7 @@ class Config(NamedTuple):
     ang_mult: float
     irreps_mlp_mid: int = 3
     max_neighbors: int = 1000
+    edge_time_encoding: bool = True
 
 
 def config_from_kwargs(score_head_kwargs: dict) -> Config:
@@ -533,11 +534,13 @@ def config_from_kwargs(score_head_kwargs: dict) -> Config:
     irreps = parse_irreps(tf['irreps_output'])
     assert parse_irreps(tf.get('irreps_input', tf['irreps_output'])) == irreps
     assert parse_irreps(k.get('irreps_query_edf', tf['irreps_output'])) == irreps
-    assert k.get('edge_time_encoding', False) and not k.get('query_time_encoding', True)
+    ete = bool(k.get('edge_time_encoding', False))
+    assert not k.get('query_time_encoding', True)
+    assert ete or k.get('ebm', False), "No time encoding! Are you sure?"       # score_head.py:72-73 (the EBM head allows it)
     assert tf.get('n_layers', 1) == 1 and tf.get('cutoff_method', 'edge_attn') == 'edge_attn'
     fc = list(tf['fc_neurons'])
-    if fc[0] == -1:
-        fc[0] = tf['length_emb_dim'] + k['time_emb_mlp'][-1]     # multiscale_tensor_field.py:63-67
+    if fc[0] == -1:                                               # multiscale_tensor_field.py:63-67
+        fc[0] = tf['length_emb_dim'] + (k['time_emb_mlp'][-1] if ete else 0)
     r0 = tf['r_cluster_multiscale'][0]
     rmin = tf.get('r_mincut_nonscalar_sh', None)
     if rmin is None:
@@ -548,7 +551,7 @@ def config_from_kwargs(score_head_kwargs: dict) -> Config:
                   length_enc_max_r=tf.get('length_enc_max_r', None), time_emb_mlp=list(k['time_emb_mlp']),
                   max_time=float(k['max_time']), time_enc_n=float(k.get('time_enc_n', 10000.)),
                   lin_mult=float(k['lin_mult']), ang_mult=float(k['ang_mult']),
-                  irreps_mlp_mid=tf.get('irreps_mlp_mid', 3))
+                  irreps_mlp_mid=tf.get('irreps_mlp_mid', 3), edge_time_encoding=ete)
 
 
 class FeaturedPoints(NamedTuple):
@@ -612,7 +615,9 @@ def key_tensor_field(cfg: Config, P, query_x: Tensor, key_pcd_multiscale: Sequen
             ge = encode_edges(kp.x, query_x, es, ed, r_cutoff=float(r), r_mincut=cfg.r_mincut_nonscalar_sh,
                               irreps_sh=irreps_sh, length_enc=enc, fill_edge_weights=None)
             fill = 1.0                                           # multiscale_tensor_field.py:139-140
-        scal = torch.cat([ge.edge_scalars, context_emb[n].index_select(0, ge.edge_dst)], dim=-1)
+        scal = ge.edge_scalars
+        if context_emb is not None:                               # multiscale_tensor_field.py:219-231
+            scal = torch.cat([scal, context_emb[n].index_select(0, ge.edge_dst)], dim=-1)
         scal = scal @ P[f"{pre}.edge_scalars_pre_linears.{n}.0.weight"].t() + P[f"{pre}.edge_scalars_pre_linears.{n}.0.bias"]
         scal = torch.nn.functional.silu(scal)
         E_src.append(ge.edge_src + n_total)
@@ -720,6 +725,24 @@ def score_head_forward(cfg: Config, P, Ts: Tensor, key_pcd_multiscale: Sequence[
     lin = torch.einsum('q,tqi->ti', w, lin_vel)
     ang = torch.einsum('q,tqi->ti', w, ang_orbital) + torch.einsum('q,tqi->ti', w, ang_spin)
     return ang, lin
+
+
+def compute_energy(cfg: Config, P, Ts: Tensor, key_pcd_multiscale: Sequence[FeaturedPoints], query_pcd: FeaturedPoints,
+                   time: Tensor, dbg: Optional[Debug] = None) -> Tensor:
+    """EbmScoreModelHead.compute_energy — score_head_ebm.py:122-174 (the critic used by agent.py:163-174 to rank poses).
+    energy_t = sum_q w_q |field(T_t x_q) - D(q_t) f_q|^2 / dim."""
+    assert Ts.ndim == 2 and Ts.shape[-1] == 7
+    irreps = cfg.irreps
+    nT, nQ = len(Ts), len(query_pcd.x)
+    tembs = None
+    if cfg.edge_time_encoding:
+        tembs = [t.unsqueeze(-2).expand(-1, nQ, -1).reshape(nT * nQ, -1) for t in time_embeddings(cfg, P, time)]
+    f_t = transform_feature_quaternion(irreps, query_pcd.f, Ts[..., :4])
+    x_t = transform_points(query_pcd.x, Ts)
+    field = key_tensor_field(cfg, P, x_t.reshape(-1, 3), key_pcd_multiscale, tembs, dbg)
+    qf = f_t.reshape(nT * nQ, -1)
+    energy = (field - qf).square().sum(dim=-1) * (1.0 / float(dim(irreps)))
+    return torch.einsum('q,tq->t', query_pcd.w, energy.view(nT, nQ))
 
 
 _Q_INDICES = torch.tensor([[1, 2, 3], [0, 3, 2], [3, 0, 1], [2, 1, 0]], dtype=torch.long)

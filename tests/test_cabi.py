@@ -36,6 +36,18 @@ def test_canonical_parameter_order_matches_reference_schema(built_lib, lmax):
     assert params.n_params(cfg) == {1: 384130, 2: 429570}[lmax]
 
 
+def test_ebm_schema(built_lib):
+    """EBM critic: pre-linear is 64x64 (no time embedding), no lin/ang_vel_tp parameters (reference score_head_ebm.py)"""
+    cfg = params.HeadConfig.from_kwargs(synthetic.ebm_head_kwargs(2))
+    assert cfg.fc_neurons == [64, 128, 64] and cfg.ebm
+    cc = _lib.make_config(cfg, -1)
+    names = dict(_lib.param_names(cc))
+    assert list(names.items()) == [(n, int(np.prod(s))) for n, s, _, _ in params.param_spec(cfg)]
+    assert names["key_tensor_field.edge_scalars_pre_linears.0.0.weight"] == 64 * 64
+    assert names["key_tensor_field.gnn_block_init.ga.sep_act.dtp_rad.net.0.weight"] == 128 * 64
+    assert not any(n.startswith(("lin_vel_tp", "ang_vel_tp")) for n in names)
+
+
 def test_unsupported_configs_are_rejected(built_lib):
     cfg = params.HeadConfig.from_kwargs(synthetic.score_head_kwargs(2))
     cc = _lib.make_config(cfg, -1)

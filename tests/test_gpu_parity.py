@@ -254,3 +254,37 @@ def test_full_size_c2_bi_equivariance_and_determinism():
     scale = float(max(ang.abs().max(), lin.abs().max()))
     assert float((ang2 - ang).abs().max()) / scale < 2e-4, float((ang2 - ang).abs().max()) / scale
     assert float((lin2 - lin).abs().max()) / scale < 2e-4
+
+
+# ---- EBM critic head -------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("lmax", [1, 2])
+def test_ebm_energy_parity_and_ranking(lmax):
+    from diffusion_edf_amd.score_head import EbmScoreModelHead
+    kw = synthetic.ebm_head_kwargs(lmax)
+    cfg = params.HeadConfig.from_kwargs(kw)
+    P = params.init_params(cfg, seed=4, randomize_all=True)
+    keys = synthetic.make_key_clouds(cfg, 1024, seed=0)
+    query = synthetic.make_query(cfg, 100, seed=0)
+    Ts = synthetic.make_poses(40, seed=3, near_object=True)
+    Ts[0] = torch.tensor([1., 0, 0, 0, 0., 0., 9.], dtype=torch.float64)
+    Ts[1, 4:] = torch.tensor([300., 0., 0.], dtype=torch.float64)                 # no edges at all: field = bias-only
+    time = torch.ones(len(Ts), dtype=torch.float64)
+    ocfg = R.config_from_kwargs(kw)
+    ok = [R.FeaturedPoints(k.x.double(), k.f.double(), k.b) for k in keys]
+    oq = R.FeaturedPoints(query.x.double(), query.f.double(), query.b, query.w.double())
+    e64 = R.compute_energy(ocfg, R.cast_params(P, torch.float64), Ts, ok, oq, time)
+    dev = torch.device('cuda:0')
+    head = EbmScoreModelHead(**{k: v for k, v in kw.items() if k != 'ebm'})
+    head.load_state_dict(P)
+    head.to(dev)
+    gk, gq = _to_dev(keys, query, dev)
+    e = head.compute_energy(Ts.to(dev).float(), gk, gq, time.to(dev).float()).cpu().double()
+    assert float((e - e64).abs().max() / e64.abs().max()) < TOL
+    # what agent.py:172-173 does with it: sort ascending (poses without any edge tie exactly: compare up to the tolerance)
+    ranked = e64[torch.argsort(e)]
+    assert bool((ranked[1:] - ranked[:-1] > -TOL * float(e64.abs().max())).all())
+    with pytest.raises(NotImplementedError):
+        head(Ts.to(dev).float(), gk, gq, time.to(dev).float())
+    with pytest.raises(NotImplementedError):
+        ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[1.0, 0.5]], [1], [0.04])

@@ -161,3 +161,21 @@ def test_sampler_matches_manual_loop_and_appends_final_pose_twice():
     assert torch.allclose(traj[..., :4].norm(dim=-1), torch.ones(5, 3, dtype=torch.float64), atol=1e-14)
     ts = R.t_schedule((1.0, 0.5), 3)
     assert abs(float(ts[0]) - 1.0) < 1e-15 and abs(float(ts[-1]) - 0.5) < 1e-15 and abs(float(ts[1]) - 0.5 ** 0.5) < 1e-15
+
+
+def test_ebm_energy_is_se3_invariant():
+    """compute_energy (score_head_ebm.py:122-174) is a scalar: invariant under a joint SE(3) move of scene and poses"""
+    kw = synthetic.ebm_head_kwargs(2)
+    cfgp = params.HeadConfig.from_kwargs(kw)
+    cfg = R.config_from_kwargs(kw)
+    P = params.init_params(cfgp, seed=2, randomize_all=True, dtype=torch.float64)
+    keys = [R.FeaturedPoints(*k) for k in synthetic.make_key_clouds(cfgp, 400, dtype=torch.float64)]
+    q = R.FeaturedPoints(*synthetic.make_query(cfgp, 80, dtype=torch.float64))
+    Ts = synthetic.make_poses(5, near_object=True)
+    t = torch.ones(5, dtype=torch.float64)
+    E = R.compute_energy(cfg, P, Ts, keys, q, t)
+    g, gt = _rand_q(3), torch.tensor([1., -2., 0.5], dtype=torch.float64)
+    keys2 = [R.FeaturedPoints(R.quaternion_apply(g, k.x) + gt, R.transform_feature_quaternion(cfg.irreps, k.f, g[None])[0], k.b) for k in keys]
+    Ts2 = torch.cat([R.quaternion_raw_multiply(g.expand(5, 4), Ts[:, :4]), R.quaternion_apply(g, Ts[:, 4:]) + gt], -1)
+    assert (R.compute_energy(cfg, P, Ts2, keys2, q, t) - E).abs().max() < 1e-11
+    assert (E > 0).all()
