@@ -42,6 +42,35 @@ DEDF_DEV f32x16 mfma32(float a, float b, f32x16 c) {
 #endif
 }
 
+// D(16x16) += A(16x4) * B(4x16), exact f32 (v_mfma_f32_16x16x4_f32, 32 cycles per SIMD).  A[i = l&15][k = l>>4],
+// B[k = l>>4][j = l&15], D: col = l&15, row = 4*(l>>4) + reg.
+DEDF_DEV f32x4 mfma16(float a, float b, f32x4 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#else
+    (void)a; (void)b; return c;
+#endif
+}
+// 16-lane-row exchanges (rows = lanes 0-15 | 16-31 | 32-47 | 48-63):
+//   swap16:  x' = [x0, y0, x2, y2]   y' = [x1, y1, x3, y3]          swap32:  x' = [x0, x1, y0, y1]   y' = [x2, x3, y2, y3]
+// Inline asm on purpose: with ROCm 7.2 the two-result builtins __builtin_amdgcn_permlane{16,32}_swap were observed to feed
+// the FIRST result to both consumers in this usage (tests/probe/mfma16_swap_probe.hip); the s_nop's are the wait states
+// between a VALU write of an operand and the swap / its consumers that hipcc does not insert inside asm.
+DEDF_DEV void swap16(float& x, float& y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+#else
+    (void)x; (void)y;
+#endif
+}
+DEDF_DEV void swap32(float& x, float& y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+#else
+    (void)x; (void)y;
+#endif
+}
+
 // exchange with the lane holding the other half of this item's channel rows
 DEDF_DEV float xor32(float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -97,6 +126,16 @@ DEDF_DEV f32x4 bld4(const Buf& b, int voff_bytes, int soff_bytes) {
 #endif
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+DEDF_DEV f32x2 bld2(const Buf& b, int voff_bytes, int soff_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(b.r, voff_bytes, soff_bytes, 0));
+#else
+    return *reinterpret_cast<const f32x2*>(b.p + voff_bytes + soff_bytes);
+#endif
+}
+
 struct Wave {            // per-lane constants of the transposed-GEMM layout
     int lane, col, hi;
     int lane16;          // byte offset of this lane inside a packed-A group (64 lanes x 16 B)
@@ -114,6 +153,8 @@ DEDF_DEV Wave make_wave(const void* wbuf, uint32_t wbytes) {
 DEDF_DEV f32x4 lda(const Wave& wv, int off, int nG, int To, int g) {
     return bld4(wv.w, wv.lane16, (off + (To * nG + g) * 256) * 4);
 }
+// A operands of the two register pairs of group g of a 16-row matrix packed by pack_A16: [group][lane][2]
+DEDF_DEV f32x2 lda16(const Wave& wv, int off, int g) { return bld2(wv.w, wv.lane * 8, (off + g * 128) * 4); }
 // acc tile <- 16 per-row values stored [tile][hi][r] at float offset `off`
 DEDF_DEV f32x16 ldrows(const Buf& b, int voff_hi64, int off, int tile) {
     f32x16 v;

@@ -203,9 +203,12 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
 
     // ---- layer 3 (-> per-edge TP weights, one 32-row tile at a time) fused with DTP #1 and the lin / sep_alpha GEMMs ----
     // accumulators: l3 = 0 -> NR0 tiles (lin scalars+gates | alpha), l3 >= 1 -> one tile per m
-    constexpr int NACC = NR0 + (L >= 1 ? 3 : 0) + (L >= 2 ? 5 : 0);
-    constexpr int AB1 = NR0, AB2 = NR0 + 3;   // first accumulator tile of the l3 = 1 / l3 = 2 outputs
+    // the 16-channel l3 = 2 outputs run on 16x16x4 MFMAs: [m][edge sub-tile 0-15 | 16-31], 4 registers each
+    constexpr int NACC = NR0 + (L >= 1 ? 3 : 0);
+    constexpr int AB1 = NR0;                  // first accumulator tile of the l3 = 1 outputs
     f32x16 acc[NACC];
+    f32x4 acc2[5][2];
+    static_for<5>([&]<int K>() { static_for<2>([&]<int S>() { acc2[K][S] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }); });
     static_for<NR0>([&]<int T>() { acc[T] = ldrows(wv, o_b_r0, T); });
     static_for<NACC - NR0>([&]<int T>() { static_for<16>([&]<int R>() { acc[NR0 + T][R] = 0.0f; }); });
     const Buf msgb = make_buf(P.msg, P.msg_bytes);
@@ -225,6 +228,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(G * 8));
             constexpr int l3 = pi.l3, gi = dtp_group_index<L>(G), NG = dtp_k<L>(l3) / 8;
             if constexpr (l3 == 0) static_for<NR0>([&]<int To>() { o.a[To] = lda(wv, o_A_lin[0], NG, To, gi); });
+            else if constexpr (l3 == 2) { const f32x2 t = lda16(wv, o_A_lin[2], gi); o.a[0][0] = t[0]; o.a[0][1] = t[1]; }
             else o.a[0] = lda(wv, o_A_lin[l3], NG, 0, gi);
         }
         return o;
@@ -264,10 +268,15 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         constexpr int l3 = pi.l3, d3 = 2 * l3 + 1;
         if constexpr (l3 == 0) {
             static_for<NR0>([&]<int To>() { mfma_group(acc[To], ao.a[To], bo.b[0][0], bo.b[1][0], bo.b[2][0], bo.b[3][0]); });
+        } else if constexpr (l3 == 1) {
+            static_for<d3>([&]<int K>() { mfma_group(acc[AB1 + K], ao.a[0], bo.b[0][K], bo.b[1][K], bo.b[2][K], bo.b[3][K]); });
         } else {
-            static_for<d3>([&]<int K>() {
-                mfma_group(acc[(l3 == 1 ? AB1 : AB2) + K], ao.a[0], bo.b[0][K], bo.b[1][K], bo.b[2][K], bo.b[3][K]);
-            });
+            static_for<2>([&]<int pr>() { static_for<d3>([&]<int K>() {
+                float x = bo.b[2 * pr][K], y = bo.b[2 * pr + 1][K];
+                swap16(x, y);                  // x: edges 0-15, y: edges 16-31, K-slots in 16-lane rows
+                acc2[K][0] = mfma16(ao.a[0][pr], x, acc2[K][0]);
+                acc2[K][1] = mfma16(ao.a[0][pr], y, acc2[K][1]);
+            }); });
         }
     };
     // layer-3 A operands: one global stream over all tiles, PD3 groups ahead
@@ -350,17 +359,26 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     }
     if constexpr (L >= 2) {
         constexpr int G0 = gate_row(2, 0);
+        // 16x16 accumulators back to the row layout (row = channel, lane = edge column + row half): two row exchanges
+        static_for<5>([&]<int K>() { static_for<4>([&]<int q>() {
+            float x = acc2[K][0][q], y = acc2[K][1][q];
+            swap16(x, y);
+            swap32(x, y);
+            u2[K][q] = x; u2[K][4 + q] = y;
+        }); });
         static_for<8>([&]<int R>() {
             const float gt = sigmoid_n(acc[G0 / 32][(G0 % 32) / 2 + R]);
-            static_for<5>([&]<int K>() { u2[K][R] = acc[AB2 + K][R] * gt; });
+            static_for<5>([&]<int K>() { u2[K][R] *= gt; });
         });
     }
     sched_fence();
 
     DEDF_STAMP(9);
     // ---- sep_value: depth-wise TP #2 (shared weights folded into A_val) + LinearRS -> value --------------------------------
-    constexpr int NV = 2 + (L >= 1 ? 3 : 0) + (L >= 2 ? 5 : 0);
+    constexpr int NV = 2 + (L >= 1 ? 3 : 0);
     f32x16 val[NV];
+    f32x4 val2[5][2];
+    static_for<5>([&]<int K>() { static_for<2>([&]<int S>() { val2[K][S] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }); });
     static_for<2>([&]<int T>() { val[T] = ldrows(wv, o_b_val0, T); });
     static_for<NV - 2>([&]<int T>() { static_for<16>([&]<int R>() { val[2 + T][R] = 0.0f; }); });
     // groups are walked in weight order (= path creation order, u ascending); region G = loads(G+2), VALU(G+1), MFMA(G)
@@ -370,7 +388,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         if constexpr (G < NGRP) {
             constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(G * 8));
             constexpr int l3 = pi.l3, gi = dtp_group_index<L>(G), NG = dtp_k<L>(l3) / 8;
-            o.a[0] = lda(wv, o_A_val[l3], NG, 0, gi);
+            if constexpr (l3 == 2) { const f32x2 t = lda16(wv, o_A_val[2], gi); o.a[0][0] = t[0]; o.a[0][1] = t[1]; }
+            else o.a[0] = lda(wv, o_A_val[l3], NG, 0, gi);
             if constexpr (l3 == 0) o.a[1] = lda(wv, o_A_val[0], NG, 1, gi);
         }
         return o;
@@ -405,10 +424,15 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         const BOps vb_nxt = valu_val.template operator()<G + 1>();
         if constexpr (l3 == 0) {
             static_for<2>([&]<int To>() { mfma_group(val[To], v0.a[To], vb_cur.b[0][0], vb_cur.b[1][0], vb_cur.b[2][0], vb_cur.b[3][0]); });
+        } else if constexpr (l3 == 1) {
+            static_for<d3>([&]<int K>() { mfma_group(val[2 + K], v0.a[0], vb_cur.b[0][K], vb_cur.b[1][K], vb_cur.b[2][K], vb_cur.b[3][K]); });
         } else {
-            static_for<d3>([&]<int K>() {
-                mfma_group(val[(l3 == 1 ? 2 : 5) + K], v0.a[0], vb_cur.b[0][K], vb_cur.b[1][K], vb_cur.b[2][K], vb_cur.b[3][K]);
-            });
+            static_for<2>([&]<int pr>() { static_for<d3>([&]<int K>() {
+                float x = vb_cur.b[2 * pr][K], y = vb_cur.b[2 * pr + 1][K];
+                swap16(x, y);
+                val2[K][0] = mfma16(v0.a[0][pr], x, val2[K][0]);
+                val2[K][1] = mfma16(v0.a[0][pr], y, val2[K][1]);
+            }); });
         }
         sched_fence();
         v0 = v1; v1 = v2; vb_cur = vb_nxt;
@@ -425,11 +449,16 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             st4(o + blk_off(1) + K * 32 + 8 * g + 4 * hi,
                 f32x4{val[2 + K][4 * g], val[2 + K][4 * g + 1], val[2 + K][4 * g + 2], val[2 + K][4 * g + 3]});
         }); });
-        if constexpr (L >= 2) static_for<5>([&]<int K>() { static_for<2>([&]<int g>() {
-            st4(o + blk_off(2) + K * 16 + 8 * g + 4 * hi,
-                f32x4{val[5 + K][4 * g], val[5 + K][4 * g + 1], val[5 + K][4 * g + 2], val[5 + K][4 * g + 3]});
-        }); });
         if (hi == 0) st4(o + D, f32x4{logit[0], logit[1], logit[2], logit[3]});
+    }
+    if constexpr (L >= 2) {   // l = 2 block straight from the 16x16 layout: lane (g, e') holds channels 4g..4g+3 of edges e' and 16+e'
+        const int g4 = (wv.lane >> 4) * 4, el = wv.lane & 15;
+        static_for<2>([&]<int S>() {
+            if (el + 16 * S < n_valid) {
+                float* o2 = P.out + (size_t)(e0 + el + 16 * S) * REC + blk_off(2) + g4;
+                static_for<5>([&]<int K>() { st4(o2 + K * 16, val2[K][S]); });
+            }
+        });
     }
     DEDF_STAMP(11);
 }

@@ -48,6 +48,26 @@ inline std::vector<float> pack_A(int O, const std::vector<KStep>& steps, WAt W) 
     return out;
 }
 
+// 16-row matrices on v_mfma_f32_16x16x4_f32: the four K-steps of a group (registers j = 0..3 of both half-waves) become two
+// MFMAs, pair p = registers (2p, 2p+1); after v_permlane16_swap the 16-lane rows of the B operand carry
+// slot0 = (hi 0, reg 2p), slot1 = (hi 0, reg 2p+1), slot2 = (hi 1, reg 2p), slot3 = (hi 1, reg 2p+1), and lane l supplies
+// A[o = l & 15][slot = l >> 4].  Image: [group][lane 64][pair 2].
+template <class WAt>
+inline std::vector<float> pack_A16(int O, const std::vector<KStep>& steps, WAt W) {
+    const int nG = ((int)steps.size() + 3) / 4;
+    std::vector<float> out((size_t)nG * 64 * 2, 0.0f);
+    for (int g = 0; g < nG; ++g)
+        for (int p = 0; p < 2; ++p)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int o = lane & 15, slot = lane >> 4;
+                const int s = 4 * g + 2 * p + (slot & 1);
+                if (s >= (int)steps.size()) continue;
+                const int k = (slot >> 1) ? steps[s].k1 : steps[s].k0;
+                if (o < O && k >= 0) out[((size_t)g * 64 + lane) * 2 + p] = W(o, k);
+            }
+    return out;
+}
+
 // K-steps that read a producer's accumulator tiles in order: K rows -> ceil(K/8) groups of 4 steps (a partial last
 // tile only contributes the register groups that hold valid rows, exactly as the kernels walk them).
 inline std::vector<KStep> chain_steps(int K) {

@@ -195,10 +195,15 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
                 const float* lb = S.get(B, ga + ".sep_act.lin.bias.0");
                 const float* ab = S.get(B, ga + ".sep_alpha.bias.0");
                 o.o_b_r0 = im.push(pack_rows(a0 + mul_of(0), [&](int i) { return i < Ol ? lb[i] : (i >= a0 ? ab[i - a0] : 0.0f); }));
+            } else if (l == 2) {      // 16 output channels: v_mfma_f32_16x16x4_f32 image (no 32-row padding)
+                o.o_A_lin[l] = im.push(pack_A16(Ol, dtp_steps<L>(l), [&](int oo, int k) { return Wl[k * Ol + oo]; }));
             } else {
                 o.o_A_lin[l] = im.push(pack_A(Ol, dtp_steps<L>(l), [&](int oo, int k) { return Wl[k * Ol + oo]; }));
             }
-            o.o_A_val[l] = im.push(pack_A(mul_of(l), dtp_steps<L>(l), [&](int oo, int k) { return Vl[k * mul_of(l) + oo] * w2[wflat(l, k)]; }));
+            if (l == 2)
+                o.o_A_val[l] = im.push(pack_A16(mul_of(l), dtp_steps<L>(l), [&](int oo, int k) { return Vl[k * mul_of(l) + oo] * w2[wflat(l, k)]; }));
+            else
+                o.o_A_val[l] = im.push(pack_A(mul_of(l), dtp_steps<L>(l), [&](int oo, int k) { return Vl[k * mul_of(l) + oo] * w2[wflat(l, k)]; }));
             lo += (size_t)K * Ol;
             vo += (size_t)K * mul_of(l);
         }
