@@ -1,6 +1,5 @@
-// Device-side building blocks (gfx950).  Kernel bodies are written as __host__ __device__ templates so that the
-// same source can be driven lane-by-lane by the CPU wave emulator in tests/emu (test infrastructure); the product
-// only ever launches the __device__ side.
+// Device-side building blocks (gfx950).  Kernel bodies are __host__ __device__ templates only so that the host pass of
+// hipcc parses them; the host variants of the wave-level primitives below are inert and never called.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -16,20 +15,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-#if !defined(__HIP_DEVICE_COMPILE__)
-// host side of the wave emulator (defined in tests/emu/wave_emu.h; never linked into the product)
-namespace emu {
-int lane();
-f32x16 mfma32(float a, float b, f32x16 c);
-float xor32(float v);
-}  // namespace emu
-#endif
-
 DEDF_DEV int lane_id() {
 #if defined(__HIP_DEVICE_COMPILE__)
     return (int)(threadIdx.x & 63);
 #else
-    return emu::lane();
+    return 0;
 #endif
 }
 
@@ -38,7 +28,7 @@ DEDF_DEV f32x16 mfma32(float a, float b, f32x16 c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 #else
-    return emu::mfma32(a, b, c);
+    (void)a; (void)b; return c;
 #endif
 }
 
@@ -63,6 +53,16 @@ DEDF_DEV void swap16(float& x, float& y) {
     (void)x; (void)y;
 #endif
 }
+// five independent swap16's (the 2l+1 = 5 components of one register pair) behind ONE pair of hazard nops
+DEDF_DEV void swap16x5(float (&x)[5], float (&y)[5]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %5\n\tv_permlane16_swap_b32 %1, %6\n\tv_permlane16_swap_b32 %2, %7\n\t"
+                 "v_permlane16_swap_b32 %3, %8\n\tv_permlane16_swap_b32 %4, %9\n\ts_nop 1"
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]));
+#else
+    (void)x; (void)y;
+#endif
+}
 DEDF_DEV void swap32(float& x, float& y) {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
@@ -76,7 +76,7 @@ DEDF_DEV float xor32(float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __shfl_xor(v, 32, 64);
 #else
-    return emu::xor32(v);
+    return v;
 #endif
 }
 

@@ -271,12 +271,15 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         } else if constexpr (l3 == 1) {
             static_for<d3>([&]<int K>() { mfma_group(acc[AB1 + K], ao.a[0], bo.b[0][K], bo.b[1][K], bo.b[2][K], bo.b[3][K]); });
         } else {
-            static_for<2>([&]<int pr>() { static_for<d3>([&]<int K>() {
-                float x = bo.b[2 * pr][K], y = bo.b[2 * pr + 1][K];
-                swap16(x, y);                  // x: edges 0-15, y: edges 16-31, K-slots in 16-lane rows
-                acc2[K][0] = mfma16(ao.a[0][pr], x, acc2[K][0]);
-                acc2[K][1] = mfma16(ao.a[0][pr], y, acc2[K][1]);
-            }); });
+            static_for<2>([&]<int pr>() {
+                float x[5], y[5];
+                static_for<5>([&]<int K>() { x[K] = bo.b[2 * pr][K]; y[K] = bo.b[2 * pr + 1][K]; });
+                swap16x5(x, y);                // x: edges 0-15, y: edges 16-31, K-slots in 16-lane rows
+                static_for<5>([&]<int K>() {
+                    acc2[K][0] = mfma16(ao.a[0][pr], x[K], acc2[K][0]);
+                    acc2[K][1] = mfma16(ao.a[0][pr], y[K], acc2[K][1]);
+                });
+            });
         }
     };
     // layer-3 A operands: one global stream over all tiles, PD3 groups ahead
@@ -427,12 +430,15 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         } else if constexpr (l3 == 1) {
             static_for<d3>([&]<int K>() { mfma_group(val[2 + K], v0.a[0], vb_cur.b[0][K], vb_cur.b[1][K], vb_cur.b[2][K], vb_cur.b[3][K]); });
         } else {
-            static_for<2>([&]<int pr>() { static_for<d3>([&]<int K>() {
-                float x = vb_cur.b[2 * pr][K], y = vb_cur.b[2 * pr + 1][K];
-                swap16(x, y);
-                val2[K][0] = mfma16(v0.a[0][pr], x, val2[K][0]);
-                val2[K][1] = mfma16(v0.a[0][pr], y, val2[K][1]);
-            }); });
+            static_for<2>([&]<int pr>() {
+                float x[5], y[5];
+                static_for<5>([&]<int K>() { x[K] = vb_cur.b[2 * pr][K]; y[K] = vb_cur.b[2 * pr + 1][K]; });
+                swap16x5(x, y);
+                static_for<5>([&]<int K>() {
+                    val2[K][0] = mfma16(v0.a[0][pr], x[K], val2[K][0]);
+                    val2[K][1] = mfma16(v0.a[0][pr], y[K], val2[K][1]);
+                });
+            });
         }
         sched_fence();
         v0 = v1; v1 = v2; vb_cur = vb_nxt;
