@@ -125,10 +125,12 @@ int check_config(const dedf_config* c, std::string& why) {
     for (int l = 0; l <= c->lmax; ++l)
         if (c->mul[l] != mul_of(l)) { why = "irreps must be 64x0e+32x1e(+16x2e)"; return DEDF_ERR_UNSUPPORTED; }
     if (c->num_heads != kHeads) { why = "num_heads must be 4"; return DEDF_ERR_UNSUPPORTED; }
-    if (c->fc_neurons[0] != (c->ebm ? kLenEmb : kFc0) || c->fc_neurons[1] != kFc1 || c->fc_neurons[2] != kFc2) {
-        why = "fc_neurons must resolve to [128,128,64] (score head) or [64,128,64] (EBM head without time encoding)"; return DEDF_ERR_UNSUPPORTED; }
+    const bool t_small = c->time_emb_mlp[0] == 256 && c->time_emb_mlp[1] == 128 && c->time_emb_mlp[2] == 64;
+    const bool t_big = c->time_emb_mlp[0] == 512 && c->time_emb_mlp[1] == 256 && c->time_emb_mlp[2] == 128;   // sapien high-res configs
+    if (!t_small && !t_big) { why = "time_emb_mlp must be [256,128,64] or [512,256,128]"; return DEDF_ERR_UNSUPPORTED; }
+    if (c->fc_neurons[0] != (c->ebm ? kLenEmb : kLenEmb + c->time_emb_mlp[2]) || c->fc_neurons[1] != kFc1 || c->fc_neurons[2] != kFc2) {
+        why = "fc_neurons must resolve to [64 + time_emb, 128, 64] (score head) or [64,128,64] (EBM head without time encoding)"; return DEDF_ERR_UNSUPPORTED; }
     if (c->length_emb_dim != kLenEmb) { why = "length_emb_dim must be 64"; return DEDF_ERR_UNSUPPORTED; }
-    if (c->time_emb_mlp[0] != kTimeEnc || c->time_emb_mlp[1] != kTimeHid || c->time_emb_mlp[2] != kTimeEmb) { why = "time_emb_mlp must be [256,128,64]"; return DEDF_ERR_UNSUPPORTED; }
     if (c->irreps_mlp_mid != kMlpMid) { why = "irreps_mlp_mid must be 3"; return DEDF_ERR_UNSUPPORTED; }
     if (c->n_scales < 1 || c->n_scales > kMaxScales) { why = "n_scales out of range"; return DEDF_ERR_INVALID; }
     bool inf = false;
@@ -165,17 +167,18 @@ int upload_weights(dedf_handle* h) {
     auto put = [&](const float* p, size_t n) { size_t o = nat.size(); nat.insert(nat.end(), p, p + n); return o; };
     const int ns = c.n_scales;
     h->nat_tw1 = nat.size();
-    for (int n = 0; n < ns; ++n) put(S.get(B, "time_mlps_multiscale." + std::to_string(n) + ".0.weight"), 128 * 256);
+    const size_t tE = c.time_emb_mlp[0], tH = c.time_emb_mlp[1], tT = c.time_emb_mlp[2], F0 = c.fc_neurons[0];
+    for (int n = 0; n < ns; ++n) put(S.get(B, "time_mlps_multiscale." + std::to_string(n) + ".0.weight"), tH * tE);
     h->nat_tb1 = nat.size();
-    for (int n = 0; n < ns; ++n) put(S.get(B, "time_mlps_multiscale." + std::to_string(n) + ".0.bias"), 128);
+    for (int n = 0; n < ns; ++n) put(S.get(B, "time_mlps_multiscale." + std::to_string(n) + ".0.bias"), tH);
     h->nat_tw2 = nat.size();
-    for (int n = 0; n < ns; ++n) put(S.get(B, "time_mlps_multiscale." + std::to_string(n) + ".2.weight"), 64 * 128);
+    for (int n = 0; n < ns; ++n) put(S.get(B, "time_mlps_multiscale." + std::to_string(n) + ".2.weight"), tT * tH);
     h->nat_tb2 = nat.size();
-    for (int n = 0; n < ns; ++n) put(S.get(B, "time_mlps_multiscale." + std::to_string(n) + ".2.bias"), 64);
+    for (int n = 0; n < ns; ++n) put(S.get(B, "time_mlps_multiscale." + std::to_string(n) + ".2.bias"), tT);
     h->nat_wpre = nat.size();
-    for (int n = 0; n < ns; ++n) put(S.get(B, "key_tensor_field.edge_scalars_pre_linears." + std::to_string(n) + ".0.weight"), 128 * 128);
+    for (int n = 0; n < ns; ++n) put(S.get(B, "key_tensor_field.edge_scalars_pre_linears." + std::to_string(n) + ".0.weight"), F0 * F0);
     h->nat_bpre = nat.size();
-    for (int n = 0; n < ns; ++n) put(S.get(B, "key_tensor_field.edge_scalars_pre_linears." + std::to_string(n) + ".0.bias"), 128);
+    for (int n = 0; n < ns; ++n) put(S.get(B, "key_tensor_field.edge_scalars_pre_linears." + std::to_string(n) + ".0.bias"), F0);
     const std::string blk = "key_tensor_field.gnn_block_init";
     const size_t nirr = h->L == 1 ? sum_mul<1>() : sum_mul<2>();
     size_t sq = 0;
@@ -185,10 +188,11 @@ int upload_weights(dedf_handle* h) {
     h->nat_wsrc = put(S.get(B, blk + ".linear_src.tp.weight"), sq);
     h->nat_bsrc = put(S.get(B, blk + ".linear_src.bias.0"), mul_of(0));
     {   // time-encoding frequencies, evaluated like torch: exp(float(k) * float(-ln(n)/127)) in float32
-        std::vector<float> fr(128);
-        const double step = std::log((double)c.time_enc_n) / (kTimeEnc / 2 - 1);
-        for (int k = 0; k < 128; ++k) fr[k] = std::exp((float)k * (float)(-step));
-        h->nat_tfreq = put(fr.data(), 128);
+        const int half = c.time_emb_mlp[0] / 2;
+        std::vector<float> fr(half);
+        const double step = std::log((double)c.time_enc_n) / (half - 1);
+        for (int k = 0; k < half; ++k) fr[k] = std::exp((float)k * (float)(-step));
+        h->nat_tfreq = put(fr.data(), half);
     }
     if (c.ebm) {   // no time encoding: the pre-linear "time rows" are just its bias, row-packed once
         std::vector<float> rows;
@@ -223,7 +227,7 @@ int ensure_workspace(dedf_handle* h, int nT) {
     cap = std::min<int64_t>(cap, 0x7fffffff - 64);
     cap = std::max<int64_t>(cap, 64);
     h->edge_cap = cap;
-    bool ok = h->d_Ts.ensure((size_t)nT * 7 * 4) && h->d_time.ensure((size_t)nT * 4) && h->d_tb.ensure((size_t)nT * ns * 128 * 4) &&
+    bool ok = h->d_Ts.ensure((size_t)nT * 7 * 4) && h->d_time.ensure((size_t)nT * 4) && h->d_tb.ensure((size_t)nT * ns * 256 * 4) &&
               h->d_pose.ensure((size_t)nT * kPoseRec * 4) && h->d_qpos.ensure(Nd * 3 * 4) && h->d_cnt.ensure(Nd * ns * 4) &&
               h->d_off.ensure(Nd * ns * 4) && h->d_blk.ensure(((Nd + kNbrBlock - 1) / kNbrBlock) * ns * 4 + 64) && h->d_tile.ensure(64 * 4) && h->d_esrc.ensure((size_t)cap * 4) &&
               h->d_edst.ensure((size_t)cap * 4) && h->d_eout.ensure((size_t)cap * REC * 4) && h->d_z.ensure(Nd * D * 4) &&
@@ -237,9 +241,9 @@ int ensure_workspace(dedf_handle* h, int nT) {
 }
 
 // one evaluation of the score head on poses already in h->d_Ts (f32) with times in h->d_time
-template <int L, bool EBM>
+template <int L, int F0>
 int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, hipStream_t st) {
-    constexpr int F0 = EBM ? kLenEmb : kFc0;
+    constexpr bool EBM = F0 == kLenEmb;           // 64: EBM critic (no time encoding); 128 / 192: score head with 64 / 128 time channels
     const dedf_config& c = h->cfg;
     const int ns = c.n_scales, nQ = h->nQ;
     const int Nd = nT * nQ;
@@ -260,8 +264,9 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         tp.time = h->d_time.as<float>(); tp.time_stride = time_stride;
         tp.w1 = nat + h->nat_tw1; tp.b1 = nat + h->nat_tb1; tp.w2 = nat + h->nat_tw2; tp.b2 = nat + h->nat_tb2;
         tp.wpre = nat + h->nat_wpre; tp.bpre = nat + h->nat_bpre; tp.tfreq = nat + h->nat_tfreq;
+        tp.E = c.time_emb_mlp[0]; tp.H = c.time_emb_mlp[1]; tp.TE = c.time_emb_mlp[2];
         tp.max_time = c.max_time; tp.time_enc_n = c.time_enc_n; tp.tb = h->d_tb.as<float>();
-        hipLaunchKernelGGL(k_time_bias, dim3(time_stride ? nT : 1, ns), dim3(128), 0, st, tp);
+        hipLaunchKernelGGL(k_time_bias, dim3(time_stride ? nT : 1, ns), dim3(256), 0, st, tp);
     }
     mark();
     // 3. neighbour search
@@ -348,8 +353,15 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
 }
 
 int score_dispatch(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, hipStream_t st) {
-    if (h->cfg.ebm) return h->L == 1 ? score_impl<1, true>(h, nT, time_stride, ang, lin, st) : score_impl<2, true>(h, nT, time_stride, ang, lin, st);
-    return h->L == 1 ? score_impl<1, false>(h, nT, time_stride, ang, lin, st) : score_impl<2, false>(h, nT, time_stride, ang, lin, st);
+    const int F0 = h->cfg.fc_neurons[0];
+    if (h->L == 1) {
+        if (F0 == 64) return score_impl<1, 64>(h, nT, time_stride, ang, lin, st);
+        if (F0 == 128) return score_impl<1, 128>(h, nT, time_stride, ang, lin, st);
+        return fail(h, DEDF_ERR_UNSUPPORTED, "lmax 1 with a 128-channel time embedding is not instantiated");
+    }
+    if (F0 == 64) return score_impl<2, 64>(h, nT, time_stride, ang, lin, st);
+    if (F0 == 128) return score_impl<2, 128>(h, nT, time_stride, ang, lin, st);
+    return score_impl<2, 192>(h, nT, time_stride, ang, lin, st);
 }
 
 }  // namespace
@@ -623,7 +635,7 @@ int dedf_debug_copy(dedf_handle* h, const char* name, void* host_dst, size_t max
     if (nm == "msg") { src = h->d_msg.p; n = (size_t)h->n_keys * D * 4; }
     else if (nm == "qpos") { src = h->d_qpos.p; n = Nd * 3 * 4; }
     else if (nm == "pose") { src = h->d_pose.p; n = (size_t)h->last_nT * kPoseRec * 4; }
-    else if (nm == "tb") { src = h->d_tb.p; n = (size_t)h->last_nT * h->cfg.n_scales * 128 * 4; }
+    else if (nm == "tb") { src = h->d_tb.p; n = (size_t)h->last_nT * h->cfg.n_scales * h->cfg.fc_neurons[0] * 4; }
     else if (nm == "edge_src") { src = h->d_esrc.p; n = E * 4; }
     else if (nm == "edge_dst") { src = h->d_edst.p; n = E * 4; }
     else if (nm == "edge_out") { src = h->d_eout.p; n = E * REC * 4; }

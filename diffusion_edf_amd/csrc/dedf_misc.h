@@ -92,44 +92,47 @@ __global__ void k_pose_prep(const float* __restrict__ Ts, const float* __restric
 // grid (nTb, n_scales), block 128.
 struct TimeParams {
     const float* time; int time_stride;             // stride 0: one shared time
-    const float *w1, *b1, *w2, *b2;                 // [n_scales][128][256], [128], [64][128], [64]
-    const float *wpre, *bpre;                       // [n_scales][128][128], [128]
-    const float* tfreq;                             // [128] exp(k * -(ln n / 127)) evaluated on the host like torch does
+    const float *w1, *b1, *w2, *b2;                 // [n_scales][H][E], [H], [TE][H], [TE]
+    const float *wpre, *bpre;                       // [n_scales][F0][F0], [F0]   (F0 = 64 + TE)
+    const float* tfreq;                             // [E/2] exp(k * -(ln n / (E/2 - 1))) evaluated on the host like torch does
+    int E, H, TE;                                   // time_emb_mlp = [E, H, TE]: [256,128,64] or [512,256,128]
     float max_time, time_enc_n;
     float* tb;
 };
-__global__ void k_time_bias(TimeParams P) {
-    __shared__ float enc[kTimeEnc], hid[kTimeHid], emb[kTimeEmb];
+constexpr int kTimeMaxEnc = 512, kTimeMaxHid = 256, kTimeMaxEmb = 128;
+__global__ __launch_bounds__(256) void k_time_bias(TimeParams P) {
+    __shared__ float enc[kTimeMaxEnc], hid[kTimeMaxHid], emb[kTimeMaxEmb];
     const int p = blockIdx.x, n = blockIdx.y, n_scales = gridDim.y, tid = threadIdx.x;
+    const int E = P.E, H = P.H, TE = P.TE, F0 = kLenEmb + TE;
     const float t = P.time[p * P.time_stride];
-    // SinusoidalPositionEmbeddings(dim 256, max_val, n) — radial_func.py:305-316
+    // SinusoidalPositionEmbeddings(dim E, max_val, n) — radial_func.py:305-316
     const float x = t / P.max_time * P.time_enc_n;
-    {
-        const float fr = P.tfreq[tid];
-        enc[tid] = sinf(x * fr);
-        enc[tid + 128] = cosf(x * fr);
+    for (int i = tid; i < E / 2; i += blockDim.x) {
+        const float fr = P.tfreq[i];
+        enc[i] = sinf(x * fr);
+        enc[i + E / 2] = cosf(x * fr);
     }
     __syncthreads();
-    {
-        const float* w = P.w1 + ((size_t)n * kTimeHid + tid) * kTimeEnc;
-        float s = P.b1[n * kTimeHid + tid];
-        for (int k = 0; k < kTimeEnc; ++k) s += w[k] * enc[k];
-        hid[tid] = s / (1.0f + expf(-s));
+    for (int i = tid; i < H; i += blockDim.x) {
+        const float* w = P.w1 + ((size_t)n * H + i) * E;
+        float s = P.b1[n * H + i];
+        for (int k = 0; k < E; ++k) s += w[k] * enc[k];
+        hid[i] = s / (1.0f + expf(-s));
     }
     __syncthreads();
-    if (tid < kTimeEmb) {
-        const float* w = P.w2 + ((size_t)n * kTimeEmb + tid) * kTimeHid;
-        float s = P.b2[n * kTimeEmb + tid];
-        for (int k = 0; k < kTimeHid; ++k) s += w[k] * hid[k];
-        emb[tid] = s;
+    for (int i = tid; i < TE; i += blockDim.x) {
+        const float* w = P.w2 + ((size_t)n * TE + i) * H;
+        float s = P.b2[n * TE + i];
+        for (int k = 0; k < H; ++k) s += w[k] * hid[k];
+        emb[i] = s;
     }
     __syncthreads();
-    {
-        const float* w = P.wpre + ((size_t)n * 128 + tid) * 128 + kLenEmb;
-        float s = P.bpre[n * 128 + tid];
-        for (int k = 0; k < kTimeEmb; ++k) s += w[k] * emb[k];
-        const int tile = tid >> 5, row = tid & 31;
-        P.tb[((size_t)p * n_scales + n) * 128 + (tile * 2 + row_hi(row)) * 16 + row_reg(row)] = s;
+    for (int i = tid; i < F0; i += blockDim.x) {
+        const float* w = P.wpre + ((size_t)n * F0 + i) * F0 + kLenEmb;
+        float s = P.bpre[n * F0 + i];
+        for (int k = 0; k < TE; ++k) s += w[k] * emb[k];
+        const int tile = i >> 5, row = i & 31;
+        P.tb[((size_t)p * n_scales + n) * F0 + (tile * 2 + row_hi(row)) * 16 + row_reg(row)] = s;
     }
 }
 

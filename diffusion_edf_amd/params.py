@@ -88,6 +88,11 @@ class HeadConfig:
         if fc[0] == -1:
             fc[0] = tf['length_emb_dim'] + (temb[-1] if ete else 0)
         assert fc[0] == tf['length_emb_dim'] + (temb[-1] if ete else 0)
+        if fc[1:] != [128, 64]:
+            raise NotImplementedError(f"fc_neurons {fc}: only [*, 128, 64] radial MLPs are instantiated (all panda_* configs and "
+                                      "sapien pick_highres; the two sapien place_highres configs use [*, 32, 32])")
+        if temb not in ([256, 128, 64], [512, 256, 128]):
+            raise NotImplementedError(f"time_emb_mlp {temb}")
         radii = [None if r is None else float(r) for r in tf['r_cluster_multiscale']]
         if 'n_scales' in tf and tf['n_scales'] is not None:
             assert tf['n_scales'] == len(radii)

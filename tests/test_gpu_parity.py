@@ -288,3 +288,23 @@ def test_ebm_energy_parity_and_ranking(lmax):
         head(Ts.to(dev).float(), gk, gq, time.to(dev).float())
     with pytest.raises(NotImplementedError):
         ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[1.0, 0.5]], [1], [0.04])
+
+
+def test_score_parity_sapien_highres_shape():
+    """reference configs/sapien/pick_highres/score_model_configs.yaml: time_emb_mlp [512,256,128] (pre-linear 192 wide), ONE finite
+    scale r = 6 cm, r_mincut_nonscalar_sh 0.1"""
+    kw = synthetic.score_head_kwargs(2, radii=(6.,))
+    kw['time_emb_mlp'] = [512, 256, 128]
+    kw['key_tensor_field_kwargs']['r_mincut_nonscalar_sh'] = 0.1
+    cfg = params.HeadConfig.from_kwargs(kw)
+    assert cfg.fc_neurons == [192, 128, 64]
+    P = params.init_params(cfg, seed=2, randomize_all=True)
+    keys = synthetic.make_key_clouds(cfg, 3000, seed=0)
+    query = synthetic.make_query(cfg, 200, seed=0)
+    Ts = synthetic.make_poses(9, seed=1, near_object=True)
+    time = torch.linspace(0.1, 1.0, len(Ts), dtype=torch.float64)
+    ang64, lin64, d64, _ = SC.oracle_run(kw, P, keys, query, Ts, time, torch.float64)
+    head, ang, lin = SC.gpu_run(kw, P, keys, query, Ts, time, debug=False)
+    assert head.stats()['n_edges'] == d64['n_edges_per_scale'] and d64['n_edges_per_scale'][0] > 100
+    scale = float(max(ang64.abs().max(), lin64.abs().max()))
+    assert float((ang.double() - ang64).abs().max()) / scale < TOL and float((lin.double() - lin64).abs().max()) / scale < TOL
