@@ -176,6 +176,45 @@ DEDF_DEV int opaque_s(int x) {
     return x;
 }
 
+// ---- split-fp16 MFMA (v_mfma_f32_32x32x16_f16, 32 cycles): 22-bit operands, fp32 accumulate ---------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+struct HL { h8 hi, lo; };
+DEDF_DEV f32x16 mfma_h(h8 a, h8 b, f32x16 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
+    (void)a; (void)b; return c;
+#endif
+}
+// x = hi + lo with hi = fp16(x), lo = fp16(x - hi): |x - hi - lo| <= 2^-22 |x| (or the fp16 subnormal step 6e-8)
+DEDF_DEV HL split8(const float (&x)[8]) {
+    HL r;
+    static_for<8>([&]<int J>() { const _Float16 h = (_Float16)x[J]; r.hi[J] = h; r.lo[J] = (_Float16)(x[J] - (float)h); });
+    return r;
+}
+// Dense layer on split-fp16 MFMAs, NTO output tiles rotated, A images [To][chunk][lane][8 halves] (hi at off_h, lo at off_l),
+// operands prefetched PD chunks ahead.   bsrc.operator()<chunk, j>() -> fp32 value of element j of the chunk (8 registers).
+template <int NTO, int NCH, int PD = 2, class BsrcF>
+DEDF_DEV void dense_rot_h(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[NTO], BsrcF&& bsrc) {
+    f32x4 rh[PD][NTO], rl[PD][NTO];
+    static_for<PD>([&]<int k>() { if constexpr (k < NCH) static_for<NTO>([&]<int To>() {
+        rh[k][To] = lda(wv, off_h, NCH, To, k); rl[k][To] = lda(wv, off_l, NCH, To, k); }); });
+    static_for<NCH>([&]<int c>() {
+        f32x4 ch[NTO], cl[NTO];
+        static_for<NTO>([&]<int To>() { ch[To] = rh[c % PD][To]; cl[To] = rl[c % PD][To]; });
+        if constexpr (c + PD < NCH) static_for<NTO>([&]<int To>() {
+            rh[c % PD][To] = lda(wv, off_h, NCH, To, c + PD); rl[c % PD][To] = lda(wv, off_l, NCH, To, c + PD); });
+        sched_fence();
+        float t[8];
+        static_for<8>([&]<int J>() { t[J] = bsrc.template operator()<c, J>(); });
+        const HL b = split8(t);
+        static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, ch[To]), b.hi, acc[To]); });
+        static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, ch[To]), b.lo, acc[To]); });
+        static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, cl[To]), b.hi, acc[To]); });
+        sched_fence();
+    });
+}
+
 // Dense layer  out[NTO tiles] += W * act  with the NTO accumulators rotated inside every K-group (consecutive MFMAs hit
 // different accumulators: an instruction between two MFMAs on the SAME accumulator costs a ~43-cycle bubble on gfx950).
 //   bop.operator()<kg, j>() -> B operand of K-step 4*kg + j;   A operands prefetched one K-group (NTO float4) ahead.

@@ -39,10 +39,10 @@ struct EdgeParams {
     const float* W;
     uint32_t W_bytes;
     int o_enc;                // [n_scales][3][2][32]  mean | 1/std | weight in (hi, s) order; infinite: freq[32] first
-    int o_A_pre;              // [n_scales][F0/32 tiles][8 groups][64][4]
-    int o_A_r1, o_b_r1, o_g_r1, o_be_r1;
-    int o_A_r2, o_b_r2, o_g_r2, o_be_r2;
-    int o_A_r3, o_off_r3;
+    int o_A_pre, o_A_pre_l;   // split-fp16 images [n_scales][F0/32 tiles][4 chunks][64][8 halves] (hi | lo)
+    int o_A_r1, o_A_r1_l, o_b_r1, o_g_r1, o_be_r1;
+    int o_A_r2, o_A_r2_l, o_b_r2, o_g_r2, o_be_r2;
+    int o_A_r3, o_A_r3_l, o_off_r3;
     int o_A_lin[4];           // l3 = 0: lin0 rows + alpha rows; l3 >= 1: mul(l3) rows
     int o_b_r0;               // row-packed bias over the l3 = 0 row space
     int o_A_val[4];           // sep_value.lin with the shared DTP weights folded in
@@ -111,6 +111,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     const int o_A_r1 = opaque_s(P.o_A_r1), o_b_r1 = opaque_s(P.o_b_r1), o_g_r1 = opaque_s(P.o_g_r1), o_be_r1 = opaque_s(P.o_be_r1);
     const int o_A_r2 = opaque_s(P.o_A_r2), o_b_r2 = opaque_s(P.o_b_r2), o_g_r2 = opaque_s(P.o_g_r2), o_be_r2 = opaque_s(P.o_be_r2);
     const int o_A_r3 = opaque_s(P.o_A_r3), o_off_r3 = opaque_s(P.o_off_r3), o_b_r0 = opaque_s(P.o_b_r0);
+    const int o_A_r1_l = opaque_s(P.o_A_r1_l), o_A_r2_l = opaque_s(P.o_A_r2_l), o_A_r3_l = opaque_s(P.o_A_r3_l);
     const int o_b_val0 = opaque_s(P.o_b_val0), o_alpha_dot = opaque_s(P.o_alpha_dot);
     int o_A_lin[L + 1], o_A_val[L + 1];
     static_for<L + 1>([&]<int l>() { o_A_lin[l] = opaque_s(P.o_A_lin[l]); o_A_val[l] = opaque_s(P.o_A_val[l]); });
@@ -181,22 +182,22 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     {
         const Buf tbb = make_buf(P.tb, P.tb_bytes);
         const int tvoff = (pose * P.tb_pose_stride) * 4 + wv.hi64;
-        const int oA = opaque_s(P.o_A_pre + scale * (NH * 8 * 256));
+        const int oA = opaque_s(P.o_A_pre + scale * (NH * 4 * 256)), oAl = opaque_s(P.o_A_pre_l + scale * (NH * 4 * 256));
         static_for<NH>([&]<int To>() { h[To] = ldrows(tbb, tvoff, scale * F0, To); });
-        dense_rot<NH, 8, 2>(wv, oA, h, [&]<int kg, int j>() { return eb[4 * kg + j]; });
+        dense_rot_h<NH, 4, 2>(wv, oA, oAl, h, [&]<int c, int j>() { return eb[8 * c + j]; });
         static_for<NH>([&]<int To>() { static_for<16>([&]<int R>() { h[To][R] = siluf(h[To][R]); }); });
     }
     DEDF_STAMP(1);
     // ---- RadialProfile layers 1, 2 (equiformer/radial_func.py:11-60) ---------------------------------------------------
     f32x16 r1[4];
     static_for<4>([&]<int To>() { r1[To] = ldrows(wv, o_b_r1, To); });
-    dense_rot<4, F0 / 8, 2>(wv, o_A_r1, r1, [&]<int kg, int j>() { return h[kg / 4][4 * (kg % 4) + j]; });
+    dense_rot_h<4, F0 / 16, 2>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return h[c / 2][8 * (c % 2) + j]; });
     DEDF_STAMP(2);
     ln_silu<4>(r1, wv, o_g_r1, o_be_r1);
     DEDF_STAMP(3);
     f32x16 r2[2];
     static_for<2>([&]<int To>() { r2[To] = ldrows(wv, o_b_r2, To); });
-    dense_rot<2, 16, 4>(wv, o_A_r2, r2, [&]<int kg, int j>() { return r1[kg / 4][4 * (kg % 4) + j]; });
+    dense_rot_h<2, 8, 2>(wv, o_A_r2, o_A_r2_l, r2, [&]<int c, int j>() { return r1[c / 2][8 * (c % 2) + j]; });
     DEDF_STAMP(4);
     ln_silu<2>(r2, wv, o_g_r2, o_be_r2);
     DEDF_STAMP(5);
@@ -282,15 +283,27 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             });
         }
     };
-    // layer-3 A operands: one global stream over all tiles, PD3 groups ahead
-    constexpr int NL3 = NWT * 8, PD3 = 4;
-    f32x4 l3ring[PD3];
-    static_for<PD3>([&]<int I>() { l3ring[I] = bld4(wv.w, wv.lane16, (o_A_r3 + I * 256) * 4); });
-    auto l3_group = [&]<int I>(f32x16& w) {
-        constexpr int gg = I % 8, T = gg / 4, g = gg % 4;
-        const f32x4 a = l3ring[I % PD3];
-        if constexpr (I + PD3 < NL3) l3ring[I % PD3] = bld4(wv.w, wv.lane16, (o_A_r3 + (I + PD3) * 256) * 4);
-        mfma_group(w, a, r2[T][4 * g], r2[T][4 * g + 1], r2[T][4 * g + 2], r2[T][4 * g + 3]);
+    // layer 3 on split-fp16 MFMAs: r2 (64 rows = 4 chunks) is split once per edge tile; per weight tile 4 chunks x 3 MFMAs.
+    // A operands (hi and lo image) form one global stream over all tiles, PD3 chunks ahead.
+    HL r2s[4];
+    static_for<4>([&]<int c>() {
+        float t[8];
+        static_for<8>([&]<int J>() { t[J] = r2[c / 2][8 * (c % 2) + J]; });
+        r2s[c] = split8(t);
+    });
+    constexpr int NL3 = NWT * 4, PD3 = 2;
+    f32x4 l3h[PD3], l3l[PD3];
+    static_for<PD3>([&]<int I>() { l3h[I] = bld4(wv.w, wv.lane16, (o_A_r3 + I * 256) * 4); l3l[I] = bld4(wv.w, wv.lane16, (o_A_r3_l + I * 256) * 4); });
+    auto l3_chunk = [&]<int I>(f32x16& w) {
+        constexpr int c = I % 4;
+        const h8 ah = __builtin_bit_cast(h8, l3h[I % PD3]), al = __builtin_bit_cast(h8, l3l[I % PD3]);
+        if constexpr (I + PD3 < NL3) {
+            l3h[I % PD3] = bld4(wv.w, wv.lane16, (o_A_r3 + (I + PD3) * 256) * 4);
+            l3l[I % PD3] = bld4(wv.w, wv.lane16, (o_A_r3_l + (I + PD3) * 256) * 4);
+        }
+        w = mfma_h(ah, r2s[c].hi, w);
+        w = mfma_h(ah, r2s[c].lo, w);
+        w = mfma_h(al, r2s[c].hi, w);
     };
     auto dump_w = [&]<int Tw>(const f32x16& w) {
         if (P.dbg_w != nullptr && valid)
@@ -304,7 +317,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     BOps b_cur;
     {
         const XOps x0 = load_X.template operator()<0>();
-        static_for<8>([&]<int gg>() { sched_fence(); l3_group.template operator()<gg>(wt); });
+        static_for<4>([&]<int cc>() { sched_fence(); l3_chunk.template operator()<cc>(wt); });
         sched_fence();
         dump_w.template operator()<0>(wt);
         b_cur = valu_group.template operator()<0>(x0, wt);
@@ -318,9 +331,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             const AOps a_nxt = load_A.template operator()<G + 1>();
             const XOps x_nn = load_X.template operator()<G + 2>();
             sched_fence();
-            if constexpr (Tw + 1 < NWT) {       // layer 3 of the next tile: groups {0,1,2 | 3,4,5 | 6,7 | -}
-                constexpr int first = g * 3, cnt = g == 0 || g == 1 ? 3 : (g == 2 ? 2 : 0);
-                static_for<cnt>([&]<int k>() { l3_group.template operator()<(Tw + 1) * 8 + first + k>(wt_next); });
+            if constexpr (Tw + 1 < NWT) {       // layer 3 of the next tile: chunks {0,1 | 2 | 3 | -}
+                constexpr int first = g == 0 ? 0 : g + 1, cnt = g == 0 ? 2 : (g == 3 ? 0 : 1);
+                static_for<cnt>([&]<int k>() { l3_chunk.template operator()<(Tw + 1) * 4 + first + k>(wt_next); });
             }
             const BOps b_nxt = valu_group.template operator()<G + 1>(x_nxt, g == 3 ? wt_next : wt);
             mfma_dtp.template operator()<G>(a_cur, b_cur);

@@ -68,6 +68,35 @@ inline std::vector<float> pack_A16(int O, const std::vector<KStep>& steps, WAt W
     return out;
 }
 
+// Split-fp16 A images for v_mfma_f32_32x32x16_f16 (3-term products hi*hi + hi*lo + lo*hi reproduce fp32 products to ~2^-22):
+// a K-chunk = 16 k's = 8 accumulator registers of each half-wave; lane (i = l & 31, h = l >> 5) supplies
+// A[out i][k = kof(chunk, j, h)], j = 0..7, as 8 halves (16 B).  Image: [out tile][chunk][lane 64][8 halves], one for the high
+// halves and one for the residuals; returned as raw bits in float vectors (4 floats per lane per chunk).
+template <class WAt, class KOf>
+inline void pack_A_h(int O, int nch, WAt W, KOf kof, std::vector<float>& img_hi, std::vector<float>& img_lo) {
+    const int nTo = (O + 31) / 32;
+    std::vector<uint16_t> H((size_t)nTo * nch * 64 * 8, 0), Lo((size_t)nTo * nch * 64 * 8, 0);
+    for (int To = 0; To < nTo; ++To)
+        for (int c = 0; c < nch; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int o = To * 32 + (lane & 31), k = kof(c, j, lane >> 5);
+                    if (o >= O || k < 0) continue;
+                    const float w = W(o, k);
+                    const _Float16 hh = (_Float16)w;
+                    const _Float16 ll = (_Float16)(w - (float)hh);
+                    const size_t idx = (((size_t)To * nch + c) * 64 + lane) * 8 + j;
+                    __builtin_memcpy(&H[idx], &hh, 2);
+                    __builtin_memcpy(&Lo[idx], &ll, 2);
+                }
+    img_hi.assign(H.size() / 2, 0.0f);
+    img_lo.assign(H.size() / 2, 0.0f);
+    __builtin_memcpy(img_hi.data(), H.data(), H.size() * 2);
+    __builtin_memcpy(img_lo.data(), Lo.data(), Lo.size() * 2);
+}
+// k of element j of chunk c when the B operand is a producer's accumulator tiles (row layout), K valid rows
+inline int chain_k(int K, int c, int j, int h) { const int k = 32 * (c / 2) + rowmap(8 * (c % 2) + j, h); return k < K ? k : -1; }
+
 // K-steps that read a producer's accumulator tiles in order: K rows -> ceil(K/8) groups of 4 steps (a partial last
 // tile only contributes the register groups that hold valid rows, exactly as the kernels walk them).
 inline std::vector<KStep> chain_steps(int K) {

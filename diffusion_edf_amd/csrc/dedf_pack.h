@@ -104,6 +104,7 @@ struct Image {
 
 struct EdgeOffsets {
     int o_enc, o_A_pre, o_A_r1, o_b_r1, o_g_r1, o_be_r1, o_A_r2, o_b_r2, o_g_r2, o_be_r2, o_A_r3, o_off_r3;
+    int o_A_pre_l, o_A_r1_l, o_A_r2_l, o_A_r3_l;      // residual (lo) images of the split-fp16 radial-MLP layers
     int o_A_lin[4], o_b_r0, o_A_val[4], o_b_val0, o_alpha_dot;
 };
 struct NodeOffsets {
@@ -138,33 +139,39 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
         }
         o.o_enc = im.push(enc);
     }
-    {   // pre-linear: length-embedding half of the weight (multiscale_tensor_field.py:141-146)
-        std::vector<KStep> st;
-        for (int s = 0; s < 32; ++s) st.push_back({s, s + 32});
-        std::vector<float> all;
+    // The radial MLP (pre-linear, layers 1-3) runs on split-fp16 MFMAs: hi / lo images per layer (dedf_layout.h::pack_A_h)
+    const int F0 = c.fc_neurons[0];      // 64 + time channels; 64 for the EBM head
+    {   // pre-linear: length-embedding columns of the weight (multiscale_tensor_field.py:141-146); B operand element j of chunk cc
+        // is the lane's embedding value 8 cc + j, i.e. k = 8 cc + j + 32 h
+        std::vector<float> all_h, all_l;
         for (int n = 0; n < c.n_scales; ++n) {
             const float* W = S.get(B, ktf + ".edge_scalars_pre_linears." + std::to_string(n) + ".0.weight");
-            const int F0 = c.fc_neurons[0];      // 128 = length emb (64) + time emb (64); 64 for the EBM head (no time)
-            auto a = pack_A(F0, st, [&](int oo, int k) { return W[oo * F0 + k]; });
-            all.insert(all.end(), a.begin(), a.end());
+            std::vector<float> ih, il;
+            pack_A_h(F0, 4, [&](int oo, int k) { return W[oo * F0 + k]; }, [](int cc, int j, int h) { return 8 * cc + j + 32 * h; }, ih, il);
+            all_h.insert(all_h.end(), ih.begin(), ih.end());
+            all_l.insert(all_l.end(), il.begin(), il.end());
         }
-        o.o_A_pre = im.push(all);
+        o.o_A_pre = im.push(all_h);
+        o.o_A_pre_l = im.push(all_l);
     }
     auto rows = [&](int O, const float* v) { return pack_rows(O, [&](int i) { return v[i]; }); };
     {
+        std::vector<float> ih, il;
         const float* W = S.get(B, rad + "net.0.weight");
-        const int F0 = c.fc_neurons[0];
-        o.o_A_r1 = im.push(pack_A(128, chain_steps(F0), [&](int oo, int k) { return W[oo * F0 + k]; }));
+        pack_A_h(128, F0 / 16, [&](int oo, int k) { return W[oo * F0 + k]; }, [&](int cc, int j, int h) { return chain_k(F0, cc, j, h); }, ih, il);
+        o.o_A_r1 = im.push(ih); o.o_A_r1_l = im.push(il);
         o.o_b_r1 = im.push(rows(128, S.get(B, rad + "net.0.bias")));
         o.o_g_r1 = im.push(rows(128, S.get(B, rad + "net.1.weight")));
         o.o_be_r1 = im.push(rows(128, S.get(B, rad + "net.1.bias")));
         const float* W2 = S.get(B, rad + "net.3.weight");
-        o.o_A_r2 = im.push(pack_A(64, chain_steps(128), [&](int oo, int k) { return W2[oo * 128 + k]; }));
+        pack_A_h(64, 8, [&](int oo, int k) { return W2[oo * 128 + k]; }, [](int cc, int j, int h) { return chain_k(128, cc, j, h); }, ih, il);
+        o.o_A_r2 = im.push(ih); o.o_A_r2_l = im.push(il);
         o.o_b_r2 = im.push(rows(64, S.get(B, rad + "net.3.bias")));
         o.o_g_r2 = im.push(rows(64, S.get(B, rad + "net.4.weight")));
         o.o_be_r2 = im.push(rows(64, S.get(B, rad + "net.4.bias")));
         const float* W3 = S.get(B, rad + "net.6.weight");
-        o.o_A_r3 = im.push(pack_A(dtp_wn<L>(), chain_steps(64), [&](int oo, int k) { return W3[oo * 64 + k]; }));
+        pack_A_h(dtp_wn<L>(), 4, [&](int oo, int k) { return W3[oo * 64 + k]; }, [](int cc, int j, int h) { return chain_k(64, cc, j, h); }, ih, il);
+        o.o_A_r3 = im.push(ih); o.o_A_r3_l = im.push(il);
         o.o_off_r3 = im.push(rows(dtp_wn<L>(), S.get(B, rad + "offset")));
     }
     {   // sep_act.lin (+ sep_alpha on the l3 = 0 K-steps) and sep_value.lin (shared DTP weights folded in)

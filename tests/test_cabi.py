@@ -83,7 +83,7 @@ def _replay_dense(A, n_groups, n_out_tiles, b_of_step):
 
 
 def test_packed_radial_layer_replays_as_dense_linear(built_lib):
-    """edge image, RadialProfile layer 1 (128 -> 128): K-step (T, r) feeds rows 32T+rowmap(r,0) / 32T+rowmap(r,1)"""
+    """edge image, RadialProfile layer 1 (128 -> 128): element j of chunk c feeds row 32(c/2)+rowmap(8(c%2)+j, lane>>5)"""
     cfg = params.HeadConfig.from_kwargs(synthetic.score_head_kwargs(2))
     cc = _lib.make_config(cfg, -1)
     P = params.init_params(cfg, 2, True)
@@ -96,13 +96,18 @@ def test_packed_radial_layer_replays_as_dense_linear(built_lib):
     img = np.ctypeslib.as_array(p, shape=(n.value,)).copy()
     built_lib.dedf_destroy(h)
     W = P["key_tensor_field.gnn_block_init.ga.sep_act.dtp_rad.net.0.weight"].double().numpy()
-    # locate the packed matrix: o_enc (4*192) + A_pre (4 scales * 4*8*256) come first, 16-byte aligned blocks
-    off = 4 * 192 + 4 * 4 * 8 * 256
-    A = img[off: off + 4 * 16 * 256].astype(np.float64)
+    # locate the packed matrix: o_enc (4*192), then A_pre hi and lo (4 scales * 4 tiles * 4 chunks * 256 floats each),
+    # then layer 1 as split-fp16 images [To 4][chunk 8][lane 64][8 halves]: hi image, lo (residual) image
+    off = 4 * 192 + 2 * 4 * 4 * 4 * 256
+    n = 4 * 8 * 64 * 4
+    hi = img[off: off + n].view(np.float16).astype(np.float64).reshape(4, 8, 64, 8)
+    lo = img[off + n: off + 2 * n].view(np.float16).astype(np.float64).reshape(4, 8, 64, 8)
     x = np.random.default_rng(0).normal(size=128)
-
-    def b_of_step(s):
-        T, r = divmod(s, 16)
-        return x[32 * T + _rowmap(r, 0)], x[32 * T + _rowmap(r, 1)]
-    got = _replay_dense(A, 16, 4, b_of_step)
+    got = np.zeros(128)
+    for To in range(4):
+        for c in range(8):
+            for lane in range(64):
+                for j in range(8):
+                    k = 32 * (c // 2) + _rowmap(8 * (c % 2) + j, lane >> 5)
+                    got[32 * To + (lane & 31)] += (hi[To, c, lane, j] + lo[To, c, lane, j]) * x[k]
     assert np.abs(got - W @ x).max() < 1e-5
