@@ -192,11 +192,34 @@ DEDF_DEV HL split8(const float (&x)[8]) {
     static_for<8>([&]<int J>() { const _Float16 h = (_Float16)x[J]; r.hi[J] = h; r.lo[J] = (_Float16)(x[J] - (float)h); });
     return r;
 }
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+// D(16x16) += A(16x16) * B(16x16) (v_mfma_f32_16x16x16_f16, 16 cycles; 48 when it depends on the previous one).
+// A[i = l&15][k = 4(l>>4) + e], B[k = 4(l>>4) + e][j = l&15], D: col = l&15, row = 4(l>>4) + reg (tests/probe/mfma16h_probe.hip)
+DEDF_DEV f32x4 mfma16h(h4 a, h4 b, f32x4 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+#else
+    (void)a; (void)b; return c;
+#endif
+}
+// Row layout (lane = edge column + 32 h, k16 = 8 h + jj packed in 4 VGPRs) -> the B operands of the two 16-column MFMAs:
+// afterwards halves 0-3 hold k16 = 4 (lane >> 4) + e of edge (lane & 15), halves 4-7 the same of edge 16 + (lane & 15).
+DEDF_DEV h8 relane16(h8 v) {
+    f32x4 f = __builtin_bit_cast(f32x4, v);
+    float a = f[0], b = f[1], c = f[2], d = f[3];
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#endif
+    return __builtin_bit_cast(h8, f32x4{a, b, c, d});
+}
+DEDF_DEV h4 half4(h8 v, int s) { return s == 0 ? __builtin_shufflevector(v, v, 0, 1, 2, 3) : __builtin_shufflevector(v, v, 4, 5, 6, 7); }
+
 // Dense layer on split-fp16 MFMAs, NTO output tiles rotated, A images [To][chunk][lane][8 halves] (hi at off_h, lo at off_l),
 // operands prefetched PD chunks ahead.   bsrc.operator()<chunk, j>() -> fp32 value of element j of the chunk (8 registers).
 template <int NTO, int NCH, int PD = 2, class BsrcF>
 DEDF_DEV void dense_rot_h(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[NTO], BsrcF&& bsrc) {
     f32x4 rh[PD][NTO], rl[PD][NTO];
+    sched_fence();      // keep the first operand requests out of the producer's epilogue (register pressure)
     static_for<PD>([&]<int k>() { if constexpr (k < NCH) static_for<NTO>([&]<int To>() {
         rh[k][To] = lda(wv, off_h, NCH, To, k); rl[k][To] = lda(wv, off_l, NCH, To, k); }); });
     static_for<NCH>([&]<int c>() {

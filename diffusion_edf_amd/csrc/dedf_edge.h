@@ -43,9 +43,9 @@ struct EdgeParams {
     int o_A_r1, o_A_r1_l, o_b_r1, o_g_r1, o_be_r1;
     int o_A_r2, o_A_r2_l, o_b_r2, o_g_r2, o_be_r2;
     int o_A_r3, o_A_r3_l, o_off_r3;
-    int o_A_lin[4];           // l3 = 0: lin0 rows + alpha rows; l3 >= 1: mul(l3) rows
+    int o_S_lin;              // split-fp16 A-operand stream (dedf_pack.h::pack_dtp_stream): l3 = 0 -> lin0 rows + alpha rows; l3 >= 1: mul(l3) rows
     int o_b_r0;               // row-packed bias over the l3 = 0 row space
-    int o_A_val[4];           // sep_value.lin with the shared DTP weights folded in
+    int o_S_val;              // same for sep_value.lin with the shared DTP weights folded in
     int o_b_val0;             // row-packed (64)
     int o_alpha_dot;          // row-packed over the two alpha tiles
     float* out;               // [E][edge_rec]
@@ -96,6 +96,68 @@ DEDF_DEV void ln_silu(f32x16 (&x)[NT], const Wave& wv, int o_gamma, int o_beta) 
 #define DEDF_PROF_ARG
 #endif
 
+// ---- linear layers fed by a depth-wise TP, on split-fp16 MFMAs ---------------------------------------------------------
+// Work unit = chunk of 16 DTP channels (dedf_net.h::dtp_item): the lane-local Clebsch-Gordan products of a chunk are split
+// into hi / lo halves (B operands), the weights come as a pre-split A-operand stream, every product is hi*hi + hi*lo + lo*hi.
+template <int L> struct BOpsH { h8 hi[2 * L + 1], lo[2 * L + 1]; };
+struct AItem { f32x4 h[2], l[2]; };
+template <int L, int NT0, int I>
+DEDF_DEV AItem load_item(const Wave& wv, int o_str) {
+    AItem a{};
+    constexpr DtpItem it = dtp_item<L>(I, NT0);
+    if constexpr (it.ntile > 0) {
+        if constexpr (dtp_pos_l3<L>(it.pos) == 2) {
+            const f32x2 th = bld2(wv.w, wv.lane * 8, (o_str + it.slot * 512) * 4);
+            const f32x2 tl = bld2(wv.w, wv.lane * 8, (o_str + it.slot * 512 + 128) * 4);
+            a.h[0][0] = th[0]; a.h[0][1] = th[1]; a.l[0][0] = tl[0]; a.l[0][1] = tl[1];
+        } else {
+            static_for<it.ntile>([&]<int n>() {
+                a.h[n] = bld4(wv.w, wv.lane16, (o_str + (it.slot + n) * 512) * 4);
+                a.l[n] = bld4(wv.w, wv.lane16, (o_str + (it.slot + n) * 512 + 256) * 4);
+            });
+        }
+    }
+    return a;
+}
+// MFMAs of the chunk at walk position C: l3 = 0 -> output tiles acc0[0 .. NT0) two at a time, l3 = 1 -> acc1[m],
+// l3 = 2 -> acc2[m][16-edge half] (16-row MFMAs).  The three terms are issued term-major so that consecutive MFMAs hit
+// different accumulators.
+template <int L, int NT0, int C, int PD>
+DEDF_DEV void mfma_chunk(const Wave& wv, int o_str, AItem (&ring)[PD], const BOpsH<L>& bo, f32x16 (&acc0)[NT0], f32x16 (&acc1)[3],
+                         f32x4 (&acc2)[5][2]) {
+    constexpr int l3 = dtp_pos_l3<L>(C), I0 = dtp_item_first<L>(C, NT0), NI = l3 == 0 ? cdiv(NT0, 2) : 1;
+    static_for<NI>([&]<int t>() {
+        constexpr int I = I0 + t;
+        const AItem a = ring[I % PD];
+        ring[I % PD] = load_item<L, NT0, I + PD>(wv, o_str);
+        if constexpr (l3 == 0) {
+            constexpr int nt = dtp_item<L>(I, NT0).ntile;
+            static_for<nt>([&]<int n>() { acc0[2 * t + n] = mfma_h(__builtin_bit_cast(h8, a.h[n]), bo.hi[0], acc0[2 * t + n]); });
+            static_for<nt>([&]<int n>() { acc0[2 * t + n] = mfma_h(__builtin_bit_cast(h8, a.h[n]), bo.lo[0], acc0[2 * t + n]); });
+            static_for<nt>([&]<int n>() { acc0[2 * t + n] = mfma_h(__builtin_bit_cast(h8, a.l[n]), bo.hi[0], acc0[2 * t + n]); });
+        } else if constexpr (l3 == 1) {
+            const h8 ah = __builtin_bit_cast(h8, a.h[0]), al = __builtin_bit_cast(h8, a.l[0]);
+            static_for<3>([&]<int K>() { acc1[K] = mfma_h(ah, bo.hi[K], acc1[K]); });
+            static_for<3>([&]<int K>() { acc1[K] = mfma_h(ah, bo.lo[K], acc1[K]); });
+            static_for<3>([&]<int K>() { acc1[K] = mfma_h(al, bo.hi[K], acc1[K]); });
+        } else {
+            const h4 ah = __builtin_bit_cast(h4, f32x2{a.h[0][0], a.h[0][1]}), al = __builtin_bit_cast(h4, f32x2{a.l[0][0], a.l[0][1]});
+            static_for<5>([&]<int K>() { static_for<2>([&]<int S>() { acc2[K][S] = mfma16h(ah, half4(bo.hi[K], S), acc2[K][S]); }); });
+            static_for<5>([&]<int K>() { static_for<2>([&]<int S>() { acc2[K][S] = mfma16h(ah, half4(bo.lo[K], S), acc2[K][S]); }); });
+            static_for<5>([&]<int K>() { static_for<2>([&]<int S>() { acc2[K][S] = mfma16h(al, half4(bo.hi[K], S), acc2[K][S]); }); });
+        }
+    });
+}
+// split the chunk's fp32 products v[m][8] into B operands (l3 = 2: re-laned for the 16-column MFMAs)
+template <int L, int l3>
+DEDF_DEV void split_chunk(const float (&v)[2 * l3 + 1][8], BOpsH<L>& o) {
+    static_for<2 * l3 + 1>([&]<int K>() {
+        const HL sp = split8(v[K]);
+        if constexpr (l3 == 2) { o.hi[K] = relane16(sp.hi); o.lo[K] = relane16(sp.lo); }
+        else { o.hi[K] = sp.hi; o.lo[K] = sp.lo; }
+    });
+}
+
 template <int L, int F0>
 DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, int n_valid DEDF_PROF_ARG) {
 #if defined(DEDF_PHASE_PROF) && defined(__HIP_DEVICE_COMPILE__)
@@ -113,8 +175,6 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     const int o_A_r3 = opaque_s(P.o_A_r3), o_off_r3 = opaque_s(P.o_off_r3), o_b_r0 = opaque_s(P.o_b_r0);
     const int o_A_r1_l = opaque_s(P.o_A_r1_l), o_A_r2_l = opaque_s(P.o_A_r2_l), o_A_r3_l = opaque_s(P.o_A_r3_l);
     const int o_b_val0 = opaque_s(P.o_b_val0), o_alpha_dot = opaque_s(P.o_alpha_dot);
-    int o_A_lin[L + 1], o_A_val[L + 1];
-    static_for<L + 1>([&]<int l>() { o_A_lin[l] = opaque_s(P.o_A_lin[l]); o_A_val[l] = opaque_s(P.o_A_val[l]); });
     const bool valid = wv.col < n_valid;
     const int e = e0 + (valid ? wv.col : 0);
     const int src = P.edge_src[e], dst = P.edge_dst[e];
@@ -191,7 +251,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // ---- RadialProfile layers 1, 2 (equiformer/radial_func.py:11-60) ---------------------------------------------------
     f32x16 r1[4];
     static_for<4>([&]<int To>() { r1[To] = ldrows(wv, o_b_r1, To); });
-    dense_rot_h<4, F0 / 16, 2>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return h[c / 2][8 * (c % 2) + j]; });
+    dense_rot_h<4, F0 / 16, 1>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return h[c / 2][8 * (c % 2) + j]; });
     DEDF_STAMP(2);
     ln_silu<4>(r1, wv, o_g_r1, o_be_r1);
     DEDF_STAMP(3);
@@ -203,86 +263,64 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     DEDF_STAMP(5);
 
     // ---- layer 3 (-> per-edge TP weights, one 32-row tile at a time) fused with DTP #1 and the lin / sep_alpha GEMMs ----
-    // accumulators: l3 = 0 -> NR0 tiles (lin scalars+gates | alpha), l3 >= 1 -> one tile per m
-    // the 16-channel l3 = 2 outputs run on 16x16x4 MFMAs: [m][edge sub-tile 0-15 | 16-31], 4 registers each
-    constexpr int NACC = NR0 + (L >= 1 ? 3 : 0);
-    constexpr int AB1 = NR0;                  // first accumulator tile of the l3 = 1 outputs
-    f32x16 acc[NACC];
+    // Chunks are walked grouped by output degree (dedf_net.h::dtp_pos_chunk): first all l3 = 0 chunks into acc0 (NR0 tiles:
+    // lin scalars + gates | alpha), then l3 = 1 into acc1 (one tile per m), then l3 = 2 into acc2 (16-channel outputs on
+    // 16x16x16 MFMAs: [m][edge sub-tile 0-15 | 16-31]).  When a group is complete its activations (logits, Gate) are
+    // computed and the gated features parked in LDS (this wave's private 30 KB) until the second depth-wise TP reads them.
+    f32x16 acc0[NR0], acc1[3];
     f32x4 acc2[5][2];
-    static_for<5>([&]<int K>() { static_for<2>([&]<int S>() { acc2[K][S] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }); });
-    static_for<NR0>([&]<int T>() { acc[T] = ldrows(wv, o_b_r0, T); });
-    static_for<NACC - NR0>([&]<int T>() { static_for<16>([&]<int R>() { acc[NR0 + T][R] = 0.0f; }); });
+    static_for<NR0>([&]<int T>() { acc0[T] = ldrows(wv, o_b_r0, T); });
     const Buf msgb = make_buf(P.msg, P.msg_bytes);
     // per-l1 lane offsets of the 4 message rows this lane owns inside an 8-row group
     const int mv0 = src * (D * 4) + hi * 16, mv1 = src * (D * 4) + hi * 48, mv2 = src * (D * 4) + hi * 80;
+    // LDS parking: slot = 4 registers of every lane ([slot][lane][4]); u0: 8 slots, u1[m]: 4 each, u2[m]: 2 each
+    constexpr int US1 = 8, US2 = US1 + 12, NSLOT = US2 + 10;
+    __shared__ f32x4 park[NSLOT * 64];
+    f32x4* const pk = park + wv.lane;
 
-    // Software pipeline over the WN/8 depth-wise-TP groups (8 weight rows = 4 K-steps each).  Region G issues, in one
-    // scheduling region so that hipcc interleaves them:  loads for G+1 / G+2,  the layer-3 MFMAs of the NEXT weight tile,
-    // the lane-local Clebsch-Gordan VALU work of group G+1 (-> its B operands),  and the lin / sep_alpha MFMAs of group G.
-    constexpr int NGRP = WN / 8;
-    struct AOps { f32x4 a[NR0]; };
-    struct XOps { f32x4 x[2 * L + 1]; };
-    struct BOps { float b[4][2 * L + 1]; };
-    auto load_A = [&]<int G>() {
-        AOps o;
-        if constexpr (G < NGRP) {
-            constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(G * 8));
-            constexpr int l3 = pi.l3, gi = dtp_group_index<L>(G), NG = dtp_k<L>(l3) / 8;
-            if constexpr (l3 == 0) static_for<NR0>([&]<int To>() { o.a[To] = lda(wv, o_A_lin[0], NG, To, gi); });
-            else if constexpr (l3 == 2) { const f32x2 t = lda16(wv, o_A_lin[2], gi); o.a[0][0] = t[0]; o.a[0][1] = t[1]; }
-            else o.a[0] = lda(wv, o_A_lin[l3], NG, 0, gi);
-        }
-        return o;
-    };
-    auto load_X = [&]<int G>() {      // this lane's 4 source-message rows of the group (contiguous in the reference layout)
-        XOps o;
-        if constexpr (G < NGRP) {
-            constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(G * 8));
-            constexpr int l1 = pi.l1, d1 = 2 * l1 + 1, u0 = G * 8 - pi.wstart;
+    // Software pipeline over the WN/16 chunks (16 weight rows = half a weight tile).  Region C issues, in one scheduling
+    // region so that hipcc interleaves them:  the source-message loads of chunk C+2,  the layer-3 MFMAs of the NEXT weight
+    // tile,  the lane-local Clebsch-Gordan VALU work + hi/lo split of chunk C+1 (-> its B operands),  the activations of a
+    // group completed by chunk C-1,  and the lin / sep_alpha MFMAs of chunk C (A operands through a ring, PDA items ahead).
+    constexpr int NCHK = WN / 16, PDA = 2;
+    struct XOps { f32x4 x[2][2 * L + 1]; };
+    auto load_X = [&]<int C>() {      // this lane's 2 x 4 source-message rows of the chunk (contiguous runs in the reference layout)
+        XOps o{};
+        if constexpr (C < NCHK) {
+            constexpr PathInfo pi = dtp_pos_path<L>(C);
+            constexpr int l1 = pi.l1, d1 = 2 * l1 + 1, u0 = dtp_pos_u0<L>(C);
             const int mv = l1 == 0 ? mv0 : (l1 == 1 ? mv1 : mv2);
-            static_for<d1>([&]<int Q>() { o.x[Q] = bld4(msgb, mv, (blk_off(l1) + u0 * d1 + 4 * Q) * 4); });
+            static_for<2>([&]<int run>() { static_for<d1>([&]<int Q>() {
+                o.x[run][Q] = bld4(msgb, mv, (blk_off(l1) + (u0 + 8 * run) * d1 + 4 * Q) * 4);
+            }); });
         }
         return o;
     };
-    auto valu_group = [&]<int G>(const XOps& xo, const f32x16& wtile) {
-        BOps o;
-        if constexpr (G < NGRP) {
-            constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(G * 8));
-            constexpr int l1 = pi.l1, l2 = pi.l2, l3 = pi.l3, d1 = 2 * l1 + 1, d3 = 2 * l3 + 1, g = G % 4;
-            using C = CG<l1, l2, l3>;
-            float m[C::NM];
-            C::make(Y.template get<l2>(), m);
-            float xr[4 * d1];
-            static_for<d1>([&]<int Q>() {
-                xr[4 * Q] = xo.x[Q][0]; xr[4 * Q + 1] = xo.x[Q][1]; xr[4 * Q + 2] = xo.x[Q][2]; xr[4 * Q + 3] = xo.x[Q][3];
-            });
-            static_for<4>([&]<int j>() {
-                float t[d3];
-                C::apply(&xr[j * d1], m, t);
-                static_for<d3>([&]<int K>() { o.b[j][K] = t[K] * wtile[4 * g + j]; });
-            });
-        }
-        return o;
-    };
-    auto mfma_dtp = [&]<int G>(const AOps& ao, const BOps& bo) {
-        constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(G * 8));
-        constexpr int l3 = pi.l3, d3 = 2 * l3 + 1;
-        if constexpr (l3 == 0) {
-            static_for<NR0>([&]<int To>() { mfma_group(acc[To], ao.a[To], bo.b[0][0], bo.b[1][0], bo.b[2][0], bo.b[3][0]); });
-        } else if constexpr (l3 == 1) {
-            static_for<d3>([&]<int K>() { mfma_group(acc[AB1 + K], ao.a[0], bo.b[0][K], bo.b[1][K], bo.b[2][K], bo.b[3][K]); });
-        } else {
-            static_for<2>([&]<int pr>() {
-                float x[5], y[5];
-                static_for<5>([&]<int K>() { x[K] = bo.b[2 * pr][K]; y[K] = bo.b[2 * pr + 1][K]; });
-                swap16x5(x, y);                // x: edges 0-15, y: edges 16-31, K-slots in 16-lane rows
-                static_for<5>([&]<int K>() {
-                    acc2[K][0] = mfma16(ao.a[0][pr], x[K], acc2[K][0]);
-                    acc2[K][1] = mfma16(ao.a[0][pr], y[K], acc2[K][1]);
+    auto valu_chunk = [&]<int C>(const XOps& xo, const f32x16& wtile) {
+        BOpsH<L> o{};
+        if constexpr (C < NCHK) {
+            constexpr PathInfo pi = dtp_pos_path<L>(C);
+            constexpr int l1 = pi.l1, l2 = pi.l2, l3 = pi.l3, d1 = 2 * l1 + 1, d3 = 2 * l3 + 1, c2 = C % 2;
+            using Cg = CG<l1, l2, l3>;
+            float m[Cg::NM];
+            Cg::make(Y.template get<l2>(), m);
+            float v[d3][8];
+            static_for<2>([&]<int run>() {
+                float xr[4 * d1];
+                static_for<d1>([&]<int Q>() { static_for<4>([&]<int i>() { xr[4 * Q + i] = xo.x[run][Q][i]; }); });
+                static_for<4>([&]<int j>() {
+                    float t[d3];
+                    Cg::apply(&xr[j * d1], m, t);
+                    static_for<d3>([&]<int K>() { v[K][4 * run + j] = t[K] * wtile[8 * c2 + 4 * run + j]; });
                 });
             });
+            split_chunk<L, l3>(v, o);
         }
+        return o;
     };
+    const int o_S_lin = opaque_s(P.o_S_lin);
+    AItem ring[PDA];
+    static_for<PDA>([&]<int I>() { ring[I] = load_item<L, NR0, I>(wv, o_S_lin); });
     // layer 3 on split-fp16 MFMAs: r2 (64 rows = 4 chunks) is split once per edge tile; per weight tile 4 chunks x 3 MFMAs.
     // A operands (hi and lo image) form one global stream over all tiles, PD3 chunks ahead.
     HL r2s[4];
@@ -305,180 +343,167 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         w = mfma_h(ah, r2s[c].lo, w);
         w = mfma_h(al, r2s[c].hi, w);
     };
-    auto dump_w = [&]<int Tw>(const f32x16& w) {
+    auto dump_w = [&]<int Tw>(const f32x16& w) {      // debug only: back to the e3nn weight order
         if (P.dbg_w != nullptr && valid)
-            static_for<16>([&]<int R>() { P.dbg_w[(size_t)e * WN + Tw * 32 + rowmap(R, hi)] = w[R]; });
+            static_for<16>([&]<int R>() { P.dbg_w[(size_t)e * WN + dtp_walk_row<L>(Tw * 32 + (R & 3) + 8 * (R >> 2)) + 4 * hi] = w[R]; });
     };
+
+    // activations of a completed group ----------------------------------------------------------------------------------
+    float logit[kHeads], g1[16], g2[8];
+    auto finish_group = [&]<int l3>() {
+        if constexpr (l3 == 0) {
+            // attention logits (graph_attention.py:233-246): heads of sep_alpha -> SmoothLeakyReLU -> . alpha_dot + log cut-off
+            constexpr int AT = alpha_row0<L>() / 32;
+            static_for<kHeads>([&]<int hd>() {
+                constexpr int T = AT + (hd >> 1), r0 = 8 * (hd & 1);
+                const f32x4 d0 = bld4(wv.w, wv.hi64, (o_alpha_dot + (hd >> 1) * 32 + r0) * 4);
+                const f32x4 d1v = bld4(wv.w, wv.hi64, (o_alpha_dot + (hd >> 1) * 32 + r0 + 4) * 4);
+                float sum = 0.0f;
+                static_for<4>([&]<int R>() { sum += slrelu_n(acc0[T][r0 + R]) * d0[R]; });
+                static_for<4>([&]<int R>() { sum += slrelu_n(acc0[T][r0 + 4 + R]) * d1v[R]; });
+                sum += xor32(sum);
+                logit[hd] = sum + logit0;
+            });
+            // Gate (fast_activation.py:210-224): SiLU on the 64 scalars, sigmoid gates for the l >= 1 channels
+            static_for<2>([&]<int T>() { static_for<4>([&]<int q>() {
+                pk[(4 * T + q) * 64] = f32x4{silu_n(acc0[T][4 * q]), silu_n(acc0[T][4 * q + 1]), silu_n(acc0[T][4 * q + 2]), silu_n(acc0[T][4 * q + 3])};
+            }); });
+            if constexpr (L >= 1) { constexpr int G0 = gate_row(1, 0); static_for<16>([&]<int R>() { g1[R] = sigmoid_n(acc0[G0 / 32][(G0 % 32) / 2 + R]); }); }
+            if constexpr (L >= 2) { constexpr int G0 = gate_row(2, 0); static_for<8>([&]<int R>() { g2[R] = sigmoid_n(acc0[G0 / 32][(G0 % 32) / 2 + R]); }); }
+        } else if constexpr (l3 == 1) {
+            static_for<3>([&]<int K>() { static_for<4>([&]<int q>() {
+                pk[(US1 + 4 * K + q) * 64] = f32x4{acc1[K][4 * q] * g1[4 * q], acc1[K][4 * q + 1] * g1[4 * q + 1], acc1[K][4 * q + 2] * g1[4 * q + 2],
+                                                   acc1[K][4 * q + 3] * g1[4 * q + 3]};
+            }); });
+        } else {
+            // 16x16 accumulators back to the row layout (row = channel, lane = edge column + row half): two row exchanges
+            static_for<5>([&]<int K>() {
+                float lo4[4], hi4[4];
+                static_for<4>([&]<int q>() {
+                    float x = acc2[K][0][q], y = acc2[K][1][q];
+                    swap16(x, y);
+                    swap32(x, y);
+                    lo4[q] = x * g2[q]; hi4[q] = y * g2[4 + q];
+                });
+                pk[(US2 + 2 * K) * 64] = f32x4{lo4[0], lo4[1], lo4[2], lo4[3]};
+                pk[(US2 + 2 * K + 1) * 64] = f32x4{hi4[0], hi4[1], hi4[2], hi4[3]};
+            });
+        }
+    };
+    auto start_group = [&]<int l3>() {
+        if constexpr (l3 == 1) static_for<3>([&]<int K>() { static_for<16>([&]<int R>() { acc1[K][R] = 0.0f; }); });
+        if constexpr (l3 == 2) static_for<5>([&]<int K>() { static_for<2>([&]<int S>() { acc2[K][S] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }); });
+    };
+
     DEDF_STAMP(6);
-    // prologue: weight tile 0, operands of groups 0 / 1, B operands of group 0
-    AOps a_cur = load_A.template operator()<0>();
+    // prologue: weight tile 0, source rows of chunks 0 / 1, B operands of chunk 0
     XOps x_nxt = load_X.template operator()<1>();
     f32x16 wt = ldrows(wv, o_off_r3, 0);
-    BOps b_cur;
+    BOpsH<L> b_cur;
     {
         const XOps x0 = load_X.template operator()<0>();
         static_for<4>([&]<int cc>() { sched_fence(); l3_chunk.template operator()<cc>(wt); });
         sched_fence();
         dump_w.template operator()<0>(wt);
-        b_cur = valu_group.template operator()<0>(x0, wt);
+        b_cur = valu_chunk.template operator()<0>(x0, wt);
     }
     DEDF_STAMP(7);
     static_for<NWT>([&]<int Tw>() {
         f32x16 wt_next = wt;
         if constexpr (Tw + 1 < NWT) wt_next = ldrows(wv, o_off_r3, Tw + 1);
-        static_for<4>([&]<int g>() {
-            constexpr int G = Tw * 4 + g;
-            const AOps a_nxt = load_A.template operator()<G + 1>();
-            const XOps x_nn = load_X.template operator()<G + 2>();
+        static_for<2>([&]<int c2>() {
+            constexpr int C = Tw * 2 + c2;
+            const XOps x_nn = load_X.template operator()<C + 2>();
+            static_for<L + 1>([&]<int g>() { if constexpr (g >= 1 && C == dtp_group_end<L>(g - 1)) start_group.template operator()<g>(); });
             sched_fence();
-            if constexpr (Tw + 1 < NWT) {       // layer 3 of the next tile: chunks {0,1 | 2 | 3 | -}
-                constexpr int first = g == 0 ? 0 : g + 1, cnt = g == 0 ? 2 : (g == 3 ? 0 : 1);
-                static_for<cnt>([&]<int k>() { l3_chunk.template operator()<(Tw + 1) * 4 + first + k>(wt_next); });
-            }
-            const BOps b_nxt = valu_group.template operator()<G + 1>(x_nxt, g == 3 ? wt_next : wt);
-            mfma_dtp.template operator()<G>(a_cur, b_cur);
+            if constexpr (c2 == 0 && Tw + 1 < NWT)       // layer 3 of the next weight tile
+                static_for<4>([&]<int k>() { l3_chunk.template operator()<(Tw + 1) * 4 + k>(wt_next); });
+            const BOpsH<L> b_nxt = valu_chunk.template operator()<C + 1>(x_nxt, c2 == 1 ? wt_next : wt);
+            mfma_chunk<L, NR0, C>(wv, o_S_lin, ring, b_cur, acc0, acc1, acc2);
+            static_for<L + 1>([&]<int g>() { if constexpr (C == dtp_group_end<L>(g)) finish_group.template operator()<g>(); });
             sched_fence();
-            if constexpr (g == 2 && Tw + 1 < NWT) dump_w.template operator()<Tw + 1>(wt_next);
-            a_cur = a_nxt; x_nxt = x_nn; b_cur = b_nxt;
+            if constexpr (c2 == 0 && Tw + 1 < NWT) dump_w.template operator()<Tw + 1>(wt_next);
+            x_nxt = x_nn; b_cur = b_nxt;
         });
         wt = wt_next;
     });
-
-    DEDF_STAMP(8);
-    // ---- attention logits (graph_attention.py:233-246): heads of sep_alpha -> SmoothLeakyReLU -> . alpha_dot + log cut-off
-    float logit[kHeads];
-    {
-        constexpr int AT = alpha_row0<L>() / 32;
-        static_for<kHeads>([&]<int hd>() {
-            constexpr int T = AT + (hd >> 1), r0 = 8 * (hd & 1);
-            const f32x4 d0 = bld4(wv.w, wv.hi64, (o_alpha_dot + (hd >> 1) * 32 + r0) * 4);
-            const f32x4 d1v = bld4(wv.w, wv.hi64, (o_alpha_dot + (hd >> 1) * 32 + r0 + 4) * 4);
-            float s = 0.0f;
-            static_for<4>([&]<int R>() { s += slrelu_n(acc[T][r0 + R]) * d0[R]; });
-            static_for<4>([&]<int R>() { s += slrelu_n(acc[T][r0 + 4 + R]) * d1v[R]; });
-            s += xor32(s);
-            logit[hd] = s + logit0;
-        });
-    }
-
-    // ---- Gate (fast_activation.py:210-224): SiLU on the 64 scalars, sigmoid gates on the l >= 1 channels -------------------
-    // u0[T][r]: scalars; u1[m][r] / u2[m][r]: gated l = 1 / l = 2 channels (row = channel)
-    f32x16 u0[2];
-    static_for<2>([&]<int T>() { static_for<16>([&]<int R>() { u0[T][R] = silu_n(acc[T][R]); }); });
-    float u1[3][16], u2[5][8];
-    if constexpr (L >= 1) {
-        constexpr int G0 = gate_row(1, 0);
-        static_for<16>([&]<int R>() {
-            const float gt = sigmoid_n(acc[G0 / 32][(G0 % 32) / 2 + R]);
-            static_for<3>([&]<int K>() { u1[K][R] = acc[AB1 + K][R] * gt; });
-        });
-    }
-    if constexpr (L >= 2) {
-        constexpr int G0 = gate_row(2, 0);
-        // 16x16 accumulators back to the row layout (row = channel, lane = edge column + row half): two row exchanges
-        static_for<5>([&]<int K>() { static_for<4>([&]<int q>() {
-            float x = acc2[K][0][q], y = acc2[K][1][q];
-            swap16(x, y);
-            swap32(x, y);
-            u2[K][q] = x; u2[K][4 + q] = y;
-        }); });
-        static_for<8>([&]<int R>() {
-            const float gt = sigmoid_n(acc[G0 / 32][(G0 % 32) / 2 + R]);
-            static_for<5>([&]<int K>() { u2[K][R] *= gt; });
-        });
-    }
+    finish_group.template operator()<L>();
     sched_fence();
 
+    DEDF_STAMP(8);
     DEDF_STAMP(9);
-    // ---- sep_value: depth-wise TP #2 (shared weights folded into A_val) + LinearRS -> value --------------------------------
-    constexpr int NV = 2 + (L >= 1 ? 3 : 0);
-    f32x16 val[NV];
+    // ---- sep_value: depth-wise TP #2 (shared weights folded into the A stream) + LinearRS -> value --------------------------
+    // same walk: l3 = 0 chunks -> val0, l3 = 1 -> val1[m], l3 = 2 -> val2; a completed group goes straight to the edge record
+    f32x16 val0[2], val1[3];
     f32x4 val2[5][2];
-    static_for<5>([&]<int K>() { static_for<2>([&]<int S>() { val2[K][S] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }); });
-    static_for<2>([&]<int T>() { val[T] = ldrows(wv, o_b_val0, T); });
-    static_for<NV - 2>([&]<int T>() { static_for<16>([&]<int R>() { val[2 + T][R] = 0.0f; }); });
-    // groups are walked in weight order (= path creation order, u ascending); region G = loads(G+2), VALU(G+1), MFMA(G)
-    struct ValOps { f32x4 a[2]; };
-    auto load_val = [&]<int G>() {
-        ValOps o;
-        if constexpr (G < NGRP) {
-            constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(G * 8));
-            constexpr int l3 = pi.l3, gi = dtp_group_index<L>(G), NG = dtp_k<L>(l3) / 8;
-            if constexpr (l3 == 2) { const f32x2 t = lda16(wv, o_A_val[2], gi); o.a[0][0] = t[0]; o.a[0][1] = t[1]; }
-            else o.a[0] = lda(wv, o_A_val[l3], NG, 0, gi);
-            if constexpr (l3 == 0) o.a[1] = lda(wv, o_A_val[0], NG, 1, gi);
-        }
-        return o;
-    };
-    auto valu_val = [&]<int G>() {
-        BOps o;
-        if constexpr (G < NGRP) {
-            constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(G * 8));
+    static_for<2>([&]<int T>() { val0[T] = ldrows(wv, o_b_val0, T); });
+    auto valu_val = [&]<int C>() {
+        BOpsH<L> o{};
+        if constexpr (C < NCHK) {
+            constexpr PathInfo pi = dtp_pos_path<L>(C);
             constexpr int l1 = pi.l1, l2 = pi.l2, l3 = pi.l3, d1 = 2 * l1 + 1, d3 = 2 * l3 + 1;
-            constexpr int gu = (G * 8 - pi.wstart) / 8;
-            using C = CG<l1, l2, l3>;
-            float m[C::NM];
-            C::make(Y.template get<l2>(), m);
-            static_for<4>([&]<int j>() {
-                float x[d1], t[d3];
-                if constexpr (l1 == 0) x[0] = u0[gu / 4][4 * (gu % 4) + j];
-                else if constexpr (l1 == 1) { static_for<3>([&]<int I>() { x[I] = u1[I][4 * gu + j]; }); }
-                else { static_for<5>([&]<int I>() { x[I] = u2[I][4 * gu + j]; }); }
-                C::apply(x, m, t);
-                static_for<d3>([&]<int K>() { o.b[j][K] = t[K]; });
+            constexpr int cu = dtp_pos_u0<L>(C) / 16;
+            using Cg = CG<l1, l2, l3>;
+            float m[Cg::NM];
+            Cg::make(Y.template get<l2>(), m);
+            float xs[d1][8];        // parked gated features of the chunk's 8 channels
+            static_for<d1>([&]<int I>() {
+                constexpr int s0 = l1 == 0 ? 2 * cu : (l1 == 1 ? US1 + 4 * I + 2 * cu : US2 + 2 * I);
+                const f32x4 a = pk[s0 * 64], b = pk[(s0 + 1) * 64];
+                static_for<4>([&]<int i>() { xs[I][i] = a[i]; xs[I][4 + i] = b[i]; });
             });
+            float v[d3][8];
+            static_for<8>([&]<int jj>() {
+                float x[d1], t[d3];
+                static_for<d1>([&]<int I>() { x[I] = xs[I][jj]; });
+                Cg::apply(x, m, t);
+                static_for<d3>([&]<int K>() { v[K][jj] = t[K]; });
+            });
+            split_chunk<L, l3>(v, o);
         }
         return o;
     };
-    ValOps v0 = load_val.template operator()<0>(), v1 = load_val.template operator()<1>();
-    BOps vb_cur = valu_val.template operator()<0>();
-    static_for<NGRP>([&]<int G>() {
-        constexpr PathInfo pi = dtp_path<L>(dtp_path_of_row<L>(G * 8));
-        constexpr int l3 = pi.l3, d3 = 2 * l3 + 1;
-        const ValOps v2 = load_val.template operator()<G + 2>();
-        sched_fence();
-        const BOps vb_nxt = valu_val.template operator()<G + 1>();
+    float* const orec = P.out + (size_t)e * REC;
+    auto store_group = [&]<int l3>() {       // value in internal layout [l][m][channel]
         if constexpr (l3 == 0) {
-            static_for<2>([&]<int To>() { mfma_group(val[To], v0.a[To], vb_cur.b[0][0], vb_cur.b[1][0], vb_cur.b[2][0], vb_cur.b[3][0]); });
+            if (valid) static_for<2>([&]<int T>() { static_for<4>([&]<int g>() {
+                st4(orec + T * 32 + 8 * g + 4 * hi, f32x4{val0[T][4 * g], val0[T][4 * g + 1], val0[T][4 * g + 2], val0[T][4 * g + 3]});
+            }); });
         } else if constexpr (l3 == 1) {
-            static_for<d3>([&]<int K>() { mfma_group(val[2 + K], v0.a[0], vb_cur.b[0][K], vb_cur.b[1][K], vb_cur.b[2][K], vb_cur.b[3][K]); });
-        } else {
-            static_for<2>([&]<int pr>() {
-                float x[5], y[5];
-                static_for<5>([&]<int K>() { x[K] = vb_cur.b[2 * pr][K]; y[K] = vb_cur.b[2 * pr + 1][K]; });
-                swap16x5(x, y);
-                static_for<5>([&]<int K>() {
-                    val2[K][0] = mfma16(v0.a[0][pr], x[K], val2[K][0]);
-                    val2[K][1] = mfma16(v0.a[0][pr], y[K], val2[K][1]);
-                });
+            if (valid) static_for<3>([&]<int K>() { static_for<4>([&]<int g>() {
+                st4(orec + blk_off(1) + K * 32 + 8 * g + 4 * hi,
+                    f32x4{val1[K][4 * g], val1[K][4 * g + 1], val1[K][4 * g + 2], val1[K][4 * g + 3]});
+            }); });
+        } else {    // l = 2 block straight from the 16x16 layout: lane (g, e') holds channels 4g..4g+3 of edges e' and 16+e'
+            const int g4 = (wv.lane >> 4) * 4, el = wv.lane & 15;
+            static_for<2>([&]<int S>() {
+                if (el + 16 * S < n_valid) {
+                    float* o2 = P.out + (size_t)(e0 + el + 16 * S) * REC + blk_off(2) + g4;
+                    static_for<5>([&]<int K>() { st4(o2 + K * 16, val2[K][S]); });
+                }
             });
         }
+    };
+    auto start_val = [&]<int l3>() {
+        if constexpr (l3 == 1) static_for<3>([&]<int K>() { static_for<16>([&]<int R>() { val1[K][R] = 0.0f; }); });
+        if constexpr (l3 == 2) static_for<5>([&]<int K>() { static_for<2>([&]<int S>() { val2[K][S] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }); });
+    };
+    const int o_S_val = opaque_s(P.o_S_val);
+    AItem vring[PDA];
+    static_for<PDA>([&]<int I>() { vring[I] = load_item<L, 2, I>(wv, o_S_val); });
+    BOpsH<L> vb_cur = valu_val.template operator()<0>();
+    static_for<NCHK>([&]<int C>() {
+        static_for<L + 1>([&]<int g>() { if constexpr (g >= 1 && C == dtp_group_end<L>(g - 1)) start_val.template operator()<g>(); });
         sched_fence();
-        v0 = v1; v1 = v2; vb_cur = vb_nxt;
+        const BOpsH<L> vb_nxt = valu_val.template operator()<C + 1>();
+        mfma_chunk<L, 2, C>(wv, o_S_val, vring, vb_cur, val0, val1, val2);
+        static_for<L + 1>([&]<int g>() { if constexpr (C == dtp_group_end<L>(g)) store_group.template operator()<g>(); });
+        sched_fence();
+        vb_cur = vb_nxt;
     });
-
     DEDF_STAMP(10);
-    // ---- store the edge record: value in internal layout [l][m][channel] + one logit per head ----------------------------
-    if (valid) {
-        float* o = P.out + (size_t)e * REC;
-        static_for<2>([&]<int T>() { static_for<4>([&]<int g>() {
-            st4(o + T * 32 + 8 * g + 4 * hi, f32x4{val[T][4 * g], val[T][4 * g + 1], val[T][4 * g + 2], val[T][4 * g + 3]});
-        }); });
-        if constexpr (L >= 1) static_for<3>([&]<int K>() { static_for<4>([&]<int g>() {
-            st4(o + blk_off(1) + K * 32 + 8 * g + 4 * hi,
-                f32x4{val[2 + K][4 * g], val[2 + K][4 * g + 1], val[2 + K][4 * g + 2], val[2 + K][4 * g + 3]});
-        }); });
-        if (hi == 0) st4(o + D, f32x4{logit[0], logit[1], logit[2], logit[3]});
-    }
-    if constexpr (L >= 2) {   // l = 2 block straight from the 16x16 layout: lane (g, e') holds channels 4g..4g+3 of edges e' and 16+e'
-        const int g4 = (wv.lane >> 4) * 4, el = wv.lane & 15;
-        static_for<2>([&]<int S>() {
-            if (el + 16 * S < n_valid) {
-                float* o2 = P.out + (size_t)(e0 + el + 16 * S) * REC + blk_off(2) + g4;
-                static_for<5>([&]<int K>() { st4(o2 + K * 16, val2[K][S]); });
-            }
-        });
-    }
+    store_group.template operator()<L>();
+    if (valid && hi == 0) st4(orec + D, f32x4{logit[0], logit[1], logit[2], logit[3]});
     DEDF_STAMP(11);
 }
 

@@ -85,6 +85,59 @@ template <int L> inline std::vector<KStep> dtp_steps(int l3) {
     return s;
 }
 
+// A "chunk" = 16 consecutive channels of one depth-wise-TP path = 8 accumulator registers x 2 half-waves = one K = 16 step
+// of the split-fp16 MFMAs.  The edge kernel walks the chunks grouped by output degree l3 (all l3 = 0 chunks, then l3 = 1,
+// ...; inside a group in e3nn weight order) so that only one group's accumulators are live at a time; the host packs the
+// last radial-MLP layer (rows = per-edge TP weights) and the A-operand streams in that walk order.
+//   position p (0 .. WN/16)  ->  e3nn weight chunk dtp_pos_chunk(p)  (weight rows 16 wc .. 16 wc + 15)
+// Element k16 = 8 h + jj of the chunk at position p (h = half-wave, jj = register 8 (p % 2) + jj of weight tile p / 2) is
+// channel chunk_row(k16) of the chunk: the register order of a row-layout tile.
+DEDF_HD constexpr int chunk_row(int k16) { const int h = k16 >> 3, jj = k16 & 7; return (jj & 3) + 8 * (jj >> 2) + 4 * h; }
+template <int L> struct DtpWalk { int chunk[64]; PathInfo path[64]; int n; };
+template <int L> DEDF_HD constexpr DtpWalk<L> make_dtp_walk() {
+    DtpWalk<L> w{};
+    int n = 0;
+    for (int l3 = 0; l3 <= L; ++l3)
+        for (int q = 0; q < dtp_num_paths<L>(); ++q) {
+            const PathInfo pi = dtp_path<L>(q);
+            if (pi.l3 != l3) continue;
+            for (int c = 0; c < pi.mul1 / 16; ++c) { w.chunk[n] = pi.wstart / 16 + c; w.path[n] = pi; ++n; }
+        }
+    w.n = n;
+    for (int i = n; i < 64; ++i) { w.chunk[i] = dtp_wn<L>() / 16; w.path[i] = PathInfo{-1, -1, -1, 0, 0, 0, 0}; }
+    return w;
+}
+template <int L> inline constexpr DtpWalk<L> kDtpWalk = make_dtp_walk<L>();
+template <int L> DEDF_HD constexpr int dtp_pos_chunk(int p) { return p < 64 ? kDtpWalk<L>.chunk[p] : dtp_wn<L>() / 16; }
+template <int L> DEDF_HD constexpr PathInfo dtp_pos_path(int p) { return p < 64 ? kDtpWalk<L>.path[p] : PathInfo{-1, -1, -1, 0, 0, 0, 0}; }
+template <int L> DEDF_HD constexpr int dtp_pos_l3(int p) { return dtp_pos_path<L>(p).l3; }
+// first channel of the chunk inside its path (u0) / inside the l3 block of the sorted DTP output
+template <int L> DEDF_HD constexpr int dtp_pos_u0(int p) { return dtp_pos_chunk<L>(p) * 16 - dtp_pos_path<L>(p).wstart; }
+template <int L> DEDF_HD constexpr int dtp_pos_channel(int p, int k16) { return dtp_pos_path<L>(p).kofs + dtp_pos_u0<L>(p) + chunk_row(k16); }
+// e3nn weight row held by row r of the (walk-ordered) last radial layer
+template <int L> DEDF_HD constexpr int dtp_walk_row(int r) { return dtp_pos_chunk<L>(r / 16) * 16 + r % 16; }
+// number of chunks with output degree <= l3 (= position one past the end of group l3)
+template <int L> DEDF_HD constexpr int dtp_group_end(int l3) { return (dtp_k<L>(0) + (l3 >= 1 ? dtp_k<L>(1) : 0) + (l3 >= 2 ? dtp_k<L>(2) : 0) + (l3 >= 3 ? dtp_k<L>(3) : 0)) / 16; }
+// A-operand stream of a linear layer fed by the depth-wise TP: chunks in walk order; an l3 = 0 chunk feeds nt0 output
+// tiles (one 512-float slot each, consumed in items of two tiles), an l3 >= 1 chunk one tile.  Slot = hi image | lo image.
+struct DtpItem { int pos, t, slot, ntile; };      // chunk position, item inside the chunk, first slot, tiles in the item
+template <int L> DEDF_HD constexpr DtpItem dtp_item(int I, int nt0) {
+    int i = 0, slot = 0;
+    for (int p = 0; p < dtp_wn<L>() / 16; ++p) {
+        const bool z = dtp_pos_l3<L>(p) == 0;
+        const int ni = z ? cdiv(nt0, 2) : 1;
+        if (I < i + ni) { const int t = I - i; return DtpItem{p, t, slot + 2 * t, z ? imin(2, nt0 - 2 * t) : 1}; }
+        i += ni; slot += z ? nt0 : 1;
+    }
+    return DtpItem{dtp_wn<L>() / 16, 0, slot, 0};
+}
+template <int L> DEDF_HD constexpr int dtp_item_first(int p, int nt0) {
+    int i = 0;
+    for (int c = 0; c < p; ++c) i += dtp_pos_l3<L>(c) == 0 ? cdiv(nt0, 2) : 1;
+    return i;
+}
+template <int L> DEDF_HD constexpr int dtp_num_slots(int nt0) { return dtp_item<L>(1 << 20, nt0).slot; }
+
 // ---- score tensor products: in1 = rotated query feature, in2 = field, outputs l3 in {0, 1} ------------------------
 template <int L> DEDF_HD constexpr int stp_num_paths() {
     int n = 0;

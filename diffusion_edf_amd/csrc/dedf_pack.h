@@ -105,7 +105,7 @@ struct Image {
 struct EdgeOffsets {
     int o_enc, o_A_pre, o_A_r1, o_b_r1, o_g_r1, o_be_r1, o_A_r2, o_b_r2, o_g_r2, o_be_r2, o_A_r3, o_off_r3;
     int o_A_pre_l, o_A_r1_l, o_A_r2_l, o_A_r3_l;      // residual (lo) images of the split-fp16 radial-MLP layers
-    int o_A_lin[4], o_b_r0, o_A_val[4], o_b_val0, o_alpha_dot;
+    int o_S_lin, o_b_r0, o_S_val, o_b_val0, o_alpha_dot;     // o_S_*: split-fp16 A-operand streams (pack_dtp_stream)
 };
 struct NodeOffsets {
     int o_A_proj[4], o_b_proj0, o_ln_w[4], o_ln_b0, o_A_f1[4], o_b_f1, o_A_f2[4], o_b_f2;
@@ -113,6 +113,45 @@ struct NodeOffsets {
 };
 
 inline float softplusf(float x) { return x > 20.0f ? x : std::log1p(std::exp(x)); }
+
+// Split-fp16 A-operand stream of a linear layer fed by the depth-wise TP (dedf_net.h::dtp_item): slots in the order the
+// edge kernel consumes them.  Slot = 512 floats: hi image (256) | lo image (256) of one (output tile x chunk) operand,
+// [lane 64][8 halves] for v_mfma_f32_32x32x16_f16 (row lane & 31, k16 = 8 (lane >> 5) + j); l3 = 2 slots hold the 16-row
+// operand of v_mfma_f32_16x16x16_f16: [lane 64][4 halves] (row lane & 15, k16 = 4 (lane >> 4) + i), hi at 0, lo at 128.
+//   W(l, o, k) -> weight of output row o of block l for sorted DTP channel k;  rows[l] = valid output rows
+template <int L, class WAt>
+inline std::vector<float> pack_dtp_stream(int nt0, const int* rows, WAt W) {
+    std::vector<uint16_t> img((size_t)dtp_num_slots<L>(nt0) * 1024, 0);
+    auto put = [&](size_t half_idx, float w) {
+        const _Float16 hh = (_Float16)w;
+        __builtin_memcpy(&img[half_idx], &hh, 2);
+        return (float)hh;
+    };
+    size_t slot = 0;
+    for (int pos = 0; pos < dtp_wn<L>() / 16; ++pos) {
+        const int l3 = dtp_pos_l3<L>(pos);
+        const int nt = l3 == 0 ? nt0 : 1;
+        for (int To = 0; To < nt; ++To, ++slot) {
+            for (int lane = 0; lane < 64; ++lane) {
+                const bool m16 = l3 == 2;
+                const int ne = m16 ? 4 : 8;
+                for (int j = 0; j < ne; ++j) {
+                    const int o = m16 ? (lane & 15) : To * 32 + (lane & 31);
+                    const int k16 = m16 ? 4 * (lane >> 4) + j : 8 * (lane >> 5) + j;
+                    if (o >= rows[l3]) continue;
+                    const float w = W(l3, o, dtp_pos_channel<L>(pos, k16));
+                    const size_t hi_idx = slot * 1024 + (size_t)lane * ne + j;
+                    const size_t lo_idx = hi_idx + (m16 ? 256 : 512);
+                    const float h = put(hi_idx, w);
+                    put(lo_idx, w - h);
+                }
+            }
+        }
+    }
+    std::vector<float> out(img.size() / 2);
+    __builtin_memcpy(out.data(), img.data(), img.size() * 2);
+    return out;
+}
 
 template <int L>
 inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, Image& im, EdgeOffsets& o) {
@@ -170,9 +209,11 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
         o.o_g_r2 = im.push(rows(64, S.get(B, rad + "net.4.weight")));
         o.o_be_r2 = im.push(rows(64, S.get(B, rad + "net.4.bias")));
         const float* W3 = S.get(B, rad + "net.6.weight");
-        pack_A_h(dtp_wn<L>(), 4, [&](int oo, int k) { return W3[oo * 64 + k]; }, [](int cc, int j, int h) { return chain_k(64, cc, j, h); }, ih, il);
+        // rows (= per-edge TP weights) in the kernel's walk order: chunks grouped by output degree (dedf_net.h::dtp_walk_row)
+        pack_A_h(dtp_wn<L>(), 4, [&](int oo, int k) { return W3[dtp_walk_row<L>(oo) * 64 + k]; }, [](int cc, int j, int h) { return chain_k(64, cc, j, h); }, ih, il);
         o.o_A_r3 = im.push(ih); o.o_A_r3_l = im.push(il);
-        o.o_off_r3 = im.push(rows(dtp_wn<L>(), S.get(B, rad + "offset")));
+        const float* off3 = S.get(B, rad + "offset");
+        o.o_off_r3 = im.push(pack_rows(dtp_wn<L>(), [&](int i) { return off3[dtp_walk_row<L>(i)]; }));
     }
     {   // sep_act.lin (+ sep_alpha on the l3 = 0 K-steps) and sep_value.lin (shared DTP weights folded in)
         const float* lw = S.get(B, ga + ".sep_act.lin.tp.weight");
@@ -187,32 +228,31 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
             }
             return -1;
         };
-        size_t lo = 0, vo = 0;
-        for (int l = 0; l <= L; ++l) {
-            const int K = dtp_k<L>(l), Ol = (l == 0 ? lin0_rows<L>() : mul_of(l));
-            const float* Wl = lw + lo;
-            const float* Vl = vw + vo;
-            if (l == 0) {
-                const int a0 = alpha_row0<L>();
-                o.o_A_lin[0] = im.push(pack_A(a0 + mul_of(0), dtp_steps<L>(0), [&](int oo, int k) {
-                    if (oo < Ol) return Wl[k * Ol + oo];
-                    if (oo >= a0) return aw[k * mul_of(0) + (oo - a0)];
-                    return 0.0f;
-                }));
-                const float* lb = S.get(B, ga + ".sep_act.lin.bias.0");
-                const float* ab = S.get(B, ga + ".sep_alpha.bias.0");
-                o.o_b_r0 = im.push(pack_rows(a0 + mul_of(0), [&](int i) { return i < Ol ? lb[i] : (i >= a0 ? ab[i - a0] : 0.0f); }));
-            } else if (l == 2) {      // 16 output channels: v_mfma_f32_16x16x4_f32 image (no 32-row padding)
-                o.o_A_lin[l] = im.push(pack_A16(Ol, dtp_steps<L>(l), [&](int oo, int k) { return Wl[k * Ol + oo]; }));
-            } else {
-                o.o_A_lin[l] = im.push(pack_A(Ol, dtp_steps<L>(l), [&](int oo, int k) { return Wl[k * Ol + oo]; }));
+        size_t lofs[4] = {0, 0, 0, 0}, vofs[4] = {0, 0, 0, 0};
+        int lrows[4] = {0, 0, 0, 0}, vrows[4] = {0, 0, 0, 0};
+        {
+            size_t lo = 0, vo = 0;
+            for (int l = 0; l <= L; ++l) {
+                lofs[l] = lo; vofs[l] = vo;
+                lo += (size_t)dtp_k<L>(l) * (l == 0 ? lin0_rows<L>() : mul_of(l));
+                vo += (size_t)dtp_k<L>(l) * mul_of(l);
+                lrows[l] = l == 0 ? alpha_row0<L>() + mul_of(0) : mul_of(l);
+                vrows[l] = mul_of(l);
             }
-            if (l == 2)
-                o.o_A_val[l] = im.push(pack_A16(mul_of(l), dtp_steps<L>(l), [&](int oo, int k) { return Vl[k * mul_of(l) + oo] * w2[wflat(l, k)]; }));
-            else
-                o.o_A_val[l] = im.push(pack_A(mul_of(l), dtp_steps<L>(l), [&](int oo, int k) { return Vl[k * mul_of(l) + oo] * w2[wflat(l, k)]; }));
-            lo += (size_t)K * Ol;
-            vo += (size_t)K * mul_of(l);
+        }
+        const int a0 = alpha_row0<L>(), O0 = lin0_rows<L>();
+        // sep_act.lin rows, then (from row a0) the sep_alpha rows, share the l3 = 0 chunks
+        o.o_S_lin = im.push(pack_dtp_stream<L>(r0_tiles<L>(), lrows, [&](int l, int oo, int k) {
+            if (l == 0) return oo < O0 ? lw[lofs[0] + (size_t)k * O0 + oo] : (oo >= a0 ? aw[(size_t)k * mul_of(0) + (oo - a0)] : 0.0f);
+            return lw[lofs[l] + (size_t)k * mul_of(l) + oo];
+        }));
+        o.o_S_val = im.push(pack_dtp_stream<L>(mul_of(0) / 32, vrows, [&](int l, int oo, int k) {
+            return vw[vofs[l] + (size_t)k * mul_of(l) + oo] * w2[wflat(l, k)];
+        }));
+        {
+            const float* lb = S.get(B, ga + ".sep_act.lin.bias.0");
+            const float* ab = S.get(B, ga + ".sep_alpha.bias.0");
+            o.o_b_r0 = im.push(pack_rows(a0 + mul_of(0), [&](int i) { return i < O0 ? lb[i] : (i >= a0 ? ab[i - a0] : 0.0f); }));
         }
         o.o_b_val0 = im.push(rows(mul_of(0), S.get(B, ga + ".sep_value.lin.bias.0")));
         o.o_alpha_dot = im.push(rows(mul_of(0), S.get(B, ga + ".alpha_dot")));

@@ -116,6 +116,11 @@ def stage_report(lmax=2, nT=6, n_scene=512, n_grasp=100, verbose=True, **kwargs)
         irreps_head = [(m // H, l) for l, m in enumerate(muls)]
         oval = R.heads2vec(d64['value'], irreps_head)
         rep['value'] = rel(val_ref[og], oval[oo])
+        off = 0
+        for l, m in enumerate(muls):      # per irreps block, each relative to its own maximum
+            n = m * (2 * l + 1)
+            rep[f'value_l{l}'] = rel(val_ref[og][:, off:off + n], oval[oo][:, off:off + n])
+            off += n
         rep['logits'] = rel(eo[:, D:][og], d64['log_alpha'][oo])
     z = head.debug_buffer('z').reshape(Nd, D)[:, perm]
     rep['attn'] = rel(z, d64['attn'])
