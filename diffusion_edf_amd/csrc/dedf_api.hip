@@ -23,7 +23,7 @@ template <int L, int F0> __global__ __launch_bounds__(64, 1) void k_edge(EdgePar
     const int ntiles = ti[P.n_scales];
     const Wave wv = make_wave(P.W, P.W_bytes);
 #if defined(DEDF_PHASE_PROF)
-    unsigned long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         int scale = 0;
@@ -37,7 +37,7 @@ template <int L, int F0> __global__ __launch_bounds__(64, 1) void k_edge(EdgePar
 #endif
     }
 #if defined(DEDF_PHASE_PROF)
-    if (P.phase_prof && wv.lane == 0) for (int i = 0; i < 12; ++i) P.phase_prof[blockIdx.x * 16 + i] += pacc[i];
+    if (P.phase_prof && wv.lane == 0) for (int i = 0; i < 16; ++i) P.phase_prof[blockIdx.x * 16 + i] += pacc[i];
 #endif
 }
 template <int L, bool EBM> __global__ __launch_bounds__(64, 1) void k_node(NodeParams P) {

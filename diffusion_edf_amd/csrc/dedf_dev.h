@@ -214,23 +214,40 @@ DEDF_DEV h8 relane16(h8 v) {
 }
 DEDF_DEV h4 half4(h8 v, int s) { return s == 0 ? __builtin_shufflevector(v, v, 0, 1, 2, 3) : __builtin_shufflevector(v, v, 4, 5, 6, 7); }
 
+// Returns v, but as an opaque function of `dep`: a request whose address goes through tie() cannot be issued before `dep`
+// exists, and (volatile) keeps its place between the scheduling fences.  hipcc otherwise lets the pure MFMA / VALU work drift
+// below the fences while the operand requests stay put, so that a whole layer's operands end up in flight (and spilled).
+DEDF_DEV int tie(int v, float dep) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r;
+    asm volatile("v_and_or_b32 %0, %1, 0, %2" : "=v"(r) : "v"(dep), "v"(v));
+    return r;
+#else
+    (void)dep; return v;
+#endif
+}
 // Dense layer on split-fp16 MFMAs, NTO output tiles rotated, A images [To][chunk][lane][8 halves] (hi at off_h, lo at off_l),
-// operands prefetched PD chunks ahead.   bsrc.operator()<chunk, j>() -> fp32 value of element j of the chunk (8 registers).
+// operands requested PD chunks ahead.   bsrc.operator()<chunk, j>() -> fp32 value of element j of the chunk (8 registers).
 template <int NTO, int NCH, int PD = 2, class BsrcF>
 DEDF_DEV void dense_rot_h(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[NTO], BsrcF&& bsrc) {
     f32x4 rh[PD][NTO], rl[PD][NTO];
-    sched_fence();      // keep the first operand requests out of the producer's epilogue (register pressure)
+    sched_fence();
     static_for<PD>([&]<int k>() { if constexpr (k < NCH) static_for<NTO>([&]<int To>() {
         rh[k][To] = lda(wv, off_h, NCH, To, k); rl[k][To] = lda(wv, off_l, NCH, To, k); }); });
     static_for<NCH>([&]<int c>() {
         f32x4 ch[NTO], cl[NTO];
         static_for<NTO>([&]<int To>() { ch[To] = rh[c % PD][To]; cl[To] = rl[c % PD][To]; });
-        if constexpr (c + PD < NCH) static_for<NTO>([&]<int To>() {
-            rh[c % PD][To] = lda(wv, off_h, NCH, To, c + PD); rl[c % PD][To] = lda(wv, off_l, NCH, To, c + PD); });
         sched_fence();
         float t[8];
         static_for<8>([&]<int J>() { t[J] = bsrc.template operator()<c, J>(); });
         const HL b = split8(t);
+        if constexpr (c + PD < NCH) {
+            const int lv = tie(wv.lane16, __builtin_bit_cast(f32x4, b.hi)[0]);
+            static_for<NTO>([&]<int To>() {
+                rh[c % PD][To] = bld4(wv.w, lv, (off_h + (To * NCH + c + PD) * 256) * 4);
+                rl[c % PD][To] = bld4(wv.w, lv, (off_l + (To * NCH + c + PD) * 256) * 4);
+            });
+        }
         static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, ch[To]), b.hi, acc[To]); });
         static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, ch[To]), b.lo, acc[To]); });
         static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, cl[To]), b.hi, acc[To]); });

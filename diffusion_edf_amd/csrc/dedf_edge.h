@@ -91,7 +91,7 @@ DEDF_DEV void ln_silu(f32x16 (&x)[NT], const Wave& wv, int o_gamma, int o_beta) 
 #define DEDF_STAMP(i) do { } while (0)
 #endif
 #if defined(DEDF_PHASE_PROF)
-#define DEDF_PROF_ARG , unsigned long long (&pacc)[12]
+#define DEDF_PROF_ARG , unsigned long long (&pacc)[16]
 #else
 #define DEDF_PROF_ARG
 #endif
@@ -269,7 +269,6 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // computed and the gated features parked in LDS (this wave's private 30 KB) until the second depth-wise TP reads them.
     f32x16 acc0[NR0], acc1[3];
     f32x4 acc2[5][2];
-    static_for<NR0>([&]<int T>() { acc0[T] = ldrows(wv, o_b_r0, T); });
     const Buf msgb = make_buf(P.msg, P.msg_bytes);
     // per-l1 lane offsets of the 4 message rows this lane owns inside an 8-row group
     const int mv0 = src * (D * 4) + hi * 16, mv1 = src * (D * 4) + hi * 48, mv2 = src * (D * 4) + hi * 80;
@@ -282,7 +281,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // region so that hipcc interleaves them:  the source-message loads of chunk C+2,  the layer-3 MFMAs of the NEXT weight
     // tile,  the lane-local Clebsch-Gordan VALU work + hi/lo split of chunk C+1 (-> its B operands),  the activations of a
     // group completed by chunk C-1,  and the lin / sep_alpha MFMAs of chunk C (A operands through a ring, PDA items ahead).
-    constexpr int NCHK = WN / 16, PDA = 2;
+    constexpr int NCHK = WN / 16, PDA = 3;
     struct XOps { f32x4 x[2][2 * L + 1]; };
     auto load_X = [&]<int C>() {      // this lane's 2 x 4 source-message rows of the chunk (contiguous runs in the reference layout)
         XOps o{};
@@ -329,19 +328,35 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         static_for<8>([&]<int J>() { t[J] = r2[c / 2][8 * (c % 2) + J]; });
         r2s[c] = split8(t);
     });
-    constexpr int NL3 = NWT * 4, PD3 = 2;
-    f32x4 l3h[PD3], l3l[PD3];
-    static_for<PD3>([&]<int I>() { l3h[I] = bld4(wv.w, wv.lane16, (o_A_r3 + I * 256) * 4); l3l[I] = bld4(wv.w, wv.lane16, (o_A_r3_l + I * 256) * 4); });
-    auto l3_chunk = [&]<int I>(f32x16& w) {
-        constexpr int c = I % 4;
-        const h8 ah = __builtin_bit_cast(h8, l3h[I % PD3]), al = __builtin_bit_cast(h8, l3l[I % PD3]);
-        if constexpr (I + PD3 < NL3) {
-            l3h[I % PD3] = bld4(wv.w, wv.lane16, (o_A_r3 + (I + PD3) * 256) * 4);
-            l3l[I % PD3] = bld4(wv.w, wv.lane16, (o_A_r3_l + (I + PD3) * 256) * 4);
+    {   // accumulator init (lin / sep_alpha biases), requested only now
+        const int hv = tie(wv.hi64, __builtin_bit_cast(f32x4, r2s[3].lo)[3]);
+        static_for<NR0>([&]<int T>() { acc0[T] = ldrows(wv.w, hv, o_b_r0, T); });
+    }
+    // Layer-3 work unit = half a weight tile (2 of the 4 K-chunks, 6 MFMAs).  Half P = 2 T + half of tile T runs in pipeline
+    // region P - 3 into wbuf[T % 2]; its operands (and the tile's offset rows, the accumulator init) are requested one region
+    // earlier, across a scheduling fence, so that the request cannot sink next to its use.
+    struct L3Half { f32x4 h[2], l[2]; };
+    auto load_l3 = [&]<int Ph>() {
+        L3Half o{};
+        if constexpr (Ph < 2 * NWT) static_for<2>([&]<int k>() {
+            o.h[k] = bld4(wv.w, wv.lane16, (o_A_r3 + (2 * Ph + k) * 256) * 4);
+            o.l[k] = bld4(wv.w, wv.lane16, (o_A_r3_l + (2 * Ph + k) * 256) * 4);
+        });
+        return o;
+    };
+    auto load_off = [&]<int T>() { f32x16 o{}; if constexpr (T < NWT) o = ldrows(wv, o_off_r3, T); return o; };
+    auto run_l3 = [&]<int Ph>(const L3Half& a, const f32x16& init, f32x16& w) {
+        if constexpr (Ph < 2 * NWT) {
+            constexpr int c0 = 2 * (Ph % 2);
+            f32x16 t = init;
+            static_for<2>([&]<int k>() {
+                const h8 ah = __builtin_bit_cast(h8, a.h[k]), al = __builtin_bit_cast(h8, a.l[k]);
+                t = mfma_h(ah, r2s[c0 + k].hi, t);
+                t = mfma_h(ah, r2s[c0 + k].lo, t);
+                t = mfma_h(al, r2s[c0 + k].hi, t);
+            });
+            w = t;
         }
-        w = mfma_h(ah, r2s[c].hi, w);
-        w = mfma_h(ah, r2s[c].lo, w);
-        w = mfma_h(al, r2s[c].hi, w);
     };
     auto dump_w = [&]<int Tw>(const f32x16& w) {      // debug only: back to the e3nn weight order
         if (P.dbg_w != nullptr && valid)
@@ -396,42 +411,51 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     };
 
     DEDF_STAMP(6);
-    // prologue: weight tile 0, source rows of chunks 0 / 1, B operands of chunk 0
+    // prologue: weight tile 0 and the first half of tile 1, source rows of chunks 0 / 1, B operands of chunk 0
+    f32x16 wbuf[2];
     XOps x_nxt = load_X.template operator()<1>();
-    f32x16 wt = ldrows(wv, o_off_r3, 0);
     BOpsH<L> b_cur;
+    L3Half l3n;
+    f32x16 offn;
     {
         const XOps x0 = load_X.template operator()<0>();
-        static_for<4>([&]<int cc>() { sched_fence(); l3_chunk.template operator()<cc>(wt); });
+        const L3Half p0 = load_l3.template operator()<0>(), p1 = load_l3.template operator()<1>(), p2 = load_l3.template operator()<2>();
+        const f32x16 off0 = load_off.template operator()<0>(), off1 = load_off.template operator()<1>();
         sched_fence();
-        dump_w.template operator()<0>(wt);
-        b_cur = valu_chunk.template operator()<0>(x0, wt);
+        l3n = load_l3.template operator()<3>();
+        offn = load_off.template operator()<2>();
+        sched_fence();
+        run_l3.template operator()<0>(p0, off0, wbuf[0]);
+        run_l3.template operator()<1>(p1, wbuf[0], wbuf[0]);
+        run_l3.template operator()<2>(p2, off1, wbuf[1]);
+        sched_fence();
+        dump_w.template operator()<0>(wbuf[0]);
+        b_cur = valu_chunk.template operator()<0>(x0, wbuf[0]);
     }
     DEDF_STAMP(7);
-    static_for<NWT>([&]<int Tw>() {
-        f32x16 wt_next = wt;
-        if constexpr (Tw + 1 < NWT) wt_next = ldrows(wv, o_off_r3, Tw + 1);
-        static_for<2>([&]<int c2>() {
-            constexpr int C = Tw * 2 + c2;
-            const XOps x_nn = load_X.template operator()<C + 2>();
-            static_for<L + 1>([&]<int g>() { if constexpr (g >= 1 && C == dtp_group_end<L>(g - 1)) start_group.template operator()<g>(); });
-            sched_fence();
-            if constexpr (c2 == 0 && Tw + 1 < NWT)       // layer 3 of the next weight tile
-                static_for<4>([&]<int k>() { l3_chunk.template operator()<(Tw + 1) * 4 + k>(wt_next); });
-            const BOpsH<L> b_nxt = valu_chunk.template operator()<C + 1>(x_nxt, c2 == 1 ? wt_next : wt);
-            mfma_chunk<L, NR0, C>(wv, o_S_lin, ring, b_cur, acc0, acc1, acc2);
-            static_for<L + 1>([&]<int g>() { if constexpr (C == dtp_group_end<L>(g)) finish_group.template operator()<g>(); });
-            sched_fence();
-            if constexpr (c2 == 0 && Tw + 1 < NWT) dump_w.template operator()<Tw + 1>(wt_next);
-            x_nxt = x_nn; b_cur = b_nxt;
-        });
-        wt = wt_next;
+    static_for<NCHK>([&]<int C>() {
+        constexpr int Ph = C + 3, T3 = Ph / 2;       // layer-3 half of this region
+        const XOps x_nn = load_X.template operator()<C + 2>();
+        const L3Half l3c = l3n;
+        const f32x16 offc = offn;
+        l3n = load_l3.template operator()<Ph + 1>();
+        if constexpr ((Ph + 1) % 2 == 0) offn = load_off.template operator()<(Ph + 1) / 2>();
+        static_for<L + 1>([&]<int g>() { if constexpr (g >= 1 && C == dtp_group_end<L>(g - 1)) start_group.template operator()<g>(); });
+        sched_fence();
+        if constexpr (Ph % 2 == 0) run_l3.template operator()<Ph>(l3c, offc, wbuf[T3 % 2]);
+        else run_l3.template operator()<Ph>(l3c, wbuf[T3 % 2], wbuf[T3 % 2]);
+        const BOpsH<L> b_nxt = valu_chunk.template operator()<C + 1>(x_nxt, wbuf[((C + 1) / 2) % 2]);
+        mfma_chunk<L, NR0, C>(wv, o_S_lin, ring, b_cur, acc0, acc1, acc2);
+        static_for<L + 1>([&]<int g>() { if constexpr (C == dtp_group_end<L>(g)) finish_group.template operator()<g>(); });
+        sched_fence();
+        if constexpr (Ph % 2 == 1 && T3 < NWT) dump_w.template operator()<T3>(wbuf[T3 % 2]);
+        x_nxt = x_nn; b_cur = b_nxt;
+        if constexpr (C + 1 == dtp_group_end<L>(0)) DEDF_STAMP(8);
+        if constexpr (L >= 2 && C + 1 == dtp_group_end<L>(1)) DEDF_STAMP(9);
     });
     finish_group.template operator()<L>();
     sched_fence();
-
-    DEDF_STAMP(8);
-    DEDF_STAMP(9);
+    DEDF_STAMP(12);
     // ---- sep_value: depth-wise TP #2 (shared weights folded into the A stream) + LinearRS -> value --------------------------
     // same walk: l3 = 0 chunks -> val0, l3 = 1 -> val1[m], l3 = 2 -> val2; a completed group goes straight to the edge record
     f32x16 val0[2], val1[3];
@@ -500,8 +524,10 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         static_for<L + 1>([&]<int g>() { if constexpr (C == dtp_group_end<L>(g)) store_group.template operator()<g>(); });
         sched_fence();
         vb_cur = vb_nxt;
+        if constexpr (C + 1 == dtp_group_end<L>(0)) DEDF_STAMP(10);
+        if constexpr (L >= 2 && C + 1 == dtp_group_end<L>(1)) DEDF_STAMP(13);
     });
-    DEDF_STAMP(10);
+    DEDF_STAMP(14);
     store_group.template operator()<L>();
     if (valid && hi == 0) st4(orec + D, f32x4{logit[0], logit[1], logit[2], logit[3]});
     DEDF_STAMP(11);

@@ -16,8 +16,8 @@ raw0 = buf.numpy().view(np.uint64).reshape(-1, 16).copy()
 head(Ts.float(), keys, query, t); torch.cuda.synchronize()
 raw1 = head.debug_buffer('phase_prof').numpy().view(np.uint64).reshape(-1, 16)
 d = (raw1 - raw0).astype(np.float64)
-names = ["geom+enc", "prelin+silu", "L1 mfma", "L1 LN+silu", "L2 mfma", "L2 LN+silu", "accinit", "E prologue(wt0)", "E main", "logits+gate", "F main", "stores"]
-tot = d[:, :12].sum(1).mean()
+names = ["geom+enc", "prelin+silu", "L1 mfma", "L1 LN+silu", "L2 mfma", "L2 LN+silu", "accinit", "E prologue(wt0)", "E l3=0 chunks", "E l3=1 chunks", "F l3=0 chunks", "stores+end", "E l3=2 chunks", "F l3=1 chunks", "F l3=2 chunks", "-"]
+tot = d[:, :16].sum(1).mean()
 E = head.stats()['n_edges_total']; tiles = sum((e + 31)//32 for e in head.stats()['n_edges'])
 print("edges", E, "tiles", tiles, "tiles/wave", tiles / d.shape[0])
 for i, n in enumerate(names):
