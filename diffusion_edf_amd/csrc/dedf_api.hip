@@ -307,6 +307,8 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         P.o_enc = o.o_enc; P.o_A_pre = o.o_A_pre; P.o_A_pre_l = o.o_A_pre_l; P.o_A_r1_l = o.o_A_r1_l; P.o_A_r2_l = o.o_A_r2_l; P.o_A_r3_l = o.o_A_r3_l; P.o_A_r1 = o.o_A_r1; P.o_b_r1 = o.o_b_r1; P.o_g_r1 = o.o_g_r1; P.o_be_r1 = o.o_be_r1;
         P.o_A_r2 = o.o_A_r2; P.o_b_r2 = o.o_b_r2; P.o_g_r2 = o.o_g_r2; P.o_be_r2 = o.o_be_r2; P.o_A_r3 = o.o_A_r3; P.o_off_r3 = o.o_off_r3;
         P.o_S_lin = o.o_S_lin; P.o_S_val = o.o_S_val;
+        P.w_unscale = o.w_unscale; P.u_scale = o.u_scale;
+        for (int l = 0; l < 4; ++l) { P.c_lin[l] = o.c_lin[l]; P.c_val[l] = o.c_val[l]; }
         P.o_b_r0 = o.o_b_r0; P.o_b_val0 = o.o_b_val0; P.o_alpha_dot = o.o_alpha_dot;
         P.out = h->d_eout.as<float>();
         P.dbg_w = h->debug ? h->d_dbgw.as<float>() : nullptr;

@@ -176,6 +176,13 @@ DEDF_DEV int opaque_s(int x) {
     return x;
 }
 
+DEDF_DEV float opaque_s(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(x));
+#endif
+    return x;
+}
+
 // ---- split-fp16 MFMA (v_mfma_f32_32x32x16_f16, 32 cycles): 22-bit operands, fp32 accumulate ---------------------------------
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 struct HL { h8 hi, lo; };

@@ -46,6 +46,7 @@ struct EdgeParams {
     int o_S_lin;              // split-fp16 A-operand stream (dedf_pack.h::pack_dtp_stream): l3 = 0 -> lin0 rows + alpha rows; l3 >= 1: mul(l3) rows
     int o_b_r0;               // row-packed bias over the l3 = 0 row space
     int o_S_val;              // same for sep_value.lin with the shared DTP weights folded in
+    float w_unscale, u_scale, c_lin[4], c_val[4];     // power-of-two operand scaling of the split-fp16 GEMMs (dedf_pack.h::EdgeOffsets)
     int o_b_val0;             // row-packed (64)
     int o_alpha_dot;          // row-packed over the two alpha tiles
     float* out;               // [E][edge_rec]
@@ -106,25 +107,18 @@ DEDF_DEV AItem load_item(const Wave& wv, int o_str) {
     AItem a{};
     constexpr DtpItem it = dtp_item<L>(I, NT0);
     if constexpr (it.ntile > 0) {
-        if constexpr (dtp_pos_l3<L>(it.pos) == 2) {
-            const f32x2 th = bld2(wv.w, wv.lane * 8, (o_str + it.slot * 512) * 4);
-            const f32x2 tl = bld2(wv.w, wv.lane * 8, (o_str + it.slot * 512 + 128) * 4);
-            a.h[0][0] = th[0]; a.h[0][1] = th[1]; a.l[0][0] = tl[0]; a.l[0][1] = tl[1];
-        } else {
-            static_for<it.ntile>([&]<int n>() {
-                a.h[n] = bld4(wv.w, wv.lane16, (o_str + (it.slot + n) * 512) * 4);
-                a.l[n] = bld4(wv.w, wv.lane16, (o_str + (it.slot + n) * 512 + 256) * 4);
-            });
-        }
+        static_for<it.ntile>([&]<int n>() {
+            a.h[n] = bld4(wv.w, wv.lane16, (o_str + (it.slot + n) * 512) * 4);
+            a.l[n] = bld4(wv.w, wv.lane16, (o_str + (it.slot + n) * 512 + 256) * 4);
+        });
     }
     return a;
 }
-// MFMAs of the chunk at walk position C: l3 = 0 -> output tiles acc0[0 .. NT0) two at a time, l3 = 1 -> acc1[m],
-// l3 = 2 -> acc2[m][16-edge half] (16-row MFMAs).  The three terms are issued term-major so that consecutive MFMAs hit
-// different accumulators.
+// MFMAs of the chunk at walk position C: l3 = 0 -> output tiles acc0[0 .. NT0) two at a time, l3 = 1 / 2 -> acc1[m] / acc2[m] (one tile
+// per component; the 16-channel l = 2 outputs only fill rows 0-15, i.e. registers 0-7).  The three terms are issued
+// term-major so that consecutive MFMAs hit different accumulators.
 template <int L, int NT0, int C, int PD>
-DEDF_DEV void mfma_chunk(const Wave& wv, int o_str, AItem (&ring)[PD], const BOpsH<L>& bo, f32x16 (&acc0)[NT0], f32x16 (&acc1)[3],
-                         f32x4 (&acc2)[5][2]) {
+DEDF_DEV void mfma_chunk(const Wave& wv, int o_str, AItem (&ring)[PD], const BOpsH<L>& bo, f32x16 (&acc0)[NT0], f32x16 (&acc1)[3], f32x16 (&acc2)[5]) {
     constexpr int l3 = dtp_pos_l3<L>(C), I0 = dtp_item_first<L>(C, NT0), NI = l3 == 0 ? cdiv(NT0, 2) : 1;
     static_for<NI>([&]<int t>() {
         constexpr int I = I0 + t;
@@ -135,27 +129,20 @@ DEDF_DEV void mfma_chunk(const Wave& wv, int o_str, AItem (&ring)[PD], const BOp
             static_for<nt>([&]<int n>() { acc0[2 * t + n] = mfma_h(__builtin_bit_cast(h8, a.h[n]), bo.hi[0], acc0[2 * t + n]); });
             static_for<nt>([&]<int n>() { acc0[2 * t + n] = mfma_h(__builtin_bit_cast(h8, a.h[n]), bo.lo[0], acc0[2 * t + n]); });
             static_for<nt>([&]<int n>() { acc0[2 * t + n] = mfma_h(__builtin_bit_cast(h8, a.l[n]), bo.hi[0], acc0[2 * t + n]); });
-        } else if constexpr (l3 == 1) {
-            const h8 ah = __builtin_bit_cast(h8, a.h[0]), al = __builtin_bit_cast(h8, a.l[0]);
-            static_for<3>([&]<int K>() { acc1[K] = mfma_h(ah, bo.hi[K], acc1[K]); });
-            static_for<3>([&]<int K>() { acc1[K] = mfma_h(ah, bo.lo[K], acc1[K]); });
-            static_for<3>([&]<int K>() { acc1[K] = mfma_h(al, bo.hi[K], acc1[K]); });
         } else {
-            const h4 ah = __builtin_bit_cast(h4, f32x2{a.h[0][0], a.h[0][1]}), al = __builtin_bit_cast(h4, f32x2{a.l[0][0], a.l[0][1]});
-            static_for<5>([&]<int K>() { static_for<2>([&]<int S>() { acc2[K][S] = mfma16h(ah, half4(bo.hi[K], S), acc2[K][S]); }); });
-            static_for<5>([&]<int K>() { static_for<2>([&]<int S>() { acc2[K][S] = mfma16h(ah, half4(bo.lo[K], S), acc2[K][S]); }); });
-            static_for<5>([&]<int K>() { static_for<2>([&]<int S>() { acc2[K][S] = mfma16h(al, half4(bo.hi[K], S), acc2[K][S]); }); });
+            constexpr int d3 = 2 * l3 + 1;
+            auto& accm = [&]() -> auto& { if constexpr (l3 == 1) return acc1; else return acc2; }();
+            const h8 ah = __builtin_bit_cast(h8, a.h[0]), al = __builtin_bit_cast(h8, a.l[0]);
+            static_for<d3>([&]<int K>() { accm[K] = mfma_h(ah, bo.hi[K], accm[K]); });
+            static_for<d3>([&]<int K>() { accm[K] = mfma_h(ah, bo.lo[K], accm[K]); });
+            static_for<d3>([&]<int K>() { accm[K] = mfma_h(al, bo.hi[K], accm[K]); });
         }
     });
 }
-// split the chunk's fp32 products v[m][8] into B operands (l3 = 2: re-laned for the 16-column MFMAs)
+// split the chunk's fp32 products v[m][8] into B operands
 template <int L, int l3>
 DEDF_DEV void split_chunk(const float (&v)[2 * l3 + 1][8], BOpsH<L>& o) {
-    static_for<2 * l3 + 1>([&]<int K>() {
-        const HL sp = split8(v[K]);
-        if constexpr (l3 == 2) { o.hi[K] = relane16(sp.hi); o.lo[K] = relane16(sp.lo); }
-        else { o.hi[K] = sp.hi; o.lo[K] = sp.lo; }
-    });
+    static_for<2 * l3 + 1>([&]<int K>() { const HL sp = split8(v[K]); o.hi[K] = sp.hi; o.lo[K] = sp.lo; });
 }
 
 template <int L, int F0>
@@ -264,11 +251,10 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
 
     // ---- layer 3 (-> per-edge TP weights, one 32-row tile at a time) fused with DTP #1 and the lin / sep_alpha GEMMs ----
     // Chunks are walked grouped by output degree (dedf_net.h::dtp_pos_chunk): first all l3 = 0 chunks into acc0 (NR0 tiles:
-    // lin scalars + gates | alpha), then l3 = 1 into acc1 (one tile per m), then l3 = 2 into acc2 (16-channel outputs on
-    // 16x16x16 MFMAs: [m][edge sub-tile 0-15 | 16-31]).  When a group is complete its activations (logits, Gate) are
-    // computed and the gated features parked in LDS (this wave's private 30 KB) until the second depth-wise TP reads them.
-    f32x16 acc0[NR0], acc1[3];
-    f32x4 acc2[5][2];
+    // lin scalars + gates | alpha), then l3 = 1 into acc1, then l3 = 2 into acc2 (one tile per m).
+    // When a group is complete its activations (logits, Gate) are computed and the gated features parked in LDS (this
+    // wave's private 30 KB) until the second depth-wise TP reads them.
+    f32x16 acc0[NR0], acc1[3], acc2[5];
     const Buf msgb = make_buf(P.msg, P.msg_bytes);
     // per-l1 lane offsets of the 4 message rows this lane owns inside an 8-row group
     const int mv0 = src * (D * 4) + hi * 16, mv1 = src * (D * 4) + hi * 48, mv2 = src * (D * 4) + hi * 80;
@@ -360,11 +346,13 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     };
     auto dump_w = [&]<int Tw>(const f32x16& w) {      // debug only: back to the e3nn weight order
         if (P.dbg_w != nullptr && valid)
-            static_for<16>([&]<int R>() { P.dbg_w[(size_t)e * WN + dtp_walk_row<L>(Tw * 32 + (R & 3) + 8 * (R >> 2)) + 4 * hi] = w[R]; });
+            static_for<16>([&]<int R>() { P.dbg_w[(size_t)e * WN + dtp_walk_row<L>(Tw * 32 + (R & 3) + 8 * (R >> 2)) + 4 * hi] = w[R] * P.w_unscale; });
     };
 
     // activations of a completed group ----------------------------------------------------------------------------------
+    // (the accumulators carry the power-of-two operand scales: c_lin brings them back, the parked features carry u_scale)
     float logit[kHeads], g1[16], g2[8];
+    const float cl0 = opaque_s(P.c_lin[0]), us = opaque_s(P.u_scale), cl1 = opaque_s(P.c_lin[1]), cl2 = opaque_s(P.c_lin[L >= 2 ? 2 : 0]);
     auto finish_group = [&]<int l3>() {
         if constexpr (l3 == 0) {
             // attention logits (graph_attention.py:233-246): heads of sep_alpha -> SmoothLeakyReLU -> . alpha_dot + log cut-off
@@ -374,40 +362,33 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 const f32x4 d0 = bld4(wv.w, wv.hi64, (o_alpha_dot + (hd >> 1) * 32 + r0) * 4);
                 const f32x4 d1v = bld4(wv.w, wv.hi64, (o_alpha_dot + (hd >> 1) * 32 + r0 + 4) * 4);
                 float sum = 0.0f;
-                static_for<4>([&]<int R>() { sum += slrelu_n(acc0[T][r0 + R]) * d0[R]; });
-                static_for<4>([&]<int R>() { sum += slrelu_n(acc0[T][r0 + 4 + R]) * d1v[R]; });
+                static_for<4>([&]<int R>() { sum += slrelu_n(acc0[T][r0 + R] * cl0) * d0[R]; });
+                static_for<4>([&]<int R>() { sum += slrelu_n(acc0[T][r0 + 4 + R] * cl0) * d1v[R]; });
                 sum += xor32(sum);
                 logit[hd] = sum + logit0;
             });
             // Gate (fast_activation.py:210-224): SiLU on the 64 scalars, sigmoid gates for the l >= 1 channels
             static_for<2>([&]<int T>() { static_for<4>([&]<int q>() {
-                pk[(4 * T + q) * 64] = f32x4{silu_n(acc0[T][4 * q]), silu_n(acc0[T][4 * q + 1]), silu_n(acc0[T][4 * q + 2]), silu_n(acc0[T][4 * q + 3])};
+                pk[(4 * T + q) * 64] = f32x4{silu_n(acc0[T][4 * q] * cl0) * us, silu_n(acc0[T][4 * q + 1] * cl0) * us, silu_n(acc0[T][4 * q + 2] * cl0) * us,
+                                             silu_n(acc0[T][4 * q + 3] * cl0) * us};
             }); });
-            if constexpr (L >= 1) { constexpr int G0 = gate_row(1, 0); static_for<16>([&]<int R>() { g1[R] = sigmoid_n(acc0[G0 / 32][(G0 % 32) / 2 + R]); }); }
-            if constexpr (L >= 2) { constexpr int G0 = gate_row(2, 0); static_for<8>([&]<int R>() { g2[R] = sigmoid_n(acc0[G0 / 32][(G0 % 32) / 2 + R]); }); }
+            if constexpr (L >= 1) { constexpr int G0 = gate_row(1, 0); static_for<16>([&]<int R>() { g1[R] = sigmoid_n(acc0[G0 / 32][(G0 % 32) / 2 + R] * cl0) * (cl1 * us); }); }
+            if constexpr (L >= 2) { constexpr int G0 = gate_row(2, 0); static_for<8>([&]<int R>() { g2[R] = sigmoid_n(acc0[G0 / 32][(G0 % 32) / 2 + R] * cl0) * (cl2 * us); }); }
         } else if constexpr (l3 == 1) {
             static_for<3>([&]<int K>() { static_for<4>([&]<int q>() {
                 pk[(US1 + 4 * K + q) * 64] = f32x4{acc1[K][4 * q] * g1[4 * q], acc1[K][4 * q + 1] * g1[4 * q + 1], acc1[K][4 * q + 2] * g1[4 * q + 2],
                                                    acc1[K][4 * q + 3] * g1[4 * q + 3]};
             }); });
         } else {
-            // 16x16 accumulators back to the row layout (row = channel, lane = edge column + row half): two row exchanges
-            static_for<5>([&]<int K>() {
-                float lo4[4], hi4[4];
-                static_for<4>([&]<int q>() {
-                    float x = acc2[K][0][q], y = acc2[K][1][q];
-                    swap16(x, y);
-                    swap32(x, y);
-                    lo4[q] = x * g2[q]; hi4[q] = y * g2[4 + q];
-                });
-                pk[(US2 + 2 * K) * 64] = f32x4{lo4[0], lo4[1], lo4[2], lo4[3]};
-                pk[(US2 + 2 * K + 1) * 64] = f32x4{hi4[0], hi4[1], hi4[2], hi4[3]};
-            });
+            static_for<5>([&]<int K>() { static_for<2>([&]<int q>() {     // 16 channels = registers 0-7
+                pk[(US2 + 2 * K + q) * 64] = f32x4{acc2[K][4 * q] * g2[4 * q], acc2[K][4 * q + 1] * g2[4 * q + 1], acc2[K][4 * q + 2] * g2[4 * q + 2],
+                                                   acc2[K][4 * q + 3] * g2[4 * q + 3]};
+            }); });
         }
     };
     auto start_group = [&]<int l3>() {
         if constexpr (l3 == 1) static_for<3>([&]<int K>() { static_for<16>([&]<int R>() { acc1[K][R] = 0.0f; }); });
-        if constexpr (l3 == 2) static_for<5>([&]<int K>() { static_for<2>([&]<int S>() { acc2[K][S] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }); });
+        if constexpr (l3 == 2) static_for<5>([&]<int K>() { static_for<16>([&]<int R>() { acc2[K][R] = 0.0f; }); });
     };
 
     DEDF_STAMP(6);
@@ -457,29 +438,34 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     sched_fence();
     DEDF_STAMP(12);
     // ---- sep_value: depth-wise TP #2 (shared weights folded into the A stream) + LinearRS -> value --------------------------
-    // same walk: l3 = 0 chunks -> val0, l3 = 1 -> val1[m], l3 = 2 -> val2; a completed group goes straight to the edge record
-    f32x16 val0[2], val1[3];
-    f32x4 val2[5][2];
+    // same walk: l3 = 0 chunks -> val0, l3 = 1 / 2 -> val1[m] / val2[m]; a completed group goes straight to the edge record
+    f32x16 val0[2], val1[3], val2[5];
     static_for<2>([&]<int T>() { val0[T] = ldrows(wv, o_b_val0, T); });
-    auto valu_val = [&]<int C>() {
+    struct XPark { f32x4 a[2 * L + 1][2]; };      // parked gated features of a chunk's 8 channels (per lane)
+    auto load_park = [&]<int C>() {
+        XPark o{};
+        if constexpr (C < NCHK) {
+            constexpr PathInfo pi = dtp_pos_path<L>(C);
+            constexpr int l1 = pi.l1, d1 = 2 * l1 + 1, cu = dtp_pos_u0<L>(C) / 16;
+            static_for<d1>([&]<int I>() {
+                constexpr int s0 = l1 == 0 ? 2 * cu : (l1 == 1 ? US1 + 4 * I + 2 * cu : US2 + 2 * I);
+                o.a[I][0] = pk[s0 * 64]; o.a[I][1] = pk[(s0 + 1) * 64];
+            });
+        }
+        return o;
+    };
+    auto valu_val = [&]<int C>(const XPark& xp) {
         BOpsH<L> o{};
         if constexpr (C < NCHK) {
             constexpr PathInfo pi = dtp_pos_path<L>(C);
             constexpr int l1 = pi.l1, l2 = pi.l2, l3 = pi.l3, d1 = 2 * l1 + 1, d3 = 2 * l3 + 1;
-            constexpr int cu = dtp_pos_u0<L>(C) / 16;
             using Cg = CG<l1, l2, l3>;
             float m[Cg::NM];
             Cg::make(Y.template get<l2>(), m);
-            float xs[d1][8];        // parked gated features of the chunk's 8 channels
-            static_for<d1>([&]<int I>() {
-                constexpr int s0 = l1 == 0 ? 2 * cu : (l1 == 1 ? US1 + 4 * I + 2 * cu : US2 + 2 * I);
-                const f32x4 a = pk[s0 * 64], b = pk[(s0 + 1) * 64];
-                static_for<4>([&]<int i>() { xs[I][i] = a[i]; xs[I][4 + i] = b[i]; });
-            });
             float v[d3][8];
             static_for<8>([&]<int jj>() {
                 float x[d1], t[d3];
-                static_for<d1>([&]<int I>() { x[I] = xs[I][jj]; });
+                static_for<d1>([&]<int I>() { x[I] = xp.a[I][jj / 4][jj % 4]; });
                 Cg::apply(x, m, t);
                 static_for<d3>([&]<int K>() { v[K][jj] = t[K]; });
             });
@@ -488,42 +474,39 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         return o;
     };
     float* const orec = P.out + (size_t)e * REC;
+    const float cv0 = opaque_s(P.c_val[0]), cv1 = opaque_s(P.c_val[1]), cv2 = opaque_s(P.c_val[L >= 2 ? 2 : 0]);
     auto store_group = [&]<int l3>() {       // value in internal layout [l][m][channel]
         if constexpr (l3 == 0) {
             if (valid) static_for<2>([&]<int T>() { static_for<4>([&]<int g>() {
-                st4(orec + T * 32 + 8 * g + 4 * hi, f32x4{val0[T][4 * g], val0[T][4 * g + 1], val0[T][4 * g + 2], val0[T][4 * g + 3]});
+                st4(orec + T * 32 + 8 * g + 4 * hi, f32x4{val0[T][4 * g], val0[T][4 * g + 1], val0[T][4 * g + 2], val0[T][4 * g + 3]} * cv0);
             }); });
-        } else if constexpr (l3 == 1) {
-            if (valid) static_for<3>([&]<int K>() { static_for<4>([&]<int g>() {
-                st4(orec + blk_off(1) + K * 32 + 8 * g + 4 * hi,
-                    f32x4{val1[K][4 * g], val1[K][4 * g + 1], val1[K][4 * g + 2], val1[K][4 * g + 3]});
+        } else {
+            constexpr int ng = mul_of(l3) / 8;     // 8-channel runs per component
+            auto& valm = [&]() -> auto& { if constexpr (l3 == 1) return val1; else return val2; }();
+            if (valid) static_for<2 * l3 + 1>([&]<int K>() { static_for<ng>([&]<int g>() {
+                st4(orec + blk_off(l3) + K * mul_of(l3) + 8 * g + 4 * hi,
+                    f32x4{valm[K][4 * g], valm[K][4 * g + 1], valm[K][4 * g + 2], valm[K][4 * g + 3]} * (l3 == 1 ? cv1 : cv2));
             }); });
-        } else {    // l = 2 block straight from the 16x16 layout: lane (g, e') holds channels 4g..4g+3 of edges e' and 16+e'
-            const int g4 = (wv.lane >> 4) * 4, el = wv.lane & 15;
-            static_for<2>([&]<int S>() {
-                if (el + 16 * S < n_valid) {
-                    float* o2 = P.out + (size_t)(e0 + el + 16 * S) * REC + blk_off(2) + g4;
-                    static_for<5>([&]<int K>() { st4(o2 + K * 16, val2[K][S]); });
-                }
-            });
         }
     };
     auto start_val = [&]<int l3>() {
         if constexpr (l3 == 1) static_for<3>([&]<int K>() { static_for<16>([&]<int R>() { val1[K][R] = 0.0f; }); });
-        if constexpr (l3 == 2) static_for<5>([&]<int K>() { static_for<2>([&]<int S>() { val2[K][S] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }); });
+        if constexpr (l3 == 2) static_for<5>([&]<int K>() { static_for<16>([&]<int R>() { val2[K][R] = 0.0f; }); });
     };
     const int o_S_val = opaque_s(P.o_S_val);
     AItem vring[PDA];
     static_for<PDA>([&]<int I>() { vring[I] = load_item<L, 2, I>(wv, o_S_val); });
-    BOpsH<L> vb_cur = valu_val.template operator()<0>();
+    XPark xp_nxt = load_park.template operator()<1>();
+    BOpsH<L> vb_cur = valu_val.template operator()<0>(load_park.template operator()<0>());
     static_for<NCHK>([&]<int C>() {
+        const XPark xp_nn = load_park.template operator()<C + 2>();
         static_for<L + 1>([&]<int g>() { if constexpr (g >= 1 && C == dtp_group_end<L>(g - 1)) start_val.template operator()<g>(); });
         sched_fence();
-        const BOpsH<L> vb_nxt = valu_val.template operator()<C + 1>();
+        const BOpsH<L> vb_nxt = valu_val.template operator()<C + 1>(xp_nxt);
         mfma_chunk<L, 2, C>(wv, o_S_val, vring, vb_cur, val0, val1, val2);
         static_for<L + 1>([&]<int g>() { if constexpr (C == dtp_group_end<L>(g)) store_group.template operator()<g>(); });
         sched_fence();
-        vb_cur = vb_nxt;
+        vb_cur = vb_nxt; xp_nxt = xp_nn;
         if constexpr (C + 1 == dtp_group_end<L>(0)) DEDF_STAMP(10);
         if constexpr (L >= 2 && C + 1 == dtp_group_end<L>(1)) DEDF_STAMP(13);
     });

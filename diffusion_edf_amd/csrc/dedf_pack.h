@@ -106,6 +106,10 @@ struct EdgeOffsets {
     int o_enc, o_A_pre, o_A_r1, o_b_r1, o_g_r1, o_be_r1, o_A_r2, o_b_r2, o_g_r2, o_be_r2, o_A_r3, o_off_r3;
     int o_A_pre_l, o_A_r1_l, o_A_r2_l, o_A_r3_l;      // residual (lo) images of the split-fp16 radial-MLP layers
     int o_S_lin, o_b_r0, o_S_val, o_b_val0, o_alpha_dot;     // o_S_*: split-fp16 A-operand streams (pack_dtp_stream)
+    // power-of-two operand scaling of the split-fp16 GEMMs (keeps the lo halves out of the fp16 subnormal range, see pow2_scale):
+    float w_unscale;        // layer-3 output (per-edge TP weights) carries 2^s3; this is 2^-s3
+    float u_scale;          // the gated features are parked as 2^su * u
+    float c_lin[4], c_val[4];   // accumulator -> true value of the lin / value GEMMs, per output degree
 };
 struct NodeOffsets {
     int o_A_proj[4], o_b_proj0, o_ln_w[4], o_ln_b0, o_A_f1[4], o_b_f1, o_A_f2[4], o_b_f2;
@@ -113,11 +117,17 @@ struct NodeOffsets {
 };
 
 inline float softplusf(float x) { return x > 20.0f ? x : std::log1p(std::exp(x)); }
+// exponent s such that 2^s * maxabs lands in [256, 512]: typical elements are then O(10..100), their fp16 residuals (2^-11 of
+// that) stay normal fp16 numbers, and the largest element is far from the fp16 maximum.  Scaling by 2^s is exact.
+inline int pow2_scale(float maxabs, int lo, int hi) {
+    if (!(maxabs > 0.0f)) return lo;
+    const int s = (int)std::floor(std::log2(512.0f / maxabs));
+    return s < lo ? lo : (s > hi ? hi : s);
+}
 
 // Split-fp16 A-operand stream of a linear layer fed by the depth-wise TP (dedf_net.h::dtp_item): slots in the order the
 // edge kernel consumes them.  Slot = 512 floats: hi image (256) | lo image (256) of one (output tile x chunk) operand,
-// [lane 64][8 halves] for v_mfma_f32_32x32x16_f16 (row lane & 31, k16 = 8 (lane >> 5) + j); l3 = 2 slots hold the 16-row
-// operand of v_mfma_f32_16x16x16_f16: [lane 64][4 halves] (row lane & 15, k16 = 4 (lane >> 4) + i), hi at 0, lo at 128.
+// [lane 64][8 halves] for v_mfma_f32_32x32x16_f16 (row lane & 31, k16 = 8 (lane >> 5) + j); rows past rows[l] are zero.
 //   W(l, o, k) -> weight of output row o of block l for sorted DTP channel k;  rows[l] = valid output rows
 template <int L, class WAt>
 inline std::vector<float> pack_dtp_stream(int nt0, const int* rows, WAt W) {
@@ -131,22 +141,16 @@ inline std::vector<float> pack_dtp_stream(int nt0, const int* rows, WAt W) {
     for (int pos = 0; pos < dtp_wn<L>() / 16; ++pos) {
         const int l3 = dtp_pos_l3<L>(pos);
         const int nt = l3 == 0 ? nt0 : 1;
-        for (int To = 0; To < nt; ++To, ++slot) {
-            for (int lane = 0; lane < 64; ++lane) {
-                const bool m16 = l3 == 2;
-                const int ne = m16 ? 4 : 8;
-                for (int j = 0; j < ne; ++j) {
-                    const int o = m16 ? (lane & 15) : To * 32 + (lane & 31);
-                    const int k16 = m16 ? 4 * (lane >> 4) + j : 8 * (lane >> 5) + j;
+        for (int To = 0; To < nt; ++To, ++slot)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int o = To * 32 + (lane & 31), k16 = 8 * (lane >> 5) + j;
                     if (o >= rows[l3]) continue;
                     const float w = W(l3, o, dtp_pos_channel<L>(pos, k16));
-                    const size_t hi_idx = slot * 1024 + (size_t)lane * ne + j;
-                    const size_t lo_idx = hi_idx + (m16 ? 256 : 512);
+                    const size_t hi_idx = slot * 1024 + (size_t)lane * 8 + j;
                     const float h = put(hi_idx, w);
-                    put(lo_idx, w - h);
+                    put(hi_idx + 512, w - h);
                 }
-            }
-        }
     }
     std::vector<float> out(img.size() / 2);
     __builtin_memcpy(out.data(), img.data(), img.size() * 2);
@@ -194,6 +198,7 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
         o.o_A_pre_l = im.push(all_l);
     }
     auto rows = [&](int O, const float* v) { return pack_rows(O, [&](int i) { return v[i]; }); };
+    int s3 = 0;
     {
         std::vector<float> ih, il;
         const float* W = S.get(B, rad + "net.0.weight");
@@ -210,10 +215,17 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
         o.o_be_r2 = im.push(rows(64, S.get(B, rad + "net.4.bias")));
         const float* W3 = S.get(B, rad + "net.6.weight");
         // rows (= per-edge TP weights) in the kernel's walk order: chunks grouped by output degree (dedf_net.h::dtp_walk_row)
-        pack_A_h(dtp_wn<L>(), 4, [&](int oo, int k) { return W3[dtp_walk_row<L>(oo) * 64 + k]; }, [](int cc, int j, int h) { return chain_k(64, cc, j, h); }, ih, il);
-        o.o_A_r3 = im.push(ih); o.o_A_r3_l = im.push(il);
         const float* off3 = S.get(B, rad + "offset");
-        o.o_off_r3 = im.push(pack_rows(dtp_wn<L>(), [&](int i) { return off3[dtp_walk_row<L>(i)]; }));
+        // the layer's output w (and with it the B operands w * CG of the lin / sep_alpha GEMMs) is produced as 2^s3 * w, s3 <= 8
+        float m3 = 0.0f;
+        for (int i = 0; i < dtp_wn<L>() * 64; ++i) m3 = std::fmax(m3, std::fabs(W3[i]));
+        for (int i = 0; i < dtp_wn<L>(); ++i) m3 = std::fmax(m3, std::fabs(off3[i]));
+        s3 = pow2_scale(m3, 0, 8);
+        const float f3 = std::ldexp(1.0f, s3);
+        pack_A_h(dtp_wn<L>(), 4, [&](int oo, int k) { return W3[dtp_walk_row<L>(oo) * 64 + k] * f3; }, [](int cc, int j, int h) { return chain_k(64, cc, j, h); }, ih, il);
+        o.o_A_r3 = im.push(ih); o.o_A_r3_l = im.push(il);
+        o.o_off_r3 = im.push(pack_rows(dtp_wn<L>(), [&](int i) { return off3[dtp_walk_row<L>(i)] * f3; }));
+        o.w_unscale = std::ldexp(1.0f, -s3);
     }
     {   // sep_act.lin (+ sep_alpha on the l3 = 0 K-steps) and sep_value.lin (shared DTP weights folded in)
         const float* lw = S.get(B, ga + ".sep_act.lin.tp.weight");
@@ -242,19 +254,37 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
         }
         const int a0 = alpha_row0<L>(), O0 = lin0_rows<L>();
         // sep_act.lin rows, then (from row a0) the sep_alpha rows, share the l3 = 0 chunks
-        o.o_S_lin = im.push(pack_dtp_stream<L>(r0_tiles<L>(), lrows, [&](int l, int oo, int k) {
+        auto lin_w = [&](int l, int oo, int k) {
             if (l == 0) return oo < O0 ? lw[lofs[0] + (size_t)k * O0 + oo] : (oo >= a0 ? aw[(size_t)k * mul_of(0) + (oo - a0)] : 0.0f);
             return lw[lofs[l] + (size_t)k * mul_of(l) + oo];
-        }));
-        o.o_S_val = im.push(pack_dtp_stream<L>(mul_of(0) / 32, vrows, [&](int l, int oo, int k) {
-            return vw[vofs[l] + (size_t)k * mul_of(l) + oo] * w2[wflat(l, k)];
-        }));
+        };
+        auto val_w = [&](int l, int oo, int k) { return vw[vofs[l] + (size_t)k * mul_of(l) + oo] * w2[wflat(l, k)]; };
+        const int su = 8;
+        int sl[4] = {0, 0, 0, 0}, sv[4] = {0, 0, 0, 0};
+        for (int l = 0; l <= L; ++l) {
+            float ml = 0.0f, mv = 0.0f;
+            for (int k = 0; k < dtp_k<L>(l); ++k) {
+                for (int oo = 0; oo < lrows[l]; ++oo) ml = std::fmax(ml, std::fabs(lin_w(l, oo, k)));
+                for (int oo = 0; oo < vrows[l]; ++oo) mv = std::fmax(mv, std::fabs(val_w(l, oo, k)));
+            }
+            sl[l] = pow2_scale(ml, 0, 20); sv[l] = pow2_scale(mv, 0, 20);
+            o.c_lin[l] = std::ldexp(1.0f, -(sl[l] + s3));
+            o.c_val[l] = std::ldexp(1.0f, -(sv[l] + su));
+        }
+        o.u_scale = std::ldexp(1.0f, su);
+        o.o_S_lin = im.push(pack_dtp_stream<L>(r0_tiles<L>(), lrows, [&](int l, int oo, int k) { return std::ldexp(lin_w(l, oo, k), sl[l]); }));
+        o.o_S_val = im.push(pack_dtp_stream<L>(mul_of(0) / 32, vrows, [&](int l, int oo, int k) { return std::ldexp(val_w(l, oo, k), sv[l]); }));
         {
             const float* lb = S.get(B, ga + ".sep_act.lin.bias.0");
             const float* ab = S.get(B, ga + ".sep_alpha.bias.0");
-            o.o_b_r0 = im.push(pack_rows(a0 + mul_of(0), [&](int i) { return i < O0 ? lb[i] : (i >= a0 ? ab[i - a0] : 0.0f); }));
+            const float f0 = std::ldexp(1.0f, sl[0] + s3);
+            o.o_b_r0 = im.push(pack_rows(a0 + mul_of(0), [&](int i) { return (i < O0 ? lb[i] : (i >= a0 ? ab[i - a0] : 0.0f)) * f0; }));
         }
-        o.o_b_val0 = im.push(rows(mul_of(0), S.get(B, ga + ".sep_value.lin.bias.0")));
+        {
+            const float* vb = S.get(B, ga + ".sep_value.lin.bias.0");
+            const float f0 = std::ldexp(1.0f, sv[0] + su);
+            o.o_b_val0 = im.push(pack_rows(mul_of(0), [&](int i) { return vb[i] * f0; }));
+        }
         o.o_alpha_dot = im.push(rows(mul_of(0), S.get(B, ga + ".alpha_dot")));
     }
 }
