@@ -12,11 +12,13 @@ Langevin update (f64).  value = (poses on all ranks) x K / max-over-ranks wall t
 One RCCL all-gather of the final poses closes the timed region.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (fused per-edge pipeline): achieved = 2 * E * 193 344 FLOP per launch / its HIP-event duration.
-                peak = the MFMA bound of the kernel's instruction mix (MI355X_MICROARCH.md): the radial MLP + pre-linear
-                (71 680 of the 193 344 MAC/edge) run as 3-term split-fp16 products on the 2.5 PFLOP/s dense fp16 MFMAs
-                (fp32-equivalent rate 2500/3 TFLOP/s), everything else is priced at the 157.3 TFLOP/s dense fp32 MFMA peak.
-                The plain fp32-MFMA fraction is reported beside it; traffic from profiles/*pmc*.json if present.
+  roofline      dominant kernel (fused per-edge pipeline): achieved = 2 * E * 193 344 FLOP per launch / its HIP-event duration
+                (fp32-equivalent algorithmic FLOP).  Every dense GEMM of the kernel (163 584 of the 193 344
+                MAC/edge) runs as a 3-term split-fp16 product (hi*hi + hi*lo + lo*hi, fp32 accumulate) on the 2.5 PFLOP/s dense
+                fp16 MFMAs of MI355X_MICROARCH.md, so its fp32-equivalent MFMA peak is 2500/3 TFLOP/s; the lane-local
+                Clebsch-Gordan contractions (29 760 MAC/edge in the dense-CG convention) never touch MFMA and are priced at the
+                157.3 TFLOP/s fp32 vector peak.  peak = the bound of that mix; the fraction of the plain fp32 MFMA peak (the
+                figure of the first kernel generation) is reported beside it.  traffic from profiles/*pmc*.json if present.
   cpu_baseline  the CPU restatement oracle ("port", fp32, same inputs) timed on this host on a bounded pose sample.
 """
 from __future__ import annotations
@@ -35,15 +37,15 @@ sys.path.insert(0, ROOT)
 
 M_EDGE = {1: 105_536, 2: 193_344}          # algorithmic MAC per edge (dense-CG convention)
 M_NODE = {1: 56_320 + 186_560, 2: 68_352 + 343_264}
-M_EDGE_SPLIT = {1: 16_384 + 128 * 128 + 128 * 64 + 64 * 224, 2: 16_384 + 128 * 128 + 128 * 64 + 64 * 480}   # MAC per edge on split-fp16 MFMAs
-PEAK_FP32_MFMA_TFLOPS = 157.3
-PEAK_FP16_MFMA_TFLOPS = 2500.0
+M_EDGE_CG = {1: 2 * 2_080, 2: 2 * 14_880}   # of which: the two depth-wise TPs (dense-CG convention), VALU work
+PEAK_FP32_MFMA_TFLOPS = 157.3             # dense fp32 MFMA = fp32 vector peak (MI355X_MICROARCH.md)
+PEAK_FP16_MFMA_TFLOPS = 2500.0            # dense fp16 MFMA
 
 
 def mix_peak_tflops(lmax):
-    """MFMA bound of k_edge's instruction mix: fp32-equivalent FLOP/s if every MFMA issued back to back"""
-    m, ms = M_EDGE[lmax], M_EDGE_SPLIT[lmax]
-    t = (m - ms) / PEAK_FP32_MFMA_TFLOPS + ms * 3.0 / PEAK_FP16_MFMA_TFLOPS
+    """bound of k_edge's instruction mix in fp32-equivalent FLOP/s: GEMMs as 3 fp16 MFMA products, CG on the fp32 VALU"""
+    m, mc = M_EDGE[lmax], M_EDGE_CG[lmax]
+    t = (m - mc) * 3.0 / PEAK_FP16_MFMA_TFLOPS + mc / PEAK_FP32_MFMA_TFLOPS
     return m / t
 
 
@@ -177,7 +179,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (score network: fp32 MFMA + 3-term split-fp16 MFMA with fp32 accumulation, fp32-equivalent error) + f64 (SE(3) Langevin state)",
+            "dtype": "f32 (score network; dense GEMMs as 3-term split-fp16 MFMA products = 22-bit operands, fp32 accumulate) + f64 (SE(3) Langevin state)",
             "data": "synthetic (seeded scene/grasp clouds of the named sizes, random-init weights of the reference architecture)",
             "config": {"workload": f"{wname}: {args.scene}-pt scene -> key clouds {'/'.join(str(len(k.x)) for k in keys)}, {args.grasp}-pt grasp -> "
                                    f"{len(query.x)} query pts, lmax={args.lmax}, {args.poses_per_gpu} poses per GPU, t 1->0.15 log-spaced, dt 0.04",
@@ -185,7 +187,7 @@ def main():
                        "edges_per_step_rank0": e_per_launch, "full_trajectories_per_s_at_50_steps": n_total * args.steps / el / 50.0},
             "roofline": {"kernel": "k_edge (fused per-edge pipeline)", "bound": "mfma", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                         "peak_definition": "MFMA bound of the instruction mix: split-fp16x3 radial MLP at 2500/3, rest at 157.3 (fp32 MFMA)",
+                         "peak_definition": "bound of the instruction mix: all GEMMs as 3-term split-fp16 products on the 2.5 PFLOP/s fp16 MFMAs (2500/3 fp32-equivalent), Clebsch-Gordan contractions on the 157.3 TFLOP/s fp32 VALU",
                          "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "avg_launch_ms": edge_ms, "algorithmic_flop_per_launch": flops,
                          "kernel_ms_per_step": {k: v / n_ev for k, v in prof["ms"].items()}},

@@ -416,7 +416,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     DEDF_STAMP(7);
     static_for<NCHK>([&]<int C>() {
         constexpr int Ph = C + 3, T3 = Ph / 2;       // layer-3 half of this region
-        const XOps x_nn = load_X.template operator()<C + 2>();
+        XOps x_nn = x_nxt;                        // chunks that read the same source rows share the request
+        if constexpr (!dtp_pos_same_x<L>(C + 2, C + 1)) x_nn = load_X.template operator()<C + 2>();
         const L3Half l3c = l3n;
         const f32x16 offc = offn;
         l3n = load_l3.template operator()<Ph + 1>();
@@ -499,7 +500,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     XPark xp_nxt = load_park.template operator()<1>();
     BOpsH<L> vb_cur = valu_val.template operator()<0>(load_park.template operator()<0>());
     static_for<NCHK>([&]<int C>() {
-        const XPark xp_nn = load_park.template operator()<C + 2>();
+        XPark xp_nn = xp_nxt;
+        if constexpr (!dtp_pos_same_x<L>(C + 2, C + 1)) xp_nn = load_park.template operator()<C + 2>();
         static_for<L + 1>([&]<int g>() { if constexpr (g >= 1 && C == dtp_group_end<L>(g - 1)) start_val.template operator()<g>(); });
         sched_fence();
         const BOpsH<L> vb_nxt = valu_val.template operator()<C + 1>(xp_nxt);

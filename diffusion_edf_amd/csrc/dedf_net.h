@@ -87,8 +87,9 @@ template <int L> inline std::vector<KStep> dtp_steps(int l3) {
 
 // A "chunk" = 16 consecutive channels of one depth-wise-TP path = 8 accumulator registers x 2 half-waves = one K = 16 step
 // of the split-fp16 MFMAs.  The edge kernel walks the chunks grouped by output degree l3 (all l3 = 0 chunks, then l3 = 1,
-// ...; inside a group in e3nn weight order) so that only one group's accumulators are live at a time; the host packs the
-// last radial-MLP layer (rows = per-edge TP weights) and the A-operand streams in that walk order.
+// ...) so that only one group's accumulators are live at a time, and inside a group by (l1, channel range) so that
+// consecutive chunks of different paths read the same input rows (dtp_pos_same_x); the host packs the last radial-MLP
+// layer (rows = per-edge TP weights) and the A-operand streams in that walk order.
 //   position p (0 .. WN/16)  ->  e3nn weight chunk dtp_pos_chunk(p)  (weight rows 16 wc .. 16 wc + 15)
 // Element k16 = 8 h + jj of the chunk at position p (h = half-wave, jj = register 8 (p % 2) + jj of weight tile p / 2) is
 // channel chunk_row(k16) of the chunk: the register order of a row-layout tile.
@@ -98,11 +99,13 @@ template <int L> DEDF_HD constexpr DtpWalk<L> make_dtp_walk() {
     DtpWalk<L> w{};
     int n = 0;
     for (int l3 = 0; l3 <= L; ++l3)
-        for (int q = 0; q < dtp_num_paths<L>(); ++q) {
-            const PathInfo pi = dtp_path<L>(q);
-            if (pi.l3 != l3) continue;
-            for (int c = 0; c < pi.mul1 / 16; ++c) { w.chunk[n] = pi.wstart / 16 + c; w.path[n] = pi; ++n; }
-        }
+        for (int l1 = 0; l1 <= L; ++l1)
+            for (int c = 0; c < mul_of(l1) / 16; ++c)
+                for (int q = 0; q < dtp_num_paths<L>(); ++q) {
+                    const PathInfo pi = dtp_path<L>(q);
+                    if (pi.l3 != l3 || pi.l1 != l1) continue;
+                    w.chunk[n] = pi.wstart / 16 + c; w.path[n] = pi; ++n;
+                }
     w.n = n;
     for (int i = n; i < 64; ++i) { w.chunk[i] = dtp_wn<L>() / 16; w.path[i] = PathInfo{-1, -1, -1, 0, 0, 0, 0}; }
     return w;
@@ -114,6 +117,10 @@ template <int L> DEDF_HD constexpr int dtp_pos_l3(int p) { return dtp_pos_path<L
 // first channel of the chunk inside its path (u0) / inside the l3 block of the sorted DTP output
 template <int L> DEDF_HD constexpr int dtp_pos_u0(int p) { return dtp_pos_chunk<L>(p) * 16 - dtp_pos_path<L>(p).wstart; }
 template <int L> DEDF_HD constexpr int dtp_pos_channel(int p, int k16) { return dtp_pos_path<L>(p).kofs + dtp_pos_u0<L>(p) + chunk_row(k16); }
+// chunks p and q read the same input channels (same l1, same channel range)
+template <int L> DEDF_HD constexpr bool dtp_pos_same_x(int p, int q) {
+    return p >= 0 && q >= 0 && p < dtp_wn<L>() / 16 && q < dtp_wn<L>() / 16 && dtp_pos_path<L>(p).l1 == dtp_pos_path<L>(q).l1 && dtp_pos_u0<L>(p) == dtp_pos_u0<L>(q);
+}
 // e3nn weight row held by row r of the (walk-ordered) last radial layer
 template <int L> DEDF_HD constexpr int dtp_walk_row(int r) { return dtp_pos_chunk<L>(r / 16) * 16 + r % 16; }
 // number of chunks with output degree <= l3 (= position one past the end of group l3)

@@ -36,7 +36,7 @@ def main(tag):
             seen.add(r[0])
             out_txt.append(" | ".join(str(x) for x in r)[:200])
     pmc = {}
-    for kind in ("fetch", "write", "sq"):
+    for kind in ("fetch", "write", "sq", "sq2", "sq3", "tcp", "ta"):
         con = db(f"{tag}_pmc_{kind}")
         if not con:
             continue
