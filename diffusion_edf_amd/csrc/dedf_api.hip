@@ -93,7 +93,7 @@ struct dedf_handle {
     int scale_start[kMaxScales + 1] = {0};
     bool have_keys = false, have_query = false;
     // device: per call
-    DevBuf d_Ts, d_time, d_tb, d_pose, d_qpos, d_cnt, d_off, d_blk, d_tile, d_esrc, d_edst, d_eout, d_z, d_nout, d_ang, d_lin, d_T64, d_dbgw;
+    DevBuf d_Ts, d_time, d_tb, d_pose, d_qpos, d_cnt, d_off, d_blk, d_tile, d_esrc, d_edst, d_eout, d_z, d_nout, d_ang, d_lin, d_T64, d_dbgw, d_dbge, d_dbgf;
     int64_t edge_cap = 0;
     int last_nT = 0;
     bool debug = false;
@@ -332,13 +332,19 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         P.qx = h->d_qx.as<float>(); P.qw = h->d_qw.as<float>(); P.nQ = nQ; P.n_nodes = Nd; P.lin_mult = c.lin_mult;
         P.W = h->d_node_w.as<float>(); P.W_bytes = (uint32_t)h->d_node_w.bytes;
         const NodeOffsets& o = h->no;
-        for (int l = 0; l < 4; ++l) { P.o_A_proj[l] = o.o_A_proj[l]; P.o_ln_w[l] = o.o_ln_w[l]; P.o_A_f1[l] = o.o_A_f1[l]; P.o_A_f2[l] = o.o_A_f2[l]; }
+        for (int l = 0; l < 4; ++l) {
+            P.o_A_proj[l] = o.o_A_proj[l]; P.o_ln_w[l] = o.o_ln_w[l]; P.o_A_f1[l] = o.o_A_f1[l]; P.o_A_f2[l] = o.o_A_f2[l];
+            P.o_A_proj_l[l] = o.o_A_proj_l[l]; P.o_A_f1_l[l] = o.o_A_f1_l[l]; P.o_A_f2_l[l] = o.o_A_f2_l[l];
+        }
+        P.sc = o.sc;
         P.o_b_proj0 = o.o_b_proj0; P.o_ln_b0 = o.o_ln_b0; P.o_b_f1 = o.o_b_f1; P.o_b_f2 = o.o_b_f2;
         if constexpr (!EBM) for (int t = 0; t < 2; ++t) {
-            for (int p = 0; p < 16; ++p) P.o_A_s[t][p] = o.o_A_s[t][p];
+            for (int p = 0; p < 16; ++p) { P.o_A_s[t][p] = o.o_A_s[t][p]; P.o_A_s_l[t][p] = o.o_A_s_l[t][p]; }
             P.o_A_sl[t][0] = o.o_A_sl[t][0]; P.o_A_sl[t][1] = o.o_A_sl[t][1]; P.o_b_sl[t] = o.o_b_sl[t];
+            P.o_A_sl_l[t][0] = o.o_A_sl_l[t][0]; P.o_A_sl_l[t][1] = o.o_A_sl_l[t][1];
         }
         P.node_out = h->d_nout.as<float>();
+        if (h->debug && h->d_dbge.ensure((size_t)Nd * D * 4) && h->d_dbgf.ensure((size_t)Nd * D * 4)) { P.dbg_emb = h->d_dbge.as<float>(); P.dbg_field = h->d_dbgf.as<float>(); }
         const int ntiles = (Nd + 31) / 32;
         hipLaunchKernelGGL((k_node<L, EBM>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
     }
@@ -643,6 +649,8 @@ int dedf_debug_copy(dedf_handle* h, const char* name, void* host_dst, size_t max
     else if (nm == "edge_out") { src = h->d_eout.p; n = E * REC * 4; }
     else if (nm == "z") { src = h->d_z.p; n = Nd * D * 4; }
     else if (nm == "node_out") { src = h->d_nout.p; n = Nd * 8 * 4; }
+    else if (nm == "emb") { src = h->d_dbge.p; n = h->d_dbge.p ? Nd * D * 4 : 0; }
+    else if (nm == "field") { src = h->d_dbgf.p; n = h->d_dbgf.p ? Nd * D * 4 : 0; }
     else if (nm == "tile_info") { src = h->d_tile.p; n = 64 * 4; }
     else if (nm == "dbg_w") { src = h->d_dbgw.p; n = h->d_dbgw.p ? E * WN * 4 : 0; }
     else if (nm == "phase_prof") { src = h->d_phase.p; n = h->d_phase.bytes; }

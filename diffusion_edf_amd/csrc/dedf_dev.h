@@ -194,9 +194,18 @@ DEDF_DEV f32x16 mfma_h(h8 a, h8 b, f32x16 c) {
 #endif
 }
 // x = hi + lo with hi = fp16(x), lo = fp16(x - hi): |x - hi - lo| <= 2^-22 |x| (or the fp16 subnormal step 6e-8)
+// The hi half is made opaque before the residual is formed: hipcc otherwise re-derives fp16(x) a second way for the
+// subtraction (v_fma_mix*_f16 beside v_cvt_pk_f16_f32) and the two do not always round alike, which breaks hi + lo == x
+// by an fp16 ulp (seen as 1e-3-level errors that came and went with unrelated code changes).
 DEDF_DEV HL split8(const float (&x)[8]) {
     HL r;
-    static_for<8>([&]<int J>() { const _Float16 h = (_Float16)x[J]; r.hi[J] = h; r.lo[J] = (_Float16)(x[J] - (float)h); });
+    static_for<8>([&]<int J>() { r.hi[J] = (_Float16)x[J]; });
+#if defined(__HIP_DEVICE_COMPILE__)
+    f32x4 hb = __builtin_bit_cast(f32x4, r.hi);
+    asm volatile("" : "+v"(hb));
+    r.hi = __builtin_bit_cast(h8, hb);
+#endif
+    static_for<8>([&]<int J>() { r.lo[J] = (_Float16)(x[J] - (float)r.hi[J]); });
     return r;
 }
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -258,6 +267,61 @@ DEDF_DEV void dense_rot_h(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[NT
         static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, ch[To]), b.hi, acc[To]); });
         static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, ch[To]), b.lo, acc[To]); });
         static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, cl[To]), b.hi, acc[To]); });
+        sched_fence();
+    });
+}
+
+DEDF_DEV HL split8(const float (&x)[8], float scale) {
+    float t[8];
+    static_for<8>([&]<int J>() { t[J] = x[J] * scale; });
+    return split8(t);
+}
+// Same with the B chunks already split:  bh.operator()<chunk>() -> HL
+template <int NTO, int NCH, int PD = 2, class BF>
+DEDF_DEV void dense_rot_hp(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[NTO], BF&& bh) {
+    f32x4 rh[PD][NTO], rl[PD][NTO];
+    sched_fence();
+    static_for<PD>([&]<int k>() { if constexpr (k < NCH) static_for<NTO>([&]<int To>() {
+        rh[k][To] = lda(wv, off_h, NCH, To, k); rl[k][To] = lda(wv, off_l, NCH, To, k); }); });
+    static_for<NCH>([&]<int c>() {
+        f32x4 ch[NTO], cl[NTO];
+        static_for<NTO>([&]<int To>() { ch[To] = rh[c % PD][To]; cl[To] = rl[c % PD][To]; });
+        sched_fence();
+        const HL b = bh.template operator()<c>();
+        if constexpr (c + PD < NCH) {
+            const int lv = tie(wv.lane16, __builtin_bit_cast(f32x4, b.hi)[0]);
+            static_for<NTO>([&]<int To>() {
+                rh[c % PD][To] = bld4(wv.w, lv, (off_h + (To * NCH + c + PD) * 256) * 4);
+                rl[c % PD][To] = bld4(wv.w, lv, (off_l + (To * NCH + c + PD) * 256) * 4);
+            });
+        }
+        static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, ch[To]), b.hi, acc[To]); });
+        static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, ch[To]), b.lo, acc[To]); });
+        static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, cl[To]), b.hi, acc[To]); });
+        sched_fence();
+    });
+}
+// One output tile (To, of a matrix with nCH chunks per tile) applied to NM right-hand sides that share the A operands
+// (e.g. the 2l+1 components of an l-block):   bh.operator()<m, chunk>() -> HL
+template <int NM, int NCH, int PD = 2, class BF>
+DEDF_DEV void dense_shared_hp(const Wave& wv, int off_h, int off_l, int nCH, int To, f32x16 (&acc)[NM], BF&& bh) {
+    f32x4 rh[PD], rl[PD];
+    sched_fence();
+    static_for<PD>([&]<int k>() { if constexpr (k < NCH) {
+        rh[k] = bld4(wv.w, wv.lane16, (off_h + (To * nCH + k) * 256) * 4); rl[k] = bld4(wv.w, wv.lane16, (off_l + (To * nCH + k) * 256) * 4); } });
+    static_for<NCH>([&]<int c>() {
+        const h8 ch = __builtin_bit_cast(h8, rh[c % PD]), cl = __builtin_bit_cast(h8, rl[c % PD]);
+        sched_fence();
+        HL b[NM];
+        static_for<NM>([&]<int m>() { b[m] = bh.template operator()<m, c>(); });
+        if constexpr (c + PD < NCH) {
+            const int lv = tie(wv.lane16, __builtin_bit_cast(f32x4, b[0].hi)[0]);
+            rh[c % PD] = bld4(wv.w, lv, (off_h + (To * nCH + c + PD) * 256) * 4);
+            rl[c % PD] = bld4(wv.w, lv, (off_l + (To * nCH + c + PD) * 256) * 4);
+        }
+        static_for<NM>([&]<int m>() { acc[m] = mfma_h(ch, b[m].hi, acc[m]); });
+        static_for<NM>([&]<int m>() { acc[m] = mfma_h(ch, b[m].lo, acc[m]); });
+        static_for<NM>([&]<int m>() { acc[m] = mfma_h(cl, b[m].hi, acc[m]); });
         sched_fence();
     });
 }

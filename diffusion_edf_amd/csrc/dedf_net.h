@@ -175,6 +175,13 @@ template <int L> DEDF_HD constexpr int stp_group_index(int p, int gu) {
     for (int q = 0; q < p; ++q) if (stp_path<L>(q).l3 == l3) n += stp_path<L>(q).mul1 / 8;
     return n + gu;
 }
+// chunk index (16 channels each) of (path p, chunk cu) among the chunks feeding l3, walking paths in creation order
+template <int L> DEDF_HD constexpr int stp_chunk_index(int p, int cu) {
+    const int l3 = stp_path<L>(p).l3;
+    int n = 0;
+    for (int q = 0; q < p; ++q) if (stp_path<L>(q).l3 == l3) n += stp_path<L>(q).mul1 / 16;
+    return n + cu;
+}
 template <int L> inline std::vector<KStep> stp_steps(int l3) {
     std::vector<KStep> s;
     for (int p = 0; p < stp_num_paths<L>(); ++p) {
@@ -205,6 +212,10 @@ DEDF_HD constexpr int gate_row(int l, int c) { int r = mul_of(0); for (int i = 1
 template <int L> DEDF_HD constexpr int edge_rec() { return feat_dim<L>() + kHeads; }                   // 244 / 164
 
 // ---- FFN row spaces (node kernel) ------------------------------------------------------------------------------------
+// accumulator -> true value of the node kernel's split-fp16 GEMMs (each weight matrix carries its own power-of-two scale,
+// the B operands a fixed 2^kNodeBShift; dedf_pack.h::pack_node)
+struct NodeScales { float proj[4], f1[4], f2[4], s[2][16], sl[2][2]; };
+constexpr int kNodeBShift = 8;
 constexpr int kMlpMid = 3;
 template <int L> DEDF_HD constexpr int f1_rows0() { int r = kMlpMid * mul_of(0); for (int l = 1; l <= L; ++l) r += kMlpMid * mul_of(l); return r; }  // 336 / 288
 DEDF_HD constexpr int f1_gate_row(int l, int c) { int r = kMlpMid * mul_of(0); for (int i = 1; i < l; ++i) r += kMlpMid * mul_of(i); return r + c; }

@@ -31,7 +31,11 @@ struct NodeParams {
     int o_A_s[2][16];                          // [tp][path]  W_p (rows u, K = v)
     int o_A_sl[2][2];                          // [tp][l3]    final LinearRS (l3 = 0: the 32 gate rows; l3 = 1: 32 rows)
     int o_b_sl[2];                             // [tp]        gate bias rows
+    int o_A_proj_l[4], o_A_f1_l[4], o_A_f2_l[4], o_A_s_l[2][16], o_A_sl_l[2][2];     // residual (lo) images of the split-fp16 operands
+    NodeScales sc;                             // accumulator -> true value, per matrix
     float* node_out;                           // [N_d][8]: w*lin_vel (3), w*(ang_orbital + ang_spin) (3), 0, 0
+    float* dbg_emb;                            // optional [N_d][D] dumps (internal layout) of the proj output and of the field (tests)
+    float* dbg_field;
 };
 
 template <int L> struct Feat {                 // one node's features in row layout: row = channel
@@ -39,11 +43,17 @@ template <int L> struct Feat {                 // one node's features in row lay
     float v1[3][16];                           // 32x1e, [m][reg]
     float v2[5][8];                            // 16x2e, [m][reg]
 };
-// B operand for K-group g (4 regs) of block l, component m
-template <int L, int l, int m, int g, int j> DEDF_DEV float feat_b(const Feat<L>& f) {
-    if constexpr (l == 0) return f.s[g / 4][4 * (g % 4) + j];
-    else if constexpr (l == 1) return f.v1[m][4 * g + j];
-    else return f.v2[m][4 * g + j];
+// the same features as split-fp16 B operands: chunks of 16 channels (8 registers of a row-layout tile), scaled by 2^kNodeBShift
+template <int L> struct FeatH { HL s[4], v1[3][2], v2[5][1]; };
+template <int L> DEDF_DEV FeatH<L> split_feat(const Feat<L>& f) {
+    constexpr float sc = (float)(1 << kNodeBShift);
+    FeatH<L> o;
+    static_for<4>([&]<int c>() { float t[8]; static_for<8>([&]<int J>() { t[J] = f.s[c / 2][8 * (c % 2) + J]; }); o.s[c] = split8(t, sc); });
+    if constexpr (L >= 1) static_for<3>([&]<int m>() { static_for<2>([&]<int c>() {
+        float t[8]; static_for<8>([&]<int J>() { t[J] = f.v1[m][8 * c + J]; }); o.v1[m][c] = split8(t, sc); }); });
+    if constexpr (L >= 2) static_for<5>([&]<int m>() {
+        float t[8]; static_for<8>([&]<int J>() { t[J] = f.v2[m][J]; }); o.v2[m][0] = split8(t, sc); });
+    return o;
 }
 
 template <int L, bool EBM>
@@ -54,15 +64,18 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     struct Off {
         int A_proj[L + 1], b_proj0, ln_w[L + 1], ln_b0, A_f1[L + 1], b_f1, A_f2[L + 1], b_f2;
         int A_s[2][stp_num_paths<L>()], A_sl[2][2], b_sl[2];
+        int A_proj_l[L + 1], A_f1_l[L + 1], A_f2_l[L + 1], A_s_l[2][stp_num_paths<L>()], A_sl_l[2][2];
     } O;
     static_for<L + 1>([&]<int l>() {
         O.A_proj[l] = opaque_s(P.o_A_proj[l]); O.ln_w[l] = opaque_s(P.o_ln_w[l]);
         O.A_f1[l] = opaque_s(P.o_A_f1[l]); O.A_f2[l] = opaque_s(P.o_A_f2[l]);
+        O.A_proj_l[l] = opaque_s(P.o_A_proj_l[l]); O.A_f1_l[l] = opaque_s(P.o_A_f1_l[l]); O.A_f2_l[l] = opaque_s(P.o_A_f2_l[l]);
     });
     O.b_proj0 = opaque_s(P.o_b_proj0); O.ln_b0 = opaque_s(P.o_ln_b0); O.b_f1 = opaque_s(P.o_b_f1); O.b_f2 = opaque_s(P.o_b_f2);
     if constexpr (!EBM) static_for<2>([&]<int t>() {
-        static_for<stp_num_paths<L>()>([&]<int p>() { O.A_s[t][p] = opaque_s(P.o_A_s[t][p]); });
+        static_for<stp_num_paths<L>()>([&]<int p>() { O.A_s[t][p] = opaque_s(P.o_A_s[t][p]); O.A_s_l[t][p] = opaque_s(P.o_A_s_l[t][p]); });
         O.A_sl[t][0] = opaque_s(P.o_A_sl[t][0]); O.A_sl[t][1] = opaque_s(P.o_A_sl[t][1]); O.b_sl[t] = opaque_s(P.o_b_sl[t]);
+        O.A_sl_l[t][0] = opaque_s(P.o_A_sl_l[t][0]); O.A_sl_l[t][1] = opaque_s(P.o_A_sl_l[t][1]);
     });
     const bool valid = n0 + wv.col < P.n_nodes;
     const int n = valid ? n0 + wv.col : n0;
@@ -87,19 +100,27 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         }); });
     }
 
-    // ---- proj: per-l dense matrix (+ bias on 0e) ---------------------------------------------------------------------------
+    // ---- proj: per-l dense matrix (+ bias on 0e); all GEMMs of this kernel are 3-term split-fp16 MFMA products -----------------
     Feat<L> emb;
-    static_for<2>([&]<int To>() { emb.s[To] = ldrows(wv, O.b_proj0, To); });
-    dense_rot<2, 8>(wv, O.A_proj[0], emb.s, [&]<int kg, int j>() { return z.s[kg / 4][4 * (kg % 4) + j]; });
-    if constexpr (L >= 1) {
-        f32x16 a[3] = {{0}, {0}, {0}};
-        dense_shared<3, 4>(wv, O.A_proj[1], 4, 0, 0, a, [&]<int m, int kg, int j>() { return z.v1[m][4 * kg + j]; });
-        static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { emb.v1[m][R] = a[m][R]; }); });
-    }
-    if constexpr (L >= 2) {
-        f32x16 a[5] = {{0}, {0}, {0}, {0}, {0}};
-        dense_shared<5, 2>(wv, O.A_proj[2], 2, 0, 0, a, [&]<int m, int kg, int j>() { return z.v2[m][4 * kg + j]; });
-        static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { emb.v2[m][R] = a[m][R]; }); });
+    {
+        const FeatH<L> zh = split_feat<L>(z);
+        f32x16 a0[2];
+        static_for<2>([&]<int To>() { a0[To] = ldrows(wv, O.b_proj0, To); });
+        dense_rot_hp<2, 4>(wv, O.A_proj[0], O.A_proj_l[0], a0, [&]<int c>() { return zh.s[c]; });
+        const float c0 = opaque_s(P.sc.proj[0]);
+        static_for<2>([&]<int To>() { static_for<16>([&]<int R>() { emb.s[To][R] = a0[To][R] * c0; }); });
+        if constexpr (L >= 1) {
+            f32x16 a[3] = {{0}, {0}, {0}};
+            dense_shared_hp<3, 2>(wv, O.A_proj[1], O.A_proj_l[1], 2, 0, a, [&]<int m, int c>() { return zh.v1[m][c]; });
+            const float c1 = opaque_s(P.sc.proj[1]);
+            static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { emb.v1[m][R] = a[m][R] * c1; }); });
+        }
+        if constexpr (L >= 2) {
+            f32x16 a[5] = {{0}, {0}, {0}, {0}, {0}};
+            dense_shared_hp<5, 1>(wv, O.A_proj[2], O.A_proj_l[2], 1, 0, a, [&]<int m, int c>() { return zh.v2[m][c]; });
+            const float c2 = opaque_s(P.sc.proj[2]);
+            static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { emb.v2[m][R] = a[m][R] * c2; }); });
+        }
     }
 
     // ---- EquivariantLayerNormV2 (equiformer/layer_norm.py:91-156) ----------------------------------------------------------
@@ -138,50 +159,85 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     // ---- FFN: FCTP+SwishGate (D -> 336x0e+96x1e+48x2e) -> Gate -> FCTP (-> D), + residual (gnn_block.py:51-57, 210-216) ----
     Feat<L> fld;
     constexpr int NF1 = f1_rows0<L>() / 32 + (f1_rows0<L>() % 32 ? 1 : 0);     // 11 (L=2) / 9 (L=1) tiles of fctp_1's 0e rows
+    constexpr float kBS = (float)(1 << kNodeBShift);
+    const FeatH<L> nh = split_feat<L>(nrm);
     {   // l = 0: 192 hidden scalars (6 tiles) -> SiLU -> fctp_2
         f32x16 hs[6];
         static_for<6>([&]<int To>() { hs[To] = ldrows(wv, O.b_f1, To); });
-        dense_rot<6, 8>(wv, O.A_f1[0], hs, [&]<int kg, int j>() { return nrm.s[kg / 4][4 * (kg % 4) + j]; });
-        static_for<6>([&]<int To>() { static_for<16>([&]<int R>() { hs[To][R] = silu_n(hs[To][R]); }); });
+        dense_rot_hp<6, 4>(wv, O.A_f1[0], O.A_f1_l[0], hs, [&]<int c>() { return nh.s[c]; });
+        const float c1 = opaque_s(P.sc.f1[0]);
+        static_for<6>([&]<int To>() { static_for<16>([&]<int R>() { hs[To][R] = silu_n(hs[To][R] * c1); }); });
         f32x16 o0[2];
         static_for<2>([&]<int T>() { o0[T] = ldrows(wv, O.b_f2, T); });
-        dense_rot<2, 24>(wv, O.A_f2[0], o0, [&]<int kg, int j>() { return hs[kg / 4][4 * (kg % 4) + j]; });
-        static_for<2>([&]<int T>() { static_for<16>([&]<int R>() { fld.s[T][R] = o0[T][R] + emb.s[T][R]; }); });
+        dense_rot_hp<2, 12>(wv, O.A_f2[0], O.A_f2_l[0], o0, [&]<int c>() {
+            float t[8];
+            static_for<8>([&]<int J>() { t[J] = hs[c / 2][8 * (c % 2) + J]; });
+            return split8(t, kBS);
+        });
+        const float c2 = opaque_s(P.sc.f2[0]);
+        static_for<2>([&]<int T>() { static_for<16>([&]<int R>() { fld.s[T][R] = o0[T][R] * c2 + emb.s[T][R]; }); });
     }
     // gate rows of fctp_1 (tiles 6 .. NF1-1 of the 0e row space): 96 gates for the 1e hidden, 48 for the 2e hidden
     constexpr int NGT = NF1 - 6;
     f32x16 gt[NGT];
     static_for<NGT>([&]<int t>() { gt[t] = ldrows(wv, O.b_f1, 6 + t); });
     {
-        // dense_rot walks tiles 0..NTO-1 of one matrix; the gate tiles start at tile 6 -> shift the matrix offset
-        const int off = O.A_f1[0] + 6 * 8 * 256;
-        dense_rot<NGT, 8>(wv, off, gt, [&]<int kg, int j>() { return nrm.s[kg / 4][4 * (kg % 4) + j]; });
-        static_for<NGT>([&]<int t>() { static_for<16>([&]<int R>() { gt[t][R] = sigmoid_n(gt[t][R]); }); });
+        // the gate tiles start at tile 6 of the same matrix (4 chunks per tile) -> shift the image offsets
+        dense_rot_hp<NGT, 4>(wv, O.A_f1[0] + 6 * 4 * 256, O.A_f1_l[0] + 6 * 4 * 256, gt, [&]<int c>() { return nh.s[c]; });
+        const float c1 = opaque_s(P.sc.f1[0]);
+        static_for<NGT>([&]<int t>() { static_for<16>([&]<int R>() { gt[t][R] = sigmoid_n(gt[t][R] * c1); }); });
     }
     if constexpr (L >= 1) {   // l = 1: hidden 96x1e (3 tiles) per component, gated, then fctp_2 (K = 96) shared over the 3 components
         f32x16 hh[3][3];      // [tile][m]
+        const float c1 = opaque_s(P.sc.f1[1]);
         static_for<3>([&]<int t>() {
             static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] = 0.0f; }); });
-            dense_shared<3, 4>(wv, O.A_f1[1], 4, t, 0, hh[t], [&]<int m, int kg, int j>() { return nrm.v1[m][4 * kg + j]; });
-            static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] *= gt[t][R]; }); });
+            dense_shared_hp<3, 2>(wv, O.A_f1[1], O.A_f1_l[1], 2, t, hh[t], [&]<int m, int c>() { return nh.v1[m][c]; });
+            static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] *= gt[t][R] * c1; }); });
         });
         f32x16 o[3] = {{0}, {0}, {0}};
-        dense_shared<3, 12>(wv, O.A_f2[1], 12, 0, 0, o, [&]<int m, int kg, int j>() { return hh[kg / 4][m][4 * (kg % 4) + j]; });
-        static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { fld.v1[m][R] = o[m][R] + emb.v1[m][R]; }); });
+        dense_shared_hp<3, 6>(wv, O.A_f2[1], O.A_f2_l[1], 6, 0, o, [&]<int m, int c>() {
+            float t[8];
+            static_for<8>([&]<int J>() { t[J] = hh[c / 2][m][8 * (c % 2) + J]; });
+            return split8(t, kBS);
+        });
+        const float c2 = opaque_s(P.sc.f2[1]);
+        static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { fld.v1[m][R] = o[m][R] * c2 + emb.v1[m][R]; }); });
     }
     if constexpr (L >= 2) {   // l = 2: hidden 48x2e (tile 0 full, tile 1 rows 0..15); gates = 0e rows 288..335 (gate tile 3, tile 4 low half)
         f32x16 hh[2][5];
+        const float c1 = opaque_s(P.sc.f1[2]);
         static_for<2>([&]<int t>() {
             static_for<5>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] = 0.0f; }); });
-            dense_shared<5, 2>(wv, O.A_f1[2], 2, t, 0, hh[t], [&]<int m, int kg, int j>() { return nrm.v2[m][4 * kg + j]; });
-            static_for<5>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] *= gt[3 + t][R]; }); });
+            dense_shared_hp<5, 1>(wv, O.A_f1[2], O.A_f1_l[2], 1, t, hh[t], [&]<int m, int c>() { return nh.v2[m][c]; });
+            static_for<5>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] *= gt[3 + t][R] * c1; }); });
         });
         f32x16 o[5] = {{0}, {0}, {0}, {0}, {0}};
-        // K = 48: groups 0..3 read hidden tile 0, groups 4..5 the valid half of tile 1
-        dense_shared<5, 6>(wv, O.A_f2[2], 6, 0, 0, o, [&]<int m, int kg, int j>() { return hh[kg / 4][m][4 * (kg % 4) + j]; });
-        static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { fld.v2[m][R] = o[m][R] + emb.v2[m][R]; }); });
+        // K = 48: chunks 0, 1 read hidden tile 0, chunk 2 the valid half of tile 1
+        dense_shared_hp<5, 3>(wv, O.A_f2[2], O.A_f2_l[2], 3, 0, o, [&]<int m, int c>() {
+            float t[8];
+            static_for<8>([&]<int J>() { t[J] = hh[c / 2][m][8 * (c % 2) + J]; });
+            return split8(t, kBS);
+        });
+        const float c2 = opaque_s(P.sc.f2[2]);
+        static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { fld.v2[m][R] = o[m][R] * c2 + emb.v2[m][R]; }); });
     }
     sched_fence();
+    // (keep this block: besides serving the stage tests it separates the FFN tail from the score stage -- ROCm 7.2 hipcc was
+    //  observed to produce a wrong lmax = 2 score stage when the two end up in one basic block)
+    if (P.dbg_field != nullptr && valid) {
+        auto dump = [&](float* base, const Feat<L>& f) {
+            float* o = base + (size_t)n * D + hi * 4;
+            static_for<2>([&]<int T>() { static_for<4>([&]<int g>() {
+                st4(o + T * 32 + 8 * g, f32x4{f.s[T][4 * g], f.s[T][4 * g + 1], f.s[T][4 * g + 2], f.s[T][4 * g + 3]}); }); });
+            if constexpr (L >= 1) static_for<3>([&]<int m>() { static_for<4>([&]<int g>() {
+                st4(o + blk_off(1) + m * 32 + 8 * g, f32x4{f.v1[m][4 * g], f.v1[m][4 * g + 1], f.v1[m][4 * g + 2], f.v1[m][4 * g + 3]}); }); });
+            if constexpr (L >= 2) static_for<5>([&]<int m>() { static_for<2>([&]<int g>() {
+                st4(o + blk_off(2) + m * 16 + 8 * g, f32x4{f.v2[m][4 * g], f.v2[m][4 * g + 1], f.v2[m][4 * g + 2], f.v2[m][4 * g + 3]}); }); });
+        };
+        dump(P.dbg_emb, emb);
+        dump(P.dbg_field, fld);
+    }
 
     // ---- score tensor products ------------------------------------------------------------------------------------------------
     const Buf qfb = make_buf(P.qf, P.qf_bytes);
@@ -239,6 +295,23 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         return;
     }
     float res[2][3];                         // per TP: mean over the 32 gated 1e channels
+    // the field as split-fp16 B operands, shared by every path of both tensor products: parked in LDS (this wave's 30 KB,
+    // slot = one h8 per lane) so that the 120 registers are free for the accumulators of the tensor products
+    constexpr int FS1 = 8, FS2 = FS1 + 12;
+    __shared__ f32x4 fpark[(FS2 + 10) * 64];
+    f32x4* const fp = fpark + wv.lane;
+    {
+        const FeatH<L> fh = split_feat<L>(fld);
+        static_for<4>([&]<int c>() { fp[(2 * c) * 64] = __builtin_bit_cast(f32x4, fh.s[c].hi); fp[(2 * c + 1) * 64] = __builtin_bit_cast(f32x4, fh.s[c].lo); });
+        if constexpr (L >= 1) static_for<3>([&]<int m>() { static_for<2>([&]<int c>() {
+            fp[(FS1 + 4 * m + 2 * c) * 64] = __builtin_bit_cast(f32x4, fh.v1[m][c].hi);
+            fp[(FS1 + 4 * m + 2 * c + 1) * 64] = __builtin_bit_cast(f32x4, fh.v1[m][c].lo);
+        }); });
+        if constexpr (L >= 2) static_for<5>([&]<int m>() {
+            fp[(FS2 + 2 * m) * 64] = __builtin_bit_cast(f32x4, fh.v2[m][0].hi);
+            fp[(FS2 + 2 * m + 1) * 64] = __builtin_bit_cast(f32x4, fh.v2[m][0].lo);
+        });
+    }
     static_for<2>([&]<int tp>() {
         f32x16 gacc = ldrows(wv, O.b_sl[tp], 0);
         f32x16 vacc[3];
@@ -247,57 +320,76 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
             constexpr PathInfo pi = stp_path<L>(p);
             constexpr int l1 = pi.l1, l2 = pi.l2, l3 = pi.l3;
             constexpr int d1 = 2 * l1 + 1, d2 = 2 * l2 + 1, d3 = 2 * l3 + 1;
-            constexpr int NGK = pi.mul2 / 8;              // K groups over v
+            constexpr int NCK = pi.mul2 / 16;             // K chunks over v
+            constexpr int NCL = stp_k<L>(l3) / 16;        // chunks per row tile of the final LinearRS image
             using C = CG<l1, l2, l3>;
+            const float bsc = opaque_s(P.sc.s[tp][p]) * kBS;      // T accumulators -> true value, times the B-operand scale of stage 2
             static_for<cdiv(pi.mul1, 32)>([&]<int To>() {
+                constexpr int NC2 = imin(2, (pi.mul1 - 32 * To) / 16);      // 16-channel chunks of this row tile
+                // operands of the final LinearRS for this tile's chunks, requested before the first-stage GEMM
+                f32x4 slh[NC2], sll[NC2];
+                static_for<NC2>([&]<int cc>() {
+                    constexpr int ci = stp_chunk_index<L>(p, 2 * To + cc);
+                    slh[cc] = bld4(wv.w, wv.lane16, (O.A_sl[tp][l3] + ci * 256) * 4);
+                    sll[cc] = bld4(wv.w, wv.lane16, (O.A_sl_l[tp][l3] + ci * 256) * 4);
+                });
                 f32x16 T[d2];
                 static_for<d2>([&]<int j>() { static_for<16>([&]<int R>() { T[j][R] = 0.0f; }); });
-                dense_shared<d2, NGK>(wv, O.A_s[tp][p], NGK, To, 0, T, [&]<int j, int kg, int jj>() {
-                    if constexpr (l2 == 0) return fld.s[kg / 4][4 * (kg % 4) + jj];
-                    else if constexpr (l2 == 1) return fld.v1[j][4 * kg + jj];
-                    else return fld.v2[j][4 * kg + jj];
+                dense_shared_hp<d2, NCK>(wv, O.A_s[tp][p], O.A_s_l[tp][p], NCK, To, T, [&]<int j, int c>() {
+                    constexpr int slot = l2 == 0 ? 2 * c : (l2 == 1 ? FS1 + 4 * j + 2 * c : FS2 + 2 * j);
+                    HL b;
+                    b.hi = __builtin_bit_cast(h8, fp[slot * 64]);
+                    b.lo = __builtin_bit_cast(h8, fp[(slot + 1) * 64]);
+                    return b;
                 });
-                static_for<imin(4, (pi.mul1 - 32 * To) / 8)>([&]<int g>() {
-                    constexpr int u0 = 32 * To + 8 * g;
-                    constexpr int gi = stp_group_index<L>(p, u0 / 8);
-                    // query feature rows u0 + 4 hi + j (reference layout), rotated by D^{l1}(q)
-                    float xr[4 * d1];
-                    const int qv = l1 == 0 ? qv0 : (l1 == 1 ? qv1 : qv2);
-                    static_for<d1>([&]<int Q>() {
-                        const f32x4 t = bld4(qfb, qv, (blk_off(l1) + u0 * d1 + 4 * Q) * 4);
-                        xr[4 * Q] = t[0]; xr[4 * Q + 1] = t[1]; xr[4 * Q + 2] = t[2]; xr[4 * Q + 3] = t[3];
+                static_for<NC2>([&]<int cc>() {
+                    constexpr int u0 = 32 * To + 16 * cc;
+                    float a[d3][8];
+                    static_for<2>([&]<int run>() {
+                        // query feature rows u0 + 8 run + 4 hi + j (reference layout), rotated by D^{l1}(q)
+                        float xr[4 * d1];
+                        const int qv = l1 == 0 ? qv0 : (l1 == 1 ? qv1 : qv2);
+                        static_for<d1>([&]<int Q>() {
+                            const f32x4 t = bld4(qfb, qv, (blk_off(l1) + (u0 + 8 * run) * d1 + 4 * Q) * 4);
+                            xr[4 * Q] = t[0]; xr[4 * Q + 1] = t[1]; xr[4 * Q + 2] = t[2]; xr[4 * Q + 3] = t[3];
+                        });
+                        static_for<4>([&]<int j>() {
+                            float x[d1], y[d2], m[C::NM], o[d3];
+                            if constexpr (l1 == 0) x[0] = xr[j];
+                            else if constexpr (l1 == 1) static_for<3>([&]<int I>() {
+                                x[I] = D1[3 * I] * xr[3 * j] + D1[3 * I + 1] * xr[3 * j + 1] + D1[3 * I + 2] * xr[3 * j + 2]; });
+                            else static_for<5>([&]<int I>() {
+                                x[I] = D2[5 * I] * xr[5 * j] + D2[5 * I + 1] * xr[5 * j + 1] + D2[5 * I + 2] * xr[5 * j + 2] +
+                                       D2[5 * I + 3] * xr[5 * j + 3] + D2[5 * I + 4] * xr[5 * j + 4]; });
+                            static_for<d2>([&]<int J>() { y[J] = T[J][8 * cc + 4 * run + j]; });
+                            C::make(y, m);
+                            C::apply(x, m, o);
+                            static_for<d3>([&]<int K>() { a[K][4 * run + j] = o[K]; });
+                        });
                     });
-                    float a[4][d3];
-                    static_for<4>([&]<int j>() {
-                        float x[d1], y[d2], m[C::NM], o[d3];
-                        if constexpr (l1 == 0) x[0] = xr[j];
-                        else if constexpr (l1 == 1) static_for<3>([&]<int I>() {
-                            x[I] = D1[3 * I] * xr[3 * j] + D1[3 * I + 1] * xr[3 * j + 1] + D1[3 * I + 2] * xr[3 * j + 2]; });
-                        else static_for<5>([&]<int I>() {
-                            x[I] = D2[5 * I] * xr[5 * j] + D2[5 * I + 1] * xr[5 * j + 1] + D2[5 * I + 2] * xr[5 * j + 2] +
-                                   D2[5 * I + 3] * xr[5 * j + 3] + D2[5 * I + 4] * xr[5 * j + 4]; });
-                        static_for<d2>([&]<int J>() { y[J] = T[J][4 * g + j]; });
-                        C::make(y, m);
-                        C::apply(x, m, o);
-                        static_for<d3>([&]<int K>() { a[j][K] = o[K]; });
-                    });
-                    constexpr int NG = stp_k<L>(l3) / 8;
+                    const h8 ah = __builtin_bit_cast(h8, slh[cc]), al = __builtin_bit_cast(h8, sll[cc]);
                     if constexpr (l3 == 0) {
-                        mfma_group(gacc, lda(wv, O.A_sl[tp][0], NG, 0, gi), a[0][0], a[1][0], a[2][0], a[3][0]);
+                        const HL b = split8(a[0], bsc);
+                        gacc = mfma_h(ah, b.hi, gacc); gacc = mfma_h(ah, b.lo, gacc); gacc = mfma_h(al, b.hi, gacc);
                     } else {
-                        const f32x4 av = lda(wv, O.A_sl[tp][1], NG, 0, gi);
-                        static_for<3>([&]<int K>() { mfma_group(vacc[K], av, a[0][K], a[1][K], a[2][K], a[3][K]); });
+                        HL b[3];
+                        static_for<3>([&]<int K>() { b[K] = split8(a[K], bsc); });
+                        static_for<3>([&]<int K>() { vacc[K] = mfma_h(ah, b[K].hi, vacc[K]); });
+                        static_for<3>([&]<int K>() { vacc[K] = mfma_h(ah, b[K].lo, vacc[K]); });
+                        static_for<3>([&]<int K>() { vacc[K] = mfma_h(al, b[K].hi, vacc[K]); });
                     }
                 });
+                (void)NCL;
                 sched_fence();
             });
         });
         // Gate (sigmoid on the 32 gates) and mean over the 32 1e channels (score_head.py:196-199)
+        const float cg = opaque_s(P.sc.sl[tp][0]), cvv = opaque_s(P.sc.sl[tp][1]) * (1.0f / 32);
         static_for<3>([&]<int K>() {
             float s = 0.0f;
-            static_for<16>([&]<int R>() { s += vacc[K][R] * sigmoid_n(gacc[R]); });
+            static_for<16>([&]<int R>() { s += vacc[K][R] * sigmoid_n(gacc[R] * cg); });
             s += xor32(s);
-            res[tp][K] = s * (1.0f / 32);
+            res[tp][K] = s * cvv;
         });
     });
 

@@ -114,6 +114,8 @@ struct EdgeOffsets {
 struct NodeOffsets {
     int o_A_proj[4], o_b_proj0, o_ln_w[4], o_ln_b0, o_A_f1[4], o_b_f1, o_A_f2[4], o_b_f2;
     int o_A_s[2][16], o_A_sl[2][2], o_b_sl[2];
+    int o_A_proj_l[4], o_A_f1_l[4], o_A_f2_l[4], o_A_s_l[2][16], o_A_sl_l[2][2];     // residual (lo) images
+    NodeScales sc;
 };
 
 inline float softplusf(float x) { return x > 20.0f ? x : std::log1p(std::exp(x)); }
@@ -291,28 +293,45 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
 
 template <int L>
 inline void pack_node(const dedf_config& c, const ParamSpec& S, const float* B, Image& im, NodeOffsets& o) {
+    // Every GEMM of the node kernel runs on split-fp16 MFMAs: hi / lo images (dedf_layout.h::pack_A_h), each matrix scaled by
+    // its own power of two (pow2_scale); biases carry the matrix scale times the fixed B-operand scale 2^kNodeBShift.
     const std::string blk = "key_tensor_field.gnn_block_init", ga = blk + ".ga";
-    auto rows = [&](int O, const float* v) { return pack_rows(O, [&](int i) { return v[i]; }); };
     const float* pw = S.get(B, ga + ".proj.tp.weight");
     const float* lnw = S.get(B, blk + ".post_norm.affine_weight");
     const float* f1w = S.get(B, blk + ".ffn.fctp_1.tp.weight");
     const float* f2w = S.get(B, blk + ".ffn.fctp_2.tp.weight");
+    // pack one matrix (O rows, K columns fed by a producer's accumulator tiles); returns its power-of-two exponent
+    auto push_h = [&](int O, int K, auto W, int& off_h, int& off_l) {
+        float mx = 0.0f;
+        for (int oo = 0; oo < O; ++oo) for (int k = 0; k < K; ++k) mx = std::fmax(mx, std::fabs(W(oo, k)));
+        const int sh = pow2_scale(mx, 0, 20);
+        std::vector<float> ih, il;
+        pack_A_h(O, cdiv(K, 16), [&](int oo, int k) { return std::ldexp(W(oo, k), sh); }, [&](int cc, int j, int h) { return chain_k(K, cc, j, h); }, ih, il);
+        off_h = im.push(ih); off_l = im.push(il);
+        return sh;
+    };
+    int s_proj0 = 0, s_f10 = 0, s_f20 = 0;
     size_t po = 0, lo = 0, f1o = 0, f2o = 0;
     for (int l = 0; l <= L; ++l) {
         const int m = mul_of(l), O1 = (l == 0 ? f1_rows0<L>() : kMlpMid * m), Kh = kMlpMid * m;
         const float* Wp = pw + po;
-        o.o_A_proj[l] = im.push(pack_A(m, chain_steps(m), [&](int oo, int k) { return Wp[k * m + oo]; }));
+        const int sp = push_h(m, m, [&](int oo, int k) { return Wp[k * m + oo]; }, o.o_A_proj[l], o.o_A_proj_l[l]);
         o.o_ln_w[l] = im.push(pack_rows(m, [&](int i) { return lnw[lo + i]; }));
         const float* W1 = f1w + f1o;
-        o.o_A_f1[l] = im.push(pack_A(O1, chain_steps(m), [&](int oo, int k) { return W1[k * O1 + oo]; }));
+        const int s1 = push_h(O1, m, [&](int oo, int k) { return W1[k * O1 + oo]; }, o.o_A_f1[l], o.o_A_f1_l[l]);
         const float* W2 = f2w + f2o;
-        o.o_A_f2[l] = im.push(pack_A(m, chain_steps(Kh), [&](int oo, int k) { return W2[k * m + oo]; }));
+        const int s2 = push_h(m, Kh, [&](int oo, int k) { return W2[k * m + oo]; }, o.o_A_f2[l], o.o_A_f2_l[l]);
+        o.sc.proj[l] = std::ldexp(1.0f, -(sp + kNodeBShift));
+        o.sc.f1[l] = std::ldexp(1.0f, -(s1 + kNodeBShift));
+        o.sc.f2[l] = std::ldexp(1.0f, -(s2 + kNodeBShift));
+        if (l == 0) { s_proj0 = sp; s_f10 = s1; s_f20 = s2; }
         po += (size_t)m * m; lo += m; f1o += (size_t)m * O1; f2o += (size_t)Kh * m;
     }
-    o.o_b_proj0 = im.push(rows(mul_of(0), S.get(B, ga + ".proj.bias.0")));
-    o.o_ln_b0 = im.push(rows(mul_of(0), S.get(B, blk + ".post_norm.affine_bias")));
-    o.o_b_f1 = im.push(rows(f1_rows0<L>(), S.get(B, blk + ".ffn.fctp_1.bias.0")));
-    o.o_b_f2 = im.push(rows(mul_of(0), S.get(B, blk + ".ffn.fctp_2.bias.0")));
+    auto rows_s = [&](int O, const float* v, int sh) { return pack_rows(O, [&](int i) { return std::ldexp(v[i], sh); }); };
+    o.o_b_proj0 = im.push(rows_s(mul_of(0), S.get(B, ga + ".proj.bias.0"), s_proj0 + kNodeBShift));
+    o.o_ln_b0 = im.push(rows_s(mul_of(0), S.get(B, blk + ".post_norm.affine_bias"), 0));
+    o.o_b_f1 = im.push(rows_s(f1_rows0<L>(), S.get(B, blk + ".ffn.fctp_1.bias.0"), s_f10 + kNodeBShift));
+    o.o_b_f2 = im.push(rows_s(mul_of(0), S.get(B, blk + ".ffn.fctp_2.bias.0"), s_f20 + kNodeBShift));
     int tp = 0;
     if (!c.ebm) for (const char* nm : {"lin_vel_tp", "ang_vel_tp"}) {
         const std::string p = std::string(nm);
@@ -320,16 +339,32 @@ inline void pack_node(const dedf_config& c, const ParamSpec& S, const float* B, 
         for (int q = 0; q < stp_num_paths<L>(); ++q) {
             const PathInfo pi = stp_path<L>(q);
             const float* W = dw + pi.wstart;
-            o.o_A_s[tp][q] = im.push(pack_A(pi.mul1, chain_steps(pi.mul2), [&](int u, int v) { return W[u * pi.mul2 + v]; }));
+            const int sh = push_h(pi.mul1, pi.mul2, [&](int u, int v) { return W[u * pi.mul2 + v]; }, o.o_A_s[tp][q], o.o_A_s_l[tp][q]);
+            o.sc.s[tp][q] = std::ldexp(1.0f, -(sh + kNodeBShift));
         }
+        // final LinearRS: K walks the 16-channel chunks of the TP output (stp_chunk_index), rows = the 32 gates (l3 = 0) / 32 1e channels
         const float* lw = S.get(B, p + ".lin.tp.weight");
         const int n1 = mul_of(1), O0 = 1 + n1;
-        const float* W0 = lw;
-        const float* W1 = lw + (size_t)stp_k<L>(0) * O0;
-        o.o_A_sl[tp][0] = im.push(pack_A(n1, stp_steps<L>(0), [&](int oo, int k) { return W0[k * O0 + 1 + oo]; }));   // row 0 (the unused 1x0e) is dropped
-        o.o_A_sl[tp][1] = im.push(pack_A(n1, stp_steps<L>(1), [&](int oo, int k) { return W1[k * n1 + oo]; }));
+        const float* Wl[2] = {lw, lw + (size_t)stp_k<L>(0) * O0};
+        int shl[2] = {0, 0};
+        for (int l3 = 0; l3 < 2; ++l3) {
+            std::vector<int> base;                      // first sorted channel of every chunk
+            for (int q = 0; q < stp_num_paths<L>(); ++q) {
+                const PathInfo pi = stp_path<L>(q);
+                if (pi.l3 == l3) for (int cu = 0; cu < pi.mul1 / 16; ++cu) base.push_back(pi.kofs + 16 * cu);
+            }
+            auto Wat = [&](int oo, int k) { return l3 == 0 ? Wl[0][k * O0 + 1 + oo] : Wl[1][k * n1 + oo]; };   // row 0 (the unused 1x0e) is dropped
+            float mx = 0.0f;
+            for (int oo = 0; oo < n1; ++oo) for (int k = 0; k < stp_k<L>(l3); ++k) mx = std::fmax(mx, std::fabs(Wat(oo, k)));
+            shl[l3] = pow2_scale(mx, 0, 20);
+            std::vector<float> ih, il;
+            pack_A_h(n1, (int)base.size(), [&](int oo, int k) { return std::ldexp(Wat(oo, k), shl[l3]); },
+                     [&](int cc, int j, int h) { return base[cc] + chunk_row(8 * h + j); }, ih, il);
+            o.o_A_sl[tp][l3] = im.push(ih); o.o_A_sl_l[tp][l3] = im.push(il);
+            o.sc.sl[tp][l3] = std::ldexp(1.0f, -(shl[l3] + kNodeBShift));
+        }
         const float* lb = S.get(B, p + ".lin.bias.0");
-        o.o_b_sl[tp] = im.push(pack_rows(n1, [&](int i) { return lb[1 + i]; }));
+        o.o_b_sl[tp] = im.push(pack_rows(n1, [&](int i) { return std::ldexp(lb[1 + i], shl[0] + kNodeBShift); }));
         ++tp;
     }
 }

@@ -125,6 +125,13 @@ def stage_report(lmax=2, nT=6, n_scene=512, n_grasp=100, verbose=True, **kwargs)
     z = head.debug_buffer('z').reshape(Nd, D)[:, perm]
     rep['attn'] = rel(z, d64['attn'])
     rep['attn_o32'] = rel(d32['attn'], d64['attn'])
+    for nm in ('emb', 'field'):          # proj output and the field after post-norm + FFN, per irreps block
+        g = head.debug_buffer(nm).reshape(Nd, D)[:, perm]
+        off = 0
+        for l, m in enumerate(muls):
+            nn = m * (2 * l + 1)
+            rep[f'{nm}_l{l}'] = rel(g[:, off:off + nn], d64[nm][:, off:off + nn])
+            off += nn
     no = head.debug_buffer('node_out').reshape(nT, nQ, 8)
     w = query.w.double()
     lin_q = d64['lin_vel_q'] * w[None, :, None]
