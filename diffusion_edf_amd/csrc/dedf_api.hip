@@ -423,6 +423,10 @@ int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, de
         fprintf(stderr, "dedf_create: %s\n", e.what());
         return DEDF_ERR_INVALID;
     }
+    if (!h->no.layout_ok) {
+        fprintf(stderr, "dedf_create: packed node image does not match the compile-time layout (dedf_net.h::kNodeLayout)\n");
+        return DEDF_ERR_RUNTIME;
+    }
     if (!h->host_only) {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device) {

@@ -212,12 +212,50 @@ DEDF_HD constexpr int gate_row(int l, int c) { int r = mul_of(0); for (int i = 1
 template <int L> DEDF_HD constexpr int edge_rec() { return feat_dim<L>() + kHeads; }                   // 244 / 164
 
 // ---- FFN row spaces (node kernel) ------------------------------------------------------------------------------------
+// ---- layout of the node kernel's weight image -------------------------------------------------------------------------------
+// Every block size depends on L only, so the offsets (in floats) are compile-time constants shared by the packer
+// (dedf_pack.h::pack_node, which checks them) and the kernel: no offset ever occupies a scalar register.  (With run-time
+// offsets the fully unrolled score stage kept > 300 scalars alive; hipcc spilled them to VGPR lanes / scratch.)
+template <int L> struct NodeLayout {
+    int A_proj[3], A_proj_l[3], ln_w[3], A_f1[3], A_f1_l[3], A_f2[3], A_f2_l[3];
+    int b_proj0, ln_b0, b_f1, b_f2;
+    int A_s[2][16], A_s_l[2][16], A_sl[2][2], A_sl_l[2][2], b_sl[2];
+    int total;
+};
+template <int L> DEDF_HD constexpr int f1_rows0_fwd();
+template <int L> DEDF_HD constexpr NodeLayout<L> make_node_layout() {
+    NodeLayout<L> n{};
+    int o = 0;
+    auto img = [&](int O, int K) { const int sz = cdiv(O, 32) * cdiv(K, 16) * 256; const int at = o; o += sz; return at; };   // one hi or lo image
+    auto rows = [&](int O) { const int at = o; o += cdiv(O, 32) * 32; return at; };
+    for (int l = 0; l <= L; ++l) {
+        const int m = mul_of(l), O1 = (l == 0 ? f1_rows0_fwd<L>() : 3 * m), Kh = 3 * m;
+        n.A_proj[l] = img(m, m); n.A_proj_l[l] = img(m, m);
+        n.ln_w[l] = rows(m);
+        n.A_f1[l] = img(O1, m); n.A_f1_l[l] = img(O1, m);
+        n.A_f2[l] = img(m, Kh); n.A_f2_l[l] = img(m, Kh);
+    }
+    n.b_proj0 = rows(mul_of(0)); n.ln_b0 = rows(mul_of(0)); n.b_f1 = rows(f1_rows0_fwd<L>()); n.b_f2 = rows(mul_of(0));
+    for (int tp = 0; tp < 2; ++tp) {
+        for (int q = 0; q < stp_num_paths<L>(); ++q) {
+            const PathInfo pi = stp_path<L>(q);
+            n.A_s[tp][q] = img(pi.mul1, pi.mul2); n.A_s_l[tp][q] = img(pi.mul1, pi.mul2);
+        }
+        for (int l3 = 0; l3 < 2; ++l3) { n.A_sl[tp][l3] = img(mul_of(1), stp_k<L>(l3)); n.A_sl_l[tp][l3] = img(mul_of(1), stp_k<L>(l3)); }
+        n.b_sl[tp] = rows(mul_of(1));
+    }
+    n.total = o;
+    return n;
+}
+
 // accumulator -> true value of the node kernel's split-fp16 GEMMs (each weight matrix carries its own power-of-two scale,
 // the B operands a fixed 2^kNodeBShift; dedf_pack.h::pack_node)
 struct NodeScales { float proj[4], f1[4], f2[4], s[2][16], sl[2][2]; };
 constexpr int kNodeBShift = 8;
 constexpr int kMlpMid = 3;
 template <int L> DEDF_HD constexpr int f1_rows0() { int r = kMlpMid * mul_of(0); for (int l = 1; l <= L; ++l) r += kMlpMid * mul_of(l); return r; }  // 336 / 288
+template <int L> DEDF_HD constexpr int f1_rows0_fwd() { return f1_rows0<L>(); }
+template <int L> inline constexpr NodeLayout<L> kNodeLayout = make_node_layout<L>();
 DEDF_HD constexpr int f1_gate_row(int l, int c) { int r = kMlpMid * mul_of(0); for (int i = 1; i < l; ++i) r += kMlpMid * mul_of(i); return r + c; }
 
 // internal feature layout: block l at blk_off(l), stored [m][mul]  (reference stores [mul][m])

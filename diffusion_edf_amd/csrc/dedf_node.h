@@ -60,23 +60,7 @@ template <int L, bool EBM>
 DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     constexpr int D = feat_dim<L>();
     const int hi = wv.hi;
-    // weight-image offsets, re-materialised per tile (see opaque_s)
-    struct Off {
-        int A_proj[L + 1], b_proj0, ln_w[L + 1], ln_b0, A_f1[L + 1], b_f1, A_f2[L + 1], b_f2;
-        int A_s[2][stp_num_paths<L>()], A_sl[2][2], b_sl[2];
-        int A_proj_l[L + 1], A_f1_l[L + 1], A_f2_l[L + 1], A_s_l[2][stp_num_paths<L>()], A_sl_l[2][2];
-    } O;
-    static_for<L + 1>([&]<int l>() {
-        O.A_proj[l] = opaque_s(P.o_A_proj[l]); O.ln_w[l] = opaque_s(P.o_ln_w[l]);
-        O.A_f1[l] = opaque_s(P.o_A_f1[l]); O.A_f2[l] = opaque_s(P.o_A_f2[l]);
-        O.A_proj_l[l] = opaque_s(P.o_A_proj_l[l]); O.A_f1_l[l] = opaque_s(P.o_A_f1_l[l]); O.A_f2_l[l] = opaque_s(P.o_A_f2_l[l]);
-    });
-    O.b_proj0 = opaque_s(P.o_b_proj0); O.ln_b0 = opaque_s(P.o_ln_b0); O.b_f1 = opaque_s(P.o_b_f1); O.b_f2 = opaque_s(P.o_b_f2);
-    if constexpr (!EBM) static_for<2>([&]<int t>() {
-        static_for<stp_num_paths<L>()>([&]<int p>() { O.A_s[t][p] = opaque_s(P.o_A_s[t][p]); O.A_s_l[t][p] = opaque_s(P.o_A_s_l[t][p]); });
-        O.A_sl[t][0] = opaque_s(P.o_A_sl[t][0]); O.A_sl[t][1] = opaque_s(P.o_A_sl[t][1]); O.b_sl[t] = opaque_s(P.o_b_sl[t]);
-        O.A_sl_l[t][0] = opaque_s(P.o_A_sl_l[t][0]); O.A_sl_l[t][1] = opaque_s(P.o_A_sl_l[t][1]);
-    });
+    constexpr NodeLayout<L> O = kNodeLayout<L>;      // weight-image offsets: compile-time constants (dedf_net.h)
     const bool valid = n0 + wv.col < P.n_nodes;
     const int n = valid ? n0 + wv.col : n0;
     const int pose = n / P.nQ, q = n - pose * P.nQ;
@@ -160,11 +144,35 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     Feat<L> fld;
     constexpr int NF1 = f1_rows0<L>() / 32 + (f1_rows0<L>() % 32 ? 1 : 0);     // 11 (L=2) / 9 (L=1) tiles of fctp_1's 0e rows
     constexpr float kBS = (float)(1 << kNodeBShift);
-    const FeatH<L> nh = split_feat<L>(nrm);
+    // split-fp16 B operands that are reused by several GEMMs are parked in LDS (this wave's 30 KB, slot = one h8 per lane):
+    // first the normalised features (FFN), later the field (score tensor products); the registers go to the accumulators
+    constexpr int FS1 = 8, FS2 = FS1 + 12;
+    __shared__ f32x4 fpark[(FS2 + 10) * 64];
+    f32x4* const fp = fpark + wv.lane;
+    auto park = [&](const Feat<L>& f) {
+        const FeatH<L> fh = split_feat<L>(f);
+        static_for<4>([&]<int c>() { fp[(2 * c) * 64] = __builtin_bit_cast(f32x4, fh.s[c].hi); fp[(2 * c + 1) * 64] = __builtin_bit_cast(f32x4, fh.s[c].lo); });
+        if constexpr (L >= 1) static_for<3>([&]<int m>() { static_for<2>([&]<int c>() {
+            fp[(FS1 + 4 * m + 2 * c) * 64] = __builtin_bit_cast(f32x4, fh.v1[m][c].hi);
+            fp[(FS1 + 4 * m + 2 * c + 1) * 64] = __builtin_bit_cast(f32x4, fh.v1[m][c].lo);
+        }); });
+        if constexpr (L >= 2) static_for<5>([&]<int m>() {
+            fp[(FS2 + 2 * m) * 64] = __builtin_bit_cast(f32x4, fh.v2[m][0].hi);
+            fp[(FS2 + 2 * m + 1) * 64] = __builtin_bit_cast(f32x4, fh.v2[m][0].lo);
+        });
+    };
+    auto parked = [&]<int l, int m, int c>() {       // chunk c of component m of block l
+        constexpr int slot = l == 0 ? 2 * c : (l == 1 ? FS1 + 4 * m + 2 * c : FS2 + 2 * m);
+        HL b;
+        b.hi = __builtin_bit_cast(h8, fp[slot * 64]);
+        b.lo = __builtin_bit_cast(h8, fp[(slot + 1) * 64]);
+        return b;
+    };
+    park(nrm);
     {   // l = 0: 192 hidden scalars (6 tiles) -> SiLU -> fctp_2
         f32x16 hs[6];
         static_for<6>([&]<int To>() { hs[To] = ldrows(wv, O.b_f1, To); });
-        dense_rot_hp<6, 4>(wv, O.A_f1[0], O.A_f1_l[0], hs, [&]<int c>() { return nh.s[c]; });
+        dense_rot_hp<6, 4, 1>(wv, O.A_f1[0], O.A_f1_l[0], hs, [&]<int c>() { return parked.template operator()<0, 0, c>(); });
         const float c1 = opaque_s(P.sc.f1[0]);
         static_for<6>([&]<int To>() { static_for<16>([&]<int R>() { hs[To][R] = silu_n(hs[To][R] * c1); }); });
         f32x16 o0[2];
@@ -183,7 +191,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     static_for<NGT>([&]<int t>() { gt[t] = ldrows(wv, O.b_f1, 6 + t); });
     {
         // the gate tiles start at tile 6 of the same matrix (4 chunks per tile) -> shift the image offsets
-        dense_rot_hp<NGT, 4>(wv, O.A_f1[0] + 6 * 4 * 256, O.A_f1_l[0] + 6 * 4 * 256, gt, [&]<int c>() { return nh.s[c]; });
+        dense_rot_hp<NGT, 4, 1>(wv, O.A_f1[0] + 6 * 4 * 256, O.A_f1_l[0] + 6 * 4 * 256, gt, [&]<int c>() { return parked.template operator()<0, 0, c>(); });
         const float c1 = opaque_s(P.sc.f1[0]);
         static_for<NGT>([&]<int t>() { static_for<16>([&]<int R>() { gt[t][R] = sigmoid_n(gt[t][R] * c1); }); });
     }
@@ -192,7 +200,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         const float c1 = opaque_s(P.sc.f1[1]);
         static_for<3>([&]<int t>() {
             static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] = 0.0f; }); });
-            dense_shared_hp<3, 2>(wv, O.A_f1[1], O.A_f1_l[1], 2, t, hh[t], [&]<int m, int c>() { return nh.v1[m][c]; });
+            dense_shared_hp<3, 2>(wv, O.A_f1[1], O.A_f1_l[1], 2, t, hh[t], [&]<int m, int c>() { return parked.template operator()<1, m, c>(); });
             static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] *= gt[t][R] * c1; }); });
         });
         f32x16 o[3] = {{0}, {0}, {0}};
@@ -209,7 +217,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         const float c1 = opaque_s(P.sc.f1[2]);
         static_for<2>([&]<int t>() {
             static_for<5>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] = 0.0f; }); });
-            dense_shared_hp<5, 1>(wv, O.A_f1[2], O.A_f1_l[2], 1, t, hh[t], [&]<int m, int c>() { return nh.v2[m][c]; });
+            dense_shared_hp<5, 1>(wv, O.A_f1[2], O.A_f1_l[2], 1, t, hh[t], [&]<int m, int c>() { return parked.template operator()<2, m, c>(); });
             static_for<5>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] *= gt[3 + t][R] * c1; }); });
         });
         f32x16 o[5] = {{0}, {0}, {0}, {0}, {0}};
@@ -295,23 +303,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         return;
     }
     float res[2][3];                         // per TP: mean over the 32 gated 1e channels
-    // the field as split-fp16 B operands, shared by every path of both tensor products: parked in LDS (this wave's 30 KB,
-    // slot = one h8 per lane) so that the 120 registers are free for the accumulators of the tensor products
-    constexpr int FS1 = 8, FS2 = FS1 + 12;
-    __shared__ f32x4 fpark[(FS2 + 10) * 64];
-    f32x4* const fp = fpark + wv.lane;
-    {
-        const FeatH<L> fh = split_feat<L>(fld);
-        static_for<4>([&]<int c>() { fp[(2 * c) * 64] = __builtin_bit_cast(f32x4, fh.s[c].hi); fp[(2 * c + 1) * 64] = __builtin_bit_cast(f32x4, fh.s[c].lo); });
-        if constexpr (L >= 1) static_for<3>([&]<int m>() { static_for<2>([&]<int c>() {
-            fp[(FS1 + 4 * m + 2 * c) * 64] = __builtin_bit_cast(f32x4, fh.v1[m][c].hi);
-            fp[(FS1 + 4 * m + 2 * c + 1) * 64] = __builtin_bit_cast(f32x4, fh.v1[m][c].lo);
-        }); });
-        if constexpr (L >= 2) static_for<5>([&]<int m>() {
-            fp[(FS2 + 2 * m) * 64] = __builtin_bit_cast(f32x4, fh.v2[m][0].hi);
-            fp[(FS2 + 2 * m + 1) * 64] = __builtin_bit_cast(f32x4, fh.v2[m][0].lo);
-        });
-    }
+    park(fld);                               // the field as B operands, shared by every path of both tensor products
     static_for<2>([&]<int tp>() {
         f32x16 gacc = ldrows(wv, O.b_sl[tp], 0);
         f32x16 vacc[3];
@@ -335,13 +327,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
                 });
                 f32x16 T[d2];
                 static_for<d2>([&]<int j>() { static_for<16>([&]<int R>() { T[j][R] = 0.0f; }); });
-                dense_shared_hp<d2, NCK>(wv, O.A_s[tp][p], O.A_s_l[tp][p], NCK, To, T, [&]<int j, int c>() {
-                    constexpr int slot = l2 == 0 ? 2 * c : (l2 == 1 ? FS1 + 4 * j + 2 * c : FS2 + 2 * j);
-                    HL b;
-                    b.hi = __builtin_bit_cast(h8, fp[slot * 64]);
-                    b.lo = __builtin_bit_cast(h8, fp[(slot + 1) * 64]);
-                    return b;
-                });
+                dense_shared_hp<d2, NCK>(wv, O.A_s[tp][p], O.A_s_l[tp][p], NCK, To, T, [&]<int j, int c>() { return parked.template operator()<l2, j, c>(); });
                 static_for<NC2>([&]<int cc>() {
                     constexpr int u0 = 32 * To + 16 * cc;
                     float a[d3][8];

@@ -116,6 +116,7 @@ struct NodeOffsets {
     int o_A_s[2][16], o_A_sl[2][2], o_b_sl[2];
     int o_A_proj_l[4], o_A_f1_l[4], o_A_f2_l[4], o_A_s_l[2][16], o_A_sl_l[2][2];     // residual (lo) images
     NodeScales sc;
+    bool layout_ok;         // the pushes reproduced dedf_net.h::kNodeLayout (checked in pack_node, enforced in dedf_create)
 };
 
 inline float softplusf(float x) { return x > 20.0f ? x : std::log1p(std::exp(x)); }
@@ -367,6 +368,18 @@ inline void pack_node(const dedf_config& c, const ParamSpec& S, const float* B, 
         o.o_b_sl[tp] = im.push(pack_rows(n1, [&](int i) { return std::ldexp(lb[1 + i], shl[0] + kNodeBShift); }));
         ++tp;
     }
+    // the kernel addresses the image through the compile-time layout: it must be what was just built
+    constexpr NodeLayout<L> nl = kNodeLayout<L>;
+    bool same = o.o_b_proj0 == nl.b_proj0 && o.o_ln_b0 == nl.ln_b0 && o.o_b_f1 == nl.b_f1 && o.o_b_f2 == nl.b_f2;
+    for (int l = 0; l <= L; ++l)
+        same = same && o.o_A_proj[l] == nl.A_proj[l] && o.o_A_proj_l[l] == nl.A_proj_l[l] && o.o_ln_w[l] == nl.ln_w[l] && o.o_A_f1[l] == nl.A_f1[l] &&
+               o.o_A_f1_l[l] == nl.A_f1_l[l] && o.o_A_f2[l] == nl.A_f2[l] && o.o_A_f2_l[l] == nl.A_f2_l[l];
+    for (int t = 0; t < tp; ++t) {
+        for (int q = 0; q < stp_num_paths<L>(); ++q) same = same && o.o_A_s[t][q] == nl.A_s[t][q] && o.o_A_s_l[t][q] == nl.A_s_l[t][q];
+        same = same && o.o_A_sl[t][0] == nl.A_sl[t][0] && o.o_A_sl_l[t][0] == nl.A_sl_l[t][0] && o.o_A_sl[t][1] == nl.A_sl[t][1] &&
+               o.o_A_sl_l[t][1] == nl.A_sl_l[t][1] && o.o_b_sl[t] == nl.b_sl[t];
+    }
+    o.layout_ok = same;
 }
 
 }  // namespace dedf

@@ -22,6 +22,10 @@ def _check(rep, stages=True):
     if stages:
         for k in ('msg', 'qpos', 'dtp_weight', 'value', 'attn', 'node_lin'):
             assert rep[k] < 2e-4, (k, rep[k])
+        # per-irreps-block stages (each relative to its own block maximum): edge value, proj output, field after the FFN
+        for k, v in rep.items():
+            if k.startswith(('value_l', 'emb_l', 'field_l')):
+                assert v < 2e-4, (k, v)
 
 
 @pytest.mark.parametrize("lmax", [1, 2])
