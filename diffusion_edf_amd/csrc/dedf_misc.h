@@ -334,22 +334,36 @@ __global__ void k_aggregate(const float* __restrict__ edge_out, const int* __res
         const int c = cnt[(size_t)n * n_dst + d];
         const size_t e0 = (size_t)tile_info[16 + n] + off[(size_t)n * n_dst + d];
         const float* rec = edge_out + e0 * REC;
-        f32x4 v_nxt = {0, 0, 0, 0}, lg_nxt = {0, 0, 0, 0};
-        if (c > 0) { lg_nxt = ld4(rec + D); if (lane < NV) v_nxt = ld4(rec + ci); }
-        for (int j = 0; j < c; ++j) {
-            const f32x4 lg = lg_nxt, v = v_nxt;
-            if (j + 1 < c) { lg_nxt = ld4(rec + (size_t)(j + 1) * REC + D); if (lane < NV) v_nxt = ld4(rec + (size_t)(j + 1) * REC + ci); }
-            float p[kHeads], sc[kHeads];
+        // U records per iteration: all their loads are in flight together (one record per iteration leaves a wave with a
+        // single KiB outstanding and the kernel latency-bound); the online-softmax update handles the group at once
+        constexpr int U = 4;
+        for (int j = 0; j < c; j += U) {
+            f32x4 lg[U], v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                lg[u] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                v[u] = f32x4{0, 0, 0, 0};
+                if (j + u < c) { lg[u] = ld4(rec + (size_t)(j + u) * REC + D); if (lane < NV) v[u] = ld4(rec + (size_t)(j + u) * REC + ci); }
+            }
+            float sc[kHeads], p[U][kHeads];
             for (int h = 0; h < kHeads; ++h) {
-                const float m_new = fmaxf(mx[h], lg[h]);
-                sc[h] = expf(mx[h] - m_new);            // exp(-inf) = 0 on the first edge
-                p[h] = expf(lg[h] - m_new);
-                sum[h] = sum[h] * sc[h] + p[h];
+                float m_new = mx[h];
+#pragma unroll
+                for (int u = 0; u < U; ++u) m_new = fmaxf(m_new, lg[u][h]);
+                sc[h] = expf(mx[h] - m_new);            // exp(-inf) = 0 on the first group
+                float ps = 0.0f;
+#pragma unroll
+                for (int u = 0; u < U; ++u) { p[u][h] = expf(lg[u][h] - m_new); ps += p[u][h]; }
+                sum[h] = sum[h] * sc[h] + ps;
                 mx[h] = m_new;
             }
-            const float ph = head == 0 ? p[0] : (head == 1 ? p[1] : (head == 2 ? p[2] : p[3]));
             const float sh = head == 0 ? sc[0] : (head == 1 ? sc[1] : (head == 2 ? sc[2] : sc[3]));
-            acc = acc * sh + v * ph;
+            acc = acc * sh;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float ph = head == 0 ? p[u][0] : (head == 1 ? p[u][1] : (head == 2 ? p[u][2] : p[u][3]));
+                acc = acc + v[u] * ph;
+            }
         }
     }
     if (lane < NV) {
