@@ -228,7 +228,7 @@ __device__ inline int block_exclusive_scan_256(int v, int* total) {
 
 template <bool FILL>
 __global__ __launch_bounds__(kNbrBlock) void k_neighbors(NbrParams P) {
-    __shared__ float kx[kNbrChunk * 3];
+    __shared__ f32x4 kx[kNbrChunk];          // (x, y, z, 0): one broadcast ds_read_b128 per key
     const int d = blockIdx.x * kNbrBlock + threadIdx.x;
     const bool act = d < P.n_dst;
     float px = 0, py = 0, pz = 0;
@@ -249,11 +249,15 @@ __global__ __launch_bounds__(kNbrBlock) void k_neighbors(NbrParams P) {
         for (int c0 = s0; c0 < s1; c0 += kNbrChunk) {
             const int nc = min(kNbrChunk, s1 - c0);
             __syncthreads();
-            for (int i = threadIdx.x; i < nc * 3; i += kNbrBlock) kx[i] = P.key_x[(size_t)c0 * 3 + i];
+            for (int i = threadIdx.x; i < nc; i += kNbrBlock) {
+                const float* kp = P.key_x + (size_t)(c0 + i) * 3;
+                kx[i] = f32x4{kp[0], kp[1], kp[2], 0.0f};
+            }
             __syncthreads();
             if (!act) continue;
             for (int i = 0; i < nc; ++i) {
-                const float dx = kx[3 * i] - px, dy = kx[3 * i + 1] - py, dz = kx[3 * i + 2] - pz;
+                const f32x4 k = kx[i];
+                const float dx = k[0] - px, dy = k[1] - py, dz = k[2] - pz;
                 const float d2 = dx * dx + dy * dy + dz * dz;
                 const bool in = (r2 <= 0.0f) || (d2 < r2);
                 if (in && (r2 <= 0.0f || c < P.max_neighbors)) {
