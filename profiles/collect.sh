@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collect the rocprofv3 evidence for one round on the GPU box:   bash profiles/collect.sh r01b
+# Collect the rocprofv3 evidence for one round on the GPU box:   bash profiles/collect.sh r01c ["trace fetch write sq bench"]
 # (run through gpurun; outputs land in gpurun_out/<tag>_*; then `python profiles/summarize.py <tag>` turns them into profiles/<tag>_*).
 # Counters are collected in their own passes with --kernel-trace only (never combined with sys/hip/hsa traces).
 set -u
@@ -9,10 +9,12 @@ OUT=$ROOT/gpurun_out
 CMD="python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -- $CMD > $OUT/${TAG}_trace_bench.json 2> $OUT/${TAG}_trace.log
+PASSES=${2:-"trace fetch write sq sq2 sq3 tcp bench"}     # each PMC pass costs ~3.5 min of box time
+has() { [[ " $PASSES " == *" $1 "* ]]; }
+has trace && rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -- $CMD > $OUT/${TAG}_trace_bench.json 2> $OUT/${TAG}_trace.log
 pass() {   # name, counters...
     local name=$1; shift
-    rocprofv3 --kernel-trace --pmc "$@" -d $OUT/${TAG}_pmc_$name -- $CMD > /dev/null 2> $OUT/${TAG}_pmc_$name.log
+    has $name && rocprofv3 --kernel-trace --pmc "$@" -d $OUT/${TAG}_pmc_$name -- $CMD > /dev/null 2> $OUT/${TAG}_pmc_$name.log
 }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
@@ -20,6 +22,5 @@ pass sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WA
 pass sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_RD
 pass sq3 SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_INST_LDS SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INSTS_SALU
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
-pass ta TA_TA_BUSY_sum TA_BUFFER_TOTAL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum
-python $ROOT/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+has bench && python $ROOT/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo done
