@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--scene", type=int, default=4096)
     ap.add_argument("--grasp", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--half", action="store_true", help="half-precision GEMM mode (model.half(), the reference's half_precision knob); NOT the headline configuration")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -123,6 +124,8 @@ def main():
     head = ScoreModelHead(**kw)
     head.load_state_dict(P)
     head.to(device)
+    if args.half:
+        head.half()
     model = ScoreModelBase(head)
     head.set_key_clouds(keys)
     head.set_query(query)
@@ -165,6 +168,7 @@ def main():
         achieved = flops / (edge_ms * 1e-3) / 1e12 if edge_ms > 0 else 0.0
         peak = mix_peak_tflops(args.lmax)
         default_workload = (args.lmax, args.scene, args.grasp, args.poses_per_gpu) == (2, 4096, 1024, 1000)
+        default_workload = default_workload and not args.half
         wname = "C2" if default_workload else ("C1" if (args.lmax, args.scene, args.grasp) == (1, 2048, 512) else "custom")
         traffic = None
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json"))) if default_workload else []:
@@ -179,7 +183,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (score network; dense GEMMs as 3-term split-fp16 MFMA products = 22-bit operands, fp32 accumulate) + f64 (SE(3) Langevin state)",
+            "dtype": ("f16 GEMM operands (half-precision mode: one fp16 MFMA product per GEMM, fp32 accumulate; rest f32) + f64 (SE(3) Langevin state)" if args.half else
+                      "f32 (score network; dense GEMMs as 3-term split-fp16 MFMA products = 22-bit operands, fp32 accumulate) + f64 (SE(3) Langevin state)"),
             "data": "synthetic (seeded scene/grasp clouds of the named sizes, random-init weights of the reference architecture)",
             "config": {"workload": f"{wname}: {args.scene}-pt scene -> key clouds {'/'.join(str(len(k.x)) for k in keys)}, {args.grasp}-pt grasp -> "
                                    f"{len(query.x)} query pts, lmax={args.lmax}, {args.poses_per_gpu} poses per GPU, t 1->0.15 log-spaced, dt 0.04",

@@ -28,7 +28,7 @@ class DedfConfig(C.Structure):
         ("length_emb_dim", C.c_int), ("time_emb_mlp", C.c_int * 3), ("irreps_mlp_mid", C.c_int), ("n_scales", C.c_int),
         ("radii", C.c_float * MAX_SCALES), ("r_mincut_nonscalar_sh", C.c_float), ("length_enc_max_r", C.c_float),
         ("max_time", C.c_float), ("time_enc_n", C.c_float), ("lin_mult", C.c_float), ("ang_mult", C.c_float),
-        ("max_neighbors", C.c_int), ("device", C.c_int), ("max_edges", C.c_int64), ("ebm", C.c_int),
+        ("max_neighbors", C.c_int), ("device", C.c_int), ("max_edges", C.c_int64), ("ebm", C.c_int), ("half_gemm", C.c_int),
     ]
 
 
@@ -110,6 +110,7 @@ def make_config(cfg: HeadConfig, device: int, max_edges: int = 0) -> DedfConfig:
     c.device = device
     c.max_edges = max_edges
     c.ebm = int(cfg.ebm)
+    c.half_gemm = int(getattr(cfg, 'half_gemm', False))
     return c
 
 

@@ -18,7 +18,7 @@ using namespace dedf;
 // ---------------------------------------------------------------------------------------------------------------------------
 // the two fused kernels: persistent waves striding over tiles (tile count lives on the device: no host round trip)
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int L, int F0> __global__ __launch_bounds__(64, 1) void k_edge(EdgeParams P) {
+template <int L, int F0, bool HP = false> __global__ __launch_bounds__(64, 1) void k_edge(EdgeParams P) {
     const int* ti = P.tile_info;
     const int ntiles = ti[P.n_scales];
     const Wave wv = make_wave(P.W, P.W_bytes);
@@ -31,19 +31,19 @@ template <int L, int F0> __global__ __launch_bounds__(64, 1) void k_edge(EdgePar
         const int k = t - ti[scale];
         const int ebase = ti[16 + scale], En = ti[16 + scale + 1] - ebase;
 #if defined(DEDF_PHASE_PROF)
-        edge_tile<L, F0>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k), pacc);
+        edge_tile<L, F0, HP>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k), pacc);
 #else
-        edge_tile<L, F0>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k));
+        edge_tile<L, F0, HP>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k));
 #endif
     }
 #if defined(DEDF_PHASE_PROF)
     if (P.phase_prof && wv.lane == 0) for (int i = 0; i < 16; ++i) P.phase_prof[blockIdx.x * 16 + i] += pacc[i];
 #endif
 }
-template <int L, bool EBM> __global__ __launch_bounds__(64, 1) void k_node(NodeParams P) {
+template <int L, bool EBM, bool HP = false> __global__ __launch_bounds__(64, 1) void k_node(NodeParams P) {
     const Wave wv = make_wave(P.W, P.W_bytes);
     const int ntiles = (P.n_nodes + 31) / 32;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) node_tile<L, EBM>(P, wv, t * 32);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) node_tile<L, EBM, HP>(P, wv, t * 32);
 }
 __global__ void k_energy_reduce(const float* __restrict__ node_out, int nT, int nQ, float* __restrict__ energy) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -132,6 +132,7 @@ int check_config(const dedf_config* c, std::string& why) {
         why = "fc_neurons must resolve to [64 + time_emb, 128, 64] (score head) or [64,128,64] (EBM head without time encoding)"; return DEDF_ERR_UNSUPPORTED; }
     if (c->length_emb_dim != kLenEmb) { why = "length_emb_dim must be 64"; return DEDF_ERR_UNSUPPORTED; }
     if (c->irreps_mlp_mid != kMlpMid) { why = "irreps_mlp_mid must be 3"; return DEDF_ERR_UNSUPPORTED; }
+    if (c->half_gemm && (c->ebm || c->fc_neurons[0] != 128)) { why = "half_gemm is available for the score head with the 128-wide pre-linear only"; return DEDF_ERR_UNSUPPORTED; }
     if (c->n_scales < 1 || c->n_scales > kMaxScales) { why = "n_scales out of range"; return DEDF_ERR_INVALID; }
     bool inf = false;
     for (int n = 0; n < c->n_scales; ++n) {
@@ -316,7 +317,11 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
 #if defined(DEDF_PHASE_PROF)
         if (h->d_phase.ensure((size_t)h->n_cu * 4 * 16 * 8)) P.phase_prof = h->d_phase.as<unsigned long long>();
 #endif
-        hipLaunchKernelGGL((k_edge<L, F0>), dim3(h->n_cu * 4), dim3(64), 0, st, P);
+        // half_gemm (the reference's half_precision knob): single-term fp16 products; instantiated for the 128-wide score head only
+        if constexpr (F0 == 128) {
+            if (h->cfg.half_gemm) hipLaunchKernelGGL((k_edge<L, F0, true>), dim3(h->n_cu * 4), dim3(64), 0, st, P);
+            else hipLaunchKernelGGL((k_edge<L, F0>), dim3(h->n_cu * 4), dim3(64), 0, st, P);
+        } else hipLaunchKernelGGL((k_edge<L, F0>), dim3(h->n_cu * 4), dim3(64), 0, st, P);
     }
     mark();
     // 5. joint softmax + aggregation
@@ -346,7 +351,10 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         P.node_out = h->d_nout.as<float>();
         if (h->debug && h->d_dbge.ensure((size_t)Nd * D * 4) && h->d_dbgf.ensure((size_t)Nd * D * 4)) { P.dbg_emb = h->d_dbge.as<float>(); P.dbg_field = h->d_dbgf.as<float>(); }
         const int ntiles = (Nd + 31) / 32;
-        hipLaunchKernelGGL((k_node<L, EBM>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
+        if constexpr (!EBM && F0 == 128) {
+            if (h->cfg.half_gemm) hipLaunchKernelGGL((k_node<L, EBM, true>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
+            else hipLaunchKernelGGL((k_node<L, EBM>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
+        } else hipLaunchKernelGGL((k_node<L, EBM>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
     }
     mark();
     // 7. per-pose reduction

@@ -244,12 +244,13 @@ DEDF_DEV int tie(int v, float dep) {
 }
 // Dense layer on split-fp16 MFMAs, NTO output tiles rotated, A images [To][chunk][lane][8 halves] (hi at off_h, lo at off_l),
 // operands requested PD chunks ahead.   bsrc.operator()<chunk, j>() -> fp32 value of element j of the chunk (8 registers).
-template <int NTO, int NCH, int PD = 2, class BsrcF>
+// HP (half-precision mode, the reference's `half_precision`): only the hi*hi term -- one MFMA and one operand image per product.
+template <int NTO, int NCH, int PD = 2, bool HP = false, class BsrcF>
 DEDF_DEV void dense_rot_h(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[NTO], BsrcF&& bsrc) {
-    f32x4 rh[PD][NTO], rl[PD][NTO];
+    f32x4 rh[PD][NTO], rl[PD][NTO] = {};
     sched_fence();
     static_for<PD>([&]<int k>() { if constexpr (k < NCH) static_for<NTO>([&]<int To>() {
-        rh[k][To] = lda(wv, off_h, NCH, To, k); rl[k][To] = lda(wv, off_l, NCH, To, k); }); });
+        rh[k][To] = lda(wv, off_h, NCH, To, k); if constexpr (!HP) rl[k][To] = lda(wv, off_l, NCH, To, k); }); });
     static_for<NCH>([&]<int c>() {
         f32x4 ch[NTO], cl[NTO];
         static_for<NTO>([&]<int To>() { ch[To] = rh[c % PD][To]; cl[To] = rl[c % PD][To]; });
@@ -261,12 +262,14 @@ DEDF_DEV void dense_rot_h(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[NT
             const int lv = tie(wv.lane16, __builtin_bit_cast(f32x4, b.hi)[0]);
             static_for<NTO>([&]<int To>() {
                 rh[c % PD][To] = bld4(wv.w, lv, (off_h + (To * NCH + c + PD) * 256) * 4);
-                rl[c % PD][To] = bld4(wv.w, lv, (off_l + (To * NCH + c + PD) * 256) * 4);
+                if constexpr (!HP) rl[c % PD][To] = bld4(wv.w, lv, (off_l + (To * NCH + c + PD) * 256) * 4);
             });
         }
         static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, ch[To]), b.hi, acc[To]); });
-        static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, ch[To]), b.lo, acc[To]); });
-        static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, cl[To]), b.hi, acc[To]); });
+        if constexpr (!HP) {
+            static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, ch[To]), b.lo, acc[To]); });
+            static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, cl[To]), b.hi, acc[To]); });
+        }
         sched_fence();
     });
 }
@@ -277,12 +280,12 @@ DEDF_DEV HL split8(const float (&x)[8], float scale) {
     return split8(t);
 }
 // Same with the B chunks already split:  bh.operator()<chunk>() -> HL
-template <int NTO, int NCH, int PD = 2, class BF>
+template <int NTO, int NCH, int PD = 2, bool HP = false, class BF>
 DEDF_DEV void dense_rot_hp(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[NTO], BF&& bh) {
-    f32x4 rh[PD][NTO], rl[PD][NTO];
+    f32x4 rh[PD][NTO], rl[PD][NTO] = {};
     sched_fence();
     static_for<PD>([&]<int k>() { if constexpr (k < NCH) static_for<NTO>([&]<int To>() {
-        rh[k][To] = lda(wv, off_h, NCH, To, k); rl[k][To] = lda(wv, off_l, NCH, To, k); }); });
+        rh[k][To] = lda(wv, off_h, NCH, To, k); if constexpr (!HP) rl[k][To] = lda(wv, off_l, NCH, To, k); }); });
     static_for<NCH>([&]<int c>() {
         f32x4 ch[NTO], cl[NTO];
         static_for<NTO>([&]<int To>() { ch[To] = rh[c % PD][To]; cl[To] = rl[c % PD][To]; });
@@ -292,23 +295,25 @@ DEDF_DEV void dense_rot_hp(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[N
             const int lv = tie(wv.lane16, __builtin_bit_cast(f32x4, b.hi)[0]);
             static_for<NTO>([&]<int To>() {
                 rh[c % PD][To] = bld4(wv.w, lv, (off_h + (To * NCH + c + PD) * 256) * 4);
-                rl[c % PD][To] = bld4(wv.w, lv, (off_l + (To * NCH + c + PD) * 256) * 4);
+                if constexpr (!HP) rl[c % PD][To] = bld4(wv.w, lv, (off_l + (To * NCH + c + PD) * 256) * 4);
             });
         }
         static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, ch[To]), b.hi, acc[To]); });
-        static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, ch[To]), b.lo, acc[To]); });
-        static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, cl[To]), b.hi, acc[To]); });
+        if constexpr (!HP) {
+            static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, ch[To]), b.lo, acc[To]); });
+            static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, cl[To]), b.hi, acc[To]); });
+        }
         sched_fence();
     });
 }
 // One output tile (To, of a matrix with nCH chunks per tile) applied to NM right-hand sides that share the A operands
 // (e.g. the 2l+1 components of an l-block):   bh.operator()<m, chunk>() -> HL
-template <int NM, int NCH, int PD = 2, class BF>
+template <int NM, int NCH, int PD = 2, bool HP = false, class BF>
 DEDF_DEV void dense_shared_hp(const Wave& wv, int off_h, int off_l, int nCH, int To, f32x16 (&acc)[NM], BF&& bh) {
-    f32x4 rh[PD], rl[PD];
+    f32x4 rh[PD], rl[PD] = {};
     sched_fence();
     static_for<PD>([&]<int k>() { if constexpr (k < NCH) {
-        rh[k] = bld4(wv.w, wv.lane16, (off_h + (To * nCH + k) * 256) * 4); rl[k] = bld4(wv.w, wv.lane16, (off_l + (To * nCH + k) * 256) * 4); } });
+        rh[k] = bld4(wv.w, wv.lane16, (off_h + (To * nCH + k) * 256) * 4); if constexpr (!HP) rl[k] = bld4(wv.w, wv.lane16, (off_l + (To * nCH + k) * 256) * 4); } });
     static_for<NCH>([&]<int c>() {
         const h8 ch = __builtin_bit_cast(h8, rh[c % PD]), cl = __builtin_bit_cast(h8, rl[c % PD]);
         sched_fence();
@@ -317,11 +322,13 @@ DEDF_DEV void dense_shared_hp(const Wave& wv, int off_h, int off_l, int nCH, int
         if constexpr (c + PD < NCH) {
             const int lv = tie(wv.lane16, __builtin_bit_cast(f32x4, b[0].hi)[0]);
             rh[c % PD] = bld4(wv.w, lv, (off_h + (To * nCH + c + PD) * 256) * 4);
-            rl[c % PD] = bld4(wv.w, lv, (off_l + (To * nCH + c + PD) * 256) * 4);
+            if constexpr (!HP) rl[c % PD] = bld4(wv.w, lv, (off_l + (To * nCH + c + PD) * 256) * 4);
         }
         static_for<NM>([&]<int m>() { acc[m] = mfma_h(ch, b[m].hi, acc[m]); });
-        static_for<NM>([&]<int m>() { acc[m] = mfma_h(ch, b[m].lo, acc[m]); });
-        static_for<NM>([&]<int m>() { acc[m] = mfma_h(cl, b[m].hi, acc[m]); });
+        if constexpr (!HP) {
+            static_for<NM>([&]<int m>() { acc[m] = mfma_h(ch, b[m].lo, acc[m]); });
+            static_for<NM>([&]<int m>() { acc[m] = mfma_h(cl, b[m].hi, acc[m]); });
+        }
         sched_fence();
     });
 }

@@ -102,14 +102,14 @@ DEDF_DEV void ln_silu(f32x16 (&x)[NT], const Wave& wv, int o_gamma, int o_beta) 
 // into hi / lo halves (B operands), the weights come as a pre-split A-operand stream, every product is hi*hi + hi*lo + lo*hi.
 template <int L> struct BOpsH { h8 hi[2 * L + 1], lo[2 * L + 1]; };
 struct AItem { f32x4 h[2], l[2]; };
-template <int L, int NT0, int I>
+template <int L, int NT0, int I, bool HP = false>
 DEDF_DEV AItem load_item(const Wave& wv, int o_str) {
     AItem a{};
     constexpr DtpItem it = dtp_item<L>(I, NT0);
     if constexpr (it.ntile > 0) {
         static_for<it.ntile>([&]<int n>() {
             a.h[n] = bld4(wv.w, wv.lane16, (o_str + (it.slot + n) * 512) * 4);
-            a.l[n] = bld4(wv.w, wv.lane16, (o_str + (it.slot + n) * 512 + 256) * 4);
+            if constexpr (!HP) a.l[n] = bld4(wv.w, wv.lane16, (o_str + (it.slot + n) * 512 + 256) * 4);
         });
     }
     return a;
@@ -117,25 +117,29 @@ DEDF_DEV AItem load_item(const Wave& wv, int o_str) {
 // MFMAs of the chunk at walk position C: l3 = 0 -> output tiles acc0[0 .. NT0) two at a time, l3 = 1 / 2 -> acc1[m] / acc2[m] (one tile
 // per component; the 16-channel l = 2 outputs only fill rows 0-15, i.e. registers 0-7).  The three terms are issued
 // term-major so that consecutive MFMAs hit different accumulators.
-template <int L, int NT0, int C, int PD>
+template <int L, int NT0, int C, bool HP, int PD>
 DEDF_DEV void mfma_chunk(const Wave& wv, int o_str, AItem (&ring)[PD], const BOpsH<L>& bo, f32x16 (&acc0)[NT0], f32x16 (&acc1)[3], f32x16 (&acc2)[5]) {
     constexpr int l3 = dtp_pos_l3<L>(C), I0 = dtp_item_first<L>(C, NT0), NI = l3 == 0 ? cdiv(NT0, 2) : 1;
     static_for<NI>([&]<int t>() {
         constexpr int I = I0 + t;
         const AItem a = ring[I % PD];
-        ring[I % PD] = load_item<L, NT0, I + PD>(wv, o_str);
+        ring[I % PD] = load_item<L, NT0, I + PD, HP>(wv, o_str);
         if constexpr (l3 == 0) {
             constexpr int nt = dtp_item<L>(I, NT0).ntile;
             static_for<nt>([&]<int n>() { acc0[2 * t + n] = mfma_h(__builtin_bit_cast(h8, a.h[n]), bo.hi[0], acc0[2 * t + n]); });
-            static_for<nt>([&]<int n>() { acc0[2 * t + n] = mfma_h(__builtin_bit_cast(h8, a.h[n]), bo.lo[0], acc0[2 * t + n]); });
-            static_for<nt>([&]<int n>() { acc0[2 * t + n] = mfma_h(__builtin_bit_cast(h8, a.l[n]), bo.hi[0], acc0[2 * t + n]); });
+            if constexpr (!HP) {
+                static_for<nt>([&]<int n>() { acc0[2 * t + n] = mfma_h(__builtin_bit_cast(h8, a.h[n]), bo.lo[0], acc0[2 * t + n]); });
+                static_for<nt>([&]<int n>() { acc0[2 * t + n] = mfma_h(__builtin_bit_cast(h8, a.l[n]), bo.hi[0], acc0[2 * t + n]); });
+            }
         } else {
             constexpr int d3 = 2 * l3 + 1;
             auto& accm = [&]() -> auto& { if constexpr (l3 == 1) return acc1; else return acc2; }();
             const h8 ah = __builtin_bit_cast(h8, a.h[0]), al = __builtin_bit_cast(h8, a.l[0]);
             static_for<d3>([&]<int K>() { accm[K] = mfma_h(ah, bo.hi[K], accm[K]); });
-            static_for<d3>([&]<int K>() { accm[K] = mfma_h(ah, bo.lo[K], accm[K]); });
-            static_for<d3>([&]<int K>() { accm[K] = mfma_h(al, bo.hi[K], accm[K]); });
+            if constexpr (!HP) {
+                static_for<d3>([&]<int K>() { accm[K] = mfma_h(ah, bo.lo[K], accm[K]); });
+                static_for<d3>([&]<int K>() { accm[K] = mfma_h(al, bo.hi[K], accm[K]); });
+            }
         }
     });
 }
@@ -145,7 +149,7 @@ DEDF_DEV void split_chunk(const float (&v)[2 * l3 + 1][8], BOpsH<L>& o) {
     static_for<2 * l3 + 1>([&]<int K>() { const HL sp = split8(v[K]); o.hi[K] = sp.hi; o.lo[K] = sp.lo; });
 }
 
-template <int L, int F0>
+template <int L, int F0, bool HP = false>
 DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, int n_valid DEDF_PROF_ARG) {
 #if defined(DEDF_PHASE_PROF) && defined(__HIP_DEVICE_COMPILE__)
     unsigned long long t_last = __builtin_readcyclecounter();
@@ -231,20 +235,20 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         const int tvoff = (pose * P.tb_pose_stride) * 4 + wv.hi64;
         const int oA = opaque_s(P.o_A_pre + scale * (NH * 4 * 256)), oAl = opaque_s(P.o_A_pre_l + scale * (NH * 4 * 256));
         static_for<NH>([&]<int To>() { h[To] = ldrows(tbb, tvoff, scale * F0, To); });
-        dense_rot_h<NH, 4, 2>(wv, oA, oAl, h, [&]<int c, int j>() { return eb[8 * c + j]; });
+        dense_rot_h<NH, 4, 2, HP>(wv, oA, oAl, h, [&]<int c, int j>() { return eb[8 * c + j]; });
         static_for<NH>([&]<int To>() { static_for<16>([&]<int R>() { h[To][R] = siluf(h[To][R]); }); });
     }
     DEDF_STAMP(1);
     // ---- RadialProfile layers 1, 2 (equiformer/radial_func.py:11-60) ---------------------------------------------------
     f32x16 r1[4];
     static_for<4>([&]<int To>() { r1[To] = ldrows(wv, o_b_r1, To); });
-    dense_rot_h<4, F0 / 16, 1>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return h[c / 2][8 * (c % 2) + j]; });
+    dense_rot_h<4, F0 / 16, 1, HP>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return h[c / 2][8 * (c % 2) + j]; });
     DEDF_STAMP(2);
     ln_silu<4>(r1, wv, o_g_r1, o_be_r1);
     DEDF_STAMP(3);
     f32x16 r2[2];
     static_for<2>([&]<int To>() { r2[To] = ldrows(wv, o_b_r2, To); });
-    dense_rot_h<2, 8, 2>(wv, o_A_r2, o_A_r2_l, r2, [&]<int c, int j>() { return r1[c / 2][8 * (c % 2) + j]; });
+    dense_rot_h<2, 8, 2, HP>(wv, o_A_r2, o_A_r2_l, r2, [&]<int c, int j>() { return r1[c / 2][8 * (c % 2) + j]; });
     DEDF_STAMP(4);
     ln_silu<2>(r2, wv, o_g_r2, o_be_r2);
     DEDF_STAMP(5);
@@ -305,7 +309,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     };
     const int o_S_lin = opaque_s(P.o_S_lin);
     AItem ring[PDA];
-    static_for<PDA>([&]<int I>() { ring[I] = load_item<L, NR0, I>(wv, o_S_lin); });
+    static_for<PDA>([&]<int I>() { ring[I] = load_item<L, NR0, I, HP>(wv, o_S_lin); });
     // layer 3 on split-fp16 MFMAs: r2 (64 rows = 4 chunks) is split once per edge tile; per weight tile 4 chunks x 3 MFMAs.
     // A operands (hi and lo image) form one global stream over all tiles, PD3 chunks ahead.
     HL r2s[4];
@@ -326,7 +330,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         L3Half o{};
         if constexpr (Ph < 2 * NWT) static_for<2>([&]<int k>() {
             o.h[k] = bld4(wv.w, wv.lane16, (o_A_r3 + (2 * Ph + k) * 256) * 4);
-            o.l[k] = bld4(wv.w, wv.lane16, (o_A_r3_l + (2 * Ph + k) * 256) * 4);
+            if constexpr (!HP) o.l[k] = bld4(wv.w, wv.lane16, (o_A_r3_l + (2 * Ph + k) * 256) * 4);
         });
         return o;
     };
@@ -338,8 +342,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             static_for<2>([&]<int k>() {
                 const h8 ah = __builtin_bit_cast(h8, a.h[k]), al = __builtin_bit_cast(h8, a.l[k]);
                 t = mfma_h(ah, r2s[c0 + k].hi, t);
-                t = mfma_h(ah, r2s[c0 + k].lo, t);
-                t = mfma_h(al, r2s[c0 + k].hi, t);
+                if constexpr (!HP) { t = mfma_h(ah, r2s[c0 + k].lo, t); t = mfma_h(al, r2s[c0 + k].hi, t); }
             });
             w = t;
         }
@@ -427,7 +430,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         if constexpr (Ph % 2 == 0) run_l3.template operator()<Ph>(l3c, offc, wbuf[T3 % 2]);
         else run_l3.template operator()<Ph>(l3c, wbuf[T3 % 2], wbuf[T3 % 2]);
         const BOpsH<L> b_nxt = valu_chunk.template operator()<C + 1>(x_nxt, wbuf[((C + 1) / 2) % 2]);
-        mfma_chunk<L, NR0, C>(wv, o_S_lin, ring, b_cur, acc0, acc1, acc2);
+        mfma_chunk<L, NR0, C, HP>(wv, o_S_lin, ring, b_cur, acc0, acc1, acc2);
         static_for<L + 1>([&]<int g>() { if constexpr (C == dtp_group_end<L>(g)) finish_group.template operator()<g>(); });
         sched_fence();
         if constexpr (Ph % 2 == 1 && T3 < NWT) dump_w.template operator()<T3>(wbuf[T3 % 2]);
@@ -496,7 +499,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     };
     const int o_S_val = opaque_s(P.o_S_val);
     AItem vring[PDA];
-    static_for<PDA>([&]<int I>() { vring[I] = load_item<L, 2, I>(wv, o_S_val); });
+    static_for<PDA>([&]<int I>() { vring[I] = load_item<L, 2, I, HP>(wv, o_S_val); });
     XPark xp_nxt = load_park.template operator()<1>();
     BOpsH<L> vb_cur = valu_val.template operator()<0>(load_park.template operator()<0>());
     static_for<NCHK>([&]<int C>() {
@@ -505,7 +508,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         static_for<L + 1>([&]<int g>() { if constexpr (g >= 1 && C == dtp_group_end<L>(g - 1)) start_val.template operator()<g>(); });
         sched_fence();
         const BOpsH<L> vb_nxt = valu_val.template operator()<C + 1>(xp_nxt);
-        mfma_chunk<L, 2, C>(wv, o_S_val, vring, vb_cur, val0, val1, val2);
+        mfma_chunk<L, 2, C, HP>(wv, o_S_val, vring, vb_cur, val0, val1, val2);
         static_for<L + 1>([&]<int g>() { if constexpr (C == dtp_group_end<L>(g)) store_group.template operator()<g>(); });
         sched_fence();
         vb_cur = vb_nxt; xp_nxt = xp_nn;

@@ -56,7 +56,7 @@ template <int L> DEDF_DEV FeatH<L> split_feat(const Feat<L>& f) {
     return o;
 }
 
-template <int L, bool EBM>
+template <int L, bool EBM, bool HP = false>
 DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     constexpr int D = feat_dim<L>();
     const int hi = wv.hi;
@@ -90,18 +90,18 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         const FeatH<L> zh = split_feat<L>(z);
         f32x16 a0[2];
         static_for<2>([&]<int To>() { a0[To] = ldrows(wv, O.b_proj0, To); });
-        dense_rot_hp<2, 4>(wv, O.A_proj[0], O.A_proj_l[0], a0, [&]<int c>() { return zh.s[c]; });
+        dense_rot_hp<2, 4, 2, HP>(wv, O.A_proj[0], O.A_proj_l[0], a0, [&]<int c>() { return zh.s[c]; });
         const float c0 = opaque_s(P.sc.proj[0]);
         static_for<2>([&]<int To>() { static_for<16>([&]<int R>() { emb.s[To][R] = a0[To][R] * c0; }); });
         if constexpr (L >= 1) {
             f32x16 a[3] = {{0}, {0}, {0}};
-            dense_shared_hp<3, 2>(wv, O.A_proj[1], O.A_proj_l[1], 2, 0, a, [&]<int m, int c>() { return zh.v1[m][c]; });
+            dense_shared_hp<3, 2, 2, HP>(wv, O.A_proj[1], O.A_proj_l[1], 2, 0, a, [&]<int m, int c>() { return zh.v1[m][c]; });
             const float c1 = opaque_s(P.sc.proj[1]);
             static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { emb.v1[m][R] = a[m][R] * c1; }); });
         }
         if constexpr (L >= 2) {
             f32x16 a[5] = {{0}, {0}, {0}, {0}, {0}};
-            dense_shared_hp<5, 1>(wv, O.A_proj[2], O.A_proj_l[2], 1, 0, a, [&]<int m, int c>() { return zh.v2[m][c]; });
+            dense_shared_hp<5, 1, 2, HP>(wv, O.A_proj[2], O.A_proj_l[2], 1, 0, a, [&]<int m, int c>() { return zh.v2[m][c]; });
             const float c2 = opaque_s(P.sc.proj[2]);
             static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { emb.v2[m][R] = a[m][R] * c2; }); });
         }
@@ -172,12 +172,12 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     {   // l = 0: 192 hidden scalars (6 tiles) -> SiLU -> fctp_2
         f32x16 hs[6];
         static_for<6>([&]<int To>() { hs[To] = ldrows(wv, O.b_f1, To); });
-        dense_rot_hp<6, 4, 1>(wv, O.A_f1[0], O.A_f1_l[0], hs, [&]<int c>() { return parked.template operator()<0, 0, c>(); });
+        dense_rot_hp<6, 4, 1, HP>(wv, O.A_f1[0], O.A_f1_l[0], hs, [&]<int c>() { return parked.template operator()<0, 0, c>(); });
         const float c1 = opaque_s(P.sc.f1[0]);
         static_for<6>([&]<int To>() { static_for<16>([&]<int R>() { hs[To][R] = silu_n(hs[To][R] * c1); }); });
         f32x16 o0[2];
         static_for<2>([&]<int T>() { o0[T] = ldrows(wv, O.b_f2, T); });
-        dense_rot_hp<2, 12>(wv, O.A_f2[0], O.A_f2_l[0], o0, [&]<int c>() {
+        dense_rot_hp<2, 12, 2, HP>(wv, O.A_f2[0], O.A_f2_l[0], o0, [&]<int c>() {
             float t[8];
             static_for<8>([&]<int J>() { t[J] = hs[c / 2][8 * (c % 2) + J]; });
             return split8(t, kBS);
@@ -191,7 +191,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     static_for<NGT>([&]<int t>() { gt[t] = ldrows(wv, O.b_f1, 6 + t); });
     {
         // the gate tiles start at tile 6 of the same matrix (4 chunks per tile) -> shift the image offsets
-        dense_rot_hp<NGT, 4, 1>(wv, O.A_f1[0] + 6 * 4 * 256, O.A_f1_l[0] + 6 * 4 * 256, gt, [&]<int c>() { return parked.template operator()<0, 0, c>(); });
+        dense_rot_hp<NGT, 4, 1, HP>(wv, O.A_f1[0] + 6 * 4 * 256, O.A_f1_l[0] + 6 * 4 * 256, gt, [&]<int c>() { return parked.template operator()<0, 0, c>(); });
         const float c1 = opaque_s(P.sc.f1[0]);
         static_for<NGT>([&]<int t>() { static_for<16>([&]<int R>() { gt[t][R] = sigmoid_n(gt[t][R] * c1); }); });
     }
@@ -200,11 +200,11 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         const float c1 = opaque_s(P.sc.f1[1]);
         static_for<3>([&]<int t>() {
             static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] = 0.0f; }); });
-            dense_shared_hp<3, 2>(wv, O.A_f1[1], O.A_f1_l[1], 2, t, hh[t], [&]<int m, int c>() { return parked.template operator()<1, m, c>(); });
+            dense_shared_hp<3, 2, 2, HP>(wv, O.A_f1[1], O.A_f1_l[1], 2, t, hh[t], [&]<int m, int c>() { return parked.template operator()<1, m, c>(); });
             static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] *= gt[t][R] * c1; }); });
         });
         f32x16 o[3] = {{0}, {0}, {0}};
-        dense_shared_hp<3, 6>(wv, O.A_f2[1], O.A_f2_l[1], 6, 0, o, [&]<int m, int c>() {
+        dense_shared_hp<3, 6, 2, HP>(wv, O.A_f2[1], O.A_f2_l[1], 6, 0, o, [&]<int m, int c>() {
             float t[8];
             static_for<8>([&]<int J>() { t[J] = hh[c / 2][m][8 * (c % 2) + J]; });
             return split8(t, kBS);
@@ -217,12 +217,12 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         const float c1 = opaque_s(P.sc.f1[2]);
         static_for<2>([&]<int t>() {
             static_for<5>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] = 0.0f; }); });
-            dense_shared_hp<5, 1>(wv, O.A_f1[2], O.A_f1_l[2], 1, t, hh[t], [&]<int m, int c>() { return parked.template operator()<2, m, c>(); });
+            dense_shared_hp<5, 1, 2, HP>(wv, O.A_f1[2], O.A_f1_l[2], 1, t, hh[t], [&]<int m, int c>() { return parked.template operator()<2, m, c>(); });
             static_for<5>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] *= gt[3 + t][R] * c1; }); });
         });
         f32x16 o[5] = {{0}, {0}, {0}, {0}, {0}};
         // K = 48: chunks 0, 1 read hidden tile 0, chunk 2 the valid half of tile 1
-        dense_shared_hp<5, 3>(wv, O.A_f2[2], O.A_f2_l[2], 3, 0, o, [&]<int m, int c>() {
+        dense_shared_hp<5, 3, 2, HP>(wv, O.A_f2[2], O.A_f2_l[2], 3, 0, o, [&]<int m, int c>() {
             float t[8];
             static_for<8>([&]<int J>() { t[J] = hh[c / 2][m][8 * (c % 2) + J]; });
             return split8(t, kBS);
@@ -319,15 +319,15 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
             static_for<cdiv(pi.mul1, 32)>([&]<int To>() {
                 constexpr int NC2 = imin(2, (pi.mul1 - 32 * To) / 16);      // 16-channel chunks of this row tile
                 // operands of the final LinearRS for this tile's chunks, requested before the first-stage GEMM
-                f32x4 slh[NC2], sll[NC2];
+                f32x4 slh[NC2], sll[NC2] = {};
                 static_for<NC2>([&]<int cc>() {
                     constexpr int ci = stp_chunk_index<L>(p, 2 * To + cc);
                     slh[cc] = bld4(wv.w, wv.lane16, (O.A_sl[tp][l3] + ci * 256) * 4);
-                    sll[cc] = bld4(wv.w, wv.lane16, (O.A_sl_l[tp][l3] + ci * 256) * 4);
+                    if constexpr (!HP) sll[cc] = bld4(wv.w, wv.lane16, (O.A_sl_l[tp][l3] + ci * 256) * 4);
                 });
                 f32x16 T[d2];
                 static_for<d2>([&]<int j>() { static_for<16>([&]<int R>() { T[j][R] = 0.0f; }); });
-                dense_shared_hp<d2, NCK>(wv, O.A_s[tp][p], O.A_s_l[tp][p], NCK, To, T, [&]<int j, int c>() { return parked.template operator()<l2, j, c>(); });
+                dense_shared_hp<d2, NCK, 2, HP>(wv, O.A_s[tp][p], O.A_s_l[tp][p], NCK, To, T, [&]<int j, int c>() { return parked.template operator()<l2, j, c>(); });
                 static_for<NC2>([&]<int cc>() {
                     constexpr int u0 = 32 * To + 16 * cc;
                     float a[d3][8];
@@ -356,13 +356,16 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
                     const h8 ah = __builtin_bit_cast(h8, slh[cc]), al = __builtin_bit_cast(h8, sll[cc]);
                     if constexpr (l3 == 0) {
                         const HL b = split8(a[0], bsc);
-                        gacc = mfma_h(ah, b.hi, gacc); gacc = mfma_h(ah, b.lo, gacc); gacc = mfma_h(al, b.hi, gacc);
+                        gacc = mfma_h(ah, b.hi, gacc);
+                        if constexpr (!HP) { gacc = mfma_h(ah, b.lo, gacc); gacc = mfma_h(al, b.hi, gacc); }
                     } else {
                         HL b[3];
                         static_for<3>([&]<int K>() { b[K] = split8(a[K], bsc); });
                         static_for<3>([&]<int K>() { vacc[K] = mfma_h(ah, b[K].hi, vacc[K]); });
-                        static_for<3>([&]<int K>() { vacc[K] = mfma_h(ah, b[K].lo, vacc[K]); });
-                        static_for<3>([&]<int K>() { vacc[K] = mfma_h(al, b[K].hi, vacc[K]); });
+                        if constexpr (!HP) {
+                            static_for<3>([&]<int K>() { vacc[K] = mfma_h(ah, b[K].lo, vacc[K]); });
+                            static_for<3>([&]<int K>() { vacc[K] = mfma_h(al, b[K].hi, vacc[K]); });
+                        }
                     }
                 });
                 (void)NCL;

@@ -41,6 +41,7 @@ class HeadConfig:
     irreps_mlp_mid: int = 3
     max_neighbors: int = 1000
     ebm: bool = False                    # EbmScoreModelHead (reference score_head_ebm.py): energy critic, no time encoding
+    half_gemm: bool = False              # the reference's half_precision knob (agent.py:50-51): single-term fp16 GEMM products
 
     @property
     def n_scales(self) -> int:

@@ -48,7 +48,8 @@ class ScoreModelHead(torch.nn.Module):
                  device: Union[str, torch.device, None] = None,
                  init_seed: int = 2,
                  max_edges: int = 0,
-                 ebm: bool = False):
+                 ebm: bool = False,
+                 half_precision: bool = False):
         super().__init__()
         kw = dict(ebm=ebm, max_time=max_time, time_emb_mlp=list(time_emb_mlp), key_tensor_field_kwargs=dict(key_tensor_field_kwargs),
                   irreps_query_edf=irreps_query_edf, lin_mult=lin_mult, ang_mult=ang_mult, time_enc_n=time_enc_n,
@@ -56,6 +57,7 @@ class ScoreModelHead(torch.nn.Module):
         if not edge_time_encoding and not query_time_encoding and not ebm:
             raise NotImplementedError("No time encoding! Are you sure?")          # reference score_head.py:72-73
         self.cfg = HeadConfig.from_kwargs(kw)
+        self.cfg.half_gemm = bool(half_precision)
         self.lin_mult, self.ang_mult = float(lin_mult), float(ang_mult)
         self.n_scales = self.cfg.n_scales
         self.max_time = float(max_time)
@@ -100,6 +102,22 @@ class ScoreModelHead(torch.nn.Module):
         if self._handle is not None:
             _lib.load().dedf_destroy(self._handle)
             self._handle = None
+
+    def half(self):
+        """``model.half()`` is how the reference switches to half precision (agent.py:50-51).  Here it selects the half-precision
+        GEMM mode of the kernels (every GEMM one fp16 MFMA product with fp32 accumulation instead of the 3-term split; tensor
+        products, norms, softmax and the SE(3) update stay fp32).  Parameters are kept as fp32 master copies; fp16 inputs are
+        accepted at the boundary."""
+        if self.cfg.ebm or self.cfg.fc_neurons[0] != 128:
+            raise NotImplementedError("half precision: score head with the [256,128,64] time MLP only")
+        self.cfg.half_gemm = True
+        self._release()
+        return self
+
+    def float(self):
+        self.cfg.half_gemm = False
+        self._release()
+        return super().float()
 
     def refresh_weights(self):
         """call after load_state_dict(): the packed device image is rebuilt on next use"""

@@ -63,6 +63,8 @@ typedef struct dedf_config {
     int64_t max_edges;                   /* edge workspace capacity per call; 0 = auto */
     int ebm;                             /* 1: EbmScoreModelHead (score_head_ebm.py): energy critic, no time encoding, fc_neurons[0] = 64,
                                             no lin/ang_vel_tp parameters; only dedf_energy is available.  0: ScoreModelHead */
+    int half_gemm;                       /* 1: the reference's half_precision knob (agent.py:29,50-51 `model.half()`): every GEMM as ONE fp16 MFMA product
+                                            (fp16 operands, fp32 accumulate) instead of the 3-term split; everything else stays fp32.  0: default */
 } dedf_config;
 
 typedef struct dedf_schedule {           /* host arrays, one entry per denoising step (score_model_base.py:146-171) */

@@ -59,11 +59,13 @@ def oracle_run(kw, P, keys, query, Ts, time, dtype):
     return ang, lin, dbg, ocfg
 
 
-def gpu_run(kw, P, keys, query, Ts, time, debug=True):
+def gpu_run(kw, P, keys, query, Ts, time, debug=True, half=False):
     dev = torch.device('cuda:0')
     head = ScoreModelHead(**kw)
     head.load_state_dict(P)
     head.to(dev)
+    if half:
+        head.half()          # the reference's half_precision switch (agent.py:50-51)
     gkeys = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
     gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
     head.set_key_clouds(gkeys)
@@ -75,11 +77,11 @@ def gpu_run(kw, P, keys, query, Ts, time, debug=True):
     return head, ang.cpu(), lin.cpu()
 
 
-def stage_report(lmax=2, nT=6, n_scene=512, n_grasp=100, verbose=True, **kwargs):
+def stage_report(lmax=2, nT=6, n_scene=512, n_grasp=100, verbose=True, half=False, **kwargs):
     kw, cfg, P, keys, query, Ts, time = build_case(lmax, nT, n_scene, n_grasp, **kwargs)
     ang64, lin64, d64, ocfg = oracle_run(kw, P, keys, query, Ts, time, torch.float64)
     ang32, lin32, d32, _ = oracle_run(kw, P, keys, query, Ts, time, torch.float32)
-    head, ang, lin = gpu_run(kw, P, keys, query, Ts, time)
+    head, ang, lin = gpu_run(kw, P, keys, query, Ts, time, half=half)
     muls = cfg.muls
     D = cfg.dim
     nQ = len(query.x)

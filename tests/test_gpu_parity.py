@@ -29,6 +29,17 @@ def _check(rep, stages=True):
 
 
 @pytest.mark.parametrize("lmax", [1, 2])
+def test_half_precision_mode(lmax):
+    """`model.half()` (reference agent.py:50-51): GEMMs as single fp16 MFMA products.  Stated tolerance 5e-3 of the score
+    scale (fp16 operands carry 2^-11 relative error; the reference's own half mode also rounds every activation to fp16);
+    the mode must really be different from the default one."""
+    rep = SC.stage_report(lmax=lmax, nT=5, n_scene=512, n_grasp=100, verbose=False, half=True)
+    assert rep['edges_gpu'] == rep['edges_oracle'] and rep['edge_set_equal']
+    assert rep['final_ang'] < 5e-3 and rep['final_lin'] < 5e-3, rep
+    assert max(rep['final_ang'], rep['final_lin']) > 3e-5, rep
+
+
+@pytest.mark.parametrize("lmax", [1, 2])
 def test_score_parity_fake_input_style(lmax):
     """sizes of ScoreModelHead._get_fake_input (reference score_head.py:220-246): a few poses, ~100 key points"""
     _check(SC.stage_report(lmax=lmax, nT=5, n_scene=512, n_grasp=100, verbose=False))
