@@ -1,5 +1,6 @@
 // libdedf.so — host side of the C ABI declared in include/dedf.h (see there for the reference interfaces replaced).
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++20 -shared -fPIC dedf_api.hip -o libdedf.so   (gfx950 only, no fallbacks)
+// Build: __graft_entry__.build() (dedf_api.hip + dedf_kernels.hip x kKernelUnits, compiled in parallel), or in one piece:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++20 -shared -fPIC -DDEDF_SINGLE_TU dedf_api.hip -o libdedf.so   (gfx950 only, no fallbacks)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -8,43 +9,17 @@
 #include <string>
 #include <vector>
 #include "../../include/dedf.h"
-#include "dedf_edge.h"
 #include "dedf_misc.h"
-#include "dedf_node.h"
 #include "dedf_pack.h"
 
 using namespace dedf;
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// the two fused kernels: persistent waves striding over tiles (tile count lives on the device: no host round trip)
-// ---------------------------------------------------------------------------------------------------------------------------
-template <int L, int F0, bool HP = false> __global__ __launch_bounds__(64, 1) void k_edge(EdgeParams P) {
-    const int* ti = P.tile_info;
-    const int ntiles = ti[P.n_scales];
-    const Wave wv = make_wave(P.W, P.W_bytes);
-#if defined(DEDF_PHASE_PROF)
-    unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#include "dedf_kernels.h"
+#if !defined(DEDF_SINGLE_TU)
+#define DEDF_DECL(unit, ...) extern template __global__ __VA_ARGS__;
+DEDF_KERNEL_LIST(DEDF_DECL)
+#undef DEDF_DECL
 #endif
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        int scale = 0;
-        while (t >= ti[scale + 1]) ++scale;
-        const int k = t - ti[scale];
-        const int ebase = ti[16 + scale], En = ti[16 + scale + 1] - ebase;
-#if defined(DEDF_PHASE_PROF)
-        edge_tile<L, F0, HP>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k), pacc);
-#else
-        edge_tile<L, F0, HP>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k));
-#endif
-    }
-#if defined(DEDF_PHASE_PROF)
-    if (P.phase_prof && wv.lane == 0) for (int i = 0; i < 16; ++i) P.phase_prof[blockIdx.x * 16 + i] += pacc[i];
-#endif
-}
-template <int L, bool EBM, bool HP = false> __global__ __launch_bounds__(64, 1) void k_node(NodeParams P) {
-    const Wave wv = make_wave(P.W, P.W_bytes);
-    const int ntiles = (P.n_nodes + 31) / 32;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) node_tile<L, EBM, HP>(P, wv, t * 32);
-}
 __global__ void k_energy_reduce(const float* __restrict__ node_out, int nT, int nQ, float* __restrict__ energy) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nT) return;

@@ -1,0 +1,54 @@
+// The two fused kernels: persistent waves striding over tiles (tile count lives on the device: no host round trip).
+// Their instantiations are compiled in separate translation units (dedf_kernels.hip, one -DDEDF_KUNIT=n each, built in
+// parallel by __graft_entry__.build()); dedf_api.hip only declares them (extern template) unless DEDF_SINGLE_TU is defined.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dedf_edge.h"
+#include "dedf_node.h"
+
+using namespace dedf;
+
+template <int L, int F0, bool HP = false> __global__ __launch_bounds__(64, 1) void k_edge(EdgeParams P) {
+    const int* ti = P.tile_info;
+    const int ntiles = ti[P.n_scales];
+    const Wave wv = make_wave(P.W, P.W_bytes);
+#if defined(DEDF_PHASE_PROF)
+    unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int scale = 0;
+        while (t >= ti[scale + 1]) ++scale;
+        const int k = t - ti[scale];
+        const int ebase = ti[16 + scale], En = ti[16 + scale + 1] - ebase;
+#if defined(DEDF_PHASE_PROF)
+        edge_tile<L, F0, HP>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k), pacc);
+#else
+        edge_tile<L, F0, HP>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k));
+#endif
+    }
+#if defined(DEDF_PHASE_PROF)
+    if (P.phase_prof && wv.lane == 0) for (int i = 0; i < 16; ++i) P.phase_prof[blockIdx.x * 16 + i] += pacc[i];
+#endif
+}
+template <int L, bool EBM, bool HP = false> __global__ __launch_bounds__(64, 1) void k_node(NodeParams P) {
+    const Wave wv = make_wave(P.W, P.W_bytes);
+    const int ntiles = (P.n_nodes + 31) / 32;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) node_tile<L, EBM, HP>(P, wv, t * 32);
+}
+
+// every instantiation the library launches: X(unit, declaration)
+#define DEDF_KERNEL_LIST(X)                                           \
+    X(0, void k_edge<2, 128, false>(EdgeParams))                      \
+    X(1, void k_edge<2, 128, true>(EdgeParams))                       \
+    X(2, void k_edge<2, 64, false>(EdgeParams))                       \
+    X(3, void k_edge<2, 192, false>(EdgeParams))                      \
+    X(4, void k_edge<1, 64, false>(EdgeParams))                       \
+    X(4, void k_edge<1, 128, false>(EdgeParams))                      \
+    X(4, void k_edge<1, 128, true>(EdgeParams))                       \
+    X(5, void k_node<2, false, false>(NodeParams))                    \
+    X(5, void k_node<2, false, true>(NodeParams))                     \
+    X(6, void k_node<2, true, false>(NodeParams))                     \
+    X(6, void k_node<1, false, false>(NodeParams))                    \
+    X(6, void k_node<1, false, true>(NodeParams))                     \
+    X(6, void k_node<1, true, false>(NodeParams))
+constexpr int kKernelUnits = 7;

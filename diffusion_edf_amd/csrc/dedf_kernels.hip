@@ -1,0 +1,44 @@
+// Explicit instantiations of the fused kernels, one group per -DDEDF_KUNIT=n (see dedf_kernels.h).
+#include "dedf_kernels.h"
+#ifndef DEDF_KUNIT
+#error "compile with -DDEDF_KUNIT=<0..kKernelUnits-1>"
+#endif
+#define DEDF_INST(unit, ...) DEDF_INST_##unit(__VA_ARGS__)
+#define DEDF_SEL(...) template __global__ __VA_ARGS__;
+#define DEDF_NOP(...)
+#if DEDF_KUNIT == 0
+#define DEDF_INST_0(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_0(...) DEDF_NOP(__VA_ARGS__)
+#endif
+#if DEDF_KUNIT == 1
+#define DEDF_INST_1(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_1(...) DEDF_NOP(__VA_ARGS__)
+#endif
+#if DEDF_KUNIT == 2
+#define DEDF_INST_2(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_2(...) DEDF_NOP(__VA_ARGS__)
+#endif
+#if DEDF_KUNIT == 3
+#define DEDF_INST_3(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_3(...) DEDF_NOP(__VA_ARGS__)
+#endif
+#if DEDF_KUNIT == 4
+#define DEDF_INST_4(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_4(...) DEDF_NOP(__VA_ARGS__)
+#endif
+#if DEDF_KUNIT == 5
+#define DEDF_INST_5(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_5(...) DEDF_NOP(__VA_ARGS__)
+#endif
+#if DEDF_KUNIT == 6
+#define DEDF_INST_6(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_6(...) DEDF_NOP(__VA_ARGS__)
+#endif
+DEDF_KERNEL_LIST(DEDF_INST)
