@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -292,11 +293,12 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
 #if defined(DEDF_PHASE_PROF)
         if (h->d_phase.ensure((size_t)h->n_cu * 4 * 16 * 8)) P.phase_prof = h->d_phase.as<unsigned long long>();
 #endif
+        static const int wpc = [] { const char* e = getenv("DEDF_EDGE_WAVES_PER_CU"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 4 ? v : 4; }();   // experiments only
         // half_gemm (the reference's half_precision knob): single-term fp16 products; instantiated for the 128-wide score head only
         if constexpr (F0 == 128) {
-            if (h->cfg.half_gemm) hipLaunchKernelGGL((k_edge<L, F0, true>), dim3(h->n_cu * 4), dim3(64), 0, st, P);
-            else hipLaunchKernelGGL((k_edge<L, F0>), dim3(h->n_cu * 4), dim3(64), 0, st, P);
-        } else hipLaunchKernelGGL((k_edge<L, F0>), dim3(h->n_cu * 4), dim3(64), 0, st, P);
+            if (h->cfg.half_gemm) hipLaunchKernelGGL((k_edge<L, F0, true>), dim3(h->n_cu * wpc), dim3(64), 0, st, P);
+            else hipLaunchKernelGGL((k_edge<L, F0>), dim3(h->n_cu * wpc), dim3(64), 0, st, P);
+        } else hipLaunchKernelGGL((k_edge<L, F0>), dim3(h->n_cu * wpc), dim3(64), 0, st, P);
     }
     mark();
     // 5. joint softmax + aggregation

@@ -1,3 +1,6 @@
+# Per-phase cycle profile of k_edge.  Build the instrumented library first (single translation unit):
+#   cd diffusion_edf_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++20 -shared -fPIC -DDEDF_SINGLE_TU -DDEDF_PHASE_PROF -I../../include dedf_api.hip -o libdedf_prof.so
+#   DEDF_LIB=diffusion_edf_amd/csrc/libdedf_prof.so python tests/phase_prof.py
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import bench
