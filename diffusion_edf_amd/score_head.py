@@ -201,6 +201,22 @@ class ScoreModelHead(torch.nn.Module):
     def warmup(self, Ts, key_pcd_multiscale, query_pcd, time):                         # reference score_head.py:213-218
         return self.forward(Ts=Ts, key_pcd_multiscale=key_pcd_multiscale, query_pcd=query_pcd, time=time)
 
+    def _get_fake_input(self):
+        """Random inputs of the reference's shapes (score_head.py:220-246: 5 poses, 100 key points per scale, 10 query points);
+        `Irreps.randn` draws N(0,1) per component, `random_quaternions` a normalised N(0,1)^4 with w >= 0 (transforms.py:349-355)."""
+        device = next(iter(self.parameters())).device
+        nT, nP, nQ = 5, 100, 10
+        q = torch.randn(nT, 4, device=device)
+        q = q / q.norm(dim=-1, keepdim=True)
+        q = torch.where(q[:, :1] < 0, -q, q)
+        Ts = torch.cat([q, torch.randn(nT, 3, device=device)], dim=-1)
+        time = torch.rand(nT, device=device)
+        key_pcd_multiscale = [FeaturedPoints(x=torch.randn(nP, 3, device=device), f=torch.randn(nP, self.key_edf_dim, device=device),
+                                             b=torch.zeros(nP, device=device, dtype=torch.long)) for _ in range(self.n_scales)]
+        query_pcd = FeaturedPoints(x=torch.randn(nQ, 3, device=device), f=torch.randn(nQ, self.query_edf_dim, device=device),
+                                   b=torch.zeros(nQ, device=device, dtype=torch.long), w=torch.ones(nQ, device=device))
+        return Ts, key_pcd_multiscale, query_pcd, time
+
     # ------------------------------------------------------------------------------------------------------------------
     def stats(self) -> dict:
         lib = _lib.load()

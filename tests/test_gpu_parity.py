@@ -28,6 +28,17 @@ def _check(rep, stages=True):
                 assert v < 2e-4, (k, v)
 
 
+def test_fake_input_runs_through_warmup():
+    """reference score_head.py:213-246: `warmup(*_get_fake_input())` is what agent.py uses to trigger compilation"""
+    from diffusion_edf_amd import synthetic
+    from diffusion_edf_amd.score_head import ScoreModelHead
+    head = ScoreModelHead(**synthetic.score_head_kwargs(2)).to('cuda:0')
+    Ts, keys, query, time = head._get_fake_input()
+    assert Ts.shape == (5, 7) and len(keys) == head.n_scales and keys[0].f.shape == (100, head.key_edf_dim) and query.x.shape == (10, 3)
+    ang, lin = head.warmup(Ts, keys, query, time)
+    assert ang.shape == (5, 3) and lin.shape == (5, 3) and torch.isfinite(ang).all() and torch.isfinite(lin).all()
+
+
 @pytest.mark.parametrize("lmax", [1, 2])
 def test_half_precision_mode(lmax):
     """`model.half()` (reference agent.py:50-51): GEMMs as single fp16 MFMA products.  Stated tolerance 5e-3 of the score
