@@ -230,6 +230,13 @@ DEDF_DEV h8 relane16(h8 v) {
 }
 DEDF_DEV h4 half4(h8 v, int s) { return s == 0 ? __builtin_shufflevector(v, v, 0, 1, 2, 3) : __builtin_shufflevector(v, v, 4, 5, 6, 7); }
 
+// A finished accumulator tile that the VALU reads next: pin it to architectural VGPRs here, so that the MFMAs write it there
+// directly instead of into AGPRs followed by 16 v_accvgpr_read copies.
+DEDF_DEV void to_vgpr(f32x16& t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(t));
+#endif
+}
 // Returns v, but as an opaque function of `dep`: a request whose address goes through tie() cannot be issued before `dep`
 // exists, and (volatile) keeps its place between the scheduling fences.  hipcc otherwise lets the pure MFMA / VALU work drift
 // below the fences while the operand requests stay put, so that a whole layer's operands end up in flight (and spilled).

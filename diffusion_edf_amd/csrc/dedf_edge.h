@@ -236,7 +236,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         const int oA = opaque_s(P.o_A_pre + scale * (NH * 4 * 256)), oAl = opaque_s(P.o_A_pre_l + scale * (NH * 4 * 256));
         static_for<NH>([&]<int To>() { h[To] = ldrows(tbb, tvoff, scale * F0, To); });
         dense_rot_h<NH, 4, 2, HP>(wv, oA, oAl, h, [&]<int c, int j>() { return eb[8 * c + j]; });
-        static_for<NH>([&]<int To>() { static_for<16>([&]<int R>() { h[To][R] = siluf(h[To][R]); }); });
+        static_for<NH>([&]<int To>() { to_vgpr(h[To]); static_for<16>([&]<int R>() { h[To][R] = siluf(h[To][R]); }); });
     }
     DEDF_STAMP(1);
     // ---- RadialProfile layers 1, 2 (equiformer/radial_func.py:11-60) ---------------------------------------------------
@@ -244,12 +244,14 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     static_for<4>([&]<int To>() { r1[To] = ldrows(wv, o_b_r1, To); });
     dense_rot_h<4, F0 / 16, 1, HP>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return h[c / 2][8 * (c % 2) + j]; });
     DEDF_STAMP(2);
+    static_for<4>([&]<int To>() { to_vgpr(r1[To]); });
     ln_silu<4>(r1, wv, o_g_r1, o_be_r1);
     DEDF_STAMP(3);
     f32x16 r2[2];
     static_for<2>([&]<int To>() { r2[To] = ldrows(wv, o_b_r2, To); });
     dense_rot_h<2, 8, 2, HP>(wv, o_A_r2, o_A_r2_l, r2, [&]<int c, int j>() { return r1[c / 2][8 * (c % 2) + j]; });
     DEDF_STAMP(4);
+    static_for<2>([&]<int To>() { to_vgpr(r2[To]); });
     ln_silu<2>(r2, wv, o_g_r2, o_be_r2);
     DEDF_STAMP(5);
 
@@ -345,6 +347,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 if constexpr (!HP) { t = mfma_h(ah, r2s[c0 + k].lo, t); t = mfma_h(al, r2s[c0 + k].hi, t); }
             });
             w = t;
+            if constexpr (Ph % 2 == 1) to_vgpr(w);      // finished tile: the VALU stage reads it
         }
     };
     auto dump_w = [&]<int Tw>(const f32x16& w) {      // debug only: back to the e3nn weight order
