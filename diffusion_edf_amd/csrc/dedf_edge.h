@@ -62,9 +62,29 @@ template <int L> struct SH {           // spherical harmonics of one edge, non-s
     }
 };
 
+// ---- per-row vectors (biases, LayerNorm affine, layer-3 offsets, alpha_dot) live in LDS ---------------------------------
+// They are the same for every tile and identical inside a half-wave; read through the vector L1 every tile they were 41
+// row tiles x 4 KiB = 29 % of the kernel's L1 delivery for 5.5 KiB of data.  Each wave copies them once into its own LDS
+// (k_edge prologue) and reads them back with broadcast ds_read_b128.  Offsets in floats, layout [tile][half][16] as packed.
+template <int L> struct RowsLds {
+    static constexpr int b1 = 0, g1 = 128, be1 = 256, b2 = 384, g2 = 448, be2 = 512, off3 = 576;
+    static constexpr int b0 = off3 + dtp_wn<L>(), val0 = b0 + r0_tiles<L>() * 32, adot = val0 + 64, total = adot + 64;
+};
+template <int L> DEDF_DEV float* rows_lds() {
+    __shared__ __attribute__((aligned(16))) float rows[RowsLds<L>::total];
+    return rows;
+}
+// accumulator tile <- 16 per-row values of row tile `tile` of the vector at LDS offset `off`
+DEDF_DEV f32x16 ldrows_lds(const float* rows, int hi, int off, int tile) {
+    f32x16 v;
+    const f32x4* p = reinterpret_cast<const f32x4*>(rows + off + tile * 32 + hi * 16);
+    static_for<4>([&]<int G>() { const f32x4 t = p[G]; v[4 * G] = t[0]; v[4 * G + 1] = t[1]; v[4 * G + 2] = t[2]; v[4 * G + 3] = t[3]; });
+    return v;
+}
+
 // LayerNorm over NT*32 channels of one item (rows split over lane and lane^32) followed by SiLU
 template <int NT>
-DEDF_DEV void ln_silu(f32x16 (&x)[NT], const Wave& wv, int o_gamma, int o_beta) {
+DEDF_DEV void ln_silu(f32x16 (&x)[NT], const Wave& wv, const float* rows, int o_gamma, int o_beta) {
     float s = 0.0f;
     static_for<NT>([&]<int T>() { static_for<16>([&]<int R>() { s += x[T][R]; }); });
     s += xor32(s);
@@ -74,7 +94,7 @@ DEDF_DEV void ln_silu(f32x16 (&x)[NT], const Wave& wv, int o_gamma, int o_beta) 
     v += xor32(v);
     const float rstd = 1.0f / sqrtf(v * (1.0f / (NT * 32)) + 1e-5f);
     static_for<NT>([&]<int T>() {
-        const f32x16 g = ldrows(wv, o_gamma, T), b = ldrows(wv, o_beta, T);
+        const f32x16 g = ldrows_lds(rows, wv.hi, o_gamma, T), b = ldrows_lds(rows, wv.hi, o_beta, T);
         static_for<16>([&]<int R>() { x[T][R] = siluf((x[T][R] - mean) * rstd * g[R] + b[R]); });
     });
 }
@@ -149,6 +169,20 @@ DEDF_DEV void split_chunk(const float (&v)[2 * l3 + 1][8], BOpsH<L>& o) {
     static_for<2 * l3 + 1>([&]<int K>() { const HL sp = split8(v[K]); o.hi[K] = sp.hi; o.lo[K] = sp.lo; });
 }
 
+// once per wave, before its first tile: copy the row vectors into LDS
+template <int L>
+DEDF_DEV void edge_rows_to_lds(const EdgeParams& P, const Wave& wv) {
+    using RL = RowsLds<L>;
+    float* rows = rows_lds<L>();
+    auto cp = [&](int dst, int src, int n) { for (int i = wv.lane; i < n; i += 64) rows[dst + i] = P.W[src + i]; };
+    cp(RL::b1, P.o_b_r1, 128); cp(RL::g1, P.o_g_r1, 128); cp(RL::be1, P.o_be_r1, 128);
+    cp(RL::b2, P.o_b_r2, 64); cp(RL::g2, P.o_g_r2, 64); cp(RL::be2, P.o_be_r2, 64);
+    cp(RL::off3, P.o_off_r3, dtp_wn<L>()); cp(RL::b0, P.o_b_r0, r0_tiles<L>() * 32);
+    cp(RL::val0, P.o_b_val0, 64); cp(RL::adot, P.o_alpha_dot, 64);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
+
 template <int L, int F0, bool HP = false>
 DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, int n_valid DEDF_PROF_ARG) {
 #if defined(DEDF_PHASE_PROF) && defined(__HIP_DEVICE_COMPILE__)
@@ -160,12 +194,11 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     constexpr int NWT = WN / 32;
     constexpr int NR0 = r0_tiles<L>();
     const int hi = wv.hi;
+    using RL = RowsLds<L>;
+    const float* const rows = rows_lds<L>();
     // weight-image offsets, re-materialised per tile (see opaque_s)
-    const int o_A_r1 = opaque_s(P.o_A_r1), o_b_r1 = opaque_s(P.o_b_r1), o_g_r1 = opaque_s(P.o_g_r1), o_be_r1 = opaque_s(P.o_be_r1);
-    const int o_A_r2 = opaque_s(P.o_A_r2), o_b_r2 = opaque_s(P.o_b_r2), o_g_r2 = opaque_s(P.o_g_r2), o_be_r2 = opaque_s(P.o_be_r2);
-    const int o_A_r3 = opaque_s(P.o_A_r3), o_off_r3 = opaque_s(P.o_off_r3), o_b_r0 = opaque_s(P.o_b_r0);
+    const int o_A_r1 = opaque_s(P.o_A_r1), o_A_r2 = opaque_s(P.o_A_r2), o_A_r3 = opaque_s(P.o_A_r3);
     const int o_A_r1_l = opaque_s(P.o_A_r1_l), o_A_r2_l = opaque_s(P.o_A_r2_l), o_A_r3_l = opaque_s(P.o_A_r3_l);
-    const int o_b_val0 = opaque_s(P.o_b_val0), o_alpha_dot = opaque_s(P.o_alpha_dot);
     const bool valid = wv.col < n_valid;
     const int e = e0 + (valid ? wv.col : 0);
     const int src = P.edge_src[e], dst = P.edge_dst[e];
@@ -241,18 +274,18 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     DEDF_STAMP(1);
     // ---- RadialProfile layers 1, 2 (equiformer/radial_func.py:11-60) ---------------------------------------------------
     f32x16 r1[4];
-    static_for<4>([&]<int To>() { r1[To] = ldrows(wv, o_b_r1, To); });
+    static_for<4>([&]<int To>() { r1[To] = ldrows_lds(rows, hi, RL::b1, To); });
     dense_rot_h<4, F0 / 16, 1, HP>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return h[c / 2][8 * (c % 2) + j]; });
     DEDF_STAMP(2);
     static_for<4>([&]<int To>() { to_vgpr(r1[To]); });
-    ln_silu<4>(r1, wv, o_g_r1, o_be_r1);
+    ln_silu<4>(r1, wv, rows, RL::g1, RL::be1);
     DEDF_STAMP(3);
     f32x16 r2[2];
-    static_for<2>([&]<int To>() { r2[To] = ldrows(wv, o_b_r2, To); });
+    static_for<2>([&]<int To>() { r2[To] = ldrows_lds(rows, hi, RL::b2, To); });
     dense_rot_h<2, 8, 2, HP>(wv, o_A_r2, o_A_r2_l, r2, [&]<int c, int j>() { return r1[c / 2][8 * (c % 2) + j]; });
     DEDF_STAMP(4);
     static_for<2>([&]<int To>() { to_vgpr(r2[To]); });
-    ln_silu<2>(r2, wv, o_g_r2, o_be_r2);
+    ln_silu<2>(r2, wv, rows, RL::g2, RL::be2);
     DEDF_STAMP(5);
 
     // ---- layer 3 (-> per-edge TP weights, one 32-row tile at a time) fused with DTP #1 and the lin / sep_alpha GEMMs ----
@@ -320,10 +353,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         static_for<8>([&]<int J>() { t[J] = r2[c / 2][8 * (c % 2) + J]; });
         r2s[c] = split8(t);
     });
-    {   // accumulator init (lin / sep_alpha biases), requested only now
-        const int hv = tie(wv.hi64, __builtin_bit_cast(f32x4, r2s[3].lo)[3]);
-        static_for<NR0>([&]<int T>() { acc0[T] = ldrows(wv.w, hv, o_b_r0, T); });
-    }
+    static_for<NR0>([&]<int T>() { acc0[T] = ldrows_lds(rows, hi, RL::b0, T); });      // accumulator init: lin / sep_alpha biases
     // Layer-3 work unit = half a weight tile (2 of the 4 K-chunks, 6 MFMAs).  Half P = 2 T + half of tile T runs in pipeline
     // region P - 3 into wbuf[T % 2]; its operands (and the tile's offset rows, the accumulator init) are requested one region
     // earlier, across a scheduling fence, so that the request cannot sink next to its use.
@@ -336,7 +366,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         });
         return o;
     };
-    auto load_off = [&]<int T>() { f32x16 o{}; if constexpr (T < NWT) o = ldrows(wv, o_off_r3, T); return o; };
+    auto load_off = [&]<int T>() { f32x16 o{}; if constexpr (T < NWT) o = ldrows_lds(rows, hi, RL::off3, T); return o; };
     auto run_l3 = [&]<int Ph>(const L3Half& a, const f32x16& init, f32x16& w) {
         if constexpr (Ph < 2 * NWT) {
             constexpr int c0 = 2 * (Ph % 2);
@@ -365,8 +395,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             constexpr int AT = alpha_row0<L>() / 32;
             static_for<kHeads>([&]<int hd>() {
                 constexpr int T = AT + (hd >> 1), r0 = 8 * (hd & 1);
-                const f32x4 d0 = bld4(wv.w, wv.hi64, (o_alpha_dot + (hd >> 1) * 32 + r0) * 4);
-                const f32x4 d1v = bld4(wv.w, wv.hi64, (o_alpha_dot + (hd >> 1) * 32 + r0 + 4) * 4);
+                const f32x4* adp = reinterpret_cast<const f32x4*>(rows + RL::adot + (hd >> 1) * 32 + hi * 16 + r0);
+                const f32x4 d0 = adp[0], d1v = adp[1];
                 float sum = 0.0f;
                 static_for<4>([&]<int R>() { sum += slrelu_n(acc0[T][r0 + R] * cl0) * d0[R]; });
                 static_for<4>([&]<int R>() { sum += slrelu_n(acc0[T][r0 + 4 + R] * cl0) * d1v[R]; });
@@ -447,7 +477,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // ---- sep_value: depth-wise TP #2 (shared weights folded into the A stream) + LinearRS -> value --------------------------
     // same walk: l3 = 0 chunks -> val0, l3 = 1 / 2 -> val1[m] / val2[m]; a completed group goes straight to the edge record
     f32x16 val0[2], val1[3], val2[5];
-    static_for<2>([&]<int T>() { val0[T] = ldrows(wv, o_b_val0, T); });
+    static_for<2>([&]<int T>() { val0[T] = ldrows_lds(rows, hi, RL::val0, T); });
     struct XPark { f32x4 a[2 * L + 1][2]; };      // parked gated features of a chunk's 8 channels (per lane)
     auto load_park = [&]<int C>() {
         XPark o{};

@@ -15,6 +15,7 @@ template <int L, int F0, bool HP = false> __global__ __launch_bounds__(64, 1) vo
 #if defined(DEDF_PHASE_PROF)
     unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+    edge_rows_to_lds<L>(P, wv);
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         int scale = 0;
         while (t >= ti[scale + 1]) ++scale;
