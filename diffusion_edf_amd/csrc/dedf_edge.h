@@ -68,7 +68,8 @@ template <int L> struct SH {           // spherical harmonics of one edge, non-s
 // (k_edge prologue) and reads them back with broadcast ds_read_b128.  Offsets in floats, layout [tile][half][16] as packed.
 template <int L> struct RowsLds {
     static constexpr int b1 = 0, g1 = 128, be1 = 256, b2 = 384, g2 = 448, be2 = 512, off3 = 576;
-    static constexpr int b0 = off3 + dtp_wn<L>(), val0 = b0 + r0_tiles<L>() * 32, adot = val0 + 64, total = adot + 64;
+    static constexpr int b0 = off3 + dtp_wn<L>(), val0 = b0 + r0_tiles<L>() * 32, adot = val0 + 64;
+    static constexpr int enc = adot + 64, total = enc + 192;      // enc: length-encoder constants of the scale being processed
 };
 template <int L> DEDF_DEV float* rows_lds() {
     __shared__ __attribute__((aligned(16))) float rows[RowsLds<L>::total];
@@ -183,6 +184,15 @@ DEDF_DEV void edge_rows_to_lds(const EdgeParams& P, const Wave& wv) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 }
 
+// whenever a wave moves on to tiles of another scale: that scale's length-encoder constants (192 floats)
+template <int L>
+DEDF_DEV void edge_enc_to_lds(const EdgeParams& P, const Wave& wv, int scale) {
+    float* rows = rows_lds<L>();
+    for (int i = wv.lane; i < 192; i += 64) rows[RowsLds<L>::enc + i] = P.W[P.o_enc + scale * 192 + i];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
+
 template <int L, int F0, bool HP = false>
 DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, int n_valid DEDF_PROF_ARG) {
 #if defined(DEDF_PHASE_PROF) && defined(__HIP_DEVICE_COMPILE__)
@@ -237,14 +247,11 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // ---- length embedding: this lane's 32 of the 64 channels (k = s + 32*hi) ------------------------------------------
     float eb[32];
     {
-        const int o_enc = P.o_enc + scale * 192;
-        const int hi128 = hi * 128;
+        const f32x4* const enc = reinterpret_cast<const f32x4*>(rows + RL::enc);       // this scale's constants (edge_enc_to_lds)
         if (radius > 0.0f) {           // GaussianRadialBasis, radial_func.py:208-227
             const float t = len / radius;
             static_for<8>([&]<int G>() {
-                const f32x4 mu = bld4(wv.w, hi128, (o_enc + 4 * G) * 4);
-                const f32x4 is = bld4(wv.w, hi128, (o_enc + 64 + 4 * G) * 4);
-                const f32x4 w = bld4(wv.w, hi128, (o_enc + 128 + 4 * G) * 4);
+                const f32x4 mu = enc[hi * 8 + G], is = enc[16 + hi * 8 + G], w = enc[32 + hi * 8 + G];
                 static_for<4>([&]<int J>() {
                     const float z = (t - mu[J]) * is[J];
                     eb[4 * G + J] = fexp(-0.5f * (z * z)) * w[J];
@@ -253,7 +260,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         } else {                       // SinusoidalPositionEmbeddings(n = 1000), radial_func.py:305-316
             const float x = len / P.len_enc_max_r * 1000.0f;
             static_for<8>([&]<int G>() {
-                const f32x4 fr = bld4(wv.w, 0, (o_enc + 4 * G) * 4);
+                const f32x4 fr = enc[G];
                 static_for<4>([&]<int J>() { eb[4 * G + J] = sin_or_cos(x * fr[J], hi); });
             });
         }

@@ -16,9 +16,11 @@ template <int L, int F0, bool HP = false> __global__ __launch_bounds__(64, 1) vo
     unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     edge_rows_to_lds<L>(P, wv);
+    int enc_scale = -1;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         int scale = 0;
         while (t >= ti[scale + 1]) ++scale;
+        if (scale != enc_scale) { edge_enc_to_lds<L>(P, wv, scale); enc_scale = scale; }
         const int k = t - ti[scale];
         const int ebase = ti[16 + scale], En = ti[16 + scale + 1] - ebase;
 #if defined(DEDF_PHASE_PROF)
