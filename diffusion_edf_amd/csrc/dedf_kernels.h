@@ -36,6 +36,7 @@ template <int L, int F0, bool HP = false> __global__ __launch_bounds__(64, 1) vo
 template <int L, bool EBM, bool HP = false> __global__ __launch_bounds__(64, 1) void k_node(NodeParams P) {
     const Wave wv = make_wave(P.W, P.W_bytes);
     const int ntiles = (P.n_nodes + 31) / 32;
+    node_rows_to_lds<L, EBM>(P, wv);
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) node_tile<L, EBM, HP>(P, wv, t * 32);
 }
 

@@ -56,11 +56,43 @@ template <int L> DEDF_DEV FeatH<L> split_feat(const Feat<L>& f) {
     return o;
 }
 
+// per-row vectors (biases, LayerNorm affine) of the node image, copied once per wave into LDS (see dedf_edge.h::RowsLds)
+template <int L> struct NodeRowsLds {
+    static constexpr int b_proj0 = 0, ln_w0 = 64, ln_w1 = 128, ln_w2 = 160, ln_b0 = 192, b_f1 = 256;
+    static constexpr int b_f2 = b_f1 + cdiv(f1_rows0<L>(), 32) * 32, b_sl0 = b_f2 + 64, b_sl1 = b_sl0 + 32, total = b_sl1 + 32;
+};
+template <int L> DEDF_DEV float* node_rows_lds() {
+    __shared__ __attribute__((aligned(16))) float rows[NodeRowsLds<L>::total];
+    return rows;
+}
+template <int L, bool EBM>
+DEDF_DEV void node_rows_to_lds(const NodeParams& P, const Wave& wv) {
+    using RL = NodeRowsLds<L>;
+    constexpr NodeLayout<L> O = kNodeLayout<L>;
+    float* rows = node_rows_lds<L>();
+    auto cp = [&](int dst, int src, int n) { for (int i = wv.lane; i < n; i += 64) rows[dst + i] = P.W[src + i]; };
+    cp(RL::b_proj0, O.b_proj0, 64); cp(RL::ln_w0, O.ln_w[0], 64); cp(RL::ln_b0, O.ln_b0, 64);
+    if constexpr (L >= 1) cp(RL::ln_w1, O.ln_w[1], 32);
+    if constexpr (L >= 2) cp(RL::ln_w2, O.ln_w[2], 32);
+    cp(RL::b_f1, O.b_f1, cdiv(f1_rows0<L>(), 32) * 32); cp(RL::b_f2, O.b_f2, 64);
+    if constexpr (!EBM) { cp(RL::b_sl0, O.b_sl[0], 32); cp(RL::b_sl1, O.b_sl[1], 32); }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
+DEDF_DEV f32x16 node_ldrows(const float* rows, int hi, int off, int tile) {
+    f32x16 v;
+    const f32x4* p = reinterpret_cast<const f32x4*>(rows + off + tile * 32 + hi * 16);
+    static_for<4>([&]<int G>() { const f32x4 t = p[G]; v[4 * G] = t[0]; v[4 * G + 1] = t[1]; v[4 * G + 2] = t[2]; v[4 * G + 3] = t[3]; });
+    return v;
+}
+
 template <int L, bool EBM, bool HP = false>
 DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     constexpr int D = feat_dim<L>();
     const int hi = wv.hi;
     constexpr NodeLayout<L> O = kNodeLayout<L>;      // weight-image offsets: compile-time constants (dedf_net.h)
+    using NR = NodeRowsLds<L>;
+    const float* const rows = node_rows_lds<L>();
     const bool valid = n0 + wv.col < P.n_nodes;
     const int n = valid ? n0 + wv.col : n0;
     const int pose = n / P.nQ, q = n - pose * P.nQ;
@@ -89,7 +121,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     {
         const FeatH<L> zh = split_feat<L>(z);
         f32x16 a0[2];
-        static_for<2>([&]<int To>() { a0[To] = ldrows(wv, O.b_proj0, To); });
+        static_for<2>([&]<int To>() { a0[To] = node_ldrows(rows, hi, NR::b_proj0, To); });
         dense_rot_hp<2, 4, 2, HP>(wv, O.A_proj[0], O.A_proj_l[0], a0, [&]<int c>() { return zh.s[c]; });
         const float c0 = opaque_s(P.sc.proj[0]);
         static_for<2>([&]<int To>() { static_for<16>([&]<int R>() { emb.s[To][R] = a0[To][R] * c0; }); });
@@ -119,7 +151,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         v += xor32(v);
         const float rs = 1.0f / sqrtf(v * (1.0f / 64) + 1e-5f);
         static_for<2>([&]<int T>() {
-            const f32x16 w = ldrows(wv, O.ln_w[0], T), b = ldrows(wv, O.ln_b0, T);
+            const f32x16 w = node_ldrows(rows, hi, NR::ln_w0, T), b = node_ldrows(rows, hi, NR::ln_b0, T);
             static_for<16>([&]<int R>() { nrm.s[T][R] = (emb.s[T][R] - mean) * (rs * w[R]) + b[R]; });
         });
     }
@@ -128,7 +160,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { v += emb.v1[m][R] * emb.v1[m][R]; }); });
         v += xor32(v);
         const float rs = 1.0f / sqrtf(v * (1.0f / (3 * 32)) + 1e-5f);
-        const f32x16 w = ldrows(wv, O.ln_w[1], 0);
+        const f32x16 w = node_ldrows(rows, hi, NR::ln_w1, 0);
         static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { nrm.v1[m][R] = emb.v1[m][R] * (rs * w[R]); }); });
     }
     if constexpr (L >= 2) {
@@ -136,7 +168,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { v += emb.v2[m][R] * emb.v2[m][R]; }); });
         v += xor32(v);
         const float rs = 1.0f / sqrtf(v * (1.0f / (5 * 16)) + 1e-5f);
-        const f32x16 w = ldrows(wv, O.ln_w[2], 0);
+        const f32x16 w = node_ldrows(rows, hi, NR::ln_w2, 0);
         static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { nrm.v2[m][R] = emb.v2[m][R] * (rs * w[R]); }); });
     }
 
@@ -171,12 +203,12 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     park(nrm);
     {   // l = 0: 192 hidden scalars (6 tiles) -> SiLU -> fctp_2
         f32x16 hs[6];
-        static_for<6>([&]<int To>() { hs[To] = ldrows(wv, O.b_f1, To); });
+        static_for<6>([&]<int To>() { hs[To] = node_ldrows(rows, hi, NR::b_f1, To); });
         dense_rot_hp<6, 4, 1, HP>(wv, O.A_f1[0], O.A_f1_l[0], hs, [&]<int c>() { return parked.template operator()<0, 0, c>(); });
         const float c1 = opaque_s(P.sc.f1[0]);
         static_for<6>([&]<int To>() { static_for<16>([&]<int R>() { hs[To][R] = silu_n(hs[To][R] * c1); }); });
         f32x16 o0[2];
-        static_for<2>([&]<int T>() { o0[T] = ldrows(wv, O.b_f2, T); });
+        static_for<2>([&]<int T>() { o0[T] = node_ldrows(rows, hi, NR::b_f2, T); });
         dense_rot_hp<2, 12, 2, HP>(wv, O.A_f2[0], O.A_f2_l[0], o0, [&]<int c>() {
             float t[8];
             static_for<8>([&]<int J>() { t[J] = hs[c / 2][8 * (c % 2) + J]; });
@@ -188,7 +220,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     // gate rows of fctp_1 (tiles 6 .. NF1-1 of the 0e row space): 96 gates for the 1e hidden, 48 for the 2e hidden
     constexpr int NGT = NF1 - 6;
     f32x16 gt[NGT];
-    static_for<NGT>([&]<int t>() { gt[t] = ldrows(wv, O.b_f1, 6 + t); });
+    static_for<NGT>([&]<int t>() { gt[t] = node_ldrows(rows, hi, NR::b_f1, 6 + t); });
     {
         // the gate tiles start at tile 6 of the same matrix (4 chunks per tile) -> shift the image offsets
         dense_rot_hp<NGT, 4, 1, HP>(wv, O.A_f1[0] + 6 * 4 * 256, O.A_f1_l[0] + 6 * 4 * 256, gt, [&]<int c>() { return parked.template operator()<0, 0, c>(); });
@@ -305,7 +337,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     float res[2][3];                         // per TP: mean over the 32 gated 1e channels
     park(fld);                               // the field as B operands, shared by every path of both tensor products
     static_for<2>([&]<int tp>() {
-        f32x16 gacc = ldrows(wv, O.b_sl[tp], 0);
+        f32x16 gacc = node_ldrows(rows, hi, tp == 0 ? NR::b_sl0 : NR::b_sl1, 0);
         f32x16 vacc[3];
         static_for<3>([&]<int K>() { static_for<16>([&]<int R>() { vacc[K][R] = 0.0f; }); });
         static_for<stp_num_paths<L>()>([&]<int p>() {
