@@ -129,8 +129,12 @@ DEDF_DEV AItem load_item(const Wave& wv, int o_str) {
     constexpr DtpItem it = dtp_item<L>(I, NT0);
     if constexpr (it.ntile > 0) {
         static_for<it.ntile>([&]<int n>() {
-            a.h[n] = bld4(wv.w, wv.lane16, (o_str + (it.slot + n) * 512) * 4);
-            if constexpr (!HP) a.l[n] = bld4(wv.w, wv.lane16, (o_str + (it.slot + n) * 512 + 256) * 4);
+            // rows 16-31 of this operand are padding: the 16-channel l = 2 outputs, and the last lin tile (112 = 3.5 x 32 rows)
+            constexpr int l3 = dtp_pos_l3<L>(it.pos);
+            constexpr bool half_rows = l3 == 2 || (l3 == 0 && NT0 == r0_tiles<L>() && lin0_rows<L>() % 32 == 16 && 2 * it.t + n == lin0_rows<L>() / 32);
+            const int lv = half_rows ? wv.lane16_r16 : wv.lane16;
+            a.h[n] = bld4(wv.w, lv, (o_str + (it.slot + n) * 512) * 4);
+            if constexpr (!HP) a.l[n] = bld4(wv.w, lv, (o_str + (it.slot + n) * 512 + 256) * 4);
         });
     }
     return a;
