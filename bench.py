@@ -197,7 +197,7 @@ def main():
                          "avg_launch_ms": edge_ms, "algorithmic_flop_per_launch": flops,
                          "kernel_ms_per_step": {k: v / n_ev for k, v in prof["ms"].items()}},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:           # the CPU reference leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.lmax, args.scene, args.grasp)
         print(json.dumps(out))
     if use_dist:
