@@ -89,8 +89,8 @@ def cpu_baseline(lmax, n_scene, n_grasp, n_sample_poses=8, t=0.5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--poses-per-gpu", type=int, default=1000)
     ap.add_argument("--lmax", type=int, default=2)
     ap.add_argument("--scene", type=int, default=4096)
