@@ -336,7 +336,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     mark();
     // 7. per-pose reduction
     if constexpr (EBM) hipLaunchKernelGGL(k_energy_reduce, dim3((nT + 127) / 128), dim3(128), 0, st, h->d_nout.as<float>(), nT, nQ, ang);
-    else hipLaunchKernelGGL(k_pose_reduce, dim3((nT + 127) / 128), dim3(128), 0, st, h->d_nout.as<float>(), nT, nQ, ang, lin);
+    else hipLaunchKernelGGL(k_pose_reduce, dim3(nT), dim3(64), 0, st, h->d_nout.as<float>(), nT, nQ, ang, lin);
     mark();
     if (h->profile) { h->prof_evals += 1; h->prof_dst += Nd; }
     if (hipGetLastError() != hipSuccess) return fail(h, DEDF_ERR_RUNTIME, "kernel launch failed");

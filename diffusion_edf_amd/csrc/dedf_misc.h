@@ -379,16 +379,22 @@ __global__ void k_aggregate(const float* __restrict__ edge_out, const int* __res
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Sum over the query points of one pose (score_head.py:207-209), fixed order.
-__global__ void k_pose_reduce(const float* __restrict__ node_out, int nT, int nQ, float* __restrict__ ang, float* __restrict__ lin) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per pose: lanes stride over the query points, then a fixed butterfly (deterministic, independent of nT).
+__global__ __launch_bounds__(64) void k_pose_reduce(const float* __restrict__ node_out, int nT, int nQ, float* __restrict__ ang, float* __restrict__ lin) {
+    const int t = blockIdx.x, lane = threadIdx.x;
     if (t >= nT) return;
     float s[6] = {0, 0, 0, 0, 0, 0};
-    for (int q = 0; q < nQ; ++q) {
+    for (int q = lane; q < nQ; q += 64) {
         const float* o = node_out + ((size_t)t * nQ + q) * 8;
-        for (int i = 0; i < 6; ++i) s[i] += o[i];
+        const f32x4 a = ld4(o), b = ld4(o + 4);
+        s[0] += a[0]; s[1] += a[1]; s[2] += a[2]; s[3] += a[3]; s[4] += b[0]; s[5] += b[1];
     }
-    lin[3 * t] = s[0]; lin[3 * t + 1] = s[1]; lin[3 * t + 2] = s[2];
-    ang[3 * t] = s[3]; ang[3 * t + 1] = s[4]; ang[3 * t + 2] = s[5];
+    for (int m = 32; m >= 1; m >>= 1)
+        for (int i = 0; i < 6; ++i) s[i] += __shfl_xor(s[i], m, 64);
+    if (lane == 0) {
+        lin[3 * t] = s[0]; lin[3 * t + 1] = s[1]; lin[3 * t + 2] = s[2];
+        ang[3 * t] = s[3]; ang[3 * t + 1] = s[4]; ang[3 * t + 2] = s[5];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
