@@ -69,7 +69,7 @@ struct dedf_handle {
     int scale_start[kMaxScales + 1] = {0};
     bool have_keys = false, have_query = false;
     // device: per call
-    DevBuf d_Ts, d_time, d_tb, d_pose, d_qpos, d_cnt, d_off, d_blk, d_tile, d_esrc, d_edst, d_eout, d_z, d_nout, d_ang, d_lin, d_T64, d_dbgw, d_dbge, d_dbgf;
+    DevBuf d_Ts, d_time, d_tb, d_pose, d_qpos, d_cnt, d_off, d_blk, d_tile, d_esrc, d_edst, d_eout, d_z, d_nout, d_ang, d_lin, d_T64, d_dbgw, d_dbge, d_dbgf, d_mask;
     int64_t edge_cap = 0;
     int last_nT = 0;
     bool debug = false;
@@ -253,6 +253,10 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     for (int n = 0; n < ns; ++n) np.r2[n] = c.radii[n] > 0 ? c.radii[n] * c.radii[n] : -1.0f;
     np.qpos = h->d_qpos.as<float>(); np.n_dst = Nd; np.cnt = h->d_cnt.as<int>(); np.off = h->d_off.as<int>(); np.blk = h->d_blk.as<int>();
     np.tile_info = h->d_tile.as<int>(); np.edge_src = h->d_esrc.as<int>(); np.edge_dst = h->d_edst.as<int>(); np.cap = h->edge_cap;
+    np.word_start[0] = 0;
+    for (int n = 0; n < ns; ++n) np.word_start[n + 1] = np.word_start[n] + (h->scale_start[n + 1] - h->scale_start[n] + 31) / 32;
+    if (!h->d_mask.ensure((size_t)np.word_start[ns] * Nd * 4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(neighbour masks) failed");
+    np.mask = h->d_mask.as<uint32_t>();
     const int nblk = (Nd + kNbrBlock - 1) / kNbrBlock;
     hipLaunchKernelGGL(k_neighbors<false>, dim3(nblk), dim3(kNbrBlock), 0, st, np);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, h->d_blk.as<int>(), nblk, ns, h->d_tile.as<int>(), h->edge_cap,

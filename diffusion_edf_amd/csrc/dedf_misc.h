@@ -207,6 +207,8 @@ struct NbrParams {
     const int* tile_info;                 // edge base per scale at [16 + n]
     int* edge_src; int* edge_dst;
     int64_t cap;
+    uint32_t* mask;                       // [word][n_dst]: neighbour bit masks written by the count pass, 32 keys per word
+    int word_start[kMaxScales + 1];       // first mask word of every scale (scale n has ceil(n_keys_n / 32) words)
 };
 constexpr int kNbrChunk = 1024;
 constexpr int kNbrBlock = 256;
@@ -226,47 +228,61 @@ __device__ inline int block_exclusive_scan_256(int v, int* total) {
     return base + x - v;
 }
 
+// Count pass: every destination tests every key of every scale (keys staged in LDS as float4: one broadcast ds_read_b128 per
+// key), counts its neighbours and leaves a bit mask of them ([word][dst], coalesced).  Fill pass: walks the set bits only.
 template <bool FILL>
 __global__ __launch_bounds__(kNbrBlock) void k_neighbors(NbrParams P) {
-    __shared__ f32x4 kx[kNbrChunk];          // (x, y, z, 0): one broadcast ds_read_b128 per key
+    __shared__ f32x4 kx[kNbrChunk];
     const int d = blockIdx.x * kNbrBlock + threadIdx.x;
     const bool act = d < P.n_dst;
     float px = 0, py = 0, pz = 0;
-    if (act) { px = P.qpos[3 * d]; py = P.qpos[3 * d + 1]; pz = P.qpos[3 * d + 2]; }
+    if (!FILL && act) { px = P.qpos[3 * d]; py = P.qpos[3 * d + 1]; pz = P.qpos[3 * d + 2]; }
     for (int n = 0; n < P.n_scales; ++n) {
         const int s0 = P.scale_start[n], s1 = P.scale_start[n + 1];
-        const float r2 = P.r2[n];
-        int c = 0;
-        int64_t base = 0;
+        const int w0 = P.word_start[n], nw = P.word_start[n + 1] - w0;
         if (FILL) {
             const int mine = act ? P.cnt[(size_t)n * P.n_dst + d] : 0;
             int total;
             const int ex = block_exclusive_scan_256(mine, &total);
             const int o = P.blk[(size_t)n * gridDim.x + blockIdx.x] + ex;
-            if (act) P.off[(size_t)n * P.n_dst + d] = o;
-            base = (int64_t)P.tile_info[16 + n] + o;
-        }
-        for (int c0 = s0; c0 < s1; c0 += kNbrChunk) {
-            const int nc = min(kNbrChunk, s1 - c0);
-            __syncthreads();
-            for (int i = threadIdx.x; i < nc; i += kNbrBlock) {
-                const float* kp = P.key_x + (size_t)(c0 + i) * 3;
-                kx[i] = f32x4{kp[0], kp[1], kp[2], 0.0f};
-            }
-            __syncthreads();
             if (!act) continue;
-            for (int i = 0; i < nc; ++i) {
-                const f32x4 k = kx[i];
-                const float dx = k[0] - px, dy = k[1] - py, dz = k[2] - pz;
-                const float d2 = dx * dx + dy * dy + dz * dz;
-                const bool in = (r2 <= 0.0f) || (d2 < r2);
-                if (in && (r2 <= 0.0f || c < P.max_neighbors)) {
-                    if (FILL && base + c < P.cap) { P.edge_src[base + c] = c0 + i; P.edge_dst[base + c] = d; }
+            P.off[(size_t)n * P.n_dst + d] = o;
+            const int64_t base = (int64_t)P.tile_info[16 + n] + o;
+            int c = 0;
+            for (int g = 0; g < nw; ++g) {
+                uint32_t word = P.mask[(size_t)(w0 + g) * P.n_dst + d];
+                while (word) {
+                    const int bit = __builtin_ctz(word);
+                    word &= word - 1;
+                    if (base + c < P.cap) { P.edge_src[base + c] = s0 + 32 * g + bit; P.edge_dst[base + c] = d; }
                     ++c;
                 }
             }
-        }
-        if (!FILL) {
+        } else {
+            const float r2 = P.r2[n];
+            int c = 0;
+            for (int c0 = s0; c0 < s1; c0 += kNbrChunk) {      // kNbrChunk is a multiple of 32: words never straddle chunks
+                const int nc = min(kNbrChunk, s1 - c0);
+                __syncthreads();
+                for (int i = threadIdx.x; i < nc; i += kNbrBlock) {
+                    const float* kp = P.key_x + (size_t)(c0 + i) * 3;
+                    kx[i] = f32x4{kp[0], kp[1], kp[2], 0.0f};
+                }
+                __syncthreads();
+                if (!act) continue;
+                for (int i0 = 0; i0 < nc; i0 += 32) {
+                    uint32_t word = 0;
+                    const int ni = min(32, nc - i0);
+                    for (int i = 0; i < ni; ++i) {
+                        const f32x4 k = kx[i0 + i];
+                        const float dx = k[0] - px, dy = k[1] - py, dz = k[2] - pz;
+                        const float d2 = dx * dx + dy * dy + dz * dz;
+                        const bool in = (r2 <= 0.0f) || (d2 < r2);
+                        if (in && (r2 <= 0.0f || c < P.max_neighbors)) { word |= 1u << i; ++c; }
+                    }
+                    P.mask[(size_t)(w0 + (c0 - s0 + i0) / 32) * P.n_dst + d] = word;
+                }
+            }
             if (act) P.cnt[(size_t)n * P.n_dst + d] = c;
             int total;
             (void)block_exclusive_scan_256(act ? c : 0, &total);
