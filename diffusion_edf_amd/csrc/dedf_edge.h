@@ -286,7 +286,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // ---- RadialProfile layers 1, 2 (equiformer/radial_func.py:11-60) ---------------------------------------------------
     f32x16 r1[4];
     static_for<4>([&]<int To>() { r1[To] = ldrows_lds(rows, hi, RL::b1, To); });
-    dense_rot_h<4, F0 / 16, 1, HP>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return h[c / 2][8 * (c % 2) + j]; });
+    dense_rot_h<4, F0 / 16, 2, HP>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return h[c / 2][8 * (c % 2) + j]; });
     DEDF_STAMP(2);
     static_for<4>([&]<int To>() { to_vgpr(r1[To]); });
     ln_silu<4>(r1, wv, rows, RL::g1, RL::be1);
