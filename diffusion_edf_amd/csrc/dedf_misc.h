@@ -273,12 +273,26 @@ __global__ __launch_bounds__(kNbrBlock) void k_neighbors(NbrParams P) {
                 for (int i0 = 0; i0 < nc; i0 += 32) {
                     uint32_t word = 0;
                     const int ni = min(32, nc - i0);
-                    for (int i = 0; i < ni; ++i) {
-                        const f32x4 k = kx[i0 + i];
-                        const float dx = k[0] - px, dy = k[1] - py, dz = k[2] - pz;
-                        const float d2 = dx * dx + dy * dy + dz * dz;
-                        const bool in = (r2 <= 0.0f) || (d2 < r2);
-                        if (in && (r2 <= 0.0f || c < P.max_neighbors)) { word |= 1u << i; ++c; }
+                    if (ni == 32 && r2 > 0.0f && c + 32 <= P.max_neighbors) {
+                        // common case (full word, finite radius, cap cannot bind): two keys per iteration on packed fp32 ops
+                        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll 4
+                        for (int i = 0; i < 32; i += 2) {
+                            const f32x4 ka = kx[i0 + i], kb = kx[i0 + i + 1];
+                            const f32x2_t dx = f32x2_t{ka[0], kb[0]} - px, dy = f32x2_t{ka[1], kb[1]} - py, dz = f32x2_t{ka[2], kb[2]} - pz;
+                            const f32x2_t d2 = dx * dx + dy * dy + dz * dz;
+                            word |= (d2[0] < r2 ? 1u : 0u) << i;
+                            word |= (d2[1] < r2 ? 2u : 0u) << i;
+                        }
+                        c += __builtin_popcount(word);
+                    } else {
+                        for (int i = 0; i < ni; ++i) {
+                            const f32x4 k = kx[i0 + i];
+                            const float dx = k[0] - px, dy = k[1] - py, dz = k[2] - pz;
+                            const float d2 = dx * dx + dy * dy + dz * dz;
+                            const bool in = (r2 <= 0.0f) || (d2 < r2);
+                            if (in && (r2 <= 0.0f || c < P.max_neighbors)) { word |= 1u << i; ++c; }
+                        }
                     }
                     P.mask[(size_t)(w0 + (c0 - s0 + i0) / 32) * P.n_dst + d] = word;
                 }
