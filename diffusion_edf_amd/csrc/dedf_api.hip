@@ -69,7 +69,7 @@ struct dedf_handle {
     int scale_start[kMaxScales + 1] = {0};
     bool have_keys = false, have_query = false;
     // device: per call
-    DevBuf d_Ts, d_time, d_tb, d_pose, d_qpos, d_cnt, d_off, d_blk, d_tile, d_esrc, d_edst, d_eout, d_z, d_nout, d_ang, d_lin, d_T64, d_dbgw, d_dbge, d_dbgf, d_mask;
+    DevBuf d_Ts, d_time, d_tb, d_pose, d_qpos, d_cnt, d_off, d_blk, d_tile, d_esrc, d_edst, d_eout, d_z, d_nout, d_ang, d_lin, d_T64, d_dbgw, d_dbge, d_dbgf, d_dbgo, d_mask;
     int64_t edge_cap = 0;
     int last_nT = 0;
     bool debug = false;
@@ -293,6 +293,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         P.o_b_r0 = o.o_b_r0; P.o_b_val0 = o.o_b_val0; P.o_alpha_dot = o.o_alpha_dot;
         P.out = h->d_eout.as<float>();
         P.dbg_w = h->debug ? h->d_dbgw.as<float>() : nullptr;
+        P.dbg_out = (h->debug && h->d_dbgo.ensure((size_t)h->edge_cap * edge_rec<L>() * 4)) ? h->d_dbgo.as<float>() : nullptr;
         P.phase_prof = nullptr;
 #if defined(DEDF_PHASE_PROF)
         if (h->d_phase.ensure((size_t)h->n_cu * 4 * 16 * 8)) P.phase_prof = h->d_phase.as<unsigned long long>();
@@ -639,7 +640,8 @@ int dedf_debug_copy(dedf_handle* h, const char* name, void* host_dst, size_t max
     else if (nm == "tb") { src = h->d_tb.p; n = (size_t)h->last_nT * h->cfg.n_scales * h->cfg.fc_neurons[0] * 4; }
     else if (nm == "edge_src") { src = h->d_esrc.p; n = E * 4; }
     else if (nm == "edge_dst") { src = h->d_edst.p; n = E * 4; }
-    else if (nm == "edge_out") { src = h->d_eout.p; n = E * REC * 4; }
+    else if (nm == "edge_out") { src = h->d_dbgo.p; n = h->d_dbgo.p ? E * REC * 4 : 0; }        // per-edge records (debug mode)
+    else if (nm == "segment_out") { src = h->d_eout.p; n = E * REC * 4; }
     else if (nm == "z") { src = h->d_z.p; n = Nd * D * 4; }
     else if (nm == "node_out") { src = h->d_nout.p; n = Nd * 8 * 4; }
     else if (nm == "emb") { src = h->d_dbge.p; n = h->d_dbge.p ? Nd * D * 4 : 0; }

@@ -49,7 +49,9 @@ struct EdgeParams {
     float w_unscale, u_scale, c_lin[4], c_val[4];     // power-of-two operand scaling of the split-fp16 GEMMs (dedf_pack.h::EdgeOffsets)
     int o_b_val0;             // row-packed (64)
     int o_alpha_dot;          // row-packed over the two alpha tiles
-    float* out;               // [E][edge_rec]
+    float* out;               // [E][edge_rec]: ONE record per (destination, tile) segment, stored at the segment's first edge:
+                              //   value = softmax-weighted mean of the segment's edge values, logit = log-sum-exp of its logits
+    float* dbg_out;           // optional [E][edge_rec] per-edge records (value, logits) for the stage tests
     float* dbg_w;             // optional [E][WN] dump of the radial weights (tests)
     unsigned long long* phase_prof;   // optional [grid][16] per-wave phase cycle sums (built with -DDEDF_PHASE_PROF)
 };
@@ -521,20 +523,120 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         }
         return o;
     };
-    float* const orec = P.out + (size_t)e * REC;
+    // ---- joint-softmax partials --------------------------------------------------------------------------------------------
+    // The tile's edges are ordered by destination, so the edges of one destination form a run of lanes ("segment").  Instead
+    // of one 976-byte record per edge, the tile emits one per segment: the segment's softmax-weighted mean value and the
+    // log-sum-exp of its logits -- k_aggregate merges them exactly as it would merge edges (softmax of softmaxes).  Segmented
+    // scans over the 32 edge columns of each half-wave run on ds_bpermute lane shuffles (no LDS memory involved).
     const float cv0 = opaque_s(P.c_val[0]), cv1 = opaque_s(P.c_val[1]), cv2 = opaque_s(P.c_val[L >= 2 ? 2 : 0]);
-    auto store_group = [&]<int l3>() {       // value in internal layout [l][m][channel]
+    // byte addresses of lane - s / lane + s (s = 1, 2, 4, 8, 16) are formed where they are used (ds_bpermute reads bits 7:2)
+    const int lane4 = wv.lane * 4;
+    auto sh_up_a = [&](int i) { return lane4 - (4 << i); };
+    auto sh_dn_a = [&](int i) { return lane4 + (4 << i); };
+    auto shf = [&](int addr, float x) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, x))); };
+    auto shi = [&](int addr, int x) { return __builtin_amdgcn_ds_bpermute(addr, x); };
+    const int col = wv.col;
+    int seg_start;                              // column of the first edge of this lane's segment
+    bool seg_last;                              // this lane is the last edge of its segment (and a real edge): it stores the record
+    float pw[kHeads], inv_s[kHeads];
+    auto mk = [&](int i) { return col - (1 << i) >= seg_start ? 1.0f : 0.0f; };      // 1.0 where lane - s still belongs to the segment
+    {
+        const int prev_dst = shi(sh_up_a(0), dst);
+        const bool head = col == 0 || dst != prev_dst || col == n_valid;      // padding lanes (col >= n_valid) form their own segment
+        seg_start = head ? col : 0;
+        static_for<5>([&]<int i>() { const int t = shi(sh_up_a(i), seg_start); if (col >= (1 << i)) seg_start = max(seg_start, t); });
+        const int next_head = shi(sh_dn_a(0), head ? 1 : 0);
+        const bool last_any = col == 31 || next_head != 0;
+        seg_last = last_any && valid;
+        int seg_end = last_any ? col : 31;
+        static_for<5>([&]<int i>() { const int t = shi(sh_dn_a(i), seg_end); if (col + (1 << i) <= 31) seg_end = min(seg_end, t); });
+        const int end_addr = ((wv.lane & 32) + seg_end) * 4;
+        float lse[kHeads];
+        static_for<kHeads>([&]<int h>() {
+            float m = logit[h];                  // inclusive prefix maximum along the segment, then the value at its last lane
+            static_for<5>([&]<int i>() { const float t = shf(sh_up_a(i), m); m = mk(i) != 0.0f ? fmaxf(m, t) : m; });
+            m = shf(end_addr, m);
+            pw[h] = valid ? fexp(logit[h] - m) : 0.0f;
+            float sum = pw[h];
+            static_for<5>([&]<int i>() { sum = fmaf(shf(sh_up_a(i), sum), mk(i), sum); });
+            inv_s[h] = 1.0f / sum;               // meaningful on the segment's last lane only
+            lse[h] = m + logf(sum);
+        });
+        if (seg_last && hi == 0) st4(P.out + (size_t)(e0 + seg_start) * REC + D, f32x4{lse[0], lse[1], lse[2], lse[3]});
+    }
+    float* const orec = P.out + (size_t)(e0 + seg_start) * REC;
+    float* const drec = P.dbg_out != nullptr ? P.dbg_out + (size_t)e * REC : nullptr;
+    // The 240 values are reduced with DPP row shifts (VALU only): an inclusive segmented scan inside each 16-lane row
+    // (row_shr 1, 2, 4, 8; sources outside the row read 0), then lane 15 of the lower row is added to the lanes of the upper
+    // row whose segment began in the lower row (row_bcast:15).  Steps beyond the longest segment of the tile are skipped.
+    int seg_len_max = col - seg_start + 1;
+    static_for<5>([&]<int i>() { seg_len_max = max(seg_len_max, shi(sh_dn_a(i), seg_len_max)); seg_len_max = max(seg_len_max, shi(sh_up_a(i), seg_len_max)); });
+    const int n_steps = __builtin_amdgcn_readfirstlane(seg_len_max <= 1 ? 0 : (seg_len_max <= 2 ? 1 : (seg_len_max <= 4 ? 2 : (seg_len_max <= 8 ? 3 : 4))));
+    const int row_start = max(seg_start, col & 16);                       // segment start clipped to this lane's 16-lane row
+    const float cross = (col >= 16 && seg_start < 16) ? 1.0f : 0.0f;      // the segment continues from the lower row
+    auto mkr = [&](int i) { return col - (1 << i) >= row_start ? 1.0f : 0.0f; };
+    // x[q] += m * x[q] of the lane selected by the DPP control, four registers per asm block (one v_fmac_f32_dpp each; the
+    // s_nop covers the VALU-write -> DPP-read wait states that hipcc cannot see inside the block)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DEDF_FMAC_DPP4(x, m, CTRL)                                                                                                  \
+    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %4 " CTRL "\n\tv_fmac_f32_dpp %1, %1, %4 " CTRL "\n\tv_fmac_f32_dpp %2, %2, %4 " CTRL \
+                 "\n\tv_fmac_f32_dpp %3, %3, %4 " CTRL                                                                               \
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "v"(m))
+#else
+#define DEDF_FMAC_DPP4(x, m, CTRL) (void)(m)
+#endif
+    auto scan_step = [&]<int i>(float (&x)[4], float m) {
+        if constexpr (i == 0) DEDF_FMAC_DPP4(x, m, "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+        else if constexpr (i == 1) DEDF_FMAC_DPP4(x, m, "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+        else if constexpr (i == 2) DEDF_FMAC_DPP4(x, m, "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+        else if constexpr (i == 3) DEDF_FMAC_DPP4(x, m, "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+        else DEDF_FMAC_DPP4(x, m, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    };
+    // NS record slots of one irreps block at once (x[n] = this lane's four channel values of slot n, true units, already
+    // weighted); afterwards the segment's last lane stores its means
+    auto emit = [&]<int NS>(f32x4 (&xv)[NS], const int (&rec_off)[NS], const float (&inv)[NS]) {
+        float x[NS][4];
+        static_for<NS>([&]<int n>() { static_for<4>([&]<int q>() { x[n][q] = xv[n][q]; }); });
+        static_for<4>([&]<int i>() {
+            if (i < n_steps) {
+                const float m = mkr(i);
+                static_for<NS>([&]<int n>() { scan_step.template operator()<i>(x[n], m); });
+            }
+        });
+        static_for<NS>([&]<int n>() { scan_step.template operator()<4>(x[n], cross); });
+        if (seg_last) static_for<NS>([&]<int n>() { st4(orec + rec_off[n], f32x4{x[n][0], x[n][1], x[n][2], x[n][3]} * inv[n]); });
+    };
+    auto store_group = [&]<int l3>() {       // value in internal layout [l][m][channel]; head of a channel = channel / (mul / 4)
         if constexpr (l3 == 0) {
-            if (valid) static_for<2>([&]<int T>() { static_for<4>([&]<int g>() {
-                st4(orec + T * 32 + 8 * g + 4 * hi, f32x4{val0[T][4 * g], val0[T][4 * g + 1], val0[T][4 * g + 2], val0[T][4 * g + 3]} * cv0);
+            f32x4 x[8]; int ro[8]; float iv[8];
+            static_for<2>([&]<int T>() { static_for<4>([&]<int g>() {
+                constexpr int hd = 2 * T + g / 2, n = 4 * T + g;
+                ro[n] = T * 32 + 8 * g + 4 * hi; iv[n] = inv_s[hd];
+                x[n] = f32x4{val0[T][4 * g], val0[T][4 * g + 1], val0[T][4 * g + 2], val0[T][4 * g + 3]} * cv0;
+                if (drec != nullptr && valid) st4(drec + ro[n], x[n]);
+                x[n] = x[n] * pw[hd];
             }); });
+            emit(x, ro, iv);
+        } else if constexpr (l3 == 1) {
+            f32x4 x[12]; int ro[12]; float iv[12];
+            static_for<3>([&]<int K>() { static_for<4>([&]<int g>() {
+                constexpr int n = 4 * K + g;
+                ro[n] = blk_off(1) + K * mul_of(1) + 8 * g + 4 * hi; iv[n] = inv_s[g];
+                x[n] = f32x4{val1[K][4 * g], val1[K][4 * g + 1], val1[K][4 * g + 2], val1[K][4 * g + 3]} * cv1;
+                if (drec != nullptr && valid) st4(drec + ro[n], x[n]);
+                x[n] = x[n] * pw[g];
+            }); });
+            emit(x, ro, iv);
         } else {
-            constexpr int ng = mul_of(l3) / 8;     // 8-channel runs per component
-            auto& valm = [&]() -> auto& { if constexpr (l3 == 1) return val1; else return val2; }();
-            if (valid) static_for<2 * l3 + 1>([&]<int K>() { static_for<ng>([&]<int g>() {
-                st4(orec + blk_off(l3) + K * mul_of(l3) + 8 * g + 4 * hi,
-                    f32x4{valm[K][4 * g], valm[K][4 * g + 1], valm[K][4 * g + 2], valm[K][4 * g + 3]} * (l3 == 1 ? cv1 : cv2));
+            f32x4 x[10]; int ro[10]; float iv[10];
+            static_for<5>([&]<int K>() { static_for<2>([&]<int g>() {        // 16 channels: head = 2 g + hi
+                constexpr int n = 2 * K + g;
+                ro[n] = blk_off(2) + K * mul_of(2) + 8 * g + 4 * hi; iv[n] = hi ? inv_s[2 * g + 1] : inv_s[2 * g];
+                x[n] = f32x4{val2[K][4 * g], val2[K][4 * g + 1], val2[K][4 * g + 2], val2[K][4 * g + 3]} * cv2;
+                if (drec != nullptr && valid) st4(drec + ro[n], x[n]);
+                x[n] = x[n] * (hi ? pw[2 * g + 1] : pw[2 * g]);
             }); });
+            emit(x, ro, iv);
         }
     };
     auto start_val = [&]<int l3>() {
@@ -561,7 +663,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     });
     DEDF_STAMP(14);
     store_group.template operator()<L>();
-    if (valid && hi == 0) st4(orec + D, f32x4{logit[0], logit[1], logit[2], logit[3]});
+    if (drec != nullptr && valid && hi == 0) st4(drec + D, f32x4{logit[0], logit[1], logit[2], logit[3]});
     DEDF_STAMP(11);
 }
 

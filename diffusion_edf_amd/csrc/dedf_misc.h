@@ -366,18 +366,26 @@ __global__ void k_aggregate(const float* __restrict__ edge_out, const int* __res
     f32x4 acc = {0, 0, 0, 0};
     for (int n = 0; n < n_scales; ++n) {
         const int c = cnt[(size_t)n * n_dst + d];
-        const size_t e0 = (size_t)tile_info[16 + n] + off[(size_t)n * n_dst + d];
-        const float* rec = edge_out + e0 * REC;
-        // U records per iteration: all their loads are in flight together (one record per iteration leaves a wave with a
-        // single KiB outstanding and the kernel latency-bound); the online-softmax update handles the group at once
+        if (c == 0) continue;
+        // k_edge left one record per (destination, 32-edge tile) segment at the segment's first edge: the destination's first
+        // edge and every tile boundary (scale-relative multiples of 32) inside its edge range
+        const int o = off[(size_t)n * n_dst + d];
+        const float* rec = edge_out + ((size_t)tile_info[16 + n] + o) * REC;
+        const int first_b = 32 - (o & 31);                 // distance (in edges) to the next tile boundary
+        const int nrec = 1 + (first_b < c ? (c - first_b + 31) / 32 : 0);
+        // U records per iteration: all their loads are in flight together; the online-softmax update handles the group at once
         constexpr int U = 4;
-        for (int j = 0; j < c; j += U) {
+        for (int j = 0; j < nrec; j += U) {
             f32x4 lg[U], v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 lg[u] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                 v[u] = f32x4{0, 0, 0, 0};
-                if (j + u < c) { lg[u] = ld4(rec + (size_t)(j + u) * REC + D); if (lane < NV) v[u] = ld4(rec + (size_t)(j + u) * REC + ci); }
+                if (j + u < nrec) {
+                    const size_t eo = j + u == 0 ? 0 : (size_t)(first_b + 32 * (j + u - 1));
+                    lg[u] = ld4(rec + eo * REC + D);
+                    if (lane < NV) v[u] = ld4(rec + eo * REC + ci);
+                }
             }
             float sc[kHeads], p[U][kHeads];
             for (int h = 0; h < kHeads; ++h) {
