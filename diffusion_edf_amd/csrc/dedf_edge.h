@@ -80,7 +80,12 @@ template <int L> DEDF_DEV float* rows_lds() {
 // accumulator tile <- 16 per-row values of row tile `tile` of the vector at LDS offset `off`
 DEDF_DEV f32x16 ldrows_lds(const float* rows, int hi, int off, int tile) {
     f32x16 v;
-    const f32x4* p = reinterpret_cast<const f32x4*>(rows + off + tile * 32 + hi * 16);
+    int lane_off = hi * 16;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(lane_off));       // keeps the reads where they are used (hipcc otherwise gathers every row read of the
+                                             // tile at one point and spills their common address register)
+#endif
+    const f32x4* p = reinterpret_cast<const f32x4*>(rows + off + tile * 32 + lane_off);
     static_for<4>([&]<int G>() { const f32x4 t = p[G]; v[4 * G] = t[0]; v[4 * G + 1] = t[1]; v[4 * G + 2] = t[2]; v[4 * G + 3] = t[3]; });
     return v;
 }
