@@ -316,7 +316,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // per-l1 lane offsets of the 4 message rows this lane owns inside an 8-row group
     const int mv0 = src * (D * 4) + hi * 16, mv1 = src * (D * 4) + hi * 48, mv2 = src * (D * 4) + hi * 80;
     // LDS parking: slot = 4 registers of every lane ([slot][lane][4]); u0: 8 slots, u1[m]: 4 each, u2[m]: 2 each
-    constexpr int US1 = 8, US2 = US1 + 12, NSLOT = US2 + 10;
+    constexpr int US1 = 8, US2 = US1 + 12, SPW = US2 + 10, NSLOT = SPW + 2;      // SPW: segment softmax weights / normalisers
     __shared__ f32x4 park[NSLOT * 64];
     f32x4* const pk = park + wv.lane;
 
@@ -543,7 +543,6 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     const int col = wv.col;
     int seg_start;                              // column of the first edge of this lane's segment
     bool seg_last;                              // this lane is the last edge of its segment (and a real edge): it stores the record
-    float pw[kHeads], inv_s[kHeads];
     auto mk = [&](int i) { return col - (1 << i) >= seg_start ? 1.0f : 0.0f; };      // 1.0 where lane - s still belongs to the segment
     {
         const int prev_dst = shi(sh_up_a(0), dst);
@@ -556,7 +555,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         int seg_end = last_any ? col : 31;
         static_for<5>([&]<int i>() { const int t = shi(sh_dn_a(i), seg_end); if (col + (1 << i) <= 31) seg_end = min(seg_end, t); });
         const int end_addr = ((wv.lane & 32) + seg_end) * 4;
-        float lse[kHeads];
+        float lse[kHeads], pw[kHeads], inv_s[kHeads];
         static_for<kHeads>([&]<int h>() {
             float m = logit[h];                  // inclusive prefix maximum along the segment, then the value at its last lane
             static_for<5>([&]<int i>() { const float t = shf(sh_up_a(i), m); m = mk(i) != 0.0f ? fmaxf(m, t) : m; });
@@ -568,18 +567,20 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             lse[h] = m + logf(sum);
         });
         if (seg_last && hi == 0) st4(P.out + (size_t)(e0 + seg_start) * REC + D, f32x4{lse[0], lse[1], lse[2], lse[3]});
+        // the per-head weights wait in LDS until each irreps block is emitted (8 registers less during the value GEMMs)
+        pk[SPW * 64] = f32x4{pw[0], pw[1], pw[2], pw[3]};
+        pk[(SPW + 1) * 64] = f32x4{inv_s[0], inv_s[1], inv_s[2], inv_s[3]};
     }
-    float* const orec = P.out + (size_t)(e0 + seg_start) * REC;
-    float* const drec = P.dbg_out != nullptr ? P.dbg_out + (size_t)e * REC : nullptr;
+    auto orec_of = [&]() { return P.out + (size_t)(e0 + seg_start) * REC; };
+    auto drec_of = [&]() { return P.dbg_out != nullptr ? P.dbg_out + (size_t)e * REC : nullptr; };
     // The 240 values are reduced with DPP row shifts (VALU only): an inclusive segmented scan inside each 16-lane row
     // (row_shr 1, 2, 4, 8; sources outside the row read 0), then lane 15 of the lower row is added to the lanes of the upper
     // row whose segment began in the lower row (row_bcast:15).  Steps beyond the longest segment of the tile are skipped.
     int seg_len_max = col - seg_start + 1;
     static_for<5>([&]<int i>() { seg_len_max = max(seg_len_max, shi(sh_dn_a(i), seg_len_max)); seg_len_max = max(seg_len_max, shi(sh_up_a(i), seg_len_max)); });
     const int n_steps = __builtin_amdgcn_readfirstlane(seg_len_max <= 1 ? 0 : (seg_len_max <= 2 ? 1 : (seg_len_max <= 4 ? 2 : (seg_len_max <= 8 ? 3 : 4))));
-    const int row_start = max(seg_start, col & 16);                       // segment start clipped to this lane's 16-lane row
-    const float cross = (col >= 16 && seg_start < 16) ? 1.0f : 0.0f;      // the segment continues from the lower row
-    auto mkr = [&](int i) { return col - (1 << i) >= row_start ? 1.0f : 0.0f; };
+    // row_start: segment start clipped to this lane's 16-lane row; cross: the segment continues from the lower row
+    auto mkr = [&](int i) { return col - (1 << i) >= max(seg_start, col & 16) ? 1.0f : 0.0f; };
     // x[q] += m * x[q] of the lane selected by the DPP control, four registers per asm block (one v_fmac_f32_dpp each; the
     // s_nop covers the VALU-write -> DPP-read wait states that hipcc cannot see inside the block)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -608,10 +609,15 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 static_for<NS>([&]<int n>() { scan_step.template operator()<i>(x[n], m); });
             }
         });
+        const float cross = (col >= 16 && seg_start < 16) ? 1.0f : 0.0f;
         static_for<NS>([&]<int n>() { scan_step.template operator()<4>(x[n], cross); });
+        float* const orec = orec_of();
         if (seg_last) static_for<NS>([&]<int n>() { st4(orec + rec_off[n], f32x4{x[n][0], x[n][1], x[n][2], x[n][3]} * inv[n]); });
     };
     auto store_group = [&]<int l3>() {       // value in internal layout [l][m][channel]; head of a channel = channel / (mul / 4)
+        const f32x4 pwv = pk[SPW * 64], ivv = pk[(SPW + 1) * 64];
+        const float pw[kHeads] = {pwv[0], pwv[1], pwv[2], pwv[3]}, inv_s[kHeads] = {ivv[0], ivv[1], ivv[2], ivv[3]};
+        float* const drec = drec_of();
         if constexpr (l3 == 0) {
             f32x4 x[8]; int ro[8]; float iv[8];
             static_for<2>([&]<int T>() { static_for<4>([&]<int g>() {
@@ -668,7 +674,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     });
     DEDF_STAMP(14);
     store_group.template operator()<L>();
-    if (drec != nullptr && valid && hi == 0) st4(drec + D, f32x4{logit[0], logit[1], logit[2], logit[3]});
+    if (P.dbg_out != nullptr && valid && hi == 0) st4(drec_of() + D, f32x4{logit[0], logit[1], logit[2], logit[3]});
     DEDF_STAMP(11);
 }
 
