@@ -179,3 +179,27 @@ def test_ebm_energy_is_se3_invariant():
     Ts2 = torch.cat([R.quaternion_raw_multiply(g.expand(5, 4), Ts[:, :4]), R.quaternion_apply(g, Ts[:, 4:]) + gt], -1)
     assert (R.compute_energy(cfg, P, Ts2, keys2, q, t) - E).abs().max() < 1e-11
     assert (E > 0).all()
+
+
+def test_segment_records_merge_to_the_joint_softmax():
+    """The edge kernel emits, per run of same-destination edges inside a tile, the run's softmax-weighted mean value and the
+    log-sum-exp of its logits; k_aggregate merges those records exactly as it would merge edges.  Check the identity the split
+    relies on (graph_attention.py:247-262 joint softmax over all edges of a destination) for arbitrary run boundaries."""
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        n = int(rng.integers(1, 60))
+        logits = rng.normal(size=n) * 6.0
+        vals = rng.normal(size=(n, 7))
+        a = np.exp(logits - logits.max())
+        direct = (a[:, None] * vals).sum(0) / a.sum()
+        cuts = np.unique(np.concatenate([[0, n], rng.integers(0, n + 1, size=int(rng.integers(0, 6)))]))
+        lse, mean = [], []
+        for s, e in zip(cuts[:-1], cuts[1:]):
+            m = logits[s:e].max()
+            p = np.exp(logits[s:e] - m)
+            lse.append(m + np.log(p.sum()))
+            mean.append((p[:, None] * vals[s:e]).sum(0) / p.sum())
+        lse, mean = np.array(lse), np.array(mean)
+        w = np.exp(lse - lse.max())
+        merged = (w[:, None] * mean).sum(0) / w.sum()
+        assert np.allclose(merged, direct, rtol=1e-12, atol=1e-12)
