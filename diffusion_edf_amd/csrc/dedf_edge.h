@@ -543,26 +543,37 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     const int col = wv.col;
     int seg_start;                              // column of the first edge of this lane's segment
     bool seg_last;                              // this lane is the last edge of its segment (and a real edge): it stores the record
-    auto mk = [&](int i) { return col - (1 << i) >= seg_start ? 1.0f : 0.0f; };      // 1.0 where lane - s still belongs to the segment
+    // scans over the 32 columns of a half-wave on DPP: row_shr / row_shl inside the 16-lane rows, row_bcast:15 to carry the lower
+    // row's last lane into the upper row (rows 1 and 3 only)
+    auto dpi = [&]<int CTRL, int ROWS, bool ZERO>(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, ROWS, 0xf, ZERO); };
+    auto dpf = [&]<int CTRL, int ROWS, bool ZERO>(float old, float x) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, x), CTRL, ROWS, 0xf, ZERO));
+    };
+    auto mkr = [&](int i) { return col - (1 << i) >= max(seg_start, col & 16); };      // lane - 2^i is in this lane's row and segment
     {
         const int prev_dst = shi(sh_up_a(0), dst);
         const bool head = col == 0 || dst != prev_dst || col == n_valid;      // padding lanes (col >= n_valid) form their own segment
-        seg_start = head ? col : 0;
-        static_for<5>([&]<int i>() { const int t = shi(sh_up_a(i), seg_start); if (col >= (1 << i)) seg_start = max(seg_start, t); });
+        seg_start = head ? col : 0;             // inclusive prefix maximum over the columns
+        static_for<4>([&]<int i>() { seg_start = max(seg_start, dpi.template operator()<0x110 + (1 << i), 0xf, true>(0, seg_start)); });
+        seg_start = max(seg_start, dpi.template operator()<0x142, 0xa, false>(0, seg_start));
         const int next_head = shi(sh_dn_a(0), head ? 1 : 0);
         const bool last_any = col == 31 || next_head != 0;
         seg_last = last_any && valid;
-        int seg_end = last_any ? col : 31;
-        static_for<5>([&]<int i>() { const int t = shi(sh_dn_a(i), seg_end); if (col + (1 << i) <= 31) seg_end = min(seg_end, t); });
+        int seg_end = last_any ? col : 31;      // inclusive suffix minimum: column of the segment's last edge
+        static_for<4>([&]<int i>() { seg_end = min(seg_end, dpi.template operator()<0x100 + (1 << i), 0xf, false>(31, seg_end)); });
+        { const int up = shi(((wv.lane & 32) + 16) * 4, seg_end); if (col < 16) seg_end = min(seg_end, up); }
         const int end_addr = ((wv.lane & 32) + seg_end) * 4;
+        const bool crossb = col >= 16 && seg_start < 16;
         float lse[kHeads], pw[kHeads], inv_s[kHeads];
         static_for<kHeads>([&]<int h>() {
             float m = logit[h];                  // inclusive prefix maximum along the segment, then the value at its last lane
-            static_for<5>([&]<int i>() { const float t = shf(sh_up_a(i), m); m = mk(i) != 0.0f ? fmaxf(m, t) : m; });
+            static_for<4>([&]<int i>() { const float t = dpf.template operator()<0x110 + (1 << i), 0xf, false>(m, m); m = mkr(i) ? fmaxf(m, t) : m; });
+            { const float t = dpf.template operator()<0x142, 0xa, false>(m, m); m = crossb ? fmaxf(m, t) : m; }
             m = shf(end_addr, m);
             pw[h] = valid ? fexp(logit[h] - m) : 0.0f;
             float sum = pw[h];
-            static_for<5>([&]<int i>() { sum = fmaf(shf(sh_up_a(i), sum), mk(i), sum); });
+            static_for<4>([&]<int i>() { const float t = dpf.template operator()<0x110 + (1 << i), 0xf, true>(0.0f, sum); sum += mkr(i) ? t : 0.0f; });
+            { const float t = dpf.template operator()<0x142, 0xa, false>(0.0f, sum); sum += crossb ? t : 0.0f; }
             inv_s[h] = 1.0f / sum;               // meaningful on the segment's last lane only
             lse[h] = m + logf(sum);
         });
@@ -576,11 +587,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // The 240 values are reduced with DPP row shifts (VALU only): an inclusive segmented scan inside each 16-lane row
     // (row_shr 1, 2, 4, 8; sources outside the row read 0), then lane 15 of the lower row is added to the lanes of the upper
     // row whose segment began in the lower row (row_bcast:15).  Steps beyond the longest segment of the tile are skipped.
-    int seg_len_max = col - seg_start + 1;
-    static_for<5>([&]<int i>() { seg_len_max = max(seg_len_max, shi(sh_dn_a(i), seg_len_max)); seg_len_max = max(seg_len_max, shi(sh_up_a(i), seg_len_max)); });
-    const int n_steps = __builtin_amdgcn_readfirstlane(seg_len_max <= 1 ? 0 : (seg_len_max <= 2 ? 1 : (seg_len_max <= 4 ? 2 : (seg_len_max <= 8 ? 3 : 4))));
-    // row_start: segment start clipped to this lane's 16-lane row; cross: the segment continues from the lower row
-    auto mkr = [&](int i) { return col - (1 << i) >= max(seg_start, col & 16) ? 1.0f : 0.0f; };
+    int n_steps = 0;                            // wave-uniform: in-row steps some lane still needs
+    static_for<4>([&]<int i>() { if (__builtin_amdgcn_ballot_w64(mkr(i)) != 0) n_steps = i + 1; });
     // x[q] += m * x[q] of the lane selected by the DPP control, four registers per asm block (one v_fmac_f32_dpp each; the
     // s_nop covers the VALU-write -> DPP-read wait states that hipcc cannot see inside the block)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -605,7 +613,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         static_for<NS>([&]<int n>() { static_for<4>([&]<int q>() { x[n][q] = xv[n][q]; }); });
         static_for<4>([&]<int i>() {
             if (i < n_steps) {
-                const float m = mkr(i);
+                const float m = mkr(i) ? 1.0f : 0.0f;
                 static_for<NS>([&]<int n>() { scan_step.template operator()<i>(x[n], m); });
             }
         });
