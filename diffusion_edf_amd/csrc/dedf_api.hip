@@ -104,8 +104,12 @@ int check_config(const dedf_config* c, std::string& why) {
     const bool t_small = c->time_emb_mlp[0] == 256 && c->time_emb_mlp[1] == 128 && c->time_emb_mlp[2] == 64;
     const bool t_big = c->time_emb_mlp[0] == 512 && c->time_emb_mlp[1] == 256 && c->time_emb_mlp[2] == 128;   // sapien high-res configs
     if (!t_small && !t_big) { why = "time_emb_mlp must be [256,128,64] or [512,256,128]"; return DEDF_ERR_UNSUPPORTED; }
-    if (c->fc_neurons[0] != (c->ebm ? kLenEmb : kLenEmb + c->time_emb_mlp[2]) || c->fc_neurons[1] != kFc1 || c->fc_neurons[2] != kFc2) {
-        why = "fc_neurons must resolve to [64 + time_emb, 128, 64] (score head) or [64,128,64] (EBM head without time encoding)"; return DEDF_ERR_UNSUPPORTED; }
+    const bool mlp_wide = c->fc_neurons[1] == kFc1 && c->fc_neurons[2] == kFc2;
+    const bool mlp_narrow = c->fc_neurons[1] == 32 && c->fc_neurons[2] == 32;       // sapien place_* score heads
+    if (c->fc_neurons[0] != (c->ebm ? kLenEmb : kLenEmb + c->time_emb_mlp[2]) || !(mlp_wide || mlp_narrow)) {
+        why = "fc_neurons must resolve to [64 + time_emb, 128, 64] or [64 + time_emb, 32, 32] (score head), or [64,128,64] (EBM head without time encoding)"; return DEDF_ERR_UNSUPPORTED; }
+    if (mlp_narrow && (c->ebm || c->fc_neurons[0] != 128 || c->half_gemm)) {
+        why = "the 32-wide radial MLP is instantiated for the fp32-accurate score head with the 128-wide pre-linear only"; return DEDF_ERR_UNSUPPORTED; }
     if (c->length_emb_dim != kLenEmb) { why = "length_emb_dim must be 64"; return DEDF_ERR_UNSUPPORTED; }
     if (c->irreps_mlp_mid != kMlpMid) { why = "irreps_mlp_mid must be 3"; return DEDF_ERR_UNSUPPORTED; }
     if (c->half_gemm && (c->ebm || c->fc_neurons[0] != 128)) { why = "half_gemm is available for the score head with the 128-wide pre-linear only"; return DEDF_ERR_UNSUPPORTED; }
@@ -301,7 +305,8 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         static const int wpc = [] { const char* e = getenv("DEDF_EDGE_WAVES_PER_CU"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 4 ? v : 4; }();   // experiments only
         // half_gemm (the reference's half_precision knob): single-term fp16 products; instantiated for the 128-wide score head only
         if constexpr (F0 == 128) {
-            if (h->cfg.half_gemm) hipLaunchKernelGGL((k_edge<L, F0, true>), dim3(h->n_cu * wpc), dim3(64), 0, st, P);
+            if (h->cfg.fc_neurons[1] == 32) hipLaunchKernelGGL((k_edge<L, F0, false, 32, 32>), dim3(h->n_cu * wpc), dim3(64), 0, st, P);
+            else if (h->cfg.half_gemm) hipLaunchKernelGGL((k_edge<L, F0, true>), dim3(h->n_cu * wpc), dim3(64), 0, st, P);
             else hipLaunchKernelGGL((k_edge<L, F0>), dim3(h->n_cu * wpc), dim3(64), 0, st, P);
         } else hipLaunchKernelGGL((k_edge<L, F0>), dim3(h->n_cu * wpc), dim3(64), 0, st, P);
     }

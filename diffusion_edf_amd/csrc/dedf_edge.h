@@ -182,13 +182,13 @@ DEDF_DEV void split_chunk(const float (&v)[2 * l3 + 1][8], BOpsH<L>& o) {
 }
 
 // once per wave, before its first tile: copy the row vectors into LDS
-template <int L>
+template <int L, int H1 = 128, int H2 = 64>
 DEDF_DEV void edge_rows_to_lds(const EdgeParams& P, const Wave& wv) {
     using RL = RowsLds<L>;
     float* rows = rows_lds<L>();
     auto cp = [&](int dst, int src, int n) { for (int i = wv.lane; i < n; i += 64) rows[dst + i] = P.W[src + i]; };
-    cp(RL::b1, P.o_b_r1, 128); cp(RL::g1, P.o_g_r1, 128); cp(RL::be1, P.o_be_r1, 128);
-    cp(RL::b2, P.o_b_r2, 64); cp(RL::g2, P.o_g_r2, 64); cp(RL::be2, P.o_be_r2, 64);
+    cp(RL::b1, P.o_b_r1, H1); cp(RL::g1, P.o_g_r1, H1); cp(RL::be1, P.o_be_r1, H1);
+    cp(RL::b2, P.o_b_r2, H2); cp(RL::g2, P.o_g_r2, H2); cp(RL::be2, P.o_be_r2, H2);
     cp(RL::off3, P.o_off_r3, dtp_wn<L>()); cp(RL::b0, P.o_b_r0, r0_tiles<L>() * 32);
     cp(RL::val0, P.o_b_val0, 64); cp(RL::adot, P.o_alpha_dot, 64);
     __builtin_amdgcn_s_waitcnt(0);
@@ -204,8 +204,10 @@ DEDF_DEV void edge_enc_to_lds(const EdgeParams& P, const Wave& wv, int scale) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 }
 
-template <int L, int F0, bool HP = false>
+// H1, H2: hidden widths of the radial MLP (fc_neurons[1:]): 128, 64 in the panda_* and sapien pick configs, 32, 32 in sapien place_*
+template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64>
 DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, int n_valid DEDF_PROF_ARG) {
+    static_assert((H1 == 128 && H2 == 64) || (H1 == 32 && H2 == 32), "radial MLP widths of the shipped configs");
 #if defined(DEDF_PHASE_PROF) && defined(__HIP_DEVICE_COMPILE__)
     unsigned long long t_last = __builtin_readcyclecounter();
 #endif
@@ -291,19 +293,20 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     }
     DEDF_STAMP(1);
     // ---- RadialProfile layers 1, 2 (equiformer/radial_func.py:11-60) ---------------------------------------------------
-    f32x16 r1[4];
-    static_for<4>([&]<int To>() { r1[To] = ldrows_lds(rows, hi, RL::b1, To); });
-    dense_rot_h<4, F0 / 16, 2, HP>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return h[c / 2][8 * (c % 2) + j]; });
+    constexpr int NT1 = H1 / 32, NT2 = H2 / 32;
+    f32x16 r1[NT1];
+    static_for<NT1>([&]<int To>() { r1[To] = ldrows_lds(rows, hi, RL::b1, To); });
+    dense_rot_h<NT1, F0 / 16, 2, HP>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return h[c / 2][8 * (c % 2) + j]; });
     DEDF_STAMP(2);
-    static_for<4>([&]<int To>() { to_vgpr(r1[To]); });
-    ln_silu<4>(r1, wv, rows, RL::g1, RL::be1);
+    static_for<NT1>([&]<int To>() { to_vgpr(r1[To]); });
+    ln_silu<NT1>(r1, wv, rows, RL::g1, RL::be1);
     DEDF_STAMP(3);
-    f32x16 r2[2];
-    static_for<2>([&]<int To>() { r2[To] = ldrows_lds(rows, hi, RL::b2, To); });
-    dense_rot_h<2, 8, 2, HP>(wv, o_A_r2, o_A_r2_l, r2, [&]<int c, int j>() { return r1[c / 2][8 * (c % 2) + j]; });
+    f32x16 r2[NT2];
+    static_for<NT2>([&]<int To>() { r2[To] = ldrows_lds(rows, hi, RL::b2, To); });
+    dense_rot_h<NT2, H1 / 16, 2, HP>(wv, o_A_r2, o_A_r2_l, r2, [&]<int c, int j>() { return r1[c / 2][8 * (c % 2) + j]; });
     DEDF_STAMP(4);
-    static_for<2>([&]<int To>() { to_vgpr(r2[To]); });
-    ln_silu<2>(r2, wv, rows, RL::g2, RL::be2);
+    static_for<NT2>([&]<int To>() { to_vgpr(r2[To]); });
+    ln_silu<NT2>(r2, wv, rows, RL::g2, RL::be2);
     DEDF_STAMP(5);
 
     // ---- layer 3 (-> per-edge TP weights, one 32-row tile at a time) fused with DTP #1 and the lin / sep_alpha GEMMs ----
@@ -363,10 +366,11 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     const int o_S_lin = opaque_s(P.o_S_lin);
     AItem ring[PDA];
     static_for<PDA>([&]<int I>() { ring[I] = load_item<L, NR0, I, HP>(wv, o_S_lin); });
-    // layer 3 on split-fp16 MFMAs: r2 (64 rows = 4 chunks) is split once per edge tile; per weight tile 4 chunks x 3 MFMAs.
-    // A operands (hi and lo image) form one global stream over all tiles, PD3 chunks ahead.
-    HL r2s[4];
-    static_for<4>([&]<int c>() {
+    // layer 3 on split-fp16 MFMAs: r2 (H2 rows = KC chunks) is split once per edge tile; per weight tile KC chunks x 3 MFMAs.
+    // A operands (hi and lo image) form one global stream over all tiles.
+    constexpr int KC = H2 / 16;
+    HL r2s[KC];
+    static_for<KC>([&]<int c>() {
         float t[8];
         static_for<8>([&]<int J>() { t[J] = r2[c / 2][8 * (c % 2) + J]; });
         r2s[c] = split8(t);
@@ -374,22 +378,25 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     static_for<NR0>([&]<int T>() { acc0[T] = ldrows_lds(rows, hi, RL::b0, T); });      // accumulator init: lin / sep_alpha biases
     // Layer-3 work unit = half a weight tile (2 of the 4 K-chunks, 6 MFMAs).  Half P = 2 T + half of tile T runs in pipeline
     // region P - 3 into wbuf[T % 2]; its operands (and the tile's offset rows, the accumulator init) are requested one region
-    // earlier, across a scheduling fence, so that the request cannot sink next to its use.
+    // earlier, across a scheduling fence, so that the request cannot sink next to its use.  With the 32-wide MLP a tile has
+    // only two K-chunks: its even half just seeds the accumulator, the odd half carries both chunks.
     struct L3Half { f32x4 h[2], l[2]; };
+    auto l3_nk = []<int Ph>() { return KC == 4 ? 2 : (Ph % 2 ? 2 : 0); };
     auto load_l3 = [&]<int Ph>() {
         L3Half o{};
-        if constexpr (Ph < 2 * NWT) static_for<2>([&]<int k>() {
-            o.h[k] = bld4(wv.w, wv.lane16, (o_A_r3 + (2 * Ph + k) * 256) * 4);
-            if constexpr (!HP) o.l[k] = bld4(wv.w, wv.lane16, (o_A_r3_l + (2 * Ph + k) * 256) * 4);
+        if constexpr (Ph < 2 * NWT) static_for<l3_nk.template operator()<Ph>()>([&]<int k>() {
+            constexpr int unit = KC == 4 ? 2 * Ph + k : 2 * (Ph / 2) + k;
+            o.h[k] = bld4(wv.w, wv.lane16, (o_A_r3 + unit * 256) * 4);
+            if constexpr (!HP) o.l[k] = bld4(wv.w, wv.lane16, (o_A_r3_l + unit * 256) * 4);
         });
         return o;
     };
     auto load_off = [&]<int T>() { f32x16 o{}; if constexpr (T < NWT) o = ldrows_lds(rows, hi, RL::off3, T); return o; };
     auto run_l3 = [&]<int Ph>(const L3Half& a, const f32x16& init, f32x16& w) {
         if constexpr (Ph < 2 * NWT) {
-            constexpr int c0 = 2 * (Ph % 2);
+            constexpr int c0 = KC == 4 ? 2 * (Ph % 2) : 0;
             f32x16 t = init;
-            static_for<2>([&]<int k>() {
+            static_for<l3_nk.template operator()<Ph>()>([&]<int k>() {
                 const h8 ah = __builtin_bit_cast(h8, a.h[k]), al = __builtin_bit_cast(h8, a.l[k]);
                 t = mfma_h(ah, r2s[c0 + k].hi, t);
                 if constexpr (!HP) { t = mfma_h(ah, r2s[c0 + k].lo, t); t = mfma_h(al, r2s[c0 + k].hi, t); }

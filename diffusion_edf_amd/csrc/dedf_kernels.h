@@ -8,14 +8,14 @@
 
 using namespace dedf;
 
-template <int L, int F0, bool HP = false> __global__ __launch_bounds__(64, 1) void k_edge(EdgeParams P) {
+template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64> __global__ __launch_bounds__(64, 1) void k_edge(EdgeParams P) {
     const int* ti = P.tile_info;
     const int ntiles = ti[P.n_scales];
     const Wave wv = make_wave(P.W, P.W_bytes);
 #if defined(DEDF_PHASE_PROF)
     unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    edge_rows_to_lds<L>(P, wv);
+    edge_rows_to_lds<L, H1, H2>(P, wv);
     int enc_scale = -1;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         int scale = 0;
@@ -24,9 +24,9 @@ template <int L, int F0, bool HP = false> __global__ __launch_bounds__(64, 1) vo
         const int k = t - ti[scale];
         const int ebase = ti[16 + scale], En = ti[16 + scale + 1] - ebase;
 #if defined(DEDF_PHASE_PROF)
-        edge_tile<L, F0, HP>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k), pacc);
+        edge_tile<L, F0, HP, H1, H2>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k), pacc);
 #else
-        edge_tile<L, F0, HP>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k));
+        edge_tile<L, F0, HP, H1, H2>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k));
 #endif
     }
 #if defined(DEDF_PHASE_PROF)
@@ -49,10 +49,12 @@ template <int L, bool EBM, bool HP = false> __global__ __launch_bounds__(64, 1) 
     X(4, void k_edge<1, 64, false>(EdgeParams))                       \
     X(4, void k_edge<1, 128, false>(EdgeParams))                      \
     X(4, void k_edge<1, 128, true>(EdgeParams))                       \
+    X(7, void k_edge<2, 128, false, 32, 32>(EdgeParams))              \
+    X(7, void k_edge<1, 128, false, 32, 32>(EdgeParams))              \
     X(5, void k_node<2, false, false>(NodeParams))                    \
     X(5, void k_node<2, false, true>(NodeParams))                     \
     X(6, void k_node<2, true, false>(NodeParams))                     \
     X(6, void k_node<1, false, false>(NodeParams))                    \
     X(6, void k_node<1, false, true>(NodeParams))                     \
     X(6, void k_node<1, true, false>(NodeParams))
-constexpr int kKernelUnits = 7;
+constexpr int kKernelUnits = 8;

@@ -41,4 +41,9 @@
 #else
 #define DEDF_INST_6(...) DEDF_NOP(__VA_ARGS__)
 #endif
+#if DEDF_KUNIT == 7
+#define DEDF_INST_7(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_7(...) DEDF_NOP(__VA_ARGS__)
+#endif
 DEDF_KERNEL_LIST(DEDF_INST)

@@ -202,30 +202,31 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
     }
     auto rows = [&](int O, const float* v) { return pack_rows(O, [&](int i) { return v[i]; }); };
     int s3 = 0;
+    const int H1 = c.fc_neurons[1], H2 = c.fc_neurons[2];      // hidden widths of the radial MLP: 128, 64 or 32, 32
     {
         std::vector<float> ih, il;
         const float* W = S.get(B, rad + "net.0.weight");
-        pack_A_h(128, F0 / 16, [&](int oo, int k) { return W[oo * F0 + k]; }, [&](int cc, int j, int h) { return chain_k(F0, cc, j, h); }, ih, il);
+        pack_A_h(H1, F0 / 16, [&](int oo, int k) { return W[oo * F0 + k]; }, [&](int cc, int j, int h) { return chain_k(F0, cc, j, h); }, ih, il);
         o.o_A_r1 = im.push(ih); o.o_A_r1_l = im.push(il);
-        o.o_b_r1 = im.push(rows(128, S.get(B, rad + "net.0.bias")));
-        o.o_g_r1 = im.push(rows(128, S.get(B, rad + "net.1.weight")));
-        o.o_be_r1 = im.push(rows(128, S.get(B, rad + "net.1.bias")));
+        o.o_b_r1 = im.push(rows(H1, S.get(B, rad + "net.0.bias")));
+        o.o_g_r1 = im.push(rows(H1, S.get(B, rad + "net.1.weight")));
+        o.o_be_r1 = im.push(rows(H1, S.get(B, rad + "net.1.bias")));
         const float* W2 = S.get(B, rad + "net.3.weight");
-        pack_A_h(64, 8, [&](int oo, int k) { return W2[oo * 128 + k]; }, [](int cc, int j, int h) { return chain_k(128, cc, j, h); }, ih, il);
+        pack_A_h(H2, H1 / 16, [&](int oo, int k) { return W2[oo * H1 + k]; }, [&](int cc, int j, int h) { return chain_k(H1, cc, j, h); }, ih, il);
         o.o_A_r2 = im.push(ih); o.o_A_r2_l = im.push(il);
-        o.o_b_r2 = im.push(rows(64, S.get(B, rad + "net.3.bias")));
-        o.o_g_r2 = im.push(rows(64, S.get(B, rad + "net.4.weight")));
-        o.o_be_r2 = im.push(rows(64, S.get(B, rad + "net.4.bias")));
+        o.o_b_r2 = im.push(rows(H2, S.get(B, rad + "net.3.bias")));
+        o.o_g_r2 = im.push(rows(H2, S.get(B, rad + "net.4.weight")));
+        o.o_be_r2 = im.push(rows(H2, S.get(B, rad + "net.4.bias")));
         const float* W3 = S.get(B, rad + "net.6.weight");
         // rows (= per-edge TP weights) in the kernel's walk order: chunks grouped by output degree (dedf_net.h::dtp_walk_row)
         const float* off3 = S.get(B, rad + "offset");
         // the layer's output w (and with it the B operands w * CG of the lin / sep_alpha GEMMs) is produced as 2^s3 * w, s3 <= 8
         float m3 = 0.0f;
-        for (int i = 0; i < dtp_wn<L>() * 64; ++i) m3 = std::fmax(m3, std::fabs(W3[i]));
+        for (int i = 0; i < dtp_wn<L>() * H2; ++i) m3 = std::fmax(m3, std::fabs(W3[i]));
         for (int i = 0; i < dtp_wn<L>(); ++i) m3 = std::fmax(m3, std::fabs(off3[i]));
         s3 = pow2_scale(m3, 0, 8);
         const float f3 = std::ldexp(1.0f, s3);
-        pack_A_h(dtp_wn<L>(), 4, [&](int oo, int k) { return W3[dtp_walk_row<L>(oo) * 64 + k] * f3; }, [](int cc, int j, int h) { return chain_k(64, cc, j, h); }, ih, il);
+        pack_A_h(dtp_wn<L>(), H2 / 16, [&](int oo, int k) { return W3[dtp_walk_row<L>(oo) * H2 + k] * f3; }, [&](int cc, int j, int h) { return chain_k(H2, cc, j, h); }, ih, il);
         o.o_A_r3 = im.push(ih); o.o_A_r3_l = im.push(il);
         o.o_off_r3 = im.push(pack_rows(dtp_wn<L>(), [&](int i) { return off3[dtp_walk_row<L>(i)] * f3; }));
         o.w_unscale = std::ldexp(1.0f, -s3);

@@ -89,9 +89,12 @@ class HeadConfig:
         if fc[0] == -1:
             fc[0] = tf['length_emb_dim'] + (temb[-1] if ete else 0)
         assert fc[0] == tf['length_emb_dim'] + (temb[-1] if ete else 0)
-        if fc[1:] != [128, 64]:
-            raise NotImplementedError(f"fc_neurons {fc}: only [*, 128, 64] radial MLPs are instantiated (all panda_* configs and "
-                                      "sapien pick_highres; the two sapien place_highres configs use [*, 32, 32])")
+        if fc[1:] not in ([128, 64], [32, 32]):
+            raise NotImplementedError(f"fc_neurons {fc}: radial MLPs are instantiated for [*, 128, 64] (panda_* configs, sapien pick_*) "
+                                      "and [*, 32, 32] (sapien place_*)")
+        if fc[1:] == [32, 32] and (ebm or fc[0] != 128):
+            raise NotImplementedError(f"fc_neurons {fc}: the 32-wide radial MLP is instantiated for the score head with a 64-channel "
+                                      "time embedding (the sapien place_* configs)")
         if temb not in ([256, 128, 64], [512, 256, 128]):
             raise NotImplementedError(f"time_emb_mlp {temb}")
         radii = [None if r is None else float(r) for r in tf['r_cluster_multiscale']]

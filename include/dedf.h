@@ -47,7 +47,8 @@ typedef struct dedf_config {
     int lmax;                            /* irreps = 64x0e + 32x1e (+ 16x2e); SH 0..lmax.  Supported: 1, 2 */
     int mul[4];                          /* must equal {64,32,16,8}[0..lmax] (every reference config) */
     int num_heads;                       /* 4 */
-    int fc_neurons[3];                   /* {64 + time_emb_mlp[2],128,64} ({64,128,64} for the EBM head): fc_neurons after the -1 is resolved (multiscale_tensor_field.py:63-67) */
+    int fc_neurons[3];                   /* {64 + time_emb_mlp[2],128,64} ({64,128,64} for the EBM head), or {128,32,32} (sapien place_* score heads):
+                                            fc_neurons after the -1 is resolved (multiscale_tensor_field.py:63-67) */
     int length_emb_dim;                  /* 64 */
     int time_emb_mlp[3];                 /* {256,128,64}, or {512,256,128} (sapien high-res configs; fc_neurons[0] = 192) */
     int irreps_mlp_mid;                  /* 3 */

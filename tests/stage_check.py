@@ -78,7 +78,12 @@ def gpu_run(kw, P, keys, query, Ts, time, debug=True, half=False):
 
 
 def stage_report(lmax=2, nT=6, n_scene=512, n_grasp=100, verbose=True, half=False, **kwargs):
-    kw, cfg, P, keys, query, Ts, time = build_case(lmax, nT, n_scene, n_grasp, **kwargs)
+    return stage_report_case(*build_case(lmax, nT, n_scene, n_grasp, **kwargs), verbose=verbose, half=half)
+
+
+def stage_report_case(kw, cfg, P, keys, query, Ts, time, verbose=True, half=False):
+    """every stage of the HIP path (debug buffers of the C ABI) against the fp64 oracle on one case"""
+    nT = len(Ts)
     ang64, lin64, d64, ocfg = oracle_run(kw, P, keys, query, Ts, time, torch.float64)
     ang32, lin32, d32, _ = oracle_run(kw, P, keys, query, Ts, time, torch.float32)
     head, ang, lin = gpu_run(kw, P, keys, query, Ts, time, half=half)

@@ -334,3 +334,23 @@ def test_score_parity_sapien_highres_shape():
     assert head.stats()['n_edges'] == d64['n_edges_per_scale'] and d64['n_edges_per_scale'][0] > 100
     scale = float(max(ang64.abs().max(), lin64.abs().max()))
     assert float((ang.double() - ang64).abs().max()) / scale < TOL and float((lin.double() - lin64).abs().max()) / scale < TOL
+
+
+def test_score_parity_sapien_place_shape():
+    """reference configs/sapien/place_highres/score_model_configs.yaml:3-25 (and place_lowres): radial MLP fc_neurons [-1, 32, 32],
+    ONE finite scale r = 6 cm, max_time 0.1, time_enc_n 1000, r_mincut_nonscalar_sh left at its default (1 % of the radius)"""
+    kw = synthetic.score_head_kwargs(2, radii=(6.,))
+    kw['max_time'] = 0.1
+    kw['time_enc_n'] = 1000.
+    kw['key_tensor_field_kwargs']['fc_neurons'] = [-1, 32, 32]
+    kw['key_tensor_field_kwargs']['r_mincut_nonscalar_sh'] = None
+    cfg = params.HeadConfig.from_kwargs(kw)
+    assert cfg.fc_neurons == [128, 32, 32]
+    P = params.init_params(cfg, seed=2, randomize_all=True)
+    keys = synthetic.make_key_clouds(cfg, 3000, seed=0)
+    query = synthetic.make_query(cfg, 200, seed=0)
+    Ts = synthetic.make_poses(9, seed=1, near_object=True)
+    time = torch.linspace(0.01, 0.1, len(Ts), dtype=torch.float64)
+    rep = SC.stage_report_case(kw, cfg, P, keys, query, Ts, time, verbose=False)
+    assert sum(rep['edges_gpu']) > 100
+    _check(rep)

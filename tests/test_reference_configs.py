@@ -36,15 +36,13 @@ def test_shipped_config_is_accepted(path, built_lib):
     if doc["model_name"] != "MultiscaleScoreModel":
         pytest.skip("PointAttentiveScoreModel (sapien configs): not the path named by BASELINE.json")
     kw = _score_head_kwargs(doc)
-    if kw["key_tensor_field_kwargs"]["fc_neurons"][1:] != [128, 64]:
-        with pytest.raises(NotImplementedError):          # sapien place_highres: [-1, 32, 32] radial MLP, documented as not instantiated
-            params.HeadConfig.from_kwargs(kw)
-        return
     cfg = params.HeadConfig.from_kwargs(kw)
     assert cfg.irreps == [(64, 0), (32, 1), (16, 2)] and cfg.num_heads == 4 and cfg.n_scales in (1, 4)
     assert cfg.ebm == bool(kw.get("ebm", False))
-    # [64 + time_emb, 128, 64]: 128 for time_emb_mlp [256,128,64], 192 for the sapien high-res [512,256,128]; 64 for the EBM critic
-    assert cfg.fc_neurons == ([64, 128, 64] if cfg.ebm else [64 + cfg.time_emb_mlp[-1], 128, 64])
+    # [64 + time_emb, 128, 64]: 128 for time_emb_mlp [256,128,64], 192 for the sapien high-res [512,256,128]; 64 for the EBM critic;
+    # the sapien place_* score heads have the narrow radial MLP [128, 32, 32]
+    narrow = kw["key_tensor_field_kwargs"]["fc_neurons"][1:] == [32, 32]
+    assert cfg.fc_neurons == ([64, 128, 64] if cfg.ebm else [64 + cfg.time_emb_mlp[-1]] + ([32, 32] if narrow else [128, 64]))
     cc = _lib.make_config(cfg, -1)
     names = _lib.param_names(cc)
     assert names == [(n, int(np.prod(s))) for n, s, _, _ in params.param_spec(cfg)]
