@@ -108,11 +108,11 @@ int check_config(const dedf_config* c, std::string& why) {
     const bool mlp_narrow = c->fc_neurons[1] == 32 && c->fc_neurons[2] == 32;       // sapien place_* score heads
     if (c->fc_neurons[0] != (c->ebm ? kLenEmb : kLenEmb + c->time_emb_mlp[2]) || !(mlp_wide || mlp_narrow)) {
         why = "fc_neurons must resolve to [64 + time_emb, 128, 64] or [64 + time_emb, 32, 32] (score head), or [64,128,64] (EBM head without time encoding)"; return DEDF_ERR_UNSUPPORTED; }
-    if (mlp_narrow && (c->ebm || c->fc_neurons[0] != 128 || c->half_gemm)) {
-        why = "the 32-wide radial MLP is instantiated for the fp32-accurate score head with the 128-wide pre-linear only"; return DEDF_ERR_UNSUPPORTED; }
+    if (mlp_narrow && (c->ebm || c->fc_neurons[0] != 128)) {
+        why = "the 32-wide radial MLP is instantiated for the score head with the 128-wide pre-linear only"; return DEDF_ERR_UNSUPPORTED; }
     if (c->length_emb_dim != kLenEmb) { why = "length_emb_dim must be 64"; return DEDF_ERR_UNSUPPORTED; }
     if (c->irreps_mlp_mid != kMlpMid) { why = "irreps_mlp_mid must be 3"; return DEDF_ERR_UNSUPPORTED; }
-    if (c->half_gemm && (c->ebm || c->fc_neurons[0] != 128)) { why = "half_gemm is available for the score head with the 128-wide pre-linear only"; return DEDF_ERR_UNSUPPORTED; }
+    if (c->half_gemm && c->lmax == 1 && c->fc_neurons[0] == 192) { why = "lmax 1 with a 128-channel time embedding is not instantiated"; return DEDF_ERR_UNSUPPORTED; }
     if (c->n_scales < 1 || c->n_scales > kMaxScales) { why = "n_scales out of range"; return DEDF_ERR_INVALID; }
     bool inf = false;
     for (int n = 0; n < c->n_scales; ++n) {
@@ -303,12 +303,17 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         if (h->d_phase.ensure((size_t)h->n_cu * 4 * 16 * 8)) P.phase_prof = h->d_phase.as<unsigned long long>();
 #endif
         static const int wpc = [] { const char* e = getenv("DEDF_EDGE_WAVES_PER_CU"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 4 ? v : 4; }();   // experiments only
-        // half_gemm (the reference's half_precision knob): single-term fp16 products; instantiated for the 128-wide score head only
+        // half_gemm (the reference's half_precision knob): single-term fp16 products
+        const dim3 grid(h->n_cu * wpc), blk(64);
+        const bool hp = h->cfg.half_gemm != 0;
         if constexpr (F0 == 128) {
-            if (h->cfg.fc_neurons[1] == 32) hipLaunchKernelGGL((k_edge<L, F0, false, 32, 32>), dim3(h->n_cu * wpc), dim3(64), 0, st, P);
-            else if (h->cfg.half_gemm) hipLaunchKernelGGL((k_edge<L, F0, true>), dim3(h->n_cu * wpc), dim3(64), 0, st, P);
-            else hipLaunchKernelGGL((k_edge<L, F0>), dim3(h->n_cu * wpc), dim3(64), 0, st, P);
-        } else hipLaunchKernelGGL((k_edge<L, F0>), dim3(h->n_cu * wpc), dim3(64), 0, st, P);
+            if (h->cfg.fc_neurons[1] == 32) {         // narrow radial MLP (sapien place_*)
+                if (hp) hipLaunchKernelGGL((k_edge<L, F0, true, 32, 32>), grid, blk, 0, st, P);
+                else hipLaunchKernelGGL((k_edge<L, F0, false, 32, 32>), grid, blk, 0, st, P);
+            } else if (hp) hipLaunchKernelGGL((k_edge<L, F0, true>), grid, blk, 0, st, P);
+            else hipLaunchKernelGGL((k_edge<L, F0>), grid, blk, 0, st, P);
+        } else if (hp) hipLaunchKernelGGL((k_edge<L, F0, true>), grid, blk, 0, st, P);
+        else hipLaunchKernelGGL((k_edge<L, F0>), grid, blk, 0, st, P);
     }
     mark();
     // 5. joint softmax + aggregation
@@ -338,10 +343,8 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         P.node_out = h->d_nout.as<float>();
         if (h->debug && h->d_dbge.ensure((size_t)Nd * D * 4) && h->d_dbgf.ensure((size_t)Nd * D * 4)) { P.dbg_emb = h->d_dbge.as<float>(); P.dbg_field = h->d_dbgf.as<float>(); }
         const int ntiles = (Nd + 31) / 32;
-        if constexpr (!EBM && F0 == 128) {
-            if (h->cfg.half_gemm) hipLaunchKernelGGL((k_node<L, EBM, true>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
-            else hipLaunchKernelGGL((k_node<L, EBM>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
-        } else hipLaunchKernelGGL((k_node<L, EBM>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
+        if (h->cfg.half_gemm) hipLaunchKernelGGL((k_node<L, EBM, true>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
+        else hipLaunchKernelGGL((k_node<L, EBM>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
     }
     mark();
     // 7. per-pose reduction

@@ -51,10 +51,17 @@ template <int L, bool EBM, bool HP = false> __global__ __launch_bounds__(64, 1) 
     X(4, void k_edge<1, 128, true>(EdgeParams))                       \
     X(7, void k_edge<2, 128, false, 32, 32>(EdgeParams))              \
     X(7, void k_edge<1, 128, false, 32, 32>(EdgeParams))              \
+    X(8, void k_edge<2, 192, true>(EdgeParams))                       \
+    X(8, void k_edge<2, 64, true>(EdgeParams))                        \
+    X(9, void k_edge<2, 128, true, 32, 32>(EdgeParams))               \
+    X(9, void k_edge<1, 64, true>(EdgeParams))                        \
+    X(9, void k_edge<1, 128, true, 32, 32>(EdgeParams))               \
+    X(9, void k_node<2, true, true>(NodeParams))                      \
+    X(9, void k_node<1, true, true>(NodeParams))                      \
     X(5, void k_node<2, false, false>(NodeParams))                    \
     X(5, void k_node<2, false, true>(NodeParams))                     \
     X(6, void k_node<2, true, false>(NodeParams))                     \
     X(6, void k_node<1, false, false>(NodeParams))                    \
     X(6, void k_node<1, false, true>(NodeParams))                     \
     X(6, void k_node<1, true, false>(NodeParams))
-constexpr int kKernelUnits = 8;
+constexpr int kKernelUnits = 10;

@@ -46,4 +46,14 @@
 #else
 #define DEDF_INST_7(...) DEDF_NOP(__VA_ARGS__)
 #endif
+#if DEDF_KUNIT == 8
+#define DEDF_INST_8(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_8(...) DEDF_NOP(__VA_ARGS__)
+#endif
+#if DEDF_KUNIT == 9
+#define DEDF_INST_9(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_9(...) DEDF_NOP(__VA_ARGS__)
+#endif
 DEDF_KERNEL_LIST(DEDF_INST)

@@ -108,8 +108,6 @@ class ScoreModelHead(torch.nn.Module):
         GEMM mode of the kernels (every GEMM one fp16 MFMA product with fp32 accumulation instead of the 3-term split; tensor
         products, norms, softmax and the SE(3) update stay fp32).  Parameters are kept as fp32 master copies; fp16 inputs are
         accepted at the boundary."""
-        if self.cfg.ebm or self.cfg.fc_neurons[0] != 128:
-            raise NotImplementedError("half precision: score head with the [256,128,64] time MLP only")
         self.cfg.half_gemm = True
         self._release()
         return self

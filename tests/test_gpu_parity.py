@@ -354,3 +354,57 @@ def test_score_parity_sapien_place_shape():
     rep = SC.stage_report_case(kw, cfg, P, keys, query, Ts, time, verbose=False)
     assert sum(rep['edges_gpu']) > 100
     _check(rep)
+
+
+@pytest.mark.parametrize("shape", ["sapien_pick", "sapien_place", "ebm"])
+def test_half_precision_mode_other_shapes(shape):
+    """`model.half()` applies to every model the reference builds (agent.py:50-51): the half-precision GEMM mode is instantiated for
+    the 192-wide pre-linear, the narrow radial MLP and the EBM critic as well.  Same stated tolerance as test_half_precision_mode."""
+    Ts = synthetic.make_poses(9, seed=1, near_object=True)
+    dev = torch.device('cuda:0')
+    if shape == "ebm":
+        from diffusion_edf_amd.score_head import EbmScoreModelHead
+        kw = synthetic.ebm_head_kwargs(2)
+        cfg = params.HeadConfig.from_kwargs(kw)
+        P = params.init_params(cfg, seed=4, randomize_all=True)
+        keys = synthetic.make_key_clouds(cfg, 1024, seed=0)
+        query = synthetic.make_query(cfg, 100, seed=0)
+        time = torch.ones(len(Ts), dtype=torch.float64)
+        ok = [R.FeaturedPoints(k.x.double(), k.f.double(), k.b) for k in keys]
+        oq = R.FeaturedPoints(query.x.double(), query.f.double(), query.b, query.w.double())
+        e64 = R.compute_energy(R.config_from_kwargs(kw), R.cast_params(P, torch.float64), Ts, ok, oq, time)
+        gk, gq = _to_dev(keys, query, dev)
+        es = []
+        for half in (False, True):
+            head = EbmScoreModelHead(**{k: v for k, v in kw.items() if k != 'ebm'})
+            head.load_state_dict(P)
+            head.to(dev)
+            if half:
+                head.half()
+            es.append(head.compute_energy(Ts.to(dev).float(), gk, gq, time.to(dev).float()).cpu().double())
+        scale = float(e64.abs().max())
+        assert float((es[0] - e64).abs().max()) / scale < TOL
+        err = float((es[1] - e64).abs().max()) / scale
+        assert 3e-6 < err < 5e-3, err
+        return
+    kw = synthetic.score_head_kwargs(2, radii=(6.,))
+    if shape == "sapien_pick":
+        kw['time_emb_mlp'] = [512, 256, 128]
+        kw['key_tensor_field_kwargs']['r_mincut_nonscalar_sh'] = 0.1
+        time = torch.linspace(0.1, 1.0, len(Ts), dtype=torch.float64)
+    else:
+        kw['max_time'] = 0.1
+        kw['time_enc_n'] = 1000.
+        kw['key_tensor_field_kwargs']['fc_neurons'] = [-1, 32, 32]
+        kw['key_tensor_field_kwargs']['r_mincut_nonscalar_sh'] = None
+        time = torch.linspace(0.01, 0.1, len(Ts), dtype=torch.float64)
+    cfg = params.HeadConfig.from_kwargs(kw)
+    P = params.init_params(cfg, seed=2, randomize_all=True)
+    keys = synthetic.make_key_clouds(cfg, 3000, seed=0)
+    query = synthetic.make_query(cfg, 200, seed=0)
+    ang64, lin64, d64, _ = SC.oracle_run(kw, P, keys, query, Ts, time, torch.float64)
+    head, ang, lin = SC.gpu_run(kw, P, keys, query, Ts, time, debug=False, half=True)
+    assert head.stats()['n_edges'] == d64['n_edges_per_scale']
+    scale = float(max(ang64.abs().max(), lin64.abs().max()))
+    err = max(float((ang.double() - ang64).abs().max()), float((lin.double() - lin64).abs().max())) / scale
+    assert 3e-5 < err < 5e-3, err
