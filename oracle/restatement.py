@@ -807,5 +807,35 @@ def sample(cfg: Config, P, T_seed: Tensor, key_pcd_multiscale, query_pcd, diffus
     return torch.stack(Ts, dim=0)
 
 
+def agent_sample(models, critic, T0: Tensor, N_steps_list, timesteps_list, temperatures_list, diffusion_schedules_list,
+                 noise_list=None, log_t_schedule=True, time_exponent_temp=1.0, time_exponent_alpha=0.5,
+                 compute_dtype=torch.float32):
+    """DiffusionEdfAgent.sample — agent.py:98-186 on already extracted features: the models denoise one after the other,
+    each starting from the previous one's final poses (:139-156); the trajectories are concatenated (:157) and, with a critic,
+    the poses are reordered by ascending energy of the final poses (:159-174).
+    `models`: [(cfg, P, key_pcd_multiscale, query_pcd)], `critic`: the same tuple or None.  Returns (Ts_out, energy_sorted)."""
+    assert len(models) == len(N_steps_list) == len(timesteps_list) == len(temperatures_list) == len(diffusion_schedules_list)
+    if noise_list is None:
+        noise_list = [None] * len(models)
+    outs = []
+    for (cfg, P, keys, query), N_steps, timesteps, temperatures, sched, noise in zip(
+            models, N_steps_list, timesteps_list, temperatures_list, diffusion_schedules_list, noise_list):
+        assert len(sched) == len(N_steps) and len(sched) == len(timesteps)
+        Ts = sample(cfg, P, T0.clone(), keys, query, sched, N_steps, timesteps, temperatures, log_t_schedule,
+                    time_exponent_temp, time_exponent_alpha, noise=noise, compute_dtype=compute_dtype)
+        T0 = Ts[-1]
+        outs.append(Ts)
+    Ts_out = torch.cat(outs, dim=0)
+    energy_sorted = None
+    if critic is not None:
+        cfg, P, keys, query = critic
+        T_last = Ts_out[-1]
+        energy = compute_energy(cfg, P, T_last.to(P[next(iter(P))].dtype), keys, query,
+                                torch.ones(len(T_last), dtype=P[next(iter(P))].dtype))
+        energy_sorted, idx = energy.sort(descending=False)
+        Ts_out = Ts_out[..., idx, :]
+    return Ts_out, energy_sorted
+
+
 def cast_params(P: Dict[str, Tensor], dtype) -> Dict[str, Tensor]:
     return {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in P.items()}

@@ -69,3 +69,54 @@ def test_sharded_run_equals_single_process(n_poses):
     ref = _FakeModel().sample(T, None, None, seed=5)
     for rank, final, traj in res:
         assert torch.equal(final, ref[-1]) and torch.equal(traj, ref)
+
+
+class _FakeStage(_FakeModel):
+    """_FakeModel with the extractor hooks and schedules DiffusionEdfAgent.sample uses (agent.py:131-141)"""
+    diffusion_schedules = [[1.0, 0.1]]
+
+    def get_key_pcd_multiscale(self, pcd):
+        return None
+
+    def get_query_pcd(self, pcd):
+        return None
+
+    def sample(self, T_seed=None, scene_pcd_multiscale=None, grasp_pcd=None, seed=0, first_pose_index=0, noise=None, **kw):
+        return super().sample(T_seed, scene_pcd_multiscale, grasp_pcd, seed=seed, first_pose_index=first_pose_index)
+
+
+def _agent_worker(rank, world, port, n_poses, q):
+    from diffusion_edf_amd.agent import DiffusionEdfAgent
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T = synthetic.make_poses(n_poses, seed=1)
+    out, _, _ = DiffusionEdfAgent(models=[_FakeStage(), _FakeStage()]).sample(None, None, T, [[3], [3]], [[0.1], [0.1]], [1.0, 1.0], seed=2)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_agent_cascade_sharded_equals_single_process():
+    """two-stage cascade of the agent over 2 ranks: every stage shards the poses and gathers its whole trajectory, so each
+    rank returns what a single process returns"""
+    from diffusion_edf_amd.agent import DiffusionEdfAgent
+    n_poses = 9
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_agent_worker, args=(r, 2, port, n_poses, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    T = synthetic.make_poses(n_poses, seed=1)
+    ref, _, _ = DiffusionEdfAgent(models=[_FakeStage(), _FakeStage()]).sample(None, None, T, [[3], [3]], [[0.1], [0.1]], [1.0, 1.0], seed=2)
+    assert ref.shape == (8, n_poses, 7)
+    for rank, out in res:
+        assert torch.equal(out, ref)

@@ -408,3 +408,55 @@ def test_half_precision_mode_other_shapes(shape):
     scale = float(max(ang64.abs().max(), lin64.abs().max()))
     err = max(float((ang.double() - ang64).abs().max()), float((lin.double() - lin64).abs().max())) / scale
     assert 3e-5 < err < 5e-3, err
+
+
+def test_agent_cascade_and_critic_ranking_match_oracle():
+    """DiffusionEdfAgent.sample (reference agent.py:98-186): low-res model -> high-res model -> critic ranking, each model with its
+    own parameters and its own (pre-extracted) key / query features, injected noise; against oracle.agent_sample."""
+    from diffusion_edf_amd import agent as A
+    dev = torch.device('cuda:0')
+    nT = 7
+    Ts = synthetic.make_poses(nT, seed=1, near_object=True)
+    specs = [(synthetic.score_head_kwargs(2), 2, 0), (synthetic.score_head_kwargs(2, radii=(3.5, 5., 6.5, 8.)), 5, 1),
+             (synthetic.ebm_head_kwargs(2), 7, 2)]
+    omodels, gmodels = [], []
+    for kw, pseed, dseed in specs:
+        cfg = params.HeadConfig.from_kwargs(kw)
+        P = params.init_params(cfg, seed=pseed, randomize_all=True)
+        keys = synthetic.make_key_clouds(cfg, 600, seed=dseed)
+        query = synthetic.make_query(cfg, 60, seed=dseed)
+        ok = [R.FeaturedPoints(k.x.double(), k.f.double(), k.b) for k in keys]
+        oq = R.FeaturedPoints(query.x.double(), query.f.double(), query.b, query.w.double())
+        omodels.append((R.config_from_kwargs(kw), P, ok, oq))
+        gk, gq = _to_dev(keys, query, dev)
+        head_kw = {k: v for k, v in kw.items() if k != 'ebm'}
+        head = (A.EbmScoreModelHead if kw.get('ebm') else ScoreModelHead)(**head_kw)
+        head.load_state_dict(P)
+        head.to(dev)
+        m = ScoreModelBase(head)
+        irr = kw['irreps_query_edf']
+        m.get_key_pcd_multiscale = A.PrecomputedFeatures(gk, irr)
+        m.get_query_pcd = A.PrecomputedFeatures(gq, irr)
+        m.diffusion_schedules = [[1.0, 0.3]] if dseed == 0 else [[0.3, 0.1], [0.1, 0.05]]
+        gmodels.append(m)
+    N_steps_list, timesteps_list, temperatures_list = [[3], [2, 2]], [[0.04], [0.02, 0.02]], [1.0, [1.0, 0.5]]
+    g = torch.Generator().manual_seed(5)
+    noise = [torch.randn(sum(n), 2, nT, 3, generator=g, dtype=torch.float64) for n in N_steps_list]
+    o64 = [(c, R.cast_params(P, torch.float64), k, q) for c, P, k, q in omodels]
+    ref, e_ref = R.agent_sample(o64[:2], o64[2], Ts, N_steps_list, timesteps_list, temperatures_list,
+                                [m.diffusion_schedules for m in gmodels[:2]], noise_list=noise, compute_dtype=torch.float64)
+    ag = A.DiffusionEdfAgent(models=gmodels[:2], critic=gmodels[2])
+    out, scene, grasp, info = ag.sample("scene", "grasp", Ts.to(dev), N_steps_list, timesteps_list, temperatures_list,
+                                        return_info=True, noise_list=noise)
+    assert scene == "scene" and grasp == "grasp"
+    assert out.shape == ref.shape == (3 + 2 + 4 + 2, nT, 7) and out.dtype == torch.float64
+    e = info["energy"].cpu()
+    assert bool((e[1:] >= e[:-1]).all())
+    assert float((e - e_ref).abs().max() / e_ref.abs().max()) < 5e-4, (e, e_ref)
+    assert float((out.cpu() - ref).abs().max()) < 5e-4, float((out.cpu() - ref).abs().max())
+    # the second model starts where the first one ended; the seed row of the whole cascade is a permutation of the input
+    assert torch.equal(out[4], out[5])
+    assert torch.equal(torch.sort(out[0, :, 6]).values, torch.sort(Ts[:, 6].to(dev)).values)
+    # no critic, no noise injection: plain cascade runs on the Philox stream
+    out2, _, _ = A.DiffusionEdfAgent(models=gmodels[:2]).sample(None, None, Ts.to(dev), N_steps_list, timesteps_list, temperatures_list, seed=4)
+    assert out2.shape == out.shape and torch.isfinite(out2).all() and torch.equal(out2[0].cpu(), Ts)
