@@ -351,40 +351,58 @@ template <int L>
 __global__ void k_aggregate(const float* __restrict__ edge_out, const int* __restrict__ cnt, const int* __restrict__ off,
                             const int* __restrict__ tile_info, int n_dst, int n_scales, float* __restrict__ z) {
     constexpr int D = feat_dim<L>(), REC = edge_rec<L>(), NV = D / 4;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (wave >= n_dst) return;
-    const int d = wave;
+    const int lane = threadIdx.x & 63;
+    // wave-uniform destination index: its counts / offsets / record addresses then live in scalar registers (scalar loads)
+    const int d = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (d >= n_dst) return;
     if (tile_info[40]) return;
     const int ci = 4 * lane;
     int head = 0;
     if (ci < blk_off(1)) head = ci / (mul_of(0) / kHeads);
     else if (L >= 1 && ci < blk_off(2)) head = ((ci - blk_off(1)) % mul_of(1)) / (mul_of(1) / kHeads);
     else if (L >= 2) head = ((ci - blk_off(2)) % mul_of(2)) / (mul_of(2) / kHeads);
+    // k_edge left one record per (destination, 32-edge tile) segment at the segment's first edge: the destination's first edge
+    // and every tile boundary (scale-relative multiples of 32) inside its edge range.  All scales' counts and offsets are
+    // requested first, then the records of all scales form ONE list that is walked U at a time.
+    int first[kMaxScales], fb[kMaxScales], pre[kMaxScales + 1];       // all wave-uniform
+    pre[0] = 0;
+#pragma unroll
+    for (int n = 0; n < kMaxScales; ++n) {
+        first[n] = 0; fb[n] = 0;
+        int nr = 0;
+        if (n < n_scales) {
+            const int c = cnt[(size_t)n * n_dst + d];
+            const int o = off[(size_t)n * n_dst + d];
+            first[n] = tile_info[16 + n] + o;        // edge index of the destination's first record
+            fb[n] = 32 - (o & 31);                   // distance (in edges) to the next tile boundary
+            nr = c == 0 ? 0 : 1 + (fb[n] < c ? (c - fb[n] + 31) / 32 : 0);
+        }
+        pre[n + 1] = pre[n] + nr;
+    }
+    const int total = pre[kMaxScales];
     // single pass, online softmax: running max / sum per head, accumulator rescaled when a head's max grows
     float mx[kHeads], sum[kHeads] = {0, 0, 0, 0};
     for (int h = 0; h < kHeads; ++h) mx[h] = -INFINITY;
     f32x4 acc = {0, 0, 0, 0};
-    for (int n = 0; n < n_scales; ++n) {
-        const int c = cnt[(size_t)n * n_dst + d];
-        if (c == 0) continue;
-        // k_edge left one record per (destination, 32-edge tile) segment at the segment's first edge: the destination's first
-        // edge and every tile boundary (scale-relative multiples of 32) inside its edge range
-        const int o = off[(size_t)n * n_dst + d];
-        const float* rec = edge_out + ((size_t)tile_info[16 + n] + o) * REC;
-        const int first_b = 32 - (o & 31);                 // distance (in edges) to the next tile boundary
-        const int nrec = 1 + (first_b < c ? (c - first_b + 31) / 32 : 0);
-        // U records per iteration: all their loads are in flight together; the online-softmax update handles the group at once
-        constexpr int U = 4;
-        for (int j = 0; j < nrec; j += U) {
+    constexpr int U = 4;          // records per iteration: all their loads are in flight together
+    for (int j0 = 0; j0 < total; j0 += 64) {
+        // lane k holds the edge index of record j0 + k of the flattened list
+        const int k = j0 + lane;
+        int ek = 0;
+#pragma unroll
+        for (int n = 0; n < kMaxScales; ++n)
+            if (k >= pre[n] && k < pre[n + 1]) { const int jj = k - pre[n]; ek = first[n] + (jj == 0 ? 0 : fb[n] + 32 * (jj - 1)); }
+        const int jend = min(64, total - j0);
+        for (int j = 0; j < jend; j += U) {
             f32x4 lg[U], v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 lg[u] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                 v[u] = f32x4{0, 0, 0, 0};
-                if (j + u < nrec) {
-                    const size_t eo = j + u == 0 ? 0 : (size_t)(first_b + 32 * (j + u - 1));
-                    lg[u] = ld4(rec + eo * REC + D);
-                    if (lane < NV) v[u] = ld4(rec + eo * REC + ci);
+                if (j + u < jend) {
+                    const float* r = edge_out + (size_t)__builtin_amdgcn_readlane(ek, j + u) * REC;
+                    lg[u] = ld4(r + D);
+                    if (lane < NV) v[u] = ld4(r + ci);
                 }
             }
             float sc[kHeads], p[U][kHeads];
