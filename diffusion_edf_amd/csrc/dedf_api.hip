@@ -69,6 +69,7 @@ struct dedf_handle {
     int scale_start[kMaxScales + 1] = {0};
     bool have_keys = false, have_query = false;
     // device: per call
+    float t_shared = 0.0f; bool use_t_shared = false;     // dedf_sample: the step's time travels as a kernel argument
     DevBuf d_Ts, d_time, d_tb, d_pose, d_qpos, d_cnt, d_off, d_blk, d_tile, d_esrc, d_edst, d_eout, d_z, d_nout, d_ang, d_lin, d_T64, d_dbgw, d_dbge, d_dbgf, d_dbgo, d_mask;
     int64_t edge_cap = 0;
     int last_nT = 0;
@@ -242,7 +243,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     // 2. time embedding -> pre-linear bias rows (EBM head: constant bias rows, uploaded once)
     if constexpr (!EBM) {
         TimeParams tp{};
-        tp.time = h->d_time.as<float>(); tp.time_stride = time_stride;
+        tp.time = h->use_t_shared ? nullptr : h->d_time.as<float>(); tp.time_stride = time_stride; tp.t_shared = h->t_shared;
         tp.w1 = nat + h->nat_tw1; tp.b1 = nat + h->nat_tb1; tp.w2 = nat + h->nat_tw2; tp.b2 = nat + h->nat_tb2;
         tp.wpre = nat + h->nat_wpre; tp.bpre = nat + h->nat_bpre; tp.tfreq = nat + h->nat_tfreq;
         tp.E = c.time_emb_mlp[0]; tp.H = c.time_emb_mlp[1]; tp.TE = c.time_emb_mlp[2];
@@ -553,9 +554,9 @@ int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedul
     HIPCK(h, hipMemcpyAsync(Ts_out, T_seed, row * 8, hipMemcpyDeviceToDevice, st));
     for (int s = 0; s < sched->n_steps; ++s) {
         hipLaunchKernelGGL(k_cast_pose, dim3((unsigned)((row + 255) / 256)), dim3(256), 0, st, h->d_T64.as<double>(), h->d_Ts.as<float>(), (int)row);
-        const float tf = (float)sched->t[s];
-        HIPCK(h, hipMemcpyAsync(h->d_time.p, &tf, 4, hipMemcpyHostToDevice, st));   // pageable 4-byte copy: staged by the runtime
+        h->t_shared = (float)sched->t[s]; h->use_t_shared = true;      // every pose shares the step's time: a kernel argument, no copy
         rc = score_dispatch(h, nT, 0, h->d_ang.as<float>(), h->d_lin.as<float>(), st);
+        h->use_t_shared = false;
         if (rc != DEDF_OK) return rc;
         LangevinParams lp{};
         lp.T = h->d_T64.as<double>(); lp.ang = h->d_ang.as<float>(); lp.lin = h->d_lin.as<float>();
