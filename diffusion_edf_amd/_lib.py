@@ -17,7 +17,7 @@ OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_RUNTIME = 0, 1, 2, 3
 
 SYMBOLS = [
     "dedf_version", "dedf_param_count", "dedf_param_name", "dedf_param_numel", "dedf_create", "dedf_destroy",
-    "dedf_last_error", "dedf_set_key_clouds", "dedf_set_query", "dedf_score", "dedf_energy", "dedf_sample", "dedf_get_stats",
+    "dedf_last_error", "dedf_set_key_clouds", "dedf_set_key_weights", "dedf_set_query", "dedf_score", "dedf_energy", "dedf_sample", "dedf_get_stats",
     "dedf_debug_enable", "dedf_debug_copy", "dedf_debug_packed", "dedf_profile_enable", "dedf_profile_read",
 ]
 
@@ -28,7 +28,7 @@ class DedfConfig(C.Structure):
         ("length_emb_dim", C.c_int), ("time_emb_mlp", C.c_int * 3), ("irreps_mlp_mid", C.c_int), ("n_scales", C.c_int),
         ("radii", C.c_float * MAX_SCALES), ("r_mincut_nonscalar_sh", C.c_float), ("length_enc_max_r", C.c_float),
         ("max_time", C.c_float), ("time_enc_n", C.c_float), ("lin_mult", C.c_float), ("ang_mult", C.c_float),
-        ("max_neighbors", C.c_int), ("device", C.c_int), ("max_edges", C.c_int64), ("ebm", C.c_int), ("half_gemm", C.c_int),
+        ("max_neighbors", C.c_int), ("device", C.c_int), ("max_edges", C.c_int64), ("ebm", C.c_int), ("half_gemm", C.c_int), ("use_src_point_attn", C.c_int),
     ]
 
 
@@ -73,6 +73,7 @@ def load() -> C.CDLL:
     lib.dedf_last_error.argtypes = [C.c_void_p]; lib.dedf_last_error.restype = C.c_char_p
     lib.dedf_set_key_clouds.argtypes = [C.c_void_p, C.c_int, P(C.c_int), P(C.c_void_p), P(C.c_void_p), C.c_void_p]
     lib.dedf_set_key_clouds.restype = C.c_int
+    lib.dedf_set_key_weights.argtypes = [C.c_void_p, C.c_int, P(C.c_int), P(C.c_void_p), C.c_void_p]; lib.dedf_set_key_weights.restype = C.c_int
     lib.dedf_set_query.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]; lib.dedf_set_query.restype = C.c_int
     lib.dedf_score.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]; lib.dedf_score.restype = C.c_int
     lib.dedf_energy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]; lib.dedf_energy.restype = C.c_int
@@ -111,6 +112,7 @@ def make_config(cfg: HeadConfig, device: int, max_edges: int = 0) -> DedfConfig:
     c.max_edges = max_edges
     c.ebm = int(cfg.ebm)
     c.half_gemm = int(getattr(cfg, 'half_gemm', False))
+    c.use_src_point_attn = int(getattr(cfg, 'use_src_point_attn', False))
     return c
 
 

@@ -4,6 +4,7 @@ cascade with critic ranking.
 Mirrors, for everything that touches the score head (same names, argument meaning, assertion messages):
 
   reference diffusion_edf/multiscale_score_model.py:27-135   -> ``MultiscaleScoreModel``
+  reference diffusion_edf/point_attentive_score_model.py:23-110 -> ``PointAttentiveScoreModel``
   reference diffusion_edf/trainer.py:35-70, 124-147           -> ``load_configs`` / checkpoint loading in ``get_models``
   reference diffusion_edf/agent.py:20-64                      -> ``get_models``
   reference diffusion_edf/agent.py:66-186                     -> ``DiffusionEdfAgent`` (``compute_critic_energy``, ``sample``)
@@ -47,6 +48,7 @@ class MultiscaleScoreModel(ScoreModelBase):
     ``score_head_kwargs`` / ``key_kwargs`` / ``query_kwargs`` are the blocks of ``score_model_configs.yaml`` unchanged; the
     keys the reference injects into ``key_tensor_field_kwargs`` (``irreps_input``, ``use_src_point_attn``,
     ``use_dst_point_attn``, :79-85) and ``irreps_query_edf`` (:93, :104) are injected here the same way."""
+    _use_src_point_attn = False
 
     def __init__(self,
                  query_model: str,
@@ -58,7 +60,7 @@ class MultiscaleScoreModel(ScoreModelBase):
                  query_extractor: Optional[Callable] = None):
         super().__init__()
         key_name = key_kwargs['feature_extractor_name']
-        if key_name not in ('UnetFeatureExtractor', 'ForwardOnlyFeatureExtractor'):
+        if not self._use_src_point_attn and key_name not in ('UnetFeatureExtractor', 'ForwardOnlyFeatureExtractor'):
             raise ValueError(f"Unknown feature extractor name: {key_name}")                    # :51
         if query_model not in ('KeypointExtractor', 'StaticKeypointModel'):
             raise ValueError(f"Unknown query model: {query_model}")                            # :62
@@ -81,7 +83,7 @@ class MultiscaleScoreModel(ScoreModelBase):
         assert 'irreps_input' not in tf.keys()
         tf['irreps_input'] = key_irreps
         assert 'use_src_point_attn' not in tf.keys()
-        tf['use_src_point_attn'] = False
+        tf['use_src_point_attn'] = self._use_src_point_attn
         assert 'use_dst_point_attn' not in tf.keys()
         tf['use_dst_point_attn'] = False
         head_cls = EbmScoreModelHead if score_head_kwargs.get("ebm", False) else ScoreModelHead
@@ -116,6 +118,17 @@ class MultiscaleScoreModel(ScoreModelBase):
         return r
 
 
+class PointAttentiveScoreModel(MultiscaleScoreModel):
+    """reference point_attentive_score_model.py:23-110: the key model is ONE KeypointExtractor whose output is the single key
+    cloud (``get_key_pcd_multiscale`` wraps it in a list, :106-107) and whose point weights ``w`` multiply the attention of every
+    edge after the softmax (``use_src_point_attn=True``, :71-72; gnn_block.py:190-194)."""
+    _use_src_point_attn = True
+
+    def get_key_pcd_multiscale(self, pcd) -> List[FeaturedPoints]:
+        out = self._extract("get_key_pcd_multiscale", self.key_model, pcd)
+        return out if isinstance(out, (list, tuple)) else [out]
+
+
 def load_configs(configs_root_dir: str, train_configs_file: str, task_configs_file: str) -> Dict[str, Dict]:
     """The three YAML files of one model directory, as reference trainer.py:41-48 reads them."""
     with open(os.path.join(configs_root_dir, train_configs_file)) as f:
@@ -143,12 +156,13 @@ def get_models(configs_root_dir: str,
     out-of-scope data loader."""
     cfgs = load_configs(configs_root_dir, train_configs_file, task_configs_file)
     name = cfgs['model']['model_name']
-    if name != 'MultiscaleScoreModel':
-        if name == 'PointAttentiveScoreModel':
-            raise NotImplementedError("PointAttentiveScoreModel is not the path this build accelerates")
-        raise ValueError(f"Unknown score model name: {name}")                                  # trainer.py:139
-    model = MultiscaleScoreModel(**cfgs['model']['model_kwargs'], deterministic=False,
-                                 key_extractor=key_extractor, query_extractor=query_extractor)
+    if name == 'PointAttentiveScoreModel':                                                     # trainer.py:134-139
+        model_cls = PointAttentiveScoreModel
+    elif name == 'MultiscaleScoreModel':
+        model_cls = MultiscaleScoreModel
+    else:
+        raise ValueError(f"Unknown score model name: {name}")
+    model = model_cls(**cfgs['model']['model_kwargs'], deterministic=False, key_extractor=key_extractor, query_extractor=query_extractor)
     if checkpoint_dir is not None:                                                              # trainer.py:141-147
         checkpoint = torch.load(checkpoint_dir, map_location='cpu')
         model.load_state_dict(checkpoint['score_model_state_dict'], strict=strict_load)

@@ -69,6 +69,7 @@ struct dedf_handle {
     int scale_start[kMaxScales + 1] = {0};
     bool have_keys = false, have_query = false;
     // device: per call
+    DevBuf d_key_w; bool have_key_w = false;              // key-point attention weights (use_src_point_attn)
     float t_shared = 0.0f; bool use_t_shared = false;     // dedf_sample: the step's time travels as a kernel argument
     DevBuf d_Ts, d_time, d_tb, d_pose, d_qpos, d_cnt, d_off, d_blk, d_tile, d_esrc, d_edst, d_eout, d_z, d_nout, d_ang, d_lin, d_T64, d_dbgw, d_dbge, d_dbgf, d_dbgo, d_mask;
     int64_t edge_cap = 0;
@@ -296,6 +297,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         P.w_unscale = o.w_unscale; P.u_scale = o.u_scale;
         for (int l = 0; l < 4; ++l) { P.c_lin[l] = o.c_lin[l]; P.c_val[l] = o.c_val[l]; }
         P.o_b_r0 = o.o_b_r0; P.o_b_val0 = o.o_b_val0; P.o_alpha_dot = o.o_alpha_dot;
+        P.key_w = h->cfg.use_src_point_attn ? h->d_key_w.as<float>() : nullptr;
         P.out = h->d_eout.as<float>();
         P.dbg_w = h->debug ? h->d_dbgw.as<float>() : nullptr;
         P.dbg_out = (h->debug && h->d_dbgo.ensure((size_t)h->edge_cap * edge_rec<L>() * 4)) ? h->d_dbgo.as<float>() : nullptr;
@@ -485,6 +487,24 @@ int dedf_set_key_clouds(dedf_handle* h, int n_scales, const int* n_pts, const fl
                            nat + h->nat_wsrc, nat + h->nat_bsrc, h->d_msg.as<float>());
     HIPCK(h, hipStreamSynchronize(st));
     h->have_keys = true;
+    h->have_key_w = false;
+    return DEDF_OK;
+}
+
+int dedf_set_key_weights(dedf_handle* h, int n_scales, const int* n_pts, const float* const* w, void* stream) {
+    if (!h) return DEDF_ERR_INVALID;
+    if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
+    if (!h->have_keys) return fail(h, DEDF_ERR_INVALID, "dedf_set_key_clouds must be called first");
+    if (n_scales != h->cfg.n_scales || !n_pts || !w) return fail(h, DEDF_ERR_INVALID, "n_scales mismatch / null arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCK(h, hipSetDevice(h->cfg.device));
+    for (int n = 0; n < n_scales; ++n)
+        if (n_pts[n] != h->scale_start[n + 1] - h->scale_start[n] || (n_pts[n] > 0 && !w[n])) return fail(h, DEDF_ERR_INVALID, "key weights do not match the key clouds");
+    if (!h->d_key_w.ensure((size_t)h->n_keys * 4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(key weights) failed");
+    for (int n = 0; n < n_scales; ++n)
+        if (n_pts[n] > 0) HIPCK(h, hipMemcpyAsync(h->d_key_w.as<float>() + h->scale_start[n], w[n], (size_t)n_pts[n] * 4, hipMemcpyDeviceToDevice, st));
+    HIPCK(h, hipStreamSynchronize(st));
+    h->have_key_w = true;
     return DEDF_OK;
 }
 
@@ -511,6 +531,7 @@ int dedf_score(dedf_handle* h, int nT, const float* Ts, const float* time, float
     if (!h) return DEDF_ERR_INVALID;
     if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
     if (!h->have_keys || !h->have_query) return fail(h, DEDF_ERR_INVALID, "set_key_clouds / set_query must be called first");
+    if (h->cfg.use_src_point_attn && !h->have_key_w) return fail(h, DEDF_ERR_INVALID, "use_src_point_attn: the key clouds carry no point weights (dedf_set_key_weights; gnn_block.py:191-192)");
     if (nT <= 0 || !Ts || !time || !ang || !lin) return fail(h, DEDF_ERR_INVALID, "bad arguments");
     if (h->cfg.ebm) return fail(h, DEDF_ERR_UNSUPPORTED, "EBM head: the score is the autograd of the energy (score_head_ebm.py:203-217), "
                                                           "which needs a backward pass and is not on the accelerated path; use dedf_energy");
@@ -528,6 +549,7 @@ int dedf_energy(dedf_handle* h, int nT, const float* Ts, const float* time, floa
     if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
     if (!h->cfg.ebm) return fail(h, DEDF_ERR_UNSUPPORTED, "dedf_energy needs a handle created with dedf_config.ebm = 1");
     if (!h->have_keys || !h->have_query) return fail(h, DEDF_ERR_INVALID, "set_key_clouds / set_query must be called first");
+    if (h->cfg.use_src_point_attn && !h->have_key_w) return fail(h, DEDF_ERR_INVALID, "use_src_point_attn: the key clouds carry no point weights (dedf_set_key_weights; gnn_block.py:191-192)");
     if (nT <= 0 || !Ts || !energy) return fail(h, DEDF_ERR_INVALID, "bad arguments");
     (void)time;   // the critic has no time encoding (configs/*/pick_ebm/score_model_configs.yaml:8-9; agent.py:170)
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -543,6 +565,7 @@ int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedul
     if (!h) return DEDF_ERR_INVALID;
     if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
     if (!h->have_keys || !h->have_query) return fail(h, DEDF_ERR_INVALID, "set_key_clouds / set_query must be called first");
+    if (h->cfg.use_src_point_attn && !h->have_key_w) return fail(h, DEDF_ERR_INVALID, "use_src_point_attn: the key clouds carry no point weights (dedf_set_key_weights; gnn_block.py:191-192)");
     if (nT <= 0 || !T_seed || !sched || sched->n_steps < 0 || !Ts_out) return fail(h, DEDF_ERR_INVALID, "bad arguments");
     if (h->cfg.ebm) return fail(h, DEDF_ERR_UNSUPPORTED, "EBM head: sampling needs the energy gradient (backward pass); use dedf_energy");
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -49,6 +49,7 @@ struct EdgeParams {
     float w_unscale, u_scale, c_lin[4], c_val[4];     // power-of-two operand scaling of the split-fp16 GEMMs (dedf_pack.h::EdgeOffsets)
     int o_b_val0;             // row-packed (64)
     int o_alpha_dot;          // row-packed over the two alpha tiles
+    const float* key_w;       // optional [sum N_s]: key-point attention weights (use_src_point_attn: alpha *= w_src after the softmax)
     float* out;               // [E][edge_rec]: ONE record per (destination, tile) segment, stored at the segment's first edge:
                               //   value = softmax-weighted mean of the segment's edge values, logit = log-sum-exp of its logits
     float* dbg_out;           // optional [E][edge_rec] per-edge records (value, logits) for the stage tests
@@ -586,7 +587,10 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         });
         if (seg_last && hi == 0) st4(P.out + (size_t)(e0 + seg_start) * REC + D, f32x4{lse[0], lse[1], lse[2], lse[3]});
         // the per-head weights wait in LDS until each irreps block is emitted (8 registers less during the value GEMMs)
-        pk[SPW * 64] = f32x4{pw[0], pw[1], pw[2], pw[3]};
+        // point attention (gnn_block.py:190-194, graph_attention.py:257-258): the edge's softmax weight is multiplied by its key
+        // point's weight AFTER the normalisation, i.e. the values are weighted by pw * w_src while the sums above are not
+        const float wsrc = P.key_w != nullptr ? P.key_w[src] : 1.0f;
+        pk[SPW * 64] = f32x4{pw[0], pw[1], pw[2], pw[3]} * wsrc;
         pk[(SPW + 1) * 64] = f32x4{inv_s[0], inv_s[1], inv_s[2], inv_s[3]};
     }
     auto orec_of = [&]() { return P.out + (size_t)(e0 + seg_start) * REC; };

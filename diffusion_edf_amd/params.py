@@ -42,6 +42,7 @@ class HeadConfig:
     max_neighbors: int = 1000
     ebm: bool = False                    # EbmScoreModelHead (reference score_head_ebm.py): energy critic, no time encoding
     half_gemm: bool = False              # the reference's half_precision knob (agent.py:50-51): single-term fp16 GEMM products
+    use_src_point_attn: bool = False     # PointAttentiveScoreModel (point_attentive_score_model.py:71-72): attention times the key points' weights
 
     @property
     def n_scales(self) -> int:
@@ -80,8 +81,8 @@ class HeadConfig:
             raise NotImplementedError("n_layers != 1")
         if tf.get('cutoff_method', 'edge_attn') != 'edge_attn':
             raise NotImplementedError("cutoff_method != 'edge_attn'")
-        if tf.get('use_src_point_attn', False) or tf.get('use_dst_point_attn', False):
-            raise NotImplementedError("point attention")
+        if tf.get('use_dst_point_attn', False):
+            raise NotImplementedError                                                   # gnn_block.py:196-197
         sh = parse_irreps(tf['irreps_sh'])
         assert all(m == 1 for m, _ in sh) and [l for _, l in sh] == list(range(len(sh)))
         fc = list(tf['fc_neurons'])
@@ -119,7 +120,8 @@ class HeadConfig:
                    length_enc_max_r=float(lmr) if lmr is not None else 0.0, time_emb_mlp=temb,
                    max_time=float(k['max_time']), time_enc_n=float(k.get('time_enc_n', 10000.)),
                    lin_mult=float(k['lin_mult']), ang_mult=float(k['ang_mult']),
-                   irreps_mlp_mid=int(tf.get('irreps_mlp_mid', 3)), ebm=ebm)
+                   irreps_mlp_mid=int(tf.get('irreps_mlp_mid', 3)), ebm=ebm,
+                   use_src_point_attn=bool(tf.get('use_src_point_attn', False)))
 
 
 # --------------------------------------------------------------------------------------------------

@@ -153,7 +153,20 @@ class ScoreModelHead(torch.nn.Module):
         fp = (C.c_void_p * n)(*[f.data_ptr() for f in fs])
         rc = lib.dedf_set_key_clouds(self._handle, n, npts, xp, fp, self._stream())
         _lib.raise_for(lib, self._handle, rc, "dedf_set_key_clouds")
-        self._scene_key = tuple((p.x.data_ptr(), p.f.data_ptr(), p.x._version, p.f._version, len(p.x)) for p in key_pcd_multiscale)
+        if self.cfg.use_src_point_attn:              # PointAttentiveScoreModel: alpha *= src_points.w[edge_src]  (gnn_block.py:190-194)
+            for p in key_pcd_multiscale:
+                assert isinstance(p.w, torch.Tensor)                                     # gnn_block.py:192
+                assert p.w.ndim == 1 and len(p.w) == len(p.x), f"{p.w.shape}"
+            ws = [p.w.detach().to(torch.float32).contiguous() for p in key_pcd_multiscale]
+            wp = (C.c_void_p * n)(*[w.data_ptr() for w in ws])
+            rc = lib.dedf_set_key_weights(self._handle, n, npts, wp, self._stream())
+            _lib.raise_for(lib, self._handle, rc, "dedf_set_key_weights")
+        self._scene_key = self._key_of(key_pcd_multiscale)
+
+    def _key_of(self, key_pcd_multiscale):
+        return tuple((p.x.data_ptr(), p.f.data_ptr(), p.x._version, p.f._version, len(p.x)) +
+                     ((p.w.data_ptr(), p.w._version) if self.cfg.use_src_point_attn and isinstance(p.w, torch.Tensor) else ())
+                     for p in key_pcd_multiscale)
 
     def set_query(self, query_pcd: FeaturedPoints):
         dev = query_pcd.x.device
@@ -171,7 +184,7 @@ class ScoreModelHead(torch.nn.Module):
                            query_pcd.f._version, query_pcd.w._version, len(x))
 
     def _sync_inputs(self, key_pcd_multiscale, query_pcd):
-        sk = tuple((p.x.data_ptr(), p.f.data_ptr(), p.x._version, p.f._version, len(p.x)) for p in key_pcd_multiscale)
+        sk = self._key_of(key_pcd_multiscale)
         if self._handle is None or sk != self._scene_key:
             self.set_key_clouds(key_pcd_multiscale)
         qk = (query_pcd.x.data_ptr(), query_pcd.f.data_ptr(), query_pcd.w.data_ptr(), query_pcd.x._version,
@@ -210,7 +223,9 @@ class ScoreModelHead(torch.nn.Module):
         Ts = torch.cat([q, torch.randn(nT, 3, device=device)], dim=-1)
         time = torch.rand(nT, device=device)
         key_pcd_multiscale = [FeaturedPoints(x=torch.randn(nP, 3, device=device), f=torch.randn(nP, self.key_edf_dim, device=device),
-                                             b=torch.zeros(nP, device=device, dtype=torch.long)) for _ in range(self.n_scales)]
+                                             b=torch.zeros(nP, device=device, dtype=torch.long),
+                                             w=torch.ones(nP, device=device) if self.cfg.use_src_point_attn else None)
+                              for _ in range(self.n_scales)]
         query_pcd = FeaturedPoints(x=torch.randn(nQ, 3, device=device), f=torch.randn(nQ, self.query_edf_dim, device=device),
                                    b=torch.zeros(nQ, device=device, dtype=torch.long), w=torch.ones(nQ, device=device))
         return Ts, key_pcd_multiscale, query_pcd, time

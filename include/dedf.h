@@ -12,6 +12,7 @@
  *                           GraphAttentionMLP2.__init__          diffusion_edf/graph_attention.py:139-214)
  *   dedf_set_key_clouds  the `key_pcd_multiscale` argument        score_head.py:143; also hoists the pose-independent
  *                        prenorm_src + linear_src                 gnn_block.py:170-171
+ *   dedf_set_key_weights `key_pcd_multiscale[n].w` (point attention)   gnn_block.py:190-194
  *   dedf_set_query       the `query_pcd` argument                 score_head.py:144,151-157
  *   dedf_score           ScoreModelHead.forward                   score_head.py:142-211
  *   dedf_sample          ScoreModelBase.sample (inner loop)       score_model_base.py:110-204
@@ -66,6 +67,9 @@ typedef struct dedf_config {
                                             no lin/ang_vel_tp parameters; only dedf_energy is available.  0: ScoreModelHead */
     int half_gemm;                       /* 1: the reference's half_precision knob (agent.py:29,50-51 `model.half()`): every GEMM as ONE fp16 MFMA product
                                             (fp16 operands, fp32 accumulate) instead of the 3-term split; everything else stays fp32.  0: default */
+    int use_src_point_attn;              /* 1: PointAttentiveScoreModel (point_attentive_score_model.py:71-72): the attention of every edge is
+                                            multiplied, after the softmax, by its key point's weight (gnn_block.py:190-194,
+                                            graph_attention.py:257-258); the weights come through dedf_set_key_weights.  0: default */
 } dedf_config;
 
 typedef struct dedf_schedule {           /* host arrays, one entry per denoising step (score_model_base.py:146-171) */
@@ -99,6 +103,9 @@ const char* dedf_last_error(const dedf_handle* h);
 /* x[s]: (n_pts[s],3), f[s]: (n_pts[s],D) device pointers; host arrays of pointers.  Copies the clouds and precomputes
  * the source message.  Synchronises `stream` before returning. */
 int dedf_set_key_clouds(dedf_handle* h, int n_scales, const int* n_pts, const float* const* x, const float* const* f, void* stream);
+/* w[s]: (n_pts[s],) device pointers: the key points' attention weights `FeaturedPoints.w` (gnn_block.py:191-193).  Required
+ * before scoring when dedf_config.use_src_point_attn = 1; call after dedf_set_key_clouds (same n_pts). */
+int dedf_set_key_weights(dedf_handle* h, int n_scales, const int* n_pts, const float* const* w, void* stream);
 /* x: (nQ,3), f: (nQ,D), w: (nQ,) device pointers (copied). */
 int dedf_set_query(dedf_handle* h, int nQ, const float* x, const float* f, const float* w, void* stream);
 

@@ -524,6 +524,7 @@ class Config(NamedTuple):
     irreps_mlp_mid: int = 3
     max_neighbors: int = 1000
     edge_time_encoding: bool = True
+    use_src_point_attn: bool = False   # PointAttentiveScoreModel (point_attentive_score_model.py:71-72): alpha *= w_src after the softmax
 
 
 def config_from_kwargs(score_head_kwargs: dict) -> Config:
@@ -538,6 +539,8 @@ def config_from_kwargs(score_head_kwargs: dict) -> Config:
     assert not k.get('query_time_encoding', True)
     assert ete or k.get('ebm', False), "No time encoding! Are you sure?"       # score_head.py:72-73 (the EBM head allows it)
     assert tf.get('n_layers', 1) == 1 and tf.get('cutoff_method', 'edge_attn') == 'edge_attn'
+    if tf.get('use_dst_point_attn', False):
+        raise NotImplementedError                                  # gnn_block.py:196-197
     fc = list(tf['fc_neurons'])
     if fc[0] == -1:                                               # multiscale_tensor_field.py:63-67
         fc[0] = tf['length_emb_dim'] + (k['time_emb_mlp'][-1] if ete else 0)
@@ -551,7 +554,8 @@ def config_from_kwargs(score_head_kwargs: dict) -> Config:
                   length_enc_max_r=tf.get('length_enc_max_r', None), time_emb_mlp=list(k['time_emb_mlp']),
                   max_time=float(k['max_time']), time_enc_n=float(k.get('time_enc_n', 10000.)),
                   lin_mult=float(k['lin_mult']), ang_mult=float(k['ang_mult']),
-                  irreps_mlp_mid=tf.get('irreps_mlp_mid', 3), edge_time_encoding=ete)
+                  irreps_mlp_mid=tf.get('irreps_mlp_mid', 3), edge_time_encoding=ete,
+                  use_src_point_attn=bool(tf.get('use_src_point_attn', False)))
 
 
 class FeaturedPoints(NamedTuple):
@@ -664,6 +668,11 @@ def key_tensor_field(cfg: Config, P, query_x: Tensor, key_pcd_multiscale: Sequen
     ssum = torch.zeros((N_dst, H), dtype=log_alpha.dtype).index_add_(0, edge_dst, torch.exp(log_alpha - mx_safe[edge_dst]))
     log_Z = torch.log(ssum) + mx_safe
     alpha = torch.exp(log_alpha - log_Z[edge_dst])
+    if cfg.use_src_point_attn:                                   # gnn_block.py:190-194, graph_attention.py:257-258: after the softmax
+        for kp in key_pcd_multiscale:
+            assert isinstance(kp.w, Tensor)
+        src_w = torch.cat([kp.w for kp in key_pcd_multiscale], dim=0)
+        alpha = alpha * src_w[edge_src].unsqueeze(-1)
     attn = value * alpha.unsqueeze(-1)
     attn = torch.zeros((N_dst,) + attn.shape[1:], dtype=attn.dtype).index_add_(0, edge_dst, attn)
     attn = heads2vec(attn, irreps_head)

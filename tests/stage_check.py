@@ -52,7 +52,7 @@ def build_case(lmax=2, nT=6, n_scene=512, n_grasp=100, seed=0, radii=(5., 10., 2
 def oracle_run(kw, P, keys, query, Ts, time, dtype):
     ocfg = R.config_from_kwargs(kw)
     Pd = R.cast_params(P, dtype)
-    okeys = [R.FeaturedPoints(k.x.to(dtype), k.f.to(dtype), k.b) for k in keys]
+    okeys = [R.FeaturedPoints(k.x.to(dtype), k.f.to(dtype), k.b, None if k.w is None else k.w.to(dtype)) for k in keys]
     oq = R.FeaturedPoints(query.x.to(dtype), query.f.to(dtype), query.b, query.w.to(dtype))
     dbg = R.Debug()
     ang, lin = R.score_head_forward(ocfg, Pd, Ts.to(dtype), okeys, oq, time.to(dtype), dbg)
@@ -66,7 +66,7 @@ def gpu_run(kw, P, keys, query, Ts, time, debug=True, half=False):
     head.to(dev)
     if half:
         head.half()          # the reference's half_precision switch (agent.py:50-51)
-    gkeys = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
+    gkeys = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev), None if k.w is None else k.w.to(dev)) for k in keys]
     gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
     head.set_key_clouds(gkeys)
     head.set_query(gq)

@@ -42,16 +42,13 @@ def _write_config_dir(d, kw, schedules=((1.0, 0.15),)):
 @pytest.mark.parametrize("d", DIRS, ids=[os.path.relpath(d, CFG_ROOT) for d in DIRS])
 def test_get_models_on_shipped_config_dirs(d):
     doc = yaml.safe_load(open(os.path.join(d, "score_model_configs.yaml")))
-    if doc["model_name"] != "MultiscaleScoreModel":
-        with pytest.raises(NotImplementedError):
-            A.get_models(d, "train_configs.yaml", "task_configs.yaml", None, "cpu", n_warmups=0)
-        return
     m = A.get_models(d, "train_configs.yaml", "task_configs.yaml", None, "cpu", n_warmups=0)
     train = yaml.safe_load(open(os.path.join(d, "train_configs.yaml")))
     assert m.diffusion_schedules == train["diffusion_configs"]["time_schedules"]
     sh = doc["model_kwargs"]["score_head_kwargs"]
     assert m.lin_mult == float(sh["lin_mult"]) and m.ang_mult == float(sh["ang_mult"])
     assert isinstance(m.score_head, A.EbmScoreModelHead) == bool(sh.get("ebm", False))
+    assert isinstance(m, A.PointAttentiveScoreModel) == (doc["model_name"] == "PointAttentiveScoreModel") == m.score_head.cfg.use_src_point_attn
     assert m.score_head.cfg.radii == [None if r is None else float(r) for r in sh["key_tensor_field_kwargs"]["r_cluster_multiscale"]]
     assert not m.training
     with pytest.raises(NotImplementedError):          # extractors are injected, never silently replaced

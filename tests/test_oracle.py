@@ -203,3 +203,42 @@ def test_segment_records_merge_to_the_joint_softmax():
         w = np.exp(lse - lse.max())
         merged = (w[:, None] * mean).sum(0) / w.sum()
         assert np.allclose(merged, direct, rtol=1e-12, atol=1e-12)
+
+
+def test_point_attention_multiplies_after_the_softmax():
+    """use_src_point_attn (gnn_block.py:190-194, graph_attention.py:257-258): alpha = softmax(.) * w_src, NOT renormalised:
+    unit weights change nothing, a common factor c scales the aggregated attention (hence the proj input) by c, and a zero
+    weight removes a key point's contribution without changing the other edges' softmax weights."""
+    from diffusion_edf_amd import params, synthetic
+    kw = synthetic.score_head_kwargs(1, radii=(None,))
+    kw['key_tensor_field_kwargs']['use_src_point_attn'] = True
+    kw0 = synthetic.score_head_kwargs(1, radii=(None,))
+    cfg, cfg0 = R.config_from_kwargs(kw), R.config_from_kwargs(kw0)
+    assert cfg.use_src_point_attn and not cfg0.use_src_point_attn
+    P = R.cast_params(params.init_params(params.HeadConfig.from_kwargs(kw), seed=2, randomize_all=True), torch.float64)
+    g = torch.Generator().manual_seed(0)
+    nK, nQ = 7, 5
+    x, f = torch.randn(nK, 3, generator=g, dtype=torch.float64) * 5, torch.randn(nK, 160, generator=g, dtype=torch.float64)
+    qx = torch.randn(nQ, 3, generator=g, dtype=torch.float64) * 5
+    temb = [torch.randn(nQ, 64, generator=g, dtype=torch.float64)]
+    b = torch.zeros(nK, dtype=torch.long)
+
+    def attn(c, w):
+        d = R.Debug()
+        R.key_tensor_field(c, P, qx, [R.FeaturedPoints(x, f, b, w)], temb, d)
+        return d['attn']
+    base = attn(cfg0, None)
+    assert torch.allclose(attn(cfg, torch.ones(nK, dtype=torch.float64)), base, atol=1e-14)
+    assert torch.allclose(attn(cfg, torch.full((nK,), 0.25, dtype=torch.float64)), 0.25 * base, atol=1e-14)
+    w = torch.ones(nK, dtype=torch.float64); w[3] = 0.0
+    d = R.Debug()
+    R.key_tensor_field(cfg0, P, qx, [R.FeaturedPoints(x, f, b, None)], temb, d)
+    # plain attention minus key point 3's softmax-weighted share
+    log_alpha, value, es, ed = d['log_alpha'], d['value'], d['edge_src'], d['edge_dst']
+    Z = torch.zeros(nQ, log_alpha.shape[1], dtype=torch.float64).index_add_(0, ed, log_alpha.exp())
+    share = (value * (log_alpha.exp() / Z[ed]).unsqueeze(-1))[es == 3]
+    expect = base.clone()
+    expect.index_add_(0, ed[es == 3], -R.heads2vec(share, [(m // cfg.num_heads, l) for m, l in cfg.irreps]))
+    assert torch.allclose(attn(cfg, w), expect, atol=1e-12)
+    with pytest.raises(AssertionError):
+        attn(cfg, None)

@@ -1,4 +1,4 @@
-"""Every MultiscaleScoreModel config the reference ships must be accepted unchanged by the drop-in heads and by the C ABI.
+"""Every score-model config the reference ships (MultiscaleScoreModel and PointAttentiveScoreModel) must be accepted unchanged by the drop-in heads and by the C ABI.
 Reads /root/reference/configs (build container only; skipped on boxes without the reference tree).  The score-head kwargs
 are assembled exactly as reference multiscale_score_model.py:64-112 does (irreps_input / irreps_query_edf injected from
 the key / query model outputs)."""
@@ -22,7 +22,7 @@ def _score_head_kwargs(doc):
     sh = dict(mk["score_head_kwargs"])
     tf = dict(sh["key_tensor_field_kwargs"])
     tf["irreps_input"] = mk["key_kwargs"]["feature_extractor_kwargs"]["irreps_output"]
-    tf["use_src_point_attn"] = False
+    tf["use_src_point_attn"] = doc["model_name"] == "PointAttentiveScoreModel"          # point_attentive_score_model.py:71-72
     tf["use_dst_point_attn"] = False
     sh["key_tensor_field_kwargs"] = tf
     q = mk["query_kwargs"]
@@ -33,12 +33,11 @@ def _score_head_kwargs(doc):
 @pytest.mark.parametrize("path", FILES, ids=[os.path.relpath(f, CFG_ROOT) for f in FILES])
 def test_shipped_config_is_accepted(path, built_lib):
     doc = yaml.safe_load(open(path))
-    if doc["model_name"] != "MultiscaleScoreModel":
-        pytest.skip("PointAttentiveScoreModel (sapien configs): not the path named by BASELINE.json")
+    assert doc["model_name"] in ("MultiscaleScoreModel", "PointAttentiveScoreModel")
     kw = _score_head_kwargs(doc)
     cfg = params.HeadConfig.from_kwargs(kw)
     assert cfg.irreps == [(64, 0), (32, 1), (16, 2)] and cfg.num_heads == 4 and cfg.n_scales in (1, 4)
-    assert cfg.ebm == bool(kw.get("ebm", False))
+    assert cfg.ebm == bool(kw.get("ebm", False)) and cfg.use_src_point_attn == (doc["model_name"] == "PointAttentiveScoreModel")
     # [64 + time_emb, 128, 64]: 128 for time_emb_mlp [256,128,64], 192 for the sapien high-res [512,256,128]; 64 for the EBM critic;
     # the sapien place_* score heads have the narrow radial MLP [128, 32, 32]
     narrow = kw["key_tensor_field_kwargs"]["fc_neurons"][1:] == [32, 32]
@@ -55,4 +54,4 @@ def test_shipped_config_is_accepted(path, built_lib):
 
 def test_all_multiscale_configs_seen():
     kinds = [yaml.safe_load(open(f))["model_name"] for f in FILES]
-    assert kinds.count("MultiscaleScoreModel") == 22
+    assert kinds.count("MultiscaleScoreModel") == 22 and kinds.count("PointAttentiveScoreModel") == 4
