@@ -70,7 +70,8 @@ struct dedf_handle {
     bool have_keys = false, have_query = false;
     // device: per call
     DevBuf d_key_w; bool have_key_w = false;              // key-point attention weights (use_src_point_attn)
-    float t_shared = 0.0f; bool use_t_shared = false;     // dedf_sample: the step's time travels as a kernel argument
+    DevBuf d_tb_steps; const float* tb_step = nullptr;    // dedf_sample: the time-bias rows of ALL steps are computed up front; tb_step = this step's rows
+    std::vector<float> h_tsteps;
     DevBuf d_Ts, d_time, d_tb, d_pose, d_qpos, d_cnt, d_off, d_blk, d_tile, d_esrc, d_edst, d_eout, d_z, d_nout, d_ang, d_lin, d_T64, d_dbgw, d_dbge, d_dbgf, d_dbgo, d_mask;
     int64_t edge_cap = 0;
     int last_nT = 0;
@@ -223,6 +224,19 @@ int ensure_workspace(dedf_handle* h, int nT) {
     return DEDF_OK;
 }
 
+// Time embedding -> pre-linear bias rows tb[row][scale][F0] for `rows` times read at time[row * time_stride]
+void launch_time_bias(dedf_handle* h, hipStream_t st, const float* time, int time_stride, int rows, float* tb) {
+    const dedf_config& c = h->cfg;
+    const float* nat = h->d_nat.as<float>();
+    TimeParams tp{};
+    tp.time = time; tp.time_stride = time_stride;
+    tp.w1 = nat + h->nat_tw1; tp.b1 = nat + h->nat_tb1; tp.w2 = nat + h->nat_tw2; tp.b2 = nat + h->nat_tb2;
+    tp.wpre = nat + h->nat_wpre; tp.bpre = nat + h->nat_bpre; tp.tfreq = nat + h->nat_tfreq;
+    tp.E = c.time_emb_mlp[0]; tp.H = c.time_emb_mlp[1]; tp.TE = c.time_emb_mlp[2];
+    tp.max_time = c.max_time; tp.time_enc_n = c.time_enc_n; tp.tb = tb;
+    hipLaunchKernelGGL(k_time_bias, dim3(rows, c.n_scales), dim3(256), 0, st, tp);
+}
+
 // one evaluation of the score head on poses already in h->d_Ts (f32) with times in h->d_time
 template <int L, int F0>
 int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, hipStream_t st) {
@@ -243,13 +257,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     hipLaunchKernelGGL(k_pose_prep<L>, dim3(nT), dim3(64), 0, st, h->d_Ts.as<float>(), h->d_qx.as<float>(), nQ, h->d_pose.as<float>(), h->d_qpos.as<float>());
     // 2. time embedding -> pre-linear bias rows (EBM head: constant bias rows, uploaded once)
     if constexpr (!EBM) {
-        TimeParams tp{};
-        tp.time = h->use_t_shared ? nullptr : h->d_time.as<float>(); tp.time_stride = time_stride; tp.t_shared = h->t_shared;
-        tp.w1 = nat + h->nat_tw1; tp.b1 = nat + h->nat_tb1; tp.w2 = nat + h->nat_tw2; tp.b2 = nat + h->nat_tb2;
-        tp.wpre = nat + h->nat_wpre; tp.bpre = nat + h->nat_bpre; tp.tfreq = nat + h->nat_tfreq;
-        tp.E = c.time_emb_mlp[0]; tp.H = c.time_emb_mlp[1]; tp.TE = c.time_emb_mlp[2];
-        tp.max_time = c.max_time; tp.time_enc_n = c.time_enc_n; tp.tb = h->d_tb.as<float>();
-        hipLaunchKernelGGL(k_time_bias, dim3(time_stride ? nT : 1, ns), dim3(256), 0, st, tp);
+        if (h->tb_step == nullptr) launch_time_bias(h, st, h->d_time.as<float>(), time_stride, time_stride ? nT : 1, h->d_tb.as<float>());
     }
     mark();
     // 3. neighbour search
@@ -277,8 +285,9 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         if constexpr (EBM) {
             P.tb = nat + h->nat_brows; P.tb_bytes = (uint32_t)((size_t)ns * F0 * 4); P.tb_pose_stride = 0;
         } else {
-            P.tb = h->d_tb.as<float>(); P.tb_bytes = (uint32_t)((size_t)(time_stride ? nT : 1) * ns * F0 * 4);
-            P.tb_pose_stride = time_stride ? ns * F0 : 0;
+            P.tb = h->tb_step ? h->tb_step : h->d_tb.as<float>();
+            P.tb_bytes = (uint32_t)((size_t)(time_stride && !h->tb_step ? nT : 1) * ns * F0 * 4);
+            P.tb_pose_stride = time_stride && !h->tb_step ? ns * F0 : 0;
         }
         P.nQ = nQ; P.n_scales = ns;
         for (int n = 0; n < ns; ++n) {
@@ -575,11 +584,21 @@ int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedul
     const size_t row = (size_t)nT * 7;
     HIPCK(h, hipMemcpyAsync(h->d_T64.p, T_seed, row * 8, hipMemcpyDeviceToDevice, st));
     HIPCK(h, hipMemcpyAsync(Ts_out, T_seed, row * 8, hipMemcpyDeviceToDevice, st));
+    // every pose shares the step's time: the time-bias rows of all steps come from ONE launch before the loop
+    const size_t tb_row = (size_t)h->cfg.n_scales * h->cfg.fc_neurons[0];
+    if (sched->n_steps > 0) {
+        if (!h->d_tb_steps.ensure((size_t)sched->n_steps * tb_row * 4) || !h->d_time.ensure((size_t)std::max(nT, sched->n_steps) * 4))
+            return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(time rows) failed");
+        h->h_tsteps.resize(sched->n_steps);
+        for (int s = 0; s < sched->n_steps; ++s) h->h_tsteps[s] = (float)sched->t[s];
+        HIPCK(h, hipMemcpyAsync(h->d_time.p, h->h_tsteps.data(), (size_t)sched->n_steps * 4, hipMemcpyHostToDevice, st));
+        launch_time_bias(h, st, h->d_time.as<float>(), 1, sched->n_steps, h->d_tb_steps.as<float>());
+    }
     for (int s = 0; s < sched->n_steps; ++s) {
         hipLaunchKernelGGL(k_cast_pose, dim3((unsigned)((row + 255) / 256)), dim3(256), 0, st, h->d_T64.as<double>(), h->d_Ts.as<float>(), (int)row);
-        h->t_shared = (float)sched->t[s]; h->use_t_shared = true;      // every pose shares the step's time: a kernel argument, no copy
+        h->tb_step = h->d_tb_steps.as<float>() + (size_t)s * tb_row;
         rc = score_dispatch(h, nT, 0, h->d_ang.as<float>(), h->d_lin.as<float>(), st);
-        h->use_t_shared = false;
+        h->tb_step = nullptr;
         if (rc != DEDF_OK) return rc;
         LangevinParams lp{};
         lp.T = h->d_T64.as<double>(); lp.ang = h->d_ang.as<float>(); lp.lin = h->d_lin.as<float>();

@@ -91,8 +91,7 @@ __global__ void k_pose_prep(const float* __restrict__ Ts, const float* __restric
 //   tb[p][n][row-packed 128] = W_pre[n][:, 64:] . MLP_n(sinusoid(time_p)) + b_pre[n]
 // grid (nTb, n_scales), block 128.
 struct TimeParams {
-    const float* time; int time_stride;             // stride 0: one shared time; time == nullptr: the shared time is t_shared (sampler)
-    float t_shared;
+    const float* time; int time_stride;             // stride 0: one shared time
     const float *w1, *b1, *w2, *b2;                 // [n_scales][H][E], [H], [TE][H], [TE]
     const float *wpre, *bpre;                       // [n_scales][F0][F0], [F0]   (F0 = 64 + TE)
     const float* tfreq;                             // [E/2] exp(k * -(ln n / (E/2 - 1))) evaluated on the host like torch does
@@ -105,7 +104,7 @@ __global__ __launch_bounds__(256) void k_time_bias(TimeParams P) {
     __shared__ float enc[kTimeMaxEnc], hid[kTimeMaxHid], emb[kTimeMaxEmb];
     const int p = blockIdx.x, n = blockIdx.y, n_scales = gridDim.y, tid = threadIdx.x;
     const int E = P.E, H = P.H, TE = P.TE, F0 = kLenEmb + TE;
-    const float t = P.time != nullptr ? P.time[p * P.time_stride] : P.t_shared;
+    const float t = P.time[p * P.time_stride];
     // SinusoidalPositionEmbeddings(dim E, max_val, n) — radial_func.py:305-316
     const float x = t / P.max_time * P.time_enc_n;
     for (int i = tid; i < E / 2; i += blockDim.x) {
