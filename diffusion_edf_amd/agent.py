@@ -12,7 +12,8 @@ Mirrors, for everything that touches the score head (same names, argument meanin
 What is NOT here: the UNet / keypoint feature extractors and ``edf_interface`` (PointCloud, SE3, the
 pre-processing pipeline).  They are *injected*: every model takes a ``key_extractor`` and a ``query_extractor`` — any callable
 ``FeaturedPoints -> List[FeaturedPoints]`` / ``FeaturedPoints -> FeaturedPoints`` with an ``irreps_output`` attribute, e.g. the
-reference's own modules running in PyTorch, or ``PrecomputedFeatures`` below.  Without them ``get_key_pcd_multiscale`` /
+reference's own modules running in PyTorch, or ``PrecomputedFeatures`` below.  The one exception is ``StaticKeypointModel``
+(the query model of the pick_* configs): it holds parameters only and is built here.  Without them ``get_key_pcd_multiscale`` /
 ``get_query_pcd`` raise ``NotImplementedError`` — there is no silent stand-in.
 """
 from __future__ import annotations
@@ -42,6 +43,33 @@ class PrecomputedFeatures(torch.nn.Module):
         return self.output
 
 
+class StaticKeypointModel(torch.nn.Module):
+    """reference keypoint_extractor.py:22-47 — the query model of every pick_* config: fixed keypoint coordinates (buffer), learned
+    features and weight logits (parameters; same names, so `query_model.*` of a reference checkpoint loads); the output is
+    repeated once per batch index present in the input."""
+
+    def __init__(self, keypoint_coords, irreps_output):
+        super().__init__()
+        keypoint_coords = torch.tensor(keypoint_coords)
+        assert keypoint_coords.ndim == 2 and keypoint_coords.shape[-1] == 3, f"{keypoint_coords.shape}"  # (nPoints, 3)
+        self.irreps_output = str(irreps_output)
+        from .params import irreps_dim, parse_irreps
+        self.register_buffer("keypoint_coords", keypoint_coords)
+        self.keypoint_features = torch.nn.Parameter(torch.randn(len(self.keypoint_coords), irreps_dim(parse_irreps(self.irreps_output))))
+        self.keypoint_weights = torch.nn.Parameter(torch.randn(len(self.keypoint_coords)))
+
+    def forward(self, input_points: FeaturedPoints) -> FeaturedPoints:
+        b = input_points.b
+        assert b.ndim == 1
+        batch_unique = torch.unique(b)
+        x = self.keypoint_coords.repeat(len(batch_unique), 1)
+        f = self.keypoint_features.repeat(len(batch_unique), 1)
+        w = torch.sigmoid(self.keypoint_weights)
+        w = w.repeat(len(batch_unique))
+        b = batch_unique.repeat(len(self.keypoint_coords))
+        return FeaturedPoints(x=x, f=f, b=b, w=w)
+
+
 class MultiscaleScoreModel(ScoreModelBase):
     """reference multiscale_score_model.py:27-135 with the two extractors injected instead of built.
 
@@ -65,6 +93,8 @@ class MultiscaleScoreModel(ScoreModelBase):
         if query_model not in ('KeypointExtractor', 'StaticKeypointModel'):
             raise ValueError(f"Unknown query model: {query_model}")                            # :62
         self.key_model = key_extractor
+        if query_extractor is None and query_model == 'StaticKeypointModel':
+            query_extractor = StaticKeypointModel(**query_kwargs)                               # :58-60 (parameters only: built here)
         self.query_model = query_extractor
         key_irreps = getattr(key_extractor, 'irreps_output', None) or key_kwargs['feature_extractor_kwargs']['irreps_output']
         if getattr(query_extractor, 'irreps_output', None):

@@ -27,7 +27,8 @@ def _model_yaml(kw):
     return dict(model_name='MultiscaleScoreModel',
                 model_kwargs=dict(score_head_kwargs=sh,
                                   key_kwargs=dict(feature_extractor_name='UnetFeatureExtractor', feature_extractor_kwargs=dict(irreps_output=irr)),
-                                  query_model='StaticKeypointModel', query_kwargs=dict(irreps_output=irr)))
+                                  query_model='StaticKeypointModel',
+                                  query_kwargs=dict(keypoint_coords=[[0.5, 0.5, 10.5], [-0.5, -0.5, 10.5]], irreps_output=irr)))
 
 
 def _write_config_dir(d, kw, schedules=((1.0, 0.15),)):
@@ -53,6 +54,18 @@ def test_get_models_on_shipped_config_dirs(d):
     assert not m.training
     with pytest.raises(NotImplementedError):          # extractors are injected, never silently replaced
         m.get_key_pcd_multiscale(None)
+    if doc["model_kwargs"]["query_model"] == "StaticKeypointModel":       # parameters only: part of the model (keypoint_extractor.py:22-47)
+        qk = doc["model_kwargs"]["query_kwargs"]
+        from diffusion_edf_amd.gnn_data import FeaturedPoints
+        q = m.get_query_pcd(FeaturedPoints(x=torch.zeros(5, 3), f=torch.zeros(5, 3), b=torch.zeros(5, dtype=torch.long)))
+        nK = len(qk["keypoint_coords"])
+        assert q.x.shape == (nK, 3) and q.f.shape == (nK, m.score_head.cfg.dim) and q.w.shape == (nK,) and q.b.shape == (nK,)
+        assert torch.equal(q.x, torch.tensor(qk["keypoint_coords"])) and bool(((q.w > 0) & (q.w < 1)).all())
+        assert {k for k in m.state_dict() if k.startswith("query_model.")} == {
+            "query_model.keypoint_coords", "query_model.keypoint_features", "query_model.keypoint_weights"}
+    else:
+        with pytest.raises(NotImplementedError):
+            m.get_query_pcd(None)
 
 
 def test_checkpoint_load_like_the_reference_agent(tmp_path):
@@ -63,7 +76,9 @@ def test_checkpoint_load_like_the_reference_agent(tmp_path):
     P = params.init_params(cfg, seed=11, randomize_all=True)
     sd = {"score_head." + k: v for k, v in P.items()}
     sd["key_model.blocks.0.weight"] = torch.zeros(3)             # extractor weights of the full reference model
-    sd["query_model.keypoint_coords"] = torch.zeros(2, 3)
+    sd["query_model.keypoint_coords"] = torch.tensor([[0.5, 0.5, 10.5], [-0.5, -0.5, 10.5]])
+    sd["query_model.keypoint_features"] = torch.randn(2, cfg.dim)
+    sd["query_model.keypoint_weights"] = torch.tensor([0.3, -1.2])
     ck = str(tmp_path / "Pick_LowRes_300.pt")
     torch.save(dict(score_model_state_dict=sd, epoch=300, steps=12345), ck)
     m = A.get_models(d, "train_configs.yaml", "task_configs.yaml", ck, "cpu", n_warmups=0)          # strict_load=False: agent.py:28
@@ -71,6 +86,8 @@ def test_checkpoint_load_like_the_reference_agent(tmp_path):
     assert set(got) == set(P)
     for k, v in P.items():
         assert torch.equal(got[k], v), k
+    q = m.get_query_pcd(synthetic.make_query(cfg, 0, seed=0, static_keypoints=True))        # StaticKeypointModel: weights from the checkpoint
+    assert torch.equal(q.f, sd["query_model.keypoint_features"]) and torch.allclose(q.w, torch.sigmoid(torch.tensor([0.3, -1.2])))
     assert m.diffusion_schedules == [[1.0, 0.15], [0.15, 0.01]]
     with pytest.raises(RuntimeError, match="Unexpected key"):
         A.get_models(d, "train_configs.yaml", "task_configs.yaml", ck, "cpu", n_warmups=0, strict_load=True)
