@@ -103,6 +103,39 @@ def run_case(i, rng):
     return err, edges_ok, desc
 
 
+def run_sample_case(i, rng):
+    """ScoreModelBase.sample (3-5 Langevin steps, injected noise) against the oracle's float64 loop with an fp32 score"""
+    kw, cfg, P, keys, query, Ts, time = draw_case(rng)
+    import oracle.restatement as R
+    from diffusion_edf_amd.score_head import ScoreModelHead
+    from diffusion_edf_amd.score_model_base import ScoreModelBase
+    Ts = Ts[:12]
+    n_steps = [int(rng.integers(1, 4)), int(rng.integers(1, 3))]
+    tmax = kw['max_time']
+    sched = [[tmax, 0.4 * tmax], [0.4 * tmax, 0.1 * tmax]]
+    dts = [float(rng.uniform(0.005, 0.05)), float(rng.uniform(0.005, 0.03))]
+    temps = [float(rng.uniform(0.0, 1.5)), float(rng.uniform(0.0, 1.0))]
+    g = torch.Generator().manual_seed(int(rng.integers(0, 1 << 30)))
+    noise = torch.randn(sum(n_steps), 2, len(Ts), 3, generator=g, dtype=torch.float64)
+    ocfg = R.config_from_kwargs(kw)._replace(max_neighbors=cfg.max_neighbors)
+    ok = [R.FeaturedPoints(k.x, k.f, k.b, k.w) for k in keys]
+    oq = R.FeaturedPoints(query.x, query.f, query.b, query.w)
+    ref = R.sample(ocfg, P, Ts, ok, oq, sched, n_steps, dts, temperatures=temps, noise=noise)
+    dev = torch.device('cuda:0')
+    head = ScoreModelHead(**kw)
+    head.cfg.max_neighbors = cfg.max_neighbors
+    head.load_state_dict(P)
+    head.to(dev)
+    gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev), None if k.w is None else k.w.to(dev)) for k in keys]
+    gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
+    out = ScoreModelBase(head).sample(Ts.to(dev), gk, gq, sched, n_steps, dts, temperatures=temps, noise=noise).cpu()
+    err = float((out - ref).abs().max())
+    move = float((ref[-1] - ref[0]).abs().max())
+    ok_ = out.shape == ref.shape and err < 1e-3 and bool(torch.isfinite(out).all())
+    print(f"sample {i:3d} |dT| {err:.2e} (poses moved {move:.2e}) steps {n_steps} nT {len(Ts)} lmax {cfg.lmax} radii {cfg.radii} cap {cfg.max_neighbors}", flush=True)
+    return err, ok_, ""
+
+
 def run_cases(n, seed):
     rng = np.random.default_rng(seed)
     bad = []
@@ -116,6 +149,12 @@ def run_cases(n, seed):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    if len(sys.argv) > 3 and sys.argv[3] == "sample":
+        rng = np.random.default_rng(seed)
+        res = [run_sample_case(i, rng) for i in range(n)]
+        nbad = sum(1 for r in res if not r[1])
+        print("FAILED" if nbad else "ALL OK", nbad, "of", n, "largest pose difference", max(r[0] for r in res))
+        sys.exit(1 if nbad else 0)
     rng = np.random.default_rng(seed)
     bad = []
     for i in range(n):
