@@ -19,6 +19,7 @@ SYMBOLS = [
     "dedf_version", "dedf_param_count", "dedf_param_name", "dedf_param_numel", "dedf_create", "dedf_destroy",
     "dedf_last_error", "dedf_set_key_clouds", "dedf_set_key_weights", "dedf_set_query", "dedf_score", "dedf_energy", "dedf_sample", "dedf_get_stats",
     "dedf_debug_enable", "dedf_debug_copy", "dedf_debug_packed", "dedf_profile_enable", "dedf_profile_read",
+    "dedf_fps", "dedf_radius",
 ]
 
 
@@ -79,6 +80,10 @@ def load() -> C.CDLL:
     lib.dedf_energy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]; lib.dedf_energy.restype = C.c_int
     lib.dedf_sample.argtypes = [C.c_void_p, C.c_int, C.c_void_p, P(DedfSchedule), C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.dedf_sample.restype = C.c_int
+    lib.dedf_fps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]; lib.dedf_fps.restype = C.c_int
+    lib.dedf_radius.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                P(C.c_int64), C.c_void_p]
+    lib.dedf_radius.restype = C.c_int
     lib.dedf_get_stats.argtypes = [C.c_void_p, P(DedfStats)]; lib.dedf_get_stats.restype = C.c_int
     lib.dedf_debug_enable.argtypes = [C.c_void_p, C.c_int]; lib.dedf_debug_enable.restype = C.c_int
     lib.dedf_debug_copy.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, P(C.c_size_t)]; lib.dedf_debug_copy.restype = C.c_int

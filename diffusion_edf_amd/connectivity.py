@@ -1,0 +1,121 @@
+"""Graph construction of the feature extractors — mirrors reference ``diffusion_edf/connectivity.py`` (``RadiusGraph`` :8-30,
+``RadiusConnect`` :34-49, ``FpsPool`` :53-80) on the HIP primitives ``dedf_fps`` / ``dedf_radius`` instead of torch_cluster /
+torch_scatter.  Single cloud (every shipped config has all batch indices 0); inputs must live on the GPU — there is no CPU path.
+SURVEY §8(f) row 1 building blocks: the UNet blocks that consume these graphs are not part of this build yet."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check_cloud(x: torch.Tensor, batch: Optional[torch.Tensor]):
+    assert x.ndim == 2 and x.shape[-1] == 3
+    if not x.is_cuda:
+        raise RuntimeError("diffusion_edf_amd.connectivity needs GPU tensors: the product has no CPU path")
+    if batch is not None and batch.numel() and int(batch.max()) != int(batch.min()):
+        raise NotImplementedError("several clouds in one batch vector (every shipped config uses a single cloud)")
+
+
+def fps(src: torch.Tensor, batch: Optional[torch.Tensor] = None, ratio: float = 0.5, random_start: bool = True) -> torch.Tensor:
+    """torch_cluster.fps as connectivity.py:62 calls it: ``ceil(ratio * N)`` indices in selection order."""
+    _check_cloud(src, batch)
+    n = len(src)
+    k = int(math.ceil(ratio * n))
+    start = int(torch.randint(n, (1,)).item()) if random_start else 0
+    x = src.detach().to(torch.float32).contiguous()
+    idx = torch.empty(k, device=src.device, dtype=torch.int32)
+    lib = _lib.load()
+    rc = lib.dedf_fps(x.data_ptr(), n, k, start, idx.data_ptr(), _stream())
+    if rc != _lib.OK:
+        raise (NotImplementedError if rc == _lib.ERR_UNSUPPORTED else RuntimeError)(f"dedf_fps failed ({rc}); clouds up to 65 536 points")
+    return idx.long()
+
+
+def radius(x: torch.Tensor, y: torch.Tensor, r: float, batch_x=None, batch_y=None, max_num_neighbors: int = 32,
+           _exclude_self: bool = False) -> torch.Tensor:
+    """torch_cluster.radius: for every point of ``y`` the points of ``x`` within ``r`` -> ``(2, E)`` = [y index, x index]."""
+    _check_cloud(x, batch_x)
+    _check_cloud(y, batch_y)
+    xs = x.detach().to(torch.float32).contiguous()
+    ys = y.detach().to(torch.float32).contiguous()
+    lib = _lib.load()
+    n = C.c_int64(0)
+    cap = min(len(ys) * min(int(max_num_neighbors), len(xs)), 16 * len(ys) + 1024)
+    while True:
+        ed = torch.empty(cap, device=x.device, dtype=torch.int64)
+        es = torch.empty(cap, device=x.device, dtype=torch.int64)
+        rc = lib.dedf_radius(xs.data_ptr(), len(xs), ys.data_ptr(), len(ys), float(r), int(max_num_neighbors), int(_exclude_self),
+                             cap, ed.data_ptr(), es.data_ptr(), C.byref(n), _stream())
+        if rc == _lib.OK:
+            break
+        if rc == _lib.ERR_INVALID and n.value > cap:
+            cap = int(n.value)
+            continue
+        raise RuntimeError(f"dedf_radius failed ({rc})")
+    return torch.stack([ed[: n.value], es[: n.value]], dim=0)
+
+
+def radius_graph(x: torch.Tensor, r: float, batch=None, loop: bool = False, max_num_neighbors: int = 32) -> torch.Tensor:
+    return radius(x, x, r, batch, batch, max_num_neighbors, _exclude_self=not loop)
+
+
+class RadiusGraph(torch.nn.Module):
+    def __init__(self, r: float, max_num_neighbors: int):
+        super().__init__()
+        self.r: float = r
+        self.max_num_neighbors: int = max_num_neighbors
+
+    def forward(self, node_coord_src: torch.Tensor, node_feature_src: torch.Tensor, batch_src: torch.Tensor):
+        assert node_coord_src.ndim == 2 and node_coord_src.shape[-1] == 3
+        node_coord_dst, batch_dst, node_feature_dst = node_coord_src, batch_src, node_feature_src
+        N_nodes = len(node_coord_dst)
+        edge = radius_graph(node_coord_dst, r=self.r, batch=batch_dst, loop=False, max_num_neighbors=self.max_num_neighbors)
+        edge_dst, edge_src = edge[0], edge[1]
+        degree = torch.zeros(N_nodes, dtype=edge_dst.dtype, device=edge_dst.device).index_add_(0, edge_dst, torch.ones_like(edge_dst))
+        return node_feature_dst, node_coord_dst, edge_src, edge_dst, degree, batch_dst
+
+
+class RadiusConnect(torch.nn.Module):
+    def __init__(self, r: float, max_num_neighbors: int, offset: Optional[float] = None):
+        super().__init__()
+        self.r: float = r
+        self.max_num_neighbors: int = max_num_neighbors
+        if offset is not None:
+            raise NotImplementedError
+        self.offset = offset
+
+    def forward(self, node_coord_src, batch_src, node_coord_dst, batch_dst) -> Tuple[torch.Tensor, torch.Tensor]:
+        edge = radius(x=node_coord_src, y=node_coord_dst, r=self.r, batch_x=batch_src, batch_y=batch_dst, max_num_neighbors=self.max_num_neighbors)
+        return edge[1], edge[0]          # edge_src, edge_dst
+
+
+class FpsPool(torch.nn.Module):
+    def __init__(self, ratio: float, random_start: bool, r: float, max_num_neighbors: int):
+        super().__init__()
+        self.ratio: float = ratio
+        self.random_start: bool = random_start
+        self.r: float = r
+        self.max_num_neighbors: int = max_num_neighbors
+        self.radius_connect = RadiusConnect(r=self.r, max_num_neighbors=self.max_num_neighbors)
+
+    def forward(self, node_coord_src: torch.Tensor, node_feature_src: torch.Tensor, batch_src: torch.Tensor):
+        assert node_coord_src.ndim == 2 and node_coord_src.shape[-1] == 3
+        node_dst_idx = fps(src=node_coord_src, batch=batch_src, ratio=self.ratio, random_start=self.random_start)
+        node_coord_dst = node_coord_src.index_select(index=node_dst_idx, dim=0)
+        batch_dst = batch_src.index_select(index=node_dst_idx, dim=0)
+        N_nodes = len(node_dst_idx)
+        edge_src, edge_dst = self.radius_connect(node_coord_src=node_coord_src, node_coord_dst=node_coord_dst, batch_src=batch_src, batch_dst=batch_dst)
+        non_self_idx = (node_dst_idx[edge_dst] != edge_src).nonzero().squeeze(-1)
+        edge_src, edge_dst = edge_src[non_self_idx], edge_dst[non_self_idx]
+        degree = torch.zeros(N_nodes, dtype=edge_dst.dtype, device=edge_dst.device).index_add_(0, edge_dst, torch.ones_like(edge_dst))
+        node_feature_dst = node_feature_src.index_select(index=node_dst_idx, dim=0)
+        return node_feature_dst, node_coord_dst, edge_src, edge_dst, degree, batch_dst

@@ -16,6 +16,7 @@
 using namespace dedf;
 
 #include "dedf_kernels.h"
+#include "dedf_graph.h"
 #if !defined(DEDF_SINGLE_TU)
 #define DEDF_DECL(unit, ...) extern template __global__ __VA_ARGS__;
 DEDF_KERNEL_LIST(DEDF_DECL)
@@ -714,6 +715,40 @@ int dedf_debug_packed(dedf_handle* h, const char* which, const float** ptr, size
     const Image& im = w == "edge" ? h->edge_img : h->node_img;
     *ptr = im.data.data();
     *n_floats = im.data.size();
+    return DEDF_OK;
+}
+
+// ---- graph primitives of the feature extractors (no handle; current device; device pointers) ------------------------------------
+int dedf_fps(const float* x, int n, int n_samples, int start, int* idx_out, void* stream) {
+    if (!x || !idx_out || n <= 0 || n_samples < 0 || n_samples > n || start < 0 || start >= n) return DEDF_ERR_INVALID;
+    if (n > 64 * kFpsBlock) return DEDF_ERR_UNSUPPORTED;          // one workgroup keeps the cloud in registers: <= 65 536 points
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n_samples == 0) return DEDF_OK;
+    if (n <= 4 * kFpsBlock) hipLaunchKernelGGL(k_fps<4>, dim3(1), dim3(kFpsBlock), 0, st, x, n, n_samples, start, idx_out);
+    else if (n <= 16 * kFpsBlock) hipLaunchKernelGGL(k_fps<16>, dim3(1), dim3(kFpsBlock), 0, st, x, n, n_samples, start, idx_out);
+    else hipLaunchKernelGGL(k_fps<64>, dim3(1), dim3(kFpsBlock), 0, st, x, n, n_samples, start, idx_out);
+    return hipGetLastError() == hipSuccess ? DEDF_OK : DEDF_ERR_RUNTIME;
+}
+
+int dedf_radius(const float* x_src, int n_src, const float* x_dst, int n_dst, float r, int max_num_neighbors, int exclude_self,
+                int64_t edge_cap, int64_t* edge_dst, int64_t* edge_src, int64_t* n_edges, void* stream) {
+    if (!x_src || !x_dst || n_src <= 0 || n_dst <= 0 || !(r > 0.0f) || max_num_neighbors <= 0 || !n_edges || edge_cap < 0) return DEDF_ERR_INVALID;
+    if (edge_cap > 0 && (!edge_dst || !edge_src)) return DEDF_ERR_INVALID;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DevBuf cnt, off;
+    if (!cnt.ensure((size_t)n_dst * 4) || !off.ensure(((size_t)n_dst + 1) * 8)) return DEDF_ERR_RUNTIME;
+    const float r2 = r * r;
+    const int nblk = (n_dst + kRadBlock - 1) / kRadBlock;
+    int64_t* total = off.as<int64_t>() + n_dst;
+    hipLaunchKernelGGL(k_radius<false>, dim3(nblk), dim3(kRadBlock), 0, st, x_src, n_src, x_dst, n_dst, r2, max_num_neighbors, exclude_self,
+                       cnt.as<int>(), (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, cnt.as<int>(), n_dst, off.as<int64_t>(), total);
+    if (hipMemcpyAsync(n_edges, total, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return DEDF_ERR_RUNTIME;
+    if (*n_edges > edge_cap) return DEDF_ERR_INVALID;            // *n_edges holds the size the caller must provide
+    if (*n_edges > 0)
+        hipLaunchKernelGGL(k_radius<true>, dim3(nblk), dim3(kRadBlock), 0, st, x_src, n_src, x_dst, n_dst, r2, max_num_neighbors, exclude_self,
+                           cnt.as<int>(), off.as<int64_t>(), edge_dst, edge_src);
+    if (hipStreamSynchronize(st) != hipSuccess) return DEDF_ERR_RUNTIME;      // cnt / off are released on return
     return DEDF_OK;
 }
 

@@ -143,6 +143,20 @@ int dedf_debug_copy(dedf_handle* h, const char* name, void* host_dst, size_t max
 /* Packed weight images (host-only handles too): "edge" | "node"; for layout tests. */
 int dedf_debug_packed(dedf_handle* h, const char* which, const float** ptr, size_t* n_floats);
 
+/* ---- Graph primitives of the feature extractors (SURVEY 8(f) row 1 building blocks; no handle, current device) ----------------
+ * They replace the torch_cluster calls of reference diffusion_edf/connectivity.py (torch_cluster is an un-vendored dependency;
+ * the semantics are restated in oracle/graph_oracle.py).  Single cloud (all batch indices 0, as in every shipped config).
+ *
+ * dedf_fps     fps(src, ratio, random_start=False)  connectivity.py:62 : x (n,3) f32 -> idx_out (n_samples,) i32 in selection
+ *              order, first = `start` (0 for random_start=False), n_samples = ceil(ratio * n); n <= 65 536.
+ * dedf_radius  radius(x, y, r, max_num_neighbors)   connectivity.py:43 / radius_graph(x, r, loop=False, ...) :22 (exclude_self = 1,
+ *              x_dst = x_src): all (dst, src) with |x_dst - x_src| < r, at most max_num_neighbors per dst (the first in source
+ *              order), sorted by dst then src, as int64 like torch.  *n_edges (HOST) receives the edge count; if it exceeds
+ *              edge_cap nothing is written and DEDF_ERR_INVALID is returned (call again with room).  Synchronises `stream`. */
+int dedf_fps(const float* x, int n, int n_samples, int start, int* idx_out, void* stream);
+int dedf_radius(const float* x_src, int n_src, const float* x_dst, int n_dst, float r, int max_num_neighbors, int exclude_self,
+                int64_t edge_cap, int64_t* edge_dst, int64_t* edge_src, int64_t* n_edges, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,109 @@
+"""Graph primitives of the feature extractors (dedf_fps / dedf_radius, diffusion_edf_amd/connectivity.py) against
+oracle/graph_oracle.py.  Index work: the bar is bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from diffusion_edf_amd import synthetic
+from oracle import graph_oracle as G
+
+
+def _cloud(n, seed):
+    return synthetic.make_scene(n, seed=seed).astype(np.float32) if hasattr(synthetic, "make_scene") else \
+        np.random.default_rng(seed).uniform(-20, 20, size=(n, 3)).astype(np.float32)
+
+
+# ---- oracle (CPU) ---------------------------------------------------------------------------------------------------------
+def test_fps_oracle_properties():
+    x = _cloud(500, 0)
+    idx = G.fps(x, 0.2)
+    assert len(idx) == 100 and idx[0] == 0 and len(set(idx.tolist())) == 100
+    # each pick maximises the distance to the picks before it
+    for i in (1, 2, 17, 99):
+        d = np.min(((x[:, None, :] - x[idx[:i]][None, :, :]) ** 2).sum(-1), axis=1)
+        assert d[idx[i]] == d.max()
+    # the min-distance to the set never increases
+    dmin = [np.min(((x[idx[i]] - x[idx[:i]]) ** 2).sum(-1)) for i in range(1, 100)]
+    assert all(a >= b - 1e-9 for a, b in zip(dmin, dmin[1:]))
+    # ratio rounding: ceil
+    assert len(G.fps(x, 0.1001)) == 51 and len(G.fps(x[:7], 0.2)) == 2
+    # same picks as the bench's own generator (float64 arithmetic) on a cloud without near-ties
+    assert np.array_equal(idx, synthetic.fps(x.astype(np.float64), 0.2))
+    # duplicates: once every distance is 0 the first index wins, like numpy argmax
+    assert G.fps(np.zeros((4, 3), np.float32), 1.0).tolist() == [0, 0, 0, 0]
+
+
+def test_radius_oracle_properties():
+    x, y = _cloud(300, 1), _cloud(120, 2)
+    ed, es = G.radius(x, y, 9.0, 1000)
+    d = np.sqrt(((y[:, None, :].astype(np.float64) - x[None, :, :]) ** 2).sum(-1))
+    far, near = d > 9.0 + 1e-4, d < 9.0 - 1e-4
+    m = np.zeros_like(d, dtype=bool); m[ed, es] = True
+    assert not (m & far).any() and m[near].all()
+    assert np.all(np.diff(ed) >= 0) and np.all((np.diff(es) > 0) | (np.diff(ed) > 0))            # sorted by dst, then src
+    ed3, es3 = G.radius(x, y, 9.0, 3)                                                           # cap: the first 3 sources of each dst
+    for dd in range(len(y)):
+        assert es3[ed3 == dd].tolist() == es[ed == dd][:3].tolist()
+    gd, gs = G.radius(x, x, 6.0, 1000, exclude_self=True)                                        # radius_graph(loop=False): symmetric, no loops
+    assert not (gd == gs).any()
+    pairs = set(zip(gd.tolist(), gs.tolist()))
+    assert all((b, a) in pairs for a, b in pairs)
+
+
+# ---- HIP path (GPU) -------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,ratio", [(1, 1.0), (7, 0.2), (820, 0.2), (4096, 0.2), (5000, 0.03), (16384, 0.2), (40000, 0.01)])
+def test_fps_bit_exact(n, ratio):
+    from diffusion_edf_amd import connectivity as K
+    x = _cloud(n, n)
+    ref = G.fps(x, ratio)
+    got = K.fps(torch.from_numpy(x).cuda(), None, ratio=ratio, random_start=False).cpu().numpy()
+    assert got.dtype == np.int64 and np.array_equal(got, ref)
+
+
+@pytest.mark.gpu
+def test_fps_ties_and_limits():
+    from diffusion_edf_amd import connectivity as K
+    grid = np.stack(np.meshgrid(np.arange(12.), np.arange(12.), np.arange(3.), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)   # many exact ties
+    assert np.array_equal(K.fps(torch.from_numpy(grid).cuda(), None, ratio=0.5, random_start=False).cpu().numpy(), G.fps(grid, 0.5))
+    z = torch.zeros(5, 3, device="cuda")
+    assert K.fps(z, None, ratio=1.0, random_start=False).tolist() == [0, 0, 0, 0, 0]
+    with pytest.raises(NotImplementedError):
+        K.fps(torch.zeros(70000, 3, device="cuda"), None, ratio=0.001, random_start=False)
+    with pytest.raises(RuntimeError):
+        K.fps(torch.zeros(5, 3), None, ratio=0.5, random_start=False)          # CPU tensor: no CPU path
+    i = K.fps(torch.from_numpy(grid).cuda(), None, ratio=0.1, random_start=True)
+    assert len(i) == 44 and len(set(i.tolist())) == 44
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ns,nd,r,cap", [(300, 120, 9.0, 1000), (300, 120, 9.0, 3), (4096, 820, 3.0, 1000), (5, 2000, 50.0, 1000), (1500, 1, 12.0, 7)])
+def test_radius_bit_exact(ns, nd, r, cap):
+    from diffusion_edf_amd import connectivity as K
+    x, y = _cloud(ns, 3), _cloud(nd, 4)
+    ed, es = G.radius(x, y, r, cap)
+    e = K.radius(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), r, max_num_neighbors=cap).cpu().numpy()
+    assert e.shape == (2, len(ed)) and np.array_equal(e[0], ed) and np.array_equal(e[1], es)
+
+
+@pytest.mark.gpu
+def test_connectivity_modules_match_oracle():
+    """RadiusGraph / FpsPool as reference connectivity.py:8-80 composes them"""
+    from diffusion_edf_amd import connectivity as K
+    x = _cloud(3000, 5)
+    xt = torch.from_numpy(x).cuda()
+    f = torch.arange(len(x), dtype=torch.float32, device="cuda")[:, None].repeat(1, 4)
+    b = torch.zeros(len(x), dtype=torch.long, device="cuda")
+    # RadiusGraph
+    fo, xo, es, ed, deg, bo = K.RadiusGraph(r=2.5, max_num_neighbors=1000)(xt, f, b)
+    rd, rs = G.radius(x, x, 2.5, 1000, exclude_self=True)
+    assert np.array_equal(ed.cpu().numpy(), rd) and np.array_equal(es.cpu().numpy(), rs)
+    assert np.array_equal(deg.cpu().numpy(), np.bincount(rd, minlength=len(x))) and fo is f and xo is xt and bo is b
+    # FpsPool: pooled nodes + bipartite edges without the pooled node itself
+    fo, xo, es, ed, deg, bo = K.FpsPool(ratio=0.25, random_start=False, r=4.0, max_num_neighbors=1000)(xt, f, b)
+    idx = G.fps(x, 0.25)
+    rd, rs = G.radius(x, x[idx], 4.0, 1000)
+    keep = idx[rd] != rs
+    assert np.array_equal(xo.cpu().numpy(), x[idx]) and np.array_equal(fo[:, 0].cpu().numpy(), idx.astype(np.float32))
+    assert np.array_equal(ed.cpu().numpy(), rd[keep]) and np.array_equal(es.cpu().numpy(), rs[keep])
+    assert np.array_equal(deg.cpu().numpy(), np.bincount(rd[keep], minlength=len(idx))) and len(bo) == len(idx)
