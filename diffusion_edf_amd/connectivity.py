@@ -49,7 +49,8 @@ def radius(x: torch.Tensor, y: torch.Tensor, r: float, batch_x=None, batch_y=Non
     ys = y.detach().to(torch.float32).contiguous()
     lib = _lib.load()
     n = C.c_int64(0)
-    cap = min(len(ys) * min(int(max_num_neighbors), len(xs)), 16 * len(ys) + 1024)
+    full = len(ys) * min(int(max_num_neighbors), len(xs))          # the most there can be; taken at once while it is small (<= 256 MB)
+    cap = full if full <= (1 << 24) else 32 * len(ys) + 1024
     while True:
         ed = torch.empty(cap, device=x.device, dtype=torch.int64)
         es = torch.empty(cap, device=x.device, dtype=torch.int64)

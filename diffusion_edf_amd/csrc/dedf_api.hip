@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 #include "../../include/dedf.h"
+#include <map>
+#include <mutex>
 #include "dedf_misc.h"
 #include "dedf_pack.h"
 
@@ -735,10 +737,17 @@ int dedf_radius(const float* x_src, int n_src, const float* x_dst, int n_dst, fl
     if (!x_src || !x_dst || n_src <= 0 || n_dst <= 0 || !(r > 0.0f) || max_num_neighbors <= 0 || !n_edges || edge_cap < 0) return DEDF_ERR_INVALID;
     if (edge_cap > 0 && (!edge_dst || !edge_src)) return DEDF_ERR_INVALID;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    DevBuf cnt, off;
+    // scratch (counts, offsets) is kept between calls, one set per device; like a handle, not for concurrent use from several threads
+    static std::mutex mu;
+    static std::map<int, std::pair<DevBuf, DevBuf>> scratch;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return DEDF_ERR_RUNTIME;
+    DevBuf& cnt = scratch[dev].first;
+    DevBuf& off = scratch[dev].second;
     if (!cnt.ensure((size_t)n_dst * 4) || !off.ensure(((size_t)n_dst + 1) * 8)) return DEDF_ERR_RUNTIME;
     const float r2 = r * r;
-    const int nblk = (n_dst + kRadBlock - 1) / kRadBlock;
+    const int nblk = (n_dst + kRadBlock / 64 - 1) / (kRadBlock / 64);          // one wave per destination
     int64_t* total = off.as<int64_t>() + n_dst;
     hipLaunchKernelGGL(k_radius<false>, dim3(nblk), dim3(kRadBlock), 0, st, x_src, n_src, x_dst, n_dst, r2, max_num_neighbors, exclude_self,
                        cnt.as<int>(), (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr);
@@ -748,7 +757,7 @@ int dedf_radius(const float* x_src, int n_src, const float* x_dst, int n_dst, fl
     if (*n_edges > 0)
         hipLaunchKernelGGL(k_radius<true>, dim3(nblk), dim3(kRadBlock), 0, st, x_src, n_src, x_dst, n_dst, r2, max_num_neighbors, exclude_self,
                            cnt.as<int>(), off.as<int64_t>(), edge_dst, edge_src);
-    if (hipStreamSynchronize(st) != hipSuccess) return DEDF_ERR_RUNTIME;      // cnt / off are released on return
+    if (hipStreamSynchronize(st) != hipSuccess) return DEDF_ERR_RUNTIME;
     return DEDF_OK;
 }
 

@@ -69,36 +69,34 @@ __global__ __launch_bounds__(kFpsBlock) void k_fps(const float* __restrict__ x, 
     }
 }
 
-// Radius search, one thread per destination point, sources streamed through LDS; neighbours in ascending source index, at most
-// `cap` per destination (the first ones).  FILL = false: cnt[d];  FILL = true: edges at off[d] (exclusive scan of cnt).
-constexpr int kRadChunk = 1024, kRadBlock = 256;
+// Radius search, one WAVE per destination point: the 64 lanes test 64 consecutive sources per step, a ballot counts them and
+// orders the hits (ascending source index for free); at most `cap` neighbours per destination (the first ones).
+// FILL = false: cnt[d];  FILL = true: edges at off[d] (exclusive scan of cnt).
+constexpr int kRadBlock = 256;
 template <bool FILL>
 __global__ __launch_bounds__(kRadBlock) void k_radius(const float* __restrict__ xs, int n_src, const float* __restrict__ xd, int n_dst, float r2, int cap,
                                                      int exclude_self, int* __restrict__ cnt, const int64_t* __restrict__ off,
                                                      int64_t* __restrict__ edge_dst, int64_t* __restrict__ edge_src) {
-    __shared__ float sx[kRadChunk * 3];
-    const int d = blockIdx.x * kRadBlock + threadIdx.x;
-    const bool live = d < n_dst;
-    const float qx = live ? xd[3 * d] : 0.0f, qy = live ? xd[3 * d + 1] : 0.0f, qz = live ? xd[3 * d + 2] : 0.0f;
+    const int lane = threadIdx.x & 63;
+    const int d = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kRadBlock + threadIdx.x) >> 6));
+    if (d >= n_dst) return;
+    const float qx = xd[3 * d], qy = xd[3 * d + 1], qz = xd[3 * d + 2];
     int c = 0;
     int64_t o = 0;
-    if (FILL && live) o = off[d];
-    for (int base = 0; base < n_src; base += kRadChunk) {
-        const int m = min(kRadChunk, n_src - base);
-        __syncthreads();
-        for (int i = threadIdx.x; i < 3 * m; i += kRadBlock) sx[i] = xs[3 * base + i];
-        __syncthreads();
-        if (!live) continue;
-        for (int k = 0; k < m && c < cap; ++k) {
-            if (exclude_self && base + k == d) continue;
-            // the oracle forms (y - x)^2 summed in order: destination minus source
-            if (dist2_rn(qx, qy, qz, sx[3 * k], sx[3 * k + 1], sx[3 * k + 2]) < r2) {
-                if (FILL) { edge_dst[o + c] = d; edge_src[o + c] = base + k; }
-                ++c;
-            }
+    if (FILL) o = off[d];
+    for (int base = 0; base < n_src && c < cap; base += 64) {
+        const int k = base + lane;
+        bool hit = false;
+        if (k < n_src && !(exclude_self && k == d))
+            hit = dist2_rn(qx, qy, qz, xs[3 * k], xs[3 * k + 1], xs[3 * k + 2]) < r2;       // the oracle forms (y - x)^2: destination minus source
+        const unsigned long long m = __ballot(hit);
+        if (FILL && hit) {
+            const int pos = c + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < cap) { edge_dst[o + pos] = d; edge_src[o + pos] = k; }
         }
+        c += __popcll(m);
     }
-    if (!FILL && live) cnt[d] = c;
+    if (!FILL && lane == 0) cnt[d] = min(c, cap);
 }
 
 // exclusive scan of cnt[n] -> off[n], total -> *total  (one workgroup; n up to a few 100 k)
