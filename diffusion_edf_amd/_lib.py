@@ -95,6 +95,8 @@ def load() -> C.CDLL:
 
 
 def make_config(cfg: HeadConfig, device: int, max_edges: int = 0) -> DedfConfig:
+    if cfg.n_scales > MAX_SCALES:
+        raise ValueError(f"{cfg.n_scales} scales: the library takes at most {MAX_SCALES} (dedf_config.radii)")
     c = DedfConfig()
     c.lmax = cfg.lmax
     for i, m in enumerate(cfg.muls):

@@ -504,3 +504,39 @@ def test_randomised_shapes_and_sizes():
     were run clean on the GPU box during round 1): final score within the tolerance and identical edge counts in every case"""
     import stress_parity
     assert stress_parity.run_cases(10, seed=2) == []
+
+
+def test_eight_scales_and_workspace_growth():
+    """the largest scale count the ABI takes (8), and ONE handle used with growing / shrinking pose batches and a changed query cloud:
+    every call must match the oracle (workspace re-allocation, stale offsets)"""
+    radii = (2.5, 3.5, 4.5, 6., 8., 10., 13., None)
+    kw = synthetic.score_head_kwargs(1, radii=radii)
+    cfg = params.HeadConfig.from_kwargs(kw)
+    assert cfg.n_scales == 8
+    P = params.init_params(cfg, seed=2, randomize_all=True)
+    keys = synthetic.make_key_clouds(cfg, 3000, seed=0)
+    dev = torch.device('cuda:0')
+    head = ScoreModelHead(**kw)
+    head.load_state_dict(P)
+    head.to(dev)
+    ocfg = R.config_from_kwargs(kw)
+    P64 = R.cast_params(P, torch.float64)
+    ok = [R.FeaturedPoints(k.x.double(), k.f.double(), k.b) for k in keys]
+    for nT, nq_pts, seed in ((3, 100, 0), (40, 300, 1), (5, 100, 2), (64, 50, 3)):
+        query = synthetic.make_query(cfg, nq_pts, seed=seed)
+        Ts = synthetic.make_poses(nT, seed=seed, near_object=True)
+        time = torch.linspace(0.15, 1.0, nT, dtype=torch.float64)
+        oq = R.FeaturedPoints(query.x.double(), query.f.double(), query.b, query.w.double())
+        d = R.Debug()
+        ang64, lin64 = R.score_head_forward(ocfg, P64, Ts, ok, oq, time, d)
+        gk, gq = _to_dev(keys, query, dev)
+        ang, lin = head(Ts.to(dev).float(), gk, gq, time.to(dev).float())
+        assert head.stats()['n_edges'] == d['n_edges_per_scale']
+        scale = float(max(ang64.abs().max(), lin64.abs().max()))
+        err = max(float((ang.cpu().double() - ang64).abs().max()), float((lin.cpu().double() - lin64).abs().max())) / scale
+        assert err < TOL, (nT, err)
+    kw9 = synthetic.score_head_kwargs(1, radii=(1., 2., 3., 4., 5., 6., 7., 8., None))
+    with pytest.raises(ValueError, match="at most 8"):
+        h9 = ScoreModelHead(**kw9)
+        h9.to(dev)
+        h9(*[t.to(dev) if isinstance(t, torch.Tensor) else t for t in h9._get_fake_input()])
