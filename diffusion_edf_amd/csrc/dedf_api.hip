@@ -728,7 +728,7 @@ int dedf_fps(const float* x, int n, int n_samples, int start, int* idx_out, void
     if (n_samples == 0) return DEDF_OK;
     if (n <= 4 * kFpsBlock) hipLaunchKernelGGL(k_fps<4>, dim3(1), dim3(kFpsBlock), 0, st, x, n, n_samples, start, idx_out);
     else if (n <= 16 * kFpsBlock) hipLaunchKernelGGL(k_fps<16>, dim3(1), dim3(kFpsBlock), 0, st, x, n, n_samples, start, idx_out);
-    else hipLaunchKernelGGL(k_fps<64>, dim3(1), dim3(kFpsBlock), 0, st, x, n, n_samples, start, idx_out);
+    else hipLaunchKernelGGL((k_fps<64, false>), dim3(1), dim3(kFpsBlock), 0, st, x, n, n_samples, start, idx_out);
     return hipGetLastError() == hipSuccess ? DEDF_OK : DEDF_ERR_RUNTIME;
 }
 

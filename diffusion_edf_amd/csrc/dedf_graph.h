@@ -23,16 +23,18 @@ __device__ __forceinline__ float dist2_rn(float ax, float ay, float az, float bx
 // Farthest point sampling of ONE cloud by one workgroup: every thread keeps PPT points and their running minimum distance in
 // registers; per sample: update, per-thread arg-max, wave butterfly, one LDS exchange between the 16 waves, ONE barrier.
 // idx_out[i] = i-th selected point (selection order, first = `start`).  Ties: smaller index (numpy argmax).
-template <int PPT>
+// KEEP = false (clouds above 16 k points): only the minimum distances stay in registers, the coordinates are re-read (coalesced, from
+// L2) every sample — 64 points per thread would not fit the 128 VGPRs a thread of a 1024-thread workgroup has.
+template <int PPT, bool KEEP = true>
 __global__ __launch_bounds__(kFpsBlock) void k_fps(const float* __restrict__ x, int n, int n_samples, int start, int* __restrict__ idx_out) {
     __shared__ float s_val[2][kFpsBlock / 64];
     __shared__ int s_idx[2][kFpsBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float px[PPT], py[PPT], pz[PPT], md[PPT];
+    float px[KEEP ? PPT : 1], py[KEEP ? PPT : 1], pz[KEEP ? PPT : 1], md[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
         const int i = tid + j * kFpsBlock;
-        px[j] = i < n ? x[3 * i] : 0.0f; py[j] = i < n ? x[3 * i + 1] : 0.0f; pz[j] = i < n ? x[3 * i + 2] : 0.0f;
+        if constexpr (KEEP) { px[j] = i < n ? x[3 * i] : 0.0f; py[j] = i < n ? x[3 * i + 1] : 0.0f; pz[j] = i < n ? x[3 * i + 2] : 0.0f; }
         md[j] = INFINITY;
     }
     int cur = start;
@@ -45,7 +47,10 @@ __global__ __launch_bounds__(kFpsBlock) void k_fps(const float* __restrict__ x, 
         for (int j = 0; j < PPT; ++j) {
             const int i = tid + j * kFpsBlock;
             if (i < n) {
-                md[j] = fminf(md[j], dist2_rn(px[j], py[j], pz[j], cx, cy, cz));
+                float qx, qy, qz;
+                if constexpr (KEEP) { qx = px[j]; qy = py[j]; qz = pz[j]; }
+                else { qx = x[3 * i]; qy = x[3 * i + 1]; qz = x[3 * i + 2]; }
+                md[j] = fminf(md[j], dist2_rn(qx, qy, qz, cx, cy, cz));
                 if (md[j] > best) { best = md[j]; bi = i; }          // ascending i inside a thread: strict > keeps the smaller index
             }
         }
