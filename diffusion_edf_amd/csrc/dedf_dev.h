@@ -126,15 +126,6 @@ DEDF_DEV f32x4 bld4(const Buf& b, int voff_bytes, int soff_bytes) {
 #endif
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-DEDF_DEV f32x2 bld2(const Buf& b, int voff_bytes, int soff_bytes) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(b.r, voff_bytes, soff_bytes, 0));
-#else
-    return *reinterpret_cast<const f32x2*>(b.p + voff_bytes + soff_bytes);
-#endif
-}
 
 struct Wave {            // per-lane constants of the transposed-GEMM layout
     int lane, col, hi;
@@ -156,8 +147,6 @@ DEDF_DEV Wave make_wave(const void* wbuf, uint32_t wbytes) {
 DEDF_DEV f32x4 lda(const Wave& wv, int off, int nG, int To, int g) {
     return bld4(wv.w, wv.lane16, (off + (To * nG + g) * 256) * 4);
 }
-// A operands of the two register pairs of group g of a 16-row matrix packed by pack_A16: [group][lane][2]
-DEDF_DEV f32x2 lda16(const Wave& wv, int off, int g) { return bld2(wv.w, wv.lane * 8, (off + g * 128) * 4); }
 // acc tile <- 16 per-row values stored [tile][hi][r] at float offset `off`
 DEDF_DEV f32x16 ldrows(const Buf& b, int voff_hi64, int off, int tile) {
     f32x16 v;
@@ -211,27 +200,6 @@ DEDF_DEV HL split8(const float (&x)[8]) {
     static_for<8>([&]<int J>() { r.lo[J] = (_Float16)(x[J] - (float)r.hi[J]); });
     return r;
 }
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-// D(16x16) += A(16x16) * B(16x16) (v_mfma_f32_16x16x16_f16, 16 cycles; 48 when it depends on the previous one).
-// A[i = l&15][k = 4(l>>4) + e], B[k = 4(l>>4) + e][j = l&15], D: col = l&15, row = 4(l>>4) + reg (tests/probe/mfma16h_probe.hip)
-DEDF_DEV f32x4 mfma16h(h4 a, h4 b, f32x4 c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
-#else
-    (void)a; (void)b; return c;
-#endif
-}
-// Row layout (lane = edge column + 32 h, k16 = 8 h + jj packed in 4 VGPRs) -> the B operands of the two 16-column MFMAs:
-// afterwards halves 0-3 hold k16 = 4 (lane >> 4) + e of edge (lane & 15), halves 4-7 the same of edge 16 + (lane & 15).
-DEDF_DEV h8 relane16(h8 v) {
-    f32x4 f = __builtin_bit_cast(f32x4, v);
-    float a = f[0], b = f[1], c = f[2], d = f[3];
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-#endif
-    return __builtin_bit_cast(h8, f32x4{a, b, c, d});
-}
-DEDF_DEV h4 half4(h8 v, int s) { return s == 0 ? __builtin_shufflevector(v, v, 0, 1, 2, 3) : __builtin_shufflevector(v, v, 4, 5, 6, 7); }
 
 // A finished accumulator tile that the VALU reads next: pin it to architectural VGPRs here, so that the MFMAs write it there
 // directly instead of into AGPRs followed by 16 v_accvgpr_read copies.

@@ -48,26 +48,6 @@ inline std::vector<float> pack_A(int O, const std::vector<KStep>& steps, WAt W) 
     return out;
 }
 
-// 16-row matrices on v_mfma_f32_16x16x4_f32: the four K-steps of a group (registers j = 0..3 of both half-waves) become two
-// MFMAs, pair p = registers (2p, 2p+1); after v_permlane16_swap the 16-lane rows of the B operand carry
-// slot0 = (hi 0, reg 2p), slot1 = (hi 0, reg 2p+1), slot2 = (hi 1, reg 2p), slot3 = (hi 1, reg 2p+1), and lane l supplies
-// A[o = l & 15][slot = l >> 4].  Image: [group][lane 64][pair 2].
-template <class WAt>
-inline std::vector<float> pack_A16(int O, const std::vector<KStep>& steps, WAt W) {
-    const int nG = ((int)steps.size() + 3) / 4;
-    std::vector<float> out((size_t)nG * 64 * 2, 0.0f);
-    for (int g = 0; g < nG; ++g)
-        for (int p = 0; p < 2; ++p)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int o = lane & 15, slot = lane >> 4;
-                const int s = 4 * g + 2 * p + (slot & 1);
-                if (s >= (int)steps.size()) continue;
-                const int k = (slot >> 1) ? steps[s].k1 : steps[s].k0;
-                if (o < O && k >= 0) out[((size_t)g * 64 + lane) * 2 + p] = W(o, k);
-            }
-    return out;
-}
-
 // Split-fp16 A images for v_mfma_f32_32x32x16_f16 (3-term products hi*hi + hi*lo + lo*hi reproduce fp32 products to ~2^-22):
 // a K-chunk = 16 k's = 8 accumulator registers of each half-wave; lane (i = l & 31, h = l >> 5) supplies
 // A[out i][k = kof(chunk, j, h)], j = 0..7, as 8 halves (16 B).  Image: [out tile][chunk][lane 64][8 halves], one for the high
