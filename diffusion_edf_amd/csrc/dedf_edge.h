@@ -3,13 +3,14 @@
 // Restates, per edge, reference graph_parser.py:146-224 (geometry, soft cut-offs, length embedding, spherical
 // harmonics), multiscale_tensor_field.py:225-234 (edge pre-linear with the time embedding), and
 // graph_attention.py:231-247 (radial MLP -> depth-wise TP -> {sep_alpha | lin -> Gate -> depth-wise TP -> lin}).
-// Nothing per-edge except the result record (value in internal layout + one logit per head, 244 floats at lmax 2)
-// reaches HBM: the 480 radial weights, the two 1568-float TP outputs and all activations stay in registers.
+// Nothing per-edge reaches HBM: the 480 radial weights, the two 1568-float TP outputs and all activations stay in registers /
+// LDS, and the results leave the kernel as ONE record per run of same-destination edges of a tile (softmax-weighted mean value
+// in internal layout + log-sum-exp of the logits per head, 244 floats at lmax 2), see "joint-softmax partials" below.
 //
 // Layout: lane = (edge column = lane & 31, row half hi = lane >> 5); see dedf_layout.h.  Every dense layer is
-// D[out][edge] += W[out][k] * act[k][edge] on v_mfma_f32_32x32x2_f32 with the previous layer's accumulator
-// registers used directly as B operands; weights stream from L2 as pre-permuted float4 per lane through one
-// buffer descriptor.
+// D[out][edge] += W[out][k] * act[k][edge] as three v_mfma_f32_32x32x16_f16 products (hi*hi + hi*lo + lo*hi, fp32 accumulate)
+// with the previous layer's accumulator registers split into fp16 hi / lo halves as B operands; weights stream from L2 as
+// pre-split, pre-permuted 16-byte A operands per lane through one buffer descriptor.
 #pragma once
 #include "dedf_dev.h"
 #include "dedf_net.h"
