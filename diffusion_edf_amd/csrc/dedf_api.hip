@@ -739,12 +739,12 @@ int dedf_radius(const float* x_src, int n_src, const float* x_dst, int n_dst, fl
     hipStream_t st = static_cast<hipStream_t>(stream);
     // scratch (counts, offsets) is kept between calls, one set per device; like a handle, not for concurrent use from several threads
     static std::mutex mu;
-    static std::map<int, std::pair<DevBuf, DevBuf>> scratch;
+    static auto* scratch = new std::map<int, std::pair<DevBuf, DevBuf>>();      // never destroyed: no hipFree after the runtime has shut down
     std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return DEDF_ERR_RUNTIME;
-    DevBuf& cnt = scratch[dev].first;
-    DevBuf& off = scratch[dev].second;
+    DevBuf& cnt = (*scratch)[dev].first;
+    DevBuf& off = (*scratch)[dev].second;
     if (!cnt.ensure((size_t)n_dst * 4) || !off.ensure(((size_t)n_dst + 1) * 8)) return DEDF_ERR_RUNTIME;
     const float r2 = r * r;
     const int nblk = (n_dst + kRadBlock / 64 - 1) / (kRadBlock / 64);          // one wave per destination
