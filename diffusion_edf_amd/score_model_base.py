@@ -11,6 +11,7 @@ pose-sharded multi-GPU run draws the same noise as a single-GPU run.
 from __future__ import annotations
 
 import ctypes as C
+import warnings
 from typing import List, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -90,6 +91,10 @@ class ScoreModelBase(torch.nn.Module):
         rc = lib.dedf_sample(head._handle, nT, T64.data_ptr(), C.byref(sch), C.c_uint64(seed), C.c_int64(first_pose_index),
                              nz.data_ptr() if nz is not None else None, out.data_ptr(), head._stream())
         _lib.raise_for(lib, head._handle, rc, "dedf_sample")
+        # dedf_sample has synchronised: the reference's zero-edge warning (multiscale_tensor_field.py:249-250) costs nothing here.
+        # (`forward` stays free of host round trips and does not warn.)
+        if n_steps > 0 and head.stats()['n_edges_total'] == 0:
+            warnings.warn("Multiscale Tensor Field: zero edges detected!")
         return out
 
     @torch.no_grad()

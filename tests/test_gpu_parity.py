@@ -540,3 +540,21 @@ def test_eight_scales_and_workspace_growth():
         h9 = ScoreModelHead(**kw9)
         h9.to(dev)
         h9(*[t.to(dev) if isinstance(t, torch.Tensor) else t for t in h9._get_fake_input()])
+
+
+def test_zero_edge_warning_like_the_reference():
+    """multiscale_tensor_field.py:249-250 warns when no edge exists; `sample` (which synchronises anyway) does the same, and the
+    poses then follow the bias-only field exactly as in the oracle"""
+    kw, cfg, P, keys, query, Ts, time = SC.build_case(1, 3, 256, 60, radii=(2., 3.), identity_pose=False)
+    Ts[:, 4:] = torch.tensor([400., 0., 0.], dtype=torch.float64)          # far away from every key point
+    dev = torch.device('cuda:0')
+    head = ScoreModelHead(**kw)
+    head.load_state_dict(P)
+    head.to(dev)
+    gk, gq = _to_dev(keys, query, dev)
+    noise = torch.zeros(1, 2, len(Ts), 3, dtype=torch.float64)
+    with pytest.warns(UserWarning, match="zero edges detected"):
+        out = ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[1.0, 0.5]], [1], [0.04], noise=noise).cpu()
+    ok = [R.FeaturedPoints(k.x, k.f, k.b) for k in keys]
+    ref = R.sample(R.config_from_kwargs(kw), P, Ts, ok, R.FeaturedPoints(query.x, query.f, query.b, query.w), [[1.0, 0.5]], [1], [0.04], noise=noise)
+    assert float((out - ref).abs().max()) < 2e-4

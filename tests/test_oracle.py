@@ -242,3 +242,34 @@ def test_point_attention_multiplies_after_the_softmax():
     assert torch.allclose(attn(cfg, w), expect, atol=1e-12)
     with pytest.raises(AssertionError):
         attn(cfg, None)
+
+
+def test_agent_sample_restatement_is_consistent():
+    """oracle.agent_sample (agent.py:98-186): one stage == sample; two stages chain through the final poses and concatenate;
+    the critic reorders the poses of every time step by ascending energy of the last step"""
+    from diffusion_edf_amd import params, synthetic
+    kw = synthetic.score_head_kwargs(1, radii=(4., None))
+    cfg = params.HeadConfig.from_kwargs(kw)
+    P = params.init_params(cfg, seed=3, randomize_all=True)
+    keys = synthetic.make_key_clouds(cfg, 200, seed=0)
+    query = synthetic.make_query(cfg, 30, seed=0)
+    ok = [R.FeaturedPoints(k.x, k.f, k.b) for k in keys]
+    oq = R.FeaturedPoints(query.x, query.f, query.b, query.w)
+    ocfg = R.config_from_kwargs(kw)
+    Ts = synthetic.make_poses(4, seed=1, near_object=True)
+    noise = [torch.randn(2, 2, 4, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(i)) for i in (1, 2)]
+    m = (ocfg, P, ok, oq)
+    one, e = R.agent_sample([m], None, Ts, [[2]], [[0.03]], [1.0], [[[1.0, 0.5]]], noise_list=noise[:1])
+    assert e is None and torch.equal(one, R.sample(ocfg, P, Ts, ok, oq, [[1.0, 0.5]], [2], [0.03], 1.0, True, 1.0, 0.5, noise=noise[0]))
+    two, _ = R.agent_sample([m, m], None, Ts, [[2], [2]], [[0.03], [0.02]], [1.0, 0.5], [[[1.0, 0.5]], [[0.5, 0.2]]], noise_list=noise)
+    assert two.shape == (8, 4, 7) and torch.equal(two[:4], one) and torch.equal(two[4], one[-1])
+    kwe = synthetic.ebm_head_kwargs(1, radii=(4., 6.))
+    cfge = params.HeadConfig.from_kwargs(kwe)
+    Pe = params.init_params(cfge, seed=5, randomize_all=True)
+    ke = synthetic.make_key_clouds(cfge, 200, seed=0)
+    crit = (R.config_from_kwargs(kwe), Pe, [R.FeaturedPoints(k.x, k.f, k.b) for k in ke], oq)
+    ranked, es = R.agent_sample([m], crit, Ts, [[2]], [[0.03]], [1.0], [[[1.0, 0.5]]], noise_list=noise[:1])
+    assert bool((es[1:] >= es[:-1]).all())
+    e_direct = R.compute_energy(crit[0], Pe, one[-1].float(), crit[2], oq, torch.ones(4))
+    order = torch.argsort(e_direct)
+    assert torch.equal(ranked, one[:, order]) and torch.allclose(es, e_direct[order])
