@@ -168,7 +168,7 @@ class TensorProduct:
                 else:
                     r = torch.einsum('zuvw,ijk,zuvij->zwk', w, C, xx)
             s, e = self.so[ins.iout]
-            out[:, s:e] += r.reshape(Z, -1)
+            out[:, s:e] += r.reshape(Z, e - s)          # (explicit width: Z may be 0 when no edge exists)
         return out
 
 
