@@ -136,6 +136,67 @@ def run_sample_case(i, rng):
     return err, ok_, ""
 
 
+def run_ebm_case(i, rng):
+    """EbmScoreModelHead.compute_energy (the critic) on random shapes; every second case in half-precision GEMM mode"""
+    import oracle.restatement as R
+    from diffusion_edf_amd.score_head import EbmScoreModelHead
+    lmax = int(rng.integers(1, 3))
+    ns = int(rng.integers(1, 5))
+    radii = tuple(sorted(float(r) for r in rng.uniform(2.5, 10.0, size=ns)))
+    kw = synthetic.ebm_head_kwargs(lmax, radii=radii)
+    kw['key_tensor_field_kwargs']['r_mincut_nonscalar_sh'] = float(rng.uniform(0.05, 0.6))
+    cfg = params.HeadConfig.from_kwargs(kw)
+    seed = int(rng.integers(0, 1 << 30))
+    P = params.init_params(cfg, seed=seed % 1000, randomize_all=True)
+    keys = synthetic.make_key_clouds(cfg, int(rng.integers(60, 1500)), seed=seed % 97)
+    nQ = int(rng.integers(1, 100))
+    query = synthetic.make_query(cfg, max(10 * nQ, 10), seed=seed % 89)
+    query = FeaturedPoints(query.x[:nQ], query.f[:nQ], query.b[:nQ], query.w[:nQ])
+    Ts = synthetic.make_poses(int(rng.integers(1, 40)), seed=seed % 83, near_object=True)
+    time = torch.ones(len(Ts), dtype=torch.float64)
+    ok = [R.FeaturedPoints(k.x.double(), k.f.double(), k.b) for k in keys]
+    oq = R.FeaturedPoints(query.x.double(), query.f.double(), query.b, query.w.double())
+    e64 = R.compute_energy(R.config_from_kwargs(kw), R.cast_params(P, torch.float64), Ts, ok, oq, time)
+    dev = torch.device('cuda:0')
+    half = bool(i % 2)
+    head = EbmScoreModelHead(**{k: v for k, v in kw.items() if k != 'ebm'})
+    head.load_state_dict(P)
+    head.to(dev)
+    if half:
+        head.half()
+    gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
+    gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
+    e = head.compute_energy(Ts.to(dev).float(), gk, gq, time.to(dev).float()).cpu().double()
+    err = float((e - e64).abs().max() / e64.abs().max())
+    ok_ = err < (5e-3 if half else 1e-4)
+    print(f"ebm {i:3d} err {err:.2e} half {half} lmax {lmax} radii {[round(r, 2) for r in radii]} keys {[len(k.x) for k in keys]} nQ {nQ} nT {len(Ts)}", flush=True)
+    return err, ok_, ""
+
+
+def run_half_case(i, rng):
+    """score head in half-precision GEMM mode (model.half()): stated tolerance 5e-3 of the score scale"""
+    kw, cfg, P, keys, query, Ts, time = draw_case(rng)
+    import oracle.restatement as R
+    from diffusion_edf_amd.score_head import ScoreModelHead
+    ocfg = R.config_from_kwargs(kw)._replace(max_neighbors=cfg.max_neighbors)
+    ok = [R.FeaturedPoints(k.x.double(), k.f.double(), k.b, None if k.w is None else k.w.double()) for k in keys]
+    oq = R.FeaturedPoints(query.x.double(), query.f.double(), query.b, query.w.double())
+    ang64, lin64 = R.score_head_forward(ocfg, R.cast_params(P, torch.float64), Ts, ok, oq, time)
+    dev = torch.device('cuda:0')
+    head = ScoreModelHead(**kw)
+    head.cfg.max_neighbors = cfg.max_neighbors
+    head.load_state_dict(P)
+    head.to(dev)
+    head.half()
+    gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev), None if k.w is None else k.w.to(dev)) for k in keys]
+    gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
+    ang, lin = head(Ts.to(dev, torch.float32), gk, gq, time.to(dev, torch.float32))
+    scale = float(max(ang64.abs().max(), lin64.abs().max()))
+    err = max(float((ang.cpu().double() - ang64).abs().max()), float((lin.cpu().double() - lin64).abs().max())) / scale
+    print(f"half {i:3d} err {err:.2e} lmax {cfg.lmax} fc {cfg.fc_neurons} radii {cfg.radii} nQ {len(query.x)} nT {len(Ts)}", flush=True)
+    return err, err < 5e-3, ""
+
+
 def run_cases(n, seed):
     rng = np.random.default_rng(seed)
     bad = []
@@ -149,11 +210,12 @@ def run_cases(n, seed):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    if len(sys.argv) > 3 and sys.argv[3] == "sample":
+    if len(sys.argv) > 3:
+        fn = {"sample": run_sample_case, "ebm": run_ebm_case, "half": run_half_case}[sys.argv[3]]
         rng = np.random.default_rng(seed)
-        res = [run_sample_case(i, rng) for i in range(n)]
+        res = [fn(i, rng) for i in range(n)]
         nbad = sum(1 for r in res if not r[1])
-        print("FAILED" if nbad else "ALL OK", nbad, "of", n, "largest pose difference", max(r[0] for r in res))
+        print("FAILED" if nbad else "ALL OK", nbad, "of", n, "largest difference", max(r[0] for r in res))
         sys.exit(1 if nbad else 0)
     rng = np.random.default_rng(seed)
     bad = []
