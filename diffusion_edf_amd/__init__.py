@@ -1,4 +1,16 @@
-"""MI355X-native implementation of the Diffusion-EDF SE(3) score-head hot path."""
-from .gnn_data import FeaturedPoints  # noqa: F401
+"""MI355X-native implementation of the Diffusion-EDF SE(3) score-head hot path.
+
+    gnn_data            FeaturedPoints, GraphEdge and their helpers              (reference diffusion_edf/gnn_data.py)
+    score_head          ScoreModelHead, EbmScoreModelHead                        (score_head.py, score_head_ebm.py)
+    score_model_base    ScoreModelBase.sample / forward                          (score_model_base.py)
+    agent               MultiscaleScoreModel, PointAttentiveScoreModel, StaticKeypointModel, get_models, DiffusionEdfAgent
+                                                                                 (multiscale_score_model.py, point_attentive_score_model.py,
+                                                                                  keypoint_extractor.py:22-47, agent.py)
+    connectivity        fps, radius, radius_graph, RadiusGraph, RadiusConnect, FpsPool   (connectivity.py)
+    dist                pose sharding over ranks + the closing RCCL all-gather
+
+Everything computes through ``csrc/libdedf.so`` (HIP, gfx950); importing a submodule that needs it fails loudly when the library
+is missing — there is no CPU path."""
+from .gnn_data import FeaturedPoints, GraphEdge  # noqa: F401
 
 __version__ = "0.1.0"
