@@ -59,15 +59,11 @@ class StaticKeypointModel(torch.nn.Module):
         self.keypoint_weights = torch.nn.Parameter(torch.randn(len(self.keypoint_coords)))
 
     def forward(self, input_points: FeaturedPoints) -> FeaturedPoints:
-        b = input_points.b
-        assert b.ndim == 1
-        batch_unique = torch.unique(b)
-        x = self.keypoint_coords.repeat(len(batch_unique), 1)
-        f = self.keypoint_features.repeat(len(batch_unique), 1)
-        w = torch.sigmoid(self.keypoint_weights)
-        w = w.repeat(len(batch_unique))
-        b = batch_unique.repeat(len(self.keypoint_coords))
-        return FeaturedPoints(x=x, f=f, b=b, w=w)
+        assert input_points.b.ndim == 1
+        batches = torch.unique(input_points.b)          # one copy of the keypoints per batch index present in the input
+        n_rep, n_kp = len(batches), len(self.keypoint_coords)
+        return FeaturedPoints(x=self.keypoint_coords.repeat(n_rep, 1), f=self.keypoint_features.repeat(n_rep, 1),
+                              b=batches.repeat(n_kp), w=torch.sigmoid(self.keypoint_weights).repeat(n_rep))
 
 
 class MultiscaleScoreModel(ScoreModelBase):
