@@ -558,3 +558,28 @@ def test_zero_edge_warning_like_the_reference():
     ok = [R.FeaturedPoints(k.x, k.f, k.b) for k in keys]
     ref = R.sample(R.config_from_kwargs(kw), P, Ts, ok, R.FeaturedPoints(query.x, query.f, query.b, query.w), [[1.0, 0.5]], [1], [0.04], noise=noise)
     assert float((out - ref).abs().max()) < 2e-4
+
+
+def test_full_size_c2_anchored_on_the_oracle_through_pose_independence():
+    """C2 inputs exactly as bench.py builds them (820/164/33/7 keys, 103 queries): poses are independent units, so (1) the oracle
+    checks a 10-pose subset at the FULL scene size, and (2) the scores those poses get inside the 1000-pose batch must equal the
+    subset's (different tiles and segment partials: equal up to fp32 summation order), which ties the full-size run to
+    oracle-checked values."""
+    import bench
+    dev = torch.device('cuda:0')
+    kw, cfg, P, keys, query, Ts = bench.build_inputs(2, 4096, 1024, 1000, 0, dev)
+    head = _gpu_head(kw, P, dev)
+    sel = torch.tensor([0, 1, 7, 99, 250, 333, 512, 777, 998, 999], device=dev)
+    t_all = torch.full((1000,), 0.5, device=dev)
+    ang_all, lin_all = head(Ts.float(), keys, query, t_all)
+    ang_s, lin_s = head(Ts[sel].float(), keys, query, t_all[:len(sel)])
+    scale = float(max(ang_all.abs().max(), lin_all.abs().max()))
+    assert float((ang_all[sel] - ang_s).abs().max()) / scale < 2e-6 and float((lin_all[sel] - lin_s).abs().max()) / scale < 2e-6
+    ocfg = R.config_from_kwargs(kw)
+    ok = [R.FeaturedPoints(k.x.cpu().double(), k.f.cpu().double(), k.b.cpu()) for k in keys]
+    oq = R.FeaturedPoints(query.x.cpu().double(), query.f.cpu().double(), query.b.cpu(), query.w.cpu().double())
+    d = R.Debug()
+    ang64, lin64 = R.score_head_forward(ocfg, R.cast_params(P, torch.float64), Ts[sel].cpu(), ok, oq, torch.full((len(sel),), 0.5, dtype=torch.float64), d)
+    assert sum(d['n_edges_per_scale']) > 10_000
+    s64 = float(max(ang64.abs().max(), lin64.abs().max()))
+    assert float((ang_all[sel].cpu().double() - ang64).abs().max()) / s64 < TOL and float((lin_all[sel].cpu().double() - lin64).abs().max()) / s64 < TOL
