@@ -583,3 +583,23 @@ def test_full_size_c2_anchored_on_the_oracle_through_pose_independence():
     assert sum(d['n_edges_per_scale']) > 10_000
     s64 = float(max(ang64.abs().max(), lin64.abs().max()))
     assert float((ang_all[sel].cpu().double() - ang64).abs().max()) / s64 < TOL and float((lin_all[sel].cpu().double() - lin64).abs().max()) / s64 < TOL
+
+
+def test_full_size_c2_sharded_sampling_equals_single_batch():
+    """what the 8-GPU run does, on one GPU: C2 poses in 8 shards with their global pose indices (Philox noise keyed by the global
+    index) against the unsharded sampler, 3 steps at temperature 1 — equal up to the fp32 summation order inside the tiles"""
+    import bench
+    from diffusion_edf_amd import dist as ddist
+    dev = torch.device('cuda:0')
+    kw, cfg, P, keys, query, Ts = bench.build_inputs(2, 4096, 1024, 1000, 0, dev)
+    m = ScoreModelBase(_gpu_head(kw, P, dev))
+    args = dict(diffusion_schedules=[[1.0, 0.5]], N_steps=[3], timesteps=[0.04], temperatures=1.0, seed=3)
+    full = m.sample(Ts, keys, query, **args)
+    parts = []
+    for r in range(8):
+        s0, s1 = ddist.shard_range(1000, 8, r)
+        parts.append(m.sample(Ts[s0:s1], keys, query, first_pose_index=s0, **args))
+    sharded = torch.cat(parts, dim=1)
+    assert sharded.shape == full.shape == (5, 1000, 7)
+    moved = float((full[-1] - full[0]).abs().max())
+    assert moved > 1.0 and float((sharded - full).abs().max()) < 1e-5 * moved, (moved, float((sharded - full).abs().max()))
