@@ -26,8 +26,13 @@ __device__ inline void wigner_from_angles(float a, float b, float c, float* D /*
     constexpr int n = 2 * LD + 1;
     float X[3][n][n];
     const float ang[3] = {a, b, c};
+#pragma unroll
     for (int t = 0; t < 3; ++t) {
-        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) X[t][i][j] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < n; ++i)
+#pragma unroll
+            for (int j = 0; j < n; ++j) X[t][i][j] = 0.0f;
+#pragma unroll
         for (int i = 0; i < n; ++i) {                      // wigner.py:21-42 (sin first, cos overwrites the centre)
             const float f = (float)(LD - i);
             X[t][i][n - 1 - i] = sinf(f * ang[t]);
@@ -37,10 +42,19 @@ __device__ inline void wigner_from_angles(float a, float b, float c, float* D /*
     float A[n][n], Bm[n][n];
     auto Jl = [](int i, int j) { if constexpr (LD == 1) return kJ1[i][j]; else return kJ2[i][j]; };
     // ((((Xa J) Xb) J) Xc)
-    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { float s = 0; for (int k = 0; k < n; ++k) s += X[0][i][k] * Jl(k, j); A[i][j] = s; }
-    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { float s = 0; for (int k = 0; k < n; ++k) s += A[i][k] * X[1][k][j]; Bm[i][j] = s; }
-    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { float s = 0; for (int k = 0; k < n; ++k) s += Bm[i][k] * Jl(k, j); A[i][j] = s; }
-    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { float s = 0; for (int k = 0; k < n; ++k) s += A[i][k] * X[2][k][j]; D[i * n + j] = s; }
+    // every loop has constant bounds and is unrolled, so that the matrices live in registers (they went to scratch otherwise)
+#define DEDF_MM(OUT, LHS, RHS)                                   \
+    _Pragma("unroll") for (int i = 0; i < n; ++i)               \
+    _Pragma("unroll") for (int j = 0; j < n; ++j) {             \
+        float s = 0;                                            \
+        _Pragma("unroll") for (int k = 0; k < n; ++k) s += LHS * RHS; \
+        OUT = s;                                                \
+    }
+    DEDF_MM(A[i][j], X[0][i][k], Jl(k, j))
+    DEDF_MM(Bm[i][j], A[i][k], X[1][k][j])
+    DEDF_MM(A[i][j], Bm[i][k], Jl(k, j))
+    DEDF_MM(D[i * n + j], A[i][k], X[2][k][j])
+#undef DEDF_MM
 }
 
 template <int L>
