@@ -275,9 +275,8 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     if (!h->d_mask.ensure((size_t)np.word_start[ns] * Nd * 4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(neighbour masks) failed");
     np.mask = h->d_mask.as<uint32_t>();
     const int nblk = (Nd + kNbrBlock - 1) / kNbrBlock;
+    np.edge_hist = h->profile ? h->d_hist.as<long long>() : nullptr;
     hipLaunchKernelGGL(k_neighbors<false>, dim3(nblk), dim3(kNbrBlock), 0, st, np);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, h->d_blk.as<int>(), nblk, ns, h->d_tile.as<int>(), h->edge_cap,
-                       h->profile ? h->d_hist.as<long long>() : nullptr);
     hipLaunchKernelGGL(k_neighbors<true>, dim3(nblk), dim3(kNbrBlock), 0, st, np);
     mark();
     // 4. fused edge pipeline

@@ -207,7 +207,7 @@ __global__ void k_src_message(const float* __restrict__ f, int n_pts, const floa
 // Radius neighbour search (torch_cluster.radius as used at graph_parser.py:339; all pairs for the infinite scale,
 // graph_parser.py:279-281).  Keys are tiny (<= a few thousand points) and static, queries move every step: brute force with
 // the key cloud streamed through LDS, one thread per destination node.  Edge order: scale, then dst, then src ascending.
-//   pass 1 (count):  cnt[n][d] and per-block totals;   k_scan: exclusive scan of the block totals + tile table;
+//   pass 1 (count):  cnt[n][d], neighbour bit masks and per-block totals;
 //   pass 2 (fill):   block-local exclusive scan of cnt + block offset -> off[n][d], then the edge lists.
 struct NbrParams {
     const float* key_x; int n_keys;
@@ -217,8 +217,9 @@ struct NbrParams {
     const float* qpos; int n_dst;
     int* cnt;                             // [n_scales][n_dst]
     int* off;                             // [n_scales][n_dst]  exclusive prefix inside the scale
-    int* blk;                             // [n_scales][n_blocks] block totals (count) -> block offsets (after k_scan)
-    const int* tile_info;                 // edge base per scale at [16 + n]
+    int* blk;                             // [n_scales][n_blocks] block totals of the count pass
+    int* tile_info;                       // written by block 0 of the fill pass: [0..n_scales] tile prefix, [16..16+n_scales] edge prefix, [40] overflow
+    long long* edge_hist;                 // optional running edge count (statistics)
     int* edge_src; int* edge_dst;
     int64_t cap;
     uint32_t* mask;                       // [word][n_dst]: neighbour bit masks written by the count pass, 32 keys per word
@@ -251,6 +252,40 @@ __global__ __launch_bounds__(kNbrBlock) void k_neighbors(NbrParams P) {
     const bool act = d < P.n_dst;
     float px = 0, py = 0, pz = 0;
     if (!FILL && act) { px = P.qpos[3 * d]; py = P.qpos[3 * d + 1]; pz = P.qpos[3 * d + 2]; }
+    // Fill pass: every block sums the block totals of the count pass for itself (a few hundred integers per scale) -> the total of
+    // every scale and the sum of the blocks before it; block 0 also writes the tile table the following kernels read.
+    __shared__ int s_tot[kMaxScales], s_pre[kMaxScales];
+    if (FILL) {
+        if (threadIdx.x < kMaxScales) { s_tot[threadIdx.x] = 0; s_pre[threadIdx.x] = 0; }
+        __syncthreads();
+        for (int n = 0; n < P.n_scales; ++n) {
+            int tot = 0, pre = 0;
+            for (int i = threadIdx.x; i < (int)gridDim.x; i += kNbrBlock) {
+                const int v = P.blk[(size_t)n * gridDim.x + i];
+                tot += v;
+                if (i < (int)blockIdx.x) pre += v;
+            }
+            for (int o = 32; o >= 1; o >>= 1) { tot += __shfl_xor(tot, o); pre += __shfl_xor(pre, o); }
+            if ((threadIdx.x & 63) == 0) { atomicAdd(&s_tot[n], tot); atomicAdd(&s_pre[n], pre); }      // integers: order-independent
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            int tiles = 0;
+            int64_t edges = 0;
+            P.tile_info[0] = 0; P.tile_info[16] = 0;
+            for (int n = 0; n < P.n_scales; ++n) {
+                edges += s_tot[n];
+                tiles += (s_tot[n] + 31) / 32;
+                P.tile_info[n + 1] = tiles;
+                P.tile_info[16 + n + 1] = (int)min(edges, (int64_t)0x7fffffff);
+            }
+            const int ovf = edges > P.cap ? 1 : 0;
+            P.tile_info[40] = ovf;
+            if (P.edge_hist) *P.edge_hist += edges;
+            if (ovf) for (int n = 0; n <= P.n_scales; ++n) P.tile_info[n] = 0;     // no tiles: downstream kernels do nothing
+        }
+    }
+    int64_t scale_base = 0;
     for (int n = 0; n < P.n_scales; ++n) {
         const int s0 = P.scale_start[n], s1 = P.scale_start[n + 1];
         const int w0 = P.word_start[n], nw = P.word_start[n + 1] - w0;
@@ -258,10 +293,11 @@ __global__ __launch_bounds__(kNbrBlock) void k_neighbors(NbrParams P) {
             const int mine = act ? P.cnt[(size_t)n * P.n_dst + d] : 0;
             int total;
             const int ex = block_exclusive_scan_256(mine, &total);
-            const int o = P.blk[(size_t)n * gridDim.x + blockIdx.x] + ex;
+            const int o = s_pre[n] + ex;
+            const int64_t base = scale_base + o;
+            scale_base += s_tot[n];
             if (!act) continue;
             P.off[(size_t)n * P.n_dst + d] = o;
-            const int64_t base = (int64_t)P.tile_info[16 + n] + o;
             int c = 0;
             for (int g = 0; g < nw; ++g) {
                 uint32_t word = P.mask[(size_t)(w0 + g) * P.n_dst + d];
@@ -316,44 +352,6 @@ __global__ __launch_bounds__(kNbrBlock) void k_neighbors(NbrParams P) {
             (void)block_exclusive_scan_256(act ? c : 0, &total);
             if (threadIdx.x == 0) P.blk[(size_t)n * gridDim.x + blockIdx.x] = total;
         }
-    }
-}
-
-// exclusive scan of the per-block totals of every scale (in place) + tile table.  One block of 1024 threads.
-// tile_info: [0..n_scales] tile prefix, [16..16+n_scales] edge prefix, [40] overflow flag
-__global__ void k_scan(int* __restrict__ blk, int n_blocks, int n_scales, int* __restrict__ tile_info, int64_t cap,
-                       long long* __restrict__ edge_hist) {
-    __shared__ int part[1024];
-    const int tid = threadIdx.x;
-    int tiles = 0;
-    int64_t edges = 0;
-    if (tid == 0) { tile_info[0] = 0; tile_info[16] = 0; }
-    for (int n = 0; n < n_scales; ++n) {
-        const int per = (n_blocks + 1023) / 1024;
-        const int i0 = min(n_blocks, tid * per), i1 = min(n_blocks, i0 + per);
-        int s = 0;
-        for (int i = i0; i < i1; ++i) s += blk[(size_t)n * n_blocks + i];
-        __syncthreads();
-        part[tid] = s;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {          // Hillis-Steele inclusive scan
-            int v = (tid >= o) ? part[tid - o] : 0;
-            __syncthreads();
-            part[tid] += v;
-            __syncthreads();
-        }
-        int run = part[tid] - s;
-        for (int i = i0; i < i1; ++i) { const int c = blk[(size_t)n * n_blocks + i]; blk[(size_t)n * n_blocks + i] = run; run += c; }
-        const int total = part[1023];
-        edges += total;
-        tiles += (total + 31) / 32;
-        if (tid == 0) { tile_info[n + 1] = tiles; tile_info[16 + n + 1] = (int)min(edges, (int64_t)0x7fffffff); }
-    }
-    if (tid == 0) {
-        const int ovf = edges > cap ? 1 : 0;
-        tile_info[40] = ovf;
-        if (edge_hist) *edge_hist += edges;
-        if (ovf) for (int n = 0; n <= n_scales; ++n) tile_info[n] = 0;     // no tiles: downstream kernels do nothing
     }
 }
 
