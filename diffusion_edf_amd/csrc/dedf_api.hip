@@ -73,6 +73,7 @@ struct dedf_handle {
     bool have_keys = false, have_query = false;
     // device: per call
     DevBuf d_key_w; bool have_key_w = false;              // key-point attention weights (use_src_point_attn)
+    const LangevinParams* fused_step = nullptr;           // dedf_sample: the per-pose reduction also carries this step's Langevin update
     DevBuf d_tb_steps; const float* tb_step = nullptr;    // dedf_sample: the time-bias rows of ALL steps are computed up front; tb_step = this step's rows
     std::vector<float> h_tsteps;
     DevBuf d_Ts, d_time, d_tb, d_pose, d_qpos, d_cnt, d_off, d_blk, d_tile, d_esrc, d_edst, d_eout, d_z, d_nout, d_ang, d_lin, d_T64, d_dbgw, d_dbge, d_dbgf, d_dbgo, d_mask;
@@ -257,7 +258,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     if ((size_t)Nd * D * 4 >= (1ull << 32)) return fail(h, DEDF_ERR_INVALID, "nT*nQ too large for one call (z buffer > 4 GiB); split the pose batch");
     mark();
     // 1. poses: Wigner-D + transformed query positions
-    hipLaunchKernelGGL(k_pose_prep<L>, dim3(nT), dim3(64), 0, st, h->d_Ts.as<float>(), h->d_qx.as<float>(), nQ, h->d_pose.as<float>(), h->d_qpos.as<float>());
+    hipLaunchKernelGGL(k_pose_prep<L>, dim3(nT), dim3(64), 0, st, h->d_Ts.as<float>(), h->fused_step ? h->fused_step->T : (const double*)nullptr, h->d_qx.as<float>(), nQ, h->d_pose.as<float>(), h->d_qpos.as<float>());
     // 2. time embedding -> pre-linear bias rows (EBM head: constant bias rows, uploaded once)
     if constexpr (!EBM) {
         if (h->tb_step == nullptr) launch_time_bias(h, st, h->d_time.as<float>(), time_stride, time_stride ? nT : 1, h->d_tb.as<float>());
@@ -363,6 +364,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     mark();
     // 7. per-pose reduction
     if constexpr (EBM) hipLaunchKernelGGL(k_energy_reduce, dim3((nT + 127) / 128), dim3(128), 0, st, h->d_nout.as<float>(), nT, nQ, ang);
+    else if (h->fused_step) hipLaunchKernelGGL(k_reduce_langevin, dim3(nT), dim3(64), 0, st, h->d_nout.as<float>(), nQ, ang, lin, *h->fused_step);
     else hipLaunchKernelGGL(k_pose_reduce, dim3(nT), dim3(64), 0, st, h->d_nout.as<float>(), nT, nQ, ang, lin);
     mark();
     if (h->profile) { h->prof_evals += 1; h->prof_dst += Nd; }
@@ -597,19 +599,19 @@ int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedul
         launch_time_bias(h, st, h->d_time.as<float>(), 1, sched->n_steps, h->d_tb_steps.as<float>());
     }
     for (int s = 0; s < sched->n_steps; ++s) {
-        hipLaunchKernelGGL(k_cast_pose, dim3((unsigned)((row + 255) / 256)), dim3(256), 0, st, h->d_T64.as<double>(), h->d_Ts.as<float>(), (int)row);
-        h->tb_step = h->d_tb_steps.as<float>() + (size_t)s * tb_row;
-        rc = score_dispatch(h, nT, 0, h->d_ang.as<float>(), h->d_lin.as<float>(), st);
-        h->tb_step = nullptr;
-        if (rc != DEDF_OK) return rc;
+        // one step = pose prep (reads the f64 state), neighbour count + fill, edge, aggregate, node, reduce + Langevin update
         LangevinParams lp{};
-        lp.T = h->d_T64.as<double>(); lp.ang = h->d_ang.as<float>(); lp.lin = h->d_lin.as<float>();
+        lp.T = h->d_T64.as<double>();
         lp.t = sched->t[s]; lp.alpha_ang = sched->alpha_ang[s]; lp.alpha_lin = sched->alpha_lin[s]; lp.temperature = sched->temperature[s];
         lp.ang_mult = h->cfg.ang_mult; lp.lin_mult = h->cfg.lin_mult;
         lp.noise = noise ? noise + (size_t)s * 2 * nT * 3 : nullptr;
         lp.seed = seed; lp.first_pose = first_pose_index; lp.step = s;
         lp.traj_out = Ts_out + (size_t)(s + 1) * row; lp.nT = nT;
-        hipLaunchKernelGGL(k_langevin, dim3((nT + 127) / 128), dim3(128), 0, st, lp);
+        h->tb_step = h->d_tb_steps.as<float>() + (size_t)s * tb_row;
+        h->fused_step = &lp;
+        rc = score_dispatch(h, nT, 0, h->d_ang.as<float>(), h->d_lin.as<float>(), st);
+        h->tb_step = nullptr; h->fused_step = nullptr;
+        if (rc != DEDF_OK) return rc;
     }
     HIPCK(h, hipMemcpyAsync(Ts_out + (size_t)(sched->n_steps + 1) * row, h->d_T64.p, row * 8, hipMemcpyDeviceToDevice, st));
     HIPCK(h, hipStreamSynchronize(st));

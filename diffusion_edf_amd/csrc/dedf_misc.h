@@ -9,13 +9,6 @@
 namespace dedf {
 
 // ------------------------------------------------------------------------------------------------------------------------
-// T (f64, sampler state) -> f32 poses + shared time
-__global__ void k_cast_pose(const double* __restrict__ T, float* __restrict__ Ts, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) Ts[i] = (float)T[i];
-}
-
-// ------------------------------------------------------------------------------------------------------------------------
 // Pose preparation: one block per pose.
 //   pose record: raw q, D^1(q), D^2(q)   with  q_n = standardize(q/|q|), R = quaternion_to_matrix(q_n),
 //   (a,b,c) = matrix_to_euler_angles(R, "YXY"), D^l = X(a) J X(b) J X(c)            (wigner.py:44-81, 257-283;
@@ -57,11 +50,13 @@ __device__ inline void wigner_from_angles(float a, float b, float c, float* D /*
 #undef DEDF_MM
 }
 
+// Ts64 != nullptr (sampler): the float64 state is read directly and rounded to fp32 here, exactly what a separate cast would give.
 template <int L>
-__global__ void k_pose_prep(const float* __restrict__ Ts, const float* __restrict__ qx, int nQ,
+__global__ void k_pose_prep(const float* __restrict__ Ts, const double* __restrict__ Ts64, const float* __restrict__ qx, int nQ,
                             float* __restrict__ pose, float* __restrict__ qpos) {
     const int t = blockIdx.x;
-    const float* T = Ts + 7 * t;
+    float T[7];
+    for (int k = 0; k < 7; ++k) T[k] = Ts64 != nullptr ? (float)Ts64[7 * (size_t)t + k] : Ts[7 * (size_t)t + k];
     const float qw = T[0], qi = T[1], qj = T[2], qk = T[3];
     if (threadIdx.x == 0) {
         float* rec = pose + (size_t)t * kPoseRec;
@@ -484,16 +479,14 @@ __device__ inline double u01(uint32_t hi, uint32_t lo) {      // (0,1]
 }
 struct LangevinParams {
     double* T;                 // [nT][7] state, updated in place
-    const float* ang; const float* lin;
     double t, alpha_ang, alpha_lin, temperature, ang_mult, lin_mult;
     const double* noise;       // [2][nT][3] for this step or nullptr
     uint64_t seed; int64_t first_pose; int step;
     double* traj_out;          // [nT][7] slot of this step
     int nT;
 };
-__global__ void k_langevin(LangevinParams P) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.nT) return;
+// update of pose i from its fp32 scores (ang, lin)
+__device__ inline void langevin_update(const LangevinParams& P, int i, const float (&ang)[3], const float (&lin)[3]) {
     double* T = P.T + 7 * (size_t)i;
     double na[3], nl[3];
     if (P.noise) {
@@ -516,8 +509,8 @@ __global__ void k_langevin(LangevinParams P) {
     const double st = sqrt(P.t);
     double da[3], dl[3];
     for (int k = 0; k < 3; ++k) {
-        const double sa = (double)P.ang[3 * i + k] / (P.ang_mult * st);
-        const double sl = (double)P.lin[3 * i + k] / (P.lin_mult * st);
+        const double sa = (double)ang[k] / (P.ang_mult * st);
+        const double sl = (double)lin[k] / (P.lin_mult * st);
         da[k] = (P.alpha_ang / 2) * sa + sqrt(P.temperature * P.alpha_ang) * na[k];
         dl[k] = (P.alpha_lin / 2) * sl + sqrt(P.temperature * P.alpha_lin) * nl[k];
     }
@@ -542,6 +535,25 @@ __global__ void k_langevin(LangevinParams P) {
     T[4] += rx; T[5] += ry; T[6] += rz;
     double* o = P.traj_out + 7 * (size_t)i;
     for (int k = 0; k < 7; ++k) o[k] = T[k];
+}
+// Sampler: sum over the query points of one pose (k_pose_reduce's order, bit for bit) and the Langevin update of that pose in one
+// launch — one wave per pose, lane 0 carries the float64 update.
+__global__ __launch_bounds__(64) void k_reduce_langevin(const float* __restrict__ node_out, int nQ, float* __restrict__ ang_out,
+                                                        float* __restrict__ lin_out, LangevinParams P) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= P.nT) return;
+    float s[6] = {0, 0, 0, 0, 0, 0};
+    for (int q = lane; q < nQ; q += 64) {
+        const float* o = node_out + ((size_t)t * nQ + q) * 8;
+        const f32x4 a = ld4(o), b = ld4(o + 4);
+        s[0] += a[0]; s[1] += a[1]; s[2] += a[2]; s[3] += a[3]; s[4] += b[0]; s[5] += b[1];
+    }
+    for (int m = 32; m >= 1; m >>= 1)
+        for (int i = 0; i < 6; ++i) s[i] += __shfl_xor(s[i], m, 64);
+    if (lane != 0) return;
+    const float lin[3] = {s[0], s[1], s[2]}, ang[3] = {s[3], s[4], s[5]};
+    for (int k = 0; k < 3; ++k) { lin_out[3 * t + k] = lin[k]; ang_out[3 * t + k] = ang[k]; }
+    langevin_update(P, t, ang, lin);
 }
 
 }  // namespace dedf
