@@ -170,8 +170,8 @@ def wigner_3j(l1: int, l2: int, l3: int) -> np.ndarray:
 # normalize2mom constants (e3nn.math.normalize2mom: 1e6 float64 N(0,1) samples, torch CPU seed 0)
 # --------------------------------------------------------------------------------------------------
 
-# Values computed with this container's torch by scripts/gen_norm2mom.py (committed) and re-derived in
-# tests/test_so3.py; hard-coded because the product must not depend on a Monte-Carlo run at import.
+# Values computed with this container's torch following that recipe; tests/test_so3.py::test_normalize2mom_constants re-derives
+# them (the provenance check).  Hard-coded because the product must not depend on a Monte-Carlo run at import.
 NORM2MOM_SILU = 1.6791767923989418
 NORM2MOM_SIGMOID = 1.8467055342154763
 NORM2MOM_SLRELU02 = 1.531320475574866
