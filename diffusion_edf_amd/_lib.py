@@ -39,7 +39,7 @@ class DedfSchedule(C.Structure):
 
 
 class DedfStats(C.Structure):
-    _fields_ = [("n_dst", C.c_int64), ("n_edges", C.c_int64 * MAX_SCALES), ("n_edges_total", C.c_int64), ("overflow", C.c_int)]
+    _fields_ = [("n_dst", C.c_int64), ("n_edges", C.c_int64 * MAX_SCALES), ("n_edges_total", C.c_int64), ("overflow", C.c_int), ("nonfinite", C.c_int)]
 
 
 class DedfProfile(C.Structure):

@@ -34,7 +34,8 @@ def fps(src: torch.Tensor, batch: Optional[torch.Tensor] = None, ratio: float = 
     x = src.detach().to(torch.float32).contiguous()
     idx = torch.empty(k, device=src.device, dtype=torch.int32)
     lib = _lib.load()
-    rc = lib.dedf_fps(x.data_ptr(), n, k, start, idx.data_ptr(), _stream())
+    with torch.cuda.device(src.device):          # dedf_fps / dedf_radius run on the CURRENT device and stream
+        rc = lib.dedf_fps(x.data_ptr(), n, k, start, idx.data_ptr(), _stream())
     if rc != _lib.OK:
         raise (NotImplementedError if rc == _lib.ERR_UNSUPPORTED else RuntimeError)(f"dedf_fps failed ({rc}); clouds up to 65 536 points")
     return idx.long()
@@ -54,8 +55,9 @@ def radius(x: torch.Tensor, y: torch.Tensor, r: float, batch_x=None, batch_y=Non
     while True:
         ed = torch.empty(cap, device=x.device, dtype=torch.int64)
         es = torch.empty(cap, device=x.device, dtype=torch.int64)
-        rc = lib.dedf_radius(xs.data_ptr(), len(xs), ys.data_ptr(), len(ys), float(r), int(max_num_neighbors), int(_exclude_self),
-                             cap, ed.data_ptr(), es.data_ptr(), C.byref(n), _stream())
+        with torch.cuda.device(x.device):
+            rc = lib.dedf_radius(xs.data_ptr(), len(xs), ys.data_ptr(), len(ys), float(r), int(max_num_neighbors), int(_exclude_self),
+                                 cap, ed.data_ptr(), es.data_ptr(), C.byref(n), _stream())
         if rc == _lib.OK:
             break
         if rc == _lib.ERR_INVALID and n.value > cap:

@@ -24,11 +24,13 @@ using namespace dedf;
 DEDF_KERNEL_LIST(DEDF_DECL)
 #undef DEDF_DECL
 #endif
-__global__ void k_energy_reduce(const float* __restrict__ node_out, int nT, int nQ, float* __restrict__ energy) {
+__global__ void k_energy_reduce(const float* __restrict__ node_out, int nT, int nQ, float* __restrict__ energy, int* __restrict__ flags) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nT) return;
     float s = 0.0f;
     for (int q = 0; q < nQ; ++q) s += node_out[((size_t)t * nQ + q) * 8];
+    if (flags[kFlagOverflow]) s = __builtin_nanf("");              // see dedf_misc.h::reduce_status
+    else if (!(fabsf(s) <= 3.0e38f)) flags[kFlagNonFinite] = 1;
     energy[t] = s;
 }
 
@@ -91,6 +93,22 @@ struct dedf_handle {
 };
 
 namespace {
+
+// Entry points run on the handle's device and leave the caller's current device as they found it.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess; else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define DEDF_ON_DEVICE(h)                                   \
+    DeviceGuard dev_guard__((h)->cfg.device);              \
+    if (!dev_guard__.ok) return fail(h, DEDF_ERR_RUNTIME, "hipSetDevice failed")
+// clears the sticky status words (overflow, non-finite) at the start of an API call
+#define DEDF_CLEAR_FLAGS(h, st) HIPCK(h, hipMemsetAsync((h)->d_tile.as<int>() + kFlagOverflow, 0, 2 * sizeof(int), st))
 
 int fail(dedf_handle* h, int code, const std::string& msg) {
     if (h) h->err = msg;
@@ -221,6 +239,11 @@ int ensure_workspace(dedf_handle* h, int nT) {
               h->d_edst.ensure((size_t)cap * 4) && h->d_eout.ensure((size_t)cap * REC * 4) && h->d_z.ensure(Nd * D * 4) &&
               h->d_nout.ensure(Nd * 8 * 4) && h->d_ang.ensure((size_t)nT * 3 * 4) && h->d_lin.ensure((size_t)nT * 3 * 4) &&
               h->d_T64.ensure((size_t)nT * 7 * 8);
+    {   // neighbour bit masks of the count pass: one word per 32 keys of every scale, per destination
+        size_t words = 0;
+        for (int n = 0; n < ns; ++n) words += (size_t)(h->scale_start[n + 1] - h->scale_start[n] + 31) / 32;
+        ok = ok && h->d_mask.ensure(words * Nd * 4);
+    }
     if (ok && h->debug) ok = h->d_dbgw.ensure((size_t)cap * WN * 4);
     if (!ok) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(workspace) failed");
     if (h->d_eout.bytes >= (1ull << 32) || h->d_z.bytes >= (1ull << 32))
@@ -273,7 +296,6 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     np.tile_info = h->d_tile.as<int>(); np.edge_src = h->d_esrc.as<int>(); np.edge_dst = h->d_edst.as<int>(); np.cap = h->edge_cap;
     np.word_start[0] = 0;
     for (int n = 0; n < ns; ++n) np.word_start[n + 1] = np.word_start[n] + (h->scale_start[n + 1] - h->scale_start[n] + 31) / 32;
-    if (!h->d_mask.ensure((size_t)np.word_start[ns] * Nd * 4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(neighbour masks) failed");
     np.mask = h->d_mask.as<uint32_t>();
     const int nblk = (Nd + kNbrBlock - 1) / kNbrBlock;
     np.edge_hist = h->profile ? h->d_hist.as<long long>() : nullptr;
@@ -363,9 +385,9 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     }
     mark();
     // 7. per-pose reduction
-    if constexpr (EBM) hipLaunchKernelGGL(k_energy_reduce, dim3((nT + 127) / 128), dim3(128), 0, st, h->d_nout.as<float>(), nT, nQ, ang);
-    else if (h->fused_step) hipLaunchKernelGGL(k_reduce_langevin, dim3(nT), dim3(64), 0, st, h->d_nout.as<float>(), nQ, ang, lin, *h->fused_step);
-    else hipLaunchKernelGGL(k_pose_reduce, dim3(nT), dim3(64), 0, st, h->d_nout.as<float>(), nT, nQ, ang, lin);
+    if constexpr (EBM) hipLaunchKernelGGL(k_energy_reduce, dim3((nT + 127) / 128), dim3(128), 0, st, h->d_nout.as<float>(), nT, nQ, ang, h->d_tile.as<int>());
+    else if (h->fused_step) hipLaunchKernelGGL(k_reduce_langevin, dim3(nT), dim3(64), 0, st, h->d_nout.as<float>(), nQ, ang, lin, *h->fused_step, h->d_tile.as<int>());
+    else hipLaunchKernelGGL(k_pose_reduce, dim3(nT), dim3(64), 0, st, h->d_nout.as<float>(), nT, nQ, ang, lin, h->d_tile.as<int>());
     mark();
     if (h->profile) { h->prof_evals += 1; h->prof_dst += Nd; }
     if (hipGetLastError() != hipSuccess) return fail(h, DEDF_ERR_RUNTIME, "kernel launch failed");
@@ -447,7 +469,8 @@ int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, de
             fprintf(stderr, "dedf_create: HIP device %d not available (this library has no CPU path)\n", cfg->device);
             return DEDF_ERR_RUNTIME;
         }
-        if (hipSetDevice(cfg->device) != hipSuccess) return DEDF_ERR_RUNTIME;
+        DeviceGuard guard(cfg->device);
+        if (!guard.ok) return DEDF_ERR_RUNTIME;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) {
             h->n_cu = prop.multiProcessorCount;
@@ -472,7 +495,7 @@ int dedf_set_key_clouds(dedf_handle* h, int n_scales, const int* n_pts, const fl
     if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
     if (n_scales != h->cfg.n_scales) return fail(h, DEDF_ERR_INVALID, "len(key_pcd_multiscale) != n_scales");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    HIPCK(h, hipSetDevice(h->cfg.device));
+    DEDF_ON_DEVICE(h);
     const size_t D = h->L == 1 ? feat_dim<1>() : feat_dim<2>();
     int total = 0;
     for (int n = 0; n < n_scales; ++n) {
@@ -510,7 +533,7 @@ int dedf_set_key_weights(dedf_handle* h, int n_scales, const int* n_pts, const f
     if (!h->have_keys) return fail(h, DEDF_ERR_INVALID, "dedf_set_key_clouds must be called first");
     if (n_scales != h->cfg.n_scales || !n_pts || !w) return fail(h, DEDF_ERR_INVALID, "n_scales mismatch / null arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    HIPCK(h, hipSetDevice(h->cfg.device));
+    DEDF_ON_DEVICE(h);
     for (int n = 0; n < n_scales; ++n)
         if (n_pts[n] != h->scale_start[n + 1] - h->scale_start[n] || (n_pts[n] > 0 && !w[n])) return fail(h, DEDF_ERR_INVALID, "key weights do not match the key clouds");
     if (!h->d_key_w.ensure((size_t)h->n_keys * 4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(key weights) failed");
@@ -527,7 +550,7 @@ int dedf_set_query(dedf_handle* h, int nQ, const float* x, const float* f, const
     if (nQ <= 0 || !x || !f) return fail(h, DEDF_ERR_INVALID, "bad query cloud");
     if (!w) return fail(h, DEDF_ERR_INVALID, "query_pcd.w is required (score_head.py:156-157)");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    HIPCK(h, hipSetDevice(h->cfg.device));
+    DEDF_ON_DEVICE(h);
     const size_t D = h->L == 1 ? feat_dim<1>() : feat_dim<2>();
     if (!h->d_qx.ensure((size_t)nQ * 3 * 4) || !h->d_qf.ensure((size_t)nQ * D * 4) || !h->d_qw.ensure((size_t)nQ * 4))
         return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(query) failed");
@@ -549,9 +572,10 @@ int dedf_score(dedf_handle* h, int nT, const float* Ts, const float* time, float
     if (h->cfg.ebm) return fail(h, DEDF_ERR_UNSUPPORTED, "EBM head: the score is the autograd of the energy (score_head_ebm.py:203-217), "
                                                           "which needs a backward pass and is not on the accelerated path; use dedf_energy");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    HIPCK(h, hipSetDevice(h->cfg.device));
+    DEDF_ON_DEVICE(h);
     int rc = ensure_workspace(h, nT);
     if (rc != DEDF_OK) return rc;
+    DEDF_CLEAR_FLAGS(h, st);
     HIPCK(h, hipMemcpyAsync(h->d_Ts.p, Ts, (size_t)nT * 7 * 4, hipMemcpyDeviceToDevice, st));
     HIPCK(h, hipMemcpyAsync(h->d_time.p, time, (size_t)nT * 4, hipMemcpyDeviceToDevice, st));
     return score_dispatch(h, nT, 1, ang, lin, st);
@@ -566,9 +590,10 @@ int dedf_energy(dedf_handle* h, int nT, const float* Ts, const float* time, floa
     if (nT <= 0 || !Ts || !energy) return fail(h, DEDF_ERR_INVALID, "bad arguments");
     (void)time;   // the critic has no time encoding (configs/*/pick_ebm/score_model_configs.yaml:8-9; agent.py:170)
     hipStream_t st = static_cast<hipStream_t>(stream);
-    HIPCK(h, hipSetDevice(h->cfg.device));
+    DEDF_ON_DEVICE(h);
     int rc = ensure_workspace(h, nT);
     if (rc != DEDF_OK) return rc;
+    DEDF_CLEAR_FLAGS(h, st);
     HIPCK(h, hipMemcpyAsync(h->d_Ts.p, Ts, (size_t)nT * 7 * 4, hipMemcpyDeviceToDevice, st));
     return score_dispatch(h, nT, 0, energy, nullptr, st);
 }
@@ -582,10 +607,11 @@ int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedul
     if (nT <= 0 || !T_seed || !sched || sched->n_steps < 0 || !Ts_out) return fail(h, DEDF_ERR_INVALID, "bad arguments");
     if (h->cfg.ebm) return fail(h, DEDF_ERR_UNSUPPORTED, "EBM head: sampling needs the energy gradient (backward pass); use dedf_energy");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    HIPCK(h, hipSetDevice(h->cfg.device));
+    DEDF_ON_DEVICE(h);
     int rc = ensure_workspace(h, nT);
     if (rc != DEDF_OK) return rc;
     const size_t row = (size_t)nT * 7;
+    DEDF_CLEAR_FLAGS(h, st);
     HIPCK(h, hipMemcpyAsync(h->d_T64.p, T_seed, row * 8, hipMemcpyDeviceToDevice, st));
     HIPCK(h, hipMemcpyAsync(Ts_out, T_seed, row * 8, hipMemcpyDeviceToDevice, st));
     // every pose shares the step's time: the time-bias rows of all steps come from ONE launch before the loop
@@ -615,9 +641,13 @@ int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedul
     }
     HIPCK(h, hipMemcpyAsync(Ts_out + (size_t)(sched->n_steps + 1) * row, h->d_T64.p, row * 8, hipMemcpyDeviceToDevice, st));
     HIPCK(h, hipStreamSynchronize(st));
-    int ovf = 0;
-    if (sched->n_steps > 0) HIPCK(h, hipMemcpy(&ovf, h->d_tile.as<int>() + 40, 4, hipMemcpyDeviceToHost));
-    if (ovf) return fail(h, DEDF_ERR_RUNTIME, "edge workspace overflow: raise dedf_config.max_edges");
+    // sticky status words of the whole call: an overflow or a non-finite score in ANY step is reported (the trajectory then holds NaNs
+    // from that step on, never stale scores)
+    int flags[2] = {0, 0};
+    if (sched->n_steps > 0) HIPCK(h, hipMemcpy(flags, h->d_tile.as<int>() + kFlagOverflow, sizeof(flags), hipMemcpyDeviceToHost));
+    if (flags[0]) return fail(h, DEDF_ERR_RUNTIME, "edge workspace overflow: raise dedf_config.max_edges");
+    if (flags[1]) return fail(h, DEDF_ERR_RUNTIME, "non-finite score: an activation left the fp16 operand range of the split-fp16 GEMMs "
+                                                   "(or the inputs / poses were not finite)");
     return DEDF_OK;
 }
 
@@ -631,14 +661,15 @@ int dedf_get_stats(dedf_handle* h, dedf_stats* out) {
     HIPCK(h, hipMemcpy(ti, h->d_tile.p, sizeof(ti), hipMemcpyDeviceToHost));
     out->n_dst = (int64_t)h->last_nT * h->nQ;
     for (int n = 0; n < h->cfg.n_scales; ++n) { out->n_edges[n] = ti[16 + n + 1] - ti[16 + n]; out->n_edges_total += out->n_edges[n]; }
-    out->overflow = ti[40];
+    out->overflow = ti[40] | ti[kFlagOverflow];
+    out->nonfinite = ti[kFlagNonFinite];
     return DEDF_OK;
 }
 
 int dedf_profile_enable(dedf_handle* h, int on) {
     if (!h) return DEDF_ERR_INVALID;
     if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
-    HIPCK(h, hipSetDevice(h->cfg.device));
+    DEDF_ON_DEVICE(h);
     if (on && !h->d_hist.p) {
         if (!h->d_hist.ensure(8)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc failed");
         HIPCK(h, hipMemset(h->d_hist.p, 0, 8));

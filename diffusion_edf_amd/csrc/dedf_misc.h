@@ -214,12 +214,15 @@ struct NbrParams {
     int* off;                             // [n_scales][n_dst]  exclusive prefix inside the scale
     int* blk;                             // [n_scales][n_blocks] block totals of the count pass
     int* tile_info;                       // written by block 0 of the fill pass: [0..n_scales] tile prefix, [16..16+n_scales] edge prefix, [40] overflow
+                                          // of this evaluation, [41] sticky overflow (set here, cleared by the host at the start of an API call),
+                                          // [42] sticky non-finite score (set by the per-pose reductions)
     long long* edge_hist;                 // optional running edge count (statistics)
     int* edge_src; int* edge_dst;
     int64_t cap;
     uint32_t* mask;                       // [word][n_dst]: neighbour bit masks written by the count pass, 32 keys per word
     int word_start[kMaxScales + 1];       // first mask word of every scale (scale n has ceil(n_keys_n / 32) words)
 };
+constexpr int kFlagOverflow = 41, kFlagNonFinite = 42;      // words of tile_info
 constexpr int kNbrChunk = 1024;
 constexpr int kNbrBlock = 256;
 
@@ -276,6 +279,7 @@ __global__ __launch_bounds__(kNbrBlock) void k_neighbors(NbrParams P) {
             }
             const int ovf = edges > P.cap ? 1 : 0;
             P.tile_info[40] = ovf;
+            if (ovf) P.tile_info[kFlagOverflow] = 1;       // sticky within one dedf_score / dedf_energy / dedf_sample call
             if (P.edge_hist) *P.edge_hist += edges;
             if (ovf) for (int n = 0; n <= P.n_scales; ++n) P.tile_info[n] = 0;     // no tiles: downstream kernels do nothing
         }
@@ -443,7 +447,19 @@ __global__ void k_aggregate(const float* __restrict__ edge_out, const int* __res
 // ------------------------------------------------------------------------------------------------------------------------
 // Sum over the query points of one pose (score_head.py:207-209), fixed order.
 // One wave per pose: lanes stride over the query points, then a fixed butterfly (deterministic, independent of nT).
-__global__ __launch_bounds__(64) void k_pose_reduce(const float* __restrict__ node_out, int nT, int nQ, float* __restrict__ ang, float* __restrict__ lin) {
+// Status words (tile_info): an edge-workspace overflow anywhere in this API call turns the outputs into NaN (the evaluation that
+// overflowed produced nothing: stale results must never look valid); a non-finite sum (fp16 operand range exceeded, or NaN inputs)
+// raises the sticky non-finite flag.
+__device__ inline bool reduce_status(int* flags, float (&s)[6]) {
+    const bool ovf = flags[kFlagOverflow] != 0;
+    if (ovf) for (int i = 0; i < 6; ++i) s[i] = __builtin_nanf("");
+    bool fin = true;
+    for (int i = 0; i < 6; ++i) fin = fin && (fabsf(s[i]) <= 3.0e38f);
+    if (!fin && !ovf) flags[kFlagNonFinite] = 1;
+    return ovf;
+}
+__global__ __launch_bounds__(64) void k_pose_reduce(const float* __restrict__ node_out, int nT, int nQ, float* __restrict__ ang, float* __restrict__ lin,
+                                                    int* __restrict__ flags) {
     const int t = blockIdx.x, lane = threadIdx.x;
     if (t >= nT) return;
     float s[6] = {0, 0, 0, 0, 0, 0};
@@ -455,6 +471,7 @@ __global__ __launch_bounds__(64) void k_pose_reduce(const float* __restrict__ no
     for (int m = 32; m >= 1; m >>= 1)
         for (int i = 0; i < 6; ++i) s[i] += __shfl_xor(s[i], m, 64);
     if (lane == 0) {
+        reduce_status(flags, s);
         lin[3 * t] = s[0]; lin[3 * t + 1] = s[1]; lin[3 * t + 2] = s[2];
         ang[3 * t] = s[3]; ang[3 * t + 1] = s[4]; ang[3 * t + 2] = s[5];
     }
@@ -539,7 +556,7 @@ __device__ inline void langevin_update(const LangevinParams& P, int i, const flo
 // Sampler: sum over the query points of one pose (k_pose_reduce's order, bit for bit) and the Langevin update of that pose in one
 // launch — one wave per pose, lane 0 carries the float64 update.
 __global__ __launch_bounds__(64) void k_reduce_langevin(const float* __restrict__ node_out, int nQ, float* __restrict__ ang_out,
-                                                        float* __restrict__ lin_out, LangevinParams P) {
+                                                        float* __restrict__ lin_out, LangevinParams P, int* __restrict__ flags) {
     const int t = blockIdx.x, lane = threadIdx.x;
     if (t >= P.nT) return;
     float s[6] = {0, 0, 0, 0, 0, 0};
@@ -551,6 +568,7 @@ __global__ __launch_bounds__(64) void k_reduce_langevin(const float* __restrict_
     for (int m = 32; m >= 1; m >>= 1)
         for (int i = 0; i < 6; ++i) s[i] += __shfl_xor(s[i], m, 64);
     if (lane != 0) return;
+    reduce_status(flags, s);
     const float lin[3] = {s[0], s[1], s[2]}, ang[3] = {s[3], s[4], s[5]};
     for (int k = 0; k < 3; ++k) { lin_out[3 * t + k] = lin[k]; ang_out[3 * t + k] = ang[k]; }
     langevin_update(P, t, ang, lin);

@@ -251,7 +251,7 @@ template <int L> DEDF_HD constexpr NodeLayout<L> make_node_layout() {
 // accumulator -> true value of the node kernel's split-fp16 GEMMs (each weight matrix carries its own power-of-two scale,
 // the B operands a fixed 2^kNodeBShift; dedf_pack.h::pack_node)
 struct NodeScales { float proj[4], f1[4], f2[4], s[2][16], sl[2][2]; };
-constexpr int kNodeBShift = 8;
+constexpr int kNodeBShift = 5;      // activation-side operand: typical magnitude 2^5 (dedf_pack.h::kActHeadroomBits)
 constexpr int kMlpMid = 3;
 template <int L> DEDF_HD constexpr int f1_rows0() { int r = kMlpMid * mul_of(0); for (int l = 1; l <= L; ++l) r += kMlpMid * mul_of(l); return r; }  // 336 / 288
 template <int L> DEDF_HD constexpr int f1_rows0_fwd() { return f1_rows0<L>(); }

@@ -37,6 +37,8 @@ def gather_poses(local: torch.Tensor, n_total: int, dim: int = 0, group=None) ->
     sizes = [shard_range(n_total, ws, r) for r in range(ws)]
     mx = max(e - s for s, e in sizes)
     x = local.movedim(dim, 0).contiguous()
+    if mx == 0:                       # no poses at all: every rank knows it (n_total is global), no collective needed
+        return local
     pad = torch.zeros((mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     pad[: x.shape[0]] = x
     out = [torch.empty_like(pad) for _ in range(ws)]
@@ -50,7 +52,7 @@ def sample_sharded(model, T_seed: torch.Tensor, scene_pcd_multiscale, grasp_pcd,
     """``ScoreModelBase.sample`` over the pose shard of this rank + the closing all-gather.
     Returns the final poses (nT,7) — or the whole (steps+2, nT, 7) trajectory — of ALL poses on every rank."""
     nT = len(T_seed)
-    local, first = shard_poses(T_seed)
+    local, first = shard_poses(T_seed)          # may be empty (world size > number of poses): sample() then returns an empty block
     traj = model.sample(local, scene_pcd_multiscale, grasp_pcd, seed=seed, first_pose_index=first, **sample_kwargs)
     if gather_trajectory:
         return gather_poses(traj, nT, dim=1)

@@ -133,9 +133,9 @@ class ScoreModelHead(torch.nn.Module):
             pass
 
     # ------------------------------------------------------------------------------------------------------------------
-    @staticmethod
-    def _stream() -> C.c_void_p:
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    def _stream(self) -> C.c_void_p:
+        """torch's current stream ON THE HANDLE'S DEVICE (which need not be the current device)"""
+        return C.c_void_p(torch.cuda.current_stream(self._handle_device).cuda_stream)
 
     def set_key_clouds(self, key_pcd_multiscale: Sequence[FeaturedPoints]):
         assert len(key_pcd_multiscale) == self.n_scales
@@ -161,12 +161,32 @@ class ScoreModelHead(torch.nn.Module):
             wp = (C.c_void_p * n)(*[w.data_ptr() for w in ws])
             rc = lib.dedf_set_key_weights(self._handle, n, npts, wp, self._stream())
             _lib.raise_for(lib, self._handle, rc, "dedf_set_key_weights")
-        self._scene_key = self._key_of(key_pcd_multiscale)
+        self._scene_key = self._refs(self._key_of(key_pcd_multiscale))
+
+    # Upload cache.  An entry holds STRONG references to the caller's tensors next to their version counters: while a cloud is
+    # cached its storage cannot be handed to another tensor by the caching allocator, so "same object, same version" really
+    # means "same contents" (a key made of data_ptr()s alone can collide with the next scene's freshly allocated tensors).
+    # In-place writes that bypass the version counter (.data, custom kernels, dlpack) are not seen: call set_key_clouds /
+    # set_query explicitly after such writes.
+    @staticmethod
+    def _refs(tensors):
+        return tuple((t, t._version) for t in tensors)
+
+    @staticmethod
+    def _same(refs, tensors) -> bool:
+        return refs is not None and len(refs) == len(tensors) and all(r[0] is t and r[1] == t._version for r, t in zip(refs, tensors))
 
     def _key_of(self, key_pcd_multiscale):
-        return tuple((p.x.data_ptr(), p.f.data_ptr(), p.x._version, p.f._version, len(p.x)) +
-                     ((p.w.data_ptr(), p.w._version) if self.cfg.use_src_point_attn and isinstance(p.w, torch.Tensor) else ())
-                     for p in key_pcd_multiscale)
+        ts = []
+        for p in key_pcd_multiscale:
+            ts += [p.x, p.f]
+            if self.cfg.use_src_point_attn and isinstance(p.w, torch.Tensor):
+                ts.append(p.w)
+        return ts
+
+    @staticmethod
+    def _query_tensors(query_pcd):
+        return [query_pcd.x, query_pcd.f, query_pcd.w]
 
     def set_query(self, query_pcd: FeaturedPoints):
         dev = query_pcd.x.device
@@ -180,16 +200,12 @@ class ScoreModelHead(torch.nn.Module):
         w = w.detach().to(torch.float32).contiguous()
         rc = lib.dedf_set_query(self._handle, len(x), x.data_ptr(), f.data_ptr(), w.data_ptr(), self._stream())
         _lib.raise_for(lib, self._handle, rc, "dedf_set_query")
-        self._query_key = (query_pcd.x.data_ptr(), query_pcd.f.data_ptr(), query_pcd.w.data_ptr(), query_pcd.x._version,
-                           query_pcd.f._version, query_pcd.w._version, len(x))
+        self._query_key = self._refs(self._query_tensors(query_pcd))
 
     def _sync_inputs(self, key_pcd_multiscale, query_pcd):
-        sk = self._key_of(key_pcd_multiscale)
-        if self._handle is None or sk != self._scene_key:
+        if self._handle is None or not self._same(self._scene_key, self._key_of(key_pcd_multiscale)):
             self.set_key_clouds(key_pcd_multiscale)
-        qk = (query_pcd.x.data_ptr(), query_pcd.f.data_ptr(), query_pcd.w.data_ptr(), query_pcd.x._version,
-              query_pcd.f._version, query_pcd.w._version, len(query_pcd.x))
-        if qk != self._query_key:
+        if not isinstance(query_pcd.w, torch.Tensor) or not self._same(self._query_key, self._query_tensors(query_pcd)):
             self.set_query(query_pcd)
 
     @torch.no_grad()
@@ -237,7 +253,7 @@ class ScoreModelHead(torch.nn.Module):
         rc = lib.dedf_get_stats(self._handle, C.byref(st))
         _lib.raise_for(lib, self._handle, rc, "dedf_get_stats")
         return dict(n_dst=st.n_dst, n_edges=[st.n_edges[i] for i in range(self.n_scales)], n_edges_total=st.n_edges_total,
-                    overflow=bool(st.overflow))
+                    overflow=bool(st.overflow), nonfinite=bool(st.nonfinite))
 
     def profile_enable(self, on: bool = True):
         lib = _lib.load()

@@ -78,6 +78,8 @@ class ScoreModelBase(torch.nn.Module):
         t, aa, al, tt = build_schedule(head.ang_mult, head.lin_mult, diffusion_schedules, N_steps, timesteps, temperatures,
                                        log_t_schedule, time_exponent_temp, time_exponent_alpha)
         n_steps, nT = len(t), len(T_seed)
+        if nT == 0:          # an empty pose block (a rank with no poses in a sharded run): nothing to launch, same output shape
+            return torch.empty(n_steps + 2, 0, 7, device=device, dtype=torch.float64)
         sch = _lib.DedfSchedule()
         sch.n_steps = n_steps
         dp = C.POINTER(C.c_double)

@@ -39,7 +39,7 @@ extern "C" {
 #define DEDF_OK 0
 #define DEDF_ERR_INVALID 1      /* bad argument / shape (the reference raises AssertionError / ValueError) */
 #define DEDF_ERR_UNSUPPORTED 2  /* configuration outside the accelerated path */
-#define DEDF_ERR_RUNTIME 3      /* HIP failure, workspace overflow */
+#define DEDF_ERR_RUNTIME 3      /* HIP failure, workspace overflow, non-finite score */
 #define DEDF_MAX_SCALES 8
 
 typedef struct dedf_handle dedf_handle;
@@ -84,7 +84,10 @@ typedef struct dedf_stats {
     int64_t n_dst;                       /* nT * nQ of the last call */
     int64_t n_edges[DEDF_MAX_SCALES];    /* edges per scale of the last score evaluation */
     int64_t n_edges_total;
-    int overflow;                        /* 1 if the edge workspace was too small (results invalid) */
+    int overflow;                        /* 1 if the edge workspace was too small in any evaluation of the last dedf_score / dedf_energy /
+                                            dedf_sample call (its outputs are NaN from that evaluation on; dedf_sample returns DEDF_ERR_RUNTIME) */
+    int nonfinite;                       /* 1 if a score / energy of the last call was not finite: an activation left the fp16 operand range
+                                            of the split-fp16 GEMMs, or inputs were not finite (dedf_sample returns DEDF_ERR_RUNTIME) */
 } dedf_stats;
 
 const char* dedf_version(void);

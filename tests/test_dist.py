@@ -50,7 +50,7 @@ def _worker(rank, world, port, n_poses, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_poses", [8, 9])
+@pytest.mark.parametrize("n_poses", [8, 9, 1])          # 1 pose on 2 ranks: one rank holds an empty shard and must still reach the collective
 def test_sharded_run_equals_single_process(n_poses):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
