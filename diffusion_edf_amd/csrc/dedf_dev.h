@@ -208,6 +208,13 @@ DEDF_DEV void to_vgpr(f32x16& t) {
     asm volatile("" : "+v"(t));
 #endif
 }
+// Make a per-lane value opaque to the optimiser at this point (no instruction): what is computed from it afterwards is not merged
+// with what was computed from it before, i.e. nothing derived from it stays alive across this point.
+DEDF_DEV void opaque_v(float& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#endif
+}
 // Returns v, but as an opaque function of `dep`: a request whose address goes through tie() cannot be issued before `dep`
 // exists, and (volatile) keeps its place between the scheduling fences.  hipcc otherwise lets the pure MFMA / VALU work drift
 // below the fences while the operand requests stay put, so that a whole layer's operands end up in flight (and spilled).

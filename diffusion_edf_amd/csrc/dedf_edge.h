@@ -320,10 +320,17 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     const Buf msgb = make_buf(P.msg, P.msg_bytes);
     // per-l1 lane offsets of the 4 message rows this lane owns inside an 8-row group
     const int mv0 = src * (D * 4) + hi * 16, mv1 = src * (D * 4) + hi * 48, mv2 = src * (D * 4) + hi * 80;
-    // LDS parking: slot = 4 registers of every lane ([slot][lane][4]); u0: 8 slots, u1[m]: 4 each, u2[m]: 2 each
-    constexpr int US1 = 8, US2 = US1 + 12, SPW = US2 + 10, NSLOT = SPW + 2;      // SPW: segment softmax weights / normalisers
+    // LDS parking: the gated features wait here as READY-MADE B operands of the value GEMMs: one 16-byte slot per lane holds the
+    // fp16 hi halves of a 16-channel chunk (8 accumulator registers), the next slot their fp16 residuals ([slot][lane][8 halves];
+    // chunk q = dedf_net.h::park_slot(degree, component, chunk) -> slots 2q | 2q + 1), lane-private
+    constexpr int NPS = park_slots<L>(), SPW = 2 * NPS, NSLOT = SPW + 2;      // SPW: segment softmax weights / normalisers
     __shared__ f32x4 park[NSLOT * 64];
     f32x4* const pk = park + wv.lane;
+    auto park_chunk = [&]<int Q>(const float (&v)[8]) {
+        const HL sp = split8(v);
+        pk[(2 * Q) * 64] = __builtin_bit_cast(f32x4, sp.hi);
+        if constexpr (!HP) pk[(2 * Q + 1) * 64] = __builtin_bit_cast(f32x4, sp.lo);
+    };
 
     // Software pipeline over the WN/16 chunks (16 weight rows = half a weight tile).  Region C issues, in one scheduling
     // region so that hipcc interleaves them:  the source-message loads of chunk C+2,  the layer-3 MFMAs of the NEXT weight
@@ -431,22 +438,25 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 logit[hd] = sum + logit0;
             });
             // Gate (fast_activation.py:210-224): SiLU on the 64 scalars, sigmoid gates for the l >= 1 channels
-            static_for<2>([&]<int T>() { static_for<4>([&]<int q>() {
-                pk[(4 * T + q) * 64] = f32x4{silu_n(acc0[T][4 * q] * cl0) * us, silu_n(acc0[T][4 * q + 1] * cl0) * us, silu_n(acc0[T][4 * q + 2] * cl0) * us,
-                                             silu_n(acc0[T][4 * q + 3] * cl0) * us};
+            static_for<2>([&]<int T>() { static_for<2>([&]<int hf>() {
+                float v[8];
+                static_for<8>([&]<int J>() { v[J] = silu_n(acc0[T][8 * hf + J] * cl0) * us; });
+                park_chunk.template operator()<park_slot<L>(0, 0, 2 * T + hf)>(v);
             }); });
             if constexpr (L >= 1) { constexpr int G0 = gate_row(1, 0); static_for<16>([&]<int R>() { g1[R] = sigmoid_n(acc0[G0 / 32][(G0 % 32) / 2 + R] * cl0) * (cl1 * us); }); }
             if constexpr (L >= 2) { constexpr int G0 = gate_row(2, 0); static_for<8>([&]<int R>() { g2[R] = sigmoid_n(acc0[G0 / 32][(G0 % 32) / 2 + R] * cl0) * (cl2 * us); }); }
         } else if constexpr (l3 == 1) {
-            static_for<3>([&]<int K>() { static_for<4>([&]<int q>() {
-                pk[(US1 + 4 * K + q) * 64] = f32x4{acc1[K][4 * q] * g1[4 * q], acc1[K][4 * q + 1] * g1[4 * q + 1], acc1[K][4 * q + 2] * g1[4 * q + 2],
-                                                   acc1[K][4 * q + 3] * g1[4 * q + 3]};
+            static_for<3>([&]<int K>() { static_for<2>([&]<int hf>() {
+                float v[8];
+                static_for<8>([&]<int J>() { v[J] = acc1[K][8 * hf + J] * g1[8 * hf + J]; });
+                park_chunk.template operator()<park_slot<L>(1, K, hf)>(v);
             }); });
         } else {
-            static_for<5>([&]<int K>() { static_for<2>([&]<int q>() {     // 16 channels = registers 0-7
-                pk[(US2 + 2 * K + q) * 64] = f32x4{acc2[K][4 * q] * g2[4 * q], acc2[K][4 * q + 1] * g2[4 * q + 1], acc2[K][4 * q + 2] * g2[4 * q + 2],
-                                                   acc2[K][4 * q + 3] * g2[4 * q + 3]};
-            }); });
+            static_for<5>([&]<int K>() {      // 16 channels = registers 0-7
+                float v[8];
+                static_for<8>([&]<int J>() { v[J] = acc2[K][J] * g2[J]; });
+                park_chunk.template operator()<park_slot<L>(2, K, 0)>(v);
+            });
         }
     };
     auto start_group = [&]<int l3>() {
@@ -502,41 +512,17 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     sched_fence();
     DEDF_STAMP(12);
     // ---- sep_value: depth-wise TP #2 (shared weights folded into the A stream) + LinearRS -> value --------------------------
-    // same walk: l3 = 0 chunks -> val0, l3 = 1 / 2 -> val1[m] / val2[m]; a completed group goes straight to the edge record
-    f32x16 val0[2], val1[3], val2[5];
-    static_for<2>([&]<int T>() { val0[T] = ldrows_lds(rows, hi, RL::val0, T); });
-    struct XPark { f32x4 a[2 * L + 1][2]; };      // parked gated features of a chunk's 8 channels (per lane)
-    auto load_park = [&]<int C>() {
-        XPark o{};
-        if constexpr (C < NCHK) {
-            constexpr PathInfo pi = dtp_pos_path<L>(C);
-            constexpr int l1 = pi.l1, d1 = 2 * l1 + 1, cu = dtp_pos_u0<L>(C) / 16;
-            static_for<d1>([&]<int I>() {
-                constexpr int s0 = l1 == 0 ? 2 * cu : (l1 == 1 ? US1 + 4 * I + 2 * cu : US2 + 2 * I);
-                o.a[I][0] = pk[s0 * 64]; o.a[I][1] = pk[(s0 + 1) * 64];
-            });
-        }
-        return o;
-    };
-    auto valu_val = [&]<int C>(const XPark& xp) {
-        BOpsH<L> o{};
-        if constexpr (C < NCHK) {
-            constexpr PathInfo pi = dtp_pos_path<L>(C);
-            constexpr int l1 = pi.l1, l2 = pi.l2, l3 = pi.l3, d1 = 2 * l1 + 1, d3 = 2 * l3 + 1;
-            using Cg = CG<l1, l2, l3>;
-            float m[Cg::NM];
-            Cg::make(Y.template get<l2>(), m);
-            float v[d3][8];
-            static_for<8>([&]<int jj>() {
-                float x[d1], t[d3];
-                static_for<d1>([&]<int I>() { x[I] = xp.a[I][jj / 4][jj % 4]; });
-                Cg::apply(x, m, t);
-                static_for<d3>([&]<int K>() { v[K][jj] = t[K]; });
-            });
-            split_chunk<L, l3>(v, o);
-        }
-        return o;
-    };
+    // The Clebsch-Gordan coefficient products of the SH (CG::make) are recomputed here from an opaque copy of the SH: merged with the
+    // first depth-wise TP's, ~130 of them would stay alive across both phases.
+    static_for<L + 1>([&]<int l>() { static_for<2 * l + 1>([&]<int i>() {
+        if constexpr (l == 0) opaque_v(Y.y0[i]); else if constexpr (l == 1) opaque_v(Y.y1[i]); else if constexpr (l == 2) opaque_v(Y.y2[i]); else opaque_v(Y.y3[i]);
+    }); });
+    // Output-side form (dedf_net.h::make_val_walk): the parked gated features are the B operands as they are, the GEMM results
+    // G_i (one tile per component i of the input degree) are contracted with the edge's SH on the VALU into val0 / val1[m] /
+    // val2[m]; paths are walked by output degree, a completed degree goes straight to the segment record.
+    // (plain scalars, not 16-register tuples: the VALU updates them element by element)
+    float val0[2][16], val1[3][16], val2[5][8];
+    static_for<2>([&]<int T>() { const f32x16 b = ldrows_lds(rows, hi, RL::val0, T); static_for<16>([&]<int R>() { val0[T][R] = b[R]; }); });
     // ---- joint-softmax partials --------------------------------------------------------------------------------------------
     // The tile's edges are ordered by destination, so the edges of one destination form a run of lanes ("segment").  Instead
     // of one 976-byte record per edge, the tile emits one per segment: the segment's softmax-weighted mean value and the
@@ -670,27 +656,104 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             emit(x, ro, iv);
         }
     };
-    auto start_val = [&]<int l3>() {
-        if constexpr (l3 == 1) static_for<3>([&]<int K>() { static_for<16>([&]<int R>() { val1[K][R] = 0.0f; }); });
-        if constexpr (l3 == 2) static_for<5>([&]<int K>() { static_for<16>([&]<int R>() { val2[K][R] = 0.0f; }); });
-    };
+    // Software pipeline over the work items: region I requests the A slots of item I + 2 and the parked B chunks of item I + 1,
+    // runs the MFMAs of item I and, beside them, the contraction of the accumulators item I - 1 completed.
+#ifndef DEDF_V_PDA
+#define DEDF_V_PDA 2
+#endif
+#ifndef DEDF_V_LAG
+#define DEDF_V_LAG 1
+#endif
+    constexpr int NVI = val_num_items<L>(), PDV = DEDF_V_PDA, RS = 2 * (PDV + 1), LAG = DEDF_V_LAG;
     const int o_S_val = opaque_s(P.o_S_val);
-    AItem vring[PDA];
-    static_for<PDA>([&]<int I>() { vring[I] = load_item<L, 2, I, HP>(wv, o_S_val); });
-    XPark xp_nxt = load_park.template operator()<1>();
-    BOpsH<L> vb_cur = valu_val.template operator()<0>(load_park.template operator()<0>());
-    static_for<NCHK>([&]<int C>() {
-        XPark xp_nn = xp_nxt;
-        if constexpr (!dtp_pos_same_x<L>(C + 2, C + 1)) xp_nn = load_park.template operator()<C + 2>();
-        static_for<L + 1>([&]<int g>() { if constexpr (g >= 1 && C == dtp_group_end<L>(g - 1)) start_val.template operator()<g>(); });
+    struct ASlot { f32x4 h, l; };
+    struct BSet { f32x4 h[3], l[3]; };
+    ASlot aring[RS];
+    // Operand requests are anchored to the VALU stream (dedf_dev.h::tie) through `tok`, a value the previous region's contraction
+    // produced: hipcc otherwise lets the MFMAs / VALU work sink below the fences while the requests stay, and a dozen operand sets
+    // end up in flight (and spilled).
+    float tok = logit0;
+    int lane16_t = wv.lane16, lane16_r16_t = wv.lane16_r16, lane_t = wv.lane;
+    auto load_A = [&]<int S>() {
+        if constexpr (S < val_num_slots<L>()) {
+            const int lv = mul_of(val_slot_l3<L>(S)) < 32 ? lane16_r16_t : lane16_t;      // rows 16-31 are padding: half the lanes fetch
+            aring[S % RS].h = bld4(wv.w, lv, (o_S_val + S * 512) * 4);
+            if constexpr (!HP) aring[S % RS].l = bld4(wv.w, lv, (o_S_val + S * 512 + 256) * 4);
+        }
+    };
+    auto load_A_of = [&]<int I>() {
+        if constexpr (I < NVI) static_for<val_item<L>(I).new_slots>([&]<int n>() { load_A.template operator()<val_item_slot0<L>(I) + n>(); });
+    };
+    auto load_B = [&]<int I>() {
+        BSet o{};
+        if constexpr (I < NVI) {
+            constexpr VItem it = val_item<L>(I);
+            const f32x4* const pkt = park + lane_t;
+            static_for<it.na>([&]<int a>() {
+                o.h[a] = pkt[(2 * it.bq[a]) * 64];
+                if constexpr (!HP) o.l[a] = pkt[(2 * it.bq[a] + 1) * 64];
+            });
+        }
+        return o;
+    };
+    auto run_item = [&]<int I>(const BSet& b, f32x16 (&G)[3]) {
+        constexpr VItem it = val_item<L>(I);
+        const f32x16 zero = {};
+        static_for<it.na>([&]<int a>() {
+            G[a] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].h), __builtin_bit_cast(h8, b.h[a]), it.first ? zero : G[a]);
+        });
+        if constexpr (!HP) {
+            static_for<it.na>([&]<int a>() { G[a] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].h), __builtin_bit_cast(h8, b.l[a]), G[a]); });
+            static_for<it.na>([&]<int a>() { G[a] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].l), __builtin_bit_cast(h8, b.h[a]), G[a]); });
+        }
+    };
+    auto contract = [&]<int I>(f32x16 (&G)[3]) {      // value[.., k] += (sum_j C_ijk Y_j) G_i   for the components this item completed
+        constexpr VItem it = val_item<L>(I);
+        constexpr PathInfo pi = dtp_path<L>(it.p);
+        constexpr int l1 = pi.l1, l2 = pi.l2, l3 = pi.l3, d3 = 2 * l3 + 1;
+        constexpr int NR = mul_of(l3) >= 32 ? 16 : mul_of(l3) / 2;       // registers holding valid rows
+        using Cg = CG<l1, l2, l3>;
+        float m[Cg::NM];
+        Cg::make(Y.template get<l2>(), m);
+        static_for<NR>([&]<int R>() {
+            float o[d3];
+            static_for<d3>([&]<int K>() {
+                if constexpr (l3 == 0) o[K] = val0[it.t][R];
+                else if constexpr (val_item_opens_group<L>(I)) o[K] = 0.0f;
+                else if constexpr (l3 == 1) o[K] = val1[K][R];
+                else o[K] = val2[K][R];
+            });
+            if constexpr (it.merge) Cg::template acc<0>(G[0][R] + G[1][R], m, o);
+            else static_for<it.na>([&]<int a>() { Cg::template acc<it.comp[a]>(G[a][R], m, o); });
+            // (opaque: the accumulation happens HERE -- hipcc otherwise defers it to the store of the block and keeps every G tile alive)
+            static_for<d3>([&]<int K>() {
+                opaque_v(o[K]);
+                if constexpr (l3 == 0) val0[it.t][R] = o[K]; else if constexpr (l3 == 1) val1[K][R] = o[K]; else val2[K][R] = o[K];
+            });
+            if constexpr (R == NR - 1) tok = o[0];
+        });
+    };
+    static_for<PDV>([&]<int I>() { load_A_of.template operator()<I>(); });
+    BSet vb_cur = load_B.template operator()<0>();
+    f32x16 G[3], Gfin[3];
+    static_for<NVI + LAG>([&]<int I>() {
+        lane16_t = tie(wv.lane16, tok); lane16_r16_t = tie(wv.lane16_r16, tok); lane_t = tie(wv.lane, tok);
+        load_A_of.template operator()<I + PDV>();
+        const BSet b_nxt = load_B.template operator()<I + 1>();
         sched_fence();
-        const BOpsH<L> vb_nxt = valu_val.template operator()<C + 1>(xp_nxt);
-        mfma_chunk<L, 2, C, HP>(wv, o_S_val, vring, vb_cur, val0, val1, val2);
-        static_for<L + 1>([&]<int g>() { if constexpr (C == dtp_group_end<L>(g)) store_group.template operator()<g>(); });
+        constexpr int F = I - LAG;                       // item whose accumulators are contracted in this region
+        constexpr bool fin = F >= 0 && val_item<L>(F).last;
+        if constexpr (LAG && fin) static_for<3>([&]<int a>() { Gfin[a] = G[a]; });
+        if constexpr (I < NVI) run_item.template operator()<I>(vb_cur, G);
+        if constexpr (fin) {
+            if constexpr (LAG) contract.template operator()<F>(Gfin); else contract.template operator()<F>(G);
+            constexpr int ge = val_item<L>(F).group_end;
+            if constexpr (ge >= 0 && ge < L) store_group.template operator()<ge>();
+        }
         sched_fence();
-        vb_cur = vb_nxt; xp_nxt = xp_nn;
-        if constexpr (C + 1 == dtp_group_end<L>(0)) DEDF_STAMP(10);
-        if constexpr (L >= 2 && C + 1 == dtp_group_end<L>(1)) DEDF_STAMP(13);
+        vb_cur = b_nxt;
+        if constexpr (F >= 0 && val_item<L>(F).group_end == 0) DEDF_STAMP(10);
+        if constexpr (L >= 2 && F >= 0 && val_item<L>(F).group_end == 1) DEDF_STAMP(13);
     });
     DEDF_STAMP(14);
     store_group.template operator()<L>();

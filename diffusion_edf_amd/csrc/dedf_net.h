@@ -145,6 +145,99 @@ template <int L> DEDF_HD constexpr int dtp_item_first(int p, int nt0) {
 }
 template <int L> DEDF_HD constexpr int dtp_num_slots(int nt0) { return dtp_item<L>(1 << 20, nt0).slot; }
 
+// ---- second depth-wise TP (attention value) in OUTPUT-SIDE form -----------------------------------------------------------
+// value[o,k] = sum_p sum_u W2[p,u,o] sum_ij C^p_ijk u[u,i] Y[j]  is evaluated as  G^p_i[o] = sum_u W2[p,u,o] u[u,i]  (a GEMM whose
+// B operand is component i of the gated features themselves -- split into fp16 hi / lo ONCE when they are gated and parked in LDS,
+// 240 values per edge instead of the 1568 depth-wise-TP outputs) followed by the lane-local contraction
+// value[o,k] += (sum_j C_ijk Y[j]) G_i[o].  Same FLOPs, the Clebsch-Gordan work moves behind the GEMM.
+// Parked B chunks (16 channels = 8 registers of each half-wave, dedf_layout.h::chain_k): slot q of (degree l, component i, chunk c).
+template <int L> DEDF_HD constexpr int park_slot(int l, int i, int c) {
+    int q = 0;
+    for (int a = 0; a < l; ++a) q += (2 * a + 1) * (mul_of(a) / 16);
+    return q + i * (mul_of(l) / 16) + c;
+}
+template <int L> DEDF_HD constexpr int park_slots() { return park_slot<L>(L + 1, 0, 0); }          // 15 (L = 2), 10 (L = 1)
+// Work item of the value GEMMs: up to three independent accumulator tiles (consecutive MFMAs never hit the same one):
+//   l1 = 0 : one component, two K-chunks at a time (partial sums, merged before the contraction)
+//   l1 = 1 : the three components of one K-chunk          l1 = 2 : components {0,1,2}, then {3,4}, of the only K-chunk
+//   l1 = 3 : components {0,1,2}, {3,4}, {5,6}
+// A operands: one 512-float slot (hi image | lo image) per (path, output tile, K-chunk), in the order first used.
+struct VItem {
+    int p, t;              // path (dtp_path), output row tile inside the l3 block
+    int na;                // accumulators
+    int comp[3], bq[3], aslot[3];
+    bool first, last;      // first / last item of its (path, tile, component set): zero the accumulators / contract them
+    bool merge;            // l1 = 0: accumulators 0 and 1 are partial sums of component 0
+    int group_end;         // output degree completed by this item's contraction, or -1
+    int new_slots;         // A slots this item is the first to use (they follow the previous item's in the stream)
+};
+template <int L> DEDF_HD constexpr int val_tiles(int l3) { return l3 == 0 ? mul_of(0) / 32 : 1; }
+template <int L> struct ValWalk { VItem item[96]; int n, n_slots; };
+template <int L> DEDF_HD constexpr ValWalk<L> make_val_walk() {
+    ValWalk<L> w{};
+    int n = 0, slot = 0;
+    for (int l3 = 0; l3 <= L; ++l3) {
+        int last_of_group = -1;
+        for (int p = 0; p < dtp_num_paths<L>(); ++p) {
+            const PathInfo pi = dtp_path<L>(p);
+            if (pi.l3 != l3) continue;
+            const int kc = mul_of(pi.l1) / 16, d1 = 2 * pi.l1 + 1;
+            for (int t = 0; t < val_tiles<L>(l3); ++t) {
+                if (pi.l1 == 0) {
+                    for (int c = 0; c < kc; c += 2) {
+                        VItem it{};
+                        it.p = p; it.t = t; it.na = 2; it.merge = true; it.group_end = -1;
+                        for (int a = 0; a < 2; ++a) { it.comp[a] = 0; it.bq[a] = park_slot<L>(0, 0, c + a); it.aslot[a] = slot + a; }
+                        it.first = c == 0; it.last = c + 2 >= kc; it.new_slots = 2;
+                        slot += 2;
+                        w.item[n++] = it;
+                    }
+                } else {
+                    for (int c = 0; c < kc; ++c) {
+                        for (int i0 = 0; i0 < d1; i0 += 3) {
+                            VItem it{};
+                            it.p = p; it.t = t; it.merge = false; it.group_end = -1;
+                            it.na = imin(3, d1 - i0);
+                            for (int a = 0; a < it.na; ++a) { it.comp[a] = i0 + a; it.bq[a] = park_slot<L>(pi.l1, i0 + a, c); it.aslot[a] = slot; }
+                            it.first = c == 0; it.last = c == kc - 1; it.new_slots = i0 == 0 ? 1 : 0;
+                            w.item[n++] = it;
+                        }
+                        slot += 1;
+                    }
+                }
+            }
+            last_of_group = n - 1;
+        }
+        if (last_of_group >= 0) w.item[last_of_group].group_end = l3;
+    }
+    w.n = n; w.n_slots = slot;
+    return w;
+}
+template <int L> inline constexpr ValWalk<L> kValWalk = make_val_walk<L>();
+template <int L> DEDF_HD constexpr int val_num_items() { return kValWalk<L>.n; }
+template <int L> DEDF_HD constexpr int val_num_slots() { return kValWalk<L>.n_slots; }
+template <int L> DEDF_HD constexpr VItem val_item(int I) { return I >= 0 && I < kValWalk<L>.n ? kValWalk<L>.item[I] : VItem{}; }
+// output degree of the path A slot S belongs to (operands of 16-row blocks are fetched by half the lanes)
+template <int L> DEDF_HD constexpr int val_slot_l3(int S) {
+    for (int i = 0; i < kValWalk<L>.n; ++i)
+        for (int a = 0; a < kValWalk<L>.item[i].na; ++a)
+            if (kValWalk<L>.item[i].aslot[a] == S) return dtp_path<L>(kValWalk<L>.item[i].p).l3;
+    return 0;
+}
+// item I completes the first contraction into its output degree (l3 >= 1: the value accumulators start from zero there)
+template <int L> DEDF_HD constexpr bool val_item_opens_group(int I) {
+    const int l3 = dtp_path<L>(kValWalk<L>.item[I].p).l3;
+    for (int i = 0; i < I; ++i)
+        if (kValWalk<L>.item[i].last && dtp_path<L>(kValWalk<L>.item[i].p).l3 == l3) return false;
+    return kValWalk<L>.item[I].last;
+}
+// first A slot that item I is the first to use (= slots consumed before it)
+template <int L> DEDF_HD constexpr int val_item_slot0(int I) {
+    int s = 0;
+    for (int i = 0; i < I && i < kValWalk<L>.n; ++i) s += kValWalk<L>.item[i].new_slots;
+    return s;
+}
+
 // ---- score tensor products: in1 = rotated query feature, in2 = field, outputs l3 in {0, 1} ------------------------
 template <int L> DEDF_HD constexpr int stp_num_paths() {
     int n = 0;

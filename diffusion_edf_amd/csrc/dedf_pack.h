@@ -165,6 +165,45 @@ inline std::vector<float> pack_dtp_stream(int nt0, const int* rows, WAt W) {
     return out;
 }
 
+// Split-fp16 A-operand stream of the attention-value GEMMs in output-side form (dedf_net.h::make_val_walk): one slot per
+// (path, output tile, K-chunk) in the order the items first use them; same slot format as pack_dtp_stream.  The K index of
+// element (h = lane >> 5, j) is channel 16 c + rowmap(j, h) of the path's input block: the order in which the gated features were
+// parked (8 consecutive accumulator registers of each half-wave).
+//   W(p, o, u) -> weight from input channel u of path p to output row o of the l3 block
+template <int L, class WAt>
+inline std::vector<float> pack_val_stream(WAt W) {
+    std::vector<uint16_t> img((size_t)val_num_slots<L>() * 1024, 0);
+    auto put = [&](size_t half_idx, float w) {
+        const _Float16 hh = (_Float16)w;
+        __builtin_memcpy(&img[half_idx], &hh, 2);
+        return (float)hh;
+    };
+    std::vector<char> done(val_num_slots<L>(), 0);
+    for (int I = 0; I < val_num_items<L>(); ++I) {
+        const VItem it = val_item<L>(I);
+        const PathInfo pi = dtp_path<L>(it.p);
+        for (int a = 0; a < it.na; ++a) {
+            const int slot = it.aslot[a];
+            if (done[slot]) continue;
+            done[slot] = 1;
+            // chunk of this accumulator: recover it from the parked slot index
+            const int c = it.bq[a] - park_slot<L>(pi.l1, it.comp[a], 0);
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int o = it.t * 32 + (lane & 31), u = 16 * c + rowmap(j, lane >> 5);
+                    if (o >= mul_of(pi.l3)) continue;
+                    const float w = W(it.p, o, u);
+                    const size_t hi_idx = (size_t)slot * 1024 + (size_t)lane * 8 + j;
+                    const float h = put(hi_idx, w);
+                    put(hi_idx + 512, w - h);
+                }
+        }
+    }
+    std::vector<float> out(img.size() / 2);
+    __builtin_memcpy(out.data(), img.data(), img.size() * 2);
+    return out;
+}
+
 template <int L>
 inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, Image& im, EdgeOffsets& o) {
     const std::string ktf = "key_tensor_field", blk = ktf + ".gnn_block_init", ga = blk + ".ga", rad = ga + ".sep_act.dtp_rad.";
@@ -283,7 +322,10 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
         }
         o.u_scale = std::ldexp(1.0f, su);
         o.o_S_lin = im.push(pack_dtp_stream<L>(r0_tiles<L>(), lrows, [&](int l, int oo, int k) { return std::ldexp(lin_w(l, oo, k), sl[l]); }));
-        o.o_S_val = im.push(pack_dtp_stream<L>(mul_of(0) / 32, vrows, [&](int l, int oo, int k) { return std::ldexp(val_w(l, oo, k), sv[l]); }));
+        o.o_S_val = im.push(pack_val_stream<L>([&](int p, int oo, int u) {
+            const PathInfo pi = dtp_path<L>(p);
+            return std::ldexp(val_w(pi.l3, oo, pi.kofs + u), sv[pi.l3]);
+        }));
         {
             const float* lb = S.get(B, ga + ".sep_act.lin.bias.0");
             const float* ab = S.get(B, ga + ".sep_alpha.bias.0");

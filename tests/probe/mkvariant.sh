@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build a variant of libdedf.so in which kernel unit 0 (k_edge<2,128,false>, the headline instantiation) is compiled with extra flags:
+#   bash tests/probe/mkvariant.sh <name> [extra hipcc flags...]   ->  diffusion_edf_amd/csrc/libdedf_<name>.so
+# The other units are taken from the last regular build (diffusion_edf_amd/csrc/_obj); with API=1 in the environment the API object
+# is rebuilt with the same extra flags too (needed for -DDEDF_PHASE_PROF).
+set -e
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+C=$ROOT/diffusion_edf_amd/csrc
+NAME=$1; shift
+F="--offload-arch=gfx950 -O3 -std=c++20 -fPIC -fno-slp-vectorize"
+hipcc $F -c -DDEDF_KUNIT=0 "$@" $C/dedf_kernels.hip -o $C/_obj/k0_$NAME.o &
+APIO=$C/_obj/api.o
+if [ -n "$API" ]; then APIO=$C/_obj/api_$NAME.o; hipcc $F -c "$@" $C/dedf_api.hip -o $APIO & fi
+wait
+OBJS="$APIO $C/_obj/k0_$NAME.o"
+for u in 1 2 3 4 5 6 7 8 9; do OBJS="$OBJS $C/_obj/k$u.o"; done
+hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $C/libdedf_$NAME.so
+echo built $C/libdedf_$NAME.so
