@@ -189,8 +189,26 @@ DEDF_DEV f32x16 mfma_h(h8 a, h8 b, f32x16 c) {
 // The hi half is made opaque before the residual is formed: hipcc otherwise re-derives fp16(x) a second way for the
 // subtraction (v_fma_mix*_f16 beside v_cvt_pk_f16_f32) and the two do not always round alike, which breaks hi + lo == x
 // by an fp16 ulp (seen as 1e-3-level errors that came and went with unrelated code changes).
+#ifndef DEDF_SPLIT_MIX
+#define DEDF_SPLIT_MIX 1
+#endif
 DEDF_DEV HL split8(const float (&x)[8]) {
     HL r;
+#if defined(__HIP_DEVICE_COMPILE__) && DEDF_SPLIT_MIX
+    // per pair of values: one v_cvt_pk_f16_f32 (hi halves), then v_fma_mixlo_f16 / v_fma_mixhi_f16 form fp16(x - hi) directly from
+    // the packed hi halves (the mixed-precision FMA converts the fp16 source on the fly; x - hi is exact in fp32, one rounding):
+    // 3 instructions per pair instead of 6 (v_cvt_pk, 2 v_cvt_f32_f16, 2 v_sub, v_cvt_pk), bit-identical halves
+    unsigned hp[4], lp[4];
+#define DEDF_SPLIT_PAIR(Q)                                                                          \
+    asm volatile("v_cvt_pk_f16_f32 %0, %2, %3\n\t"                                                   \
+                 "v_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"             \
+                 "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"                 \
+                 : "=&v"(hp[Q]), "=&v"(lp[Q]) : "v"(x[2 * Q]), "v"(x[2 * Q + 1]))
+    DEDF_SPLIT_PAIR(0); DEDF_SPLIT_PAIR(1); DEDF_SPLIT_PAIR(2); DEDF_SPLIT_PAIR(3);
+#undef DEDF_SPLIT_PAIR
+    r.hi = __builtin_bit_cast(h8, u32x4{hp[0], hp[1], hp[2], hp[3]});
+    r.lo = __builtin_bit_cast(h8, u32x4{lp[0], lp[1], lp[2], lp[3]});
+#else
     static_for<8>([&]<int J>() { r.hi[J] = (_Float16)x[J]; });
 #if defined(__HIP_DEVICE_COMPILE__)
     f32x4 hb = __builtin_bit_cast(f32x4, r.hi);
@@ -198,6 +216,7 @@ DEDF_DEV HL split8(const float (&x)[8]) {
     r.hi = __builtin_bit_cast(h8, hb);
 #endif
     static_for<8>([&]<int J>() { r.lo[J] = (_Float16)(x[J] - (float)r.hi[J]); });
+#endif
     return r;
 }
 
@@ -230,15 +249,22 @@ DEDF_DEV int tie(int v, float dep) {
 // Dense layer on split-fp16 MFMAs, NTO output tiles rotated, A images [To][chunk][lane][8 halves] (hi at off_h, lo at off_l),
 // operands requested PD chunks ahead.   bsrc.operator()<chunk, j>() -> fp32 value of element j of the chunk (8 registers).
 // HP (half-precision mode, the reference's `half_precision`): only the hi*hi term -- one MFMA and one operand image per product.
-template <int NTO, int NCH, int PD = 2, bool HP = false, class BsrcF>
-DEDF_DEV void dense_rot_h(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[NTO], BsrcF&& bsrc) {
-    f32x4 rh[PD][NTO], rl[PD][NTO] = {};
-    sched_fence();
+// The first PD chunks' operands can be requested ahead of time (dense_prefetch, e.g. before the previous layer's activation math):
+// with one wave per SIMD nothing else hides the latency of the first requests of a layer.
+template <int NTO, int PD> struct DenseRing { f32x4 h[PD][NTO], l[PD][NTO]; };
+template <int NTO, int NCH, int PD = 2, bool HP = false>
+DEDF_DEV DenseRing<NTO, PD> dense_prefetch(const Wave& wv, int off_h, int off_l) {
+    DenseRing<NTO, PD> r{};
     static_for<PD>([&]<int k>() { if constexpr (k < NCH) static_for<NTO>([&]<int To>() {
-        rh[k][To] = lda(wv, off_h, NCH, To, k); if constexpr (!HP) rl[k][To] = lda(wv, off_l, NCH, To, k); }); });
+        r.h[k][To] = lda(wv, off_h, NCH, To, k); if constexpr (!HP) r.l[k][To] = lda(wv, off_l, NCH, To, k); }); });
+    return r;
+}
+template <int NTO, int NCH, int PD = 2, bool HP = false, class BsrcF>
+DEDF_DEV void dense_rot_h(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[NTO], BsrcF&& bsrc, DenseRing<NTO, PD> ring) {
+    sched_fence();
     static_for<NCH>([&]<int c>() {
         f32x4 ch[NTO], cl[NTO];
-        static_for<NTO>([&]<int To>() { ch[To] = rh[c % PD][To]; cl[To] = rl[c % PD][To]; });
+        static_for<NTO>([&]<int To>() { ch[To] = ring.h[c % PD][To]; cl[To] = ring.l[c % PD][To]; });
         sched_fence();
         float t[8];
         static_for<8>([&]<int J>() { t[J] = bsrc.template operator()<c, J>(); });
@@ -246,8 +272,8 @@ DEDF_DEV void dense_rot_h(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[NT
         if constexpr (c + PD < NCH) {
             const int lv = tie(wv.lane16, __builtin_bit_cast(f32x4, b.hi)[0]);
             static_for<NTO>([&]<int To>() {
-                rh[c % PD][To] = bld4(wv.w, lv, (off_h + (To * NCH + c + PD) * 256) * 4);
-                if constexpr (!HP) rl[c % PD][To] = bld4(wv.w, lv, (off_l + (To * NCH + c + PD) * 256) * 4);
+                ring.h[c % PD][To] = bld4(wv.w, lv, (off_h + (To * NCH + c + PD) * 256) * 4);
+                if constexpr (!HP) ring.l[c % PD][To] = bld4(wv.w, lv, (off_l + (To * NCH + c + PD) * 256) * 4);
             });
         }
         static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, ch[To]), b.hi, acc[To]); });
@@ -257,6 +283,11 @@ DEDF_DEV void dense_rot_h(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[NT
         }
         sched_fence();
     });
+}
+template <int NTO, int NCH, int PD = 2, bool HP = false, class BsrcF>
+DEDF_DEV void dense_rot_h(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[NTO], BsrcF&& bsrc) {
+    sched_fence();
+    dense_rot_h<NTO, NCH, PD, HP>(wv, off_h, off_l, acc, static_cast<BsrcF&&>(bsrc), dense_prefetch<NTO, NCH, PD, HP>(wv, off_h, off_l));
 }
 
 DEDF_DEV HL split8(const float (&x)[8], float scale) {
@@ -399,6 +430,25 @@ DEDF_DEV float fexp(float x) {
 }
 DEDF_DEV float sigmoidf(float x) { return rcp(1.0f + fexp(-x)); }
 DEDF_DEV float siluf(float x) { return x * sigmoidf(x); }
+// Staged forms over N independent values: every stage is written across all values before the next one starts.  hipcc keeps the
+// source order of a fully unrolled body; written value by value the five dependent instructions of a sigmoid (v_mul, v_exp, v_add,
+// v_rcp, v_mul) issue back to back through one temporary and every one of them waits for its predecessor (plus the transcendental
+// wait states) -- with one wave per SIMD nothing else fills those slots.
+template <int N> DEDF_DEV void sigmoid_stage(const float (&x)[N], float (&s)[N]) {        // s = 1 / (1 + exp(-x))
+    static_for<N>([&]<int i>() { s[i] = x[i] * -1.44269504088896340736f; });
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_for<N>([&]<int i>() { s[i] = __builtin_amdgcn_exp2f(s[i]); });
+#else
+    static_for<N>([&]<int i>() { s[i] = exp2f(s[i]); });
+#endif
+    static_for<N>([&]<int i>() { s[i] = 1.0f + s[i]; });
+    static_for<N>([&]<int i>() { s[i] = rcp(s[i]); });
+}
+template <int N> DEDF_DEV void silu_stage(float (&x)[N]) {                                // x <- x * sigmoid(x)
+    float s[N];
+    sigmoid_stage<N>(x, s);
+    static_for<N>([&]<int i>() { x[i] = x[i] * s[i]; });
+}
 // normalize2mom-wrapped activations (reference equiformer/fast_activation.py:69)
 DEDF_DEV float silu_n(float x) { return siluf(x) * kNormSilu; }
 DEDF_DEV float sigmoid_n(float x) { return sigmoidf(x) * kNormSigmoid; }

@@ -105,7 +105,10 @@ DEDF_DEV void ln_silu(f32x16 (&x)[NT], const Wave& wv, const float* rows, int o_
     const float rstd = 1.0f / sqrtf(v * (1.0f / (NT * 32)) + 1e-5f);
     static_for<NT>([&]<int T>() {
         const f32x16 g = ldrows_lds(rows, wv.hi, o_gamma, T), b = ldrows_lds(rows, wv.hi, o_beta, T);
-        static_for<16>([&]<int R>() { x[T][R] = siluf((x[T][R] - mean) * rstd * g[R] + b[R]); });
+        float y[16];
+        static_for<16>([&]<int R>() { y[R] = (x[T][R] - mean) * rstd * g[R] + b[R]; });
+        silu_stage<16>(y);
+        static_for<16>([&]<int R>() { x[T][R] = y[R]; });
     });
 }
 
@@ -229,6 +232,19 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     const int src = P.edge_src[e], dst = P.edge_dst[e];
     const int pose = dst / P.nQ;
 
+    // operands of the edge pre-linear (first K-chunks) and its per-pose bias rows: requested before the geometry / length-encoding
+    // VALU work, which hides their latency
+    constexpr int NH = F0 / 32;      // pre-linear width: 128 (length + time embedding) or 64 (EBM critic: length only)
+    f32x16 h[NH];
+    const int oA_pre = opaque_s(P.o_A_pre + scale * (NH * 4 * 256)), oAl_pre = opaque_s(P.o_A_pre_l + scale * (NH * 4 * 256));
+    {
+        const Buf tbb = make_buf(P.tb, P.tb_bytes);
+        const int tvoff = (pose * P.tb_pose_stride) * 4 + wv.hi64;
+        static_for<NH>([&]<int To>() { h[To] = ldrows(tbb, tvoff, scale * F0, To); });
+    }
+    auto ring_pre = dense_prefetch<NH, 4, 2, HP>(wv, oA_pre, oAl_pre);
+    sched_fence();
+
     // ---- geometry (graph_parser.py:159-215) ---------------------------------------------------------------------
     const float vx = P.key_x[3 * src + 0] - P.qpos[3 * dst + 0];
     const float vy = P.key_x[3 * src + 1] - P.qpos[3 * dst + 1];
@@ -265,12 +281,21 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         const f32x4* const enc = reinterpret_cast<const f32x4*>(rows + RL::enc);       // this scale's constants (edge_enc_to_lds)
         if (radius > 0.0f) {           // GaussianRadialBasis, radial_func.py:208-227
             const float t = len / radius;
-            static_for<8>([&]<int G>() {
-                const f32x4 mu = enc[hi * 8 + G], is = enc[16 + hi * 8 + G], w = enc[32 + hi * 8 + G];
-                static_for<4>([&]<int J>() {
-                    const float z = (t - mu[J]) * is[J];
-                    eb[4 * G + J] = fexp(-0.5f * (z * z)) * w[J];
+            static_for<2>([&]<int Hf>() {      // 16 channels at a time, stage by stage (see sigmoid_stage)
+                float z[16], wv16[16];
+                static_for<4>([&]<int G4>() {
+                    constexpr int G = 4 * Hf + G4;
+                    const f32x4 mu = enc[hi * 8 + G], is = enc[16 + hi * 8 + G], w = enc[32 + hi * 8 + G];
+                    static_for<4>([&]<int J>() { z[4 * G4 + J] = (t - mu[J]) * is[J]; wv16[4 * G4 + J] = w[J]; });
                 });
+                static_for<16>([&]<int i>() { z[i] = -0.5f * (z[i] * z[i]); });
+                static_for<16>([&]<int i>() { z[i] = z[i] * 1.44269504088896340736f; });
+#if defined(__HIP_DEVICE_COMPILE__)
+                static_for<16>([&]<int i>() { z[i] = __builtin_amdgcn_exp2f(z[i]); });
+#else
+                static_for<16>([&]<int i>() { z[i] = exp2f(z[i]); });
+#endif
+                static_for<16>([&]<int i>() { eb[16 * Hf + i] = z[i] * wv16[i]; });
             });
         } else {                       // SinusoidalPositionEmbeddings(n = 1000), radial_func.py:305-316
             const float x = len / P.len_enc_max_r * 1000.0f;
@@ -283,33 +308,33 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
 
     DEDF_STAMP(0);
     // ---- edge pre-linear + SiLU (multiscale_tensor_field.py:225-234); time part + bias arrive as per-pose rows --------
-    constexpr int NH = F0 / 32;      // pre-linear width: 128 (length + time embedding) or 64 (EBM critic: length only)
-    f32x16 h[NH];
-    {
-        const Buf tbb = make_buf(P.tb, P.tb_bytes);
-        const int tvoff = (pose * P.tb_pose_stride) * 4 + wv.hi64;
-        const int oA = opaque_s(P.o_A_pre + scale * (NH * 4 * 256)), oAl = opaque_s(P.o_A_pre_l + scale * (NH * 4 * 256));
-        static_for<NH>([&]<int To>() { h[To] = ldrows(tbb, tvoff, scale * F0, To); });
-        dense_rot_h<NH, 4, 2, HP>(wv, oA, oAl, h, [&]<int c, int j>() { return eb[8 * c + j]; });
-        static_for<NH>([&]<int To>() { to_vgpr(h[To]); static_for<16>([&]<int R>() { h[To][R] = siluf(h[To][R]); }); });
-    }
+    constexpr int NT1 = H1 / 32, NT2 = H2 / 32;
+    dense_rot_h<NH, 4, 2, HP>(wv, oA_pre, oAl_pre, h, [&]<int c, int j>() { return eb[8 * c + j]; }, ring_pre);
+    auto ring_r1 = dense_prefetch<NT1, F0 / 16, 2, HP>(wv, o_A_r1, o_A_r1_l);      // layer 1's first operands: under the SiLU below
+    sched_fence();
+    static_for<NH>([&]<int To>() {
+        to_vgpr(h[To]);
+        float y[16];
+        static_for<16>([&]<int R>() { y[R] = h[To][R]; });
+        silu_stage<16>(y);
+        static_for<16>([&]<int R>() { h[To][R] = y[R]; });
+    });
     DEDF_STAMP(1);
     // ---- RadialProfile layers 1, 2 (equiformer/radial_func.py:11-60) ---------------------------------------------------
-    constexpr int NT1 = H1 / 32, NT2 = H2 / 32;
     f32x16 r1[NT1];
     static_for<NT1>([&]<int To>() { r1[To] = ldrows_lds(rows, hi, RL::b1, To); });
-    dense_rot_h<NT1, F0 / 16, 2, HP>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return h[c / 2][8 * (c % 2) + j]; });
+    dense_rot_h<NT1, F0 / 16, 2, HP>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return h[c / 2][8 * (c % 2) + j]; }, ring_r1);
     DEDF_STAMP(2);
+    auto ring_r2 = dense_prefetch<NT2, H1 / 16, 2, HP>(wv, o_A_r2, o_A_r2_l);      // layer 2's first operands: under the LayerNorm below
+    sched_fence();
     static_for<NT1>([&]<int To>() { to_vgpr(r1[To]); });
     ln_silu<NT1>(r1, wv, rows, RL::g1, RL::be1);
     DEDF_STAMP(3);
     f32x16 r2[NT2];
     static_for<NT2>([&]<int To>() { r2[To] = ldrows_lds(rows, hi, RL::b2, To); });
-    dense_rot_h<NT2, H1 / 16, 2, HP>(wv, o_A_r2, o_A_r2_l, r2, [&]<int c, int j>() { return r1[c / 2][8 * (c % 2) + j]; });
+    dense_rot_h<NT2, H1 / 16, 2, HP>(wv, o_A_r2, o_A_r2_l, r2, [&]<int c, int j>() { return r1[c / 2][8 * (c % 2) + j]; }, ring_r2);
     DEDF_STAMP(4);
-    static_for<NT2>([&]<int To>() { to_vgpr(r2[To]); });
-    ln_silu<NT2>(r2, wv, rows, RL::g2, RL::be2);
-    DEDF_STAMP(5);
+    // (layer 2's LayerNorm + SiLU run in the prologue of the next stage, under its first operand requests)
 
     // ---- layer 3 (-> per-edge TP weights, one 32-row tile at a time) fused with DTP #1 and the lin / sep_alpha GEMMs ----
     // Chunks are walked grouped by output degree (dedf_net.h::dtp_pos_chunk): first all l3 = 0 chunks into acc0 (NR0 tiles:
@@ -379,12 +404,6 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // A operands (hi and lo image) form one global stream over all tiles.
     constexpr int KC = H2 / 16;
     HL r2s[KC];
-    static_for<KC>([&]<int c>() {
-        float t[8];
-        static_for<8>([&]<int J>() { t[J] = r2[c / 2][8 * (c % 2) + J]; });
-        r2s[c] = split8(t);
-    });
-    static_for<NR0>([&]<int T>() { acc0[T] = ldrows_lds(rows, hi, RL::b0, T); });      // accumulator init: lin / sep_alpha biases
     // Layer-3 work unit = half a weight tile (2 of the 4 K-chunks, 6 MFMAs).  Half P = 2 T + half of tile T runs in pipeline
     // region P - 3 into wbuf[T % 2]; its operands (and the tile's offset rows, the accumulator init) are requested one region
     // earlier, across a scheduling fence, so that the request cannot sink next to its use.  With the 32-wide MLP a tile has
@@ -431,20 +450,40 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 constexpr int T = AT + (hd >> 1), r0 = 8 * (hd & 1);
                 const f32x4* adp = reinterpret_cast<const f32x4*>(rows + RL::adot + (hd >> 1) * 32 + hi * 16 + r0);
                 const f32x4 d0 = adp[0], d1v = adp[1];
+                // SmoothLeakyReLU(0.2) x normalize2mom (dedf_dev.h::slrelu_n), eight values stage by stage
+                float x8[8], s8[8];
+                static_for<8>([&]<int R>() { x8[R] = acc0[T][r0 + R] * cl0; });
+                sigmoid_stage<8>(x8, s8);
                 float sum = 0.0f;
-                static_for<4>([&]<int R>() { sum += slrelu_n(acc0[T][r0 + R] * cl0) * d0[R]; });
-                static_for<4>([&]<int R>() { sum += slrelu_n(acc0[T][r0 + 4 + R] * cl0) * d1v[R]; });
+                static_for<8>([&]<int R>() {
+                    const float v = (0.6f * x8[R] + 0.4f * x8[R] * (2.0f * s8[R] - 1.0f)) * kNormSlrelu;
+                    sum += v * (R < 4 ? d0[R & 3] : d1v[R & 3]);
+                });
                 sum += xor32(sum);
                 logit[hd] = sum + logit0;
             });
             // Gate (fast_activation.py:210-224): SiLU on the 64 scalars, sigmoid gates for the l >= 1 channels
             static_for<2>([&]<int T>() { static_for<2>([&]<int hf>() {
                 float v[8];
-                static_for<8>([&]<int J>() { v[J] = silu_n(acc0[T][8 * hf + J] * cl0) * us; });
+                static_for<8>([&]<int J>() { v[J] = acc0[T][8 * hf + J] * cl0; });
+                silu_stage<8>(v);
+                static_for<8>([&]<int J>() { v[J] = v[J] * (kNormSilu * us); });
                 park_chunk.template operator()<park_slot<L>(0, 0, 2 * T + hf)>(v);
             }); });
-            if constexpr (L >= 1) { constexpr int G0 = gate_row(1, 0); static_for<16>([&]<int R>() { g1[R] = sigmoid_n(acc0[G0 / 32][(G0 % 32) / 2 + R] * cl0) * (cl1 * us); }); }
-            if constexpr (L >= 2) { constexpr int G0 = gate_row(2, 0); static_for<8>([&]<int R>() { g2[R] = sigmoid_n(acc0[G0 / 32][(G0 % 32) / 2 + R] * cl0) * (cl2 * us); }); }
+            if constexpr (L >= 1) {
+                constexpr int G0 = gate_row(1, 0);
+                float x16[16];
+                static_for<16>([&]<int R>() { x16[R] = acc0[G0 / 32][(G0 % 32) / 2 + R] * cl0; });
+                sigmoid_stage<16>(x16, g1);
+                static_for<16>([&]<int R>() { g1[R] = g1[R] * (kNormSigmoid * (cl1 * us)); });
+            }
+            if constexpr (L >= 2) {
+                constexpr int G0 = gate_row(2, 0);
+                float x8[8];
+                static_for<8>([&]<int R>() { x8[R] = acc0[G0 / 32][(G0 % 32) / 2 + R] * cl0; });
+                sigmoid_stage<8>(x8, g2);
+                static_for<8>([&]<int R>() { g2[R] = g2[R] * (kNormSigmoid * (cl2 * us)); });
+            }
         } else if constexpr (l3 == 1) {
             static_for<3>([&]<int K>() { static_for<2>([&]<int hf>() {
                 float v[8];
@@ -475,6 +514,17 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         const XOps x0 = load_X.template operator()<0>();
         const L3Half p0 = load_l3.template operator()<0>(), p1 = load_l3.template operator()<1>(), p2 = load_l3.template operator()<2>();
         const f32x16 off0 = load_off.template operator()<0>(), off1 = load_off.template operator()<1>();
+        sched_fence();
+        // layer 2's LayerNorm + SiLU and the split of its output (B operands of layer 3), under the requests above
+        static_for<NT2>([&]<int To>() { to_vgpr(r2[To]); });
+        ln_silu<NT2>(r2, wv, rows, RL::g2, RL::be2);
+        DEDF_STAMP(5);
+        static_for<KC>([&]<int c>() {
+            float t[8];
+            static_for<8>([&]<int J>() { t[J] = r2[c / 2][8 * (c % 2) + J]; });
+            r2s[c] = split8(t);
+        });
+        static_for<NR0>([&]<int T>() { acc0[T] = ldrows_lds(rows, hi, RL::b0, T); });      // accumulator init: lin / sep_alpha biases
         sched_fence();
         l3n = load_l3.template operator()<3>();
         offn = load_off.template operator()<2>();
