@@ -9,8 +9,8 @@ Mirrors, for everything that touches the score head (same names, argument meanin
   reference diffusion_edf/agent.py:20-64                      -> ``get_models``
   reference diffusion_edf/agent.py:66-186                     -> ``DiffusionEdfAgent`` (``compute_critic_energy``, ``sample``)
 
-What is NOT here: the UNet / keypoint feature extractors and ``edf_interface`` (PointCloud, SE3, the
-pre-processing pipeline).  They are *injected*: every model takes a ``key_extractor`` and a ``query_extractor`` — any callable
+What is NOT here: the UNet / keypoint feature extractors and ``edf_interface`` (PointCloud, SE3 types; the
+pre-processing steps its YAML names are in ``preprocess.py``, the task-level files agent.yaml / server.yaml in ``configs.py``).  They are *injected*: every model takes a ``key_extractor`` and a ``query_extractor`` — any callable
 ``FeaturedPoints -> List[FeaturedPoints]`` / ``FeaturedPoints -> FeaturedPoints`` with an ``irreps_output`` attribute, e.g. the
 reference's own modules running in PyTorch, or ``PrecomputedFeatures`` below.  The one exception is ``StaticKeypointModel``
 (the query model of the pick_* configs): it holds parameters only and is built here.  Without them ``get_key_pcd_multiscale`` /
@@ -191,7 +191,15 @@ def get_models(configs_root_dir: str,
     model = model_cls(**cfgs['model']['model_kwargs'], deterministic=False, key_extractor=key_extractor, query_extractor=query_extractor)
     if checkpoint_dir is not None:                                                              # trainer.py:141-147
         checkpoint = torch.load(checkpoint_dir, map_location='cpu')
-        model.load_state_dict(checkpoint['score_model_state_dict'], strict=strict_load)
+        res = model.load_state_dict(checkpoint['score_model_state_dict'], strict=strict_load)
+        # strict_load=False (the reference's default, agent.py:28) tolerates missing / extra keys of the injected feature extractors.
+        # The score head is THIS build's product: a key of it that does not line up means the schema differs from the checkpoint's
+        # and the head would silently run on its seeded init -- never acceptable.
+        bad = [k for k in list(res.missing_keys) + list(res.unexpected_keys) if k.startswith('score_head.')]
+        if bad:
+            raise RuntimeError(f"checkpoint {checkpoint_dir}: score_head parameters do not match the schema of this build: "
+                               f"missing {[k for k in res.missing_keys if k.startswith('score_head.')][:8]}, "
+                               f"unexpected {[k for k in res.unexpected_keys if k.startswith('score_head.')][:8]}")
         print(f"Successfully Loaded checkpoint @ epoch: {checkpoint['epoch']} (steps: {checkpoint['steps']})")
     model = model.to(device).eval()
     model.diffusion_schedules = cfgs['train']['diffusion_configs']['time_schedules']
@@ -222,9 +230,16 @@ class DiffusionEdfAgent():
                  models: Optional[List[ScoreModelBase]] = None,
                  critic: Optional[ScoreModelBase] = None,
                  proc_fn: Optional[Callable] = None,
-                 unprocess_fn: Optional[Callable] = None):
-        if preprocess_config or unprocess_config:
-            raise NotImplementedError("edf_interface pre-processing is not part of this build: pass proc_fn / unprocess_fn")
+                 unprocess_fn: Optional[Callable] = None,
+                 proc_registry: Optional[Dict[str, Callable]] = None):
+        # reference agent.py:79-80: proc_fn = compose_proc_fn(preprocess_config).  The procs the shipped preprocess.yaml files name
+        # (downsample, rescale; crop_bbox) are in preprocess.py; ``proc_registry`` adds / overrides names, explicit ``proc_fn`` /
+        # ``unprocess_fn`` callables win over the configs.
+        from .preprocess import compose_proc_fn
+        if proc_fn is None and preprocess_config:
+            proc_fn = compose_proc_fn(preprocess_config, proc_registry)
+        if unprocess_fn is None and unprocess_config:
+            unprocess_fn = compose_proc_fn(unprocess_config, proc_registry)
         if critic is not None:
             self.critic = critic
         elif critic_kwargs is not None:
@@ -269,9 +284,11 @@ class DiffusionEdfAgent():
         if noise_list is None:
             noise_list = [None for _ in range(len(self.models))]
 
-        scene_pcd = self.proc_fn(scene_pcd)
-        grasp_pcd = self.proc_fn(grasp_pcd)
-        Ts_init = self.proc_fn(Ts_init)
+        # (composed pipelines are told which input they see: crop_bbox of the sapien task files targets the scene cloud only)
+        with_role = getattr(self.proc_fn, "accepts_role", False)
+        scene_pcd = self.proc_fn(scene_pcd, role="scene_pcd") if with_role else self.proc_fn(scene_pcd)
+        grasp_pcd = self.proc_fn(grasp_pcd, role="grasp_pcd") if with_role else self.proc_fn(grasp_pcd)
+        Ts_init = self.proc_fn(Ts_init, role="poses") if with_role else self.proc_fn(Ts_init)
         scene_input, grasp_input = scene_pcd, grasp_pcd
         T0: torch.Tensor = Ts_init.poses if hasattr(Ts_init, 'poses') else Ts_init
         assert T0.ndim == 2 and T0.shape[-1] == 7, f"{T0.shape}"

@@ -1,5 +1,5 @@
 """Point-cloud pre-processing named by the reference's ``preprocess.yaml`` files (``configs/*/preprocess.yaml``:
-``downsample`` → ``rescale``; ``crop_bbox`` is present but commented out in every shipped file).
+``[crop_bbox →] downsample → rescale``; the two sapien task files crop the scene cloud, the panda files have the crop commented out).
 
 The reference composes them from ``edf_interface.data.preprocess`` (``train_utils.py:24-31``), an un-vendored submodule that
 is absent from the reference tree — semantics restated from the YAML comments (metres → centimetres, voxel size in metres,
@@ -37,10 +37,11 @@ def rescale(obj, rescale_factor: float):
     return obj
 
 
-def crop_bbox(obj, bbox: Sequence[Sequence[float]], targets: Optional[Sequence[str]] = None):
-    """keep the points inside ``[[x0,x1],[y0,y1],[z0,z1]]``.  ``targets`` (names of demo fields in the reference) is accepted and
-    ignored: the caller decides which cloud it passes."""
-    if not isinstance(obj, FeaturedPoints):
+def crop_bbox(obj, bbox: Sequence[Sequence[float]], targets: Optional[Sequence[str]] = None, role: Optional[str] = None):
+    """keep the points inside ``[[x0,x1],[y0,y1],[z0,z1]]``.  ``targets`` names the inputs the crop applies to (the sapien task
+    files crop ``['scene_pcd']`` only); ``role`` is what the caller says the object is (``'scene_pcd'``, ``'grasp_pcd'``,
+    ``'poses'``) -- with ``targets`` given and a role outside it, the object passes through; without a role the crop applies."""
+    if not isinstance(obj, FeaturedPoints) or (targets is not None and role is not None and role not in targets):
         return obj
     lo = torch.tensor([b[0] for b in bbox], dtype=obj.x.dtype, device=obj.x.device)
     hi = torch.tensor([b[1] for b in bbox], dtype=obj.x.dtype, device=obj.x.device)
@@ -79,15 +80,18 @@ def compose_proc_fn(preprocess_config: Optional[List[Dict[str, Any]]], registry:
     applies the procs in order.  Unknown names raise ``AttributeError`` like the reference's ``getattr(preprocess, name)``."""
     reg = dict(PROCS)
     reg.update(registry or {})
+    import inspect
     steps = []
     for proc in preprocess_config or []:
         if proc["name"] not in reg:
             raise AttributeError(f"unknown preprocess step '{proc['name']}' (known: {sorted(reg)})")
-        steps.append(partial(reg[proc["name"]], **(proc.get("kwargs") or {})))
+        fn = reg[proc["name"]]
+        steps.append((partial(fn, **(proc.get("kwargs") or {})), "role" in inspect.signature(fn).parameters))
 
-    def proc_fn(obj):
-        for step in steps:
-            obj = step(obj)
+    def proc_fn(obj, role: Optional[str] = None):
+        for step, takes_role in steps:
+            obj = step(obj, role=role) if takes_role else step(obj)
         return obj
 
+    proc_fn.accepts_role = True
     return proc_fn

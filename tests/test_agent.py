@@ -11,6 +11,7 @@ import yaml
 
 from diffusion_edf_amd import agent as A
 from diffusion_edf_amd import params, synthetic
+from diffusion_edf_amd.gnn_data import FeaturedPoints
 
 CFG_ROOT = "/root/reference/configs"
 DIRS = sorted(os.path.dirname(f) for f in glob.glob(os.path.join(CFG_ROOT, "*", "*", "score_model_configs.yaml")))
@@ -95,6 +96,15 @@ def test_checkpoint_load_like_the_reference_agent(tmp_path):
     torch.save(dict(score_model_state_dict={k: v for k, v in sd.items() if k.startswith("score_head.")}, epoch=1, steps=1), ck)
     with pytest.raises(RuntimeError, match="Missing key"):
         A.get_models(d, "train_configs.yaml", "task_configs.yaml", ck, "cpu", n_warmups=0, strict_load=True)
+    # strict_load=False forgives the extractors' keys, never the score head's: a head parameter the checkpoint lacks (or one it
+    # has and this build does not know) would leave the head on its seeded init without a word
+    with pytest.raises(RuntimeError, match="score_head parameters do not match"):
+        A.get_models(d, "train_configs.yaml", "task_configs.yaml", ck, "cpu", n_warmups=0)
+    sd2 = {"score_head." + k: v for k, v in P.items()}
+    sd2["score_head.some_renamed_block.weight"] = torch.zeros(4)
+    torch.save(dict(score_model_state_dict=sd2, epoch=1, steps=1), ck)
+    with pytest.raises(RuntimeError, match="score_head parameters do not match"):
+        A.get_models(d, "train_configs.yaml", "task_configs.yaml", ck, "cpu", n_warmups=0)
 
 
 def test_model_assembly_errors_match_reference():
@@ -127,5 +137,105 @@ def test_agent_sample_argument_contract():
         ag.sample(None, None, T, [[1], [1]], [[0.1], [0.1]], [1.0, 1.0, 1.0])
     with pytest.raises(AssertionError, match=r"torch.Size\(\[3, 6\]\)"):
         ag.sample(None, None, torch.zeros(3, 6), [[1], [1]], [[0.1], [0.1]], [1.0, 1.0])
-    with pytest.raises(NotImplementedError):
-        A.DiffusionEdfAgent(models=[], preprocess_config=[dict(name="downsample")])
+    with pytest.raises(AttributeError, match="unknown preprocess step"):          # the reference's getattr(preprocess, name) fails likewise
+        A.DiffusionEdfAgent(models=[], preprocess_config=[dict(name="no_such_proc", kwargs={})])
+
+
+# ---- task front-end: agent.yaml / server.yaml / preprocess.yaml ---------------------------------------------------------------
+
+def test_preprocess_procs_of_the_shipped_yaml():
+    """downsample (voxel average, metres) -> rescale (x100) as configs/*/preprocess.yaml lists them; poses only feel the rescale"""
+    from diffusion_edf_amd import preprocess as PP
+    x = torch.tensor([[0.001, 0.002, 0.003], [0.004, 0.006, 0.009], [0.011, 0.002, 0.003], [-0.004, 0.0, 0.0], [0.002, 0.001, 0.0]])
+    f = torch.arange(15, dtype=torch.float32).reshape(5, 3)
+    pcd = FeaturedPoints(x=x, f=f, b=torch.zeros(5, dtype=torch.long))
+    cfg = [dict(name="downsample", kwargs=dict(voxel_size=0.01, coord_reduction="average")), dict(name="rescale", kwargs=dict(rescale_factor=100.0))]
+    fn = PP.compose_proc_fn(cfg)
+    out = fn(pcd)
+    # voxels (ix,iy,iz): points 0,1,4 -> (0,0,0); point 2 -> (1,0,0); point 3 -> (-1,0,0); output sorted by voxel index
+    assert out.x.shape == (3, 3) and out.f.shape == (3, 3) and torch.equal(out.b, torch.zeros(3, dtype=torch.long))
+    assert torch.allclose(out.x[0], x[3] * 100) and torch.allclose(out.x[2], x[2] * 100)
+    assert torch.allclose(out.x[1], x[[0, 1, 4]].mean(0) * 100) and torch.allclose(out.f[1], f[[0, 1, 4]].mean(0))
+    T = torch.tensor([[1., 0, 0, 0, 0.1, 0.2, 0.3]])
+    assert torch.allclose(fn(T), torch.tensor([[1., 0, 0, 0, 10., 20., 30.]])) and torch.equal(T[0, 4:], torch.tensor([0.1, 0.2, 0.3]))
+    assert fn("anything else") == "anything else"
+    back = PP.compose_proc_fn([dict(name="rescale", kwargs=dict(rescale_factor=0.01))])
+    assert torch.allclose(back(fn(T)), T)
+    centre = PP.downsample(pcd, voxel_size=0.01, coord_reduction="center")
+    assert torch.allclose(centre.x, torch.tensor([[-0.005, 0.005, 0.005], [0.005, 0.005, 0.005], [0.015, 0.005, 0.005]]))
+    crop = PP.crop_bbox(pcd, bbox=[[0.0, 0.02], [0.0, 0.01], [0.0, 0.01]])
+    assert len(crop.x) == 4
+    # two clouds in one batch vector are downsampled separately
+    two = FeaturedPoints(x=torch.cat([x, x]), f=torch.cat([f, f]), b=torch.tensor([0] * 5 + [1] * 5))
+    assert torch.equal(PP.downsample(two, 0.01).b, torch.tensor([0, 0, 0, 1, 1, 1]))
+
+
+REF_CONFIGS = "/root/reference/configs"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CONFIGS), reason="reference tree not present")
+def test_task_front_end_reads_every_shipped_task_directory():
+    """agent.yaml / server.yaml / preprocess.yaml of all five shipped task directories (reference agent_server.py:48-86, 204-213)"""
+    from diffusion_edf_amd import configs as CF
+    dirs = CF.list_task_dirs(REF_CONFIGS)
+    assert [os.path.basename(d) for d in dirs] == ["panda_bottle", "panda_bowl", "panda_mug", "sapien", "sapien_bottle"]
+    for d in dirs:
+        tc = CF.TaskConfigs.load(d)
+        assert tc.root == "/root/reference" and tc.device == "cuda"
+        for task in CF.TASKS:
+            assert len(tc.models[task]) == 2                                            # low-res -> high-res cascade
+            for e in tc.models[task] + ([tc.critic[task]] if tc.critic[task] else []):
+                r = e.resolved(tc.root, "skip")
+                assert os.path.isfile(os.path.join(r["configs_root_dir"], r["train_configs_file"])) and r["checkpoint_dir"] is None
+                assert e.resolved(tc.root, "if_present")["checkpoint_dir"] is None        # every *.pt here is a git-LFS pointer
+            kw = tc.sample_kwargs(task)
+            assert len(kw["N_steps_list"]) == len(kw["timesteps_list"]) == len(kw["temperatures_list"]) == len(kw["diffusion_schedules_list"]) == 2
+            assert tc.n_denoising_steps(task) in (650, 900, 1000) or tc.n_denoising_steps(task) > 0
+        names = [p["name"] for p in tc.preprocess_config]
+        assert names == (["crop_bbox"] if "sapien" in d else []) + ["downsample", "rescale"] and tc.preprocess_config[-1]["kwargs"]["rescale_factor"] == 100.0
+        if "sapien" in d:                      # the crop targets the scene cloud only
+            from diffusion_edf_amd import preprocess as PP
+            fn = PP.compose_proc_fn(tc.preprocess_config)
+            far = FeaturedPoints(x=torch.tensor([[5.0, 5.0, 5.0], [0.0, 0.0, 0.9]]), f=torch.zeros(2, 3), b=torch.zeros(2, dtype=torch.long))
+            assert len(fn(far, role="scene_pcd").x) == 1 and len(fn(far, role="grasp_pcd").x) == 2
+        assert [p["name"] for p in tc.unprocess_config] == ["rescale"]
+    mug = CF.TaskConfigs.load(os.path.join(REF_CONFIGS, "panda_mug"))
+    assert mug.critic["pick"] is not None and mug.n_denoising_steps("pick") == 900       # 200+200 | 200+200+100 (server.yaml:2)
+    with pytest.raises(FileNotFoundError, match="git-LFS pointer"):
+        mug.models["pick"][0].resolved(mug.root, "require")
+    with pytest.raises(ValueError, match="Unknown task name"):
+        mug.sample_kwargs("push")
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CONFIGS), reason="reference tree not present")
+def test_task_front_end_builds_the_agent_of_the_notebook_call_sequence():
+    """configs/panda_mug -> DiffusionEdfAgent (two score models + critic built from the reference's own YAML, seeded init because the
+    checkpoints are LFS pointers), pre-processing composed from preprocess.yaml, and the server.yaml arguments accepted by `sample`
+    (the models are swapped for CPU stand-ins here: the heads themselves only run on the GPU)"""
+    from diffusion_edf_amd import configs as CF
+    tc = CF.TaskConfigs.load(os.path.join(REF_CONFIGS, "panda_mug"))
+    feats = A.PrecomputedFeatures(None, "64x0e+32x1e+16x2e")
+    ag = tc.build_agent("pick", extractors=[dict(key_extractor=feats), dict(key_extractor=feats)], critic_extractors=dict(key_extractor=feats),
+                        device="cpu", checkpoints="skip", n_warmups=0)
+    assert len(ag.models) == 2 and ag.critic is not None
+    assert [type(m).__name__ for m in ag.models] == ["MultiscaleScoreModel"] * 2 and ag.critic.score_head.cfg.ebm
+    assert ag.models[0].score_head.cfg.radii == [5.0, 10.0, 20.0, None] and ag.models[1].score_head.cfg.radii == [3.5, 5.0, 6.5, 8.0]
+    assert ag.models[0].diffusion_schedules == [[1.0, 0.15], [0.15, 0.01]] or len(ag.models[0].diffusion_schedules) >= 1
+    pcd = FeaturedPoints(x=torch.rand(200, 3) * 0.05, f=torch.rand(200, 3), b=torch.zeros(200, dtype=torch.long))
+    out = ag.proc_fn(pcd)
+    assert len(out.x) < 200 and float(out.x.max()) > 1.0                                  # voxel-downsampled, now in centimetres
+    assert torch.allclose(ag.unprocess_fn(ag.proc_fn(torch.tensor([[1., 0, 0, 0, 0.1, 0.2, 0.3]]))), torch.tensor([[1., 0, 0, 0, 0.1, 0.2, 0.3]]))
+
+    class Stage:                                   # stands in for ScoreModelBase.sample on CPU: one pose row per step
+        def __init__(self, m):
+            self.diffusion_schedules = m.diffusion_schedules
+        get_key_pcd_multiscale = staticmethod(lambda p: None)
+        get_query_pcd = staticmethod(lambda p: None)
+
+        def sample(self, T_seed=None, N_steps=None, **kw):
+            return T_seed[None].repeat(sum(N_steps) + 2, 1, 1)
+    ag.models = [Stage(m) for m in ag.models]
+    ag.critic = None
+    T0 = torch.tensor([[1., 0, 0, 0, 0.1, 0.2, 0.3]] * 3)
+    Ts, scene, grasp = ag.sample(pcd, pcd, T0, **tc.sample_kwargs("pick"))
+    assert Ts.shape == (400 + 2 + 500 + 2, 3, 7) and torch.allclose(Ts[-1, :, 4:], T0[:, 4:] * 100.0)
