@@ -67,7 +67,8 @@ struct dedf_handle {
     int n_cu = 256;
     // device: weights
     DevBuf d_edge_w, d_node_w, d_nat;     // d_nat: natural-layout weights for the small kernels
-    size_t nat_tw1 = 0, nat_tb1 = 0, nat_tw2 = 0, nat_tb2 = 0, nat_wpre = 0, nat_bpre = 0, nat_lnw = 0, nat_lnb = 0, nat_wsrc = 0, nat_bsrc = 0, nat_tfreq = 0, nat_brows = 0;
+    size_t nat_tw1 = 0, nat_tb1 = 0, nat_tw2 = 0, nat_tb2 = 0, nat_wpre = 0, nat_bpre = 0, nat_lnw = 0, nat_lnb = 0, nat_wsrc = 0, nat_bsrc = 0, nat_tfreq = 0, nat_brows = 0, nat_wdst = 0, nat_bdst = 0;
+    DevBuf d_msg_dst;
     // device: scene / query
     DevBuf d_key_x, d_key_f, d_msg, d_qx, d_qf, d_qw;
     int n_keys = 0, nQ = 0;
@@ -122,6 +123,15 @@ int fail(dedf_handle* h, int code, const std::string& msg) {
 
 int check_config(const dedf_config* c, std::string& why) {
     if (!c) { why = "null config"; return DEDF_ERR_INVALID; }
+    if (c->unet_layer) {       // one {radial, gnn} layer of the UNet feature extractor (unet_feature_extractor.py:141-202)
+        if (c->lmax != 2 || c->mul[0] != 64 || c->mul[1] != 32 || c->mul[2] != 16) { why = "UNet layer: irreps must be 64x0e+32x1e+16x2e (levels 2, 3 and the mid block of the shipped configs; the 32x0e+16x1e+8x2e levels are not instantiated)"; return DEDF_ERR_UNSUPPORTED; }
+        if (c->num_heads != kHeads) { why = "num_heads must be 4"; return DEDF_ERR_UNSUPPORTED; }
+        if (c->fc_neurons[0] != 64 || c->fc_neurons[1] != 32 || c->fc_neurons[2] != 32) { why = "UNet layer: fc_neurons must be [64, 32, 32]"; return DEDF_ERR_UNSUPPORTED; }
+        if (c->irreps_mlp_mid != kMlpMid) { why = "irreps_mlp_mid must be 3"; return DEDF_ERR_UNSUPPORTED; }
+        if (c->n_scales != 1 || !(c->radii[0] > 0)) { why = "UNet layer: n_scales = 1 and radii[0] = the level's connection radius"; return DEDF_ERR_INVALID; }
+        if (c->ebm || c->half_gemm || c->use_src_point_attn) { why = "UNet layer: ebm / half_gemm / use_src_point_attn do not apply"; return DEDF_ERR_UNSUPPORTED; }
+        return DEDF_OK;
+    }
     if (c->lmax != 1 && c->lmax != 2) { why = "lmax must be 1 or 2 (lmax 3 is a next-row item)"; return DEDF_ERR_UNSUPPORTED; }
     for (int l = 0; l <= c->lmax; ++l)
         if (c->mul[l] != mul_of(l)) { why = "irreps must be 64x0e+32x1e(+16x2e)"; return DEDF_ERR_UNSUPPORTED; }
@@ -172,6 +182,16 @@ int upload_weights(dedf_handle* h) {
     std::vector<float> nat;
     auto put = [&](const float* p, size_t n) { size_t o = nat.size(); nat.insert(nat.end(), p, p + n); return o; };
     const int ns = c.n_scales;
+    if (c.unet_layer) {        // linear_src (no bias) and linear_dst (+ bias), block.py:109-115
+        size_t sq = 0;
+        for (int l = 0; l <= h->L; ++l) sq += (size_t)mul_of(l) * mul_of(l);
+        h->nat_wsrc = put(S.get(B, "gnn.linear_src.tp.weight"), sq);
+        h->nat_wdst = put(S.get(B, "gnn.linear_dst.tp.weight"), sq);
+        h->nat_bdst = put(S.get(B, "gnn.linear_dst.bias.0"), mul_of(0));
+        if (!h->d_nat.ensure(nat.size() * 4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(nat) failed");
+        HIPCK(h, hipMemcpy(h->d_nat.p, nat.data(), nat.size() * 4, hipMemcpyHostToDevice));
+        return DEDF_OK;
+    }
     h->nat_tw1 = nat.size();
     const size_t tE = c.time_emb_mlp[0], tH = c.time_emb_mlp[1], tT = c.time_emb_mlp[2], F0 = c.fc_neurons[0];
     for (int n = 0; n < ns; ++n) put(S.get(B, "time_mlps_multiscale." + std::to_string(n) + ".0.weight"), tH * tE);
@@ -493,6 +513,7 @@ const char* dedf_last_error(const dedf_handle* h) { return h ? h->err.c_str() : 
 int dedf_set_key_clouds(dedf_handle* h, int n_scales, const int* n_pts, const float* const* x, const float* const* f, void* stream) {
     if (!h) return DEDF_ERR_INVALID;
     if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
+    if (h->cfg.unet_layer) return fail(h, DEDF_ERR_UNSUPPORTED, "UNet-layer handle: use dedf_layer_forward");
     if (n_scales != h->cfg.n_scales) return fail(h, DEDF_ERR_INVALID, "len(key_pcd_multiscale) != n_scales");
     hipStream_t st = static_cast<hipStream_t>(stream);
     DEDF_ON_DEVICE(h);
@@ -547,6 +568,7 @@ int dedf_set_key_weights(dedf_handle* h, int n_scales, const int* n_pts, const f
 int dedf_set_query(dedf_handle* h, int nQ, const float* x, const float* f, const float* w, void* stream) {
     if (!h) return DEDF_ERR_INVALID;
     if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
+    if (h->cfg.unet_layer) return fail(h, DEDF_ERR_UNSUPPORTED, "UNet-layer handle: use dedf_layer_forward");
     if (nQ <= 0 || !x || !f) return fail(h, DEDF_ERR_INVALID, "bad query cloud");
     if (!w) return fail(h, DEDF_ERR_INVALID, "query_pcd.w is required (score_head.py:156-157)");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -566,6 +588,7 @@ int dedf_set_query(dedf_handle* h, int nQ, const float* x, const float* f, const
 int dedf_score(dedf_handle* h, int nT, const float* Ts, const float* time, float* ang, float* lin, void* stream) {
     if (!h) return DEDF_ERR_INVALID;
     if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
+    if (h->cfg.unet_layer) return fail(h, DEDF_ERR_UNSUPPORTED, "UNet-layer handle: use dedf_layer_forward");
     if (!h->have_keys || !h->have_query) return fail(h, DEDF_ERR_INVALID, "set_key_clouds / set_query must be called first");
     if (h->cfg.use_src_point_attn && !h->have_key_w) return fail(h, DEDF_ERR_INVALID, "use_src_point_attn: the key clouds carry no point weights (dedf_set_key_weights; gnn_block.py:191-192)");
     if (nT <= 0 || !Ts || !time || !ang || !lin) return fail(h, DEDF_ERR_INVALID, "bad arguments");
@@ -648,6 +671,89 @@ int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedul
     if (flags[0]) return fail(h, DEDF_ERR_RUNTIME, "edge workspace overflow: raise dedf_config.max_edges");
     if (flags[1]) return fail(h, DEDF_ERR_RUNTIME, "non-finite score: an activation left the fp16 operand range of the split-fp16 GEMMs "
                                                    "(or the inputs / poses were not finite)");
+    return DEDF_OK;
+}
+
+int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const float* f_src, int n_dst, const float* x_dst, const float* f_dst,
+                       int64_t n_edges, const int64_t* edge_src, const int64_t* edge_dst, float* out, void* stream) {
+    if (!h) return DEDF_ERR_INVALID;
+    if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
+    if (!h->cfg.unet_layer) return fail(h, DEDF_ERR_UNSUPPORTED, "dedf_layer_forward needs a handle created with dedf_config.unet_layer = 1");
+    if (n_src <= 0 || n_dst <= 0 || n_edges < 0 || !x_src || !f_src || !x_dst || !f_dst || !out || (n_edges > 0 && (!edge_src || !edge_dst)))
+        return fail(h, DEDF_ERR_INVALID, "bad arguments");
+    constexpr int L = 2;
+    constexpr size_t D = feat_dim<L>(), REC = edge_rec<L>();
+    if ((size_t)n_src * D * 4 >= (1ull << 32) || (size_t)n_dst * D * 4 >= (1ull << 32) || n_edges >= 0x7fffffff - 64)
+        return fail(h, DEDF_ERR_INVALID, "graph too large for one call");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DEDF_ON_DEVICE(h);
+    const size_t E = (size_t)std::max<int64_t>(n_edges, 1);
+    bool ok = h->d_msg.ensure((size_t)n_src * D * 4) && h->d_msg_dst.ensure((size_t)n_dst * D * 4) && h->d_tile.ensure(64 * 4) &&
+              h->d_esrc.ensure(E * 4) && h->d_edst.ensure(E * 4) && h->d_cnt.ensure((size_t)n_dst * 4) && h->d_off.ensure((size_t)n_dst * 4) &&
+              h->d_eout.ensure(E * REC * 4) && h->d_z.ensure((size_t)n_dst * D * 4);
+    if (!ok) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(workspace) failed");
+    HIPCK(h, hipMemsetAsync(h->d_tile.p, 0, 64 * 4, st));
+    const float* nat = h->d_nat.as<float>();
+    // messages: linear_src(f_src), linear_dst(f_dst) -- no LayerNorm in front of them (block.py:149-153)
+    hipLaunchKernelGGL((k_src_message<L, false>), dim3(n_src), dim3(64), 0, st, f_src, n_src, (const float*)nullptr, (const float*)nullptr,
+                       nat + h->nat_wsrc, (const float*)nullptr, h->d_msg.as<float>());
+    hipLaunchKernelGGL((k_src_message<L, false>), dim3(n_dst), dim3(64), 0, st, f_dst, n_dst, (const float*)nullptr, (const float*)nullptr,
+                       nat + h->nat_wdst, nat + h->nat_bdst, h->d_msg_dst.as<float>());
+    {
+        const int64_t work = std::max<int64_t>(n_edges, n_dst);
+        hipLaunchKernelGGL(k_edge_lists, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, edge_src, edge_dst, n_edges, n_src, n_dst,
+                           h->d_esrc.as<int>(), h->d_edst.as<int>(), h->d_cnt.as<int>(), h->d_off.as<int>(), h->d_tile.as<int>());
+    }
+    const dedf_config& c = h->cfg;
+    {
+        EdgeParams P{};
+        P.key_x = x_src; P.qpos = x_dst; P.edge_src = h->d_esrc.as<int>(); P.edge_dst = h->d_edst.as<int>();
+        P.tile_info = h->d_tile.as<int>();
+        P.msg = h->d_msg.as<float>(); P.msg_bytes = (uint32_t)((size_t)n_src * D * 4);
+        P.msg_dst = h->d_msg_dst.as<float>(); P.msg_dst_bytes = (uint32_t)((size_t)n_dst * D * 4);
+        P.tb = nullptr; P.tb_bytes = 0; P.tb_pose_stride = 0;
+        P.nQ = 1; P.n_scales = 1;
+        // GaussianRadialBasisLayerFiniteCutoff(cutoff = 0.99 r): offset = 0.01 cutoff; t = (len - offset) / (cutoff - offset)
+        const float cutoff = (float)(0.99 * (double)c.radii[0]), offset = (float)(0.01 * (double)cutoff);
+        P.radius[0] = cutoff - offset; P.cut_begin[0] = offset; P.cut_div[0] = 1.0f;
+        P.ns_lo = 0.0f; P.ns_div = 1.0f; P.len_enc_max_r = 1.0f;
+        P.W = h->d_edge_w.as<float>(); P.W_bytes = (uint32_t)h->d_edge_w.bytes;
+        const EdgeOffsets& o = h->eo;
+        P.o_enc = o.o_enc; P.o_A_pre = o.o_A_pre; P.o_A_pre_l = o.o_A_pre_l; P.o_A_r1_l = o.o_A_r1_l; P.o_A_r2_l = o.o_A_r2_l; P.o_A_r3_l = o.o_A_r3_l; P.o_A_r1 = o.o_A_r1; P.o_b_r1 = o.o_b_r1; P.o_g_r1 = o.o_g_r1; P.o_be_r1 = o.o_be_r1;
+        P.o_A_r2 = o.o_A_r2; P.o_b_r2 = o.o_b_r2; P.o_g_r2 = o.o_g_r2; P.o_be_r2 = o.o_be_r2; P.o_A_r3 = o.o_A_r3; P.o_off_r3 = o.o_off_r3;
+        P.o_S_lin = o.o_S_lin; P.o_S_val = o.o_S_val;
+        P.w_unscale = o.w_unscale; P.u_scale = o.u_scale;
+        for (int l = 0; l < 4; ++l) { P.c_lin[l] = o.c_lin[l]; P.c_val[l] = o.c_val[l]; }
+        P.o_b_r0 = o.o_b_r0; P.o_b_val0 = o.o_b_val0; P.o_alpha_dot = o.o_alpha_dot;
+        P.key_w = nullptr;
+        P.out = h->d_eout.as<float>();
+        P.dbg_w = nullptr; P.dbg_out = nullptr; P.phase_prof = nullptr;
+        hipLaunchKernelGGL((k_edge<2, 64, false, 32, 32, true>), dim3(h->n_cu * 4), dim3(64), 0, st, P);
+    }
+    hipLaunchKernelGGL(k_aggregate<L>, dim3((n_dst + 3) / 4), dim3(256), 0, st, h->d_eout.as<float>(), h->d_cnt.as<int>(), h->d_off.as<int>(),
+                       h->d_tile.as<int>(), n_dst, 1, h->d_z.as<float>());
+    {
+        NodeParams P{};
+        P.z = h->d_z.as<float>(); P.z_bytes = (uint32_t)((size_t)n_dst * D * 4);
+        P.f_dst = f_dst; P.f_dst_bytes = (uint32_t)((size_t)n_dst * D * 4);
+        P.feat_out = out;
+        P.nQ = 1; P.n_nodes = n_dst; P.lin_mult = 1.0f;
+        P.W = h->d_node_w.as<float>(); P.W_bytes = (uint32_t)h->d_node_w.bytes;
+        const NodeOffsets& o = h->no;
+        for (int l = 0; l < 4; ++l) {
+            P.o_A_proj[l] = o.o_A_proj[l]; P.o_ln_w[l] = o.o_ln_w[l]; P.o_A_f1[l] = o.o_A_f1[l]; P.o_A_f2[l] = o.o_A_f2[l];
+            P.o_A_proj_l[l] = o.o_A_proj_l[l]; P.o_A_f1_l[l] = o.o_A_f1_l[l]; P.o_A_f2_l[l] = o.o_A_f2_l[l];
+        }
+        P.sc = o.sc;
+        P.o_b_proj0 = o.o_b_proj0; P.o_ln_b0 = o.o_ln_b0; P.o_b_f1 = o.o_b_f1; P.o_b_f2 = o.o_b_f2;
+        const int ntiles = (n_dst + 31) / 32;
+        hipLaunchKernelGGL((k_node<2, false, false, true>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
+    }
+    if (hipGetLastError() != hipSuccess) return fail(h, DEDF_ERR_RUNTIME, "kernel launch failed");
+    HIPCK(h, hipStreamSynchronize(st));
+    int bad = 0;
+    HIPCK(h, hipMemcpy(&bad, h->d_tile.as<int>() + kFlagBadEdges, 4, hipMemcpyDeviceToHost));
+    if (bad) return fail(h, DEDF_ERR_INVALID, "edge lists: edge_dst must be sorted ascending and every index inside its cloud");
     return DEDF_OK;
 }
 

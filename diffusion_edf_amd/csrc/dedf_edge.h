@@ -26,6 +26,8 @@ struct EdgeParams {
     const int* tile_info;     // [0..n_scales] tile prefix, [16..16+n_scales] edge prefix
     const float* msg;         // [sum N_s][D]  source message (LN + LinearRS of key features), reference layout
     uint32_t msg_bytes;
+    const float* msg_dst;     // UNet layer only: [N_d][D] destination message (linear_dst), reference layout
+    uint32_t msg_dst_bytes;
     const float* tb;          // [(nT|1)][n_scales][F0] row-packed: W_pre[:,64:] c_t + b_pre  (b_pre alone when F0 = 64)
     uint32_t tb_bytes;
     int tb_pose_stride;       // floats; 0 when every pose shares the time (sampler)
@@ -210,9 +212,13 @@ DEDF_DEV void edge_enc_to_lds(const EdgeParams& P, const Wave& wv, int scale) {
 }
 
 // H1, H2: hidden widths of the radial MLP (fc_neurons[1:]): 128, 64 in the panda_* and sapien pick configs, 32, 32 in sapien place_*
-template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64>
+// UN: the edge pipeline of a UNet layer (block.EquiformerBlock + GraphAttentionMLP, block.py:141-174, graph_attention.py:84-122):
+//     message = linear_src(f_src)[src] + linear_dst(f_dst)[dst], the radial MLP reads the radial basis directly (no pre-linear, no
+//     time), GaussianRadialBasisLayerFiniteCutoff instead of GaussianRadialBasis, SH without the non-scalar cut-off, no edge logit
+template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false>
 DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, int n_valid DEDF_PROF_ARG) {
     static_assert((H1 == 128 && H2 == 64) || (H1 == 32 && H2 == 32), "radial MLP widths of the shipped configs");
+    static_assert(!UN || F0 == 64, "UNet layer: the radial MLP reads the 64 radial-basis channels");
 #if defined(DEDF_PHASE_PROF) && defined(__HIP_DEVICE_COMPILE__)
     unsigned long long t_last = __builtin_readcyclecounter();
 #endif
@@ -235,14 +241,18 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // operands of the edge pre-linear (first K-chunks) and its per-pose bias rows: requested before the geometry / length-encoding
     // VALU work, which hides their latency
     constexpr int NH = F0 / 32;      // pre-linear width: 128 (length + time embedding) or 64 (EBM critic: length only)
+    constexpr int NT1 = H1 / 32, NT2 = H2 / 32;
     f32x16 h[NH];
     const int oA_pre = opaque_s(P.o_A_pre + scale * (NH * 4 * 256)), oAl_pre = opaque_s(P.o_A_pre_l + scale * (NH * 4 * 256));
-    {
+    if constexpr (!UN) {
         const Buf tbb = make_buf(P.tb, P.tb_bytes);
         const int tvoff = (pose * P.tb_pose_stride) * 4 + wv.hi64;
         static_for<NH>([&]<int To>() { h[To] = ldrows(tbb, tvoff, scale * F0, To); });
     }
-    auto ring_pre = dense_prefetch<NH, 4, 2, HP>(wv, oA_pre, oAl_pre);
+    DenseRing<NH, 2> ring_pre{};
+    DenseRing<NT1, 2> ring_r1u{};
+    if constexpr (!UN) ring_pre = dense_prefetch<NH, 4, 2, HP>(wv, oA_pre, oAl_pre);
+    else ring_r1u = dense_prefetch<NT1, 4, 2, HP>(wv, o_A_r1, o_A_r1_l);
     sched_fence();
 
     // ---- geometry (graph_parser.py:159-215) ---------------------------------------------------------------------
@@ -252,11 +262,11 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     const float len = sqrtf(vx * vx + vy * vy + vz * vz);
     const float radius = P.radius[scale];
     float logit0 = 0.0f;
-    if (radius > 0.0f) {
+    if (!UN && radius > 0.0f) {
         const float cut = 1.0f - soft_step((len - P.cut_begin[scale]) / P.cut_div[scale]);
         logit0 = logf(fmaxf(cut, 1e-12f));
     }
-    const float cns = soft_step((len - P.ns_lo) / P.ns_div);
+    const float cns = UN ? 1.0f : soft_step((len - P.ns_lo) / P.ns_div);
     SH<L> Y;
     {
         const float inv = 1.0f / fmaxf(len, 1e-12f);
@@ -280,7 +290,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     {
         const f32x4* const enc = reinterpret_cast<const f32x4*>(rows + RL::enc);       // this scale's constants (edge_enc_to_lds)
         if (radius > 0.0f) {           // GaussianRadialBasis, radial_func.py:208-227
-            const float t = len / radius;
+            // UNet layer (GaussianRadialBasisLayerFiniteCutoff, radial_func.py:262-278): t = (len - offset) / (cutoff - offset); the host
+            // passes cutoff - offset as `radius` and the offset as `cut_begin`
+            const float t = UN ? (len - P.cut_begin[scale]) / radius : len / radius;
             static_for<2>([&]<int Hf>() {      // 16 channels at a time, stage by stage (see sigmoid_stage)
                 float z[16], wv16[16];
                 static_for<4>([&]<int G4>() {
@@ -297,6 +309,11 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
 #endif
                 static_for<16>([&]<int i>() { eb[16 * Hf + i] = z[i] * wv16[i]; });
             });
+            if constexpr (UN) {        // soft_square_cutoff(t, thr = 0.8, infinite = False), radial_func.py:24-29: fades IN over t in (0, 0.2)
+                const float x1 = 1.0f - t;
+                const float c = t > 0.5f ? 1.0f : 1.0f - soft_step((x1 - 0.8f) / (1.0f - 0.8f));
+                static_for<32>([&]<int i>() { eb[i] = eb[i] * c; });
+            }
         } else {                       // SinusoidalPositionEmbeddings(n = 1000), radial_func.py:305-316
             const float x = len / P.len_enc_max_r * 1000.0f;
             static_for<8>([&]<int G>() {
@@ -308,22 +325,27 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
 
     DEDF_STAMP(0);
     // ---- edge pre-linear + SiLU (multiscale_tensor_field.py:225-234); time part + bias arrive as per-pose rows --------
-    constexpr int NT1 = H1 / 32, NT2 = H2 / 32;
-    dense_rot_h<NH, 4, 2, HP>(wv, oA_pre, oAl_pre, h, [&]<int c, int j>() { return eb[8 * c + j]; }, ring_pre);
-    auto ring_r1 = dense_prefetch<NT1, F0 / 16, 2, HP>(wv, o_A_r1, o_A_r1_l);      // layer 1's first operands: under the SiLU below
-    sched_fence();
-    static_for<NH>([&]<int To>() {
-        to_vgpr(h[To]);
-        float y[16];
-        static_for<16>([&]<int R>() { y[R] = h[To][R]; });
-        silu_stage<16>(y);
-        static_for<16>([&]<int R>() { h[To][R] = y[R]; });
-    });
+    DenseRing<NT1, 2> ring_r1 = ring_r1u;
+    if constexpr (!UN) {
+        dense_rot_h<NH, 4, 2, HP>(wv, oA_pre, oAl_pre, h, [&]<int c, int j>() { return eb[8 * c + j]; }, ring_pre);
+        ring_r1 = dense_prefetch<NT1, F0 / 16, 2, HP>(wv, o_A_r1, o_A_r1_l);      // layer 1's first operands: under the SiLU below
+        sched_fence();
+        static_for<NH>([&]<int To>() {
+            to_vgpr(h[To]);
+            float y[16];
+            static_for<16>([&]<int R>() { y[R] = h[To][R]; });
+            silu_stage<16>(y);
+            static_for<16>([&]<int R>() { h[To][R] = y[R]; });
+        });
+    }
     DEDF_STAMP(1);
     // ---- RadialProfile layers 1, 2 (equiformer/radial_func.py:11-60) ---------------------------------------------------
     f32x16 r1[NT1];
     static_for<NT1>([&]<int To>() { r1[To] = ldrows_lds(rows, hi, RL::b1, To); });
-    dense_rot_h<NT1, F0 / 16, 2, HP>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return h[c / 2][8 * (c % 2) + j]; }, ring_r1);
+    if constexpr (UN)        // no pre-linear: layer 1 reads the radial basis (K = 64 = four chunks of this lane's embedding values)
+        dense_rot_h<NT1, 4, 2, HP>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return eb[8 * c + j]; }, ring_r1);
+    else
+        dense_rot_h<NT1, F0 / 16, 2, HP>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return h[c / 2][8 * (c % 2) + j]; }, ring_r1);
     DEDF_STAMP(2);
     auto ring_r2 = dense_prefetch<NT2, H1 / 16, 2, HP>(wv, o_A_r2, o_A_r2_l);      // layer 2's first operands: under the LayerNorm below
     sched_fence();
@@ -343,8 +365,10 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // wave's private 30 KB) until the second depth-wise TP reads them.
     f32x16 acc0[NR0], acc1[3], acc2[5];
     const Buf msgb = make_buf(P.msg, P.msg_bytes);
+    const Buf msgd = make_buf(P.msg_dst, P.msg_dst_bytes);      // UNet layer: the destination's message is added (block.py:155)
     // per-l1 lane offsets of the 4 message rows this lane owns inside an 8-row group
     const int mv0 = src * (D * 4) + hi * 16, mv1 = src * (D * 4) + hi * 48, mv2 = src * (D * 4) + hi * 80;
+    const int dv0 = dst * (D * 4) + hi * 16, dv1 = dst * (D * 4) + hi * 48, dv2 = dst * (D * 4) + hi * 80;
     // LDS parking: the gated features wait here as READY-MADE B operands of the value GEMMs: one 16-byte slot per lane holds the
     // fp16 hi halves of a 16-channel chunk (8 accumulator registers), the next slot their fp16 residuals ([slot][lane][8 halves];
     // chunk q = dedf_net.h::park_slot(degree, component, chunk) -> slots 2q | 2q + 1), lane-private
@@ -362,7 +386,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // tile,  the lane-local Clebsch-Gordan VALU work + hi/lo split of chunk C+1 (-> its B operands),  the activations of a
     // group completed by chunk C-1,  and the lin / sep_alpha MFMAs of chunk C (A operands through a ring, PDA items ahead).
     constexpr int NCHK = WN / 16, PDA = 3;
-    struct XOps { f32x4 x[2][2 * L + 1]; };
+    struct XOps { f32x4 x[2][2 * L + 1]; f32x4 xd[UN ? 2 : 1][2 * L + 1]; };
     auto load_X = [&]<int C>() {      // this lane's 2 x 4 source-message rows of the chunk (contiguous runs in the reference layout)
         XOps o{};
         if constexpr (C < NCHK) {
@@ -372,6 +396,12 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             static_for<2>([&]<int run>() { static_for<d1>([&]<int Q>() {
                 o.x[run][Q] = bld4(msgb, mv, (blk_off(l1) + (u0 + 8 * run) * d1 + 4 * Q) * 4);
             }); });
+            if constexpr (UN) {
+                const int dv = l1 == 0 ? dv0 : (l1 == 1 ? dv1 : dv2);
+                static_for<2>([&]<int run>() { static_for<d1>([&]<int Q>() {
+                    o.xd[run][Q] = bld4(msgd, dv, (blk_off(l1) + (u0 + 8 * run) * d1 + 4 * Q) * 4);
+                }); });
+            }
         }
         return o;
     };
@@ -386,7 +416,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             float v[d3][8];
             static_for<2>([&]<int run>() {
                 float xr[4 * d1];
-                static_for<d1>([&]<int Q>() { static_for<4>([&]<int i>() { xr[4 * Q + i] = xo.x[run][Q][i]; }); });
+                static_for<d1>([&]<int Q>() { static_for<4>([&]<int i>() {
+                    if constexpr (UN) xr[4 * Q + i] = xo.x[run][Q][i] + xo.xd[run][Q][i]; else xr[4 * Q + i] = xo.x[run][Q][i];
+                }); });
                 static_for<4>([&]<int j>() {
                     float t[d3];
                     Cg::apply(&xr[j * d1], m, t);

@@ -8,7 +8,7 @@
 
 using namespace dedf;
 
-template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64> __global__ __launch_bounds__(64, 1) void k_edge(EdgeParams P) {
+template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false> __global__ __launch_bounds__(64, 1) void k_edge(EdgeParams P) {
     const int* ti = P.tile_info;
     const int ntiles = ti[P.n_scales];
     const Wave wv = make_wave(P.W, P.W_bytes);
@@ -24,20 +24,20 @@ template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64> __global__ 
         const int k = t - ti[scale];
         const int ebase = ti[16 + scale], En = ti[16 + scale + 1] - ebase;
 #if defined(DEDF_PHASE_PROF)
-        edge_tile<L, F0, HP, H1, H2>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k), pacc);
+        edge_tile<L, F0, HP, H1, H2, UN>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k), pacc);
 #else
-        edge_tile<L, F0, HP, H1, H2>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k));
+        edge_tile<L, F0, HP, H1, H2, UN>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k));
 #endif
     }
 #if defined(DEDF_PHASE_PROF)
     if (P.phase_prof && wv.lane == 0) for (int i = 0; i < 16; ++i) P.phase_prof[blockIdx.x * 16 + i] += pacc[i];
 #endif
 }
-template <int L, bool EBM, bool HP = false> __global__ __launch_bounds__(64, 1) void k_node(NodeParams P) {
+template <int L, bool EBM, bool HP = false, bool UN = false> __global__ __launch_bounds__(64, 1) void k_node(NodeParams P) {
     const Wave wv = make_wave(P.W, P.W_bytes);
     const int ntiles = (P.n_nodes + 31) / 32;
-    node_rows_to_lds<L, EBM>(P, wv);
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) node_tile<L, EBM, HP>(P, wv, t * 32);
+    node_rows_to_lds<L, EBM || UN>(P, wv);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) node_tile<L, EBM, HP, UN>(P, wv, t * 32);
 }
 
 // every instantiation the library launches: X(unit, declaration)
@@ -63,5 +63,7 @@ template <int L, bool EBM, bool HP = false> __global__ __launch_bounds__(64, 1) 
     X(6, void k_node<2, true, false>(NodeParams))                     \
     X(6, void k_node<1, false, false>(NodeParams))                    \
     X(6, void k_node<1, false, true>(NodeParams))                     \
-    X(6, void k_node<1, true, false>(NodeParams))
-constexpr int kKernelUnits = 10;
+    X(6, void k_node<1, true, false>(NodeParams))                     \
+    X(10, void k_edge<2, 64, false, 32, 32, true>(EdgeParams))        \
+    X(10, void k_node<2, false, false, true>(NodeParams))
+constexpr int kKernelUnits = 11;

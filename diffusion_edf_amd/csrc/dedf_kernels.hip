@@ -56,4 +56,9 @@
 #else
 #define DEDF_INST_9(...) DEDF_NOP(__VA_ARGS__)
 #endif
+#if DEDF_KUNIT == 10
+#define DEDF_INST_10(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_10(...) DEDF_NOP(__VA_ARGS__)
+#endif
 DEDF_KERNEL_LIST(DEDF_INST)

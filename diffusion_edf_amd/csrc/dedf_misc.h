@@ -148,7 +148,9 @@ __global__ __launch_bounds__(256) void k_time_bias(TimeParams P) {
 // ------------------------------------------------------------------------------------------------------------------------
 // Source message (pose independent): EquivariantLayerNormV2 + LinearRS(bias) on every key point
 // (gnn_block.py:170-171, layer_norm.py:91-156, tensor_product_rescale.py:176-185).  One block (64 threads) per point.
-template <int L>
+// NORM = false: LinearRS only, `bias` may be null (the linear_src / linear_dst of a UNet block: block.py:149-153 overwrites the
+// LayerNorm outputs, so the linears see the raw features).
+template <int L, bool NORM = true>
 __global__ void k_src_message(const float* __restrict__ f, int n_pts, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                               const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ msg) {
     constexpr int D = feat_dim<L>();
@@ -158,7 +160,7 @@ __global__ void k_src_message(const float* __restrict__ f, int n_pts, const floa
     for (int i = tid; i < D; i += 64) x[i] = fi[i];
     __syncthreads();
     int woff = 0, chan = 0;
-    for (int l = 0; l <= L; ++l) {
+    if constexpr (NORM) for (int l = 0; l <= L; ++l) {
         const int m = mul_of(l), d = 2 * l + 1, off = blk_off(l);
         // statistics of block l (serial in thread 0: 240 values, runs once per scene)
         if (tid == 0) {
@@ -190,7 +192,7 @@ __global__ void k_src_message(const float* __restrict__ f, int n_pts, const floa
         const int m = mul_of(l), d = 2 * l + 1, off = blk_off(l);
         for (int i = tid; i < m * d; i += 64) {
             const int w = i / d, k = i % d;
-            float s = (l == 0) ? bias[w] : 0.0f;
+            float s = (l == 0 && bias != nullptr) ? bias[w] : 0.0f;
             for (int u = 0; u < m; ++u) s += W[woff + u * m + w] * x[off + u * d + k];
             o[off + i] = s;
         }
@@ -351,6 +353,32 @@ __global__ __launch_bounds__(kNbrBlock) void k_neighbors(NbrParams P) {
             (void)block_exclusive_scan_256(act ? c : 0, &total);
             if (threadIdx.x == 0) P.blk[(size_t)n * gridDim.x + blockIdx.x] = total;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Explicit edge lists (UNet layers: the graphs come from dedf_fps / dedf_radius, int64 like torch_cluster's, sorted by destination):
+// 32-bit copies for the edge kernel, per-destination counts / offsets for k_aggregate, the tile table, and a validity check
+// (sortedness, index ranges) whose result lands in tile_info[43].
+constexpr int kFlagBadEdges = 43;
+__global__ void k_edge_lists(const int64_t* __restrict__ src64, const int64_t* __restrict__ dst64, int64_t n_edges, int n_src, int n_dst,
+                             int* __restrict__ esrc, int* __restrict__ edst, int* __restrict__ cnt, int* __restrict__ off, int* __restrict__ tile_info) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        tile_info[0] = 0; tile_info[1] = (int)((n_edges + 31) / 32);
+        tile_info[16] = 0; tile_info[17] = (int)n_edges; tile_info[40] = 0;
+    }
+    if (i < n_edges) {
+        const int64_t s = src64[i], d = dst64[i];
+        bool bad = s < 0 || s >= n_src || d < 0 || d >= n_dst;
+        if (i > 0 && dst64[i - 1] > d) bad = true;
+        if (bad) tile_info[kFlagBadEdges] = 1;
+        esrc[i] = bad ? 0 : (int)s; edst[i] = bad ? 0 : (int)d;
+    }
+    if (i < n_dst) {      // lower bounds of i and i + 1 in the sorted destination list
+        auto lb = [&](int64_t v) { int64_t lo = 0, hi = n_edges; while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (dst64[m] < v) lo = m + 1; else hi = m; } return lo; };
+        const int64_t a = lb(i), b = lb(i + 1);
+        off[i] = (int)a; cnt[i] = (int)(b - a);
     }
 }
 

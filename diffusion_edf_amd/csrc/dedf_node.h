@@ -33,6 +33,8 @@ struct NodeParams {
     int o_b_sl[2];                             // [tp]        gate bias rows
     int o_A_proj_l[4], o_A_f1_l[4], o_A_f2_l[4], o_A_s_l[2][16], o_A_sl_l[2][2];     // residual (lo) images of the split-fp16 operands
     NodeScales sc;                             // accumulator -> true value, per matrix
+    const float* f_dst; uint32_t f_dst_bytes;  // UNet layer only: [N_d][D] destination input features (first skip connection, block.py:165)
+    float* feat_out;                           // UNet layer only: [N_d][D] output features, reference layout
     float* node_out;                           // [N_d][8]: w*lin_vel (3), w*(ang_orbital + ang_spin) (3), 0, 0
     float* dbg_emb;                            // optional [N_d][D] dumps (internal layout) of the proj output and of the field (tests)
     float* dbg_field;
@@ -86,7 +88,45 @@ DEDF_DEV f32x16 node_ldrows(const float* rows, int hi, int off, int tile) {
     return v;
 }
 
-template <int L, bool EBM, bool HP = false>
+// UN: the node half of a UNet layer (block.py:164-172): out1 = f_dst + proj(attention); out = out1 + FFN(norm_2(out1)) -> feat_out.
+// (the `emb` of the score head plays out1: its residual `field = FFN(LN(emb)) + emb` is exactly that second skip connection)
+// Feature rows in the reference layout <-> row layout: lane (hi) owns channels 8 gu + 4 hi + j (j < 4) of every 8-channel group gu,
+// i.e. 4 (2l+1) contiguous floats of a node's block l.
+template <int L> DEDF_DEV void feat_add_ref(Feat<L>& f, const Buf& b, int node_off_bytes, int hi) {
+    static_for<L + 1>([&]<int l>() {
+        constexpr int d = 2 * l + 1;
+        const int v = node_off_bytes + hi * (16 * d);
+        static_for<mul_of(l) / 8>([&]<int gu>() {
+            float xr[4 * d];
+            static_for<d>([&]<int Q>() {
+                const f32x4 t = bld4(b, v, (blk_off(l) + gu * 8 * d + 4 * Q) * 4);
+                xr[4 * Q] = t[0]; xr[4 * Q + 1] = t[1]; xr[4 * Q + 2] = t[2]; xr[4 * Q + 3] = t[3];
+            });
+            static_for<4>([&]<int j>() { static_for<d>([&]<int I>() {
+                if constexpr (l == 0) f.s[gu / 4][4 * (gu % 4) + j] += xr[j];
+                else if constexpr (l == 1) f.v1[I][4 * gu + j] += xr[j * d + I];
+                else f.v2[I][4 * gu + j] += xr[j * d + I];
+            }); });
+        });
+    });
+}
+template <int L> DEDF_DEV void feat_store_ref(const Feat<L>& f, float* node_ptr, int hi) {
+    static_for<L + 1>([&]<int l>() {
+        constexpr int d = 2 * l + 1;
+        float* const o = node_ptr + blk_off(l) + hi * (4 * d);
+        static_for<mul_of(l) / 8>([&]<int gu>() {
+            float xr[4 * d];
+            static_for<4>([&]<int j>() { static_for<d>([&]<int I>() {
+                if constexpr (l == 0) xr[j] = f.s[gu / 4][4 * (gu % 4) + j];
+                else if constexpr (l == 1) xr[j * d + I] = f.v1[I][4 * gu + j];
+                else xr[j * d + I] = f.v2[I][4 * gu + j];
+            }); });
+            static_for<d>([&]<int Q>() { st4(o + gu * 8 * d + 4 * Q, f32x4{xr[4 * Q], xr[4 * Q + 1], xr[4 * Q + 2], xr[4 * Q + 3]}); });
+        });
+    });
+}
+
+template <int L, bool EBM, bool HP = false, bool UN = false>
 DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     constexpr int D = feat_dim<L>();
     const int hi = wv.hi;
@@ -138,6 +178,8 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
             static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { emb.v2[m][R] = a[m][R] * c2; }); });
         }
     }
+
+    if constexpr (UN) feat_add_ref<L>(emb, make_buf(P.f_dst, P.f_dst_bytes), n * (D * 4), hi);      // node_output = node_input_dst + ga(...)
 
     // ---- EquivariantLayerNormV2 (equiformer/layer_norm.py:91-156) ----------------------------------------------------------
     Feat<L> nrm;
@@ -279,6 +321,10 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         dump(P.dbg_field, fld);
     }
 
+    if constexpr (UN) {
+        if (valid) feat_store_ref<L>(fld, P.feat_out + (size_t)n * D, hi);
+        return;
+    }
     // ---- score tensor products ------------------------------------------------------------------------------------------------
     const Buf qfb = make_buf(P.qf, P.qf_bytes);
     const Buf pb = make_buf(P.pose, P.pose_bytes);

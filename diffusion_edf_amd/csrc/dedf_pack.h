@@ -30,8 +30,53 @@ struct ParamSpec {
     }
 };
 
+// one UNet layer: state_dict names of the ModuleDict {'radial', 'gnn'} (reference unet_feature_extractor.py:141-156; block.py:62-139,
+// graph_attention.py:11-82).  norm_1_src / norm_1_dst exist in the reference's state dict and are dead (block.py:149-153).
+template <int L>
+inline ParamSpec build_spec_unet_layer(const dedf_config& c) {
+    ParamSpec S;
+    const int nb = c.fc_neurons[0];
+    S.add("radial.mean", nb); S.add("radial.std_logit", nb); S.add("radial.weight_logit", nb);
+    size_t sq = 0;
+    for (int l = 0; l <= L; ++l) sq += (size_t)mul_of(l) * mul_of(l);
+    const std::string g = "gnn";
+    S.add(g + ".norm_1_src.affine_weight", sum_mul<L>()); S.add(g + ".norm_1_src.affine_bias", mul_of(0));
+    S.add(g + ".linear_src.tp.weight", sq);
+    S.add(g + ".norm_1_dst.affine_weight", sum_mul<L>()); S.add(g + ".norm_1_dst.affine_bias", mul_of(0));
+    S.add(g + ".linear_dst.tp.weight", sq); S.add(g + ".linear_dst.bias.0", mul_of(0));
+    const std::string ga = g + ".ga", rad = ga + ".sep_act.dtp_rad.";
+    const int ch[4] = {c.fc_neurons[0], c.fc_neurons[1], c.fc_neurons[2], dtp_wn<L>()};
+    S.add(rad + "net.0.weight", (size_t)ch[1] * ch[0]); S.add(rad + "net.0.bias", ch[1]);
+    S.add(rad + "net.1.weight", ch[1]); S.add(rad + "net.1.bias", ch[1]);
+    S.add(rad + "net.3.weight", (size_t)ch[2] * ch[1]); S.add(rad + "net.3.bias", ch[2]);
+    S.add(rad + "net.4.weight", ch[2]); S.add(rad + "net.4.bias", ch[2]);
+    S.add(rad + "net.6.weight", (size_t)ch[3] * ch[2]);
+    S.add(rad + "offset", ch[3]);
+    size_t lin_n = 0, val_n = 0;
+    for (int l = 0; l <= L; ++l) {
+        lin_n += (size_t)dtp_k<L>(l) * (l == 0 ? lin0_rows<L>() : mul_of(l));
+        val_n += (size_t)dtp_k<L>(l) * mul_of(l);
+    }
+    S.add(ga + ".sep_act.lin.tp.weight", lin_n); S.add(ga + ".sep_act.lin.bias.0", lin0_rows<L>());
+    S.add(ga + ".sep_alpha.tp.weight", (size_t)dtp_k<L>(0) * mul_of(0)); S.add(ga + ".sep_alpha.bias.0", mul_of(0));
+    S.add(ga + ".sep_value.dtp.tp.weight", dtp_wn<L>());
+    S.add(ga + ".sep_value.lin.tp.weight", val_n); S.add(ga + ".sep_value.lin.bias.0", mul_of(0));
+    S.add(ga + ".alpha_dot", mul_of(0));
+    S.add(ga + ".proj.tp.weight", sq); S.add(ga + ".proj.bias.0", mul_of(0));
+    S.add(g + ".norm_2.affine_weight", sum_mul<L>()); S.add(g + ".norm_2.affine_bias", mul_of(0));
+    size_t f1 = 0, f2 = 0;
+    for (int l = 0; l <= L; ++l) {
+        f1 += (size_t)mul_of(l) * (l == 0 ? f1_rows0<L>() : kMlpMid * mul_of(l));
+        f2 += (size_t)kMlpMid * mul_of(l) * mul_of(l);
+    }
+    S.add(g + ".ffn.fctp_1.tp.weight", f1); S.add(g + ".ffn.fctp_1.bias.0", f1_rows0<L>());
+    S.add(g + ".ffn.fctp_2.tp.weight", f2); S.add(g + ".ffn.fctp_2.bias.0", mul_of(0));
+    return S;
+}
+
 template <int L>
 inline ParamSpec build_spec(const dedf_config& c) {
+    if (c.unet_layer) return build_spec_unet_layer<L>(c);
     ParamSpec S;
     const int* te = c.time_emb_mlp;
     for (int n = 0; n < c.n_scales; ++n) {
@@ -206,14 +251,16 @@ inline std::vector<float> pack_val_stream(WAt W) {
 
 template <int L>
 inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, Image& im, EdgeOffsets& o) {
-    const std::string ktf = "key_tensor_field", blk = ktf + ".gnn_block_init", ga = blk + ".ga", rad = ga + ".sep_act.dtp_rad.";
-    // length encoders (reference radial_func.py:168-227, 291-316)
+    const bool un = c.unet_layer != 0;
+    const std::string ktf = "key_tensor_field", blk = un ? std::string("gnn") : ktf + ".gnn_block_init", ga = blk + ".ga", rad = ga + ".sep_act.dtp_rad.";
+    // length encoders (reference radial_func.py:168-227, 291-316; UNet layer: GaussianRadialBasisLayerFiniteCutoff :231-278, whose
+    // Gaussian part has the same three parameter rows -- its rescaling of the length and its soft cut-off are kernel arguments)
     {
         std::vector<float> enc((size_t)c.n_scales * 192, 0.0f);
         for (int n = 0; n < c.n_scales; ++n) {
             float* e = enc.data() + (size_t)n * 192;
             if (c.radii[n] > 0) {
-                const std::string pm = ktf + ".graph_parsers." + std::to_string(n) + ".length_enc.param_module.";
+                const std::string pm = un ? std::string("radial.") : ktf + ".graph_parsers." + std::to_string(n) + ".length_enc.param_module.";
                 const float *sl = S.get(B, pm + "std_logit"), *wl = S.get(B, pm + "weight_logit"), *mu = S.get(B, pm + "mean");
                 for (int k = 0; k < 64; ++k) {
                     const int hi = k / 32, s = k % 32;
@@ -231,7 +278,8 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
     }
     // The radial MLP (pre-linear, layers 1-3) runs on split-fp16 MFMAs: hi / lo images per layer (dedf_layout.h::pack_A_h)
     const int F0 = c.fc_neurons[0];      // 64 + time channels; 64 for the EBM head
-    {   // pre-linear: length-embedding columns of the weight (multiscale_tensor_field.py:141-146); B operand element j of chunk cc
+    if (un) { o.o_A_pre = o.o_A_pre_l = 0; }
+    else {   // pre-linear: length-embedding columns of the weight (multiscale_tensor_field.py:141-146); B operand element j of chunk cc
         // is the lane's embedding value 8 cc + j, i.e. k = 8 cc + j + 32 h
         std::vector<float> all_h, all_l;
         for (int n = 0; n < c.n_scales; ++n) {
@@ -250,7 +298,10 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
     {
         std::vector<float> ih, il;
         const float* W = S.get(B, rad + "net.0.weight");
-        pack_A_h(H1, F0 / 16, [&](int oo, int k) { return W[oo * F0 + k]; }, [&](int cc, int j, int h) { return chain_k(F0, cc, j, h); }, ih, il);
+        // K order of layer 1: the previous layer's accumulator tiles; for a UNet layer the length embedding itself (no pre-linear):
+        // element j of chunk cc is the lane's embedding value 8 cc + j, i.e. k = 8 cc + j + 32 h
+        pack_A_h(H1, F0 / 16, [&](int oo, int k) { return W[oo * F0 + k]; },
+                 [&](int cc, int j, int h) { return un ? 8 * cc + j + 32 * h : chain_k(F0, cc, j, h); }, ih, il);
         o.o_A_r1 = im.push(ih); o.o_A_r1_l = im.push(il);
         o.o_b_r1 = im.push(rows(H1, S.get(B, rad + "net.0.bias")));
         o.o_g_r1 = im.push(rows(H1, S.get(B, rad + "net.1.weight")));
@@ -345,9 +396,10 @@ template <int L>
 inline void pack_node(const dedf_config& c, const ParamSpec& S, const float* B, Image& im, NodeOffsets& o) {
     // Every GEMM of the node kernel runs on split-fp16 MFMAs: hi / lo images (dedf_layout.h::pack_A_h), each matrix scaled by
     // its own power of two (pow2_scale); biases carry the matrix scale times the fixed B-operand scale 2^kNodeBShift.
-    const std::string blk = "key_tensor_field.gnn_block_init", ga = blk + ".ga";
+    const bool un = c.unet_layer != 0;
+    const std::string blk = un ? "gnn" : "key_tensor_field.gnn_block_init", ga = blk + ".ga", post = blk + (un ? ".norm_2" : ".post_norm");
     const float* pw = S.get(B, ga + ".proj.tp.weight");
-    const float* lnw = S.get(B, blk + ".post_norm.affine_weight");
+    const float* lnw = S.get(B, post + ".affine_weight");
     const float* f1w = S.get(B, blk + ".ffn.fctp_1.tp.weight");
     const float* f2w = S.get(B, blk + ".ffn.fctp_2.tp.weight");
     // pack one matrix (O rows, K columns fed by a producer's accumulator tiles); returns its power-of-two exponent
@@ -379,11 +431,11 @@ inline void pack_node(const dedf_config& c, const ParamSpec& S, const float* B, 
     }
     auto rows_s = [&](int O, const float* v, int sh) { return pack_rows(O, [&](int i) { return std::ldexp(v[i], sh); }); };
     o.o_b_proj0 = im.push(rows_s(mul_of(0), S.get(B, ga + ".proj.bias.0"), s_proj0 + kNodeBShift));
-    o.o_ln_b0 = im.push(rows_s(mul_of(0), S.get(B, blk + ".post_norm.affine_bias"), 0));
+    o.o_ln_b0 = im.push(rows_s(mul_of(0), S.get(B, post + ".affine_bias"), 0));
     o.o_b_f1 = im.push(rows_s(f1_rows0<L>(), S.get(B, blk + ".ffn.fctp_1.bias.0"), s_f10 + kNodeBShift));
     o.o_b_f2 = im.push(rows_s(mul_of(0), S.get(B, blk + ".ffn.fctp_2.bias.0"), s_f20 + kNodeBShift));
     int tp = 0;
-    if (!c.ebm) for (const char* nm : {"lin_vel_tp", "ang_vel_tp"}) {
+    if (!c.ebm && !un) for (const char* nm : {"lin_vel_tp", "ang_vel_tp"}) {
         const std::string p = std::string(nm);
         const float* dw = S.get(B, p + ".dtp.tp.weight");
         for (int q = 0; q < stp_num_paths<L>(); ++q) {

@@ -252,6 +252,12 @@ def init_params(cfg: HeadConfig, seed: int = 2, randomize_all: bool = False,
     g = torch.Generator().manual_seed(seed)
     P: Dict[str, torch.Tensor] = {}
     for name, shape, kind, scale in param_spec(cfg):
+        P[name] = _init_one(g, shape, kind, scale, randomize_all).to(dtype)
+    return P
+
+
+def _init_one(g, shape, kind, scale, randomize_all):
+    if True:
         if kind in ('linear_w', 'linear_b'):
             b = 1.0 / math.sqrt(scale)
             t = (torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * b
@@ -282,9 +288,83 @@ def init_params(cfg: HeadConfig, seed: int = 2, randomize_all: bool = False,
             t = (torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * b
         else:
             raise ValueError(kind)
-        P[name] = t.to(dtype)
-    return P
+        return t
 
 
 def n_params(cfg: HeadConfig) -> int:
     return sum(int(np.prod(s)) for _, s, _, _ in param_spec(cfg))
+
+
+# --------------------------------------------------------------------------------------------------
+# one layer of the UNet feature extractor (first slice)
+# --------------------------------------------------------------------------------------------------
+
+def unet_layer_param_spec(irreps: Irreps, fc_neurons: List[int], num_heads: int = 4, lmax_sh: int = 2,
+                          irreps_mlp_mid: int = 3) -> List[Tuple[str, Tuple[int, ...], str, float]]:
+    """Schema of the ModuleDict {'radial': GaussianRadialBasisLayerFiniteCutoff, 'gnn': block.EquiformerBlock} the reference builds
+    for every UNet layer (unet_feature_extractor.py:141-156; names = its state_dict keys below e.g. ``down_blocks.3.pool_layer.``),
+    irreps_src == irreps_dst.  Same tuple format as ``param_spec``."""
+    S: List[Tuple[str, Tuple[int, ...], str, float]] = []
+    muls = [m for m, _ in irreps]
+    L, n0, nirr = len(muls) - 1, muls[0], sum(muls)
+    nb = fc_neurons[0]
+    S.append(("radial.mean", (1, nb), 'linspace', 0.0))                                             # radial_func.py:242-243
+    S.append(("radial.std_logit", (1, nb), 'const', math.log(math.exp(2.0 / nb) - 1)))              # :248-249
+    S.append(("radial.weight_logit", (1, nb), 'const', -math.log(4.0 / 1. - 1)))                    # :251-252
+    g = "gnn"
+    sq = 'tp_w:' + ','.join(f"{m*m}:{m}" for m in muls)
+    S.append((f"{g}.norm_1_src.affine_weight", (nirr,), 'ones', 0)); S.append((f"{g}.norm_1_src.affine_bias", (n0,), 'zeros', 0))
+    S.append((f"{g}.linear_src.tp.weight", (sum(m * m for m in muls),), sq, 0))                        # src_bias=False
+    S.append((f"{g}.norm_1_dst.affine_weight", (nirr,), 'ones', 0)); S.append((f"{g}.norm_1_dst.affine_bias", (n0,), 'zeros', 0))
+    S.append((f"{g}.linear_dst.tp.weight", (sum(m * m for m in muls),), sq, 0))
+    S.append((f"{g}.linear_dst.bias.0", (n0,), 'zeros', 0))
+    ga = f"{g}.ga"
+    sh_ls = list(range(lmax_sh + 1))
+    paths = dtp_paths(irreps, sh_ls, [1] * len(sh_ls), list(range(L + 1)))
+    wn = sum(p[3] for p in paths)
+    ch = list(fc_neurons) + [wn]
+    idx = 0
+    for i in range(1, len(ch)):
+        last = i == len(ch) - 1
+        S.append((f"{ga}.sep_act.dtp_rad.net.{idx}.weight", (ch[i], ch[i - 1]), 'linear_w', ch[i - 1]))
+        if not last:
+            S.append((f"{ga}.sep_act.dtp_rad.net.{idx}.bias", (ch[i],), 'linear_b', ch[i - 1]))
+            S.append((f"{ga}.sep_act.dtp_rad.net.{idx + 1}.weight", (ch[i],), 'ones', 0))
+            S.append((f"{ga}.sep_act.dtp_rad.net.{idx + 1}.bias", (ch[i],), 'zeros', 0))
+            idx += 3
+    S.append((f"{ga}.sep_act.dtp_rad.offset", (wn,), 'linear_b', ch[-2]))
+    by_l = dtp_sorted_out(paths)
+    mul_dtp = [sum(paths[p][3] for p in by_l.get(l, [])) for l in range(L + 1)]
+    lin_out = [n0 + sum(muls[1:])] + muls[1:]
+    S.append((f"{ga}.sep_act.lin.tp.weight", (sum(a * b for a, b in zip(mul_dtp, lin_out)),),
+              'tp_w:' + ','.join(f"{a*b}:{a}" for a, b in zip(mul_dtp, lin_out)), 0))
+    S.append((f"{ga}.sep_act.lin.bias.0", (lin_out[0],), 'zeros', 0))
+    a_blocks = [paths[p][3] for p in by_l[0]]
+    S.append((f"{ga}.sep_alpha.tp.weight", (sum(a * n0 for a in a_blocks),), 'tp_w:' + ','.join(f"{a*n0}:{sum(a_blocks)}" for a in a_blocks), 0))
+    S.append((f"{ga}.sep_alpha.bias.0", (n0,), 'zeros', 0))
+    S.append((f"{ga}.sep_value.dtp.tp.weight", (wn,), 'tp_w:' + f"{wn}:1", 0))
+    S.append((f"{ga}.sep_value.lin.tp.weight", (sum(a * b for a, b in zip(mul_dtp, muls)),),
+              'tp_w:' + ','.join(f"{a*b}:{a}" for a, b in zip(mul_dtp, muls)), 0))
+    S.append((f"{ga}.sep_value.lin.bias.0", (n0,), 'zeros', 0))
+    S.append((f"{ga}.alpha_dot", (1, num_heads, n0 // num_heads), 'xavier', 0))
+    S.append((f"{ga}.proj.tp.weight", (sum(m * m for m in muls),), sq, 0))
+    S.append((f"{ga}.proj.bias.0", (n0,), 'zeros', 0))
+    S.append((f"{g}.norm_2.affine_weight", (nirr,), 'ones', 0)); S.append((f"{g}.norm_2.affine_bias", (n0,), 'zeros', 0))
+    mid = [m * irreps_mlp_mid for m in muls]
+    f1_out = [mid[0] + sum(mid[1:])] + mid[1:]
+    S.append((f"{g}.ffn.fctp_1.tp.weight", (sum(a * b for a, b in zip(muls, f1_out)),), 'tp_w:' + ','.join(f"{a*b}:{a}" for a, b in zip(muls, f1_out)), 0))
+    S.append((f"{g}.ffn.fctp_1.bias.0", (f1_out[0],), 'zeros', 0))
+    S.append((f"{g}.ffn.fctp_2.tp.weight", (sum(a * b for a, b in zip(mid, muls)),), 'tp_w:' + ','.join(f"{a*b}:{a}" for a, b in zip(mid, muls)), 0))
+    S.append((f"{g}.ffn.fctp_2.bias.0", (n0,), 'zeros', 0))
+    return S
+
+
+def init_from_spec(spec, seed: int = 2, randomize_all: bool = False, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """seeded init of any schema in the ``param_spec`` tuple format (see ``init_params``)"""
+    class _C:            # init_params only needs `param_spec(cfg)`: feed it the ready-made list
+        pass
+    g = torch.Generator().manual_seed(seed)
+    P: Dict[str, torch.Tensor] = {}
+    for name, shape, kind, scale in spec:
+        P[name] = _init_one(g, shape, kind, scale, randomize_all).to(dtype)
+    return P

@@ -17,6 +17,7 @@
  *   dedf_score           ScoreModelHead.forward                   score_head.py:142-211
  *   dedf_sample          ScoreModelBase.sample (inner loop)       score_model_base.py:110-204
  *   dedf_energy          EbmScoreModelHead.compute_energy         score_head_ebm.py:122-174
+ *   dedf_layer_forward   one {radial, gnn} layer of UnetFeatureExtractor      unet_feature_extractor.py:141-202, 289-324; block.py:141-174
  *   dedf_destroy         module deletion
  *
  * Conventions: all tensor arguments are DEVICE pointers owned by the caller (the library never frees or mutates
@@ -70,6 +71,11 @@ typedef struct dedf_config {
     int use_src_point_attn;              /* 1: PointAttentiveScoreModel (point_attentive_score_model.py:71-72): the attention of every edge is
                                             multiplied, after the softmax, by its key point's weight (gnn_block.py:190-194,
                                             graph_attention.py:257-258); the weights come through dedf_set_key_weights.  0: default */
+    int unet_layer;                      /* 1: the handle is ONE layer of the UNet feature extractor (unet_feature_extractor.py:141-202):
+                                            GaussianRadialBasisLayerFiniteCutoff + block.EquiformerBlock with GraphAttentionMLP, irreps_src =
+                                            irreps_dst = 64x0e+32x1e+16x2e, fc_neurons {64,32,32} (levels 2, 3 and the mid block of every shipped
+                                            UNet config); radii[0] = the level's connection radius, n_scales = 1; the time / score fields are
+                                            ignored; only dedf_layer_forward is available.  0: score / critic head */
 } dedf_config;
 
 typedef struct dedf_schedule {           /* host arrays, one entry per denoising step (score_model_base.py:146-171) */
@@ -124,6 +130,15 @@ int dedf_energy(dedf_handle* h, int nT, const float* Ts, const float* time, floa
  * (score_model_base.py:199-201).  Synchronises `stream` before returning (overflow check). */
 int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedule* sched, uint64_t seed,
                 int64_t first_pose_index, const double* noise, double* Ts_out, void* stream);
+
+/* One UNet layer (dedf_config.unet_layer = 1) on a bipartite graph, reference unet_feature_extractor.py:289-302 (pool layer) / :316-324
+ * (radius-graph layers) -> block.EquiformerBlock.forward (block.py:141-174):
+ *   x_src (n_src,3), f_src (n_src,D), x_dst (n_dst,3), f_dst (n_dst,D) f32; edge_src / edge_dst (n_edges,) int64 as torch_cluster /
+ *   dedf_radius return them, SORTED BY edge_dst (dedf_radius, FpsPool and RadiusGraph order); out (n_dst,D) f32 = the block's output
+ *   features of the destination nodes.  Nodes without incoming edges get the bias-only attention output, like the reference's scatter.
+ * Returns DEDF_ERR_INVALID if edge_dst is not sorted or an index is out of range (checked on device, reported after a sync). */
+int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const float* f_src, int n_dst, const float* x_dst, const float* f_dst,
+                       int64_t n_edges, const int64_t* edge_src, const int64_t* edge_dst, float* out, void* stream);
 
 int dedf_get_stats(dedf_handle* h, dedf_stats* out);   /* synchronises the last used stream */
 

@@ -79,4 +79,24 @@ out["time"] = tt.numpy()
 out["sinus_time"] = RF.SinusoidalPositionEmbeddings(dim=256, max_val=1., n=10000.)(tt).numpy()
 out["sinus_time_f64"] = RF.SinusoidalPositionEmbeddings(dim=256, max_val=1., n=10000.)(tt.double()).numpy()
 np.savez(os.path.join(HERE, "radial_func.npz"), **out)
+
+# ---- radial_func.py: GaussianRadialBasisLayerFiniteCutoff (the radial basis of the UNet blocks, unet_feature_extractor.py:144) -----
+out = {}
+g2 = torch.Generator().manual_seed(7)
+d = torch.cat([torch.rand(300, generator=g2) * 7.5, torch.tensor([0.0, 0.01, 0.066, 0.0663, 0.07, 1.3, 6.63, 6.7])])
+out["dist"] = d.numpy()
+for nb, r in ((64, 6.7), (64, 15.0), (32, 3.0)):
+    lay = RF.GaussianRadialBasisLayerFiniteCutoff(num_basis=nb, cutoff=0.99 * r)
+    with torch.no_grad():      # trained-looking parameters, so that every term of the formula is pinned
+        lay.mean.add_(torch.randn(1, nb, generator=g2) * 0.02)
+        lay.std_logit.add_(torch.randn(1, nb, generator=g2) * 0.3)
+        lay.weight_logit.add_(torch.randn(1, nb, generator=g2) * 0.5)
+        tag = f"{nb}_{str(r).replace('.', 'p')}"
+        out[f"mean_{tag}"] = lay.mean.numpy().copy()
+        out[f"std_logit_{tag}"] = lay.std_logit.numpy().copy()
+        out[f"weight_logit_{tag}"] = lay.weight_logit.numpy().copy()
+        out[f"cutoff_offset_{tag}"] = np.array([lay.cutoff, lay.offset])
+        out[f"out_{tag}"] = lay(d).numpy()
+        out[f"out_f64_{tag}"] = lay.double()(d.double()).numpy()
+np.savez(os.path.join(HERE, "unet_radial.npz"), **out)
 print("wrote", os.listdir(HERE))
