@@ -156,9 +156,31 @@ DEDF_DEV AItem load_item(const Wave& wv, int o_str) {
 // MFMAs of the chunk at walk position C: l3 = 0 -> output tiles acc0[0 .. NT0) two at a time, l3 = 1 / 2 -> acc1[m] / acc2[m] (one tile
 // per component; the 16-channel l = 2 outputs only fill rows 0-15, i.e. registers 0-7).  The three terms are issued
 // term-major so that consecutive MFMAs hit different accumulators.
+// Output-side chunks (dedf_net.h::dtp_path_out_side) accumulate G_i = W . (w x_i) into `go`: one tile per input component i -- or, for
+// scalar inputs (one component), one tile per product term, so that consecutive MFMAs still hit different accumulators.
 template <int L, int NT0, int C, bool HP, int PD>
-DEDF_DEV void mfma_chunk(const Wave& wv, int o_str, AItem (&ring)[PD], const BOpsH<L>& bo, f32x16 (&acc0)[NT0], f32x16 (&acc1)[3], f32x16 (&acc2)[5]) {
+DEDF_DEV void mfma_chunk(const Wave& wv, int o_str, AItem (&ring)[PD], const BOpsH<L>& bo, f32x16 (&acc0)[NT0], f32x16 (&acc1)[3], f32x16 (&acc2)[5],
+                         f32x16 (&go)[3]) {
     constexpr int l3 = dtp_pos_l3<L>(C), I0 = dtp_item_first<L>(C, NT0), NI = l3 == 0 ? cdiv(NT0, 2) : 1;
+    if constexpr (dtp_pos_out<L>(C)) {
+        constexpr int d1 = 2 * dtp_pos_path<L>(C).l1 + 1;
+        static_assert(d1 == 1 || d1 == 3, "output-side paths of lmax <= 2");
+        constexpr bool first = dtp_pos_path_first<L>(C);
+        const AItem a = ring[I0 % PD];
+        ring[I0 % PD] = load_item<L, NT0, I0 + PD, HP>(wv, o_str);
+        const h8 ah = __builtin_bit_cast(h8, a.h[0]), al = __builtin_bit_cast(h8, a.l[0]);
+        const f32x16 zero = {};
+        if constexpr (d1 == 1) {
+            go[0] = mfma_h(ah, bo.hi[0], first ? zero : go[0]);
+            if constexpr (!HP) { go[1] = mfma_h(ah, bo.lo[0], first ? zero : go[1]); go[2] = mfma_h(al, bo.hi[0], first ? zero : go[2]); }
+        } else {
+            static_for<3>([&]<int i>() { go[i] = mfma_h(ah, bo.hi[i], first ? zero : go[i]); });
+            if constexpr (!HP) {
+                static_for<3>([&]<int i>() { go[i] = mfma_h(ah, bo.lo[i], go[i]); });
+                static_for<3>([&]<int i>() { go[i] = mfma_h(al, bo.hi[i], go[i]); });
+            }
+        }
+    } else
     static_for<NI>([&]<int t>() {
         constexpr int I = I0 + t;
         const AItem a = ring[I % PD];
@@ -411,6 +433,19 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             constexpr PathInfo pi = dtp_pos_path<L>(C);
             constexpr int l1 = pi.l1, l2 = pi.l2, l3 = pi.l3, d1 = 2 * l1 + 1, d3 = 2 * l3 + 1, c2 = C % 2;
             using Cg = CG<l1, l2, l3>;
+            if constexpr (dtp_pos_out<L>(C)) {      // output-side: B_i = w x_i, no contraction here
+                float v[d1][8];
+                static_for<2>([&]<int run>() {
+                    static_for<d1>([&]<int Q>() { static_for<4>([&]<int i>() {
+                        // element 4 Q + i of the run = component (4 Q + i) % d1 of channel (4 Q + i) / d1
+                        constexpr int ch = (4 * Q + i) / d1, cmp = (4 * Q + i) % d1;
+                        float x;
+                        if constexpr (UN) x = xo.x[run][Q][i] + xo.xd[run][Q][i]; else x = xo.x[run][Q][i];
+                        v[cmp][4 * run + ch] = x * wtile[8 * c2 + 4 * run + ch];
+                    }); });
+                });
+                static_for<d1>([&]<int I>() { const HL sp = split8(v[I]); o.hi[I] = sp.hi; o.lo[I] = sp.lo; });
+            } else {
             float m[Cg::NM];
             Cg::make(Y.template get<l2>(), m);
             float v[d3][8];
@@ -426,6 +461,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 });
             });
             split_chunk<L, l3>(v, o);
+            }
         }
         return o;
     };
@@ -468,6 +504,33 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     auto dump_w = [&]<int Tw>(const f32x16& w) {      // debug only: back to the e3nn weight order
         if (P.dbg_w != nullptr && valid)
             static_for<16>([&]<int R>() { P.dbg_w[(size_t)e * WN + dtp_walk_row<L>(Tw * 32 + (R & 3) + 8 * (R >> 2)) + 4 * hi] = w[R] * P.w_unscale; });
+    };
+
+    // Output-side paths (dedf_net.h::dtp_path_out_side): G tiles of the path in flight, VALU-side sums of the contracted results per
+    // output degree, and the contraction of a completed path  vacc[k] += (sum_j C_ijk Y_j) G_i  (one region after its last MFMAs).
+    f32x16 go[3], gfin[3];
+    float vacc1[3][16], vacc2[5][8];
+    auto contract_out = [&]<int Ce>(f32x16 (&G)[3]) {
+        constexpr PathInfo pi = dtp_pos_path<L>(Ce);
+        constexpr int l1 = pi.l1, l2 = pi.l2, l3 = pi.l3, d1 = 2 * l1 + 1, d3 = 2 * l3 + 1;
+        constexpr int NR = mul_of(l3) >= 32 ? 16 : mul_of(l3) / 2;
+        using Cg = CG<l1, l2, l3>;
+        float m[Cg::NM];
+        Cg::make(Y.template get<l2>(), m);
+        static_for<NR>([&]<int R>() {
+            float o[d3];
+            static_for<d3>([&]<int K>() {
+                if constexpr (dtp_pos_opens_vacc<L>(Ce)) o[K] = 0.0f;
+                else if constexpr (l3 == 1) o[K] = vacc1[K][R];
+                else o[K] = vacc2[K][R];
+            });
+            if constexpr (d1 == 1) Cg::template acc<0>(HP ? G[0][R] : (G[0][R] + G[1][R]) + G[2][R], m, o);      // the three product terms
+            else static_for<d1>([&]<int I>() { Cg::template acc<I>(G[I][R], m, o); });
+            static_for<d3>([&]<int K>() {
+                opaque_v(o[K]);      // accumulate here (see the value stage)
+                if constexpr (l3 == 1) vacc1[K][R] = o[K]; else vacc2[K][R] = o[K];
+            });
+        });
     };
 
     // activations of a completed group ----------------------------------------------------------------------------------
@@ -519,13 +582,18 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         } else if constexpr (l3 == 1) {
             static_for<3>([&]<int K>() { static_for<2>([&]<int hf>() {
                 float v[8];
-                static_for<8>([&]<int J>() { v[J] = acc1[K][8 * hf + J] * g1[8 * hf + J]; });
+                static_for<8>([&]<int J>() {
+                    if constexpr (dtp_group_has_out<L>(1)) v[J] = (acc1[K][8 * hf + J] + vacc1[K][8 * hf + J]) * g1[8 * hf + J];
+                    else v[J] = acc1[K][8 * hf + J] * g1[8 * hf + J];
+                });
                 park_chunk.template operator()<park_slot<L>(1, K, hf)>(v);
             }); });
         } else {
             static_for<5>([&]<int K>() {      // 16 channels = registers 0-7
                 float v[8];
-                static_for<8>([&]<int J>() { v[J] = acc2[K][J] * g2[J]; });
+                static_for<8>([&]<int J>() {
+                    if constexpr (dtp_group_has_out<L>(2)) v[J] = (acc2[K][J] + vacc2[K][J]) * g2[J]; else v[J] = acc2[K][J] * g2[J];
+                });
                 park_chunk.template operator()<park_slot<L>(2, K, 0)>(v);
             });
         }
@@ -582,7 +650,10 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         if constexpr (Ph % 2 == 0) run_l3.template operator()<Ph>(l3c, offc, wbuf[T3 % 2]);
         else run_l3.template operator()<Ph>(l3c, wbuf[T3 % 2], wbuf[T3 % 2]);
         const BOpsH<L> b_nxt = valu_chunk.template operator()<C + 1>(x_nxt, wbuf[((C + 1) / 2) % 2]);
-        mfma_chunk<L, NR0, C, HP>(wv, o_S_lin, ring, b_cur, acc0, acc1, acc2);
+        constexpr bool fin_out = C >= 1 && dtp_pos_out<L>(C - 1) && dtp_pos_path_last<L>(C - 1);      // an output-side path ended at C - 1
+        if constexpr (fin_out) static_for<3>([&]<int a>() { gfin[a] = go[a]; });
+        mfma_chunk<L, NR0, C, HP>(wv, o_S_lin, ring, b_cur, acc0, acc1, acc2, go);
+        if constexpr (fin_out) contract_out.template operator()<C - 1>(gfin);
         static_for<L + 1>([&]<int g>() { if constexpr (C == dtp_group_end<L>(g)) finish_group.template operator()<g>(); });
         sched_fence();
         if constexpr (Ph % 2 == 1 && T3 < NWT) dump_w.template operator()<T3>(wbuf[T3 % 2]);
@@ -590,6 +661,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         if constexpr (C + 1 == dtp_group_end<L>(0)) DEDF_STAMP(8);
         if constexpr (L >= 2 && C + 1 == dtp_group_end<L>(1)) DEDF_STAMP(9);
     });
+    if constexpr (dtp_pos_out<L>(NCHK - 1)) contract_out.template operator()<NCHK - 1>(go);
     finish_group.template operator()<L>();
     sched_fence();
     DEDF_STAMP(12);

@@ -95,17 +95,29 @@ template <int L> inline std::vector<KStep> dtp_steps(int l3) {
 // channel chunk_row(k16) of the chunk: the register order of a row-layout tile.
 DEDF_HD constexpr int chunk_row(int k16) { const int h = k16 >> 3, jj = k16 & 7; return (jj & 3) + 8 * (jj >> 2) + 4 * h; }
 template <int L> struct DtpWalk { int chunk[64]; PathInfo path[64]; int n; };
+// A path whose input degree is lower than its output degree is evaluated in OUTPUT-SIDE form by the edge kernel's first depth-wise TP
+// as well (see make_val_walk): B operands = per-edge weight x message component (2 l1 + 1 of them per channel instead of the 2 l3 + 1
+// contracted ones), the contraction with the SH follows the GEMM.  Fewer operand splits, MFMAs and Clebsch-Gordan multiply-adds.
+template <int L> DEDF_HD constexpr bool dtp_path_out_side(const PathInfo& pi) { return pi.l1 < pi.l3; }
 template <int L> DEDF_HD constexpr DtpWalk<L> make_dtp_walk() {
     DtpWalk<L> w{};
     int n = 0;
-    for (int l3 = 0; l3 <= L; ++l3)
+    for (int l3 = 0; l3 <= L; ++l3) {
+        // input-side paths: by input degree and channel range, so that consecutive chunks of different paths share their source rows
         for (int l1 = 0; l1 <= L; ++l1)
             for (int c = 0; c < mul_of(l1) / 16; ++c)
                 for (int q = 0; q < dtp_num_paths<L>(); ++q) {
                     const PathInfo pi = dtp_path<L>(q);
-                    if (pi.l3 != l3 || pi.l1 != l1) continue;
+                    if (pi.l3 != l3 || pi.l1 != l1 || dtp_path_out_side<L>(pi)) continue;
                     w.chunk[n] = pi.wstart / 16 + c; w.path[n] = pi; ++n;
                 }
+        // output-side paths last (their contraction then meets the group's activations), every path's chunks contiguous
+        for (int q = 0; q < dtp_num_paths<L>(); ++q) {
+            const PathInfo pi = dtp_path<L>(q);
+            if (pi.l3 != l3 || !dtp_path_out_side<L>(pi)) continue;
+            for (int c = 0; c < mul_of(pi.l1) / 16; ++c) { w.chunk[n] = pi.wstart / 16 + c; w.path[n] = pi; ++n; }
+        }
+    }
     w.n = n;
     for (int i = n; i < 64; ++i) { w.chunk[i] = dtp_wn<L>() / 16; w.path[i] = PathInfo{-1, -1, -1, 0, 0, 0, 0}; }
     return w;
@@ -120,6 +132,21 @@ template <int L> DEDF_HD constexpr int dtp_pos_channel(int p, int k16) { return 
 // chunks p and q read the same input channels (same l1, same channel range)
 template <int L> DEDF_HD constexpr bool dtp_pos_same_x(int p, int q) {
     return p >= 0 && q >= 0 && p < dtp_wn<L>() / 16 && q < dtp_wn<L>() / 16 && dtp_pos_path<L>(p).l1 == dtp_pos_path<L>(q).l1 && dtp_pos_u0<L>(p) == dtp_pos_u0<L>(q);
+}
+// output-side chunk at walk position p?  first / last chunk of its path?
+template <int L> DEDF_HD constexpr bool dtp_pos_out(int p) { return p >= 0 && p < dtp_wn<L>() / 16 && dtp_path_out_side<L>(dtp_pos_path<L>(p)); }
+template <int L> DEDF_HD constexpr bool dtp_pos_path_first(int p) { return dtp_pos_u0<L>(p) == 0; }
+template <int L> DEDF_HD constexpr bool dtp_pos_path_last(int p) { return dtp_pos_u0<L>(p) + 16 == dtp_pos_path<L>(p).mul1; }
+// the output-side path ending at p is the first of its output degree to be contracted (the VALU-side accumulators start there)
+template <int L> DEDF_HD constexpr bool dtp_pos_opens_vacc(int p) {
+    if (!dtp_pos_out<L>(p) || !dtp_pos_path_last<L>(p)) return false;
+    for (int q = 0; q < p; ++q)
+        if (dtp_pos_out<L>(q) && dtp_pos_path_last<L>(q) && dtp_pos_l3<L>(q) == dtp_pos_l3<L>(p)) return false;
+    return true;
+}
+template <int L> DEDF_HD constexpr bool dtp_group_has_out(int l3) {
+    for (int q = 0; q < dtp_wn<L>() / 16; ++q) if (dtp_pos_out<L>(q) && dtp_pos_l3<L>(q) == l3) return true;
+    return false;
 }
 // e3nn weight row held by row r of the (walk-ordered) last radial layer
 template <int L> DEDF_HD constexpr int dtp_walk_row(int r) { return dtp_pos_chunk<L>(r / 16) * 16 + r % 16; }

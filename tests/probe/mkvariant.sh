@@ -13,6 +13,7 @@ APIO=$C/_obj/api.o
 if [ -n "$API" ]; then APIO=$C/_obj/api_$NAME.o; hipcc $F -c "$@" $C/dedf_api.hip -o $APIO & fi
 wait
 OBJS="$APIO $C/_obj/k0_$NAME.o"
-for u in 1 2 3 4 5 6 7 8 9; do OBJS="$OBJS $C/_obj/k$u.o"; done
+NU=$(grep -o "kKernelUnits = [0-9]*" $C/dedf_kernels.h | grep -o "[0-9]*$")
+for u in $(seq 1 $((NU - 1))); do OBJS="$OBJS $C/_obj/k$u.o"; done
 hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $C/libdedf_$NAME.so
 echo built $C/libdedf_$NAME.so
