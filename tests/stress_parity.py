@@ -99,6 +99,17 @@ def run_case(i, rng):
         print(f"   (edge count differs from the fp64 restatement {dbg['n_edges_per_scale']}; fp32 restatement {d32['n_edges_per_scale']})")
     desc = (f"lmax {cfg.lmax} radii {cfg.radii} fc {cfg.fc_neurons} temb {cfg.time_emb_mlp[0]} pattn {cfg.use_src_point_attn} cap {max_nb} "
             f"keys {[len(k.x) for k in keys]} nQ {len(query.x)} nT {len(Ts)} E {dbg['n_edges_per_scale']}")
+    if err >= 1e-4 and edges_ok:
+        # ill-conditioned case?  The reference computes in fp32: if ITS arithmetic (the fp32 restatement) is as far from fp64 as the
+        # kernel is, and the kernel agrees with the fp32 restatement to 2e-5, the case says nothing about the kernel (seen once in 200
+        # cases: seed 101 case 182, fp32 restatement 2.6e-4 from fp64, kernel 6.7e-6 from the fp32 restatement)
+        ok32 = [R.FeaturedPoints(k.x, k.f, k.b, k.w) for k in keys]
+        a32, l32 = R.score_head_forward(ocfg, R.cast_params(P, torch.float32), Ts.float(), ok32, R.FeaturedPoints(query.x, query.f, query.b, query.w), time.float())
+        gap = max(float((a32.double() - ang64).abs().max()), float((l32.double() - lin64).abs().max())) / scale
+        e32 = max(float((ang.cpu().double() - a32.double()).abs().max()), float((lin.cpu().double() - l32.double()).abs().max())) / scale
+        print(f"   (fp32 restatement vs fp64: {gap:.2e}; kernel vs fp32 restatement: {e32:.2e})")
+        if e32 < 2e-5 and gap > 0.5 * err:
+            err = e32
     print(f"case {i:3d} err {err:.2e} edges_ok {edges_ok}  {desc}", flush=True)
     return err, edges_ok, desc
 
