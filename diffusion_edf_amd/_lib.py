@@ -19,7 +19,7 @@ SYMBOLS = [
     "dedf_version", "dedf_param_count", "dedf_param_name", "dedf_param_numel", "dedf_create", "dedf_destroy",
     "dedf_last_error", "dedf_set_key_clouds", "dedf_set_key_weights", "dedf_set_query", "dedf_score", "dedf_energy", "dedf_sample", "dedf_get_stats",
     "dedf_debug_enable", "dedf_debug_copy", "dedf_debug_packed", "dedf_profile_enable", "dedf_profile_read",
-    "dedf_fps", "dedf_radius", "dedf_layer_forward",
+    "dedf_fps", "dedf_radius", "dedf_layer_forward", "dedf_linear_rs",
 ]
 
 
@@ -30,7 +30,7 @@ class DedfConfig(C.Structure):
         ("radii", C.c_float * MAX_SCALES), ("r_mincut_nonscalar_sh", C.c_float), ("length_enc_max_r", C.c_float),
         ("max_time", C.c_float), ("time_enc_n", C.c_float), ("lin_mult", C.c_float), ("ang_mult", C.c_float),
         ("max_neighbors", C.c_int), ("device", C.c_int), ("max_edges", C.c_int64), ("ebm", C.c_int), ("half_gemm", C.c_int), ("use_src_point_attn", C.c_int),
-        ("unet_layer", C.c_int),
+        ("unet_layer", C.c_int), ("unet_valid", C.c_int * 3), ("unet_fc_valid", C.c_int * 3),
     ]
 
 
@@ -88,6 +88,8 @@ def load() -> C.CDLL:
     lib.dedf_layer_forward.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]
     lib.dedf_layer_forward.restype = C.c_int
+    lib.dedf_linear_rs.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_int), C.c_void_p, C.c_void_p]
+    lib.dedf_linear_rs.restype = C.c_int
     lib.dedf_get_stats.argtypes = [C.c_void_p, P(DedfStats)]; lib.dedf_get_stats.restype = C.c_int
     lib.dedf_debug_enable.argtypes = [C.c_void_p, C.c_int]; lib.dedf_debug_enable.restype = C.c_int
     lib.dedf_debug_copy.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, P(C.c_size_t)]; lib.dedf_debug_copy.restype = C.c_int
@@ -129,8 +131,9 @@ def make_config(cfg: HeadConfig, device: int, max_edges: int = 0) -> DedfConfig:
 
 
 def make_unet_layer_config(radius: float, device: int, fc_neurons=(64, 32, 32), muls=(64, 32, 16), num_heads: int = 4,
-                           irreps_mlp_mid: int = 3) -> DedfConfig:
-    """dedf_config of ONE UNet layer (dedf_config.unet_layer = 1): irreps 64x0e+32x1e+16x2e, radial MLP [64,32,32]"""
+                           irreps_mlp_mid: int = 3, valid=None, fc_valid=None) -> DedfConfig:
+    """dedf_config of ONE UNet layer (dedf_config.unet_layer = 1): irreps 64x0e+32x1e+16x2e, radial MLP [64,32,32]; `valid` / `fc_valid`:
+    true multiplicities / radial widths of a narrower model that runs zero-padded (dedf.h: unet_valid, unet_fc_valid)"""
     c = DedfConfig()
     c.lmax = len(muls) - 1
     for i, m in enumerate(muls):
@@ -145,6 +148,9 @@ def make_unet_layer_config(radius: float, device: int, fc_neurons=(64, 32, 32), 
     c.max_neighbors = 1000
     c.device = device
     c.unet_layer = 1
+    for i in range(3):
+        c.unet_valid[i] = 0 if valid is None else int(valid[i])
+        c.unet_fc_valid[i] = 0 if fc_valid is None else int(fc_valid[i])
     return c
 
 

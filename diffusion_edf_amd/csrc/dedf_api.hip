@@ -130,6 +130,10 @@ int check_config(const dedf_config* c, std::string& why) {
         if (c->irreps_mlp_mid != kMlpMid) { why = "irreps_mlp_mid must be 3"; return DEDF_ERR_UNSUPPORTED; }
         if (c->n_scales != 1 || !(c->radii[0] > 0)) { why = "UNet layer: n_scales = 1 and radii[0] = the level's connection radius"; return DEDF_ERR_INVALID; }
         if (c->ebm || c->half_gemm || c->use_src_point_attn) { why = "UNet layer: ebm / half_gemm / use_src_point_attn do not apply"; return DEDF_ERR_UNSUPPORTED; }
+        for (int l = 0; l < 3; ++l) {
+            if (c->unet_valid[l] < 0 || c->unet_valid[l] > c->mul[l] || (c->unet_valid[l] > 0 && c->unet_valid[l] % 4)) { why = "UNet layer: unet_valid[l] must be 0 or a multiple of 4 up to mul[l]"; return DEDF_ERR_INVALID; }
+            if (c->unet_fc_valid[l] < 0 || c->unet_fc_valid[l] > c->fc_neurons[l]) { why = "UNet layer: unet_fc_valid out of range"; return DEDF_ERR_INVALID; }
+        }
         return DEDF_OK;
     }
     if (c->lmax != 1 && c->lmax != 2) { why = "lmax must be 1 or 2 (lmax 3 is a next-row item)"; return DEDF_ERR_UNSUPPORTED; }
@@ -713,6 +717,10 @@ int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const floa
         P.msg_dst = h->d_msg_dst.as<float>(); P.msg_dst_bytes = (uint32_t)((size_t)n_dst * D * 4);
         P.tb = nullptr; P.tb_bytes = 0; P.tb_pose_stride = 0;
         P.nQ = 1; P.n_scales = 1;
+        for (int i = 0; i < 2; ++i) {      // masked LayerNorms of the radial MLP (true widths of a padded model)
+            const int full = c.fc_neurons[1 + i], v = c.unet_fc_valid[1 + i] > 0 ? c.unet_fc_valid[1 + i] : full;
+            P.ln_inv_n[i] = 1.0f / (float)v; P.ln_pad[i] = (float)(full - v);
+        }
         // GaussianRadialBasisLayerFiniteCutoff(cutoff = 0.99 r): offset = 0.01 cutoff; t = (len - offset) / (cutoff - offset)
         const float cutoff = (float)(0.99 * (double)c.radii[0]), offset = (float)(0.01 * (double)cutoff);
         P.radius[0] = cutoff - offset; P.cut_begin[0] = offset; P.cut_div[0] = 1.0f;
@@ -738,6 +746,8 @@ int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const floa
         P.f_dst = f_dst; P.f_dst_bytes = (uint32_t)((size_t)n_dst * D * 4);
         P.feat_out = out;
         P.nQ = 1; P.n_nodes = n_dst; P.lin_mult = 1.0f;
+        for (int l = 0; l < 3; ++l) P.ln_inv_n[l] = 1.0f / (float)(c.unet_valid[l] > 0 ? c.unet_valid[l] : c.mul[l]);
+        P.ln_pad0 = (float)(c.mul[0] - (c.unet_valid[0] > 0 ? c.unet_valid[0] : c.mul[0]));
         P.W = h->d_node_w.as<float>(); P.W_bytes = (uint32_t)h->d_node_w.bytes;
         const NodeOffsets& o = h->no;
         for (int l = 0; l < 4; ++l) {
@@ -856,6 +866,17 @@ int dedf_debug_packed(dedf_handle* h, const char* which, const float** ptr, size
     *ptr = im.data.data();
     *n_floats = im.data.size();
     return DEDF_OK;
+}
+
+// ---- per-node LayerNorm + LinearRS (no handle; current device; device pointers) --------------------------------------------------
+int dedf_linear_rs(const float* f, int n, const float* ln_w, const float* ln_b, const float* W, const float* bias, const int* valid,
+                   float* out, void* stream) {
+    if (!f || !W || !out || n <= 0 || ((ln_w == nullptr) != (ln_b == nullptr))) return DEDF_ERR_INVALID;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int v0 = valid ? valid[0] : 0, v1 = valid ? valid[1] : 0, v2 = valid ? valid[2] : 0;
+    if (ln_w) hipLaunchKernelGGL((k_src_message<2, true>), dim3(n), dim3(64), 0, st, f, n, ln_w, ln_b, W, bias, out, v0, v1, v2);
+    else hipLaunchKernelGGL((k_src_message<2, false>), dim3(n), dim3(64), 0, st, f, n, ln_w, ln_b, W, bias, out, 0, 0, 0);
+    return hipGetLastError() == hipSuccess ? DEDF_OK : DEDF_ERR_RUNTIME;
 }
 
 // ---- graph primitives of the feature extractors (no handle; current device; device pointers) ------------------------------------

@@ -28,6 +28,7 @@ struct EdgeParams {
     uint32_t msg_bytes;
     const float* msg_dst;     // UNet layer only: [N_d][D] destination message (linear_dst), reference layout
     uint32_t msg_dst_bytes;
+    float ln_inv_n[2], ln_pad[2];   // UNet layer only: 1 / true width and number of padded channels of the radial MLP's two LayerNorms
     const float* tb;          // [(nT|1)][n_scales][F0] row-packed: W_pre[:,64:] c_t + b_pre  (b_pre alone when F0 = 64)
     uint32_t tb_bytes;
     int tb_pose_stride;       // floats; 0 when every pose shares the time (sampler)
@@ -95,16 +96,21 @@ DEDF_DEV f32x16 ldrows_lds(const float* rows, int hi, int off, int tile) {
 }
 
 // LayerNorm over NT*32 channels of one item (rows split over lane and lane^32) followed by SiLU
-template <int NT>
-DEDF_DEV void ln_silu(f32x16 (&x)[NT], const Wave& wv, const float* rows, int o_gamma, int o_beta) {
+// MASKED (UNet layers whose true width is smaller than the instantiated one): only the first n channels are real, the others are exactly
+// 0 on entry (zero-padded weights and biases) and must stay out of the statistics: mean = sum / n, and every padded channel
+// contributes exactly mean^2 to sum (x - mean)^2, which is taken out again (inv_n = 1 / n, n_pad = NT * 32 - n); their affine
+// parameters are zero, so they leave as SiLU(0) = 0.
+template <int NT, bool MASKED = false>
+DEDF_DEV void ln_silu(f32x16 (&x)[NT], const Wave& wv, const float* rows, int o_gamma, int o_beta, float inv_n = 0.0f, float n_pad = 0.0f) {
     float s = 0.0f;
     static_for<NT>([&]<int T>() { static_for<16>([&]<int R>() { s += x[T][R]; }); });
     s += xor32(s);
-    const float mean = s * (1.0f / (NT * 32));
+    const float mean = MASKED ? s * inv_n : s * (1.0f / (NT * 32));
     float v = 0.0f;
     static_for<NT>([&]<int T>() { static_for<16>([&]<int R>() { const float d = x[T][R] - mean; v += d * d; }); });
     v += xor32(v);
-    const float rstd = 1.0f / sqrtf(v * (1.0f / (NT * 32)) + 1e-5f);
+    if constexpr (MASKED) v = fmaxf(v - n_pad * (mean * mean), 0.0f);
+    const float rstd = 1.0f / sqrtf(v * (MASKED ? inv_n : 1.0f / (NT * 32)) + 1e-5f);
     static_for<NT>([&]<int T>() {
         const f32x16 g = ldrows_lds(rows, wv.hi, o_gamma, T), b = ldrows_lds(rows, wv.hi, o_beta, T);
         float y[16];
@@ -372,7 +378,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     auto ring_r2 = dense_prefetch<NT2, H1 / 16, 2, HP>(wv, o_A_r2, o_A_r2_l);      // layer 2's first operands: under the LayerNorm below
     sched_fence();
     static_for<NT1>([&]<int To>() { to_vgpr(r1[To]); });
-    ln_silu<NT1>(r1, wv, rows, RL::g1, RL::be1);
+    ln_silu<NT1, UN>(r1, wv, rows, RL::g1, RL::be1, P.ln_inv_n[0], P.ln_pad[0]);
     DEDF_STAMP(3);
     f32x16 r2[NT2];
     static_for<NT2>([&]<int To>() { r2[To] = ldrows_lds(rows, hi, RL::b2, To); });
@@ -617,7 +623,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         sched_fence();
         // layer 2's LayerNorm + SiLU and the split of its output (B operands of layer 3), under the requests above
         static_for<NT2>([&]<int To>() { to_vgpr(r2[To]); });
-        ln_silu<NT2>(r2, wv, rows, RL::g2, RL::be2);
+        ln_silu<NT2, UN>(r2, wv, rows, RL::g2, RL::be2, P.ln_inv_n[1], P.ln_pad[1]);
         DEDF_STAMP(5);
         static_for<KC>([&]<int c>() {
             float t[8];

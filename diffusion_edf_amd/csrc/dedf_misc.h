@@ -150,9 +150,13 @@ __global__ __launch_bounds__(256) void k_time_bias(TimeParams P) {
 // (gnn_block.py:170-171, layer_norm.py:91-156, tensor_product_rescale.py:176-185).  One block (64 threads) per point.
 // NORM = false: LinearRS only, `bias` may be null (the linear_src / linear_dst of a UNet block: block.py:149-153 overwrites the
 // LayerNorm outputs, so the linears see the raw features).
+// v0..v2: true multiplicities for the LayerNorm statistics of zero-padded models (0 = all channels): the padded channels are exactly 0
+// and their affine weights are 0; the mean is taken over the true channels and the mean^2 each padded 0e channel adds to the variance
+// sum is taken out again.
 template <int L, bool NORM = true>
 __global__ void k_src_message(const float* __restrict__ f, int n_pts, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-                              const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ msg) {
+                              const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ msg,
+                              int v0 = 0, int v1 = 0, int v2 = 0) {
     constexpr int D = feat_dim<L>();
     __shared__ float x[D], red[2];
     const int pt = blockIdx.x, tid = threadIdx.x;
@@ -164,15 +168,17 @@ __global__ void k_src_message(const float* __restrict__ f, int n_pts, const floa
         const int m = mul_of(l), d = 2 * l + 1, off = blk_off(l);
         // statistics of block l (serial in thread 0: 240 values, runs once per scene)
         if (tid == 0) {
+            const int vl = l == 0 ? v0 : (l == 1 ? v1 : v2), mv = vl > 0 ? vl : m;
             float mean = 0.0f;
-            if (l == 0) { for (int c = 0; c < m; ++c) mean += x[off + c]; mean /= m; }
+            if (l == 0) { for (int c = 0; c < m; ++c) mean += x[off + c]; mean /= mv; }
             float v = 0.0f;
             for (int c = 0; c < m; ++c) {
                 float s = 0.0f;
                 for (int k = 0; k < d; ++k) { const float t = x[off + c * d + k] - mean; s += t * t; }
                 v += s / d;
             }
-            red[0] = mean; red[1] = 1.0f / sqrtf(v / m + 1e-5f);
+            v = fmaxf(v - (float)(m - mv) * (mean * mean), 0.0f);
+            red[0] = mean; red[1] = 1.0f / sqrtf(v / mv + 1e-5f);
         }
         __syncthreads();
         const float mean = red[0], rs = red[1];

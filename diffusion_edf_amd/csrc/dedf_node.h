@@ -35,6 +35,7 @@ struct NodeParams {
     NodeScales sc;                             // accumulator -> true value, per matrix
     const float* f_dst; uint32_t f_dst_bytes;  // UNet layer only: [N_d][D] destination input features (first skip connection, block.py:165)
     float* feat_out;                           // UNet layer only: [N_d][D] output features, reference layout
+    float ln_inv_n[3], ln_pad0;                // UNet layer only: 1 / (true multiplicity) per degree and the number of padded 0e channels (masked norm_2)
     float* node_out;                           // [N_d][8]: w*lin_vel (3), w*(ang_orbital + ang_spin) (3), 0, 0
     float* dbg_emb;                            // optional [N_d][D] dumps (internal layout) of the proj output and of the field (tests)
     float* dbg_field;
@@ -187,11 +188,13 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         float s = 0.0f;
         static_for<2>([&]<int T>() { static_for<16>([&]<int R>() { s += emb.s[T][R]; }); });
         s += xor32(s);
-        const float mean = s * (1.0f / 64);
+        // (UN: masked statistics over the true channels only, see dedf_edge.h::ln_silu)
+        const float mean = UN ? s * P.ln_inv_n[0] : s * (1.0f / 64);
         float v = 0.0f;
         static_for<2>([&]<int T>() { static_for<16>([&]<int R>() { const float d = emb.s[T][R] - mean; v += d * d; }); });
         v += xor32(v);
-        const float rs = 1.0f / sqrtf(v * (1.0f / 64) + 1e-5f);
+        if constexpr (UN) v = fmaxf(v - P.ln_pad0 * (mean * mean), 0.0f);
+        const float rs = 1.0f / sqrtf(v * (UN ? P.ln_inv_n[0] : 1.0f / 64) + 1e-5f);
         static_for<2>([&]<int T>() {
             const f32x16 w = node_ldrows(rows, hi, NR::ln_w0, T), b = node_ldrows(rows, hi, NR::ln_b0, T);
             static_for<16>([&]<int R>() { nrm.s[T][R] = (emb.s[T][R] - mean) * (rs * w[R]) + b[R]; });
@@ -201,7 +204,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         float v = 0.0f;
         static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { v += emb.v1[m][R] * emb.v1[m][R]; }); });
         v += xor32(v);
-        const float rs = 1.0f / sqrtf(v * (1.0f / (3 * 32)) + 1e-5f);
+        const float rs = 1.0f / sqrtf(v * (UN ? P.ln_inv_n[1] * (1.0f / 3) : 1.0f / (3 * 32)) + 1e-5f);
         const f32x16 w = node_ldrows(rows, hi, NR::ln_w1, 0);
         static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { nrm.v1[m][R] = emb.v1[m][R] * (rs * w[R]); }); });
     }
@@ -209,7 +212,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         float v = 0.0f;
         static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { v += emb.v2[m][R] * emb.v2[m][R]; }); });
         v += xor32(v);
-        const float rs = 1.0f / sqrtf(v * (1.0f / (5 * 16)) + 1e-5f);
+        const float rs = 1.0f / sqrtf(v * (UN ? P.ln_inv_n[2] * (1.0f / 5) : 1.0f / (5 * 16)) + 1e-5f);
         const f32x16 w = node_ldrows(rows, hi, NR::ln_w2, 0);
         static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { nrm.v2[m][R] = emb.v2[m][R] * (rs * w[R]); }); });
     }

@@ -267,7 +267,9 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
                     const float sd = softplusf(sl[k]) + 1e-5f;
                     e[0 + hi * 32 + s] = mu[k] + 0.0f;
                     e[64 + hi * 32 + s] = 1.0f / sd;
-                    e[128 + hi * 32 + s] = (1.0f / (1.0f + std::exp(-wl[k]))) * (4.0f * std::sqrt((float)c.length_emb_dim));
+                    // (UNet layer narrower than instantiated: the normaliser is sqrt(true num_basis), radial_func.py:259)
+                    const float nbasis = (float)(un && c.unet_fc_valid[0] > 0 ? c.unet_fc_valid[0] : c.length_emb_dim);
+                    e[128 + hi * 32 + s] = (1.0f / (1.0f + std::exp(-wl[k]))) * (4.0f * std::sqrt(nbasis));
                 }
             } else {
                 const double step = std::log(1000.0) / (32 - 1);

@@ -300,12 +300,14 @@ def n_params(cfg: HeadConfig) -> int:
 # --------------------------------------------------------------------------------------------------
 
 def unet_layer_param_spec(irreps: Irreps, fc_neurons: List[int], num_heads: int = 4, lmax_sh: int = 2,
-                          irreps_mlp_mid: int = 3) -> List[Tuple[str, Tuple[int, ...], str, float]]:
+                          irreps_mlp_mid: int = 3, irreps_src: Optional[Irreps] = None) -> List[Tuple[str, Tuple[int, ...], str, float]]:
     """Schema of the ModuleDict {'radial': GaussianRadialBasisLayerFiniteCutoff, 'gnn': block.EquiformerBlock} the reference builds
-    for every UNet layer (unet_feature_extractor.py:141-156; names = its state_dict keys below e.g. ``down_blocks.3.pool_layer.``),
-    irreps_src == irreps_dst.  Same tuple format as ``param_spec``."""
+    for every UNet layer (unet_feature_extractor.py:141-156; names = its state_dict keys below e.g. ``down_blocks.3.pool_layer.``).
+    ``irreps`` = irreps_dst = the block's irreps_emb; ``irreps_src`` (default: the same) only shapes norm_1_src / linear_src
+    (block.py:108-109).  Same tuple format as ``param_spec``."""
     S: List[Tuple[str, Tuple[int, ...], str, float]] = []
     muls = [m for m, _ in irreps]
+    muls_src = muls if irreps_src is None else [m for m, _ in irreps_src]
     L, n0, nirr = len(muls) - 1, muls[0], sum(muls)
     nb = fc_neurons[0]
     S.append(("radial.mean", (1, nb), 'linspace', 0.0))                                             # radial_func.py:242-243
@@ -313,8 +315,9 @@ def unet_layer_param_spec(irreps: Irreps, fc_neurons: List[int], num_heads: int 
     S.append(("radial.weight_logit", (1, nb), 'const', -math.log(4.0 / 1. - 1)))                    # :251-252
     g = "gnn"
     sq = 'tp_w:' + ','.join(f"{m*m}:{m}" for m in muls)
-    S.append((f"{g}.norm_1_src.affine_weight", (nirr,), 'ones', 0)); S.append((f"{g}.norm_1_src.affine_bias", (n0,), 'zeros', 0))
-    S.append((f"{g}.linear_src.tp.weight", (sum(m * m for m in muls),), sq, 0))                        # src_bias=False
+    S.append((f"{g}.norm_1_src.affine_weight", (sum(muls_src),), 'ones', 0)); S.append((f"{g}.norm_1_src.affine_bias", (muls_src[0],), 'zeros', 0))
+    S.append((f"{g}.linear_src.tp.weight", (sum(a * b for a, b in zip(muls_src, muls)),),
+              'tp_w:' + ','.join(f"{a*b}:{a}" for a, b in zip(muls_src, muls)), 0))                    # src_bias=False
     S.append((f"{g}.norm_1_dst.affine_weight", (nirr,), 'ones', 0)); S.append((f"{g}.norm_1_dst.affine_bias", (n0,), 'zeros', 0))
     S.append((f"{g}.linear_dst.tp.weight", (sum(m * m for m in muls),), sq, 0))
     S.append((f"{g}.linear_dst.bias.0", (n0,), 'zeros', 0))

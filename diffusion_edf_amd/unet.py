@@ -12,10 +12,11 @@ and applies it to a bipartite graph ``edge_src -> edge_dst`` with ``edge_vec = x
 (``dedf_layer_forward``: the fused edge kernel in its UNet mode — destination message added, radial basis read by the radial MLP
 directly, no edge logits — the joint-softmax aggregation, and the node kernel with the block's two skip connections).
 
-Instantiated for ``irreps_src = irreps_dst = 64x0e+32x1e+16x2e`` with ``fc_neurons [64, 32, 32]``: levels 2 and 3 and the mid block of
-every UNet the reference ships (``configs/*/*/score_model_configs.yaml: irreps_emb[2:]``).  The two fine levels (``32x0e+16x1e+8x2e``,
-``[32, 16, 16]``) need a kernel family with 8-channel blocks and are not built; ``irreps_src != irreps_dst`` (the level-2 pool layer)
-likewise.  Graphs come from ``connectivity.FpsPool`` / ``RadiusGraph`` (HIP ``dedf_fps`` / ``dedf_radius``).  GPU only.
+The kernels are instantiated for ``64x0e+32x1e+16x2e`` with ``fc_neurons [64, 32, 32]`` (levels 2 and 3 and the mid block of every UNet
+the reference ships, ``configs/*/*/score_model_configs.yaml: irreps_emb[2:]``).  The two fine levels (``32x0e+16x1e+8x2e``,
+``[32, 16, 16]``) and the layers between levels of different width run on the SAME kernels as zero-padded wide layers — an exact
+embedding, see ``unet_pad.py`` — at the price of the padded arithmetic.  Graphs come from ``connectivity.FpsPool`` / ``RadiusGraph``
+(HIP ``dedf_fps`` / ``dedf_radius``).  GPU only.
 """
 from __future__ import annotations
 
@@ -24,29 +25,41 @@ from typing import Dict, List, Optional, Sequence
 
 import torch
 
-from . import _lib
+from . import _lib, unet_pad
 from .params import init_from_spec, unet_layer_param_spec
 from .score_head import _register
 from .so3 import irreps_dim, parse_irreps
 
 
+_SHAPES = {(64, 32, 16): "wide", (32, 16, 8): "narrow"}
+
+
 class UnetLayer(torch.nn.Module):
-    """{'radial', 'gnn'} of one UNet layer.  ``forward`` returns the new destination features ``(n_dst, D)``."""
+    """{'radial', 'gnn'} of one UNet layer.  ``forward`` returns the new destination features ``(n_dst, D_dst)``.
+
+    ``irreps`` is the block's ``irreps_dst`` (= its ``irreps_emb``), ``irreps_src`` the irreps of the source features (pool / unpool layers
+    between levels of different width).  Both ``64x0e+32x1e+16x2e`` and ``32x0e+16x1e+8x2e`` are accepted, with ``fc_neurons``
+    ``[64, 32, 32]`` or ``[32, 16, 16]``: the narrow shapes run zero-padded on the wide kernels (``unet_pad.py``; exact, not approximate)."""
 
     def __init__(self, irreps: str = '64x0e+32x1e+16x2e', irreps_edge_attr: str = '1x0e+1x1e+1x2e', num_heads: int = 4,
-                 fc_neurons: Sequence[int] = (64, 32, 32), radius: float = 15.0, irreps_mlp_mid: int = 3, init_seed: int = 2):
+                 fc_neurons: Sequence[int] = (64, 32, 32), radius: float = 15.0, irreps_mlp_mid: int = 3, init_seed: int = 2,
+                 irreps_src: Optional[str] = None):
         super().__init__()
         self.irreps = parse_irreps(irreps)
+        self.irreps_src = self.irreps if irreps_src is None else parse_irreps(irreps_src)
         sh = parse_irreps(irreps_edge_attr)
-        if [m for m, _ in self.irreps] != [64, 32, 16] or [l for _, l in self.irreps] != [0, 1, 2]:
-            raise NotImplementedError(f"UnetLayer is instantiated for 64x0e+32x1e+16x2e (UNet levels 2, 3, mid block), not {irreps}")
-        if list(fc_neurons) != [64, 32, 32]:
-            raise NotImplementedError(f"UnetLayer is instantiated for fc_neurons [64, 32, 32], not {list(fc_neurons)}")
+        for irr in (self.irreps, self.irreps_src):
+            if tuple(m for m, _ in irr) not in _SHAPES or [l for _, l in irr] != [0, 1, 2]:
+                raise NotImplementedError(f"UnetLayer: irreps must be 64x0e+32x1e+16x2e or 32x0e+16x1e+8x2e, not {irr}")
+        if list(fc_neurons) not in ([64, 32, 32], [32, 16, 16]):
+            raise NotImplementedError(f"UnetLayer: fc_neurons must be [64, 32, 32] or [32, 16, 16], not {list(fc_neurons)}")
         if [l for _, l in sh] != [0, 1, 2] or any(m != 1 for m, _ in sh) or num_heads != 4 or irreps_mlp_mid != 3:
             raise NotImplementedError("UnetLayer: irreps_edge_attr 1x0e+1x1e+1x2e, 4 heads, irreps_mlp_mid 3")
         self.fc_neurons, self.num_heads, self.radius = list(fc_neurons), num_heads, float(radius)
-        self.dim = irreps_dim(self.irreps)
-        for name, t in init_from_spec(unet_layer_param_spec(self.irreps, self.fc_neurons, num_heads), seed=init_seed).items():
+        self.muls, self.muls_src = [m for m, _ in self.irreps], [m for m, _ in self.irreps_src]
+        self.dim, self.dim_src = irreps_dim(self.irreps), irreps_dim(self.irreps_src)
+        spec = unet_layer_param_spec(self.irreps, self.fc_neurons, num_heads, irreps_src=self.irreps_src)
+        for name, t in init_from_spec(spec, seed=init_seed).items():
             _register(self, name, t)
         self._handle = None
         self._handle_device: Optional[torch.device] = None
@@ -77,8 +90,14 @@ class UnetLayer(torch.nn.Module):
                                "(the CPU restatement lives under oracle/ and is test infrastructure).")
         lib = _lib.load()
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        ccfg = _lib.make_unet_layer_config(self.radius, idx, self.fc_neurons, [m for m, _ in self.irreps], self.num_heads)
-        blob = _lib.pack_params(ccfg, {k: v for k, v in self.state_dict().items()})
+        narrow = self.muls != unet_pad.WIDE or self.muls_src != unet_pad.WIDE or self.fc_neurons != unet_pad.WIDE_FC
+        state = {k: v for k, v in self.state_dict().items()}
+        if narrow:
+            state = unet_pad.expand_layer_params(state, self.muls, self.fc_neurons, self.muls_src)
+        ccfg = _lib.make_unet_layer_config(self.radius, idx, unet_pad.WIDE_FC, unet_pad.WIDE, self.num_heads,
+                                           valid=self.muls if self.muls != unet_pad.WIDE else None,
+                                           fc_valid=self.fc_neurons if self.fc_neurons != unet_pad.WIDE_FC else None)
+        blob = _lib.pack_params(ccfg, state)
         h = C.c_void_p()
         rc = lib.dedf_create(C.byref(ccfg), blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, C.byref(h))
         if rc != _lib.OK:
@@ -89,21 +108,242 @@ class UnetLayer(torch.nn.Module):
     def forward(self, node_coord_src: torch.Tensor, node_input_src: torch.Tensor, node_coord_dst: torch.Tensor,
                 node_input_dst: torch.Tensor, edge_src: torch.Tensor, edge_dst: torch.Tensor) -> torch.Tensor:
         """Arguments as the reference has them at the call site (``unet_feature_extractor.py:289-302``): coordinates and features of
-        both node sets and the edge lists (int64, sorted by ``edge_dst`` as ``FpsPool`` / ``RadiusGraph`` return them)."""
+        both node sets and the edge lists (int64).  Edges sorted by ``edge_dst`` (as ``FpsPool`` / ``RadiusGraph`` return them) are used
+        as they are; any other order (the reversed graphs of the up path) is sorted here — the sums do not depend on it."""
         assert node_coord_src.ndim == 2 and node_coord_src.shape[-1] == 3 and node_coord_dst.ndim == 2 and node_coord_dst.shape[-1] == 3
-        assert node_input_src.shape == (len(node_coord_src), self.dim), f"{node_input_src.shape}"
+        assert node_input_src.shape == (len(node_coord_src), self.dim_src), f"{node_input_src.shape}"
         assert node_input_dst.shape == (len(node_coord_dst), self.dim), f"{node_input_dst.shape}"
         assert edge_src.ndim == 1 and edge_src.shape == edge_dst.shape
         dev = node_coord_src.device
         self._ensure_handle(dev)
         lib = _lib.load()
         f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
-        xs, fs, xd, fd = f32(node_coord_src), f32(node_input_src), f32(node_coord_dst), f32(node_input_dst)
-        es = edge_src.detach().to(device=dev, dtype=torch.int64).contiguous()
-        ed = edge_dst.detach().to(device=dev, dtype=torch.int64).contiguous()
-        out = torch.empty(len(xd), self.dim, device=dev, dtype=torch.float32)
+        xs, xd = f32(node_coord_src), f32(node_coord_dst)
+        fs = unet_pad.pad_features(f32(node_input_src), self.muls_src).contiguous()
+        fd = unet_pad.pad_features(f32(node_input_dst), self.muls).contiguous()
+        es = edge_src.detach().to(device=dev, dtype=torch.int64)
+        ed = edge_dst.detach().to(device=dev, dtype=torch.int64)
+        if len(ed) > 1 and bool((ed[1:] < ed[:-1]).any()):
+            order = torch.sort(ed, stable=True).indices
+            es, ed = es[order], ed[order]
+        es, ed = es.contiguous(), ed.contiguous()
+        out = torch.empty(len(xd), 240, device=dev, dtype=torch.float32)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         rc = lib.dedf_layer_forward(self._handle, len(xs), xs.data_ptr(), fs.data_ptr(), len(xd), xd.data_ptr(), fd.data_ptr(),
                                     len(es), es.data_ptr(), ed.data_ptr(), out.data_ptr(), stream)
         _lib.raise_for(lib, self._handle, rc, "dedf_layer_forward")
-        return out.to(node_input_dst.dtype)
+        return unet_pad.unpad_features(out, self.muls).to(node_input_dst.dtype)
+
+
+# =====================================================================================================================================
+# The whole extractor
+# =====================================================================================================================================
+
+def _muls(irreps) -> List[int]:
+    return [m for m, _ in irreps]
+
+
+class NodeLinear(torch.nn.Module):
+    """[EquivariantLayerNormV2 +] LinearRS per node on the HIP kernel ``dedf_linear_rs`` — the reference's ``LinearRS`` (``input_emb``,
+    unet_feature_extractor.py:64-66) and ``ProjectIfMismatch`` (skip.py:13-34: LayerNorm over irreps_in, then LinearRS with bias; identity when
+    the irreps agree).  Parameter names as in the reference: ``tp.weight`` / ``bias.0`` (LinearRS), ``layernorm.affine_*`` + ``skip.tp.weight``
+    / ``skip.bias.0`` (ProjectIfMismatch).  Narrow irreps run zero-padded like the layers (``unet_pad.py``)."""
+
+    def __init__(self, irreps_in, irreps_out, layernorm: bool, prefix: str = "", init_seed: int = 2):
+        super().__init__()
+        self.irreps_in, self.irreps_out = parse_irreps(irreps_in) if isinstance(irreps_in, str) else list(irreps_in), \
+            parse_irreps(irreps_out) if isinstance(irreps_out, str) else list(irreps_out)
+        self.has_ln, self.prefix = layernorm, prefix
+        self.m_in = {l: m for m, l in self.irreps_in}
+        self.m_out = _muls(self.irreps_out)
+        assert [l for _, l in self.irreps_out] == [0, 1, 2] and tuple(self.m_out) in _SHAPES
+        assert all(l in (0, 1, 2) for l in self.m_in) and all(self.m_in.get(l, 0) <= unet_pad.WIDE[l] for l in range(3))
+        g = torch.Generator().manual_seed(init_seed)
+        blocks = [(self.m_in.get(l, 0), self.m_out[l]) for l in range(3)]
+        w = torch.cat([torch.randn(a * b, generator=g) / max(a, 1) ** 0.5 for a, b in blocks if a > 0])
+        lin = prefix + ("skip." if layernorm else "")
+        _register(self, lin + "tp.weight", w)
+        _register(self, lin + "bias.0", torch.zeros(self.m_out[0]))
+        if layernorm:
+            _register(self, prefix + "layernorm.affine_weight", torch.ones(sum(self.m_in.values())))
+            _register(self, prefix + "layernorm.affine_bias", torch.zeros(self.m_in.get(0, 0)))
+        self._dev = None
+
+    def _pl_in(self, l):      # placement of the input channels of degree l inside the wide block
+        m = self.m_in.get(l, 0)
+        return unet_pad.place(m, unet_pad.WIDE[l]) if (m and m % 4 == 0 and tuple(self.m_in.get(k, 0) for k in range(3)) in _SHAPES) else torch.arange(m)
+
+    def _wide(self, dev):
+        if self._dev is not None and self._dev[0] == dev:
+            return self._dev[1:]
+        sd = {k: v.detach().float().cpu() for k, v in self.state_dict().items()}
+        lin = self.prefix + ("skip." if self.has_ln else "")
+        M = unet_pad.WIDE
+        W, o = [], 0
+        for l in range(3):
+            a, b = self.m_in.get(l, 0), self.m_out[l]
+            full = torch.zeros(M[l], M[l])
+            if a:
+                full[self._pl_in(l)[:, None], unet_pad.place(b, M[l])[None, :]] = sd[lin + "tp.weight"][o:o + a * b].reshape(a, b)
+                o += a * b
+            W.append(full.reshape(-1))
+        bias = torch.zeros(M[0]); bias[unet_pad.place(self.m_out[0], M[0])] = sd[lin + "bias.0"]
+        lnw = lnb = None
+        valid = None
+        if self.has_ln:
+            lnw, lnb, ow = torch.zeros(sum(M)), torch.zeros(M[0]), 0
+            it = 0
+            for l in range(3):
+                a = self.m_in.get(l, 0)
+                lnw[ow + self._pl_in(l)] = sd[self.prefix + "layernorm.affine_weight"][it:it + a]
+                it += a; ow += M[l]
+            lnb[self._pl_in(0)] = sd[self.prefix + "layernorm.affine_bias"]
+            valid = (C.c_int * 3)(*[self.m_in.get(l, 0) or M[l] for l in range(3)])
+        t = lambda v: None if v is None else v.to(dev).contiguous()
+        self._dev = (dev, t(torch.cat(W)), t(bias), t(lnw), t(lnb), valid)
+        return self._dev[1:]
+
+    def load_state_dict(self, *a, **k):
+        self._dev = None
+        return super().load_state_dict(*a, **k)
+
+    def pad_in(self, f: torch.Tensor) -> torch.Tensor:
+        out = f.new_zeros(len(f), 240)
+        o_t = o_w = 0
+        for l in range(3):
+            a, d, Mw = self.m_in.get(l, 0), 2 * l + 1, unet_pad.WIDE[l]
+            if a:
+                out[:, o_w:o_w + Mw * d].view(-1, Mw, d)[:, self._pl_in(l).to(f.device), :] = f[:, o_t:o_t + a * d].reshape(-1, a, d)
+                o_t += a * d
+            o_w += Mw * d
+        return out
+
+    @torch.no_grad()
+    def forward(self, f: torch.Tensor) -> torch.Tensor:
+        if not f.is_cuda:
+            raise RuntimeError("diffusion_edf_amd.unet needs GPU tensors: the product has no CPU path")
+        dev = f.device
+        W, bias, lnw, lnb, valid = self._wide(dev)
+        x = self.pad_in(f.detach().float()).contiguous()
+        out = torch.empty_like(x)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            rc = lib.dedf_linear_rs(x.data_ptr(), len(x), None if lnw is None else lnw.data_ptr(), None if lnb is None else lnb.data_ptr(),
+                                    W.data_ptr(), bias.data_ptr(), valid, out.data_ptr(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != _lib.OK:
+            raise RuntimeError(f"dedf_linear_rs failed ({rc})")
+        return unet_pad.unpad_features(out, self.m_out).to(f.dtype)
+
+
+class _ParitySign(torch.nn.Module):
+    """holds the ``sign`` buffer of the reference's ``ParityInversionSh`` (utils.py:26-47) so that reference state dicts load strictly; the
+    kernels never read it (the harmonics of a swapped edge are recomputed, Y_l(-v) = (-1)^l Y_l(v))"""
+
+    def __init__(self, irreps):
+        super().__init__()
+        self.register_buffer('sign', torch.cat([torch.full(((2 * l + 1) * m,), -1.0 if l % 2 else 1.0) for m, l in parse_irreps(str(irreps))]))
+
+
+class UnetFeatureExtractor(torch.nn.Module):
+    """reference ``unet_feature_extractor.py:19-417`` on the MI355X-native kernels: same constructor keywords (the
+    ``feature_extractor_kwargs`` block of the score-model YAML files), same state-dict names (``input_emb.*``, ``down_blocks.N.pool_proj.*``,
+    ``down_blocks.N.pool_layer.{radial,gnn}.*``, ``down_blocks.N.layer_stack.I.*``, ``mid_block.I.*``, ``up_blocks.K.layer_stack.I.*``,
+    ``up_blocks.K.unpool_layer.*``, ``project_outputs.N.*``), same ``forward(pcd) -> List[FeaturedPoints]``.
+
+    Graphs: ``connectivity.FpsPool`` / ``RadiusGraph`` (HIP FPS + radius search); layers: ``UnetLayer``; projections: ``NodeLinear``; the up
+    path re-uses the down path's graphs with source and destination swapped — ``ParityInversionSh`` (utils.py:26-47) is implicit, the edge
+    kernel evaluates the harmonics of the swapped edge vector.  Skip connections ``(a + b) / sqrt(3)`` as at ``:347,359``.
+    Supported: lmax 2, irreps_emb per level 64x0e+32x1e+16x2e or 32x0e+16x1e+8x2e with fc_neurons [64,32,32] / [32,16,16], 4 heads,
+    pool_method 'fps', attn_type 'mlp' — every UNet the reference ships.  Dropout / drop-path are identity in eval and not modelled."""
+
+    def __init__(self, irreps_input, irreps_output, irreps_emb, irreps_edge_attr, num_heads, fc_neurons, n_layers, pool_ratio, radius,
+                 deterministic: bool = False, pool_method='fps', irreps_mlp_mid=3, attn_type='mlp', alpha_drop=0.1, proj_drop=0.1,
+                 drop_path_rate=0.0, n_layers_midstream: int = 2, n_scales: Optional[int] = None, output_scalespace=None):
+        super().__init__()
+        import math
+        from . import connectivity as CN
+        self._ctor = dict(irreps_input=irreps_input, irreps_output=irreps_output, irreps_emb=list(irreps_emb), fc_neurons=[list(f) for f in fc_neurons],
+                          n_layers=list(n_layers), pool_ratio=list(pool_ratio), n_layers_midstream=n_layers_midstream)
+        self.irreps_output = str(irreps_output)
+        self.irreps_emb = [str(i) for i in irreps_emb]
+        self.n_scales = len(self.irreps_emb) if n_scales is None else n_scales
+        ns = self.n_scales
+        assert ns == len(self.irreps_emb) == len(irreps_edge_attr) == len(num_heads) == len(fc_neurons) == len(radius) == len(pool_ratio) == len(n_layers)
+        if irreps_input is None:
+            raise NotImplementedError("irreps_input=None")
+        if any(str(a).replace(' ', '') not in ('1x0e+1x1e+1x2e',) for a in irreps_edge_attr) or any(h != 4 for h in num_heads):
+            raise NotImplementedError("UnetFeatureExtractor: irreps_edge_attr 1x0e+1x1e+1x2e and 4 heads per level")
+        if (pool_method if isinstance(pool_method, str) else pool_method[0]) != 'fps' or (attn_type if isinstance(attn_type, str) else attn_type[0]) != 'mlp':
+            raise NotImplementedError
+        if irreps_mlp_mid != 3:
+            raise NotImplementedError
+        self.output_scalespace = [ns + n if n < 0 else n for n in (list(range(ns)) if output_scalespace is None else output_scalespace)]
+        self.deterministic, self.n_layers, self.n_layers_midstream = deterministic, list(n_layers), n_layers_midstream
+        self.radius = [radius[0]]
+        for n, r in enumerate(radius[1:]):                                    # :78-86 (note the reference's pool_ratio[n-1])
+            self.radius.append(self.radius[-1] / math.sqrt(pool_ratio[n - 1]) if r is None else r)
+        emb, fc = self.irreps_emb, [list(f) for f in fc_neurons]
+        self.input_emb = NodeLinear(irreps_input, emb[0], layernorm=False, init_seed=7)
+        seeds = iter(range(100, 10 ** 6))
+        mk = lambda n, src, dst: UnetLayer(irreps=dst, irreps_src=src, fc_neurons=fc[n], radius=self.radius[n], init_seed=next(seeds))
+        self.down_blocks = torch.nn.ModuleList()
+        for n in range(ns):
+            blk = torch.nn.ModuleDict()
+            blk['pool'] = CN.FpsPool(ratio=pool_ratio[n], random_start=not deterministic, r=self.radius[n], max_num_neighbors=1000)
+            prev = emb[max(n - 1, 0)]
+            blk['pool_proj'] = NodeLinear(prev, emb[n], layernorm=True) if parse_irreps(prev) != parse_irreps(emb[n]) else torch.nn.Identity()
+            blk['radius_graph'] = CN.RadiusGraph(r=self.radius[n], max_num_neighbors=1000)
+            blk['pool_layer'] = mk(n, prev, emb[n])
+            blk['layer_stack'] = torch.nn.ModuleList([mk(n, emb[n], emb[n]) for _ in range(n_layers[n] - 1)])
+            self.down_blocks.append(blk)
+        self.mid_block = torch.nn.ModuleList([mk(ns - 1, emb[-1], emb[-1]) for _ in range(n_layers_midstream)])
+        self.up_blocks = torch.nn.ModuleList()
+        for n in range(ns - 1, -1, -1):
+            blk = torch.nn.ModuleDict()
+            blk['layer_stack'] = torch.nn.ModuleList([mk(n, emb[n], emb[n]) for _ in range(n_layers[n] - 1)])
+            blk['unpool_layer'] = mk(n, emb[n], emb[max(n - 1, 0)])
+            blk['parity_inversion'] = _ParitySign(irreps_edge_attr[n])
+            self.up_blocks.append(blk)
+        self.project_outputs = torch.nn.ModuleList(
+            [NodeLinear(emb[n], irreps_output, layernorm=True) if parse_irreps(emb[n]) != parse_irreps(irreps_output) else torch.nn.Identity()
+             for n in range(ns)])
+
+    @torch.no_grad()
+    def forward(self, pcd):
+        import math
+        from .gnn_data import FeaturedPoints
+        x, f, b = pcd.x, pcd.f, pcd.b
+        assert f.ndim == 2 and x.ndim == 2 and b.ndim == 1 and len(f) == len(x) == len(b)
+        f = self.input_emb(f)
+        down_out, down_edges = [(f, x, b)], []
+        for blk in self.down_blocks:
+            f_dst, x_dst, es, ed, _, b_dst = blk['pool'](x, f, b)                                    # :279-282
+            f_dst = blk['pool_proj'](f_dst)
+            f = blk['pool_layer'](x, f, x_dst, f_dst, es, ed)
+            x_src_pool, x, b = x, x_dst, b_dst
+            down_out.append((f, x, b)); down_edges.append((es, ed, x_src_pool, x))
+            _, _, es, ed, _, _ = blk['radius_graph'](x, f, b)                                         # :306-311
+            for layer in blk['layer_stack']:
+                f = layer(x, f, x, f, es, ed)
+                down_out.append((f, x, b)); down_edges.append((es, ed, x, x))
+        for layer in self.mid_block:                                                                  # :332-344 (the last radius graph)
+            f = layer(x, f, x, f, es, ed)
+        f_skip, _, _ = down_out.pop()
+        f = (f + f_skip) / math.sqrt(3)                                                               # :347
+        up_out = []
+        for k, blk in enumerate(self.up_blocks):
+            for layer in blk['layer_stack']:
+                f_skip, x_dst, b_dst = down_out.pop()
+                es, ed, _, _ = down_edges.pop()
+                f_dst = (f + f_skip) / math.sqrt(3)                                                   # :359
+                f = layer(x, f, x_dst, f_dst, ed, es)                                                 # source / destination swapped (:358)
+                x, b = x_dst, b_dst
+            up_out.append((f, x, b))
+            f_dst, x_dst, b_dst = down_out.pop()                                                      # :381-403
+            es, ed, _, _ = down_edges.pop()
+            if k != self.n_scales - 1:
+                f = blk['unpool_layer'](x, f, x_dst, f_dst, ed, es)
+                x, b = x_dst, b_dst
+        up_out = up_out[::-1]
+        return [FeaturedPoints(x=up_out[s][1], f=self.project_outputs[s](up_out[s][0]), b=up_out[s][2], w=None)
+                for s in range(self.n_scales) if s in self.output_scalespace]

@@ -76,6 +76,11 @@ typedef struct dedf_config {
                                             irreps_dst = 64x0e+32x1e+16x2e, fc_neurons {64,32,32} (levels 2, 3 and the mid block of every shipped
                                             UNet config); radii[0] = the level's connection radius, n_scales = 1; the time / score fields are
                                             ignored; only dedf_layer_forward is available.  0: score / critic head */
+    int unet_valid[3];                   /* UNet layer: true multiplicities of the block's irreps (0 = all of mul[]).  A 32x0e+16x1e+8x2e layer (levels 0-1 of
+                                            the shipped UNets) runs on the 64/32/16 kernels with zero-padded parameters (diffusion_edf_amd/unet.py
+                                            builds them); what the padding cannot express -- LayerNorm statistics over the true channels only -- is told
+                                            to the kernels by these counts */
+    int unet_fc_valid[3];                /* UNet layer: true {num_basis, h1, h2} of the radial network when narrower than fc_neurons (0 = fc_neurons) */
 } dedf_config;
 
 typedef struct dedf_schedule {           /* host arrays, one entry per denoising step (score_model_base.py:146-171) */
@@ -171,6 +176,12 @@ int dedf_debug_packed(dedf_handle* h, const char* which, const float** ptr, size
  *              x_dst = x_src): all (dst, src) with |x_dst - x_src| < r, at most max_num_neighbors per dst (the first in source
  *              order), sorted by dst then src, as int64 like torch.  *n_edges (HOST) receives the edge count; if it exceeds
  *              edge_cap nothing is written and DEDF_ERR_INVALID is returned (call again with room).  Synchronises `stream`. */
+/* dedf_linear_rs  per-node [EquivariantLayerNormV2 +] LinearRS on 64x0e+32x1e+16x2e features (skip.py:13-34 ProjectIfMismatch, the UNet's
+ *              input / output projections): f (n,240) -> out (n,240).  W: per degree l a (mul_l x mul_l) [in][out] matrix, concatenated;
+ *              bias (64) or NULL; ln_w (112) / ln_b (64) or both NULL (no LayerNorm); valid[3]: true multiplicities for the LayerNorm
+ *              statistics (padded models), NULL = full.  All device pointers. */
+int dedf_linear_rs(const float* f, int n, const float* ln_w, const float* ln_b, const float* W, const float* bias, const int* valid,
+                   float* out, void* stream);
 int dedf_fps(const float* x, int n, int n_samples, int start, int* idx_out, void* stream);
 int dedf_radius(const float* x_src, int n_src, const float* x_dst, int n_dst, float r, int max_num_neighbors, int exclude_self,
                 int64_t edge_cap, int64_t* edge_dst, int64_t* edge_src, int64_t* n_edges, void* stream);

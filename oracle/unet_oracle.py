@@ -32,12 +32,61 @@ from . import restatement as R
 
 
 class LayerConfig(NamedTuple):
-    irreps: R.Irreps            # irreps_src == irreps_dst == irreps_emb of the layer
+    irreps: R.Irreps            # irreps_dst == irreps_emb of the layer
     irreps_sh: R.Irreps
     num_heads: int
     fc_neurons: list            # [num_basis, h1, h2]
     radius: float               # the level's connection radius; the radial basis uses cutoff = 0.99 * radius
     irreps_mlp_mid: int = 3
+    irreps_src: Optional[R.Irreps] = None      # default: same as irreps (pool / unpool layers between levels of different width differ)
+    # "embedded model" switches, used ONLY to validate diffusion_edf_amd/unet_pad.py on the CPU: a narrow layer zero-padded into the wide
+    # shape equals the narrow layer iff the LayerNorms use the true channel counts and the radial basis the true num_basis
+    valid: Optional[list] = None               # true multiplicities per degree (norm_2 statistics)
+    fc_valid: Optional[list] = None            # true [num_basis, h1, h2]
+
+
+def _masked_layer_norm(x: Tensor, n_valid: int, w: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
+    """LayerNorm whose statistics run over the n_valid true channels of a zero-padded vector (padded entries are 0 on entry)"""
+    mean = x.sum(-1, keepdim=True) / n_valid
+    var = ((x - mean) ** 2).sum(-1, keepdim=True) - (x.shape[-1] - n_valid) * mean ** 2
+    return (x - mean) / torch.sqrt(var / n_valid + eps) * w + b
+
+
+def _radial_profile(x: Tensor, P, prefix: str, fc_valid) -> Tensor:
+    if fc_valid is None:
+        return R.radial_profile(x, P, prefix, 3)
+    idx = 0
+    for i in range(3):
+        x = x @ P[f"{prefix}.net.{idx}.weight"].t()
+        if i < 2:
+            x = x + P[f"{prefix}.net.{idx}.bias"]
+            x = _masked_layer_norm(x, fc_valid[1 + i], P[f"{prefix}.net.{idx + 1}.weight"], P[f"{prefix}.net.{idx + 1}.bias"])
+            x = torch.nn.functional.silu(x)
+            idx += 3
+    return x + P[f"{prefix}.offset"].reshape(1, -1)
+
+
+def _norm_v2(x: Tensor, irreps, P, prefix: str, valid, eps: float = 1e-5) -> Tensor:
+    if valid is None:
+        return R.equivariant_layer_norm_v2(x, irreps, P, prefix)
+    fields, ix, iw = [], 0, 0
+    for (mul, l), nv in zip(irreps, valid):
+        d = 2 * l + 1
+        f = x[:, ix:ix + mul * d].reshape(-1, mul, d)
+        ix += mul * d
+        if l == 0:
+            mean = f.sum(dim=1, keepdim=True) / nv
+            f = f - mean
+            norm = (f.pow(2).mean(-1).sum(dim=1, keepdim=True) - (mul - nv) * mean[..., 0] ** 2) / nv
+        else:
+            norm = f.pow(2).mean(-1).sum(dim=1, keepdim=True) / nv
+        norm = (norm + eps).pow(-0.5) * P[f"{prefix}.affine_weight"][None, iw:iw + mul]
+        iw += mul
+        f = f * norm.reshape(-1, mul, 1)
+        if d == 1:
+            f = f + P[f"{prefix}.affine_bias"][:mul].reshape(mul, 1)
+        fields.append(f.reshape(-1, mul * d))
+    return torch.cat(fields, dim=-1)
 
 
 def soft_step(x, n: int = 3):                        # radial_func.py:15-17
@@ -55,7 +104,7 @@ def soft_square_cutoff(x, thr: float = 0.8, n: int = 3, infinite: bool = False):
 
 
 def radial_basis_finite_cutoff(dist: Tensor, mean: Tensor, std_logit: Tensor, weight_logit: Tensor, cutoff: float,
-                               offset: Optional[float] = None, cutoff_thr_ratio: float = 0.8) -> Tensor:
+                               offset: Optional[float] = None, cutoff_thr_ratio: float = 0.8, num_basis_norm: Optional[int] = None) -> Tensor:
     """GaussianRadialBasisLayerFiniteCutoff.forward — radial_func.py:262-278 (soft_cutoff=True, infinite=False, max_weight 4)."""
     num_basis = mean.shape[-1]
     if offset is None:
@@ -66,7 +115,7 @@ def radial_basis_finite_cutoff(dist: Tensor, mean: Tensor, std_logit: Tensor, we
     x = torch.exp(-0.5 * (((x - mean) / std) ** 2))
     x = torch.sigmoid(weight_logit) * 4.0 * x
     x = x * soft_square_cutoff(d, thr=cutoff_thr_ratio, infinite=False)
-    return x * math.sqrt(num_basis)
+    return x * math.sqrt(num_basis if num_basis_norm is None else num_basis_norm)
 
 
 def layer_forward(cfg: LayerConfig, P: Dict[str, Tensor], x_src: Tensor, f_src: Tensor, x_dst: Tensor, f_dst: Tensor,
@@ -78,10 +127,11 @@ def layer_forward(cfg: LayerConfig, P: Dict[str, Tensor], x_src: Tensor, f_src: 
     edge_length = edge_vec.norm(dim=1, p=2)
     edge_attr = R.spherical_harmonics(irreps_sh, edge_vec)
     edge_scalars = radial_basis_finite_cutoff(edge_length, P["radial.mean"], P["radial.std_logit"], P["radial.weight_logit"],
-                                              cutoff=0.99 * cfg.radius)
+                                              cutoff=0.99 * cfg.radius, num_basis_norm=None if cfg.fc_valid is None else cfg.fc_valid[0])
     g = "gnn"
+    irreps_src = irreps if cfg.irreps_src is None else cfg.irreps_src
     # block.py:149-153: the LayerNorm outputs are overwritten -> the linears act on the raw inputs
-    msg_src = R.linear_rs(f_src, irreps, irreps, P, f"{g}.linear_src", bias=False)
+    msg_src = R.linear_rs(f_src, irreps_src, irreps, P, f"{g}.linear_src", bias=False)
     msg_dst = R.linear_rs(f_dst, irreps, irreps, P, f"{g}.linear_dst", bias=True)
     message = msg_src[edge_src] + msg_dst[edge_dst]
 
@@ -89,7 +139,7 @@ def layer_forward(cfg: LayerConfig, P: Dict[str, Tensor], x_src: Tensor, f_src: 
     irreps_head = [(m // H, l) for m, l in irreps]
     mul_alpha = irreps[0][0]
     dtp1, dtp1_out_simpl, lin1_out, gate1 = R.separable_fctp_dtp_lin(irreps, irreps_sh, irreps, True)
-    weight = R.radial_profile(edge_scalars, P, f"{ga}.sep_act.dtp_rad", len(cfg.fc_neurons))
+    weight = _radial_profile(edge_scalars, P, f"{ga}.sep_act.dtp_rad", cfg.fc_valid)
     m1 = dtp1(message, edge_attr, weight)
     log_alpha = R.linear_rs(m1, dtp1.irout, [(mul_alpha, 0)], P, f"{ga}.sep_alpha")
     log_alpha = R.vec2heads(log_alpha, [(mul_alpha // H, 0)], H)
@@ -113,7 +163,7 @@ def layer_forward(cfg: LayerConfig, P: Dict[str, Tensor], x_src: Tensor, f_src: 
     node_features = R.linear_rs(attn, irreps, irreps, P, f"{ga}.proj")
 
     node_output = f_dst + node_features                                                    # block.py:165
-    nf = R.equivariant_layer_norm_v2(node_output, irreps, P, f"{g}.norm_2")
+    nf = _norm_v2(node_output, irreps, P, f"{g}.norm_2", cfg.valid)
     mid = R.simplify(R.sort_even_first([(m, l) for _ in range(cfg.irreps_mlp_mid) for m, l in irreps])[0])
     sc, gt, gd = R.irreps2gate(mid)
     ffn_in = R.simplify(sc + gt + gd)
@@ -128,3 +178,87 @@ def layer_forward(cfg: LayerConfig, P: Dict[str, Tensor], x_src: Tensor, f_src: 
         dbg.update(edge_length=edge_length, edge_attr=edge_attr, edge_scalars=edge_scalars, msg_src=msg_src, msg_dst=msg_dst,
                    dtp_weight=weight, log_alpha=log_alpha, value=value, attn=attn, proj=node_features, out=out)
     return out
+
+
+# =====================================================================================================================================
+# The whole extractor — unet_feature_extractor.py:260-417
+# =====================================================================================================================================
+
+class UnetConfig(NamedTuple):
+    irreps_input: R.Irreps
+    irreps_output: R.Irreps
+    irreps_emb: list            # per scale
+    fc_neurons: list            # per scale
+    n_layers: list
+    pool_ratio: list
+    radius: list                # per scale, already resolved (:78-86)
+    n_layers_midstream: int = 2
+    num_heads: int = 4
+    irreps_sh: R.Irreps = [(1, 0), (1, 1), (1, 2)]
+    max_num_neighbors: int = 1000
+    output_scalespace: Optional[list] = None
+
+
+def _sub(P: Dict[str, Tensor], prefix: str) -> Dict[str, Tensor]:
+    return {k[len(prefix):]: v for k, v in P.items() if k.startswith(prefix)}
+
+
+def project_if_mismatch(x: Tensor, ir_in, ir_out, P, prefix: str) -> Tensor:
+    """skip.py:13-34: identity for equal irreps, else EquivariantLayerNormV2(irreps_in) then LinearRS(bias)"""
+    if list(ir_in) == list(ir_out):
+        return x
+    x = R.equivariant_layer_norm_v2(x, ir_in, P, f"{prefix}.layernorm")
+    return R.linear_rs(x, ir_in, ir_out, P, f"{prefix}.skip", bias=True)
+
+
+def unet_forward(cfg: UnetConfig, P: Dict[str, Tensor], x: Tensor, f: Tensor, dbg: Optional[dict] = None):
+    """-> [(coords, features)] per output scale.  ``x`` (N,3) float32 — the graphs are built in float32 exactly like torch_cluster does
+    (graph_oracle.py), the layers run in the dtype of ``f`` / ``P`` on those coordinates.  Single cloud (batch all 0), deterministic FPS
+    (start at point 0), eval mode (dropout / drop-path are identity)."""
+    from . import graph_oracle as GO
+    ns, emb, dt = len(cfg.irreps_emb), cfg.irreps_emb, f.dtype
+    assert x.dtype == torch.float32
+    lcfg = lambda n, src, dst: LayerConfig(dst, cfg.irreps_sh, cfg.num_heads, cfg.fc_neurons[n], cfg.radius[n], irreps_src=src)
+    run = lambda c, prefix, xs, fs, xd, fd, es, ed: layer_forward(c, _sub(P, prefix), xs.to(dt), fs, xd.to(dt), fd, es, ed)
+    f = R.linear_rs(f, cfg.irreps_input, emb[0], P, "input_emb", bias=True)                            # :270-271
+    down_out, down_edges = [(f, x)], []
+    for n in range(ns):
+        prev = emb[max(n - 1, 0)]
+        idx = GO.fps(x.numpy(), cfg.pool_ratio[n], start=0)                                             # FpsPool, connectivity.py:56-80
+        x_dst = x[torch.from_numpy(idx)]
+        ed, es = GO.radius(x.numpy(), x_dst.numpy(), cfg.radius[n], cfg.max_num_neighbors)
+        keep = idx[ed] != es
+        es, ed = torch.from_numpy(es[keep]), torch.from_numpy(ed[keep])
+        f_dst = project_if_mismatch(f[torch.from_numpy(idx)], prev, emb[n], P, f"down_blocks.{n}.pool_proj")
+        f = run(lcfg(n, prev, emb[n]), f"down_blocks.{n}.pool_layer.", x, f, x_dst, f_dst, es, ed)     # :283-299
+        x = x_dst
+        down_out.append((f, x)); down_edges.append((es, ed))
+        ed, es = GO.radius(x.numpy(), x.numpy(), cfg.radius[n], cfg.max_num_neighbors, exclude_self=True)      # RadiusGraph, :306-313
+        es, ed = torch.from_numpy(es), torch.from_numpy(ed)
+        for i in range(cfg.n_layers[n] - 1):
+            f = run(lcfg(n, emb[n], emb[n]), f"down_blocks.{n}.layer_stack.{i}.", x, f, x, f, es, ed)
+            down_out.append((f, x)); down_edges.append((es, ed))
+    for i in range(cfg.n_layers_midstream):                                                            # :332-344
+        f = run(lcfg(ns - 1, emb[-1], emb[-1]), f"mid_block.{i}.", x, f, x, f, es, ed)
+    f_skip, _ = down_out.pop()
+    f = (f + f_skip) / math.sqrt(3)                                                                    # :346-347
+    up_out = []
+    for k in range(ns):
+        n = ns - 1 - k
+        for i in range(cfg.n_layers[n] - 1):
+            f_skip, x_dst = down_out.pop()
+            es, ed = down_edges.pop()
+            f_dst = (f + f_skip) / math.sqrt(3)                                                        # :359
+            # :358 swaps source and destination and flips the odd harmonics; Y_l(-v) = (-1)^l Y_l(v), so that is the harmonics of the swapped
+            # edge vector, which layer_forward computes itself
+            f = run(lcfg(n, emb[n], emb[n]), f"up_blocks.{k}.layer_stack.{i}.", x, f, x_dst, f_dst, ed, es)
+            x = x_dst
+        up_out.append((x, f))
+        f_dst, x_dst = down_out.pop()                                                                  # :381-383
+        es, ed = down_edges.pop()
+        if k != ns - 1:
+            f = run(lcfg(n, emb[n], emb[max(n - 1, 0)]), f"up_blocks.{k}.unpool_layer.", x, f, x_dst, f_dst, ed, es)
+            x = x_dst
+    up_out = up_out[::-1]
+    scales = list(range(ns)) if cfg.output_scalespace is None else [ns + s if s < 0 else s for s in cfg.output_scalespace]
+    return [(up_out[s][0], project_if_mismatch(up_out[s][1], emb[s], cfg.irreps_output, P, f"project_outputs.{s}")) for s in range(ns) if s in scales]
