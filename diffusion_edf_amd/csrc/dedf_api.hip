@@ -79,6 +79,7 @@ struct dedf_handle {
     const LangevinParams* fused_step = nullptr;           // dedf_sample: the per-pose reduction also carries this step's Langevin update
     DevBuf d_tb_steps; const float* tb_step = nullptr;    // dedf_sample: the time-bias rows of ALL steps are computed up front; tb_step = this step's rows
     std::vector<float> h_tsteps;
+    bool want_field = false;          // dedf_field: the node kernel also writes the field / emb of every node
     DevBuf d_Ts, d_time, d_tb, d_pose, d_qpos, d_cnt, d_off, d_blk, d_tile, d_esrc, d_edst, d_eout, d_z, d_nout, d_ang, d_lin, d_T64, d_dbgw, d_dbge, d_dbgf, d_dbgo, d_mask;
     int64_t edge_cap = 0;
     int last_nT = 0;
@@ -146,8 +147,10 @@ int check_config(const dedf_config* c, std::string& why) {
     const bool mlp_wide = c->fc_neurons[1] == kFc1 && c->fc_neurons[2] == kFc2;
     const bool mlp_narrow = c->fc_neurons[1] == 32 && c->fc_neurons[2] == 32;       // sapien place_* score heads
     if (c->fc_neurons[0] != (c->ebm ? kLenEmb : kLenEmb + c->time_emb_mlp[2]) || !(mlp_wide || mlp_narrow)) {
-        why = "fc_neurons must resolve to [64 + time_emb, 128, 64] or [64 + time_emb, 32, 32] (score head), or [64,128,64] (EBM head without time encoding)"; return DEDF_ERR_UNSUPPORTED; }
-    if (mlp_narrow && (c->ebm || c->fc_neurons[0] != 128)) {
+        why = "fc_neurons must resolve to [64 + time_emb, 128, 64] or [64 + time_emb, 32, 32] (score head), or [64,128,64] / [64,32,32] (EBM head / context-free field, no time encoding)"; return DEDF_ERR_UNSUPPORTED; }
+    if (mlp_narrow && c->ebm && (c->lmax != 2 || c->half_gemm)) {
+        why = "the context-free field with the 32-wide radial MLP (KeypointExtractor) is instantiated for lmax 2, full precision only"; return DEDF_ERR_UNSUPPORTED; }
+    if (mlp_narrow && !c->ebm && c->fc_neurons[0] != 128) {
         why = "the 32-wide radial MLP is instantiated for the score head with the 128-wide pre-linear only"; return DEDF_ERR_UNSUPPORTED; }
     if (c->length_emb_dim != kLenEmb) { why = "length_emb_dim must be 64"; return DEDF_ERR_UNSUPPORTED; }
     if (c->irreps_mlp_mid != kMlpMid) { why = "irreps_mlp_mid must be 3"; return DEDF_ERR_UNSUPPORTED; }
@@ -373,6 +376,10 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
                 else hipLaunchKernelGGL((k_edge<L, F0, false, 32, 32>), grid, blk, 0, st, P);
             } else if (hp) hipLaunchKernelGGL((k_edge<L, F0, true>), grid, blk, 0, st, P);
             else hipLaunchKernelGGL((k_edge<L, F0>), grid, blk, 0, st, P);
+        } else if constexpr (F0 == 64 && L == 2) {
+            if (h->cfg.fc_neurons[1] == 32) hipLaunchKernelGGL((k_edge<L, F0, false, 32, 32>), grid, blk, 0, st, P);      // KeypointExtractor fields
+            else if (hp) hipLaunchKernelGGL((k_edge<L, F0, true>), grid, blk, 0, st, P);
+            else hipLaunchKernelGGL((k_edge<L, F0>), grid, blk, 0, st, P);
         } else if (hp) hipLaunchKernelGGL((k_edge<L, F0, true>), grid, blk, 0, st, P);
         else hipLaunchKernelGGL((k_edge<L, F0>), grid, blk, 0, st, P);
     }
@@ -402,7 +409,8 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
             P.o_A_sl_l[t][0] = o.o_A_sl_l[t][0]; P.o_A_sl_l[t][1] = o.o_A_sl_l[t][1];
         }
         P.node_out = h->d_nout.as<float>();
-        if (h->debug && h->d_dbge.ensure((size_t)Nd * D * 4) && h->d_dbgf.ensure((size_t)Nd * D * 4)) { P.dbg_emb = h->d_dbge.as<float>(); P.dbg_field = h->d_dbgf.as<float>(); }
+        if ((h->debug || h->want_field) && h->d_dbge.ensure((size_t)Nd * D * 4) && h->d_dbgf.ensure((size_t)Nd * D * 4)) { P.dbg_emb = h->d_dbge.as<float>(); P.dbg_field = h->d_dbgf.as<float>(); }
+        else if (h->want_field) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(field) failed");
         const int ntiles = (Nd + 31) / 32;
         if (h->cfg.half_gemm) hipLaunchKernelGGL((k_node<L, EBM, true>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
         else hipLaunchKernelGGL((k_node<L, EBM>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
@@ -623,6 +631,53 @@ int dedf_energy(dedf_handle* h, int nT, const float* Ts, const float* time, floa
     DEDF_CLEAR_FLAGS(h, st);
     HIPCK(h, hipMemcpyAsync(h->d_Ts.p, Ts, (size_t)nT * 7 * 4, hipMemcpyDeviceToDevice, st));
     return score_dispatch(h, nT, 0, energy, nullptr, st);
+}
+
+int dedf_field(dedf_handle* h, int n, const float* x, float* field_out, float* emb_out, void* stream) {
+    if (!h) return DEDF_ERR_INVALID;
+    if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
+    if (!h->cfg.ebm || h->cfg.unet_layer) return fail(h, DEDF_ERR_UNSUPPORTED, "dedf_field needs a handle created with dedf_config.ebm = 1 (a field without context encoding)");
+    if (h->cfg.use_src_point_attn) return fail(h, DEDF_ERR_UNSUPPORTED, "dedf_field: use_src_point_attn does not apply");
+    if (!h->have_keys) return fail(h, DEDF_ERR_INVALID, "set_key_clouds must be called first");
+    if (n <= 0 || !x || !field_out) return fail(h, DEDF_ERR_INVALID, "bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DEDF_ON_DEVICE(h);
+    const size_t D = h->L == 1 ? feat_dim<1>() : feat_dim<2>();
+    // the points become the query cloud of ONE identity pose; their features / weights only feed the energy, which is discarded
+    if (!h->d_qx.ensure((size_t)n * 3 * 4) || !h->d_qf.ensure((size_t)n * D * 4) || !h->d_qw.ensure((size_t)n * 4))
+        return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(query) failed");
+    HIPCK(h, hipMemcpyAsync(h->d_qx.p, x, (size_t)n * 3 * 4, hipMemcpyDeviceToDevice, st));
+    HIPCK(h, hipMemsetAsync(h->d_qf.p, 0, (size_t)n * D * 4, st));
+    HIPCK(h, hipMemsetAsync(h->d_qw.p, 0, (size_t)n * 4, st));
+    h->nQ = n;
+    h->have_query = false;
+    int rc = ensure_workspace(h, 1);
+    if (rc != DEDF_OK) return rc;
+    DEDF_CLEAR_FLAGS(h, st);
+    static const float kIdentity[7] = {1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    HIPCK(h, hipMemcpyAsync(h->d_Ts.p, kIdentity, sizeof(kIdentity), hipMemcpyHostToDevice, st));
+    h->want_field = true;
+    rc = score_dispatch(h, 1, 0, h->d_ang.as<float>(), nullptr, st);
+    h->want_field = false;
+    if (rc != DEDF_OK) return rc;
+    const int nb = (int)(((size_t)n * D + 255) / 256);
+    if (h->L == 1) {
+        hipLaunchKernelGGL(k_internal_to_ref<1>, dim3(nb), dim3(256), 0, st, h->d_dbgf.as<float>(), field_out, n);
+        if (emb_out) hipLaunchKernelGGL(k_internal_to_ref<1>, dim3(nb), dim3(256), 0, st, h->d_dbge.as<float>(), emb_out, n);
+    } else {
+        hipLaunchKernelGGL(k_internal_to_ref<2>, dim3(nb), dim3(256), 0, st, h->d_dbgf.as<float>(), field_out, n);
+        if (emb_out) hipLaunchKernelGGL(k_internal_to_ref<2>, dim3(nb), dim3(256), 0, st, h->d_dbge.as<float>(), emb_out, n);
+    }
+    if (hipGetLastError() != hipSuccess) return fail(h, DEDF_ERR_RUNTIME, "kernel launch failed");
+    return DEDF_OK;
+}
+
+int dedf_keypoint_weight(const float* field, const float* emb, int n, int stride, const float* skip_W, const float* skip_b, const float* ln_w,
+                         const float* ln_b, const float* lin_w, float lin_b, int sigmoid, float mult, float* out, void* stream) {
+    if (!field || !emb || n <= 0 || stride < 64 || !skip_W || !skip_b || !ln_w || !ln_b || !lin_w || !out) return DEDF_ERR_INVALID;
+    hipLaunchKernelGGL(k_keypoint_weight, dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), field, emb, n, stride, skip_W, skip_b,
+                       ln_w, ln_b, lin_w, lin_b, sigmoid, mult, out);
+    return hipGetLastError() == hipSuccess ? DEDF_OK : DEDF_ERR_RUNTIME;
 }
 
 int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedule* sched, uint64_t seed, int64_t first_pose_index,

@@ -65,5 +65,6 @@ template <int L, bool EBM, bool HP = false, bool UN = false> __global__ __launch
     X(6, void k_node<1, false, true>(NodeParams))                     \
     X(6, void k_node<1, true, false>(NodeParams))                     \
     X(10, void k_edge<2, 64, false, 32, 32, true>(EdgeParams))        \
-    X(10, void k_node<2, false, false, true>(NodeParams))
-constexpr int kKernelUnits = 11;
+    X(10, void k_node<2, false, false, true>(NodeParams))             \
+    X(11, void k_edge<2, 64, false, 32, 32>(EdgeParams))
+constexpr int kKernelUnits = 12;

@@ -207,6 +207,43 @@ __global__ void k_src_message(const float* __restrict__ f, int n_pts, const floa
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// dedf_field: node features from the node kernel's internal layout [l][m][channel] to the reference layout [l][channel][m]
+template <int L>
+__global__ void k_internal_to_ref(const float* __restrict__ in, float* __restrict__ out, int n) {
+    constexpr int D = feat_dim<L>();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n * D) return;
+    const int node = (int)(i / D), k = (int)(i % D);
+    int l = 0;
+    while (l < L && k >= blk_off(l + 1)) ++l;
+    const int d = 2 * l + 1, r = k - blk_off(l), c = r / d, m = r % d;
+    out[i] = in[(size_t)node * D + blk_off(l) + m * mul_of(l) + c];
+}
+
+// dedf_keypoint_weight (keypoint_extractor.py:111-119,185-194): one wave per point, lane = scalar channel
+__global__ void k_keypoint_weight(const float* __restrict__ field, const float* __restrict__ emb, int n, int stride, const float* __restrict__ skip_W,
+                                  const float* __restrict__ skip_b, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                  const float* __restrict__ lin_w, float lin_b, int sigmoid, float mult, float* __restrict__ out) {
+    const int pt = blockIdx.x * 4 + threadIdx.x / 64, c = threadIdx.x % 64;
+    if (pt >= n) return;
+    const float* e = emb + (size_t)pt * stride;
+    float pre = field[(size_t)pt * stride + c] - e[c] + skip_b[c];
+    for (int u = 0; u < 64; ++u) pre += skip_W[u * 64 + c] * e[u];
+    auto wave_sum = [](float v) {
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+    const float mean = wave_sum(pre) * (1.0f / 64);
+    const float dv = pre - mean;
+    const float var = wave_sum(dv * dv) * (1.0f / 64);
+    float y = dv / sqrtf(var + 1e-5f) * ln_w[c] + ln_b[c];
+    y = y / (1.0f + expf(-y));
+    float w = wave_sum(y * lin_w[c]) + lin_b;
+    if (sigmoid) w = 1.0f / (1.0f + expf(-w));
+    if (c == 0) out[pt] = w * mult;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // Radius neighbour search (torch_cluster.radius as used at graph_parser.py:339; all pairs for the infinite scale,
 // graph_parser.py:279-281).  Keys are tiny (<= a few thousand points) and static, queries move every step: brute force with
 // the key cloud streamed through LDS, one thread per destination node.  Edge order: scale, then dst, then src ascending.

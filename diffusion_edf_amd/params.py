@@ -93,9 +93,9 @@ class HeadConfig:
         if fc[1:] not in ([128, 64], [32, 32]):
             raise NotImplementedError(f"fc_neurons {fc}: radial MLPs are instantiated for [*, 128, 64] (panda_* configs, sapien pick_*) "
                                       "and [*, 32, 32] (sapien place_*)")
-        if fc[1:] == [32, 32] and (ebm or fc[0] != 128):
+        if fc[1:] == [32, 32] and fc[0] != (64 if ebm else 128):
             raise NotImplementedError(f"fc_neurons {fc}: the 32-wide radial MLP is instantiated for the score head with a 64-channel "
-                                      "time embedding (the sapien place_* configs)")
+                                      "time embedding (the sapien place_* configs) and for context-free fields (KeypointExtractor)")
         if temb not in ([256, 128, 64], [512, 256, 128]):
             raise NotImplementedError(f"time_emb_mlp {temb}")
         radii = [None if r is None else float(r) for r in tf['r_cluster_multiscale']]

@@ -18,6 +18,9 @@
  *   dedf_sample          ScoreModelBase.sample (inner loop)       score_model_base.py:110-204
  *   dedf_energy          EbmScoreModelHead.compute_energy         score_head_ebm.py:122-174
  *   dedf_layer_forward   one {radial, gnn} layer of UnetFeatureExtractor      unet_feature_extractor.py:141-202, 289-324; block.py:141-174
+ *   dedf_field           MultiscaleTensorField.forward at given points          multiscale_tensor_field.py:192-260 (KeypointExtractor's two fields,
+ *                                                                                keypoint_extractor.py:179-188)
+ *   dedf_keypoint_weight the weight head of KeypointExtractor                   keypoint_extractor.py:113-119, 189-194; gnn_block.py:112,214-216
  *   dedf_destroy         module deletion
  *
  * Conventions: all tensor arguments are DEVICE pointers owned by the caller (the library never frees or mutates
@@ -49,7 +52,8 @@ typedef struct dedf_config {
     int lmax;                            /* irreps = 64x0e + 32x1e (+ 16x2e); SH 0..lmax.  Supported: 1, 2 */
     int mul[4];                          /* must equal {64,32,16,8}[0..lmax] (every reference config) */
     int num_heads;                       /* 4 */
-    int fc_neurons[3];                   /* {64 + time_emb_mlp[2],128,64} ({64,128,64} for the EBM head), or {128,32,32} (sapien place_* score heads):
+    int fc_neurons[3];                   /* {64 + time_emb_mlp[2],128,64} ({64,128,64} for the EBM head), {128,32,32} (sapien place_* score heads), or
+                                            {64,32,32} with ebm = 1 (the context-free fields of KeypointExtractor, lmax 2 only):
                                             fc_neurons after the -1 is resolved (multiscale_tensor_field.py:63-67) */
     int length_emb_dim;                  /* 64 */
     int time_emb_mlp[3];                 /* {256,128,64}, or {512,256,128} (sapien high-res configs; fc_neurons[0] = 192) */
@@ -144,6 +148,23 @@ int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedul
  * Returns DEDF_ERR_INVALID if edge_dst is not sorted or an index is out of range (checked on device, reported after a sync). */
 int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const float* f_src, int n_dst, const float* x_dst, const float* f_dst,
                        int64_t n_edges, const int64_t* edge_src, const int64_t* edge_dst, float* out, void* stream);
+
+/* MultiscaleTensorField.forward(query_points, input_points_multiscale, context_emb=None) (multiscale_tensor_field.py:192-260) for a field
+ * without context encoding and without query features -- the key field of an EBM-type handle (dedf_config.ebm = 1), which is also what
+ * KeypointExtractor.tensor_field / .weight_field are (keypoint_extractor.py:97-112: irreps_query = None, edge_context_emb_dim = None).
+ * x: (n,3) points in the frame of the key clouds (dedf_set_key_clouds must have been called) -> field_out (n,D): the block's output
+ * FFN(post_norm(emb)) + emb, and, if emb_out != NULL, emb (n,D): the attention output before the FFN (gnn_block.py:199-209) -- a field whose
+ * irreps_output differs from its input irreps ends in skip_2(emb) instead of emb, see dedf_keypoint_weight.  Reference feature layout.
+ * Replaces the query cloud of the handle (call dedf_set_query again before dedf_energy).  Points without any neighbour get the bias-only value. */
+int dedf_field(dedf_handle* h, int n, const float* x, float* field_out, float* emb_out, void* stream);
+
+/* The scalar head of KeypointExtractor.weight_field + weight_post (keypoint_extractor.py:111-119,185-194) from the outputs of dedf_field on a handle
+ * whose ffn.fctp_2 is the weight field's (192x0e -> 64x0e; the rows of the other degrees zero):
+ *   pre = (field[:, :64] - emb[:, :64]) + skip_W^T emb[:, :64] + skip_b         FFN output + skip_2 = LinearRS(emb -> 64x0e, bias), gnn_block.py:112,214-216
+ *   w   = act(lin_w . SiLU(LayerNorm(pre; ln_w, ln_b)) + lin_b) * mult          torch.nn.LayerNorm(64) eps 1e-5, SiLU, Linear(64,1); act = sigmoid (1) or identity (0)
+ * field, emb: (n,D) with D >= 64 = row stride `stride` floats; skip_W (64,64) [in][out]; all device pointers except lin_b, mult; out (n,). */
+int dedf_keypoint_weight(const float* field, const float* emb, int n, int stride, const float* skip_W, const float* skip_b, const float* ln_w,
+                         const float* ln_b, const float* lin_w, float lin_b, int sigmoid, float mult, float* out, void* stream);
 
 int dedf_get_stats(dedf_handle* h, dedf_stats* out);   /* synchronises the last used stream */
 

@@ -595,10 +595,13 @@ def time_embeddings(cfg: Config, P, time: Tensor) -> List[Tensor]:
 
 
 def key_tensor_field(cfg: Config, P, query_x: Tensor, key_pcd_multiscale: Sequence[FeaturedPoints],
-                     context_emb: List[Tensor], dbg: Optional[Debug] = None) -> Tensor:
+                     context_emb: List[Tensor], dbg: Optional[Debug] = None, pre: str = "key_tensor_field",
+                     irreps_output: Optional[Irreps] = None) -> Tensor:
     """MultiscaleTensorField.forward (multiscale_tensor_field.py:192-260) + EquiformerBlock.forward
-    (gnn_block.py:164-218) + GraphAttentionMLP2.forward (graph_attention.py:218-273)."""
-    pre = "key_tensor_field"
+    (gnn_block.py:164-218) + GraphAttentionMLP2.forward (graph_attention.py:218-273).
+    ``pre``: where the module sits in the state dict (``tensor_field`` / ``weight_field`` inside a KeypointExtractor);
+    ``irreps_output``: the field's output irreps when they differ from its input irreps (the KeypointExtractor's weight field,
+    keypoint_extractor.py:111-112): the FFN then ends in them and skip_2 is a LinearRS with bias (gnn_block.py:112)."""
     irreps, irreps_sh, H = cfg.irreps, cfg.irreps_sh, cfg.num_heads
     n_total = 0
     E_src, E_dst, E_attr, E_scal, E_logit, E_len = [], [], [], [], [], []
@@ -688,10 +691,14 @@ def key_tensor_field(cfg: Config, P, query_x: Tensor, key_pcd_multiscale: Sequen
     h = t1(out, y1, P[f"{blk}.ffn.fctp_1.tp.weight"])
     h = add_bias(h, ffn_in, P, f"{blk}.ffn.fctp_1")
     h = gate(h, sc, gt, gd)
-    t2 = fctp(mid, [(1, 0)], irreps)
+    ir_out = irreps if irreps_output is None else irreps_output
+    t2 = fctp(mid, [(1, 0)], ir_out)
     o = t2(h, y1, P[f"{blk}.ffn.fctp_2.tp.weight"])
-    o = add_bias(o, irreps, P, f"{blk}.ffn.fctp_2")
-    o = o + emb
+    o = add_bias(o, ir_out, P, f"{blk}.ffn.fctp_2")
+    if list(ir_out) == list(irreps):
+        o = o + emb                                               # skip_2 = Identity
+    else:
+        o = o + linear_rs(emb, irreps, ir_out, P, f"{blk}.skip_2.skip", bias=True)      # ProjectIfMismatch(layernorm=False)
     if dbg is not None:
         dbg.update(edge_src=edge_src, edge_dst=edge_dst, edge_attr=edge_attr, edge_scalars=edge_scalars,
                    edge_logits=edge_logits, edge_length=torch.cat(E_len), msg_src=msg_src, dtp_weight=weight,

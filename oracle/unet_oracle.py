@@ -262,3 +262,35 @@ def unet_forward(cfg: UnetConfig, P: Dict[str, Tensor], x: Tensor, f: Tensor, db
     up_out = up_out[::-1]
     scales = list(range(ns)) if cfg.output_scalespace is None else [ns + s if s < 0 else s for s in cfg.output_scalespace]
     return [(up_out[s][0], project_if_mismatch(up_out[s][1], emb[s], cfg.irreps_output, P, f"project_outputs.{s}")) for s in range(ns) if s in scales]
+
+
+# =====================================================================================================================================
+# KeypointExtractor — keypoint_extractor.py:50-197
+# =====================================================================================================================================
+
+def keypoint_extractor_forward(unet_cfg: UnetConfig, field_cfg: "R.Config", P: Dict[str, Tensor], x: Tensor, f: Tensor, pool_ratio: float,
+                               bbox=None, weight_sigmoid: bool = True, weight_mult: Optional[float] = None, dbg: Optional[dict] = None):
+    """-> (key-point coordinates, features (nK, D), weights (nK,)).  ``x`` float32 (graphs and FPS in float32), arithmetic in the dtype of ``f``.
+    UNet on the whole cloud (:172); key points = FPS over the points inside ``bbox`` (:136-150, deterministic start); ``tensor_field`` and
+    ``weight_field`` (MultiscaleTensorField without context / query features, :97-112) evaluated at them; ``weight_post`` = LayerNorm, SiLU,
+    Linear(·,1), Sigmoid (:113-118)."""
+    from . import graph_oracle as GO
+    dt = f.dtype
+    scales = unet_forward(unet_cfg, _sub(P, "feature_extractor."), x, f)
+    key_pcds = [R.FeaturedPoints(x=xs.to(dt), f=fs, b=torch.zeros(len(xs), dtype=torch.long), w=None) for xs, fs in scales]
+    xq = x
+    if bbox is not None:
+        bb = torch.tensor(bbox, dtype=x.dtype)
+        xq = xq[((xq >= bb[:, 0]) & (xq <= bb[:, 1])).all(dim=-1)]
+    xq = xq[torch.from_numpy(GO.fps(xq.numpy(), pool_ratio, start=0))]
+    feat = R.key_tensor_field(field_cfg, P, xq.to(dt), key_pcds, None, pre="tensor_field")
+    wpre = R.key_tensor_field(field_cfg, P, xq.to(dt), key_pcds, None, pre="weight_field", irreps_output=[(P["weight_post.0.weight"].numel(), 0)])
+    h = torch.nn.functional.layer_norm(wpre, (wpre.shape[-1],), P["weight_post.0.weight"], P["weight_post.0.bias"], 1e-5)
+    w = (torch.nn.functional.silu(h) @ P["weight_post.2.weight"].t() + P["weight_post.2.bias"]).squeeze(-1)
+    if weight_sigmoid:
+        w = torch.sigmoid(w)
+    if weight_mult is not None:
+        w = w * weight_mult
+    if dbg is not None:
+        dbg.update(scales=scales, wpre=wpre)
+    return xq, feat, w

@@ -1,0 +1,156 @@
+"""KeypointExtractor (keypoint_extractor.py:50-197): the place tasks' query model = UNet + FPS key points + two context-free
+MultiscaleTensorFields + the weight head.  CPU: schema / construction / oracle sanity.  GPU: dedf_field and the whole extractor against the fp64
+restatement."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from diffusion_edf_amd import synthetic
+from oracle import restatement as R
+from oracle import unet_oracle as U
+from test_unet import _oracle_cfg, _randomized, _unet_kwargs
+
+WIDE = "64x0e+32x1e+16x2e"
+
+
+def _query_kwargs(radii=(5.0, 10.0, 20.0, 40.0), bbox=((-30.0, 30.0), (-30.0, 30.0), (8.0, 100.0)), unet="panda_highres", pool_ratio=0.1):
+    """the query_kwargs block of configs/panda_*/place_*/score_model_configs.yaml"""
+    return dict(weight_activation="sigmoid", weight_mult=None,
+                keypoint_kwargs=dict(pool_ratio=pool_ratio, weight_pre_emb_dim=64, bbox=None if bbox is None else [list(b) for b in bbox]),
+                feature_extractor_kwargs=_unet_kwargs(unet),
+                tensor_field_kwargs=dict(irreps_output=WIDE, irreps_sh="1x0e+1x1e+1x2e", num_heads=4, fc_neurons=[-1, 32, 32], length_emb_dim=64,
+                                         r_cluster_multiscale=list(radii), n_scales=len(radii)))
+
+
+def _field_cfg(radii):
+    irr = R.parse_irreps(WIDE)
+    return R.Config(irreps=irr, irreps_sh=R.parse_irreps("1x0e+1x1e+1x2e"), num_heads=4, fc_neurons=[64, 32, 32], length_emb_dim=64,
+                    r_cluster_multiscale=list(radii), r_mincut_nonscalar_sh=0.01 * radii[0], length_enc_max_r=None, time_emb_mlp=[256, 128, 64],
+                    max_time=1.0, time_enc_n=10000.0, lin_mult=1.0, ang_mult=1.0, edge_time_encoding=False)
+
+
+def test_keypoint_extractor_schema():
+    from diffusion_edf_amd.keypoint_extractor import KeypointExtractor, MultiscaleTensorField, StaticKeypointModel
+    m = KeypointExtractor(**_query_kwargs(), deterministic=True)
+    sd = m.state_dict()
+    names = set(sd)
+    for k in ("feature_extractor.input_emb.tp.weight", "feature_extractor.mid_block.0.gnn.ga.alpha_dot",
+              "tensor_field.graph_parsers.3.length_enc.param_module.mean", "tensor_field.edge_scalars_pre_linears.0.0.weight",
+              "tensor_field.gnn_block_init.prenorm_src.affine_weight", "tensor_field.gnn_block_init.linear_src.bias.0",
+              "tensor_field.gnn_block_init.ga.sep_act.dtp_rad.net.0.weight", "tensor_field.gnn_block_init.post_norm.affine_bias",
+              "tensor_field.gnn_block_init.ffn.fctp_2.tp.weight", "weight_field.gnn_block_init.skip_2.skip.tp.weight",
+              "weight_field.gnn_block_init.skip_2.skip.bias.0", "weight_post.0.weight", "weight_post.2.bias"):
+        assert k in names, k
+    assert not any(k.startswith("tensor_field.gnn_block_init.skip_2") or "time_mlps" in k or "key_tensor_field" in k for k in names)
+    assert sd["tensor_field.edge_scalars_pre_linears.2.0.weight"].shape == (64, 64)                  # no context: fc_neurons[0] = length_emb_dim
+    assert sd["tensor_field.gnn_block_init.ga.sep_act.dtp_rad.net.0.weight"].shape == (32, 64)
+    assert sd["tensor_field.gnn_block_init.ffn.fctp_2.tp.weight"].numel() == 192 * 64 + 96 * 32 + 48 * 16
+    assert sd["weight_field.gnn_block_init.ffn.fctp_2.tp.weight"].numel() == 192 * 64                # ends in 64x0e
+    assert sd["weight_field.gnn_block_init.skip_2.skip.tp.weight"].numel() == 64 * 64
+    assert "weight_mult_logit" not in names
+    m2 = KeypointExtractor(**dict(_query_kwargs(), weight_mult=2.0), deterministic=True)
+    assert abs(float(torch.nn.functional.softplus(m2.state_dict()["weight_mult_logit"])) - 2.0) < 1e-6
+    with pytest.raises(NotImplementedError):
+        MultiscaleTensorField(irreps_input=WIDE, irreps_output=WIDE, irreps_sh="1x0e+1x1e+1x2e", num_heads=4, fc_neurons=[-1, 32, 32],
+                              length_emb_dim=64, irreps_query=WIDE, r_cluster_multiscale=[5.0], edge_context_emb_dim=None)
+    with pytest.raises(RuntimeError):                        # no CPU path
+        from diffusion_edf_amd.gnn_data import FeaturedPoints
+        m(FeaturedPoints(x=torch.zeros(50, 3), f=torch.zeros(50, 3), b=torch.zeros(50, dtype=torch.long), w=None))
+    s = StaticKeypointModel([[0.0, 0.0, 1.0], [1.0, 0.0, 0.0]], WIDE)
+    from diffusion_edf_amd.gnn_data import FeaturedPoints
+    out = s(FeaturedPoints(x=torch.zeros(4, 3), f=torch.zeros(4, 3), b=torch.zeros(4, dtype=torch.long), w=None))
+    assert out.x.shape == (2, 3) and out.f.shape == (2, 240) and out.w.shape == (2,) and bool(((out.w > 0) & (out.w < 1)).all())
+    assert set(s.state_dict()) == {"keypoint_coords", "keypoint_features", "keypoint_weights"}
+
+
+def _object_cloud(n, seed):
+    """a grasped-object-sized cloud: the synthetic scene shrunk into the bbox region"""
+    x = synthetic.make_scene(n, seed=seed).astype(np.float32)
+    x = (x - x.mean(0)) * 0.5
+    x[:, 2] += 14.0 - x[:, 2].min()
+    return torch.from_numpy(x.astype(np.float32))
+
+
+def test_keypoint_extractor_oracle_small():
+    """weights in (0,1), key points inside the bbox, the weight field's skip_2 really is the LinearRS (zeroing it changes the weights), and the
+    field at a point far from everything is the bias-only value (no edges: attention output 0 -> emb = proj bias)"""
+    from diffusion_edf_amd.keypoint_extractor import KeypointExtractor
+    radii = (5.0, 10.0, 20.0, 40.0)
+    m = KeypointExtractor(**_query_kwargs(radii), deterministic=True)
+    sd = _randomized(m, seed=2)
+    P = R.cast_params(sd, torch.float64)
+    x = _object_cloud(1200, seed=1)
+    x[:, 2] -= 8.0                                                      # part of the cloud below the bbox floor
+    f = torch.rand(len(x), 3, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    bbox = _query_kwargs()["keypoint_kwargs"]["bbox"]
+    xq, feat, w = U.keypoint_extractor_forward(_oracle_cfg(m.feature_extractor), _field_cfg(radii), P, x, f, 0.1, bbox=bbox)
+    n_in = int(((x >= torch.tensor(bbox)[:, 0]) & (x <= torch.tensor(bbox)[:, 1])).all(-1).sum())
+    assert 0 < n_in < len(x) and len(xq) == math.ceil(0.1 * n_in) and float(xq[:, 2].min()) >= 8.0
+    assert feat.shape == (len(xq), 240) and w.shape == (len(xq),) and bool(((w > 0) & (w < 1)).all()) and bool(torch.isfinite(feat).all())
+    P0 = dict(P)
+    P0["weight_field.gnn_block_init.skip_2.skip.tp.weight"] = P0["weight_field.gnn_block_init.skip_2.skip.tp.weight"] * 0
+    _, feat0, w0 = U.keypoint_extractor_forward(_oracle_cfg(m.feature_extractor), _field_cfg(radii), P0, x, f, 0.1, bbox=bbox)
+    assert torch.equal(feat0, feat) and float((w0 - w).abs().max()) > 1e-4
+
+
+@pytest.mark.gpu
+def test_dedf_field_matches_the_oracle_and_handles_isolated_points():
+    """MultiscaleTensorField.forward on the HIP path (dedf_field) against the restatement, on random key clouds at four finite scales; the query
+    points include some beyond every radius (no edges): their field is the bias-only value, as the reference's scatter gives"""
+    from diffusion_edf_amd.gnn_data import FeaturedPoints
+    from diffusion_edf_amd.keypoint_extractor import MultiscaleTensorField
+    dev = torch.device("cuda:0")
+    radii = (5.0, 10.0, 20.0, 40.0)
+    g = torch.Generator().manual_seed(0)
+    key = [FeaturedPoints(x=torch.rand(n, 3, generator=g) * 50.0, f=torch.randn(n, 240, generator=g), b=torch.zeros(n, dtype=torch.long), w=None)
+           for n in (900, 300, 90, 30)]
+    xq = torch.cat([torch.rand(200, 3, generator=g) * 50.0, torch.tensor([[500.0, 0.0, 0.0], [0.0, -400.0, 90.0]])])
+    for scalar_out in (False, True):
+        m = MultiscaleTensorField(irreps_input=WIDE, irreps_output="64x0e" if scalar_out else WIDE, irreps_sh="1x0e+1x1e+1x2e", num_heads=4,
+                                  fc_neurons=[-1, 32, 32], length_emb_dim=64, irreps_query=None, r_cluster_multiscale=list(radii),
+                                  edge_context_emb_dim=None)
+        sd = _randomized(m, seed=7)
+        P = R.cast_params({"tf." + k: v for k, v in sd.items()}, torch.float64)
+        kd = [R.FeaturedPoints(x=p.x.double(), f=p.f.double(), b=p.b, w=None) for p in key]
+        ref = R.key_tensor_field(_field_cfg(radii), P, xq.double(), kd, None, pre="tf", irreps_output=[(64, 0)] if scalar_out else None)
+        m.to(dev)
+        out = m(FeaturedPoints(x=xq.to(dev), f=torch.empty(len(xq), 3, device=dev), b=torch.zeros(len(xq), dtype=torch.long, device=dev), w=None),
+                [FeaturedPoints(x=p.x.to(dev), f=p.f.to(dev), b=p.b.to(dev), w=None) for p in key])
+        got = out.f.cpu().double()
+        assert got.shape == ref.shape and torch.equal(out.x.cpu(), xq)
+        err = float((got - ref).abs().max()) / float(ref.abs().max())
+        assert err < 1e-4, (scalar_out, err)
+        assert float((got[-2:] - ref[-2:]).abs().max()) < 1e-5 * float(ref.abs().max())          # isolated points
+        assert float((ref[-1] - ref[-2]).abs().max()) < 1e-12                                      # ... all get the same bias-only value
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_points,bbox", [(5000, True), (2500, False)])
+def test_keypoint_extractor_matches_the_oracle(n_points, bbox):
+    from diffusion_edf_amd.gnn_data import FeaturedPoints
+    from diffusion_edf_amd.keypoint_extractor import KeypointExtractor
+    dev = torch.device("cuda:0")
+    radii = (5.0, 10.0, 20.0, 40.0)
+    kw = _query_kwargs(radii) if bbox else _query_kwargs(radii, bbox=None)
+    m = KeypointExtractor(**kw, deterministic=True)
+    sd = _randomized(m, seed=9)
+    x = _object_cloud(n_points, seed=3)
+    if bbox:
+        x[:, 2] -= 8.0
+    f = torch.rand(n_points, 3, generator=torch.Generator().manual_seed(1))
+    xr, fr, wr = U.keypoint_extractor_forward(_oracle_cfg(m.feature_extractor), _field_cfg(radii), R.cast_params(sd, torch.float64), x, f.double(),
+                                              0.1, bbox=kw["keypoint_kwargs"]["bbox"])
+    m.to(dev)
+    out = m(FeaturedPoints(x=x.to(dev), f=f.to(dev), b=torch.zeros(n_points, dtype=torch.long, device=dev), w=None))
+    assert torch.equal(out.x.cpu(), xr) and out.f.shape == fr.shape and out.w.shape == wr.shape
+    got = out.f.cpu().double()
+    off = 0
+    for mul, l in R.parse_irreps(WIDE):
+        d = mul * (2 * l + 1)
+        err = float((got[:, off:off + d] - fr[:, off:off + d]).abs().max()) / float(fr[:, off:off + d].abs().max())
+        assert err < 2e-4, (l, err)
+        off += d
+    assert float((out.w.cpu().double() - wr).abs().max()) < 2e-4
+    assert float(wr.max() - wr.min()) > 1e-3                       # the weights are not a constant
