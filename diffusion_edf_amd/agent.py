@@ -9,12 +9,14 @@ Mirrors, for everything that touches the score head (same names, argument meanin
   reference diffusion_edf/agent.py:20-64                      -> ``get_models``
   reference diffusion_edf/agent.py:66-186                     -> ``DiffusionEdfAgent`` (``compute_critic_energy``, ``sample``)
 
-What is NOT here: the UNet / keypoint feature extractors and ``edf_interface`` (PointCloud, SE3 types; the
-pre-processing steps its YAML names are in ``preprocess.py``, the task-level files agent.yaml / server.yaml in ``configs.py``).  They are *injected*: every model takes a ``key_extractor`` and a ``query_extractor`` — any callable
-``FeaturedPoints -> List[FeaturedPoints]`` / ``FeaturedPoints -> FeaturedPoints`` with an ``irreps_output`` attribute, e.g. the
-reference's own modules running in PyTorch, or ``PrecomputedFeatures`` below.  The one exception is ``StaticKeypointModel``
-(the query model of the pick_* configs): it holds parameters only and is built here.  Without them ``get_key_pcd_multiscale`` /
-``get_query_pcd`` raise ``NotImplementedError`` — there is no silent stand-in.
+The feature extractors are built from the YAML blocks like the reference builds them — ``UnetFeatureExtractor``
+/ ``ForwardOnlyFeatureExtractor`` (``unet.py``), ``KeypointExtractor`` and ``StaticKeypointModel`` (``keypoint_extractor.py``), all on the
+HIP kernels — so a reference
+``score_model_state_dict`` loads into ``key_model.*`` / ``query_model.*`` / ``score_head.*`` by name.  They can also be *injected*: every model
+takes a ``key_extractor`` and a ``query_extractor`` — any callable ``FeaturedPoints -> List[FeaturedPoints]`` / ``FeaturedPoints ->
+FeaturedPoints`` with an ``irreps_output`` attribute, e.g. ``PrecomputedFeatures`` below.  What is NOT here: ``edf_interface`` (PointCloud, SE3
+types; the pre-processing steps its YAML names are in ``preprocess.py``, the task-level files agent.yaml / server.yaml in ``configs.py``),
+and the Pyro service.
 """
 from __future__ import annotations
 
@@ -27,6 +29,7 @@ import yaml
 
 from . import dist as ddist
 from .gnn_data import FeaturedPoints
+from .keypoint_extractor import KeypointExtractor, StaticKeypointModel
 from .score_head import EbmScoreModelHead, ScoreModelHead
 from .score_model_base import ScoreModelBase
 
@@ -41,29 +44,6 @@ class PrecomputedFeatures(torch.nn.Module):
 
     def forward(self, pcd=None):
         return self.output
-
-
-class StaticKeypointModel(torch.nn.Module):
-    """reference keypoint_extractor.py:22-47 — the query model of every pick_* config: fixed keypoint coordinates (buffer), learned
-    features and weight logits (parameters; same names, so `query_model.*` of a reference checkpoint loads); the output is
-    repeated once per batch index present in the input."""
-
-    def __init__(self, keypoint_coords, irreps_output):
-        super().__init__()
-        keypoint_coords = torch.tensor(keypoint_coords)
-        assert keypoint_coords.ndim == 2 and keypoint_coords.shape[-1] == 3, f"{keypoint_coords.shape}"  # (nPoints, 3)
-        self.irreps_output = str(irreps_output)
-        from .params import irreps_dim, parse_irreps
-        self.register_buffer("keypoint_coords", keypoint_coords)
-        self.keypoint_features = torch.nn.Parameter(torch.randn(len(self.keypoint_coords), irreps_dim(parse_irreps(self.irreps_output))))
-        self.keypoint_weights = torch.nn.Parameter(torch.randn(len(self.keypoint_coords)))
-
-    def forward(self, input_points: FeaturedPoints) -> FeaturedPoints:
-        assert input_points.b.ndim == 1
-        batches = torch.unique(input_points.b)          # one copy of the keypoints per batch index present in the input
-        n_rep, n_kp = len(batches), len(self.keypoint_coords)
-        return FeaturedPoints(x=self.keypoint_coords.repeat(n_rep, 1), f=self.keypoint_features.repeat(n_rep, 1),
-                              b=batches.repeat(n_kp), w=torch.sigmoid(self.keypoint_weights).repeat(n_rep))
 
 
 class MultiscaleScoreModel(ScoreModelBase):
@@ -88,9 +68,17 @@ class MultiscaleScoreModel(ScoreModelBase):
             raise ValueError(f"Unknown feature extractor name: {key_name}")                    # :51
         if query_model not in ('KeypointExtractor', 'StaticKeypointModel'):
             raise ValueError(f"Unknown query model: {query_model}")                            # :62
+        if key_extractor is None and self._use_src_point_attn:
+            key_extractor = KeypointExtractor(**copy.deepcopy(key_kwargs), deterministic=deterministic)     # point_attentive_score_model.py:34-37
+        elif key_extractor is None:
+            from .unet import ForwardOnlyFeatureExtractor, UnetFeatureExtractor
+            cls = UnetFeatureExtractor if key_name == 'UnetFeatureExtractor' else ForwardOnlyFeatureExtractor
+            key_extractor = cls(**key_kwargs['feature_extractor_kwargs'], deterministic=deterministic)     # :40-51
         self.key_model = key_extractor
         if query_extractor is None and query_model == 'StaticKeypointModel':
-            query_extractor = StaticKeypointModel(**query_kwargs)                               # :58-60 (parameters only: built here)
+            query_extractor = StaticKeypointModel(**query_kwargs)                               # :58-60
+        elif query_extractor is None and query_model == 'KeypointExtractor':
+            query_extractor = KeypointExtractor(**copy.deepcopy(query_kwargs), deterministic=deterministic)                  # :54-57
         self.query_model = query_extractor
         key_irreps = getattr(key_extractor, 'irreps_output', None) or key_kwargs['feature_extractor_kwargs']['irreps_output']
         if getattr(query_extractor, 'irreps_output', None):
@@ -125,8 +113,7 @@ class MultiscaleScoreModel(ScoreModelBase):
 
     def _extract(self, which: str, fn, pcd):
         if fn is None:
-            raise NotImplementedError(f"{which}: the feature extractors are not part of this build (SURVEY §8(f) row 1); pass "
-                                      "key_extractor / query_extractor (e.g. the reference's modules or PrecomputedFeatures)")
+            raise NotImplementedError(f"{which}: no extractor")
         return fn(pcd)
 
     def get_key_pcd_multiscale(self, pcd) -> List[FeaturedPoints]:                              # :130-131

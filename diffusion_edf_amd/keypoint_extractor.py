@@ -193,7 +193,7 @@ class KeypointExtractor(torch.nn.Module):
                  feature_extractor_name: str = 'UnetFeatureExtractor', weight_activation: str = 'sigmoid',
                  weight_mult: Optional[Union[float, int]] = None, deterministic: bool = False):
         super().__init__()
-        from .unet import UnetFeatureExtractor
+        from .unet import ForwardOnlyFeatureExtractor, UnetFeatureExtractor
         self.deterministic = deterministic
         self.pool_ratio = float(keypoint_kwargs['pool_ratio'])
         self.keypoint_bbox = keypoint_kwargs.get('bbox', None)
@@ -212,9 +212,12 @@ class KeypointExtractor(torch.nn.Module):
             self.weight_mult_logit = None
         else:
             self.weight_mult_logit = torch.nn.Parameter(torch.log(torch.exp(torch.tensor(float(weight_mult))) - 1), requires_grad=False)
-        if feature_extractor_name != 'UnetFeatureExtractor':
-            raise NotImplementedError(f"feature extractor {feature_extractor_name!r} (no shipped config uses it)")
-        self.feature_extractor = UnetFeatureExtractor(**feature_extractor_kwargs, deterministic=deterministic)
+        if feature_extractor_name == 'UnetFeatureExtractor':
+            self.feature_extractor = UnetFeatureExtractor(**feature_extractor_kwargs, deterministic=deterministic)
+        elif feature_extractor_name == 'ForwardOnlyFeatureExtractor':
+            self.feature_extractor = ForwardOnlyFeatureExtractor(**feature_extractor_kwargs, deterministic=deterministic)
+        else:
+            raise ValueError(f"Unknown feature extractor name: {feature_extractor_name}")
         tf = dict(tensor_field_kwargs)
         for k in ('irreps_input', 'irreps_query', 'edge_context_emb_dim'):
             assert k not in tf                                                         # :93-101

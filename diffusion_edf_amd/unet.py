@@ -256,6 +256,8 @@ class UnetFeatureExtractor(torch.nn.Module):
     Supported: lmax 2, irreps_emb per level 64x0e+32x1e+16x2e or 32x0e+16x1e+8x2e with fc_neurons [64,32,32] / [32,16,16], 4 heads,
     pool_method 'fps', attn_type 'mlp' — every UNet the reference ships.  Dropout / drop-path are identity in eval and not modelled."""
 
+    _forward_only = False
+
     def __init__(self, irreps_input, irreps_output, irreps_emb, irreps_edge_attr, num_heads, fc_neurons, n_layers, pool_ratio, radius,
                  deterministic: bool = False, pool_method='fps', irreps_mlp_mid=3, attn_type='mlp', alpha_drop=0.1, proj_drop=0.1,
                  drop_path_rate=0.0, n_layers_midstream: int = 2, n_scales: Optional[int] = None, output_scalespace=None):
@@ -296,9 +298,9 @@ class UnetFeatureExtractor(torch.nn.Module):
             blk['pool_layer'] = mk(n, prev, emb[n])
             blk['layer_stack'] = torch.nn.ModuleList([mk(n, emb[n], emb[n]) for _ in range(n_layers[n] - 1)])
             self.down_blocks.append(blk)
-        self.mid_block = torch.nn.ModuleList([mk(ns - 1, emb[-1], emb[-1]) for _ in range(n_layers_midstream)])
+        self.mid_block = torch.nn.ModuleList([mk(ns - 1, emb[-1], emb[-1]) for _ in range(0 if self._forward_only else n_layers_midstream)])
         self.up_blocks = torch.nn.ModuleList()
-        for n in range(ns - 1, -1, -1):
+        for n in range(-1 if self._forward_only else ns - 1, -1, -1):
             blk = torch.nn.ModuleDict()
             blk['layer_stack'] = torch.nn.ModuleList([mk(n, emb[n], emb[n]) for _ in range(n_layers[n] - 1)])
             blk['unpool_layer'] = mk(n, emb[n], emb[max(n - 1, 0)])
@@ -315,7 +317,7 @@ class UnetFeatureExtractor(torch.nn.Module):
         x, f, b = pcd.x, pcd.f, pcd.b
         assert f.ndim == 2 and x.ndim == 2 and b.ndim == 1 and len(f) == len(x) == len(b)
         f = self.input_emb(f)
-        down_out, down_edges = [(f, x, b)], []
+        down_out, down_edges, scale_out = [(f, x, b)], [], []
         for blk in self.down_blocks:
             f_dst, x_dst, es, ed, _, b_dst = blk['pool'](x, f, b)                                    # :279-282
             f_dst = blk['pool_proj'](f_dst)
@@ -326,6 +328,10 @@ class UnetFeatureExtractor(torch.nn.Module):
             for layer in blk['layer_stack']:
                 f = layer(x, f, x, f, es, ed)
                 down_out.append((f, x, b)); down_edges.append((es, ed, x, x))
+            scale_out.append((f, x, b))
+        if self._forward_only:                                                                        # forward_only_feature_extractor.py:258-274
+            return [FeaturedPoints(x=scale_out[s][1], f=self.project_outputs[s](scale_out[s][0]), b=scale_out[s][2], w=None)
+                    for s in range(self.n_scales) if s in self.output_scalespace]
         for layer in self.mid_block:                                                                  # :332-344 (the last radius graph)
             f = layer(x, f, x, f, es, ed)
         f_skip, _, _ = down_out.pop()
@@ -347,3 +353,11 @@ class UnetFeatureExtractor(torch.nn.Module):
         up_out = up_out[::-1]
         return [FeaturedPoints(x=up_out[s][1], f=self.project_outputs[s](up_out[s][0]), b=up_out[s][2], w=None)
                 for s in range(self.n_scales) if s in self.output_scalespace]
+
+
+class ForwardOnlyFeatureExtractor(UnetFeatureExtractor):
+    """reference ``forward_only_feature_extractor.py:19-275`` (the key model of the sapien high-res configs): the down path of the UNet only —
+    per scale FpsPool -> pool layer -> radius-graph layer stack — and the features at the end of each scale, projected to ``irreps_output``.
+    Same constructor keywords (``n_layers_midstream`` is accepted and unused, as in the reference); state-dict names ``input_emb.*``,
+    ``down_blocks.N.*``, ``project_outputs.N.*``."""
+    _forward_only = True

@@ -211,8 +211,9 @@ def project_if_mismatch(x: Tensor, ir_in, ir_out, P, prefix: str) -> Tensor:
     return R.linear_rs(x, ir_in, ir_out, P, f"{prefix}.skip", bias=True)
 
 
-def unet_forward(cfg: UnetConfig, P: Dict[str, Tensor], x: Tensor, f: Tensor, dbg: Optional[dict] = None):
-    """-> [(coords, features)] per output scale.  ``x`` (N,3) float32 — the graphs are built in float32 exactly like torch_cluster does
+def unet_forward(cfg: UnetConfig, P: Dict[str, Tensor], x: Tensor, f: Tensor, dbg: Optional[dict] = None, forward_only: bool = False):
+    """-> [(coords, features)] per output scale.  ``forward_only``: ForwardOnlyFeatureExtractor (forward_only_feature_extractor.py:196-274) = the
+    down path alone, one output per scale taken after its layer stack.  ``x`` (N,3) float32 — the graphs are built in float32 exactly like torch_cluster does
     (graph_oracle.py), the layers run in the dtype of ``f`` / ``P`` on those coordinates.  Single cloud (batch all 0), deterministic FPS
     (start at point 0), eval mode (dropout / drop-path are identity)."""
     from . import graph_oracle as GO
@@ -221,7 +222,8 @@ def unet_forward(cfg: UnetConfig, P: Dict[str, Tensor], x: Tensor, f: Tensor, db
     lcfg = lambda n, src, dst: LayerConfig(dst, cfg.irreps_sh, cfg.num_heads, cfg.fc_neurons[n], cfg.radius[n], irreps_src=src)
     run = lambda c, prefix, xs, fs, xd, fd, es, ed: layer_forward(c, _sub(P, prefix), xs.to(dt), fs, xd.to(dt), fd, es, ed)
     f = R.linear_rs(f, cfg.irreps_input, emb[0], P, "input_emb", bias=True)                            # :270-271
-    down_out, down_edges = [(f, x)], []
+    down_out, down_edges, scale_out = [(f, x)], [], []
+    scales = list(range(ns)) if cfg.output_scalespace is None else [ns + s if s < 0 else s for s in cfg.output_scalespace]
     for n in range(ns):
         prev = emb[max(n - 1, 0)]
         idx = GO.fps(x.numpy(), cfg.pool_ratio[n], start=0)                                             # FpsPool, connectivity.py:56-80
@@ -238,6 +240,9 @@ def unet_forward(cfg: UnetConfig, P: Dict[str, Tensor], x: Tensor, f: Tensor, db
         for i in range(cfg.n_layers[n] - 1):
             f = run(lcfg(n, emb[n], emb[n]), f"down_blocks.{n}.layer_stack.{i}.", x, f, x, f, es, ed)
             down_out.append((f, x)); down_edges.append((es, ed))
+        scale_out.append((x, f))
+    if forward_only:
+        return [(scale_out[s][0], project_if_mismatch(scale_out[s][1], emb[s], cfg.irreps_output, P, f"project_outputs.{s}")) for s in range(ns) if s in scales]
     for i in range(cfg.n_layers_midstream):                                                            # :332-344
         f = run(lcfg(ns - 1, emb[-1], emb[-1]), f"mid_block.{i}.", x, f, x, f, es, ed)
     f_skip, _ = down_out.pop()
@@ -260,7 +265,6 @@ def unet_forward(cfg: UnetConfig, P: Dict[str, Tensor], x: Tensor, f: Tensor, db
             f = run(lcfg(n, emb[n], emb[max(n - 1, 0)]), f"up_blocks.{k}.unpool_layer.", x, f, x_dst, f_dst, ed, es)
             x = x_dst
     up_out = up_out[::-1]
-    scales = list(range(ns)) if cfg.output_scalespace is None else [ns + s if s < 0 else s for s in cfg.output_scalespace]
     return [(up_out[s][0], project_if_mismatch(up_out[s][1], emb[s], cfg.irreps_output, P, f"project_outputs.{s}")) for s in range(ns) if s in scales]
 
 

@@ -12,6 +12,7 @@ import yaml
 from diffusion_edf_amd import agent as A
 from diffusion_edf_amd import params, synthetic
 from diffusion_edf_amd.gnn_data import FeaturedPoints
+from test_unet import _unet_kwargs
 
 CFG_ROOT = "/root/reference/configs"
 DIRS = sorted(os.path.dirname(f) for f in glob.glob(os.path.join(CFG_ROOT, "*", "*", "score_model_configs.yaml")))
@@ -27,7 +28,7 @@ def _model_yaml(kw):
         tf.pop(k, None)
     return dict(model_name='MultiscaleScoreModel',
                 model_kwargs=dict(score_head_kwargs=sh,
-                                  key_kwargs=dict(feature_extractor_name='UnetFeatureExtractor', feature_extractor_kwargs=dict(irreps_output=irr)),
+                                  key_kwargs=dict(feature_extractor_name='UnetFeatureExtractor', feature_extractor_kwargs=_unet_kwargs("panda_lowres")),
                                   query_model='StaticKeypointModel',
                                   query_kwargs=dict(keypoint_coords=[[0.5, 0.5, 10.5], [-0.5, -0.5, 10.5]], irreps_output=irr)))
 
@@ -53,20 +54,36 @@ def test_get_models_on_shipped_config_dirs(d):
     assert isinstance(m, A.PointAttentiveScoreModel) == (doc["model_name"] == "PointAttentiveScoreModel") == m.score_head.cfg.use_src_point_attn
     assert m.score_head.cfg.radii == [None if r is None else float(r) for r in sh["key_tensor_field_kwargs"]["r_cluster_multiscale"]]
     assert not m.training
-    with pytest.raises(NotImplementedError):          # extractors are injected, never silently replaced
-        m.get_key_pcd_multiscale(None)
+    # the feature extractors are built from the YAML blocks like the reference builds them (multiscale_score_model.py:40-62,
+    # point_attentive_score_model.py:34-50), under the reference's state-dict prefixes; they run on the GPU only
+    from diffusion_edf_amd.gnn_data import FeaturedPoints
+    from diffusion_edf_amd.keypoint_extractor import KeypointExtractor
+    from diffusion_edf_amd.unet import ForwardOnlyFeatureExtractor, UnetFeatureExtractor
+    kk = doc["model_kwargs"]["key_kwargs"]
+    want = KeypointExtractor if doc["model_name"] == "PointAttentiveScoreModel" else \
+        {"UnetFeatureExtractor": UnetFeatureExtractor, "ForwardOnlyFeatureExtractor": ForwardOnlyFeatureExtractor}[kk["feature_extractor_name"]]
+    assert type(m.key_model) is want
+    names = set(m.state_dict())
+    unet_prefix = "key_model.feature_extractor." if want is KeypointExtractor else "key_model."
+    assert unet_prefix + "input_emb.tp.weight" in names and unet_prefix + "down_blocks.0.pool_layer.gnn.ga.alpha_dot" in names
+    assert (unet_prefix + "mid_block.0.radial.mean" in names) == (kk["feature_extractor_name"] == "UnetFeatureExtractor")
+    if want is KeypointExtractor:
+        assert "key_model.weight_field.gnn_block_init.skip_2.skip.tp.weight" in names and "key_model.weight_post.2.weight" in names
+    cloud = FeaturedPoints(x=torch.zeros(5, 3), f=torch.zeros(5, 3), b=torch.zeros(5, dtype=torch.long))
+    with pytest.raises(RuntimeError):                  # no CPU path, and no silent stand-in
+        m.get_key_pcd_multiscale(cloud)
     if doc["model_kwargs"]["query_model"] == "StaticKeypointModel":       # parameters only: part of the model (keypoint_extractor.py:22-47)
         qk = doc["model_kwargs"]["query_kwargs"]
-        from diffusion_edf_amd.gnn_data import FeaturedPoints
-        q = m.get_query_pcd(FeaturedPoints(x=torch.zeros(5, 3), f=torch.zeros(5, 3), b=torch.zeros(5, dtype=torch.long)))
+        q = m.get_query_pcd(cloud)
         nK = len(qk["keypoint_coords"])
         assert q.x.shape == (nK, 3) and q.f.shape == (nK, m.score_head.cfg.dim) and q.w.shape == (nK,) and q.b.shape == (nK,)
         assert torch.equal(q.x, torch.tensor(qk["keypoint_coords"])) and bool(((q.w > 0) & (q.w < 1)).all())
         assert {k for k in m.state_dict() if k.startswith("query_model.")} == {
             "query_model.keypoint_coords", "query_model.keypoint_features", "query_model.keypoint_weights"}
     else:
-        with pytest.raises(NotImplementedError):
-            m.get_query_pcd(None)
+        assert type(m.query_model) is KeypointExtractor and "query_model.tensor_field.gnn_block_init.ga.alpha_dot" in names
+        with pytest.raises(RuntimeError):
+            m.get_query_pcd(cloud)
 
 
 def test_checkpoint_load_like_the_reference_agent(tmp_path):

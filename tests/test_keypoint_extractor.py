@@ -154,3 +154,55 @@ def test_keypoint_extractor_matches_the_oracle(n_points, bbox):
         off += d
     assert float((out.w.cpu().double() - wr).abs().max()) < 2e-4
     assert float(wr.max() - wr.min()) > 1e-3                       # the weights are not a constant
+
+
+@pytest.mark.gpu
+def test_whole_place_model_from_clouds_to_scores():
+    """MultiscaleScoreModel assembled from YAML-shaped blocks (UNet key model, KeypointExtractor query model, score head), every stage on the HIP
+    path: scene cloud -> key_pcd_multiscale, grasp cloud -> query_pcd, (poses, time) -> (ang, lin), against the chained restatement.  The score
+    sees the extractors' ~1e-4 feature differences through two more nonlinear stages, hence the looser bound at the end."""
+    from diffusion_edf_amd import agent as A, params
+    from diffusion_edf_amd.gnn_data import FeaturedPoints
+    from test_agent import _model_yaml
+    dev = torch.device("cuda:0")
+    radii = (5.0, 10.0, 20.0, 40.0)
+    hk = synthetic.score_head_kwargs(2)
+    doc = _model_yaml(hk)["model_kwargs"]
+    doc["query_model"], doc["query_kwargs"] = "KeypointExtractor", _query_kwargs(radii)
+    m = A.MultiscaleScoreModel(**doc, deterministic=True)
+    assert set(k.split(".")[0] for k in m.state_dict()) == {"key_model", "query_model", "score_head"}
+    _randomized(m.key_model, seed=1); _randomized(m.query_model, seed=2)
+    hcfg = params.HeadConfig.from_kwargs(hk)
+    Ph = params.init_params(hcfg, seed=3, randomize_all=True)
+    m.score_head.load_state_dict(Ph)
+    m.to(dev).eval()
+    scene = torch.from_numpy(synthetic.make_scene(8000, seed=5).astype(np.float32))
+    grasp = _object_cloud(3000, seed=6)
+    grasp[:, 2] -= 8.0
+    g = torch.Generator().manual_seed(0)
+    fs, fg = torch.rand(len(scene), 3, generator=g), torch.rand(len(grasp), 3, generator=g)
+    fp = lambda x, f: FeaturedPoints(x=x.to(dev), f=f.to(dev), b=torch.zeros(len(x), dtype=torch.long, device=dev), w=None)
+    key = m.get_key_pcd_multiscale(fp(scene, fs))
+    query = m.get_query_pcd(fp(grasp, fg))
+    # restatement, stage by stage
+    Pk = R.cast_params({k: v for k, v in m.key_model.state_dict().items()}, torch.float64)
+    Pq = R.cast_params({k: v for k, v in m.query_model.state_dict().items()}, torch.float64)
+    key_ref = U.unet_forward(_oracle_cfg(m.key_model), Pk, scene, fs.double())
+    xq, fq, wq = U.keypoint_extractor_forward(_oracle_cfg(m.query_model.feature_extractor), _field_cfg(radii), Pq, grasp, fg.double(), 0.1,
+                                              bbox=doc["query_kwargs"]["keypoint_kwargs"]["bbox"])
+    assert [len(k.x) for k in key] == [len(k[0]) for k in key_ref] and torch.equal(query.x.cpu(), xq)
+    for k, (xr, fr) in zip(key, key_ref):
+        assert float((k.f.cpu().double() - fr).abs().max()) < 2e-4 * float(fr.abs().max())
+    assert float((query.f.cpu().double() - fq).abs().max()) < 2e-4 * float(fq.abs().max()) and float((query.w.cpu().double() - wq).abs().max()) < 2e-4
+    nT = 24
+    q = torch.randn(nT, 4, generator=g, dtype=torch.float64)
+    Ts = torch.cat([q / q.norm(dim=-1, keepdim=True), torch.randn(nT, 3, generator=g, dtype=torch.float64) * 6.0 + torch.tensor([0.0, 0.0, 4.0])], -1)
+    time = torch.rand(nT, generator=g, dtype=torch.float64) * 0.9 + 0.05
+    ang, lin = m.score_head(Ts.float().to(dev), key, query, time.float().to(dev))
+    rcfg = R.config_from_kwargs(hk)
+    kd = [R.FeaturedPoints(x=xr.double(), f=fr, b=torch.zeros(len(xr), dtype=torch.long), w=None) for xr, fr in key_ref]
+    qd = R.FeaturedPoints(x=xq.double(), f=fq, b=torch.zeros(len(xq), dtype=torch.long), w=wq)
+    ang_r, lin_r = R.score_head_forward(rcfg, R.cast_params(Ph, torch.float64), Ts, kd, qd, time)
+    for got, ref in ((ang, ang_r), (lin, lin_r)):
+        err = float((got.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+        assert err < 2e-3, err
