@@ -185,8 +185,8 @@ def test_whole_place_model_from_clouds_to_scores():
     key = m.get_key_pcd_multiscale(fp(scene, fs))
     query = m.get_query_pcd(fp(grasp, fg))
     # restatement, stage by stage
-    Pk = R.cast_params({k: v for k, v in m.key_model.state_dict().items()}, torch.float64)
-    Pq = R.cast_params({k: v for k, v in m.query_model.state_dict().items()}, torch.float64)
+    Pk = R.cast_params({k: v.cpu() for k, v in m.key_model.state_dict().items()}, torch.float64)
+    Pq = R.cast_params({k: v.cpu() for k, v in m.query_model.state_dict().items()}, torch.float64)
     key_ref = U.unet_forward(_oracle_cfg(m.key_model), Pk, scene, fs.double())
     xq, fq, wq = U.keypoint_extractor_forward(_oracle_cfg(m.query_model.feature_extractor), _field_cfg(radii), Pq, grasp, fg.double(), 0.1,
                                               bbox=doc["query_kwargs"]["keypoint_kwargs"]["bbox"])
