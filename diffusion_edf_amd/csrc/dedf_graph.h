@@ -21,56 +21,100 @@ __device__ __forceinline__ float dist2_rn(float ax, float ay, float az, float bx
 }
 
 // Farthest point sampling of ONE cloud by one workgroup: every thread keeps PPT points and their running minimum distance in
-// registers; per sample: update, per-thread arg-max, wave butterfly, one LDS exchange between the 16 waves, ONE barrier.
-// idx_out[i] = i-th selected point (selection order, first = `start`).  Ties: smaller index (numpy argmax).
+// registers; per sample: update, per-thread arg-max, wave butterfly, one LDS exchange between the 16 waves.
+// The sample loop is a serial chain of n_samples steps on ONE CU, and a step is bound by the VALU instructions the 16 waves issue
+// (4 cycles per wave64 instruction per SIMD), so the step is written for instruction count:
+//   * two points per instruction with the packed fp32 ops (v_pk_add/mul_f32): 8 packed operations per PAIR for the distance, rounded
+//     exactly like the oracle (fp contraction off: no FMA);
+//   * the arg-max travels as ONE 64-bit key (distance bits << 32 | 0x7fffffff - index; distances are >= 0, so the unsigned order of
+//     the key is "larger distance, then smaller index" = numpy argmax);
+//   * the winner's coordinates come back through LDS from the thread that owns the point (no dependent global load), and the
+//     selected indices are collected in LDS and written out once per 1024 samples (a barrier waits for outstanding global stores).
+// idx_out[i] = i-th selected point (selection order, first = `start`).
 // KEEP = false (clouds above 16 k points): only the minimum distances stay in registers, the coordinates are re-read (coalesced, from
 // L2) every sample — 64 points per thread would not fit the 128 VGPRs a thread of a 1024-thread workgroup has.
+typedef float fps_f2 __attribute__((ext_vector_type(2)));
+
 template <int PPT, bool KEEP = true>
 __global__ __launch_bounds__(kFpsBlock) void k_fps(const float* __restrict__ x, int n, int n_samples, int start, int* __restrict__ idx_out) {
-    __shared__ float s_val[2][kFpsBlock / 64];
-    __shared__ int s_idx[2][kFpsBlock / 64];
+#pragma clang fp contract(off)
+    static_assert(PPT % 2 == 0, "points are processed in pairs");
+    constexpr int NW = kFpsBlock / 64, NP = PPT / 2;
+    __shared__ unsigned long long s_key[2][NW];
+    __shared__ float s_xyz[2][4];
+    __shared__ int s_out[kFpsBlock];                            // selected indices, flushed every kFpsBlock samples
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float px[KEEP ? PPT : 1], py[KEEP ? PPT : 1], pz[KEEP ? PPT : 1], md[PPT];
+    fps_f2 px[KEEP ? NP : 1], py[KEEP ? NP : 1], pz[KEEP ? NP : 1], md[NP];
+    auto ld = [&](int i, int k) { return x[3 * min(i, n - 1) + k]; };            // padding slots read the last point; their md is pinned at -1
 #pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const int i = tid + j * kFpsBlock;
-        if constexpr (KEEP) { px[j] = i < n ? x[3 * i] : 0.0f; py[j] = i < n ? x[3 * i + 1] : 0.0f; pz[j] = i < n ? x[3 * i + 2] : 0.0f; }
-        md[j] = INFINITY;
+    for (int j = 0; j < NP; ++j) {
+        const int i0 = tid + (2 * j) * kFpsBlock, i1 = i0 + kFpsBlock;
+        if constexpr (KEEP) { px[j] = fps_f2{ld(i0, 0), ld(i1, 0)}; py[j] = fps_f2{ld(i0, 1), ld(i1, 1)}; pz[j] = fps_f2{ld(i0, 2), ld(i1, 2)}; }
+        md[j] = fps_f2{i0 < n ? INFINITY : -1.0f, i1 < n ? INFINITY : -1.0f};       // -1: below every real distance, stays -1 under min
     }
     int cur = start;
+    float cx = x[3 * cur], cy = x[3 * cur + 1], cz = x[3 * cur + 2];
     for (int s = 0; s < n_samples; ++s) {
-        if (tid == 0) idx_out[s] = cur;
-        const float cx = x[3 * cur], cy = x[3 * cur + 1], cz = x[3 * cur + 2];
+        if (tid == 0) s_out[s & (kFpsBlock - 1)] = cur;         // (a global store here would be waited for at every barrier)
+        const fps_f2 c_x = fps_f2{cx, cx}, c_y = fps_f2{cy, cy}, c_z = fps_f2{cz, cz};
+        int tid_s = tid;
+        if constexpr (!KEEP) asm volatile("" : "+v"(tid_s));    // addresses are formed per sample: 64 loop-invariant offsets would not fit the registers
         float best = -1.0f;
-        int bi = 0x7fffffff;
+        int bj = -1;                                                                   // slot (2 * pair + half) of the thread's arg-max
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            const int i = tid + j * kFpsBlock;
-            if (i < n) {
-                float qx, qy, qz;
-                if constexpr (KEEP) { qx = px[j]; qy = py[j]; qz = pz[j]; }
-                else { qx = x[3 * i]; qy = x[3 * i + 1]; qz = x[3 * i + 2]; }
-                md[j] = fminf(md[j], dist2_rn(qx, qy, qz, cx, cy, cz));
-                if (md[j] > best) { best = md[j]; bi = i; }          // ascending i inside a thread: strict > keeps the smaller index
+        for (int j = 0; j < NP; ++j) {
+            fps_f2 qx, qy, qz;
+            if constexpr (KEEP) { qx = px[j]; qy = py[j]; qz = pz[j]; }
+            else {
+                const int i0 = tid_s + (2 * j) * kFpsBlock, i1 = i0 + kFpsBlock;
+                qx = fps_f2{ld(i0, 0), ld(i1, 0)}; qy = fps_f2{ld(i0, 1), ld(i1, 1)}; qz = fps_f2{ld(i0, 2), ld(i1, 2)};
             }
+            const fps_f2 dx = qx - c_x, dy = qy - c_y, dz = qz - c_z;
+            const fps_f2 d2 = (dx * dx + dy * dy) + dz * dz;
+            fps_f2 m = md[j];
+            m.x = fminf(m.x, d2.x); m.y = fminf(m.y, d2.y);
+            md[j] = m;
+            if (m.x > best) { best = m.x; bj = 2 * j; }                               // ascending index inside a thread: strict > keeps the smaller one
+            if (m.y > best) { best = m.y; bj = 2 * j + 1; }
+            if constexpr (!KEEP) __builtin_amdgcn_sched_barrier(0);     // keep the re-loads of later pairs from piling up in registers
         }
+        const int bi = tid + bj * kFpsBlock;
+        unsigned long long key = bj < 0 ? 0ull : ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(0x7fffffff - bi);
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
-            const float ov = __shfl_xor(best, o);
-            const int oi = __shfl_xor(bi, o);
-            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            const unsigned long long ok = __shfl_xor(key, o);
+            key = ok > key ? ok : key;
         }
         const int buf = s & 1;
-        if (lane == 0) { s_val[buf][wave] = best; s_idx[buf][wave] = bi; }
+        if (lane == 0) s_key[buf][wave] = key;
         __syncthreads();
-        best = s_val[buf][0]; bi = s_idx[buf][0];
-#pragma unroll
-        for (int w = 1; w < kFpsBlock / 64; ++w) {
-            const float ov = s_val[buf][w];
-            const int oi = s_idx[buf][w];
-            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        if ((s & (kFpsBlock - 1)) == kFpsBlock - 1 || s == n_samples - 1) {
+            const int base = s & ~(kFpsBlock - 1);
+            if (base + tid <= s) idx_out[base + tid] = s_out[tid];
         }
-        cur = bi;
+        key = s_key[buf][0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            const unsigned long long ok = s_key[buf][w];
+            key = ok > key ? ok : key;
+        }
+        cur = 0x7fffffff - (int)(unsigned)(key & 0xffffffffull);
+        if constexpr (KEEP) {
+            if (tid == (cur & (kFpsBlock - 1))) {                                      // the owner publishes the coordinates
+                const int slot = cur / kFpsBlock;
+                float ox = 0.0f, oy = 0.0f, oz = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    if (slot == 2 * j) { ox = px[j].x; oy = py[j].x; oz = pz[j].x; }
+                    if (slot == 2 * j + 1) { ox = px[j].y; oy = py[j].y; oz = pz[j].y; }
+                }
+                s_xyz[buf][0] = ox; s_xyz[buf][1] = oy; s_xyz[buf][2] = oz;
+            }
+            __syncthreads();
+            cx = s_xyz[buf][0]; cy = s_xyz[buf][1]; cz = s_xyz[buf][2];
+        } else {
+            cx = x[3 * cur]; cy = x[3 * cur + 1]; cz = x[3 * cur + 2];
+        }
     }
 }
 

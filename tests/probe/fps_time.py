@@ -1,0 +1,17 @@
+"""time dedf_fps alone: python tests/probe/fps_time.py"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from diffusion_edf_amd import synthetic
+from diffusion_edf_amd.connectivity import fps
+dev = torch.device("cuda:0")
+for n, ratio in ((16384, 0.2), (16384, 0.05), (4096, 0.25), (3277, 0.2), (65536, 0.05)):
+    x = torch.from_numpy(synthetic.make_scene(n, seed=0).astype(np.float32)).to(dev)
+    b = torch.zeros(n, dtype=torch.long, device=dev)
+    fps(x, b, ratio=ratio, random_start=False); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        idx = fps(x, b, ratio=ratio, random_start=False)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    print(f"fps n={n} -> {len(idx)} samples: {ms:.3f} ms = {ms * 1e3 / len(idx):.2f} us / sample")
