@@ -7,7 +7,7 @@ around that is networking and stays out; this module is the part a notebook or a
 ``agent.sample(...)``:
 
     task = TaskConfigs.load("configs/panda_mug", root="/path/to/reference")
-    agent = task.build_agent("pick", extractors={...})                 # DiffusionEdfAgent with models + critic + proc_fn
+    agent = task.build_agent("pick")                                   # DiffusionEdfAgent with models (extractors included) + critic + proc_fn
     Ts, scene, grasp = agent.sample(scene_pcd, grasp_pcd, T_seed, **task.sample_kwargs("pick"))
 
 Paths inside agent.yaml (``configs_root_dir``, ``checkpoint_dir``) are relative to the reference repository root; ``root``
@@ -118,9 +118,8 @@ class TaskConfigs:
         """``DiffusionEdfAgent`` of one task: its score models (low-res → high-res cascade), its critic if the file names one, and
         the pre- / un-processing pipelines of preprocess.yaml.
 
-        ``extractors[i]`` = ``{"key_extractor": ..., "query_extractor": ...}`` for model i (``critic_extractors`` likewise): the
-        feature extractors are injected, see ``agent.py``.  Entries may be omitted for models whose query model is the built-in
-        ``StaticKeypointModel``; a missing key extractor surfaces as ``NotImplementedError`` on first use, not here."""
+        The models build their feature extractors from the YAML blocks (``agent.py``); ``extractors[i]`` = ``{"key_extractor": ...,
+        "query_extractor": ...}`` for model i (``critic_extractors`` likewise) overrides them, e.g. with ``PrecomputedFeatures``."""
         from .agent import DiffusionEdfAgent
         if task not in TASKS:
             raise ValueError(f"Unknown task name: {task}")
