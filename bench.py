@@ -23,6 +23,8 @@ Extra objects on the JSON line:
   cpu_baseline  the CPU restatement oracle ("port", fp32, same inputs) timed on this host on a bounded pose sample: 1 thread, 16
                 threads and all physical cores (lscpu).
   config.score_fwd_ms_at_t0.5   one score evaluation (no Langevin update) of the seeded poses at the fixed time t = 0.5.
+  config.feature_extractors_ms  the step before the path, outside the timed region (N = 1): UnetFeatureExtractor on the scene cloud,
+                                KeypointExtractor on the grasp cloud (random-init weights of the shipped panda shapes); ms per forward.
 """
 from __future__ import annotations
 
@@ -116,6 +118,35 @@ def cpu_baseline(lmax, n_scene, n_grasp, n_sample_poses=32, t=0.5, budget_s=8.0)
                        + "; ".join(f"{k} thread(s): {v['reps']} x {v['poses']} poses in {v['seconds']} s" for k, v in legs.items()))
 
 
+def extractor_times(n_scene: int, n_grasp: int, device, reps: int = 5):
+    import numpy as np
+    from diffusion_edf_amd import synthetic
+    from diffusion_edf_amd.gnn_data import FeaturedPoints
+    from diffusion_edf_amd.keypoint_extractor import KeypointExtractor
+    from diffusion_edf_amd.unet import UnetFeatureExtractor
+
+    def cloud(x):
+        x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(device)
+        return FeaturedPoints(x=x, f=torch.rand(len(x), 3, device=device), b=torch.zeros(len(x), dtype=torch.long, device=device), w=None)
+
+    def timed(fn):
+        fn(); fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3, out
+
+    unet = UnetFeatureExtractor(**synthetic.unet_kwargs("panda_lowres"), deterministic=True).to(device)
+    scene = cloud(synthetic.make_scene(n_scene, seed=0))
+    ms_u, levels = timed(lambda: unet(scene))
+    kp = KeypointExtractor(**synthetic.keypoint_extractor_kwargs(bbox=None), deterministic=True).to(device)
+    grasp = cloud(synthetic.make_grasp(n_grasp, seed=0))
+    ms_k, q = timed(lambda: kp(grasp))
+    return {"unet_scene": ms_u, "unet_levels": [len(l.x) for l in levels], "keypoint_grasp": ms_k, "keypoints": len(q.x)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,6 +157,7 @@ def main():
     ap.add_argument("--scene", type=int, default=4096)
     ap.add_argument("--grasp", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extractors", action="store_true", help="skip the (untimed) feature-extractor measurement")
     ap.add_argument("--half", action="store_true", help="half-precision GEMM mode (model.half(), the reference's half_precision knob); NOT the headline configuration")
     args = ap.parse_args()
 
@@ -212,6 +244,12 @@ def main():
         fixed = {"ms": e0.elapsed_time(e1) / n_rep, "edges": pf["n_edges"] / max(1, pf["n_evals"]),
                  "k_edge_ms": pf["ms"]["edge"] / max(1, pf["n_evals"])}
 
+    # outside the timed region too: the step BEFORE the path on clouds of the workload's sizes -- the UNet key model on
+    # the scene cloud and the KeypointExtractor query model on the grasp cloud, once per agent.sample in a deployment
+    extract = None
+    if rank == 0 and world == 1 and args.lmax == 2 and not args.no_extractors:
+        extract = extractor_times(args.scene, args.grasp, device)
+
     if rank == 0:
         n_ev = max(1, prof["n_evals"])
         edge_ms = prof["ms"]["edge"] / n_ev
@@ -244,7 +282,7 @@ def main():
                                    f"{len(query.x)} query pts, lmax={args.lmax}, {args.poses_per_gpu} poses per GPU, t 1->0.15 log-spaced, dt 0.04",
                        "poses_total": n_total, "parallelism": f"pose-parallel dp{world}, one RCCL all-gather at the end",
                        "edges_per_step_rank0": e_per_launch, "full_trajectories_per_s_at_50_steps": n_total * args.steps / el / 50.0,
-                       "score_fwd_ms_at_t0.5": fixed},
+                       "score_fwd_ms_at_t0.5": fixed, "feature_extractors_ms": extract},
             "roofline": {"kernel": "k_edge (fused per-edge pipeline)", "bound": "valu-issue", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "peak_definition": "dense fp16 MFMA peak 2500 TFLOP/s / 3 (every GEMM is a 3-term split-fp16 product, fp32 accumulate): the hardware matrix peak of the arithmetic the kernel uses, in fp32-equivalent FLOP/s",

@@ -123,3 +123,33 @@ def make_poses(n: int, seed: int = 1, first_pose_index: int = 0, near_object: bo
             p = np.array([rng.uniform(-20, 20), rng.uniform(-20, 20), rng.uniform(0, 25)])
         out[i, :4], out[i, 4:] = q, p
     return torch.tensor(out, dtype=dtype)
+
+
+# ---- the feature-extractor blocks of the shipped YAML files (tests, bench) --------------------------------------------------------
+
+def unet_kwargs(kind: str = "panda_lowres") -> dict:
+    """the four feature_extractor_kwargs blocks the reference ships (configs/*/*/score_model_configs.yaml)"""
+    narrow, wide = "32x0e+16x1e+8x2e", "64x0e+32x1e+16x2e"
+    sh = "1x0e+1x1e+1x2e"
+    base = dict(irreps_input="3x0e", irreps_output=wide, irreps_mlp_mid=3, attn_type="mlp", alpha_drop=0.1, proj_drop=0.1, drop_path_rate=0.0,
+                pool_method="fps", n_layers_midstream=2)
+    if kind == "panda_lowres":         # pool_ratio 0.2 (…/pick_lowres, place_ebm …)
+        return dict(base, irreps_emb=[narrow, narrow, wide, wide], fc_neurons=[[32, 16, 16]] * 2 + [[64, 32, 32]] * 2, irreps_edge_attr=[sh] * 4,
+                    num_heads=[4] * 4, n_layers=[2] * 4, pool_ratio=[0.2] * 4, radius=[3.0, None, None, None], n_scales=4)
+    if kind == "panda_highres":        # pool_ratio 0.25
+        return dict(unet_kwargs("panda_lowres"), pool_ratio=[0.25] * 4)
+    if kind == "sapien_lowres":        # every level wide
+        return dict(unet_kwargs("panda_highres"), irreps_emb=[wide] * 4, fc_neurons=[[64, 32, 32]] * 4)
+    if kind == "sapien_highres":       # one scale, seven layers
+        return dict(base, irreps_emb=[wide], fc_neurons=[[64, 32, 32]], irreps_edge_attr=[sh], num_heads=[4], n_layers=[7], pool_ratio=[0.25],
+                    radius=[3.0], n_scales=1)
+    raise KeyError(kind)
+
+
+def keypoint_extractor_kwargs(radii=(5.0, 10.0, 20.0, 40.0), bbox=((-30.0, 30.0), (-30.0, 30.0), (8.0, 100.0)), unet="panda_highres", pool_ratio=0.1):
+    """the query_kwargs block of configs/panda_*/place_*/score_model_configs.yaml"""
+    return dict(weight_activation="sigmoid", weight_mult=None,
+                keypoint_kwargs=dict(pool_ratio=pool_ratio, weight_pre_emb_dim=64, bbox=None if bbox is None else [list(b) for b in bbox]),
+                feature_extractor_kwargs=unet_kwargs(unet),
+                tensor_field_kwargs=dict(irreps_output='64x0e+32x1e+16x2e', irreps_sh="1x0e+1x1e+1x2e", num_heads=4, fc_neurons=[-1, 32, 32], length_emb_dim=64,
+                                         r_cluster_multiscale=list(radii), n_scales=len(radii)))

@@ -15,13 +15,7 @@ from test_unet import _oracle_cfg, _randomized, _unet_kwargs
 WIDE = "64x0e+32x1e+16x2e"
 
 
-def _query_kwargs(radii=(5.0, 10.0, 20.0, 40.0), bbox=((-30.0, 30.0), (-30.0, 30.0), (8.0, 100.0)), unet="panda_highres", pool_ratio=0.1):
-    """the query_kwargs block of configs/panda_*/place_*/score_model_configs.yaml"""
-    return dict(weight_activation="sigmoid", weight_mult=None,
-                keypoint_kwargs=dict(pool_ratio=pool_ratio, weight_pre_emb_dim=64, bbox=None if bbox is None else [list(b) for b in bbox]),
-                feature_extractor_kwargs=_unet_kwargs(unet),
-                tensor_field_kwargs=dict(irreps_output=WIDE, irreps_sh="1x0e+1x1e+1x2e", num_heads=4, fc_neurons=[-1, 32, 32], length_emb_dim=64,
-                                         r_cluster_multiscale=list(radii), n_scales=len(radii)))
+_query_kwargs = synthetic.keypoint_extractor_kwargs
 
 
 def _field_cfg(radii):
@@ -206,3 +200,54 @@ def test_whole_place_model_from_clouds_to_scores():
     for got, ref in ((ang, ang_r), (lin, lin_r)):
         err = float((got.cpu().double() - ref).abs().max()) / float(ref.abs().max())
         assert err < 2e-3, err
+
+
+@pytest.mark.gpu
+def test_whole_point_attentive_model_from_clouds_to_scores():
+    """PointAttentiveScoreModel (the sapien *_lowres configs) assembled from YAML-shaped blocks: the key model is ONE KeypointExtractor whose
+    weighted key points form the single, all-pairs key cloud (point_attentive_score_model.py:34-37,106-107); the query model a StaticKeypointModel"""
+    from diffusion_edf_amd import agent as A, params
+    from diffusion_edf_amd.gnn_data import FeaturedPoints
+    from test_agent import _model_yaml
+    dev = torch.device("cuda:0")
+    radii = (5.0, 10.0, 20.0, 40.0)
+    hk = synthetic.score_head_kwargs(2, radii=(None,))
+    hk["key_tensor_field_kwargs"]["fc_neurons"] = [-1, 32, 32]                     # configs/sapien/place_lowres/score_model_configs.yaml:15
+    doc = _model_yaml(hk)["model_kwargs"]
+    doc["key_kwargs"] = dict(_query_kwargs(radii, bbox=None, pool_ratio=0.05), feature_extractor_name="UnetFeatureExtractor")
+    m = A.PointAttentiveScoreModel(**doc, deterministic=True)
+    _randomized(m.key_model, seed=4)
+    hk_full = copy_with_point_attn(hk)
+    hcfg = params.HeadConfig.from_kwargs(hk_full)
+    Ph = params.init_params(hcfg, seed=5, randomize_all=True)
+    m.score_head.load_state_dict(Ph)
+    m.to(dev).eval()
+    scene = torch.from_numpy(synthetic.make_scene(6000, seed=8).astype(np.float32))
+    g = torch.Generator().manual_seed(0)
+    fs = torch.rand(len(scene), 3, generator=g)
+    pcd = FeaturedPoints(x=scene.to(dev), f=fs.to(dev), b=torch.zeros(len(scene), dtype=torch.long, device=dev), w=None)
+    key = m.get_key_pcd_multiscale(pcd)
+    query = m.get_query_pcd(pcd)
+    assert len(key) == 1 and len(key[0].x) == 300 and key[0].w is not None and len(query.x) == 2
+    Pk = R.cast_params({k: v.cpu() for k, v in m.key_model.state_dict().items()}, torch.float64)
+    xk, fk, wk = U.keypoint_extractor_forward(_oracle_cfg(m.key_model.feature_extractor), _field_cfg(radii), Pk, scene, fs.double(), 0.05, bbox=None)
+    assert torch.equal(key[0].x.cpu(), xk) and float((key[0].w.cpu().double() - wk).abs().max()) < 2e-4
+    nT = 16
+    q = torch.randn(nT, 4, generator=g, dtype=torch.float64)
+    Ts = torch.cat([q / q.norm(dim=-1, keepdim=True), torch.randn(nT, 3, generator=g, dtype=torch.float64) * 6.0 + torch.tensor([0.0, 0.0, 4.0])], -1)
+    time = torch.rand(nT, generator=g, dtype=torch.float64) * 0.9 + 0.05
+    ang, lin = m.score_head(Ts.float().to(dev), key, query, time.float().to(dev))
+    rcfg = R.config_from_kwargs(hk_full)
+    kd = [R.FeaturedPoints(x=xk.double(), f=fk, b=torch.zeros(len(xk), dtype=torch.long), w=wk)]
+    qd = R.FeaturedPoints(x=query.x.cpu().double(), f=query.f.cpu().double(), b=torch.zeros(len(query.x), dtype=torch.long), w=query.w.cpu().double())
+    ang_r, lin_r = R.score_head_forward(rcfg, R.cast_params(Ph, torch.float64), Ts, kd, qd, time)
+    for got, ref in ((ang, ang_r), (lin, lin_r)):
+        err = float((got.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+        assert err < 2e-3, err
+
+
+def copy_with_point_attn(hk):
+    import copy
+    out = copy.deepcopy(hk)
+    out["key_tensor_field_kwargs"]["use_src_point_attn"] = True
+    return out
