@@ -139,7 +139,7 @@ class PointAttentiveScoreModel(MultiscaleScoreModel):
 
     def get_key_pcd_multiscale(self, pcd) -> List[FeaturedPoints]:
         out = self._extract("get_key_pcd_multiscale", self.key_model, pcd)
-        return out if isinstance(out, (list, tuple)) else [out]
+        return [out] if isinstance(out, FeaturedPoints) else list(out)       # (FeaturedPoints is itself a tuple)
 
 
 def load_configs(configs_root_dir: str, train_configs_file: str, task_configs_file: str) -> Dict[str, Dict]:

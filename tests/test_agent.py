@@ -256,3 +256,16 @@ def test_task_front_end_builds_the_agent_of_the_notebook_call_sequence():
     T0 = torch.tensor([[1., 0, 0, 0, 0.1, 0.2, 0.3]] * 3)
     Ts, scene, grasp = ag.sample(pcd, pcd, T0, **tc.sample_kwargs("pick"))
     assert Ts.shape == (400 + 2 + 500 + 2, 3, 7) and torch.allclose(Ts[-1, :, 4:], T0[:, 4:] * 100.0)
+
+
+def test_point_attentive_model_wraps_its_single_key_cloud():
+    """point_attentive_score_model.py:106-107 returns [key_model(pcd)]; FeaturedPoints is a NamedTuple, so "is it already a sequence" must not be
+    asked with isinstance(·, tuple)"""
+    hk = synthetic.score_head_kwargs(2, radii=(None,))
+    doc = _model_yaml(hk)["model_kwargs"]
+    cloud = FeaturedPoints(x=torch.zeros(5, 3), f=torch.zeros(5, 240), b=torch.zeros(5, dtype=torch.long), w=torch.ones(5))
+    m = A.PointAttentiveScoreModel(**doc, key_extractor=A.PrecomputedFeatures(cloud, "64x0e+32x1e+16x2e"))
+    out = m.get_key_pcd_multiscale(None)
+    assert isinstance(out, list) and len(out) == 1 and out[0] is cloud
+    m2 = A.PointAttentiveScoreModel(**doc, key_extractor=A.PrecomputedFeatures([cloud], "64x0e+32x1e+16x2e"))
+    assert len(m2.get_key_pcd_multiscale(None)) == 1
