@@ -1,7 +1,7 @@
 """Graph construction of the feature extractors — mirrors reference ``diffusion_edf/connectivity.py`` (``RadiusGraph`` :8-30,
 ``RadiusConnect`` :34-49, ``FpsPool`` :53-80) on the HIP primitives ``dedf_fps`` / ``dedf_radius`` instead of torch_cluster /
 torch_scatter.  Single cloud (every shipped config has all batch indices 0); inputs must live on the GPU — there is no CPU path.
-SURVEY §8(f) row 1 building blocks: the UNet blocks that consume these graphs are not part of this build yet."""
+The UNet / keypoint extractors that consume these graphs: ``unet.py``, ``keypoint_extractor.py``."""
 from __future__ import annotations
 
 import ctypes as C
@@ -25,9 +25,11 @@ def _check_cloud(x: torch.Tensor, batch: Optional[torch.Tensor]):
         raise NotImplementedError("several clouds in one batch vector (every shipped config uses a single cloud)")
 
 
-def fps(src: torch.Tensor, batch: Optional[torch.Tensor] = None, ratio: float = 0.5, random_start: bool = True) -> torch.Tensor:
-    """torch_cluster.fps as connectivity.py:62 calls it: ``ceil(ratio * N)`` indices in selection order."""
-    _check_cloud(src, batch)
+def fps(src: torch.Tensor, batch: Optional[torch.Tensor] = None, ratio: float = 0.5, random_start: bool = True, _trusted: bool = False) -> torch.Tensor:
+    """torch_cluster.fps as connectivity.py:62 calls it: ``ceil(ratio * N)`` indices in selection order.
+    (``_trusted``: the caller has already checked that the batch vector holds one cloud — the check reads back from the device.)"""
+    if not _trusted:
+        _check_cloud(src, batch)
     n = len(src)
     k = int(math.ceil(ratio * n))
     start = int(torch.randint(n, (1,)).item()) if random_start else 0
@@ -42,10 +44,11 @@ def fps(src: torch.Tensor, batch: Optional[torch.Tensor] = None, ratio: float = 
 
 
 def radius(x: torch.Tensor, y: torch.Tensor, r: float, batch_x=None, batch_y=None, max_num_neighbors: int = 32,
-           _exclude_self: bool = False) -> torch.Tensor:
+           _exclude_self: bool = False, _trusted: bool = False) -> torch.Tensor:
     """torch_cluster.radius: for every point of ``y`` the points of ``x`` within ``r`` -> ``(2, E)`` = [y index, x index]."""
-    _check_cloud(x, batch_x)
-    _check_cloud(y, batch_y)
+    if not _trusted:
+        _check_cloud(x, batch_x)
+        _check_cloud(y, batch_y)
     xs = x.detach().to(torch.float32).contiguous()
     ys = y.detach().to(torch.float32).contiguous()
     lib = _lib.load()
@@ -67,8 +70,10 @@ def radius(x: torch.Tensor, y: torch.Tensor, r: float, batch_x=None, batch_y=Non
     return torch.stack([ed[: n.value], es[: n.value]], dim=0)
 
 
-def radius_graph(x: torch.Tensor, r: float, batch=None, loop: bool = False, max_num_neighbors: int = 32) -> torch.Tensor:
-    return radius(x, x, r, batch, batch, max_num_neighbors, _exclude_self=not loop)
+def radius_graph(x: torch.Tensor, r: float, batch=None, loop: bool = False, max_num_neighbors: int = 32, _trusted: bool = False) -> torch.Tensor:
+    if not _trusted:
+        _check_cloud(x, batch)
+    return radius(x, x, r, batch, batch, max_num_neighbors, _exclude_self=not loop, _trusted=True)
 
 
 def _in_degree(edge_dst: torch.Tensor, n_nodes: int) -> torch.Tensor:
@@ -84,8 +89,8 @@ class RadiusGraph(torch.nn.Module):
         super().__init__()
         self.r, self.max_num_neighbors = r, max_num_neighbors
 
-    def forward(self, node_coord_src: torch.Tensor, node_feature_src: torch.Tensor, batch_src: torch.Tensor):
-        dst, src = radius_graph(node_coord_src, self.r, batch_src, loop=False, max_num_neighbors=self.max_num_neighbors)
+    def forward(self, node_coord_src: torch.Tensor, node_feature_src: torch.Tensor, batch_src: torch.Tensor, _trusted: bool = False):
+        dst, src = radius_graph(node_coord_src, self.r, batch_src, loop=False, max_num_neighbors=self.max_num_neighbors, _trusted=_trusted)
         return node_feature_src, node_coord_src, src, dst, _in_degree(dst, len(node_coord_src)), batch_src
 
 
@@ -98,8 +103,8 @@ class RadiusConnect(torch.nn.Module):
             raise NotImplementedError
         self.r, self.max_num_neighbors, self.offset = r, max_num_neighbors, offset
 
-    def forward(self, node_coord_src, batch_src, node_coord_dst, batch_dst) -> Tuple[torch.Tensor, torch.Tensor]:
-        dst, src = radius(node_coord_src, node_coord_dst, self.r, batch_src, batch_dst, self.max_num_neighbors)
+    def forward(self, node_coord_src, batch_src, node_coord_dst, batch_dst, _trusted: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        dst, src = radius(node_coord_src, node_coord_dst, self.r, batch_src, batch_dst, self.max_num_neighbors, _trusted=_trusted)
         return src, dst
 
 
@@ -112,10 +117,10 @@ class FpsPool(torch.nn.Module):
         self.ratio, self.random_start, self.r, self.max_num_neighbors = ratio, random_start, r, max_num_neighbors
         self.radius_connect = RadiusConnect(r=r, max_num_neighbors=max_num_neighbors)
 
-    def forward(self, node_coord_src: torch.Tensor, node_feature_src: torch.Tensor, batch_src: torch.Tensor):
-        picked = fps(node_coord_src, batch_src, ratio=self.ratio, random_start=self.random_start)
+    def forward(self, node_coord_src: torch.Tensor, node_feature_src: torch.Tensor, batch_src: torch.Tensor, _trusted: bool = False):
+        picked = fps(node_coord_src, batch_src, ratio=self.ratio, random_start=self.random_start, _trusted=_trusted)
         coord, feat, batch = node_coord_src[picked], node_feature_src[picked], batch_src[picked]
-        src, dst = self.radius_connect(node_coord_src, batch_src, coord, batch)
+        src, dst = self.radius_connect(node_coord_src, batch_src, coord, batch, _trusted=True)      # (a sub-sample of a single cloud is one)
         other = picked[dst] != src                      # drop the edge from a pooled node to the source point it was sampled from
         src, dst = src[other], dst[other]
         return feat, coord, src, dst, _in_degree(dst, len(picked)), batch

@@ -79,6 +79,8 @@ struct dedf_handle {
     const LangevinParams* fused_step = nullptr;           // dedf_sample: the per-pose reduction also carries this step's Langevin update
     DevBuf d_tb_steps; const float* tb_step = nullptr;    // dedf_sample: the time-bias rows of ALL steps are computed up front; tb_step = this step's rows
     std::vector<float> h_tsteps;
+    bool defer_check = false;         // dedf_layer_defer_check
+    DevBuf d_sticky;
     bool want_field = false;          // dedf_field: the node kernel also writes the field / emb of every node
     DevBuf d_Ts, d_time, d_tb, d_pose, d_qpos, d_cnt, d_off, d_blk, d_tile, d_esrc, d_edst, d_eout, d_z, d_nout, d_ang, d_lin, d_T64, d_dbgw, d_dbge, d_dbgf, d_dbgo, d_mask;
     int64_t edge_cap = 0;
@@ -814,11 +816,44 @@ int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const floa
         const int ntiles = (n_dst + 31) / 32;
         hipLaunchKernelGGL((k_node<2, false, false, true>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
     }
+    if (h->defer_check) {          // chains of layers: the verdict of the edge-list check is kept on the device for dedf_layer_check
+        if (!h->d_sticky.p) {
+            if (!h->d_sticky.ensure(4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(flag) failed");
+            HIPCK(h, hipMemsetAsync(h->d_sticky.p, 0, 4, st));
+        }
+        hipLaunchKernelGGL(k_or_flag, dim3(1), dim3(1), 0, st, h->d_tile.as<int>() + kFlagBadEdges, h->d_sticky.as<int>());
+        if (hipGetLastError() != hipSuccess) return fail(h, DEDF_ERR_RUNTIME, "kernel launch failed");
+        return DEDF_OK;
+    }
     if (hipGetLastError() != hipSuccess) return fail(h, DEDF_ERR_RUNTIME, "kernel launch failed");
     HIPCK(h, hipStreamSynchronize(st));
     int bad = 0;
     HIPCK(h, hipMemcpy(&bad, h->d_tile.as<int>() + kFlagBadEdges, 4, hipMemcpyDeviceToHost));
     if (bad) return fail(h, DEDF_ERR_INVALID, "edge lists: edge_dst must be sorted ascending and every index inside its cloud");
+    return DEDF_OK;
+}
+
+int dedf_layer_defer_check(dedf_handle* h, int on) {
+    if (!h) return DEDF_ERR_INVALID;
+    if (!h->cfg.unet_layer) return fail(h, DEDF_ERR_UNSUPPORTED, "UNet-layer handles only");
+    h->defer_check = on != 0;
+    return DEDF_OK;
+}
+
+int dedf_layer_check(dedf_handle* h, void* stream) {
+    if (!h) return DEDF_ERR_INVALID;
+    if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
+    if (!h->cfg.unet_layer) return fail(h, DEDF_ERR_UNSUPPORTED, "UNet-layer handles only");
+    if (!h->d_sticky.p) return DEDF_OK;                 // nothing has run in deferred mode
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DEDF_ON_DEVICE(h);
+    int bad = 0;
+    HIPCK(h, hipMemcpyAsync(&bad, h->d_sticky.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCK(h, hipStreamSynchronize(st));
+    if (bad) {
+        HIPCK(h, hipMemsetAsync(h->d_sticky.p, 0, 4, st));
+        return fail(h, DEDF_ERR_INVALID, "edge lists: edge_dst must be sorted ascending and every index inside its cloud");
+    }
     return DEDF_OK;
 }
 

@@ -425,6 +425,10 @@ __global__ void k_edge_lists(const int64_t* __restrict__ src64, const int64_t* _
     }
 }
 
+__global__ void k_or_flag(const int* __restrict__ flag, int* __restrict__ sticky) {
+    if (*flag) *sticky = 1;
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // Joint softmax over ALL scales' edges of one destination node + weighted aggregation (graph_attention.py:253-266;
 // scatter_logsumexp / scatter restated: max-shifted, empty segments give 0).  One wave per destination, lane = float4 of

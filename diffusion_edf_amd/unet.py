@@ -63,6 +63,7 @@ class UnetLayer(torch.nn.Module):
             _register(self, name, t)
         self._handle = None
         self._handle_device: Optional[torch.device] = None
+        self._deferred = False
 
     # ------------------------------------------------------------------------------------------------------------------
     def _release(self):
@@ -102,7 +103,7 @@ class UnetLayer(torch.nn.Module):
         rc = lib.dedf_create(C.byref(ccfg), blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, C.byref(h))
         if rc != _lib.OK:
             _lib.raise_for(lib, None, rc, "dedf_create failed (see stderr)")
-        self._handle, self._handle_device = h, device
+        self._handle, self._handle_device, self._deferred = h, device, False
 
     @torch.no_grad()
     def forward(self, node_coord_src: torch.Tensor, node_input_src: torch.Tensor, node_coord_dst: torch.Tensor,
@@ -110,29 +111,52 @@ class UnetLayer(torch.nn.Module):
         """Arguments as the reference has them at the call site (``unet_feature_extractor.py:289-302``): coordinates and features of
         both node sets and the edge lists (int64).  Edges sorted by ``edge_dst`` (as ``FpsPool`` / ``RadiusGraph`` return them) are used
         as they are; any other order (the reversed graphs of the up path) is sorted here — the sums do not depend on it."""
-        assert node_coord_src.ndim == 2 and node_coord_src.shape[-1] == 3 and node_coord_dst.ndim == 2 and node_coord_dst.shape[-1] == 3
         assert node_input_src.shape == (len(node_coord_src), self.dim_src), f"{node_input_src.shape}"
         assert node_input_dst.shape == (len(node_coord_dst), self.dim), f"{node_input_dst.shape}"
+        dev = node_coord_src.device
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32)
+        fs = unet_pad.pad_features(f32(node_input_src), self.muls_src)
+        fd = unet_pad.pad_features(f32(node_input_dst), self.muls)
+        ed = edge_dst.detach().to(device=dev, dtype=torch.int64)
+        dst_sorted = not (len(ed) > 1 and bool((ed[1:] < ed[:-1]).any()))
+        out = self.forward_wide(node_coord_src, fs, node_coord_dst, fd, edge_src, ed, dst_sorted=dst_sorted)
+        return unet_pad.unpad_features(out, self.muls).to(node_input_dst.dtype)
+
+    @torch.no_grad()
+    def forward_wide(self, node_coord_src, f_src_wide, node_coord_dst, f_dst_wide, edge_src, edge_dst, dst_sorted: bool, deferred: bool = False):
+        """the same on features already in the 240-wide kernel layout (``unet_pad.pad_features``) -> (n_dst, 240) in that layout: what the
+        extractors chain, padding once at the input and un-padding once at the outputs.  ``dst_sorted=False`` sorts the edges by destination
+        (no device read-back); ``deferred``: do not synchronise, the edge-list verdict is collected later (``check``)."""
+        assert node_coord_src.ndim == 2 and node_coord_src.shape[-1] == 3 and node_coord_dst.ndim == 2 and node_coord_dst.shape[-1] == 3
+        assert f_src_wide.shape == (len(node_coord_src), 240) and f_dst_wide.shape == (len(node_coord_dst), 240)
         assert edge_src.ndim == 1 and edge_src.shape == edge_dst.shape
         dev = node_coord_src.device
         self._ensure_handle(dev)
         lib = _lib.load()
         f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
-        xs, xd = f32(node_coord_src), f32(node_coord_dst)
-        fs = unet_pad.pad_features(f32(node_input_src), self.muls_src).contiguous()
-        fd = unet_pad.pad_features(f32(node_input_dst), self.muls).contiguous()
+        xs, xd, fs, fd = f32(node_coord_src), f32(node_coord_dst), f32(f_src_wide), f32(f_dst_wide)
         es = edge_src.detach().to(device=dev, dtype=torch.int64)
         ed = edge_dst.detach().to(device=dev, dtype=torch.int64)
-        if len(ed) > 1 and bool((ed[1:] < ed[:-1]).any()):
+        if not dst_sorted:
             order = torch.sort(ed, stable=True).indices
             es, ed = es[order], ed[order]
         es, ed = es.contiguous(), ed.contiguous()
         out = torch.empty(len(xd), 240, device=dev, dtype=torch.float32)
+        if deferred != self._deferred:
+            lib.dedf_layer_defer_check(self._handle, int(deferred))
+            self._deferred = deferred
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         rc = lib.dedf_layer_forward(self._handle, len(xs), xs.data_ptr(), fs.data_ptr(), len(xd), xd.data_ptr(), fd.data_ptr(),
                                     len(es), es.data_ptr(), ed.data_ptr(), out.data_ptr(), stream)
         _lib.raise_for(lib, self._handle, rc, "dedf_layer_forward")
-        return unet_pad.unpad_features(out, self.muls).to(node_input_dst.dtype)
+        return out
+
+    def check(self):
+        """collect the edge-list verdict of the ``deferred`` calls since the last check (synchronises)"""
+        if self._handle is not None and self._deferred:
+            lib = _lib.load()
+            rc = lib.dedf_layer_check(self._handle, C.c_void_p(torch.cuda.current_stream(self._handle_device).cuda_stream))
+            _lib.raise_for(lib, self._handle, rc, "dedf_layer_forward")
 
 
 # =====================================================================================================================================
@@ -168,10 +192,17 @@ class NodeLinear(torch.nn.Module):
             _register(self, prefix + "layernorm.affine_weight", torch.ones(sum(self.m_in.values())))
             _register(self, prefix + "layernorm.affine_bias", torch.zeros(self.m_in.get(0, 0)))
         self._dev = None
+        self._pl_cache = {}
 
     def _pl_in(self, l):      # placement of the input channels of degree l inside the wide block
         m = self.m_in.get(l, 0)
         return unet_pad.place(m, unet_pad.WIDE[l]) if (m and m % 4 == 0 and tuple(self.m_in.get(k, 0) for k in range(3)) in _SHAPES) else torch.arange(m)
+
+    def _pl_dev(self, l, dev):
+        key = (l, str(dev))
+        if key not in self._pl_cache:
+            self._pl_cache[key] = self._pl_in(l).to(dev)
+        return self._pl_cache[key]
 
     def _wide(self, dev):
         if self._dev is not None and self._dev[0] == dev:
@@ -213,7 +244,7 @@ class NodeLinear(torch.nn.Module):
         for l in range(3):
             a, d, Mw = self.m_in.get(l, 0), 2 * l + 1, unet_pad.WIDE[l]
             if a:
-                out[:, o_w:o_w + Mw * d].view(-1, Mw, d)[:, self._pl_in(l).to(f.device), :] = f[:, o_t:o_t + a * d].reshape(-1, a, d)
+                out[:, o_w:o_w + Mw * d].view(-1, Mw, d)[:, self._pl_dev(l, f.device), :] = f[:, o_t:o_t + a * d].reshape(-1, a, d)
                 o_t += a * d
             o_w += Mw * d
         return out
@@ -222,9 +253,14 @@ class NodeLinear(torch.nn.Module):
     def forward(self, f: torch.Tensor) -> torch.Tensor:
         if not f.is_cuda:
             raise RuntimeError("diffusion_edf_amd.unet needs GPU tensors: the product has no CPU path")
-        dev = f.device
+        return unet_pad.unpad_features(self.forward_wide(self.pad_in(f.detach().float())), self.m_out).to(f.dtype)
+
+    @torch.no_grad()
+    def forward_wide(self, x: torch.Tensor) -> torch.Tensor:
+        """(n, 240) in the kernel layout -> (n, 240) in the kernel layout"""
+        dev = x.device
         W, bias, lnw, lnb, valid = self._wide(dev)
-        x = self.pad_in(f.detach().float()).contiguous()
+        x = x.contiguous()
         out = torch.empty_like(x)
         lib = _lib.load()
         with torch.cuda.device(dev):
@@ -232,7 +268,7 @@ class NodeLinear(torch.nn.Module):
                                     W.data_ptr(), bias.data_ptr(), valid, out.data_ptr(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         if rc != _lib.OK:
             raise RuntimeError(f"dedf_linear_rs failed ({rc})")
-        return unet_pad.unpad_features(out, self.m_out).to(f.dtype)
+        return out
 
 
 class _ParitySign(torch.nn.Module):
@@ -312,47 +348,66 @@ class UnetFeatureExtractor(torch.nn.Module):
 
     @torch.no_grad()
     def forward(self, pcd):
+        """Inside, features travel in the 240-wide kernel layout (padded once after ``input_emb``, un-padded once at the outputs), the layers
+        run without host synchronisation (their edge-list verdicts are collected at the end) and the graphs' batch check is done once."""
         import math
+        from . import connectivity as CN
         from .gnn_data import FeaturedPoints
         x, f, b = pcd.x, pcd.f, pcd.b
         assert f.ndim == 2 and x.ndim == 2 and b.ndim == 1 and len(f) == len(x) == len(b)
-        f = self.input_emb(f)
-        down_out, down_edges, scale_out = [(f, x, b)], [], []
+        if not f.is_cuda:
+            raise RuntimeError("diffusion_edf_amd.unet needs GPU tensors: the product has no CPU path")
+        CN._check_cloud(x, b)
+        dt = f.dtype
+        x = x.detach().float().contiguous()
+        run = lambda layer, xs, fs, xd, fd, es, ed, srt: layer.forward_wide(xs, fs, xd, fd, es, ed, dst_sorted=srt, deferred=True)
+        lin = lambda mod, v: v if isinstance(mod, torch.nn.Identity) else mod.forward_wide(v)
+        f = self.input_emb.forward_wide(self.input_emb.pad_in(f.detach().float()))
+        down_out, down_edges, scale_out, used = [(f, x, b)], [], [], []
         for blk in self.down_blocks:
-            f_dst, x_dst, es, ed, _, b_dst = blk['pool'](x, f, b)                                    # :279-282
-            f_dst = blk['pool_proj'](f_dst)
-            f = blk['pool_layer'](x, f, x_dst, f_dst, es, ed)
-            x_src_pool, x, b = x, x_dst, b_dst
-            down_out.append((f, x, b)); down_edges.append((es, ed, x_src_pool, x))
-            _, _, es, ed, _, _ = blk['radius_graph'](x, f, b)                                         # :306-311
+            f_dst, x_dst, es, ed, _, b_dst = blk['pool'](x, f, b, _trusted=True)                     # :279-282
+            f_dst = lin(blk['pool_proj'], f_dst)
+            f = run(blk['pool_layer'], x, f, x_dst, f_dst, es, ed, True)
+            used.append(blk['pool_layer'])
+            x, b = x_dst, b_dst
+            down_out.append((f, x, b)); down_edges.append((es, ed))
+            _, _, es, ed, _, _ = blk['radius_graph'](x, f, b, _trusted=True)                          # :306-311
             for layer in blk['layer_stack']:
-                f = layer(x, f, x, f, es, ed)
-                down_out.append((f, x, b)); down_edges.append((es, ed, x, x))
+                f = run(layer, x, f, x, f, es, ed, True)
+                used.append(layer)
+                down_out.append((f, x, b)); down_edges.append((es, ed))
             scale_out.append((f, x, b))
-        if self._forward_only:                                                                        # forward_only_feature_extractor.py:258-274
-            return [FeaturedPoints(x=scale_out[s][1], f=self.project_outputs[s](scale_out[s][0]), b=scale_out[s][2], w=None)
-                    for s in range(self.n_scales) if s in self.output_scalespace]
-        for layer in self.mid_block:                                                                  # :332-344 (the last radius graph)
-            f = layer(x, f, x, f, es, ed)
-        f_skip, _, _ = down_out.pop()
-        f = (f + f_skip) / math.sqrt(3)                                                               # :347
-        up_out = []
-        for k, blk in enumerate(self.up_blocks):
-            for layer in blk['layer_stack']:
-                f_skip, x_dst, b_dst = down_out.pop()
-                es, ed, _, _ = down_edges.pop()
-                f_dst = (f + f_skip) / math.sqrt(3)                                                   # :359
-                f = layer(x, f, x_dst, f_dst, ed, es)                                                 # source / destination swapped (:358)
-                x, b = x_dst, b_dst
-            up_out.append((f, x, b))
-            f_dst, x_dst, b_dst = down_out.pop()                                                      # :381-403
-            es, ed, _, _ = down_edges.pop()
-            if k != self.n_scales - 1:
-                f = blk['unpool_layer'](x, f, x_dst, f_dst, ed, es)
-                x, b = x_dst, b_dst
-        up_out = up_out[::-1]
-        return [FeaturedPoints(x=up_out[s][1], f=self.project_outputs[s](up_out[s][0]), b=up_out[s][2], w=None)
-                for s in range(self.n_scales) if s in self.output_scalespace]
+        if not self._forward_only:
+            for layer in self.mid_block:                                                              # :332-344 (the last radius graph)
+                f = run(layer, x, f, x, f, es, ed, True)
+                used.append(layer)
+            f_skip, _, _ = down_out.pop()
+            f = (f + f_skip) / math.sqrt(3)                                                           # :347
+            up_out = []
+            for k, blk in enumerate(self.up_blocks):
+                for layer in blk['layer_stack']:
+                    f_skip, x_dst, b_dst = down_out.pop()
+                    es, ed = down_edges.pop()
+                    f_dst = (f + f_skip) / math.sqrt(3)                                               # :359
+                    f = run(layer, x, f, x_dst, f_dst, ed, es, False)                                 # source / destination swapped (:358)
+                    used.append(layer)
+                    x, b = x_dst, b_dst
+                up_out.append((f, x, b))
+                f_dst, x_dst, b_dst = down_out.pop()                                                  # :381-403
+                es, ed = down_edges.pop()
+                if k != self.n_scales - 1:
+                    f = run(blk['unpool_layer'], x, f, x_dst, f_dst, ed, es, False)
+                    used.append(blk['unpool_layer'])
+                    x, b = x_dst, b_dst
+            scale_out = up_out[::-1]                                                                  # else: forward_only_feature_extractor.py:258-274
+        outs = []
+        for s in range(self.n_scales):
+            if s in self.output_scalespace:
+                fo = unet_pad.unpad_features(lin(self.project_outputs[s], scale_out[s][0]), _muls(parse_irreps(self.irreps_output)))
+                outs.append(FeaturedPoints(x=scale_out[s][1].to(pcd.x.dtype), f=fo.to(dt), b=scale_out[s][2], w=None))
+        for layer in used:
+            layer.check()
+        return outs
 
 
 class ForwardOnlyFeatureExtractor(UnetFeatureExtractor):

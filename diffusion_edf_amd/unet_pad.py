@@ -33,6 +33,17 @@ def place(m: int, M: int) -> torch.Tensor:
     return (c // (m // HEADS)) * (M // HEADS) + c % (m // HEADS)
 
 
+_PLACE_DEV = {}
+
+
+def place_on(m: int, M: int, device) -> torch.Tensor:
+    """`place` as a device tensor, built once per (m, M, device)"""
+    key = (m, M, str(device))
+    if key not in _PLACE_DEV:
+        _PLACE_DEV[key] = place(m, M).to(device)
+    return _PLACE_DEV[key]
+
+
 def _first(m: int) -> torch.Tensor:
     return torch.arange(m)
 
@@ -45,7 +56,7 @@ def pad_features(f: torch.Tensor, muls: Sequence[int]) -> torch.Tensor:
     o_t = o_w = 0
     for l, (m, M) in enumerate(zip(muls, WIDE)):
         d = 2 * l + 1
-        idx = place(m, M).to(f.device)
+        idx = place_on(m, M, f.device)
         out[:, o_w:o_w + M * d].view(-1, M, d)[:, idx, :] = f[:, o_t:o_t + m * d].reshape(-1, m, d)
         o_t += m * d
         o_w += M * d
@@ -58,7 +69,7 @@ def unpad_features(f: torch.Tensor, muls: Sequence[int]) -> torch.Tensor:
     parts, o_w = [], 0
     for l, (m, M) in enumerate(zip(muls, WIDE)):
         d = 2 * l + 1
-        parts.append(f[:, o_w:o_w + M * d].reshape(-1, M, d)[:, place(m, M).to(f.device), :].reshape(-1, m * d))
+        parts.append(f[:, o_w:o_w + M * d].reshape(-1, M, d)[:, place_on(m, M, f.device), :].reshape(-1, m * d))
         o_w += M * d
     return torch.cat(parts, dim=-1)
 

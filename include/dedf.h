@@ -149,6 +149,12 @@ int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedul
 int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const float* f_src, int n_dst, const float* x_dst, const float* f_dst,
                        int64_t n_edges, const int64_t* edge_src, const int64_t* edge_dst, float* out, void* stream);
 
+/* Chains of layers (a whole UNet is 17 of them): with on = 1, dedf_layer_forward returns WITHOUT synchronising; the verdict of its edge-list
+ * check accumulates on the device and is returned -- and cleared -- by dedf_layer_check, which synchronises `stream`: DEDF_OK or
+ * DEDF_ERR_INVALID.  Bad edges are replaced by (0, 0) inside the call, so a deferred verdict never means an out-of-range access. */
+int dedf_layer_defer_check(dedf_handle* h, int on);
+int dedf_layer_check(dedf_handle* h, void* stream);
+
 /* MultiscaleTensorField.forward(query_points, input_points_multiscale, context_emb=None) (multiscale_tensor_field.py:192-260) for a field
  * without context encoding and without query features -- the key field of an EBM-type handle (dedf_config.ebm = 1), which is also what
  * KeypointExtractor.tensor_field / .weight_field are (keypoint_extractor.py:97-112: irreps_query = None, edge_context_emb_dim = None).
