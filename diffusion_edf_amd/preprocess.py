@@ -61,12 +61,13 @@ def downsample(obj, voxel_size: float, coord_reduction: str = "average"):
     ijk = torch.floor(obj.x / voxel_size).to(torch.int64)
     key = torch.cat([obj.b.to(torch.int64)[:, None], ijk], dim=-1)
     uniq, inv = torch.unique(key, dim=0, return_inverse=True)          # sorted lexicographically
-    n = len(uniq)
-    cnt = torch.zeros(n, dtype=obj.x.dtype, device=obj.x.device).index_add_(0, inv, torch.ones_like(obj.x[:, 0]))
+    # voxel means in a FIXED summation order (points of a voxel in input order, one sequential pass per voxel): scatter-adds with atomics
+    # would make the coordinates -- and with them every graph and score downstream -- differ in the last bits from call to call
+    order = torch.sort(inv, stable=True).indices
+    counts = torch.bincount(inv, minlength=len(uniq))
 
     def mean(v):
-        acc = torch.zeros((n,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device).index_add_(0, inv, v)
-        return acc / cnt.reshape((n,) + (1,) * (v.ndim - 1)).to(v.dtype)
+        return torch.segment_reduce(v.index_select(0, order), "mean", lengths=counts, axis=0)
 
     x = mean(obj.x) if coord_reduction == "average" else (uniq[:, 1:].to(obj.x.dtype) + 0.5) * voxel_size
     return FeaturedPoints(x=x, f=mean(obj.f), b=uniq[:, 0].to(obj.b.dtype), w=None if obj.w is None else mean(obj.w))

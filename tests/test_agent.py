@@ -269,3 +269,82 @@ def test_point_attentive_model_wraps_its_single_key_cloud():
     assert isinstance(out, list) and len(out) == 1 and out[0] is cloud
     m2 = A.PointAttentiveScoreModel(**doc, key_extractor=A.PrecomputedFeatures([cloud], "64x0e+32x1e+16x2e"))
     assert len(m2.get_key_pcd_multiscale(None)) == 1
+
+
+def _write_task_tree(root, schedules=((1.0, 0.15),)):
+    """a task directory in the reference's layout (configs/<task>/{agent,server,preprocess}.yaml + one directory per model) for a place task:
+    low-res and high-res score models with UNet key model + KeypointExtractor query model, and an EBM critic"""
+    from test_keypoint_extractor import _query_kwargs
+    task = os.path.join(root, "configs", "toy_place")
+
+    def model_dir(name, radii, ebm):
+        hk = synthetic.score_head_kwargs(2, radii=radii)
+        if ebm:
+            hk.update(ebm=True, edge_time_encoding=False, query_time_encoding=False)
+        doc = _model_yaml(hk)
+        doc["model_kwargs"]["query_model"] = "KeypointExtractor"
+        doc["model_kwargs"]["query_kwargs"] = _query_kwargs((5.0, 10.0, 20.0, 40.0), bbox=None)
+        d = os.path.join(task, name)
+        os.makedirs(d, exist_ok=True)
+        yaml.safe_dump(dict(model_config_file='score_model_configs.yaml', device='cuda:0',
+                            diffusion_configs=dict(time_schedules=[list(s) for s in schedules], t_augment=0.01)), open(os.path.join(d, 'train_configs.yaml'), 'w'))
+        yaml.safe_dump(dict(task_type='place'), open(os.path.join(d, 'task_configs.yaml'), 'w'))
+        yaml.safe_dump(doc, open(os.path.join(d, 'score_model_configs.yaml'), 'w'))
+        return dict(configs_root_dir=os.path.join("configs", "toy_place", name), train_configs_file="train_configs.yaml",
+                    task_configs_file="task_configs.yaml", checkpoint_dir=None, n_warmups=0)
+    agent = dict(device="cuda:0", model_kwargs=dict(
+        place_models_kwargs=[model_dir("place_lowres", (5., 10., 20., None), False), model_dir("place_highres", (3.5, 5., 6.5, 8.), False)],
+        place_critic_kwargs=model_dir("place_ebm", (5., 10., 20., None), True), pick_models_kwargs=[], pick_critic_kwargs=None))
+    os.makedirs(task, exist_ok=True)
+    yaml.safe_dump(agent, open(os.path.join(task, "agent.yaml"), "w"))
+    yaml.safe_dump(dict(place_diffusion_configs=dict(N_steps_list=[[3], [2]], timesteps_list=[[0.04], [0.02]], temperatures_list=[1.0, 1.0],
+                                                     diffusion_schedules_list=[[[1.0, 0.3]], [[0.3, 0.1]]], log_t_schedule=True,
+                                                     time_exponent_temp=1.0, time_exponent_alpha=0.5)), open(os.path.join(task, "server.yaml"), "w"))
+    yaml.safe_dump(dict(preprocess_config=[dict(name="downsample", kwargs=dict(voxel_size=0.005, coord_reduction="average")),
+                                           dict(name="rescale", kwargs=dict(rescale_factor=100.0))],
+                        unprocess_config=[dict(name="rescale", kwargs=dict(rescale_factor=0.01))]), open(os.path.join(task, "preprocess.yaml"), "w"))
+    return task
+
+
+def test_toy_task_tree_loads_on_the_host(tmp_path):
+    from diffusion_edf_amd import configs as CF
+    tc = CF.TaskConfigs.load(_write_task_tree(str(tmp_path)))
+    assert len(tc.models["place"]) == 2 and tc.critic["place"] is not None and tc.n_denoising_steps("place") == 5
+
+
+@pytest.mark.gpu
+def test_task_directory_to_ranked_poses_on_the_gpu(tmp_path):
+    """the whole deployment path with nothing injected: task directory -> DiffusionEdfAgent (UNet + KeypointExtractor + score heads + critic, all
+    on the HIP path) -> sample(raw clouds in metres, T_seed) -> trajectories ordered by critic energy.  Every stage has its own parity test;
+    this one checks that they are wired like agent.py:98-186: shapes, units, ordering, determinism."""
+    from diffusion_edf_amd import configs as CF
+    dev = torch.device("cuda:0")
+    tc = CF.TaskConfigs.load(_write_task_tree(str(tmp_path)))
+    ag = tc.build_agent("place", checkpoints="skip", device="cuda:0", n_warmups=0)
+    from diffusion_edf_amd.keypoint_extractor import KeypointExtractor
+    from diffusion_edf_amd.unet import UnetFeatureExtractor
+    assert all(type(m.key_model) is UnetFeatureExtractor and type(m.query_model) is KeypointExtractor for m in ag.models + [ag.critic])
+    import numpy as np
+    g = torch.Generator().manual_seed(0)
+    scene_x = torch.from_numpy(synthetic.make_scene(6000, seed=1).astype(np.float32)) * 0.01                   # metres
+    grasp_x = torch.from_numpy(synthetic.make_grasp(1500, seed=2).astype(np.float32)) * 0.01
+    fp = lambda x: FeaturedPoints(x=x.to(dev), f=torch.rand(len(x), 3, generator=g).to(dev), b=torch.zeros(len(x), dtype=torch.long, device=dev))
+    scene, grasp = fp(scene_x), fp(grasp_x)
+    T0 = synthetic.make_poses(12, seed=3).to(dev)
+    T0[:, 4:] *= 0.01                                                                                          # metres
+    kw = tc.sample_kwargs("place")
+    torch.manual_seed(7)             # get_models builds the extractors with deterministic=False like agent.py:20-64: FPS starts at a random point
+    Ts, scene_p, grasp_p, info = ag.sample(scene, grasp, T0, **kw, return_info=True, seed=5)
+    assert Ts.shape == ((3 + 2) + (2 + 2), 12, 7) and bool(torch.isfinite(Ts).all())
+    assert len(scene_p.x) < len(scene.x) and float(scene_p.x.abs().max()) > 5.0                                # downsampled, centimetres
+    assert torch.allclose(Ts[..., :4].norm(dim=-1), torch.ones_like(Ts[..., 0]), atol=1e-5)
+    e = info["energy"]
+    assert e.shape == (12,) and bool((e[1:] >= e[:-1]).all()) and float(e[-1] - e[0]) > 0
+    first = Ts[0].double()
+    assert float((first[:, 4:].sort(dim=0).values - (T0[:, 4:].double() * 100.0).sort(dim=0).values).abs().max()) < 1e-4   # the seeds, in cm, re-ordered
+    assert float((Ts[-1, :, 4:] - Ts[0, :, 4:]).abs().max()) > 1e-3                                           # the poses moved
+    torch.manual_seed(7)
+    Ts2, _, _ = ag.sample(scene, grasp, T0, **kw, seed=5)
+    assert torch.equal(Ts2, Ts)                                         # same FPS starts + counter-based Langevin noise: bit-reproducible
+    back = ag.unprocess_fn(Ts[-1])
+    assert torch.allclose(back[:, 4:], Ts[-1][:, 4:] * 0.01)
