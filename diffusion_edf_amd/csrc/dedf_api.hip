@@ -79,6 +79,8 @@ struct dedf_handle {
     const LangevinParams* fused_step = nullptr;           // dedf_sample: the per-pose reduction also carries this step's Langevin update
     DevBuf d_tb_steps; const float* tb_step = nullptr;    // dedf_sample: the time-bias rows of ALL steps are computed up front; tb_step = this step's rows
     std::vector<float> h_tsteps;
+    bool radial_table = true;         // sampler: tabulate the radial network's front per launch (DEDF_RADIAL_TABLE=0 / dedf_set_radial_table turn it off)
+    DevBuf d_rtab;
     bool defer_check = false;         // dedf_layer_defer_check
     DevBuf d_sticky;
     bool want_field = false;          // dedf_field: the node kernel also writes the field / emb of every node
@@ -372,7 +374,32 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         // half_gemm (the reference's half_precision knob): single-term fp16 products
         const dim3 grid(h->n_cu * wpc), blk(64);
         const bool hp = h->cfg.half_gemm != 0;
-        if constexpr (F0 == 128) {
+        // Sampler (every pose shares the step's time): the front of the radial network is a function of (scale, length) only -- tabulate
+        // it once per launch on a fine length grid with the tile's own code and interpolate per edge (dedf_edge.h: EdgeParams::rtab)
+        bool use_tab = false;
+        if constexpr (F0 == 128 && L == 2 && !EBM) {
+            use_tab = h->radial_table && !hp && h->cfg.fc_neurons[1] == kFc1 && P.tb_pose_stride == 0 && !h->debug;
+            if (use_tab) {
+                int row = 0;
+                for (int n = 0; n < ns; ++n) {
+                    const bool fin = c.radii[n] > 0;
+                    const int G = fin ? kRtabFinite : kRtabInfinite;
+                    const double span = fin ? (double)c.radii[n] : kRtabInfiniteSpan * (double)c.length_enc_max_r;
+                    P.rtab_row0[n] = row; P.rtab_n[n] = G;
+                    P.rtab_step[n] = (float)(span / G); P.rtab_inv_step[n] = (float)(G / span);
+                    row += G + 3;
+                }
+                const size_t bytes = (size_t)row * 64 * 4;
+                if (!h->d_rtab.ensure(bytes)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(radial table) failed");
+                P.rtab = h->d_rtab.as<float>(); P.rtab_out = h->d_rtab.as<float>(); P.rtab_bytes = (uint32_t)bytes;
+                int ntab = 0;
+                for (int n = 0; n < ns; ++n) ntab += (P.rtab_n[n] + 3 + 31) / 32;
+                hipLaunchKernelGGL((k_radial_table<2, 128>), dim3(std::min(ntab, h->n_cu * 4)), blk, 0, st, P);
+                hipLaunchKernelGGL((k_edge<2, 128, false, 128, 64, false, 1>), grid, blk, 0, st, P);
+            }
+        }
+        if (use_tab) {
+        } else if constexpr (F0 == 128) {
             if (h->cfg.fc_neurons[1] == 32) {         // narrow radial MLP (sapien place_*)
                 if (hp) hipLaunchKernelGGL((k_edge<L, F0, true, 32, 32>), grid, blk, 0, st, P);
                 else hipLaunchKernelGGL((k_edge<L, F0, false, 32, 32>), grid, blk, 0, st, P);
@@ -481,6 +508,7 @@ int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, de
     h->cfg = *cfg;
     h->L = cfg->lmax;
     h->host_only = cfg->device < 0;
+    if (const char* e = getenv("DEDF_RADIAL_TABLE")) h->radial_table = atoi(e) != 0;
     if (h->L == 1) build_all<1>(h.get()); else build_all<2>(h.get());
     if (!params || n_params != h->spec.total) {
         fprintf(stderr, "dedf_create: expected %zu parameters, got %zu\n", h->spec.total, n_params);
@@ -830,6 +858,12 @@ int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const floa
     int bad = 0;
     HIPCK(h, hipMemcpy(&bad, h->d_tile.as<int>() + kFlagBadEdges, 4, hipMemcpyDeviceToHost));
     if (bad) return fail(h, DEDF_ERR_INVALID, "edge lists: edge_dst must be sorted ascending and every index inside its cloud");
+    return DEDF_OK;
+}
+
+int dedf_set_radial_table(dedf_handle* h, int on) {
+    if (!h) return DEDF_ERR_INVALID;
+    h->radial_table = on != 0;
     return DEDF_OK;
 }
 

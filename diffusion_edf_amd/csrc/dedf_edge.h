@@ -59,6 +59,16 @@ struct EdgeParams {
     float* dbg_out;           // optional [E][edge_rec] per-edge records (value, logits) for the stage tests
     float* dbg_w;             // optional [E][WN] dump of the radial weights (tests)
     unsigned long long* phase_prof;   // optional [grid][16] per-wave phase cycle sums (built with -DDEDF_PHASE_PROF)
+    // Radial table (edge_tile MODE 1 / 2): when every pose of a launch shares the diffusion time -- the sampler -- everything in front of
+    // layer 3 of the radial network (length encoding, pre-linear, layers 1 and 2 with their LayerNorm + SiLU) is a function of (scale,
+    // edge length) alone.  k_radial_table evaluates it with the kernel's own code on a fine length grid once per launch
+    // ([row][half][32] floats: row g of scale n is the node at length (g - 1) * rtab_step[n]; rtab_n[n] + 3 rows from rtab_row0[n]); the
+    // edge kernel reads four neighbouring rows per edge and interpolates (4-point Lagrange: error ~ 0.023 step^4 |d4f/dlen4|).
+    const float* rtab;
+    uint32_t rtab_bytes;
+    float* rtab_out;
+    int rtab_row0[kMaxScales], rtab_n[kMaxScales];
+    float rtab_step[kMaxScales], rtab_inv_step[kMaxScales];
 };
 
 template <int L> struct SH {           // spherical harmonics of one edge, non-scalar blocks already cut off
@@ -243,10 +253,19 @@ DEDF_DEV void edge_enc_to_lds(const EdgeParams& P, const Wave& wv, int scale) {
 // UN: the edge pipeline of a UNet layer (block.EquiformerBlock + GraphAttentionMLP, block.py:141-174, graph_attention.py:84-122):
 //     message = linear_src(f_src)[src] + linear_dst(f_dst)[dst], the radial MLP reads the radial basis directly (no pre-linear, no
 //     time), GaussianRadialBasisLayerFiniteCutoff instead of GaussianRadialBasis, SH without the non-scalar cut-off, no edge logit
-template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false>
-DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, int n_valid DEDF_PROF_ARG) {
+// Geometry of the NEXT tile, carried across the persistent tile loop by the table-reading kernel (MODE 1): with the radial network's front
+// gone, a tile would otherwise start with three dependent round trips to memory (edge indices -> coordinates -> table rows) and nothing to
+// put under them.  The indices are requested at the top of the previous tile, the coordinates in its middle.
+struct GeoPre { int ok, src, dst; float vx, vy, vz; };
+
+// MODE 0: everything per edge.  MODE 1: the radial network's front comes from the radial table (EdgeParams::rtab) for every tile whose
+// lengths lie inside the table, per edge otherwise (the all-pairs scale has no a-priori bound).  MODE 2: table generator -- "edge" e of
+// the tile is table row e of `scale`; the tile ends after layer 2's activation.
+template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false, int MODE = 0>
+DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, int n_valid, GeoPre& geo, int e_next DEDF_PROF_ARG) {
     static_assert((H1 == 128 && H2 == 64) || (H1 == 32 && H2 == 32), "radial MLP widths of the shipped configs");
     static_assert(!UN || F0 == 64, "UNet layer: the radial MLP reads the 64 radial-basis channels");
+    static_assert(MODE == 0 || !UN, "the radial table is the sampler's");
 #if defined(DEDF_PHASE_PROF) && defined(__HIP_DEVICE_COMPILE__)
     unsigned long long t_last = __builtin_readcyclecounter();
 #endif
@@ -263,8 +282,13 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     const int o_A_r1_l = opaque_s(P.o_A_r1_l), o_A_r2_l = opaque_s(P.o_A_r2_l), o_A_r3_l = opaque_s(P.o_A_r3_l);
     const bool valid = wv.col < n_valid;
     const int e = e0 + (valid ? wv.col : 0);
-    const int src = P.edge_src[e], dst = P.edge_dst[e];
-    const int pose = dst / P.nQ;
+    int src = 0, dst = 0, pose = 0;
+    if constexpr (MODE == 1) {
+        if (geo.ok) { src = geo.src; dst = geo.dst; } else { src = P.edge_src[e]; dst = P.edge_dst[e]; }
+        pose = dst / P.nQ;
+    } else if constexpr (MODE != 2) { src = P.edge_src[e]; dst = P.edge_dst[e]; pose = dst / P.nQ; }
+    int nsrc = 0, ndst = 0;            // MODE 1: the next tile's indices, requested now
+    if constexpr (MODE == 1) { if (e_next >= 0) { nsrc = P.edge_src[e_next]; ndst = P.edge_dst[e_next]; } }
 
     // operands of the edge pre-linear (first K-chunks) and its per-pose bias rows: requested before the geometry / length-encoding
     // VALU work, which hides their latency
@@ -272,22 +296,28 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     constexpr int NT1 = H1 / 32, NT2 = H2 / 32;
     f32x16 h[NH];
     const int oA_pre = opaque_s(P.o_A_pre + scale * (NH * 4 * 256)), oAl_pre = opaque_s(P.o_A_pre_l + scale * (NH * 4 * 256));
-    if constexpr (!UN) {
-        const Buf tbb = make_buf(P.tb, P.tb_bytes);
-        const int tvoff = (pose * P.tb_pose_stride) * 4 + wv.hi64;
-        static_for<NH>([&]<int To>() { h[To] = ldrows(tbb, tvoff, scale * F0, To); });
-    }
     DenseRing<NH, 2> ring_pre{};
     DenseRing<NT1, 2> ring_r1u{};
-    if constexpr (!UN) ring_pre = dense_prefetch<NH, 4, 2, HP>(wv, oA_pre, oAl_pre);
-    else ring_r1u = dense_prefetch<NT1, 4, 2, HP>(wv, o_A_r1, o_A_r1_l);
-    sched_fence();
+    auto front_requests = [&]() {
+        if constexpr (!UN) {
+            const Buf tbb = make_buf(P.tb, P.tb_bytes);
+            const int tvoff = (pose * P.tb_pose_stride) * 4 + wv.hi64;
+            static_for<NH>([&]<int To>() { h[To] = ldrows(tbb, tvoff, scale * F0, To); });
+            ring_pre = dense_prefetch<NH, 4, 2, HP>(wv, oA_pre, oAl_pre);
+        } else ring_r1u = dense_prefetch<NT1, 4, 2, HP>(wv, o_A_r1, o_A_r1_l);
+    };
+    if constexpr (MODE != 1) { front_requests(); sched_fence(); }      // (MODE 1 asks for them only when a tile falls back to the per-edge front)
 
     // ---- geometry (graph_parser.py:159-215) ---------------------------------------------------------------------
-    const float vx = P.key_x[3 * src + 0] - P.qpos[3 * dst + 0];
-    const float vy = P.key_x[3 * src + 1] - P.qpos[3 * dst + 1];
-    const float vz = P.key_x[3 * src + 2] - P.qpos[3 * dst + 2];
-    const float len = sqrtf(vx * vx + vy * vy + vz * vz);
+    float vx = 0.0f, vy = 0.0f, vz = 1.0f, len;
+    if constexpr (MODE == 2) len = (float)(e - 1) * P.rtab_step[scale];
+    else if (MODE == 1 && geo.ok) { vx = geo.vx; vy = geo.vy; vz = geo.vz; len = sqrtf(vx * vx + vy * vy + vz * vz); }
+    else {
+        vx = P.key_x[3 * src + 0] - P.qpos[3 * dst + 0];
+        vy = P.key_x[3 * src + 1] - P.qpos[3 * dst + 1];
+        vz = P.key_x[3 * src + 2] - P.qpos[3 * dst + 2];
+        len = sqrtf(vx * vx + vy * vy + vz * vz);
+    }
     const float radius = P.radius[scale];
     float logit0 = 0.0f;
     if (!UN && radius > 0.0f) {
@@ -313,77 +343,108 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         static_assert(L <= 2, "l = 3 spherical harmonics are a next-row item");
     }
 
-    // ---- length embedding: this lane's 32 of the 64 channels (k = s + 32*hi) ------------------------------------------
-    float eb[32];
-    {
-        const f32x4* const enc = reinterpret_cast<const f32x4*>(rows + RL::enc);       // this scale's constants (edge_enc_to_lds)
-        if (radius > 0.0f) {           // GaussianRadialBasis, radial_func.py:208-227
-            // UNet layer (GaussianRadialBasisLayerFiniteCutoff, radial_func.py:262-278): t = (len - offset) / (cutoff - offset); the host
-            // passes cutoff - offset as `radius` and the offset as `cut_begin`
-            const float t = UN ? (len - P.cut_begin[scale]) / radius : len / radius;
-            static_for<2>([&]<int Hf>() {      // 16 channels at a time, stage by stage (see sigmoid_stage)
-                float z[16], wv16[16];
-                static_for<4>([&]<int G4>() {
-                    constexpr int G = 4 * Hf + G4;
-                    const f32x4 mu = enc[hi * 8 + G], is = enc[16 + hi * 8 + G], w = enc[32 + hi * 8 + G];
-                    static_for<4>([&]<int J>() { z[4 * G4 + J] = (t - mu[J]) * is[J]; wv16[4 * G4 + J] = w[J]; });
+    f32x16 r2[NT2];
+    f32x4 trow[MODE == 1 ? 4 : 1][8];      // MODE 1: this lane's halves of the four table rows around its length
+    float tw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    bool tab = false;          // wave-uniform: this tile takes the radial network's front from the table
+    if constexpr (MODE == 1) {
+        const float pos = len * P.rtab_inv_step[scale];
+        tab = __all(!valid || pos < (float)P.rtab_n[scale]) != 0;
+        if (tab) {
+            const float ps = valid ? pos : 0.0f;
+            const int i0 = (int)ps;
+            const float u = ps - (float)i0;
+            // 4-point Lagrange weights for the nodes at -1, 0, 1, 2 (rows i0 .. i0 + 3)
+            const float um = u - 1.0f, up = u + 1.0f, u2 = u - 2.0f;
+            const float w0 = -(1.0f / 6) * u * um * u2, w1 = 0.5f * up * um * u2, w2 = -0.5f * up * u * u2, w3 = (1.0f / 6) * up * u * um;
+            const Buf rtb = make_buf(P.rtab, P.rtab_bytes);
+            const int rv = ((P.rtab_row0[scale] + i0) * 2 + hi) * 128;
+            // the four rows are only REQUESTED here; they are combined in the prologue of the fused stage, under its operand requests
+            static_for<4>([&]<int K>() { static_for<8>([&]<int Q>() { trow[K][Q] = bld4(rtb, rv, K * 256 + Q * 16); }); });
+            tw[0] = w0; tw[1] = w1; tw[2] = w2; tw[3] = w3;
+        } else front_requests();
+    }
+    if (!tab) {
+        // ---- length embedding: this lane's 32 of the 64 channels (k = s + 32*hi) ------------------------------------------
+        float eb[32];
+        {
+            const f32x4* const enc = reinterpret_cast<const f32x4*>(rows + RL::enc);       // this scale's constants (edge_enc_to_lds)
+            if (radius > 0.0f) {           // GaussianRadialBasis, radial_func.py:208-227
+                // UNet layer (GaussianRadialBasisLayerFiniteCutoff, radial_func.py:262-278): t = (len - offset) / (cutoff - offset); the host
+                // passes cutoff - offset as `radius` and the offset as `cut_begin`
+                const float t = UN ? (len - P.cut_begin[scale]) / radius : len / radius;
+                static_for<2>([&]<int Hf>() {      // 16 channels at a time, stage by stage (see sigmoid_stage)
+                    float z[16], wv16[16];
+                    static_for<4>([&]<int G4>() {
+                        constexpr int G = 4 * Hf + G4;
+                        const f32x4 mu = enc[hi * 8 + G], is = enc[16 + hi * 8 + G], w = enc[32 + hi * 8 + G];
+                        static_for<4>([&]<int J>() { z[4 * G4 + J] = (t - mu[J]) * is[J]; wv16[4 * G4 + J] = w[J]; });
+                    });
+                    static_for<16>([&]<int i>() { z[i] = -0.5f * (z[i] * z[i]); });
+                    static_for<16>([&]<int i>() { z[i] = z[i] * 1.44269504088896340736f; });
+    #if defined(__HIP_DEVICE_COMPILE__)
+                    static_for<16>([&]<int i>() { z[i] = __builtin_amdgcn_exp2f(z[i]); });
+    #else
+                    static_for<16>([&]<int i>() { z[i] = exp2f(z[i]); });
+    #endif
+                    static_for<16>([&]<int i>() { eb[16 * Hf + i] = z[i] * wv16[i]; });
                 });
-                static_for<16>([&]<int i>() { z[i] = -0.5f * (z[i] * z[i]); });
-                static_for<16>([&]<int i>() { z[i] = z[i] * 1.44269504088896340736f; });
-#if defined(__HIP_DEVICE_COMPILE__)
-                static_for<16>([&]<int i>() { z[i] = __builtin_amdgcn_exp2f(z[i]); });
-#else
-                static_for<16>([&]<int i>() { z[i] = exp2f(z[i]); });
-#endif
-                static_for<16>([&]<int i>() { eb[16 * Hf + i] = z[i] * wv16[i]; });
-            });
-            if constexpr (UN) {        // soft_square_cutoff(t, thr = 0.8, infinite = False), radial_func.py:24-29: fades IN over t in (0, 0.2)
-                const float x1 = 1.0f - t;
-                const float c = t > 0.5f ? 1.0f : 1.0f - soft_step((x1 - 0.8f) / (1.0f - 0.8f));
-                static_for<32>([&]<int i>() { eb[i] = eb[i] * c; });
+                if constexpr (UN) {        // soft_square_cutoff(t, thr = 0.8, infinite = False), radial_func.py:24-29: fades IN over t in (0, 0.2)
+                    const float x1 = 1.0f - t;
+                    const float c = t > 0.5f ? 1.0f : 1.0f - soft_step((x1 - 0.8f) / (1.0f - 0.8f));
+                    static_for<32>([&]<int i>() { eb[i] = eb[i] * c; });
+                }
+            } else {                       // SinusoidalPositionEmbeddings(n = 1000), radial_func.py:305-316
+                const float x = len / P.len_enc_max_r * 1000.0f;
+                static_for<8>([&]<int G>() {
+                    const f32x4 fr = enc[G];
+                    static_for<4>([&]<int J>() { eb[4 * G + J] = sin_or_cos(x * fr[J], hi); });
+                });
             }
-        } else {                       // SinusoidalPositionEmbeddings(n = 1000), radial_func.py:305-316
-            const float x = len / P.len_enc_max_r * 1000.0f;
-            static_for<8>([&]<int G>() {
-                const f32x4 fr = enc[G];
-                static_for<4>([&]<int J>() { eb[4 * G + J] = sin_or_cos(x * fr[J], hi); });
+        }
+
+        DEDF_STAMP(0);
+        // ---- edge pre-linear + SiLU (multiscale_tensor_field.py:225-234); time part + bias arrive as per-pose rows --------
+        DenseRing<NT1, 2> ring_r1 = ring_r1u;
+        if constexpr (!UN) {
+            dense_rot_h<NH, 4, 2, HP>(wv, oA_pre, oAl_pre, h, [&]<int c, int j>() { return eb[8 * c + j]; }, ring_pre);
+            ring_r1 = dense_prefetch<NT1, F0 / 16, 2, HP>(wv, o_A_r1, o_A_r1_l);      // layer 1's first operands: under the SiLU below
+            sched_fence();
+            static_for<NH>([&]<int To>() {
+                to_vgpr(h[To]);
+                float y[16];
+                static_for<16>([&]<int R>() { y[R] = h[To][R]; });
+                silu_stage<16>(y);
+                static_for<16>([&]<int R>() { h[To][R] = y[R]; });
             });
         }
-    }
-
-    DEDF_STAMP(0);
-    // ---- edge pre-linear + SiLU (multiscale_tensor_field.py:225-234); time part + bias arrive as per-pose rows --------
-    DenseRing<NT1, 2> ring_r1 = ring_r1u;
-    if constexpr (!UN) {
-        dense_rot_h<NH, 4, 2, HP>(wv, oA_pre, oAl_pre, h, [&]<int c, int j>() { return eb[8 * c + j]; }, ring_pre);
-        ring_r1 = dense_prefetch<NT1, F0 / 16, 2, HP>(wv, o_A_r1, o_A_r1_l);      // layer 1's first operands: under the SiLU below
+        DEDF_STAMP(1);
+        // ---- RadialProfile layers 1, 2 (equiformer/radial_func.py:11-60) ---------------------------------------------------
+        f32x16 r1[NT1];
+        static_for<NT1>([&]<int To>() { r1[To] = ldrows_lds(rows, hi, RL::b1, To); });
+        if constexpr (UN)        // no pre-linear: layer 1 reads the radial basis (K = 64 = four chunks of this lane's embedding values)
+            dense_rot_h<NT1, 4, 2, HP>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return eb[8 * c + j]; }, ring_r1);
+        else
+            dense_rot_h<NT1, F0 / 16, 2, HP>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return h[c / 2][8 * (c % 2) + j]; }, ring_r1);
+        DEDF_STAMP(2);
+        auto ring_r2 = dense_prefetch<NT2, H1 / 16, 2, HP>(wv, o_A_r2, o_A_r2_l);      // layer 2's first operands: under the LayerNorm below
         sched_fence();
-        static_for<NH>([&]<int To>() {
-            to_vgpr(h[To]);
-            float y[16];
-            static_for<16>([&]<int R>() { y[R] = h[To][R]; });
-            silu_stage<16>(y);
-            static_for<16>([&]<int R>() { h[To][R] = y[R]; });
-        });
+        static_for<NT1>([&]<int To>() { to_vgpr(r1[To]); });
+        ln_silu<NT1, UN>(r1, wv, rows, RL::g1, RL::be1, P.ln_inv_n[0], P.ln_pad[0]);
+        DEDF_STAMP(3);
+        static_for<NT2>([&]<int To>() { r2[To] = ldrows_lds(rows, hi, RL::b2, To); });
+        dense_rot_h<NT2, H1 / 16, 2, HP>(wv, o_A_r2, o_A_r2_l, r2, [&]<int c, int j>() { return r1[c / 2][8 * (c % 2) + j]; }, ring_r2);
+        DEDF_STAMP(4);
     }
-    DEDF_STAMP(1);
-    // ---- RadialProfile layers 1, 2 (equiformer/radial_func.py:11-60) ---------------------------------------------------
-    f32x16 r1[NT1];
-    static_for<NT1>([&]<int To>() { r1[To] = ldrows_lds(rows, hi, RL::b1, To); });
-    if constexpr (UN)        // no pre-linear: layer 1 reads the radial basis (K = 64 = four chunks of this lane's embedding values)
-        dense_rot_h<NT1, 4, 2, HP>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return eb[8 * c + j]; }, ring_r1);
-    else
-        dense_rot_h<NT1, F0 / 16, 2, HP>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return h[c / 2][8 * (c % 2) + j]; }, ring_r1);
-    DEDF_STAMP(2);
-    auto ring_r2 = dense_prefetch<NT2, H1 / 16, 2, HP>(wv, o_A_r2, o_A_r2_l);      // layer 2's first operands: under the LayerNorm below
-    sched_fence();
-    static_for<NT1>([&]<int To>() { to_vgpr(r1[To]); });
-    ln_silu<NT1, UN>(r1, wv, rows, RL::g1, RL::be1, P.ln_inv_n[0], P.ln_pad[0]);
-    DEDF_STAMP(3);
-    f32x16 r2[NT2];
-    static_for<NT2>([&]<int To>() { r2[To] = ldrows_lds(rows, hi, RL::b2, To); });
-    dense_rot_h<NT2, H1 / 16, 2, HP>(wv, o_A_r2, o_A_r2_l, r2, [&]<int c, int j>() { return r1[c / 2][8 * (c % 2) + j]; }, ring_r2);
-    DEDF_STAMP(4);
+    if constexpr (MODE == 2) {      // generator: layer 2's activation, one table row per grid node, done
+        static_for<NT2>([&]<int To>() { to_vgpr(r2[To]); });
+        ln_silu<NT2, false>(r2, wv, rows, RL::g2, RL::be2);
+        if (valid) {
+            float* const o = P.rtab_out + ((size_t)(P.rtab_row0[scale] + e) * 2 + hi) * 32;
+            static_for<8>([&]<int Q>() { st4(o + 4 * Q, f32x4{r2[Q / 4][4 * (Q % 4)], r2[Q / 4][4 * (Q % 4) + 1], r2[Q / 4][4 * (Q % 4) + 2], r2[Q / 4][4 * (Q % 4) + 3]}); });
+        }
+        return;
+    }
     // (layer 2's LayerNorm + SiLU run in the prologue of the next stage, under its first operand requests)
 
     // ---- layer 3 (-> per-edge TP weights, one 32-row tile at a time) fused with DTP #1 and the lin / sep_alpha GEMMs ----
@@ -622,8 +683,14 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         const f32x16 off0 = load_off.template operator()<0>(), off1 = load_off.template operator()<1>();
         sched_fence();
         // layer 2's LayerNorm + SiLU and the split of its output (B operands of layer 3), under the requests above
-        static_for<NT2>([&]<int To>() { to_vgpr(r2[To]); });
-        ln_silu<NT2, UN>(r2, wv, rows, RL::g2, RL::be2, P.ln_inv_n[1], P.ln_pad[1]);
+        if (!tab) {
+            static_for<NT2>([&]<int To>() { to_vgpr(r2[To]); });
+            ln_silu<NT2, UN>(r2, wv, rows, RL::g2, RL::be2, P.ln_inv_n[1], P.ln_pad[1]);
+        } else if constexpr (MODE == 1) {
+            static_for<8>([&]<int Q>() { static_for<4>([&]<int J>() {
+                r2[Q / 4][4 * (Q % 4) + J] = (tw[0] * trow[0][Q][J] + tw[1] * trow[1][Q][J]) + (tw[2] * trow[2][Q][J] + tw[3] * trow[3][Q][J]);
+            }); });
+        }
         DEDF_STAMP(5);
         static_for<KC>([&]<int c>() {
             float t[8];
@@ -671,6 +738,13 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     finish_group.template operator()<L>();
     sched_fence();
     DEDF_STAMP(12);
+    float nk[3] = {0.0f, 0.0f, 0.0f}, nq[3] = {0.0f, 0.0f, 0.0f};       // MODE 1: the next tile's coordinates, requested here
+    if constexpr (MODE == 1) {
+        if (e_next >= 0) {
+            static_for<3>([&]<int i>() { nk[i] = P.key_x[3 * nsrc + i]; nq[i] = P.qpos[3 * ndst + i]; });
+        }
+        sched_fence();
+    }
     // ---- sep_value: depth-wise TP #2 (shared weights folded into the A stream) + LinearRS -> value --------------------------
     // The Clebsch-Gordan coefficient products of the SH (CG::make) are recomputed here from an opaque copy of the SH: merged with the
     // first depth-wise TP's, ~130 of them would stay alive across both phases.
@@ -918,6 +992,10 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     DEDF_STAMP(14);
     store_group.template operator()<L>();
     if (P.dbg_out != nullptr && valid && hi == 0) st4(drec_of() + D, f32x4{logit[0], logit[1], logit[2], logit[3]});
+    if constexpr (MODE == 1) {
+        geo.ok = e_next >= 0; geo.src = nsrc; geo.dst = ndst;
+        geo.vx = nk[0] - nq[0]; geo.vy = nk[1] - nq[1]; geo.vz = nk[2] - nq[2];
+    }
     DEDF_STAMP(11);
 }
 

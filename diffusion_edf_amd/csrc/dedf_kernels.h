@@ -8,7 +8,7 @@
 
 using namespace dedf;
 
-template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false> __global__ __launch_bounds__(64, 1) void k_edge(EdgeParams P) {
+template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false, int MODE = 0> __global__ __launch_bounds__(64, 1) void k_edge(EdgeParams P) {
     const int* ti = P.tile_info;
     const int ntiles = ti[P.n_scales];
     const Wave wv = make_wave(P.W, P.W_bytes);
@@ -17,21 +17,58 @@ template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = f
 #endif
     edge_rows_to_lds<L, H1, H2>(P, wv);
     int enc_scale = -1;
+    GeoPre geo{};
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         int scale = 0;
         while (t >= ti[scale + 1]) ++scale;
         if (scale != enc_scale) { edge_enc_to_lds<L>(P, wv, scale); enc_scale = scale; }
         const int k = t - ti[scale];
         const int ebase = ti[16 + scale], En = ti[16 + scale + 1] - ebase;
+        int e_next = -1;               // MODE 1: this lane's edge of the wave's next tile (padding lanes read the tile's first edge)
+        if constexpr (MODE == 1) {
+            const int tn = t + gridDim.x;
+            if (tn < ntiles) {
+                int sn = scale;
+                while (tn >= ti[sn + 1]) ++sn;
+                const int kn = tn - ti[sn], eb = ti[16 + sn], nv = min(32, ti[16 + sn + 1] - eb - 32 * kn);
+                e_next = eb + 32 * kn + (wv.col < nv ? wv.col : 0);
+            }
+        }
 #if defined(DEDF_PHASE_PROF)
-        edge_tile<L, F0, HP, H1, H2, UN>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k), pacc);
+        edge_tile<L, F0, HP, H1, H2, UN, MODE>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k), geo, e_next, pacc);
 #else
-        edge_tile<L, F0, HP, H1, H2, UN>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k));
+        edge_tile<L, F0, HP, H1, H2, UN, MODE>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k), geo, e_next);
 #endif
     }
 #if defined(DEDF_PHASE_PROF)
     if (P.phase_prof && wv.lane == 0) for (int i = 0; i < 16; ++i) P.phase_prof[blockIdx.x * 16 + i] += pacc[i];
 #endif
+}
+// Radial table of the sampler (EdgeParams::rtab): the front of the radial network on the length grid of every scale, computed by the edge
+// tile's own code (edge_tile MODE 2), 32 grid nodes per tile.
+template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64> __global__ __launch_bounds__(64, 1) void k_radial_table(EdgeParams P) {
+    const Wave wv = make_wave(P.W, P.W_bytes);
+    edge_rows_to_lds<L, H1, H2>(P, wv);
+    int enc_scale = -1;
+    for (int t = blockIdx.x;; t += gridDim.x) {
+        int scale = 0, base = 0;
+        for (; scale < P.n_scales; ++scale) {
+            const int nt = (P.rtab_n[scale] + 3 + 31) / 32;
+            if (t - base < nt) break;
+            base += nt;
+        }
+        if (scale >= P.n_scales) break;
+        if (scale != enc_scale) { edge_enc_to_lds<L>(P, wv, scale); enc_scale = scale; }
+        const int k = t - base, nrows = P.rtab_n[scale] + 3;
+#if defined(DEDF_PHASE_PROF)
+        unsigned long long pacc[16];
+        GeoPre geo{};
+        edge_tile<L, F0, HP, H1, H2, false, 2>(P, wv, scale, 32 * k, min(32, nrows - 32 * k), geo, -1, pacc);
+#else
+        GeoPre geo{};
+        edge_tile<L, F0, HP, H1, H2, false, 2>(P, wv, scale, 32 * k, min(32, nrows - 32 * k), geo, -1);
+#endif
+    }
 }
 template <int L, bool EBM, bool HP = false, bool UN = false> __global__ __launch_bounds__(64, 1) void k_node(NodeParams P) {
     const Wave wv = make_wave(P.W, P.W_bytes);
@@ -66,5 +103,7 @@ template <int L, bool EBM, bool HP = false, bool UN = false> __global__ __launch
     X(6, void k_node<1, true, false>(NodeParams))                     \
     X(10, void k_edge<2, 64, false, 32, 32, true>(EdgeParams))        \
     X(10, void k_node<2, false, false, true>(NodeParams))             \
-    X(11, void k_edge<2, 64, false, 32, 32>(EdgeParams))
-constexpr int kKernelUnits = 12;
+    X(11, void k_edge<2, 64, false, 32, 32>(EdgeParams))              \
+    X(12, void k_edge<2, 128, false, 128, 64, false, 1>(EdgeParams))  \
+    X(11, void k_radial_table<2, 128>(EdgeParams))
+constexpr int kKernelUnits = 13;

@@ -66,4 +66,9 @@
 #else
 #define DEDF_INST_11(...) DEDF_NOP(__VA_ARGS__)
 #endif
+#if DEDF_KUNIT == 12
+#define DEDF_INST_12(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_12(...) DEDF_NOP(__VA_ARGS__)
+#endif
 DEDF_KERNEL_LIST(DEDF_INST)

@@ -13,6 +13,10 @@ namespace dedf {
 
 constexpr int kHeads = 4;
 constexpr int kFc0 = 128, kFc1 = 128, kFc2 = 64;     // fc_neurons of every shipped config (resolved)
+// radial table of the sampler (dedf_edge.h: EdgeParams::rtab): grid intervals of a finite scale over [0, r) and of the all-pairs scale over
+// [0, kRtabInfiniteSpan * length_enc_max_r) (longer edges fall back to the per-edge evaluation)
+constexpr int kRtabFinite = 2048, kRtabInfinite = 32768;
+constexpr double kRtabInfiniteSpan = 1.5;
 constexpr int kLenEmb = 64, kTimeEmb = 64, kTimeEnc = 256, kTimeHid = 128;
 constexpr int kMaxScales = 8;
 

@@ -97,6 +97,8 @@ class ScoreModelHead(torch.nn.Module):
             _lib.raise_for(lib, None, rc, "dedf_create failed (see stderr)")
         self._handle, self._handle_device = h, device
         self._scene_key = self._query_key = None
+        if getattr(self, "_radial_table", None) is not None:
+            lib.dedf_set_radial_table(h, int(self._radial_table))
 
     def _release(self):
         if self._handle is not None:
@@ -116,6 +118,14 @@ class ScoreModelHead(torch.nn.Module):
         self.cfg.half_gemm = False
         self._release()
         return super().float()
+
+    def set_radial_table(self, on: bool):
+        """the sampler's radial table (``dedf_set_radial_table``, on by default): when every pose of a step shares the diffusion time, the
+        front of the radial network is tabulated once per step on a fine length grid and interpolated per edge; ``False`` evaluates it per
+        edge everywhere (what ``forward`` always does: it takes one time per pose)"""
+        self._radial_table = bool(on)
+        if self._handle is not None:
+            _lib.load().dedf_set_radial_table(self._handle, int(self._radial_table))
 
     def refresh_weights(self):
         """call after load_state_dict(): the packed device image is rebuilt on next use"""

@@ -149,6 +149,16 @@ int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedul
 int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const float* f_src, int n_dst, const float* x_dst, const float* f_dst,
                        int64_t n_edges, const int64_t* edge_src, const int64_t* edge_dst, float* out, void* stream);
 
+/* The sampler's radial table.  When every pose of a launch shares the diffusion time (dedf_sample; dedf_score never does: it takes one time per
+ * pose), everything in front of layer 3 of the radial network -- length encoding, edge pre-linear with the time embedding, RadialProfile layers
+ * 1 and 2 with their LayerNorm + SiLU (multiscale_tensor_field.py:225-234, equiformer/radial_func.py:11-60) -- depends on (scale, edge length)
+ * only.  By default dedf_sample evaluates it once per step on a fine length grid per scale (2 048 intervals over [0, r) for a finite scale,
+ * 32 768 over [0, 1.5 length_enc_max_r) for the all-pairs scale; longer edges are evaluated per edge) with the edge kernel's own code, and the
+ * edge kernel interpolates the 64 activations per edge (4-point Lagrange; measured deviation from the per-edge evaluation: see DESIGN.md section 5).
+ * on = 0 restores the per-edge evaluation everywhere (also: environment DEDF_RADIAL_TABLE=0).  Instantiated for lmax 2, time_emb_mlp
+ * {256,128,64}, fc_neurons {128,128,64}, full precision; every other shape evaluates per edge. */
+int dedf_set_radial_table(dedf_handle* h, int on);
+
 /* Chains of layers (a whole UNet is 17 of them): with on = 1, dedf_layer_forward returns WITHOUT synchronising; the verdict of its edge-list
  * check accumulates on the device and is returned -- and cleared -- by dedf_layer_check, which synchronises `stream`: DEDF_OK or
  * DEDF_ERR_INVALID.  Bad edges are replaced by (0, 0) inside the call, so a deferred verdict never means an out-of-range access. */

@@ -9,14 +9,20 @@ dev = torch.device('cuda:0')
 kw, cfg, P, keys, query, Ts = bench.build_inputs(2, 4096, 1024, 1000, 0, dev)
 head = ScoreModelHead(**kw); head.load_state_dict(P); head.to(dev)
 t = torch.full((1000,), 0.5, device=dev)
-for _ in range(3): head(Ts.float(), keys, query, t)
+if os.environ.get("SAMPLE"):          # the sampler's path (shared time: radial table) instead of the score forward
+    from diffusion_edf_amd.score_model_base import ScoreModelBase
+    _m = ScoreModelBase(head)
+    run = lambda: _m.sample(Ts, keys, query, [[0.5, 0.5]], [1], [1e-9], temperatures=0.0)
+else:
+    run = lambda: head(Ts.float(), keys, query, t)
+for _ in range(3): run()
 torch.cuda.synchronize()
 # zero prof
 import ctypes as C
 from diffusion_edf_amd import _lib
 buf = head.debug_buffer('phase_prof')   # float32 view of u64 data
 raw0 = buf.numpy().view(np.uint64).reshape(-1, 16).copy()
-head(Ts.float(), keys, query, t); torch.cuda.synchronize()
+run(); torch.cuda.synchronize()
 raw1 = head.debug_buffer('phase_prof').numpy().view(np.uint64).reshape(-1, 16)
 d = (raw1 - raw0).astype(np.float64)
 names = ["geom+enc", "prelin+silu", "L1 mfma", "L1 LN+silu", "L2 mfma", "L2 LN+silu", "accinit", "E prologue(wt0)", "E l3=0 chunks", "E l3=1 chunks", "F l3=0 chunks", "stores+end", "E l3=2 chunks", "F l3=1 chunks", "F l3=2 chunks", "-"]

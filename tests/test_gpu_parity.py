@@ -116,6 +116,7 @@ def test_sampler_langevin_update_is_float64_exact_given_scores():
     head = ScoreModelHead(**kw)
     head.load_state_dict(P)
     head.to(dev)
+    head.set_radial_table(False)          # same arithmetic in `forward` and in the sampler: this test is about the update, not the score
     gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
     gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
     t = 0.7
@@ -124,6 +125,46 @@ def test_sampler_langevin_update_is_float64_exact_given_scores():
     z = torch.zeros(len(Ts), 3, dtype=torch.float64)
     ref = R.langevin_step(ocfg, Ts, ang.cpu(), lin.cpu(), float(torch.tensor(t, dtype=torch.float32)), 0.04, 0.0, 0.5, 0.5, z, z)
     assert float((out[1] - ref).abs().max()) < 1e-12
+
+
+def test_radial_table_of_the_sampler_against_the_per_edge_evaluation():
+    """dedf_sample tabulates the front of the radial network per step (shared time) and interpolates it per edge; the same step with the table
+    switched off evaluates it per edge.  One noise-free step from the same poses: the displacement is alpha/2 * score, so the relative
+    difference of the displacements IS the relative difference of the scores.  The per-edge evaluation is itself an fp32 evaluation of
+    high-frequency length features (sin(10 len) at len ~ 50: argument rounding alone is ~3e-5 rad) and sits 3e-6 ... 2e-5 from the fp64
+    oracle; the table path must (a) stay within 1e-5 of it and (b) be no further from the ORACLE than the per-edge path plus 5e-6, far inside
+    the stated 1e-4.  Covered: trained-looking random length-encoder parameters, the coarse and the fine diffusion time, finite scales, the
+    all-pairs scale, and poses so far out that all-pairs tiles leave the table and fall back to the per-edge front."""
+    dev = torch.device('cuda:0')
+    for radii, far, nT, with_oracle in (((5., 10., 20., None), False, 12, True), ((3.5, 5., 6.5, 8.), False, 48, False), ((5., 10., 20., None), True, 48, False)):
+        kw, cfg, P, keys, query, Ts, time = SC.build_case(2, nT, 1024 if with_oracle else 2048, 128 if with_oracle else 256, radii=radii)
+        if far:
+            Ts = Ts.clone(); Ts[::3, 4:] += torch.tensor([120.0, 60.0, 40.0], dtype=Ts.dtype)      # beyond 1.5 * length_enc_max_r from the scene
+        head = ScoreModelHead(**kw)
+        head.load_state_dict(P)
+        head.to(dev)
+        gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
+        gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
+        for t in (0.9, 0.05):
+            outs = []
+            for on in (True, False):
+                head.set_radial_table(on)
+                outs.append(ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[t, t]], [1], [0.04], temperatures=0.0).cpu())
+            d_on, d_off = (outs[0][1] - outs[0][0])[:, 4:], (outs[1][1] - outs[1][0])[:, 4:]
+            scale = float(d_off.abs().max())
+            assert scale > 1e-3
+            dev_on_off = float((d_on - d_off).abs().max()) / scale
+            assert dev_on_off < 1e-5, (radii, far, t, dev_on_off)
+            assert dev_on_off > 0.0                                      # (the table path really ran)
+            if with_oracle:
+                ocfg = R.config_from_kwargs(kw)
+                k64 = [R.FeaturedPoints(k.x.double(), k.f.double(), k.b, None) for k in keys]
+                q64 = R.FeaturedPoints(query.x.double(), query.f.double(), query.b, query.w.double())
+                ang, lin = R.score_head_forward(ocfg, R.cast_params(P, torch.float64), Ts, k64, q64, torch.full((len(Ts),), t, dtype=torch.float64))
+                z = torch.zeros(len(Ts), 3, dtype=torch.float64)
+                d_ref = (R.langevin_step(ocfg, Ts, ang, lin, t, 0.04, 0.0, 0.5, 0.5, z, z) - Ts)[:, 4:]
+                e_on, e_off = float((d_on - d_ref).abs().max()) / scale, float((d_off - d_ref).abs().max()) / scale
+                assert e_on < 1e-4 and e_on < e_off + 5e-6, (t, e_on, e_off)
 
 
 def test_philox_noise_is_shard_invariant_and_seed_dependent():
