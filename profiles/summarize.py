@@ -45,8 +45,13 @@ def main(tag):
         for name, cname, n, avg, tot in con.execute(q):
             pmc.setdefault(name, {})[cname] = {"launches": n, "avg": avg, "sum": tot}
     summary = {"tag": tag, "per_kernel": pmc}
+    # the kernel of bench.py's TIMED region: the sampler's table-reading instantiation (`..., false, 1>`) when it ran, else the per-edge one
+    # (which also serves the untimed score-forward figure of the same command)
+    edge_names = [n for n in pmc if n.startswith("void k_edge")]
+    timed = [n for n in edge_names if n.rstrip().split("(")[0].endswith(", 1>")] or edge_names
+    summary["edge_kernel_name"] = timed[-1] if timed else None
     for name, c in pmc.items():
-        if name.startswith("void k_edge"):
+        if timed and name == timed[-1]:
             f = c.get("FETCH_SIZE", {}).get("avg")
             w = c.get("WRITE_SIZE", {}).get("avg")
             if f is not None and w is not None:
