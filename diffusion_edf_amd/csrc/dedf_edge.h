@@ -348,6 +348,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     float tw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     bool tab = false;          // wave-uniform: this tile takes the radial network's front from the table
     if constexpr (MODE == 1) {
+        DEDF_STAMP(0);
         const float pos = len * P.rtab_inv_step[scale];
         tab = __all(!valid || pos < (float)P.rtab_n[scale]) != 0;
         if (tab) {
@@ -363,6 +364,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             static_for<4>([&]<int K>() { static_for<8>([&]<int Q>() { trow[K][Q] = bld4(rtb, rv, K * 256 + Q * 16); }); });
             tw[0] = w0; tw[1] = w1; tw[2] = w2; tw[3] = w3;
         } else front_requests();
+        DEDF_STAMP(1);
     }
     if (!tab) {
         // ---- length embedding: this lane's 32 of the 64 channels (k = s + 32*hi) ------------------------------------------

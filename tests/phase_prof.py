@@ -31,4 +31,5 @@ E = head.stats()['n_edges_total']; tiles = sum((e + 31)//32 for e in head.stats(
 print("edges", E, "tiles", tiles, "tiles/wave", tiles / d.shape[0])
 for i, n in enumerate(names):
     print(f"{n:18s} {d[:, i].mean() / (tiles / d.shape[0]):10.0f} cycles/tile  {100 * d[:, i].mean() / tot:5.1f}%")
+# (SAMPLE=1, table-reading kernel: slots 0 / 1 = tile start -> geometry done -> table rows requested; 2-4 unused; 5 = combine; 6 = up to the fused stage)
 print("total cycles/tile", tot / (tiles / d.shape[0]))
