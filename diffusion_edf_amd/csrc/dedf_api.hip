@@ -377,8 +377,9 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         // Sampler (every pose shares the step's time): the front of the radial network is a function of (scale, length) only -- tabulate
         // it once per launch on a fine length grid with the tile's own code and interpolate per edge (dedf_edge.h: EdgeParams::rtab)
         bool use_tab = false;
-        if constexpr (F0 == 128 && L == 2 && !EBM) {
-            use_tab = h->radial_table && !hp && h->cfg.fc_neurons[1] == kFc1 && P.tb_pose_stride == 0 && !h->debug;
+        if constexpr ((F0 == 128 || F0 == 192) && L == 2 && !EBM) {
+            const bool narrow = h->cfg.fc_neurons[1] == 32;
+            use_tab = h->radial_table && !hp && P.tb_pose_stride == 0 && !h->debug && !(narrow && F0 == 192);
             if (use_tab) {
                 int row = 0;
                 for (int n = 0; n < ns; ++n) {
@@ -394,8 +395,17 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
                 P.rtab = h->d_rtab.as<float>(); P.rtab_out = h->d_rtab.as<float>(); P.rtab_bytes = (uint32_t)bytes;
                 int ntab = 0;
                 for (int n = 0; n < ns; ++n) ntab += (P.rtab_n[n] + 3 + 31) / 32;
-                hipLaunchKernelGGL((k_radial_table<2, 128>), dim3(std::min(ntab, h->n_cu * 4)), blk, 0, st, P);
-                hipLaunchKernelGGL((k_edge<2, 128, false, 128, 64, false, 1>), grid, blk, 0, st, P);
+                const dim3 tgrid(std::min(ntab, h->n_cu * 4));
+                if constexpr (F0 == 192) {
+                    hipLaunchKernelGGL((k_radial_table<2, 192>), tgrid, blk, 0, st, P);
+                    hipLaunchKernelGGL((k_edge<2, 192, false, 128, 64, false, 1>), grid, blk, 0, st, P);
+                } else if (narrow) {
+                    hipLaunchKernelGGL((k_radial_table<2, 128, false, 32, 32>), tgrid, blk, 0, st, P);
+                    hipLaunchKernelGGL((k_edge<2, 128, false, 32, 32, false, 1>), grid, blk, 0, st, P);
+                } else {
+                    hipLaunchKernelGGL((k_radial_table<2, 128>), tgrid, blk, 0, st, P);
+                    hipLaunchKernelGGL((k_edge<2, 128, false, 128, 64, false, 1>), grid, blk, 0, st, P);
+                }
             }
         }
         if (use_tab) {

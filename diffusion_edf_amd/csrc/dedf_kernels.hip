@@ -71,4 +71,14 @@
 #else
 #define DEDF_INST_12(...) DEDF_NOP(__VA_ARGS__)
 #endif
+#if DEDF_KUNIT == 13
+#define DEDF_INST_13(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_13(...) DEDF_NOP(__VA_ARGS__)
+#endif
+#if DEDF_KUNIT == 14
+#define DEDF_INST_14(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_14(...) DEDF_NOP(__VA_ARGS__)
+#endif
 DEDF_KERNEL_LIST(DEDF_INST)

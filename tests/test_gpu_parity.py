@@ -167,6 +167,37 @@ def test_radial_table_of_the_sampler_against_the_per_edge_evaluation():
                 assert e_on < 1e-4 and e_on < e_off + 5e-6, (t, e_on, e_off)
 
 
+@pytest.mark.parametrize("shape", ["time_emb_128", "narrow_radial_mlp"])
+def test_radial_table_other_score_head_shapes(shape):
+    """the table path of the two other lmax-2 score-head shapes the reference ships: pre-linear 192 wide (time_emb_mlp [512,256,128], sapien
+    pick_highres) and the radial MLP [128,32,32] (sapien place_*)"""
+    dev = torch.device('cuda:0')
+    kw = synthetic.score_head_kwargs(2, radii=(4., 8., None))
+    if shape == "time_emb_128":
+        kw['time_emb_mlp'] = [512, 256, 128]
+    else:
+        kw['key_tensor_field_kwargs']['fc_neurons'] = [-1, 32, 32]
+    cfg = params.HeadConfig.from_kwargs(kw)
+    P = params.init_params(cfg, seed=4, randomize_all=True)
+    keys = synthetic.make_key_clouds(cfg, 1024, seed=1)
+    query = synthetic.make_query(cfg, 128, seed=1)
+    Ts = synthetic.make_poses(24, seed=2, near_object=True)
+    head = ScoreModelHead(**kw)
+    head.load_state_dict(P)
+    head.to(dev)
+    gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
+    gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
+    for t in (0.8, 0.03):
+        outs = []
+        for on in (True, False):
+            head.set_radial_table(on)
+            outs.append(ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[t, t]], [1], [0.04], temperatures=0.0).cpu())
+        d_on, d_off = (outs[0][1] - outs[0][0])[:, 4:], (outs[1][1] - outs[1][0])[:, 4:]
+        scale = float(d_off.abs().max())
+        dev_on_off = float((d_on - d_off).abs().max()) / scale
+        assert scale > 1e-3 and 0.0 < dev_on_off < 1e-5, (shape, t, dev_on_off)
+
+
 def test_philox_noise_is_shard_invariant_and_seed_dependent():
     """poses sharded as [0:5] + [5:8] with first_pose_index draw the same noise as the unsharded run"""
     kw, cfg, P, keys, query, Ts, time = SC.build_case(1, 8, 256, 40)
