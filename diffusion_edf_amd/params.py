@@ -296,7 +296,7 @@ def n_params(cfg: HeadConfig) -> int:
 
 
 # --------------------------------------------------------------------------------------------------
-# one layer of the UNet feature extractor (first slice)
+# one layer of the UNet feature extractor (the whole extractor: unet.py)
 # --------------------------------------------------------------------------------------------------
 
 def unet_layer_param_spec(irreps: Irreps, fc_neurons: List[int], num_heads: int = 4, lmax_sh: int = 2,

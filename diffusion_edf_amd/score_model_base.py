@@ -47,8 +47,7 @@ def build_schedule(ang_mult: float, lin_mult: float, diffusion_schedules, N_step
 
 
 class ScoreModelBase(torch.nn.Module):
-    """Holds a ``score_head``; subclasses / callers provide key and query feature extractors (out of scope here,
-    SURVEY §8(f) row 1)."""
+    """Holds a ``score_head``; the subclasses in ``agent.py`` add the key and query feature extractors (``unet.py``, ``keypoint_extractor.py``)."""
 
     def __init__(self, score_head: Optional[ScoreModelHead] = None):
         super().__init__()
