@@ -1019,8 +1019,12 @@ int dedf_fps(const float* x, int n, int n_samples, int start, int* idx_out, void
     if (n > 64 * kFpsBlock) return DEDF_ERR_UNSUPPORTED;          // one workgroup keeps the cloud in registers: <= 65 536 points
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (n_samples == 0) return DEDF_OK;
-    if (n <= 4 * kFpsBlock) hipLaunchKernelGGL(k_fps<4>, dim3(1), dim3(kFpsBlock), 0, st, x, n, n_samples, start, idx_out);
-    else if (n <= 16 * kFpsBlock) hipLaunchKernelGGL(k_fps<16>, dim3(1), dim3(kFpsBlock), 0, st, x, n, n_samples, start, idx_out);
+    // workgroup size by cloud size (measured, tests/probe/fps_time.py): a sample costs a fixed part that grows with the number of waves
+    // (0.43 / 0.79 / 1.95 us for 4 / 8 / 16 waves: butterfly, exchange and barriers are issued once per wave) plus 0.04 us per point held
+    // by a thread (0.075 us with 16 waves: four waves share a SIMD)
+    if (n <= 16 * 256) hipLaunchKernelGGL((k_fps<16, true, 256>), dim3(1), dim3(256), 0, st, x, n, n_samples, start, idx_out);
+    else if (n <= 16 * 512) hipLaunchKernelGGL((k_fps<16, true, 512>), dim3(1), dim3(512), 0, st, x, n, n_samples, start, idx_out);
+    else if (n <= 32 * 512) hipLaunchKernelGGL((k_fps<32, true, 512>), dim3(1), dim3(512), 0, st, x, n, n_samples, start, idx_out);
     else hipLaunchKernelGGL((k_fps<64, false>), dim3(1), dim3(kFpsBlock), 0, st, x, n, n_samples, start, idx_out);
     return hipGetLastError() == hipSuccess ? DEDF_OK : DEDF_ERR_RUNTIME;
 }

@@ -20,10 +20,11 @@ __device__ __forceinline__ float dist2_rn(float ax, float ay, float az, float bx
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
-// Farthest point sampling of ONE cloud by one workgroup: every thread keeps PPT points and their running minimum distance in
-// registers; per sample: update, per-thread arg-max, wave butterfly, one LDS exchange between the 16 waves.
-// The sample loop is a serial chain of n_samples steps on ONE CU, and a step is bound by the VALU instructions the 16 waves issue
-// (4 cycles per wave64 instruction per SIMD), so the step is written for instruction count:
+// Farthest point sampling of ONE cloud by one workgroup of BLOCK threads: every thread keeps PPT points and their running minimum distance
+// in registers; per sample: update, per-thread arg-max, wave butterfly, one LDS exchange between the waves.
+// The sample loop is a serial chain of n_samples steps on ONE CU.  A step costs a fixed part that every wave issues (butterfly, exchange,
+// barriers: 0.43 / 0.79 / 1.95 us with 4 / 8 / 16 waves) plus the per-point update (0.04 us per point of a thread while at most two waves
+// share a SIMD), so dedf_fps picks 256 threads up to 4 096 points and 512 up to 16 384; the step itself is written for instruction count:
 //   * two points per instruction with the packed fp32 ops (v_pk_add/mul_f32): 8 packed operations per PAIR for the distance, rounded
 //     exactly like the oracle (fp contraction off: no FMA);
 //   * the arg-max travels as ONE 64-bit key (distance bits << 32 | 0x7fffffff - index; distances are >= 0, so the unsigned order of
@@ -31,31 +32,51 @@ __device__ __forceinline__ float dist2_rn(float ax, float ay, float az, float bx
 //   * the winner's coordinates come back through LDS from the thread that owns the point (no dependent global load), and the
 //     selected indices are collected in LDS and written out once per 1024 samples (a barrier waits for outstanding global stores).
 // idx_out[i] = i-th selected point (selection order, first = `start`).
-// KEEP = false (clouds above 16 k points): only the minimum distances stay in registers, the coordinates are re-read (coalesced, from
-// L2) every sample — 64 points per thread would not fit the 128 VGPRs a thread of a 1024-thread workgroup has.
+// KEEP = false (clouds above 16 k points, 1 024 threads): only the minimum distances stay in registers, the coordinates are re-read
+// (coalesced, from L2) every sample — 64 points per thread would not fit the 128 VGPRs a thread of a 1024-thread workgroup has.
 typedef float fps_f2 __attribute__((ext_vector_type(2)));
 
-template <int PPT, bool KEEP = true>
-__global__ __launch_bounds__(kFpsBlock) void k_fps(const float* __restrict__ x, int n, int n_samples, int start, int* __restrict__ idx_out) {
+// max of a 64-bit key over the wave on the DPP path (no LDS crossbar): xor 1, xor 2, half-mirror and mirror inside every row of 16 lanes,
+// then the row results are passed on with row_bcast:15 / row_bcast:31; lane 63 ends up with the maximum, which is broadcast as a scalar.
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long key) {
+    auto step = [&]<int CTRL, int ROW_MASK>() {
+        const int lo = (int)(unsigned)key, hi = (int)(unsigned)(key >> 32);
+        const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+        const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+        const unsigned long long ok = ((unsigned long long)ohi << 32) | olo;
+        key = ok > key ? ok : key;
+    };
+    step.template operator()<0xB1, 0xf>();      // quad_perm [1,0,3,2]
+    step.template operator()<0x4E, 0xf>();      // quad_perm [2,3,0,1]
+    step.template operator()<0x141, 0xf>();     // row_half_mirror
+    step.template operator()<0x140, 0xf>();     // row_mirror
+    step.template operator()<0x142, 0xa>();     // row_bcast:15 -> rows 1, 3
+    step.template operator()<0x143, 0xc>();     // row_bcast:31 -> rows 2, 3
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int PPT, bool KEEP = true, int BLOCK = kFpsBlock>
+__global__ __launch_bounds__(BLOCK) void k_fps(const float* __restrict__ x, int n, int n_samples, int start, int* __restrict__ idx_out) {
 #pragma clang fp contract(off)
     static_assert(PPT % 2 == 0, "points are processed in pairs");
-    constexpr int NW = kFpsBlock / 64, NP = PPT / 2;
+    constexpr int NW = BLOCK / 64, NP = PPT / 2;
     __shared__ unsigned long long s_key[2][NW];
     __shared__ float s_xyz[2][4];
-    __shared__ int s_out[kFpsBlock];                            // selected indices, flushed every kFpsBlock samples
+    __shared__ int s_out[BLOCK];                            // selected indices, flushed every BLOCK samples
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     fps_f2 px[KEEP ? NP : 1], py[KEEP ? NP : 1], pz[KEEP ? NP : 1], md[NP];
     auto ld = [&](int i, int k) { return x[3 * min(i, n - 1) + k]; };            // padding slots read the last point; their md is pinned at -1
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        const int i0 = tid + (2 * j) * kFpsBlock, i1 = i0 + kFpsBlock;
+        const int i0 = tid + (2 * j) * BLOCK, i1 = i0 + BLOCK;
         if constexpr (KEEP) { px[j] = fps_f2{ld(i0, 0), ld(i1, 0)}; py[j] = fps_f2{ld(i0, 1), ld(i1, 1)}; pz[j] = fps_f2{ld(i0, 2), ld(i1, 2)}; }
         md[j] = fps_f2{i0 < n ? INFINITY : -1.0f, i1 < n ? INFINITY : -1.0f};       // -1: below every real distance, stays -1 under min
     }
     int cur = start;
     float cx = x[3 * cur], cy = x[3 * cur + 1], cz = x[3 * cur + 2];
     for (int s = 0; s < n_samples; ++s) {
-        if (tid == 0) s_out[s & (kFpsBlock - 1)] = cur;         // (a global store here would be waited for at every barrier)
+        if (tid == 0) s_out[s & (BLOCK - 1)] = cur;         // (a global store here would be waited for at every barrier)
         const fps_f2 c_x = fps_f2{cx, cx}, c_y = fps_f2{cy, cy}, c_z = fps_f2{cz, cz};
         int tid_s = tid;
         if constexpr (!KEEP) asm volatile("" : "+v"(tid_s));    // addresses are formed per sample: 64 loop-invariant offsets would not fit the registers
@@ -66,7 +87,7 @@ __global__ __launch_bounds__(kFpsBlock) void k_fps(const float* __restrict__ x, 
             fps_f2 qx, qy, qz;
             if constexpr (KEEP) { qx = px[j]; qy = py[j]; qz = pz[j]; }
             else {
-                const int i0 = tid_s + (2 * j) * kFpsBlock, i1 = i0 + kFpsBlock;
+                const int i0 = tid_s + (2 * j) * BLOCK, i1 = i0 + BLOCK;
                 qx = fps_f2{ld(i0, 0), ld(i1, 0)}; qy = fps_f2{ld(i0, 1), ld(i1, 1)}; qz = fps_f2{ld(i0, 2), ld(i1, 2)};
             }
             const fps_f2 dx = qx - c_x, dy = qy - c_y, dz = qz - c_z;
@@ -78,18 +99,14 @@ __global__ __launch_bounds__(kFpsBlock) void k_fps(const float* __restrict__ x, 
             if (m.y > best) { best = m.y; bj = 2 * j + 1; }
             if constexpr (!KEEP) __builtin_amdgcn_sched_barrier(0);     // keep the re-loads of later pairs from piling up in registers
         }
-        const int bi = tid + bj * kFpsBlock;
+        const int bi = tid + bj * BLOCK;
         unsigned long long key = bj < 0 ? 0ull : ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(0x7fffffff - bi);
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const unsigned long long ok = __shfl_xor(key, o);
-            key = ok > key ? ok : key;
-        }
+        key = wave_max_u64(key);                                                      // wave-uniform
         const int buf = s & 1;
         if (lane == 0) s_key[buf][wave] = key;
         __syncthreads();
-        if ((s & (kFpsBlock - 1)) == kFpsBlock - 1 || s == n_samples - 1) {
-            const int base = s & ~(kFpsBlock - 1);
+        if ((s & (BLOCK - 1)) == BLOCK - 1 || s == n_samples - 1) {
+            const int base = s & ~(BLOCK - 1);
             if (base + tid <= s) idx_out[base + tid] = s_out[tid];
         }
         key = s_key[buf][0];
@@ -100,8 +117,8 @@ __global__ __launch_bounds__(kFpsBlock) void k_fps(const float* __restrict__ x, 
         }
         cur = 0x7fffffff - (int)(unsigned)(key & 0xffffffffull);
         if constexpr (KEEP) {
-            if (tid == (cur & (kFpsBlock - 1))) {                                      // the owner publishes the coordinates
-                const int slot = cur / kFpsBlock;
+            if (tid == (cur & (BLOCK - 1))) {                                      // the owner publishes the coordinates
+                const int slot = cur / BLOCK;
                 float ox = 0.0f, oy = 0.0f, oz = 0.0f;
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
