@@ -16,6 +16,9 @@
  *   dedf_set_query       the `query_pcd` argument                 score_head.py:144,151-157
  *   dedf_score           ScoreModelHead.forward                   score_head.py:142-211
  *   dedf_sample          ScoreModelBase.sample (inner loop)       score_model_base.py:110-204
+ *   dedf_set_radial_table   switch of dedf_sample's per-step radial table (no reference counterpart; see its declaration)
+ *   dedf_linear_rs       LinearRS / ProjectIfMismatch per node     equiformer/tensor_product_rescale.py:176-185, skip.py:13-34
+ *   dedf_fps, dedf_radius   torch_cluster fps / radius / radius_graph as connectivity.py:22,43,62 calls them
  *   dedf_energy          EbmScoreModelHead.compute_energy         score_head_ebm.py:122-174
  *   dedf_layer_forward   one {radial, gnn} layer of UnetFeatureExtractor      unet_feature_extractor.py:141-202, 289-324; block.py:141-174
  *   dedf_field           MultiscaleTensorField.forward at given points          multiscale_tensor_field.py:192-260 (KeypointExtractor's two fields,
