@@ -253,6 +253,9 @@ DEDF_DEV void edge_enc_to_lds(const EdgeParams& P, const Wave& wv, int scale) {
 // UN: the edge pipeline of a UNet layer (block.EquiformerBlock + GraphAttentionMLP, block.py:141-174, graph_attention.py:84-122):
 //     message = linear_src(f_src)[src] + linear_dst(f_dst)[dst], the radial MLP reads the radial basis directly (no pre-linear, no
 //     time), GaussianRadialBasisLayerFiniteCutoff instead of GaussianRadialBasis, SH without the non-scalar cut-off, no edge logit
+#ifndef DEDF_RTAB_COALESCED
+#define DEDF_RTAB_COALESCED 0      // measured: 2.45-2.47 ms against 2.47-2.51 ms for the per-lane requests: within noise, kept for reference
+#endif
 // Geometry of the NEXT tile, carried across the persistent tile loop by the table-reading kernel (MODE 1): with the radial network's front
 // gone, a tile would otherwise start with three dependent round trips to memory (edge indices -> coordinates -> table rows) and nothing to
 // put under them.  The indices are requested at the top of the previous tile, the coordinates in its middle.
@@ -343,6 +346,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         static_assert(L <= 2, "l = 3 spherical harmonics are a next-row item");
     }
 
+    constexpr int NPS = park_slots<L>(), SPW = 2 * NPS, NSLOT = SPW + 2;      // SPW: segment softmax weights / normalisers
+    __shared__ f32x4 park[NSLOT * 64];         // (declared here: the table path stages its rows in it before the parking starts)
     f32x16 r2[NT2];
     f32x4 trow[MODE == 1 ? 4 : 1][8];      // MODE 1: this lane's halves of the four table rows around its length
     float tw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -360,9 +365,34 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             const float w0 = -(1.0f / 6) * u * um * u2, w1 = 0.5f * up * um * u2, w2 = -0.5f * up * u * u2, w3 = (1.0f / 6) * up * u * um;
             const Buf rtb = make_buf(P.rtab, P.rtab_bytes);
             const int rv = ((P.rtab_row0[scale] + i0) * 2 + hi) * 128;
+#if DEDF_RTAB_COALESCED
+            // Coalesced form: an edge's four rows are 1 KB of consecutive memory, but in the operand layout a lane owns 128 bytes of each row
+            // of ITS edge -- 32 requests per lane in which all 64 lanes touch different lines (2 048 sixteen-byte lane requests per tile,
+            // bound by the address path).  Instead 16 consecutive lanes fetch one row of one edge (256 contiguous bytes), four edges per
+            // request, the wave's private LDS turns the rows round to the per-edge ownership, and the combine reads them back.
+            (void)rv;
+            const int rowoff = (P.rtab_row0[scale] + i0) * 256;
+            int eoff[8];
+            static_for<8>([&]<int T>() { eoff[T] = __shfl(rowoff, 4 * T + (wv.lane >> 4), 64) + (wv.lane & 15) * 16; });
+            f32x4* const stg_w = park + (wv.lane >> 4) * 17 + (wv.lane & 15);        // [edge][17]: one pad slot per edge against bank conflicts
+            const f32x4* const stg_r = park + wv.col * 17 + hi * 8;
+            static_for<4>([&]<int K>() { static_for<8>([&]<int T>() { trow[K][T] = bld4(rtb, eoff[T], K * 256); }); });      // all 32 requests first
+            const float twv[4] = {w0, w1, w2, w3};
+            static_for<4>([&]<int K>() {
+                static_for<8>([&]<int T>() { stg_w[(4 * T) * 17] = trow[K][T]; });
+                static_for<8>([&]<int Q>() {
+                    const f32x4 a = stg_r[Q];
+                    static_for<4>([&]<int J>() {
+                        if constexpr (K == 0) r2[Q / 4][4 * (Q % 4) + J] = twv[0] * a[J];
+                        else r2[Q / 4][4 * (Q % 4) + J] += twv[K] * a[J];
+                    });
+                });
+            });
+#else
             // the four rows are only REQUESTED here; they are combined in the prologue of the fused stage, under its operand requests
             static_for<4>([&]<int K>() { static_for<8>([&]<int Q>() { trow[K][Q] = bld4(rtb, rv, K * 256 + Q * 16); }); });
             tw[0] = w0; tw[1] = w1; tw[2] = w2; tw[3] = w3;
+#endif
         } else front_requests();
         DEDF_STAMP(1);
     }
@@ -463,8 +493,6 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // LDS parking: the gated features wait here as READY-MADE B operands of the value GEMMs: one 16-byte slot per lane holds the
     // fp16 hi halves of a 16-channel chunk (8 accumulator registers), the next slot their fp16 residuals ([slot][lane][8 halves];
     // chunk q = dedf_net.h::park_slot(degree, component, chunk) -> slots 2q | 2q + 1), lane-private
-    constexpr int NPS = park_slots<L>(), SPW = 2 * NPS, NSLOT = SPW + 2;      // SPW: segment softmax weights / normalisers
-    __shared__ f32x4 park[NSLOT * 64];
     f32x4* const pk = park + wv.lane;
     auto park_chunk = [&]<int Q>(const float (&v)[8]) {
         const HL sp = split8(v);
@@ -688,7 +716,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         if (!tab) {
             static_for<NT2>([&]<int To>() { to_vgpr(r2[To]); });
             ln_silu<NT2, UN>(r2, wv, rows, RL::g2, RL::be2, P.ln_inv_n[1], P.ln_pad[1]);
-        } else if constexpr (MODE == 1) {
+        } else if constexpr (MODE == 1 && !DEDF_RTAB_COALESCED) {
             static_for<8>([&]<int Q>() { static_for<4>([&]<int J>() {
                 r2[Q / 4][4 * (Q % 4) + J] = (tw[0] * trow[0][Q][J] + tw[1] * trow[1][Q][J]) + (tw[2] * trow[2][Q][J] + tw[3] * trow[3][Q][J]);
             }); });
