@@ -123,7 +123,7 @@ def cpu_baseline(lmax, n_scene, n_grasp, n_sample_poses=32, t=0.5, budget_s=8.0)
                        + "; ".join(f"{k} thread(s): {v['reps']} x {v['poses']} poses in {v['seconds']} s" for k, v in legs.items()))
 
 
-def radial_table_note(args, flops, e_per_launch, edge_ms, peak):
+def radial_table_note(args, flops, e_per_launch, edge_ms, peak, per_edge=None):
     """`achieved` / `frac` count the ALGORITHMIC FLOP of the reference per edge.  In the sampler every pose of a step shares the
     time, so the front of the radial network is a function of (scale, edge length): the default path evaluates it once per step on a length
     grid and interpolates per edge -- 40 960 of the 193 344 MAC/edge are then not executed per edge.  This object says so and gives the
@@ -133,7 +133,11 @@ def radial_table_note(args, flops, e_per_launch, edge_ms, peak):
         return {"enabled": False}
     ex = 2.0 * e_per_launch * (M_EDGE[args.lmax] - M_EDGE_FRONT[args.lmax])
     ach = ex / (edge_ms * 1e-3) / 1e12 if edge_ms > 0 else 0.0
-    return {"enabled": True, "executed_flop_per_launch": ex, "achieved_on_executed_flop": ach, "frac_on_executed_flop": ach / peak,
+    pe = None
+    if per_edge is not None:      # the per-edge reading of the same K steps (timed like `value`): frac on the same algorithmic FLOP, all of them executed
+        pe = dict(per_edge)
+        pe["frac"] = (flops / (per_edge["k_edge_ms"] * 1e-3) / 1e12) / peak if per_edge["k_edge_ms"] > 0 else 0.0
+    return {"enabled": True, "without_table": pe, "executed_flop_per_launch": ex, "achieved_on_executed_flop": ach, "frac_on_executed_flop": ach / peak,
             "what": "front of the radial network (length encoding, edge pre-linear, RadialProfile layers 1-2) tabulated per step on 2 048 (finite "
                     "scale) / 32 768 (all-pairs scale) length intervals by the edge tile's own code, 4-point Lagrange interpolation per edge; the "
                     "generator's time is inside avg_launch_ms; deviation from the per-edge evaluation <= 4e-6 of the score, both 3e-6..2e-5 from "
@@ -248,6 +252,35 @@ def main():
         el = float(tt.item())
     assert torch.isfinite(final).all()
 
+    # The same K steps from the same poses with the sampler's radial table switched OFF (every edge evaluates the whole radial network), timed
+    # the same way on every rank: reported next to `value` so that both readings of the workload are in the one JSON line.
+    per_edge = None
+    if args.lmax == 2 and not args.half and not args.no_radial_table:
+        head.set_radial_table(False)
+        run(T, 2, first)
+        head.profile_enable(True)
+        head.profile_read()
+        barrier()
+        t1 = time.perf_counter()
+        traj2 = run(T, args.steps, first)
+        if use_dist:
+            ddist.gather_poses(traj2[-1], n_total)
+        barrier()
+        el2 = time.perf_counter() - t1
+        prof2 = head.profile_read()
+        head.profile_enable(False)
+        head.set_radial_table(True)
+        if use_dist:
+            tt = torch.tensor([el2], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el2 = float(tt.item())
+        per_edge = {"value": n_total * args.steps / el2, "ms_per_step": el2 / args.steps * 1e3,
+                    "k_edge_ms": prof2["ms"]["edge"] / max(1, prof2["n_evals"]),
+                    # after ONE step from the same poses with the same noise (later steps diverge: the Langevin map of a random-init
+                    # network is chaotic, any rounding difference grows by orders of magnitude over K steps)
+                    "max_pose_difference_after_1_step": float((traj2[1] - traj[1]).abs().max()),
+                    "pose_displacement_of_that_step": float((traj[1] - traj[0]).abs().max())}
+
     # outside the timed region: the score forward alone on the SEEDED poses at the fixed time t = 0.5 --
     # a figure that does not depend on --steps (the edge count of a trajectory drifts with the number of steps taken)
     fixed = None
@@ -316,7 +349,7 @@ def main():
                          "mix_bound": {"peak": mix_peak_tflops(args.lmax), "frac": achieved / mix_peak_tflops(args.lmax),
                                        "definition": "GEMMs on the split-fp16 MFMA peak in series with the dense-convention Clebsch-Gordan MACs on the 157.3 TFLOP/s fp32 VALU peak"},
                          "avg_launch_ms": edge_ms, "algorithmic_flop_per_launch": flops,
-                         "radial_table": radial_table_note(args, flops, e_per_launch, edge_ms, peak),
+                         "radial_table": radial_table_note(args, flops, e_per_launch, edge_ms, peak, per_edge),
                          "kernel_ms_per_step": {k: v / n_ev for k, v in prof["ms"].items()}},
         }
         if not args.no_cpu_baseline and world == 1:           # the CPU reference leg is timed at N = 1 only
