@@ -74,6 +74,7 @@ class MultiscaleTensorField(torch.nn.Module):
             _register(self, "gnn_block_init.skip_2.skip.tp.weight", torch.randn(64 * 64, generator=g) / 8.0)
             _register(self, "gnn_block_init.skip_2.skip.bias.0", torch.zeros(64))
         self._handle, self._handle_device, self._keys = None, None, None
+        self.register_load_state_dict_post_hook(MultiscaleTensorField._after_load)
 
     # ------------------------------------------------------------------------------------------------------------------
     def _c_state(self) -> Dict[str, torch.Tensor]:
@@ -94,10 +95,8 @@ class MultiscaleTensorField(torch.nn.Module):
             self._handle = None
         self._keys = None
 
-    def load_state_dict(self, *a, **k):
-        r = super().load_state_dict(*a, **k)
+    def _after_load(self, *_):          # also when a parent module loads a checkpoint
         self._release()
-        return r
 
     def __del__(self):
         try:

@@ -69,6 +69,7 @@ class ScoreModelHead(torch.nn.Module):
         self._max_edges = int(max_edges)
         for name, t in init_params(self.cfg, seed=init_seed).items():
             _register(self, name, t)
+        self.register_load_state_dict_post_hook(ScoreModelHead._after_load)
         self._handle = None
         self._handle_device: Optional[torch.device] = None
         self._scene_key = None
@@ -131,10 +132,8 @@ class ScoreModelHead(torch.nn.Module):
         """call after load_state_dict(): the packed device image is rebuilt on next use"""
         self._release()
 
-    def load_state_dict(self, *a, **k):
-        r = super().load_state_dict(*a, **k)
+    def _after_load(self, *_):          # post hook: fires for this module's own load_state_dict AND when a parent module loads a checkpoint
         self.refresh_weights()
-        return r
 
     def __del__(self):
         try:

@@ -64,6 +64,7 @@ class UnetLayer(torch.nn.Module):
         self._handle = None
         self._handle_device: Optional[torch.device] = None
         self._deferred = False
+        self.register_load_state_dict_post_hook(UnetLayer._after_load)
 
     # ------------------------------------------------------------------------------------------------------------------
     def _release(self):
@@ -71,10 +72,10 @@ class UnetLayer(torch.nn.Module):
             _lib.load().dedf_destroy(self._handle)
             self._handle = None
 
-    def load_state_dict(self, *a, **k):
-        r = super().load_state_dict(*a, **k)
-        self._release()                       # the packed device image is rebuilt on next use
-        return r
+    # (the packed device image is rebuilt on next use after ANY load: a post hook also fires when a parent module loads a checkpoint,
+    #  which never calls the children's load_state_dict)
+    def _after_load(self, *_):
+        self._release()
 
     def __del__(self):
         try:
@@ -193,6 +194,7 @@ class NodeLinear(torch.nn.Module):
             _register(self, prefix + "layernorm.affine_bias", torch.zeros(self.m_in.get(0, 0)))
         self._dev = None
         self._pl_cache = {}
+        self.register_load_state_dict_post_hook(NodeLinear._after_load)
 
     def _pl_in(self, l):      # placement of the input channels of degree l inside the wide block
         m = self.m_in.get(l, 0)
@@ -234,9 +236,8 @@ class NodeLinear(torch.nn.Module):
         self._dev = (dev, t(torch.cat(W)), t(bias), t(lnw), t(lnb), valid)
         return self._dev[1:]
 
-    def load_state_dict(self, *a, **k):
+    def _after_load(self, *_):
         self._dev = None
-        return super().load_state_dict(*a, **k)
 
     def pad_in(self, f: torch.Tensor) -> torch.Tensor:
         out = f.new_zeros(len(f), 240)
