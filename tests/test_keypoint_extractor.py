@@ -121,7 +121,7 @@ def test_dedf_field_matches_the_oracle_and_handles_isolated_points():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_points,bbox", [(5000, True), (2500, False)])
+@pytest.mark.parametrize("n_points,bbox", [(3500, True), (2000, False)])
 def test_keypoint_extractor_matches_the_oracle(n_points, bbox):
     from diffusion_edf_amd.gnn_data import FeaturedPoints
     from diffusion_edf_amd.keypoint_extractor import KeypointExtractor
@@ -170,8 +170,8 @@ def test_whole_place_model_from_clouds_to_scores():
     Ph = params.init_params(hcfg, seed=3, randomize_all=True)
     m.score_head.load_state_dict(Ph)
     m.to(dev).eval()
-    scene = torch.from_numpy(synthetic.make_scene(8000, seed=5).astype(np.float32))
-    grasp = _object_cloud(3000, seed=6)
+    scene = torch.from_numpy(synthetic.make_scene(5000, seed=5).astype(np.float32))
+    grasp = _object_cloud(2500, seed=6)
     grasp[:, 2] -= 8.0
     g = torch.Generator().manual_seed(0)
     fs, fg = torch.rand(len(scene), 3, generator=g), torch.rand(len(grasp), 3, generator=g)
@@ -222,13 +222,13 @@ def test_whole_point_attentive_model_from_clouds_to_scores():
     Ph = params.init_params(hcfg, seed=5, randomize_all=True)
     m.score_head.load_state_dict(Ph)
     m.to(dev).eval()
-    scene = torch.from_numpy(synthetic.make_scene(6000, seed=8).astype(np.float32))
+    scene = torch.from_numpy(synthetic.make_scene(4000, seed=8).astype(np.float32))
     g = torch.Generator().manual_seed(0)
     fs = torch.rand(len(scene), 3, generator=g)
     pcd = FeaturedPoints(x=scene.to(dev), f=fs.to(dev), b=torch.zeros(len(scene), dtype=torch.long, device=dev), w=None)
     key = m.get_key_pcd_multiscale(pcd)
     query = m.get_query_pcd(pcd)
-    assert len(key) == 1 and len(key[0].x) == 300 and key[0].w is not None and len(query.x) == 2
+    assert len(key) == 1 and len(key[0].x) == 200 and key[0].w is not None and len(query.x) == 2
     Pk = R.cast_params({k: v.cpu() for k, v in m.key_model.state_dict().items()}, torch.float64)
     xk, fk, wk = U.keypoint_extractor_forward(_oracle_cfg(m.key_model.feature_extractor), _field_cfg(radii), Pk, scene, fs.double(), 0.05, bbox=None)
     assert torch.equal(key[0].x.cpu(), xk) and float((key[0].w.cpu().double() - wk).abs().max()) < 2e-4
