@@ -349,7 +349,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     constexpr int NPS = park_slots<L>(), SPW = 2 * NPS, NSLOT = SPW + 2;      // SPW: segment softmax weights / normalisers
     __shared__ f32x4 park[NSLOT * 64];         // (declared here: the table path stages its rows in it before the parking starts)
     f32x16 r2[NT2];
-    f32x4 trow[MODE == 1 ? 4 : 1][8];      // MODE 1: this lane's halves of the four table rows around its length
+    f32x4 trow[MODE == 1 ? 4 : 1][8];      // MODE 1: this lane's halves of the four table rows around its length (16 * NT2 floats of the 32 are used:
+                                           // the row stride stays 256 B for the narrow radial MLP too)
     float tw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     bool tab = false;          // wave-uniform: this tile takes the radial network's front from the table
     if constexpr (MODE == 1) {
@@ -380,7 +381,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             const float twv[4] = {w0, w1, w2, w3};
             static_for<4>([&]<int K>() {
                 static_for<8>([&]<int T>() { stg_w[(4 * T) * 17] = trow[K][T]; });
-                static_for<8>([&]<int Q>() {
+                static_for<4 * NT2>([&]<int Q>() {
                     const f32x4 a = stg_r[Q];
                     static_for<4>([&]<int J>() {
                         if constexpr (K == 0) r2[Q / 4][4 * (Q % 4) + J] = twv[0] * a[J];
@@ -390,7 +391,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             });
 #else
             // the four rows are only REQUESTED here; they are combined in the prologue of the fused stage, under its operand requests
-            static_for<4>([&]<int K>() { static_for<8>([&]<int Q>() { trow[K][Q] = bld4(rtb, rv, K * 256 + Q * 16); }); });
+            static_for<4>([&]<int K>() { static_for<4 * NT2>([&]<int Q>() { trow[K][Q] = bld4(rtb, rv, K * 256 + Q * 16); }); });
             tw[0] = w0; tw[1] = w1; tw[2] = w2; tw[3] = w3;
 #endif
         } else front_requests();
@@ -473,7 +474,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         ln_silu<NT2, false>(r2, wv, rows, RL::g2, RL::be2);
         if (valid) {
             float* const o = P.rtab_out + ((size_t)(P.rtab_row0[scale] + e) * 2 + hi) * 32;
-            static_for<8>([&]<int Q>() { st4(o + 4 * Q, f32x4{r2[Q / 4][4 * (Q % 4)], r2[Q / 4][4 * (Q % 4) + 1], r2[Q / 4][4 * (Q % 4) + 2], r2[Q / 4][4 * (Q % 4) + 3]}); });
+            static_for<4 * NT2>([&]<int Q>() { st4(o + 4 * Q, f32x4{r2[Q / 4][4 * (Q % 4)], r2[Q / 4][4 * (Q % 4) + 1], r2[Q / 4][4 * (Q % 4) + 2], r2[Q / 4][4 * (Q % 4) + 3]}); });
         }
         return;
     }
@@ -717,7 +718,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             static_for<NT2>([&]<int To>() { to_vgpr(r2[To]); });
             ln_silu<NT2, UN>(r2, wv, rows, RL::g2, RL::be2, P.ln_inv_n[1], P.ln_pad[1]);
         } else if constexpr (MODE == 1 && !DEDF_RTAB_COALESCED) {
-            static_for<8>([&]<int Q>() { static_for<4>([&]<int J>() {
+            static_for<4 * NT2>([&]<int Q>() { static_for<4>([&]<int J>() {
                 r2[Q / 4][4 * (Q % 4) + J] = (tw[0] * trow[0][Q][J] + tw[1] * trow[1][Q][J]) + (tw[2] * trow[2][Q][J] + tw[3] * trow[3][Q][J]);
             }); });
         }
