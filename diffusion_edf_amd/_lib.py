@@ -138,7 +138,7 @@ def make_config(cfg: HeadConfig, device: int, max_edges: int = 0) -> DedfConfig:
 
 
 def make_unet_layer_config(radius: float, device: int, fc_neurons=(64, 32, 32), muls=(64, 32, 16), num_heads: int = 4,
-                           irreps_mlp_mid: int = 3, valid=None, fc_valid=None) -> DedfConfig:
+                           irreps_mlp_mid: int = 3, valid=None, fc_valid=None, half_gemm: bool = False) -> DedfConfig:
     """dedf_config of ONE UNet layer (dedf_config.unet_layer = 1): irreps 64x0e+32x1e+16x2e, radial MLP [64,32,32]; `valid` / `fc_valid`:
     true multiplicities / radial widths of a narrower model that runs zero-padded (dedf.h: unet_valid, unet_fc_valid)"""
     c = DedfConfig()
@@ -155,6 +155,7 @@ def make_unet_layer_config(radius: float, device: int, fc_neurons=(64, 32, 32), 
     c.max_neighbors = 1000
     c.device = device
     c.unet_layer = 1
+    c.half_gemm = int(bool(half_gemm))
     for i in range(3):
         c.unet_valid[i] = 0 if valid is None else int(valid[i])
         c.unet_fc_valid[i] = 0 if fc_valid is None else int(fc_valid[i])

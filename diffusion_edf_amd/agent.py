@@ -190,8 +190,11 @@ def get_models(configs_root_dir: str,
         print(f"Successfully Loaded checkpoint @ epoch: {checkpoint['epoch']} (steps: {checkpoint['steps']})")
     model = model.to(device).eval()
     model.diffusion_schedules = cfgs['train']['diffusion_configs']['time_schedules']
-    if half_precision:
+    if half_precision:              # agent.py:50-51 `model.half()`: here the half-precision GEMM mode of the head and of the extractors' layers
         model.score_head.half()
+        for m in (model.key_model, model.query_model):
+            if isinstance(m, torch.nn.Module) and type(m).half is not torch.nn.Module.half:
+                m.half()
     if n_warmups and torch.device(device).type == 'cuda':
         print(f"Warming up the model for {n_warmups} iterations", flush=True)
         fake = model.score_head._get_fake_input()

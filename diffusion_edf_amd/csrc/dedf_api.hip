@@ -134,7 +134,7 @@ int check_config(const dedf_config* c, std::string& why) {
         if (c->fc_neurons[0] != 64 || c->fc_neurons[1] != 32 || c->fc_neurons[2] != 32) { why = "UNet layer: fc_neurons must be [64, 32, 32]"; return DEDF_ERR_UNSUPPORTED; }
         if (c->irreps_mlp_mid != kMlpMid) { why = "irreps_mlp_mid must be 3"; return DEDF_ERR_UNSUPPORTED; }
         if (c->n_scales != 1 || !(c->radii[0] > 0)) { why = "UNet layer: n_scales = 1 and radii[0] = the level's connection radius"; return DEDF_ERR_INVALID; }
-        if (c->ebm || c->half_gemm || c->use_src_point_attn) { why = "UNet layer: ebm / half_gemm / use_src_point_attn do not apply"; return DEDF_ERR_UNSUPPORTED; }
+        if (c->ebm || c->use_src_point_attn) { why = "UNet layer: ebm / use_src_point_attn do not apply"; return DEDF_ERR_UNSUPPORTED; }
         for (int l = 0; l < 3; ++l) {
             if (c->unet_valid[l] < 0 || c->unet_valid[l] > c->mul[l] || (c->unet_valid[l] > 0 && c->unet_valid[l] % 4)) { why = "UNet layer: unet_valid[l] must be 0 or a multiple of 4 up to mul[l]"; return DEDF_ERR_INVALID; }
             if (c->unet_fc_valid[l] < 0 || c->unet_fc_valid[l] > c->fc_neurons[l]) { why = "UNet layer: unet_fc_valid out of range"; return DEDF_ERR_INVALID; }
@@ -831,7 +831,8 @@ int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const floa
         P.key_w = nullptr;
         P.out = h->d_eout.as<float>();
         P.dbg_w = nullptr; P.dbg_out = nullptr; P.phase_prof = nullptr;
-        hipLaunchKernelGGL((k_edge<2, 64, false, 32, 32, true>), dim3(h->n_cu * 4), dim3(64), 0, st, P);
+        if (h->cfg.half_gemm) hipLaunchKernelGGL((k_edge<2, 64, true, 32, 32, true>), dim3(h->n_cu * 4), dim3(64), 0, st, P);
+        else hipLaunchKernelGGL((k_edge<2, 64, false, 32, 32, true>), dim3(h->n_cu * 4), dim3(64), 0, st, P);
     }
     hipLaunchKernelGGL(k_aggregate<L>, dim3((n_dst + 3) / 4), dim3(256), 0, st, h->d_eout.as<float>(), h->d_cnt.as<int>(), h->d_off.as<int>(),
                        h->d_tile.as<int>(), n_dst, 1, h->d_z.as<float>());
@@ -852,7 +853,8 @@ int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const floa
         P.sc = o.sc;
         P.o_b_proj0 = o.o_b_proj0; P.o_ln_b0 = o.o_ln_b0; P.o_b_f1 = o.o_b_f1; P.o_b_f2 = o.o_b_f2;
         const int ntiles = (n_dst + 31) / 32;
-        hipLaunchKernelGGL((k_node<2, false, false, true>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
+        if (h->cfg.half_gemm) hipLaunchKernelGGL((k_node<2, false, true, true>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
+        else hipLaunchKernelGGL((k_node<2, false, false, true>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
     }
     if (h->defer_check) {          // chains of layers: the verdict of the edge-list check is kept on the device for dedf_layer_check
         if (!h->d_sticky.p) {

@@ -109,5 +109,7 @@ template <int L, bool EBM, bool HP = false, bool UN = false> __global__ __launch
     X(13, void k_edge<2, 192, false, 128, 64, false, 1>(EdgeParams))  \
     X(10, void k_radial_table<2, 192>(EdgeParams))                    \
     X(14, void k_edge<2, 128, false, 32, 32, false, 1>(EdgeParams))   \
-    X(10, void k_radial_table<2, 128, false, 32, 32>(EdgeParams))
-constexpr int kKernelUnits = 15;
+    X(10, void k_radial_table<2, 128, false, 32, 32>(EdgeParams))     \
+    X(15, void k_edge<2, 64, true, 32, 32, true>(EdgeParams))         \
+    X(15, void k_node<2, false, true, true>(NodeParams))
+constexpr int kKernelUnits = 16;

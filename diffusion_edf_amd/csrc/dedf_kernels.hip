@@ -81,4 +81,9 @@
 #else
 #define DEDF_INST_14(...) DEDF_NOP(__VA_ARGS__)
 #endif
+#if DEDF_KUNIT == 15
+#define DEDF_INST_15(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_15(...) DEDF_NOP(__VA_ARGS__)
+#endif
 DEDF_KERNEL_LIST(DEDF_INST)

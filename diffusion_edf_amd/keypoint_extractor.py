@@ -230,6 +230,15 @@ class KeypointExtractor(torch.nn.Module):
             p.requires_grad_(False)
         self.irreps_output = str(tensor_field_kwargs['irreps_output'])
 
+    def half(self):
+        """``model.half()``: the UNet's layers switch to single-product fp16 GEMMs; the two fields and the weight head stay in full precision"""
+        self.feature_extractor.half()
+        return self
+
+    def float(self):
+        self.feature_extractor.float()
+        return self
+
     @torch.no_grad()
     def init_query_points(self, src_points: FeaturedPoints, retain_feature: bool = False, retain_weight: bool = False) -> FeaturedPoints:
         """``:128-169``: points inside the bbox, then FPS with ``pool_ratio`` (start at the first point when deterministic)"""

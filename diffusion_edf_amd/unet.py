@@ -64,6 +64,7 @@ class UnetLayer(torch.nn.Module):
         self._handle = None
         self._handle_device: Optional[torch.device] = None
         self._deferred = False
+        self._half = False
         self.register_load_state_dict_post_hook(UnetLayer._after_load)
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -76,6 +77,18 @@ class UnetLayer(torch.nn.Module):
     #  which never calls the children's load_state_dict)
     def _after_load(self, *_):
         self._release()
+
+    def half(self):
+        """the reference's ``model.half()`` (agent.py:50-51) for this layer: every GEMM of its two fused kernels as ONE fp16 MFMA product (fp16
+        operands, fp32 accumulation) instead of the 3-term split; parameters stay fp32 master copies, everything else stays fp32"""
+        self._half = True
+        self._release()
+        return self
+
+    def float(self):
+        self._half = False
+        self._release()
+        return self
 
     def __del__(self):
         try:
@@ -98,7 +111,7 @@ class UnetLayer(torch.nn.Module):
             state = unet_pad.expand_layer_params(state, self.muls, self.fc_neurons, self.muls_src)
         ccfg = _lib.make_unet_layer_config(self.radius, idx, unet_pad.WIDE_FC, unet_pad.WIDE, self.num_heads,
                                            valid=self.muls if self.muls != unet_pad.WIDE else None,
-                                           fc_valid=self.fc_neurons if self.fc_neurons != unet_pad.WIDE_FC else None)
+                                           fc_valid=self.fc_neurons if self.fc_neurons != unet_pad.WIDE_FC else None, half_gemm=self._half)
         blob = _lib.pack_params(ccfg, state)
         h = C.c_void_p()
         rc = lib.dedf_create(C.byref(ccfg), blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, C.byref(h))
@@ -294,6 +307,19 @@ class UnetFeatureExtractor(torch.nn.Module):
     pool_method 'fps', attn_type 'mlp' — every UNet the reference ships.  Dropout / drop-path are identity in eval and not modelled."""
 
     _forward_only = False
+
+    def half(self):
+        """half-precision GEMM mode of every layer (``UnetLayer.half``); the per-node projections and the graph primitives stay fp32"""
+        for m in self.modules():
+            if isinstance(m, UnetLayer):
+                m.half()
+        return self
+
+    def float(self):
+        for m in self.modules():
+            if isinstance(m, UnetLayer):
+                m.float()
+        return self
 
     def __init__(self, irreps_input, irreps_output, irreps_emb, irreps_edge_attr, num_heads, fc_neurons, n_layers, pool_ratio, radius,
                  deterministic: bool = False, pool_method='fps', irreps_mlp_mid=3, attn_type='mlp', alpha_drop=0.1, proj_drop=0.1,

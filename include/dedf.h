@@ -82,7 +82,7 @@ typedef struct dedf_config {
                                             GaussianRadialBasisLayerFiniteCutoff + block.EquiformerBlock with GraphAttentionMLP, irreps_src =
                                             irreps_dst = 64x0e+32x1e+16x2e, fc_neurons {64,32,32} (levels 2, 3 and the mid block of every shipped
                                             UNet config); radii[0] = the level's connection radius, n_scales = 1; the time / score fields are
-                                            ignored; only dedf_layer_forward is available.  0: score / critic head */
+                                            ignored; only dedf_layer_forward is available; half_gemm applies.  0: score / critic head */
     int unet_valid[3];                   /* UNet layer: true multiplicities of the block's irreps (0 = all of mul[]).  A 32x0e+16x1e+8x2e layer (levels 0-1 of
                                             the shipped UNets) runs on the 64/32/16 kernels with zero-padded parameters (diffusion_edf_amd/unet.py
                                             builds them); what the padding cannot express -- LayerNorm statistics over the true channels only -- is told
