@@ -79,7 +79,7 @@ struct dedf_handle {
     const LangevinParams* fused_step = nullptr;           // dedf_sample: the per-pose reduction also carries this step's Langevin update
     DevBuf d_tb_steps; const float* tb_step = nullptr;    // dedf_sample: the time-bias rows of ALL steps are computed up front; tb_step = this step's rows
     std::vector<float> h_tsteps;
-    bool radial_table = true;         // sampler: tabulate the radial network's front per launch (DEDF_RADIAL_TABLE=0 / dedf_set_radial_table turn it off)
+    int radial_table = 1;         // sampler: tabulate the radial network's front per launch (DEDF_RADIAL_TABLE=0 / dedf_set_radial_table turn it off)
     DevBuf d_rtab;
     bool defer_check = false;         // dedf_layer_defer_check
     DevBuf d_sticky;
@@ -379,7 +379,8 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         bool use_tab = false;
         if constexpr ((F0 == 128 || F0 == 192) && L == 2 && !EBM) {
             const bool narrow = h->cfg.fc_neurons[1] == 32;
-            use_tab = h->radial_table && !hp && P.tb_pose_stride == 0 && !h->debug && !(narrow && F0 == 192);
+            // (worth its 34 us generator launch from ~6 rounds of edge tiles on: ~20 edges per destination node -> 8 192 nodes)
+            use_tab = h->radial_table != 0 && !hp && P.tb_pose_stride == 0 && !h->debug && !(narrow && F0 == 192) && (Nd >= kRtabMinNodes || h->radial_table == 2);
             if (use_tab) {
                 int row = 0;
                 for (int n = 0; n < ns; ++n) {
@@ -518,7 +519,7 @@ int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, de
     h->cfg = *cfg;
     h->L = cfg->lmax;
     h->host_only = cfg->device < 0;
-    if (const char* e = getenv("DEDF_RADIAL_TABLE")) h->radial_table = atoi(e) != 0;
+    if (const char* e = getenv("DEDF_RADIAL_TABLE")) h->radial_table = std::max(0, std::min(2, atoi(e)));
     if (h->L == 1) build_all<1>(h.get()); else build_all<2>(h.get());
     if (!params || n_params != h->spec.total) {
         fprintf(stderr, "dedf_create: expected %zu parameters, got %zu\n", h->spec.total, n_params);
@@ -875,7 +876,8 @@ int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const floa
 
 int dedf_set_radial_table(dedf_handle* h, int on) {
     if (!h) return DEDF_ERR_INVALID;
-    h->radial_table = on != 0;
+    if (on < 0 || on > 2) return fail(h, DEDF_ERR_INVALID, "dedf_set_radial_table: 0 off, 1 automatic, 2 always");
+    h->radial_table = on;
     return DEDF_OK;
 }
 

@@ -17,6 +17,8 @@ constexpr int kFc0 = 128, kFc1 = 128, kFc2 = 64;     // fc_neurons of every ship
 // [0, kRtabInfiniteSpan * length_enc_max_r) (longer edges fall back to the per-edge evaluation)
 constexpr int kRtabFinite = 2048, kRtabInfinite = 32768;
 constexpr double kRtabInfiniteSpan = 1.5;
+constexpr int kRtabMinNodes = 8192;        // pose x query nodes below which the sampler evaluates the front per edge (small batches: the
+                                           // table's generator launch costs more than it saves)
 constexpr int kLenEmb = 64, kTimeEmb = 64, kTimeEnc = 256, kTimeHid = 128;
 constexpr int kMaxScales = 8;
 

@@ -122,11 +122,11 @@ class ScoreModelHead(torch.nn.Module):
 
     def set_radial_table(self, on: bool):
         """the sampler's radial table (``dedf_set_radial_table``, on by default): when every pose of a step shares the diffusion time, the
-        front of the radial network is tabulated once per step on a fine length grid and interpolated per edge; ``False`` evaluates it per
+        front of the radial network is tabulated once per step on a fine length grid and interpolated per edge; ``True`` = automatic (batches of at least 8 192 pose x query nodes), ``"always"`` regardless of the batch size, ``False`` evaluates it per
         edge everywhere (what ``forward`` always does: it takes one time per pose)"""
-        self._radial_table = bool(on)
+        self._radial_table = 2 if on == "always" else int(bool(on))          # "always": also for batches too small for it to pay (tests)
         if self._handle is not None:
-            _lib.load().dedf_set_radial_table(self._handle, int(self._radial_table))
+            _lib.load().dedf_set_radial_table(self._handle, self._radial_table)
 
     def refresh_weights(self):
         """call after load_state_dict(): the packed device image is rebuilt on next use"""

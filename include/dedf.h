@@ -158,7 +158,9 @@ int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const floa
  * only.  By default dedf_sample evaluates it once per step on a fine length grid per scale (2 048 intervals over [0, r) for a finite scale,
  * 32 768 over [0, 1.5 length_enc_max_r) for the all-pairs scale; longer edges are evaluated per edge) with the edge kernel's own code, and the
  * edge kernel interpolates the 64 activations per edge (4-point Lagrange; measured deviation from the per-edge evaluation: see DESIGN.md section 5).
- * on = 0 restores the per-edge evaluation everywhere (also: environment DEDF_RADIAL_TABLE=0).  Instantiated for the lmax-2 score heads of the shipped
+ * Batches below 8 192 pose x query nodes evaluate per edge as well (the generator launch would cost more than it saves).
+ * on = 1 is this default; on = 0 restores the per-edge evaluation everywhere, on = 2 uses the table at every batch size (tests) -- also through the
+ * environment: DEDF_RADIAL_TABLE=0|1|2.  Instantiated for the lmax-2 score heads of the shipped
  * configs in full precision -- fc_neurons {128,128,64}, {192,128,64} (time_emb_mlp {512,256,128}) and {128,32,32}; lmax 1, the half-precision mode,
  * the EBM critic and the UNet layers evaluate per edge. */
 int dedf_set_radial_table(dedf_handle* h, int on);

@@ -23,7 +23,7 @@ for radii in ((5., 10., 20., None), (3.5, 5., 6.5, 8.), (None,), (5.,)):
         z = torch.zeros(len(Ts), 3, dtype=torch.float64)
         ref = R.langevin_step(ocfg, Ts, ang, lin, t, 0.04, 0.0, 0.5, 0.5, z, z)
         outs = []
-        for on in (True, False):
+        for on in ("always", False):
             head.set_radial_table(on)
             outs.append(ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[t, t]], [1], [0.04], temperatures=0.0).cpu())
         d_ref = (ref - Ts)[:, 4:]

@@ -147,7 +147,7 @@ def test_radial_table_of_the_sampler_against_the_per_edge_evaluation():
         gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
         for t in (0.9, 0.05):
             outs = []
-            for on in (True, False):
+            for on in ("always", False):
                 head.set_radial_table(on)
                 outs.append(ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[t, t]], [1], [0.04], temperatures=0.0).cpu())
             d_on, d_off = (outs[0][1] - outs[0][0])[:, 4:], (outs[1][1] - outs[1][0])[:, 4:]
@@ -189,7 +189,7 @@ def test_radial_table_other_score_head_shapes(shape):
     gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
     for t in (0.8, 0.03):
         outs = []
-        for on in (True, False):
+        for on in ("always", False):
             head.set_radial_table(on)
             outs.append(ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[t, t]], [1], [0.04], temperatures=0.0).cpu())
         d_on, d_off = (outs[0][1] - outs[0][0])[:, 4:], (outs[1][1] - outs[1][0])[:, 4:]
