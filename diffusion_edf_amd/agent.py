@@ -142,6 +142,18 @@ class PointAttentiveScoreModel(MultiscaleScoreModel):
         return [out] if isinstance(out, FeaturedPoints) else list(out)       # (FeaturedPoints is itself a tuple)
 
 
+# Persistent BUFFERS a reference ``score_model_state_dict`` carries and this build's schema does not need (they hold constants, no trained
+# state): e3nn ``o3.TensorProduct.output_mask`` and the constants of its generated code (``_compiled_main_*``, ``_w3j_*``), the
+# ``cutoff_eps`` of every graph parser (graph_parser.py:37), the Wigner ``J`` matrices of ``SliceAndTransform`` (wigner.py:215) and
+# ``ParityInversionSh.sign`` (utils.py:44).
+_REFERENCE_ONLY_SUFFIXES = ('.output_mask', '.cutoff_eps', '.J', '.sign')
+_REFERENCE_ONLY_MARKERS = ('._compiled_main', '._w3j_', '.tp._w3j')
+
+
+def is_reference_only_buffer(key: str) -> bool:
+    return key.endswith(_REFERENCE_ONLY_SUFFIXES) or any(m in key for m in _REFERENCE_ONLY_MARKERS)
+
+
 def load_configs(configs_root_dir: str, train_configs_file: str, task_configs_file: str) -> Dict[str, Dict]:
     """The three YAML files of one model directory, as reference trainer.py:41-48 reads them."""
     with open(os.path.join(configs_root_dir, train_configs_file)) as f:
@@ -178,15 +190,24 @@ def get_models(configs_root_dir: str,
     model = model_cls(**cfgs['model']['model_kwargs'], deterministic=False, key_extractor=key_extractor, query_extractor=query_extractor)
     if checkpoint_dir is not None:                                                              # trainer.py:141-147
         checkpoint = torch.load(checkpoint_dir, map_location='cpu')
-        res = model.load_state_dict(checkpoint['score_model_state_dict'], strict=strict_load)
-        # strict_load=False (the reference's default, agent.py:28) tolerates missing / extra keys of the injected feature extractors.
-        # The score head is THIS build's product: a key of it that does not line up means the schema differs from the checkpoint's
-        # and the head would silently run on its seeded init -- never acceptable.
-        bad = [k for k in list(res.missing_keys) + list(res.unexpected_keys) if k.startswith('score_head.')]
-        if bad:
-            raise RuntimeError(f"checkpoint {checkpoint_dir}: score_head parameters do not match the schema of this build: "
-                               f"missing {[k for k in res.missing_keys if k.startswith('score_head.')][:8]}, "
-                               f"unexpected {[k for k in res.unexpected_keys if k.startswith('score_head.')][:8]}")
+        sd = checkpoint['score_model_state_dict']
+        if strict_load:             # strict means strict about PARAMETERS: the reference-only buffers below are not part of this build's schema
+            own = set(model.state_dict())
+            sd = {k: v for k, v in sd.items() if k in own or not is_reference_only_buffer(k)}
+        res = model.load_state_dict(sd, strict=strict_load)
+        # strict_load=False (the reference's default, agent.py:28) tolerates missing / extra keys of INJECTED feature extractors.
+        # Everything this build constructs itself -- the score head always, the key / query models unless they were injected -- is
+        # checked: a parameter that does not line up means the schema differs from the checkpoint's and that module would silently run
+        # on its seeded init, which is never acceptable.  Reference-only persistent buffers (e3nn's `output_mask` / compiled-code
+        # constants, `cutoff_eps` of graph_parser.py:37, the Wigner `J` of wigner.py:215, ParityInversionSh's `sign`) carry no trained
+        # state and are tolerated.
+        built = ['score_head.'] + (['key_model.'] if key_extractor is None else []) + (['query_model.'] if query_extractor is None else [])
+        mine = lambda k: any(k.startswith(p) for p in built)
+        missing = [k for k in res.missing_keys if mine(k) and not is_reference_only_buffer(k)]
+        unexpected = [k for k in res.unexpected_keys if mine(k) and not is_reference_only_buffer(k)]
+        if missing or unexpected:
+            raise RuntimeError(f"checkpoint {checkpoint_dir}: parameters of {built} do not match the schema of this build: "
+                               f"missing {missing[:8]}, unexpected {unexpected[:8]}")
         print(f"Successfully Loaded checkpoint @ epoch: {checkpoint['epoch']} (steps: {checkpoint['steps']})")
     model = model.to(device).eval()
     model.diffusion_schedules = cfgs['train']['diffusion_configs']['time_schedules']

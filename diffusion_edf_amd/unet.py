@@ -286,7 +286,8 @@ class NodeLinear(torch.nn.Module):
 
 
 class _ParitySign(torch.nn.Module):
-    """holds the ``sign`` buffer of the reference's ``ParityInversionSh`` (utils.py:26-47) so that reference state dicts load strictly; the
+    """holds the ``sign`` buffer of the reference's ``ParityInversionSh`` (utils.py:26-47) so that this key of a reference state dict finds a home (the reference's other
+    persistent buffers -- e3nn ``tp.output_mask`` etc. -- are tolerated by ``agent.get_models``, see ``agent.is_reference_only_buffer``); the
     kernels never read it (the harmonics of a swapped edge are recomputed, Y_l(-v) = (-1)^l Y_l(v))"""
 
     def __init__(self, irreps):

@@ -86,41 +86,78 @@ def test_get_models_on_shipped_config_dirs(d):
             m.get_query_pcd(cloud)
 
 
+def _reference_buffers(model_sd, cfg):
+    """keys of persistent BUFFERS a reference checkpoint carries next to the parameters (constants, no trained state): e3nn's
+    `tp.output_mask` for every TensorProduct, `cutoff_eps` of every graph parser (graph_parser.py:37), the Wigner J of every
+    SliceAndTransform (wigner.py:215), constants of e3nn's generated code"""
+    extra = {}
+    for k in model_sd:
+        if k.endswith(".tp.weight"):
+            extra[k[:-len("weight")] + "output_mask"] = torch.ones(7)
+            extra[k[:-len("weight")] + "_compiled_main_left_right._w3j_1_1_0"] = torch.ones(3, 3, 1)
+    for n in range(cfg.n_scales):
+        extra[f"score_head.key_tensor_field.graph_parsers.{n}.cutoff_eps"] = torch.tensor(1e-12)
+    for i, (_, l) in enumerate(cfg.irreps):
+        extra[f"score_head.transform_irreps.transforms.{i}.J"] = torch.eye(2 * l + 1)
+    return extra
+
+
 def test_checkpoint_load_like_the_reference_agent(tmp_path):
     kw = synthetic.score_head_kwargs(2)
     d = str(tmp_path / "pick_lowres")
     _write_config_dir(d, kw, schedules=((1.0, 0.15), (0.15, 0.01)))
     cfg = params.HeadConfig.from_kwargs(kw)
     P = params.init_params(cfg, seed=11, randomize_all=True)
-    sd = {"score_head." + k: v for k, v in P.items()}
-    sd["key_model.blocks.0.weight"] = torch.zeros(3)             # extractor weights of the full reference model
+    # the full reference model: key model (built here from the YAML block, so its names are this build's schema), static key points, head
+    ref = A.get_models(d, "train_configs.yaml", "task_configs.yaml", None, "cpu", n_warmups=0)
+    g = torch.Generator().manual_seed(5)
+    sd = {k: v + 0.01 * torch.randn(v.shape, generator=g) if v.is_floating_point() else v.clone()
+          for k, v in ref.state_dict().items() if k.startswith("key_model.")}
+    sd.update({"score_head." + k: v for k, v in P.items()})
     sd["query_model.keypoint_coords"] = torch.tensor([[0.5, 0.5, 10.5], [-0.5, -0.5, 10.5]])
     sd["query_model.keypoint_features"] = torch.randn(2, cfg.dim)
     sd["query_model.keypoint_weights"] = torch.tensor([0.3, -1.2])
+    # ... and the persistent buffers a genuine reference checkpoint always carries: tolerated, also under strict_load=True
+    sd_ref = dict(sd, **_reference_buffers(sd, cfg))
     ck = str(tmp_path / "Pick_LowRes_300.pt")
-    torch.save(dict(score_model_state_dict=sd, epoch=300, steps=12345), ck)
-    m = A.get_models(d, "train_configs.yaml", "task_configs.yaml", ck, "cpu", n_warmups=0)          # strict_load=False: agent.py:28
-    got = m.score_head.state_dict()
-    assert set(got) == set(P)
-    for k, v in P.items():
-        assert torch.equal(got[k], v), k
+    torch.save(dict(score_model_state_dict=sd_ref, epoch=300, steps=12345), ck)
+    for strict in (False, True):
+        m = A.get_models(d, "train_configs.yaml", "task_configs.yaml", ck, "cpu", n_warmups=0, strict_load=strict)   # default False: agent.py:28
+        got = m.score_head.state_dict()
+        assert set(got) == set(P)
+        for k, v in P.items():
+            assert torch.equal(got[k], v), k
+        for k, v in m.state_dict().items():
+            if k.startswith("key_model."):
+                assert torch.equal(v, sd[k]), k                                                # the extractor really took the checkpoint's values
     q = m.get_query_pcd(synthetic.make_query(cfg, 0, seed=0, static_keypoints=True))        # StaticKeypointModel: weights from the checkpoint
     assert torch.equal(q.f, sd["query_model.keypoint_features"]) and torch.allclose(q.w, torch.sigmoid(torch.tensor([0.3, -1.2])))
     assert m.diffusion_schedules == [[1.0, 0.15], [0.15, 0.01]]
+    # an INJECTED key extractor is the caller's: its keys are not this build's to judge under strict_load=False
+    inj = {k: v for k, v in sd.items() if not k.startswith("key_model.")}
+    inj["key_model.blocks.0.weight"] = torch.zeros(3)
+    torch.save(dict(score_model_state_dict=inj, epoch=1, steps=1), ck)
+    A.get_models(d, "train_configs.yaml", "task_configs.yaml", ck, "cpu", n_warmups=0, key_extractor=lambda pcd: None)
+    with pytest.raises(RuntimeError, match="do not match the schema"):          # ... but a key model built here must find its parameters
+        A.get_models(d, "train_configs.yaml", "task_configs.yaml", ck, "cpu", n_warmups=0)
     with pytest.raises(RuntimeError, match="Unexpected key"):
-        A.get_models(d, "train_configs.yaml", "task_configs.yaml", ck, "cpu", n_warmups=0, strict_load=True)
+        A.get_models(d, "train_configs.yaml", "task_configs.yaml", ck, "cpu", n_warmups=0, strict_load=True, key_extractor=lambda pcd: None)
+    # a renamed / missing extractor parameter is as fatal as a head parameter: that module would silently run on its seeded init
+    k0 = next(k for k in sd if k.startswith("key_model.") and k.endswith("ga.alpha_dot"))
+    ren = {(k0 + "_renamed" if k == k0 else k): v for k, v in sd.items()}
+    torch.save(dict(score_model_state_dict=ren, epoch=1, steps=1), ck)
+    with pytest.raises(RuntimeError, match="do not match the schema"):
+        A.get_models(d, "train_configs.yaml", "task_configs.yaml", ck, "cpu", n_warmups=0)
     sd.pop("score_head.key_tensor_field.gnn_block_init.ga.alpha_dot")
-    torch.save(dict(score_model_state_dict={k: v for k, v in sd.items() if k.startswith("score_head.")}, epoch=1, steps=1), ck)
+    torch.save(dict(score_model_state_dict=sd, epoch=1, steps=1), ck)
     with pytest.raises(RuntimeError, match="Missing key"):
         A.get_models(d, "train_configs.yaml", "task_configs.yaml", ck, "cpu", n_warmups=0, strict_load=True)
-    # strict_load=False forgives the extractors' keys, never the score head's: a head parameter the checkpoint lacks (or one it
-    # has and this build does not know) would leave the head on its seeded init without a word
-    with pytest.raises(RuntimeError, match="score_head parameters do not match"):
+    with pytest.raises(RuntimeError, match="do not match the schema"):
         A.get_models(d, "train_configs.yaml", "task_configs.yaml", ck, "cpu", n_warmups=0)
-    sd2 = {"score_head." + k: v for k, v in P.items()}
+    sd2 = {k: v for k, v in sd_ref.items()}
     sd2["score_head.some_renamed_block.weight"] = torch.zeros(4)
     torch.save(dict(score_model_state_dict=sd2, epoch=1, steps=1), ck)
-    with pytest.raises(RuntimeError, match="score_head parameters do not match"):
+    with pytest.raises(RuntimeError, match="do not match the schema"):
         A.get_models(d, "train_configs.yaml", "task_configs.yaml", ck, "cpu", n_warmups=0)
 
 
