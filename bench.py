@@ -17,12 +17,13 @@ Extra objects on the JSON line:
                 MAC/edge) runs as a 3-term split-fp16 product (hi*hi + hi*lo + lo*hi, fp32 accumulate) on the 2.5 PFLOP/s dense
                 fp16 MFMAs of MI355X_MICROARCH.md, so the hardware MFMA peak of this arithmetic is peak = 2500 / 3 TFLOP/s
                 fp32-equivalent and frac = achieved / peak.  The kernel is limited by VALU issue (one wave per SIMD), not by
-                the matrix pipes: "bound" says so.  `mix_bound` is the secondary figure that also prices the lane-local
+                the matrix pipes: "bound" says so.  Since round 3 `achieved` / `frac` count the FLOP the kernel EXECUTES per edge (152 384 MAC
+                with the sampler's radial table); the algorithmic count is reported beside them as `achieved_algorithmic` / `frac_algorithmic`,
+                and `frac_mfma_issued` is the MFMA issue fraction from the PMC counters of the newest profile.  `mix_bound` is the secondary figure that also prices the lane-local
                 Clebsch-Gordan contractions (29 760 MAC/edge in the dense-CG convention) on the 157.3 TFLOP/s fp32 vector peak, in
                 series with the GEMMs.  traffic = HBM bytes per launch from the newest profiles/*pmc*.json (`traffic_source` names it).
                 roofline.radial_table: the sampler tabulates the front of the radial network per step (every pose shares the time), so 40 960
-                of the 193 344 algorithmic MAC/edge are not executed per edge; `frac` stays on the algorithmic count, the
-                object gives the fraction on the executed count next to it.
+                of the 193 344 algorithmic MAC/edge are not executed per edge; the object also carries the per-edge reading of the same K steps.
   cpu_baseline  the CPU restatement oracle ("port", fp32, same inputs) timed on this host on a bounded pose sample: 1 thread, 16
                 threads and all physical cores (lscpu).
   config.score_fwd_ms_at_t0.5   one score evaluation (no Langevin update) of the seeded poses at the fixed time t = 0.5.
@@ -319,14 +320,23 @@ def main():
         default_workload = (args.lmax, args.scene, args.grasp, args.poses_per_gpu) == (2, 4096, 1024, 1000)
         default_workload = default_workload and not args.half
         wname = "C2" if default_workload else ("C1" if (args.lmax, args.scene, args.grasp) == (1, 2048, 512) else "custom")
-        traffic, traffic_src = None, None
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json"))) if default_workload else []:
+        traffic, traffic_src, mfma_issued = None, None, None
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json")), key=os.path.getmtime) if default_workload else []:
             try:
-                v = json.load(open(f)).get("edge_kernel_hbm_bytes_per_launch")
+                doc = json.load(open(f))
+                v = doc.get("edge_kernel_hbm_bytes_per_launch")
                 if v is not None:
                     traffic, traffic_src = v, "profiles/" + os.path.basename(f) + " (separate rocprofv3 --pmc passes of `bench.py --steps 5 --warmup 1`)"
+                    mfma_issued = doc.get("edge_kernel_frac_mfma_issued")
             except Exception:
                 pass
+        # FLOP the edge kernel EXECUTES per edge: with the sampler's radial table the front of the radial network (40 960 MAC) runs per grid
+        # node, not per edge.  `frac` is on the executed count (a hardware utilisation figure); `frac_algorithmic` keeps the reference's
+        # algorithmic count of SURVEY 8(d) (what the work is worth, not what the pipes did).
+        table_on = args.lmax == 2 and not args.half and not args.no_radial_table
+        m_exec = M_EDGE[args.lmax] - (M_EDGE_FRONT[args.lmax] if table_on else 0)
+        flops_exec = 2.0 * e_per_launch * m_exec
+        achieved_exec = flops_exec / (edge_ms * 1e-3) / 1e12 if edge_ms > 0 else 0.0
         out = {
             "metric": f"denoised SE(3) poses/sec (pose-steps/s, {args.scene // 1024}k-pt scene / {args.grasp}-pt grasp, lmax={args.lmax})",
             "value": n_total * args.steps / el,
@@ -342,8 +352,11 @@ def main():
                        "poses_total": n_total, "parallelism": f"pose-parallel dp{world}, one RCCL all-gather at the end",
                        "edges_per_step_rank0": e_per_launch, "full_trajectories_per_s_at_50_steps": n_total * args.steps / el / 50.0,
                        "score_fwd_ms_at_t0.5": fixed, "feature_extractors_ms": extract},
-            "roofline": {"kernel": "k_edge (fused per-edge pipeline)", "bound": "valu-issue", "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
+            "roofline": {"kernel": "k_edge (fused per-edge pipeline)", "bound": "valu-issue", "achieved": achieved_exec, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved_exec / peak, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac_definition": f"EXECUTED FLOP: 2 x {m_exec} MAC per edge" + (" (193 344 algorithmic - 40 960 that the sampler's radial table evaluates per grid node)" if table_on and args.lmax == 2 else "") + " x edges of the launch / its HIP-event duration / peak",
+                         "achieved_algorithmic": achieved, "frac_algorithmic": achieved / peak,
+                         "frac_mfma_issued": mfma_issued, "frac_mfma_issued_definition": "SQ_INSTS_MFMA x 32 768 FLOP / launch time in the kernel trace / 2.5 PFLOP/s, from the file `traffic_source` names (the MFMAs the kernel issues, all three split terms counted)",
                          "peak_definition": "dense fp16 MFMA peak 2500 TFLOP/s / 3 (every GEMM is a 3-term split-fp16 product, fp32 accumulate): the hardware matrix peak of the arithmetic the kernel uses, in fp32-equivalent FLOP/s",
                          "dtype": "f16 x3 split (22-bit operands), f32 accumulate",
                          "mix_bound": {"peak": mix_peak_tflops(args.lmax), "frac": achieved / mix_peak_tflops(args.lmax),

@@ -50,6 +50,19 @@ def main(tag):
     edge_names = [n for n in pmc if n.startswith("void k_edge")]
     timed = [n for n in edge_names if n.rstrip().split("(")[0].endswith(", 1>")] or edge_names
     summary["edge_kernel_name"] = timed[-1] if timed else None
+    # average duration of the timed kernel in the kernel trace of the same command, and the MFMA issue fraction that follows from it:
+    # SQ_INSTS_MFMA x 32 768 FLOP (one v_mfma_f32_32x32x16_f16) / launch time / 2.5 PFLOP/s dense fp16
+    con = db(f"{tag}_trace")
+    if con and timed:
+        for r in con.execute("select name, average from top_kernels"):
+            if r[0] == timed[-1]:
+                summary["edge_kernel_avg_us_in_trace"] = r[1]
+    for name, c in pmc.items():
+        if timed and name == timed[-1]:
+            n_mfma = c.get("SQ_INSTS_MFMA", {}).get("avg")
+            if n_mfma is not None and summary.get("edge_kernel_avg_us_in_trace"):
+                summary["edge_kernel_mfma_insts_per_launch"] = n_mfma
+                summary["edge_kernel_frac_mfma_issued"] = n_mfma * 32768.0 / (summary["edge_kernel_avg_us_in_trace"] * 1e-6) / 2.5e15
     for name, c in pmc.items():
         if timed and name == timed[-1]:
             f = c.get("FETCH_SIZE", {}).get("avg")
