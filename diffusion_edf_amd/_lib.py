@@ -19,7 +19,7 @@ SYMBOLS = [
     "dedf_version", "dedf_param_count", "dedf_param_name", "dedf_param_numel", "dedf_create", "dedf_destroy",
     "dedf_last_error", "dedf_set_key_clouds", "dedf_set_key_weights", "dedf_set_query", "dedf_score", "dedf_energy", "dedf_sample", "dedf_get_stats",
     "dedf_debug_enable", "dedf_debug_copy", "dedf_debug_packed", "dedf_profile_enable", "dedf_profile_read",
-    "dedf_fps", "dedf_radius", "dedf_layer_forward", "dedf_linear_rs", "dedf_field", "dedf_keypoint_weight", "dedf_layer_defer_check", "dedf_layer_check", "dedf_set_radial_table",
+    "dedf_fps", "dedf_radius", "dedf_layer_forward", "dedf_linear_rs", "dedf_field", "dedf_keypoint_weight", "dedf_layer_defer_check", "dedf_layer_check", "dedf_set_radial_table", "dedf_linear_rs_lmax",
 ]
 
 
@@ -30,7 +30,7 @@ class DedfConfig(C.Structure):
         ("radii", C.c_float * MAX_SCALES), ("r_mincut_nonscalar_sh", C.c_float), ("length_enc_max_r", C.c_float),
         ("max_time", C.c_float), ("time_enc_n", C.c_float), ("lin_mult", C.c_float), ("ang_mult", C.c_float),
         ("max_neighbors", C.c_int), ("device", C.c_int), ("max_edges", C.c_int64), ("ebm", C.c_int), ("half_gemm", C.c_int), ("use_src_point_attn", C.c_int),
-        ("unet_layer", C.c_int), ("unet_valid", C.c_int * 3), ("unet_fc_valid", C.c_int * 3),
+        ("unet_layer", C.c_int), ("unet_valid", C.c_int * 4), ("unet_fc_valid", C.c_int * 3),
     ]
 
 
@@ -90,6 +90,8 @@ def load() -> C.CDLL:
     lib.dedf_layer_forward.restype = C.c_int
     lib.dedf_linear_rs.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_int), C.c_void_p, C.c_void_p]
     lib.dedf_linear_rs.restype = C.c_int
+    lib.dedf_linear_rs_lmax.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_int), C.c_void_p, C.c_void_p]
+    lib.dedf_linear_rs_lmax.restype = C.c_int
     lib.dedf_set_radial_table.argtypes = [C.c_void_p, C.c_int]; lib.dedf_set_radial_table.restype = C.c_int
     lib.dedf_layer_defer_check.argtypes = [C.c_void_p, C.c_int]; lib.dedf_layer_defer_check.restype = C.c_int
     lib.dedf_layer_check.argtypes = [C.c_void_p, C.c_void_p]; lib.dedf_layer_check.restype = C.c_int
@@ -156,8 +158,9 @@ def make_unet_layer_config(radius: float, device: int, fc_neurons=(64, 32, 32), 
     c.device = device
     c.unet_layer = 1
     c.half_gemm = int(bool(half_gemm))
-    for i in range(3):
+    for i in range(len(muls)):
         c.unet_valid[i] = 0 if valid is None else int(valid[i])
+    for i in range(3):
         c.unet_fc_valid[i] = 0 if fc_valid is None else int(fc_valid[i])
     return c
 

@@ -59,8 +59,9 @@ struct dedf_handle {
     std::string err;
     bool host_only = false;
     int L = 2;
-    ParamSpec spec;
-    std::vector<float> params;
+    ParamSpec spec, kspec;                // canonical parameter list in the reference's TRUE shapes (the C ABI's blob) / in the kernels' shapes
+    std::vector<float> params, kparams;   // (they differ at lmax 3 only: 8x3e runs zero-padded as 16x3e, dedf_pack.h::pad_params)
+    DevBuf d_qf_true;                     // lmax 3: staging of the true-shape query features before they are padded
     Image edge_img, node_img;
     EdgeOffsets eo{};
     NodeOffsets no{};
@@ -129,21 +130,28 @@ int fail(dedf_handle* h, int code, const std::string& msg) {
 int check_config(const dedf_config* c, std::string& why) {
     if (!c) { why = "null config"; return DEDF_ERR_INVALID; }
     if (c->unet_layer) {       // one {radial, gnn} layer of the UNet feature extractor (unet_feature_extractor.py:141-202)
-        if (c->lmax != 2 || c->mul[0] != 64 || c->mul[1] != 32 || c->mul[2] != 16) { why = "UNet layer: irreps must be 64x0e+32x1e+16x2e (levels 2, 3 and the mid block of the shipped configs; the 32x0e+16x1e+8x2e levels are not instantiated)"; return DEDF_ERR_UNSUPPORTED; }
+        if ((c->lmax != 2 && c->lmax != 3) || c->mul[0] != 64 || c->mul[1] != 32 || c->mul[2] != 16 || (c->lmax == 3 && c->mul[3] != 16)) {
+            why = "UNet layer: irreps must be the kernel shapes 64x0e+32x1e+16x2e (lmax 2) or 64x0e+32x1e+16x2e+16x3e (lmax 3: 8x3e zero-padded; narrower levels run zero-padded too, see unet_valid)"; return DEDF_ERR_UNSUPPORTED; }
         if (c->num_heads != kHeads) { why = "num_heads must be 4"; return DEDF_ERR_UNSUPPORTED; }
         if (c->fc_neurons[0] != 64 || c->fc_neurons[1] != 32 || c->fc_neurons[2] != 32) { why = "UNet layer: fc_neurons must be [64, 32, 32]"; return DEDF_ERR_UNSUPPORTED; }
         if (c->irreps_mlp_mid != kMlpMid) { why = "irreps_mlp_mid must be 3"; return DEDF_ERR_UNSUPPORTED; }
         if (c->n_scales != 1 || !(c->radii[0] > 0)) { why = "UNet layer: n_scales = 1 and radii[0] = the level's connection radius"; return DEDF_ERR_INVALID; }
         if (c->ebm || c->use_src_point_attn) { why = "UNet layer: ebm / use_src_point_attn do not apply"; return DEDF_ERR_UNSUPPORTED; }
-        for (int l = 0; l < 3; ++l) {
+        for (int l = 0; l <= c->lmax; ++l)
             if (c->unet_valid[l] < 0 || c->unet_valid[l] > c->mul[l] || (c->unet_valid[l] > 0 && c->unet_valid[l] % 4)) { why = "UNet layer: unet_valid[l] must be 0 or a multiple of 4 up to mul[l]"; return DEDF_ERR_INVALID; }
+        if (c->lmax == 3 && (c->unet_valid[3] == 0 || c->unet_valid[3] > 8)) { why = "UNet layer, lmax 3: unet_valid[3] must name the true 3e multiplicity (8 or 4)"; return DEDF_ERR_INVALID; }
+        for (int l = 0; l < 3; ++l)
             if (c->unet_fc_valid[l] < 0 || c->unet_fc_valid[l] > c->fc_neurons[l]) { why = "UNet layer: unet_fc_valid out of range"; return DEDF_ERR_INVALID; }
-        }
         return DEDF_OK;
     }
-    if (c->lmax != 1 && c->lmax != 2) { why = "lmax must be 1 or 2 (lmax 3 is a next-row item)"; return DEDF_ERR_UNSUPPORTED; }
+    if (c->lmax < 1 || c->lmax > 3) { why = "lmax must be 1, 2 or 3"; return DEDF_ERR_UNSUPPORTED; }
     for (int l = 0; l <= c->lmax; ++l)
-        if (c->mul[l] != mul_of(l)) { why = "irreps must be 64x0e+32x1e(+16x2e)"; return DEDF_ERR_UNSUPPORTED; }
+        if (c->mul[l] != true_mul(l)) { why = "irreps must be 64x0e+32x1e(+16x2e(+8x3e))"; return DEDF_ERR_UNSUPPORTED; }
+    if (c->lmax == 3) {      // instantiated at lmax 3: the score head and the EBM critic / context-free field of the panda shapes, full precision
+        const bool ok3 = !c->half_gemm && c->fc_neurons[1] == kFc1 && c->fc_neurons[2] == kFc2 && (c->ebm || c->time_emb_mlp[2] == 64);
+        const bool kp3 = !c->half_gemm && c->ebm && c->fc_neurons[1] == 32 && c->fc_neurons[2] == 32;       // KeypointExtractor fields
+        if (!ok3 && !kp3) { why = "lmax 3 is instantiated for fc_neurons [64 + 64, 128, 64] (score head), [64, 128, 64] / [64, 32, 32] (EBM critic / context-free field), full precision"; return DEDF_ERR_UNSUPPORTED; }
+    }
     if (c->num_heads != kHeads) { why = "num_heads must be 4"; return DEDF_ERR_UNSUPPORTED; }
     const bool t_small = c->time_emb_mlp[0] == 256 && c->time_emb_mlp[1] == 128 && c->time_emb_mlp[2] == 64;
     const bool t_big = c->time_emb_mlp[0] == 512 && c->time_emb_mlp[1] == 256 && c->time_emb_mlp[2] == 128;   // sapien high-res configs
@@ -152,8 +160,8 @@ int check_config(const dedf_config* c, std::string& why) {
     const bool mlp_narrow = c->fc_neurons[1] == 32 && c->fc_neurons[2] == 32;       // sapien place_* score heads
     if (c->fc_neurons[0] != (c->ebm ? kLenEmb : kLenEmb + c->time_emb_mlp[2]) || !(mlp_wide || mlp_narrow)) {
         why = "fc_neurons must resolve to [64 + time_emb, 128, 64] or [64 + time_emb, 32, 32] (score head), or [64,128,64] / [64,32,32] (EBM head / context-free field, no time encoding)"; return DEDF_ERR_UNSUPPORTED; }
-    if (mlp_narrow && c->ebm && (c->lmax != 2 || c->half_gemm)) {
-        why = "the context-free field with the 32-wide radial MLP (KeypointExtractor) is instantiated for lmax 2, full precision only"; return DEDF_ERR_UNSUPPORTED; }
+    if (mlp_narrow && c->ebm && (c->lmax < 2 || c->half_gemm)) {
+        why = "the context-free field with the 32-wide radial MLP (KeypointExtractor) is instantiated for lmax 2 and 3, full precision only"; return DEDF_ERR_UNSUPPORTED; }
     if (mlp_narrow && !c->ebm && c->fc_neurons[0] != 128) {
         why = "the 32-wide radial MLP is instantiated for the score head with the 128-wide pre-linear only"; return DEDF_ERR_UNSUPPORTED; }
     if (c->length_emb_dim != kLenEmb) { why = "length_emb_dim must be 64"; return DEDF_ERR_UNSUPPORTED; }
@@ -169,22 +177,36 @@ int check_config(const dedf_config* c, std::string& why) {
     return DEDF_OK;
 }
 
-template <int L> void build_all(dedf_handle* h) {
-    h->spec = build_spec<L>(h->cfg);
+// the run-time irreps bookkeeping of the packers' schema must be what the kernels' compile-time description says
+template <int L> bool irreps_consistent(const IrrepsRT& K) {
+    bool ok = K.L == L && K.dtp_wn == dtp_wn<L>() && K.stp_wn == stp_wn<L>() && K.lin0_rows() == lin0_rows<L>() && K.f1_rows0() == f1_rows0<L>() &&
+              (int)K.dtp.size() == dtp_num_paths<L>() && (int)K.stp.size() == stp_num_paths<L>() && K.stp_k[0] == stp_k<L>(0) && K.stp_k[1] == stp_k<L>(1);
+    for (int l = 0; l <= L; ++l) ok = ok && K.mul[l] == mul_of(l) && K.hid[l] == hid_of(l) && K.dtp_k[l] == dtp_k<L>(l);
+    for (int p = 0; ok && p < dtp_num_paths<L>(); ++p) ok = K.dtp[p].wstart == dtp_path<L>(p).wstart && K.dtp[p].kofs == dtp_path<L>(p).kofs && K.dtp[p].l3 == dtp_path<L>(p).l3;
+    for (int p = 0; ok && p < stp_num_paths<L>(); ++p) ok = K.stp[p].wstart == stp_path<L>(p).wstart && K.stp[p].kofs == stp_path<L>(p).kofs;
+    return ok;
 }
 template <int L> void pack_all(dedf_handle* h) {
-    pack_edge<L>(h->cfg, h->spec, h->params.data(), h->edge_img, h->eo);
-    pack_node<L>(h->cfg, h->spec, h->params.data(), h->node_img, h->no);
+    pack_edge<L>(h->cfg, h->kspec, h->kparams.data(), h->edge_img, h->eo);
+    pack_node<L>(h->cfg, h->kspec, h->kparams.data(), h->node_img, h->no);
 }
 
+// the C ABI's canonical parameter list: TRUE shapes for the score / critic heads; UNet-layer handles take the kernel shapes (the caller pads)
 ParamSpec spec_for(const dedf_config* c) {
-    return c->lmax == 1 ? build_spec<1>(*c) : build_spec<2>(*c);
+    return build_spec(IrrepsRT(c->lmax, c->unet_layer != 0), *c);
 }
+
+size_t feat_dim_rt(int L) { return L == 1 ? feat_dim<1>() : (L == 2 ? feat_dim<2>() : feat_dim<3>()); }            // kernel layout
+size_t true_feat_dim_rt(int L) { return L == 1 ? true_feat_dim<1>() : (L == 2 ? true_feat_dim<2>() : true_feat_dim<3>()); }
+size_t edge_rec_rt(int L) { return feat_dim_rt(L) + kHeads; }
+size_t dtp_wn_rt(int L) { return L == 1 ? dtp_wn<1>() : (L == 2 ? dtp_wn<2>() : dtp_wn<3>()); }
+size_t pose_rec_rt(int L) { return L >= 3 ? pose_rec<3>() : pose_rec<2>(); }
 
 int upload_weights(dedf_handle* h) {
     const dedf_config& c = h->cfg;
-    const ParamSpec& S = h->spec;
+    const ParamSpec& S = h->spec;          // natural-layout weights of the small kernels: the TRUE shapes (k_src_message<L, ., TRUE_IN>)
     const float* B = h->params.data();
+    const IrrepsRT T(h->L, c.unet_layer != 0);
     if (!h->d_edge_w.ensure(h->edge_img.data.size() * 4) || !h->d_node_w.ensure(h->node_img.data.size() * 4))
         return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(weights) failed");
     HIPCK(h, hipMemcpy(h->d_edge_w.p, h->edge_img.data.data(), h->edge_img.data.size() * 4, hipMemcpyHostToDevice));
@@ -194,8 +216,7 @@ int upload_weights(dedf_handle* h) {
     auto put = [&](const float* p, size_t n) { size_t o = nat.size(); nat.insert(nat.end(), p, p + n); return o; };
     const int ns = c.n_scales;
     if (c.unet_layer) {        // linear_src (no bias) and linear_dst (+ bias), block.py:109-115
-        size_t sq = 0;
-        for (int l = 0; l <= h->L; ++l) sq += (size_t)mul_of(l) * mul_of(l);
+        const size_t sq = T.sq();
         h->nat_wsrc = put(S.get(B, "gnn.linear_src.tp.weight"), sq);
         h->nat_wdst = put(S.get(B, "gnn.linear_dst.tp.weight"), sq);
         h->nat_bdst = put(S.get(B, "gnn.linear_dst.bias.0"), mul_of(0));
@@ -217,9 +238,7 @@ int upload_weights(dedf_handle* h) {
     h->nat_bpre = nat.size();
     for (int n = 0; n < ns; ++n) put(S.get(B, "key_tensor_field.edge_scalars_pre_linears." + std::to_string(n) + ".0.bias"), F0);
     const std::string blk = "key_tensor_field.gnn_block_init";
-    const size_t nirr = h->L == 1 ? sum_mul<1>() : sum_mul<2>();
-    size_t sq = 0;
-    for (int l = 0; l <= h->L; ++l) sq += (size_t)mul_of(l) * mul_of(l);
+    const size_t nirr = T.sum_mul(), sq = T.sq();
     h->nat_lnw = put(S.get(B, blk + ".prenorm_src.affine_weight"), nirr);
     h->nat_lnb = put(S.get(B, blk + ".prenorm_src.affine_bias"), mul_of(0));
     h->nat_wsrc = put(S.get(B, blk + ".linear_src.tp.weight"), sq);
@@ -247,9 +266,7 @@ int upload_weights(dedf_handle* h) {
 
 int ensure_workspace(dedf_handle* h, int nT) {
     const int L = h->L;
-    const size_t D = L == 1 ? feat_dim<1>() : feat_dim<2>();
-    const size_t REC = L == 1 ? edge_rec<1>() : edge_rec<2>();
-    const size_t WN = L == 1 ? dtp_wn<1>() : dtp_wn<2>();
+    const size_t D = feat_dim_rt(L), REC = edge_rec_rt(L), WN = dtp_wn_rt(L);
     const size_t Nd = (size_t)nT * h->nQ;
     const int ns = h->cfg.n_scales;
     // worst case: every key of every scale is a neighbour (capped per scale by max_neighbors for finite scales)
@@ -265,7 +282,7 @@ int ensure_workspace(dedf_handle* h, int nT) {
     cap = std::max<int64_t>(cap, 64);
     h->edge_cap = cap;
     bool ok = h->d_Ts.ensure((size_t)nT * 7 * 4) && h->d_time.ensure((size_t)nT * 4) && h->d_tb.ensure((size_t)nT * ns * 256 * 4) &&
-              h->d_pose.ensure((size_t)nT * kPoseRec * 4) && h->d_qpos.ensure(Nd * 3 * 4) && h->d_cnt.ensure(Nd * ns * 4) &&
+              h->d_pose.ensure((size_t)nT * pose_rec_rt(L) * 4) && h->d_qpos.ensure(Nd * 3 * 4) && h->d_cnt.ensure(Nd * ns * 4) &&
               h->d_off.ensure(Nd * ns * 4) && h->d_blk.ensure(((Nd + kNbrBlock - 1) / kNbrBlock) * ns * 4 + 64) && h->d_tile.ensure(64 * 4) && h->d_esrc.ensure((size_t)cap * 4) &&
               h->d_edst.ensure((size_t)cap * 4) && h->d_eout.ensure((size_t)cap * REC * 4) && h->d_z.ensure(Nd * D * 4) &&
               h->d_nout.ensure(Nd * 8 * 4) && h->d_ang.ensure((size_t)nT * 3 * 4) && h->d_lin.ensure((size_t)nT * 3 * 4) &&
@@ -377,6 +394,32 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         // Sampler (every pose shares the step's time): the front of the radial network is a function of (scale, length) only -- tabulate
         // it once per launch on a fine length grid with the tile's own code and interpolate per edge (dedf_edge.h: EdgeParams::rtab)
         bool use_tab = false;
+        if constexpr (L == 3) {
+            static_assert(F0 == 128 || F0 == 64, "lmax 3 instantiations");
+            if constexpr (F0 == 128) {
+                use_tab = h->radial_table != 0 && P.tb_pose_stride == 0 && !h->debug && (Nd >= kRtabMinNodes || h->radial_table == 2);
+                if (use_tab) {
+                    int row = 0;
+                    for (int n = 0; n < ns; ++n) {
+                        const bool fin = c.radii[n] > 0;
+                        const int G = fin ? kRtabFinite : kRtabInfinite;
+                        const double span = fin ? (double)c.radii[n] : kRtabInfiniteSpan * (double)c.length_enc_max_r;
+                        P.rtab_row0[n] = row; P.rtab_n[n] = G;
+                        P.rtab_step[n] = (float)(span / G); P.rtab_inv_step[n] = (float)(G / span);
+                        row += G + 3;
+                    }
+                    const size_t bytes = (size_t)row * 64 * 4;
+                    if (!h->d_rtab.ensure(bytes)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(radial table) failed");
+                    P.rtab = h->d_rtab.as<float>(); P.rtab_out = h->d_rtab.as<float>(); P.rtab_bytes = (uint32_t)bytes;
+                    int ntab = 0;
+                    for (int n = 0; n < ns; ++n) ntab += (P.rtab_n[n] + 3 + 31) / 32;
+                    hipLaunchKernelGGL((k_radial_table<3, 128>), dim3(std::min(ntab, h->n_cu * 4)), blk, 0, st, P);
+                    hipLaunchKernelGGL((k_edge<3, 128, false, 128, 64, false, 1>), grid, blk, 0, st, P);
+                } else hipLaunchKernelGGL((k_edge<3, 128, false>), grid, blk, 0, st, P);
+            } else if (h->cfg.fc_neurons[1] == 32) hipLaunchKernelGGL((k_edge<3, 64, false, 32, 32>), grid, blk, 0, st, P);
+            else hipLaunchKernelGGL((k_edge<3, 64, false>), grid, blk, 0, st, P);
+            (void)hp;
+        }
         if constexpr ((F0 == 128 || F0 == 192) && L == 2 && !EBM) {
             const bool narrow = h->cfg.fc_neurons[1] == 32;
             // (worth its 34 us generator launch from ~6 rounds of edge tiles on: ~20 edges per destination node -> 8 192 nodes)
@@ -409,6 +452,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
                 }
             }
         }
+        if constexpr (L < 3) {
         if (use_tab) {
         } else if constexpr (F0 == 128) {
             if (h->cfg.fc_neurons[1] == 32) {         // narrow radial MLP (sapien place_*)
@@ -422,6 +466,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
             else hipLaunchKernelGGL((k_edge<L, F0>), grid, blk, 0, st, P);
         } else if (hp) hipLaunchKernelGGL((k_edge<L, F0, true>), grid, blk, 0, st, P);
         else hipLaunchKernelGGL((k_edge<L, F0>), grid, blk, 0, st, P);
+        }
     }
     mark();
     // 5. joint softmax + aggregation
@@ -433,7 +478,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         NodeParams P{};
         P.z = h->d_z.as<float>(); P.z_bytes = (uint32_t)((size_t)Nd * D * 4);
         P.qf = h->d_qf.as<float>(); P.qf_bytes = (uint32_t)((size_t)nQ * D * 4);
-        P.pose = h->d_pose.as<float>(); P.pose_bytes = (uint32_t)((size_t)nT * kPoseRec * 4);
+        P.pose = h->d_pose.as<float>(); P.pose_bytes = (uint32_t)((size_t)nT * pose_rec<L>() * 4);
         P.qx = h->d_qx.as<float>(); P.qw = h->d_qw.as<float>(); P.nQ = nQ; P.n_nodes = Nd; P.lin_mult = c.lin_mult;
         P.W = h->d_node_w.as<float>(); P.W_bytes = (uint32_t)h->d_node_w.bytes;
         const NodeOffsets& o = h->no;
@@ -452,7 +497,8 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         if ((h->debug || h->want_field) && h->d_dbge.ensure((size_t)Nd * D * 4) && h->d_dbgf.ensure((size_t)Nd * D * 4)) { P.dbg_emb = h->d_dbge.as<float>(); P.dbg_field = h->d_dbgf.as<float>(); }
         else if (h->want_field) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(field) failed");
         const int ntiles = (Nd + 31) / 32;
-        if (h->cfg.half_gemm) hipLaunchKernelGGL((k_node<L, EBM, true>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
+        if constexpr (L == 3) hipLaunchKernelGGL((k_node<L, EBM>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
+        else if (h->cfg.half_gemm) hipLaunchKernelGGL((k_node<L, EBM, true>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
         else hipLaunchKernelGGL((k_node<L, EBM>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
     }
     mark();
@@ -474,6 +520,11 @@ int score_dispatch(dedf_handle* h, int nT, int time_stride, float* ang, float* l
         if (F0 == 64) return score_impl<1, 64>(h, nT, time_stride, ang, lin, st);
         if (F0 == 128) return score_impl<1, 128>(h, nT, time_stride, ang, lin, st);
         return fail(h, DEDF_ERR_UNSUPPORTED, "lmax 1 with a 128-channel time embedding is not instantiated");
+    }
+    if (h->L == 3) {
+        if (F0 == 64) return score_impl<3, 64>(h, nT, time_stride, ang, lin, st);
+        if (F0 == 128) return score_impl<3, 128>(h, nT, time_stride, ang, lin, st);
+        return fail(h, DEDF_ERR_UNSUPPORTED, "lmax 3 with a 128-channel time embedding is not instantiated");
     }
     if (F0 == 64) return score_impl<2, 64>(h, nT, time_stride, ang, lin, st);
     if (F0 == 128) return score_impl<2, 128>(h, nT, time_stride, ang, lin, st);
@@ -520,14 +571,21 @@ int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, de
     h->L = cfg->lmax;
     h->host_only = cfg->device < 0;
     if (const char* e = getenv("DEDF_RADIAL_TABLE")) h->radial_table = std::max(0, std::min(2, atoi(e)));
-    if (h->L == 1) build_all<1>(h.get()); else build_all<2>(h.get());
+    const IrrepsRT T(h->L, cfg->unet_layer != 0), K(h->L, true);
+    h->spec = build_spec(T, h->cfg);
+    h->kspec = build_spec(K, h->cfg);
+    if (!(h->L == 1 ? irreps_consistent<1>(K) : (h->L == 2 ? irreps_consistent<2>(K) : irreps_consistent<3>(K)))) {
+        fprintf(stderr, "dedf_create: run-time irreps bookkeeping (dedf_pack.h::IrrepsRT) disagrees with dedf_net.h\n");
+        return DEDF_ERR_RUNTIME;
+    }
     if (!params || n_params != h->spec.total) {
         fprintf(stderr, "dedf_create: expected %zu parameters, got %zu\n", h->spec.total, n_params);
         return DEDF_ERR_INVALID;
     }
     h->params.assign(params, params + n_params);
     try {
-        if (h->L == 1) pack_all<1>(h.get()); else pack_all<2>(h.get());
+        h->kparams = pad_params(h->cfg, T, h->spec, K, h->kspec, h->params.data());
+        if (h->L == 1) pack_all<1>(h.get()); else if (h->L == 2) pack_all<2>(h.get()); else pack_all<3>(h.get());
     } catch (const std::exception& e) {
         fprintf(stderr, "dedf_create: %s\n", e.what());
         return DEDF_ERR_INVALID;
@@ -570,7 +628,7 @@ int dedf_set_key_clouds(dedf_handle* h, int n_scales, const int* n_pts, const fl
     if (n_scales != h->cfg.n_scales) return fail(h, DEDF_ERR_INVALID, "len(key_pcd_multiscale) != n_scales");
     hipStream_t st = static_cast<hipStream_t>(stream);
     DEDF_ON_DEVICE(h);
-    const size_t D = h->L == 1 ? feat_dim<1>() : feat_dim<2>();
+    const size_t D = feat_dim_rt(h->L), Dt = true_feat_dim_rt(h->L);      // key features arrive in the true shapes; the message leaves in the kernel layout
     int total = 0;
     for (int n = 0; n < n_scales; ++n) {
         if (n_pts[n] < 0 || (n_pts[n] > 0 && (!x[n] || !f[n]))) return fail(h, DEDF_ERR_INVALID, "bad key cloud");
@@ -581,20 +639,23 @@ int dedf_set_key_clouds(dedf_handle* h, int n_scales, const int* n_pts, const fl
     if (total <= 0) return fail(h, DEDF_ERR_INVALID, "empty key clouds");
     if ((size_t)total * D * 4 >= (1ull << 32)) return fail(h, DEDF_ERR_INVALID, "key clouds too large");
     h->n_keys = total;
-    if (!h->d_key_x.ensure((size_t)total * 3 * 4) || !h->d_key_f.ensure((size_t)total * D * 4) || !h->d_msg.ensure((size_t)total * D * 4))
+    if (!h->d_key_x.ensure((size_t)total * 3 * 4) || !h->d_key_f.ensure((size_t)total * Dt * 4) || !h->d_msg.ensure((size_t)total * D * 4))
         return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(key clouds) failed");
     for (int n = 0; n < n_scales; ++n) {
         if (n_pts[n] == 0) continue;
         HIPCK(h, hipMemcpyAsync(h->d_key_x.as<float>() + (size_t)h->scale_start[n] * 3, x[n], (size_t)n_pts[n] * 3 * 4, hipMemcpyDeviceToDevice, st));
-        HIPCK(h, hipMemcpyAsync(h->d_key_f.as<float>() + (size_t)h->scale_start[n] * D, f[n], (size_t)n_pts[n] * D * 4, hipMemcpyDeviceToDevice, st));
+        HIPCK(h, hipMemcpyAsync(h->d_key_f.as<float>() + (size_t)h->scale_start[n] * Dt, f[n], (size_t)n_pts[n] * Dt * 4, hipMemcpyDeviceToDevice, st));
     }
     const float* nat = h->d_nat.as<float>();
     if (h->L == 1)
         hipLaunchKernelGGL(k_src_message<1>, dim3(total), dim3(64), 0, st, h->d_key_f.as<float>(), total, nat + h->nat_lnw, nat + h->nat_lnb,
                            nat + h->nat_wsrc, nat + h->nat_bsrc, h->d_msg.as<float>());
-    else
+    else if (h->L == 2)
         hipLaunchKernelGGL(k_src_message<2>, dim3(total), dim3(64), 0, st, h->d_key_f.as<float>(), total, nat + h->nat_lnw, nat + h->nat_lnb,
                            nat + h->nat_wsrc, nat + h->nat_bsrc, h->d_msg.as<float>());
+    else
+        hipLaunchKernelGGL((k_src_message<3, true, true>), dim3(total), dim3(64), 0, st, h->d_key_f.as<float>(), total, nat + h->nat_lnw, nat + h->nat_lnb,
+                           nat + h->nat_wsrc, nat + h->nat_bsrc, h->d_msg.as<float>(), 0, 0, 0, 0);
     HIPCK(h, hipStreamSynchronize(st));
     h->have_keys = true;
     h->have_key_w = false;
@@ -626,10 +687,15 @@ int dedf_set_query(dedf_handle* h, int nQ, const float* x, const float* f, const
     if (!w) return fail(h, DEDF_ERR_INVALID, "query_pcd.w is required (score_head.py:156-157)");
     hipStream_t st = static_cast<hipStream_t>(stream);
     DEDF_ON_DEVICE(h);
-    const size_t D = h->L == 1 ? feat_dim<1>() : feat_dim<2>();
+    const size_t D = feat_dim_rt(h->L), Dt = true_feat_dim_rt(h->L);
     if (!h->d_qx.ensure((size_t)nQ * 3 * 4) || !h->d_qf.ensure((size_t)nQ * D * 4) || !h->d_qw.ensure((size_t)nQ * 4))
         return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(query) failed");
     HIPCK(h, hipMemcpyAsync(h->d_qx.p, x, (size_t)nQ * 3 * 4, hipMemcpyDeviceToDevice, st));
+    if (h->L == 3) {      // true shapes (8x3e) -> kernel layout (16x3e, zero-padded)
+        if (!h->d_qf_true.ensure((size_t)nQ * Dt * 4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(query) failed");
+        HIPCK(h, hipMemcpyAsync(h->d_qf_true.p, f, (size_t)nQ * Dt * 4, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_pad_features<3>, dim3((unsigned)(((size_t)nQ * D + 255) / 256)), dim3(256), 0, st, h->d_qf_true.as<float>(), h->d_qf.as<float>(), nQ);
+    } else
     HIPCK(h, hipMemcpyAsync(h->d_qf.p, f, (size_t)nQ * D * 4, hipMemcpyDeviceToDevice, st));
     HIPCK(h, hipMemcpyAsync(h->d_qw.p, w, (size_t)nQ * 4, hipMemcpyDeviceToDevice, st));
     HIPCK(h, hipStreamSynchronize(st));
@@ -683,7 +749,7 @@ int dedf_field(dedf_handle* h, int n, const float* x, float* field_out, float* e
     if (n <= 0 || !x || !field_out) return fail(h, DEDF_ERR_INVALID, "bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     DEDF_ON_DEVICE(h);
-    const size_t D = h->L == 1 ? feat_dim<1>() : feat_dim<2>();
+    const size_t D = feat_dim_rt(h->L), Dt = true_feat_dim_rt(h->L);
     // the points become the query cloud of ONE identity pose; their features / weights only feed the energy, which is discarded
     if (!h->d_qx.ensure((size_t)n * 3 * 4) || !h->d_qf.ensure((size_t)n * D * 4) || !h->d_qw.ensure((size_t)n * 4))
         return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(query) failed");
@@ -701,8 +767,11 @@ int dedf_field(dedf_handle* h, int n, const float* x, float* field_out, float* e
     rc = score_dispatch(h, 1, 0, h->d_ang.as<float>(), nullptr, st);
     h->want_field = false;
     if (rc != DEDF_OK) return rc;
-    const int nb = (int)(((size_t)n * D + 255) / 256);
-    if (h->L == 1) {
+    const int nb = (int)(((size_t)n * Dt + 255) / 256);
+    if (h->L == 3) {
+        hipLaunchKernelGGL(k_internal_to_ref<3>, dim3(nb), dim3(256), 0, st, h->d_dbgf.as<float>(), field_out, n);
+        if (emb_out) hipLaunchKernelGGL(k_internal_to_ref<3>, dim3(nb), dim3(256), 0, st, h->d_dbge.as<float>(), emb_out, n);
+    } else if (h->L == 1) {
         hipLaunchKernelGGL(k_internal_to_ref<1>, dim3(nb), dim3(256), 0, st, h->d_dbgf.as<float>(), field_out, n);
         if (emb_out) hipLaunchKernelGGL(k_internal_to_ref<1>, dim3(nb), dim3(256), 0, st, h->d_dbge.as<float>(), emb_out, n);
     } else {
@@ -774,14 +843,12 @@ int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedul
     return DEDF_OK;
 }
 
-int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const float* f_src, int n_dst, const float* x_dst, const float* f_dst,
+}  // extern "C"
+
+namespace {
+template <int L>
+int layer_forward_impl(dedf_handle* h, int n_src, const float* x_src, const float* f_src, int n_dst, const float* x_dst, const float* f_dst,
                        int64_t n_edges, const int64_t* edge_src, const int64_t* edge_dst, float* out, void* stream) {
-    if (!h) return DEDF_ERR_INVALID;
-    if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
-    if (!h->cfg.unet_layer) return fail(h, DEDF_ERR_UNSUPPORTED, "dedf_layer_forward needs a handle created with dedf_config.unet_layer = 1");
-    if (n_src <= 0 || n_dst <= 0 || n_edges < 0 || !x_src || !f_src || !x_dst || !f_dst || !out || (n_edges > 0 && (!edge_src || !edge_dst)))
-        return fail(h, DEDF_ERR_INVALID, "bad arguments");
-    constexpr int L = 2;
     constexpr size_t D = feat_dim<L>(), REC = edge_rec<L>();
     if ((size_t)n_src * D * 4 >= (1ull << 32) || (size_t)n_dst * D * 4 >= (1ull << 32) || n_edges >= 0x7fffffff - 64)
         return fail(h, DEDF_ERR_INVALID, "graph too large for one call");
@@ -832,8 +899,8 @@ int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const floa
         P.key_w = nullptr;
         P.out = h->d_eout.as<float>();
         P.dbg_w = nullptr; P.dbg_out = nullptr; P.phase_prof = nullptr;
-        if (h->cfg.half_gemm) hipLaunchKernelGGL((k_edge<2, 64, true, 32, 32, true>), dim3(h->n_cu * 4), dim3(64), 0, st, P);
-        else hipLaunchKernelGGL((k_edge<2, 64, false, 32, 32, true>), dim3(h->n_cu * 4), dim3(64), 0, st, P);
+        if (h->cfg.half_gemm) hipLaunchKernelGGL((k_edge<L, 64, true, 32, 32, true>), dim3(h->n_cu * 4), dim3(64), 0, st, P);
+        else hipLaunchKernelGGL((k_edge<L, 64, false, 32, 32, true>), dim3(h->n_cu * 4), dim3(64), 0, st, P);
     }
     hipLaunchKernelGGL(k_aggregate<L>, dim3((n_dst + 3) / 4), dim3(256), 0, st, h->d_eout.as<float>(), h->d_cnt.as<int>(), h->d_off.as<int>(),
                        h->d_tile.as<int>(), n_dst, 1, h->d_z.as<float>());
@@ -843,7 +910,7 @@ int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const floa
         P.f_dst = f_dst; P.f_dst_bytes = (uint32_t)((size_t)n_dst * D * 4);
         P.feat_out = out;
         P.nQ = 1; P.n_nodes = n_dst; P.lin_mult = 1.0f;
-        for (int l = 0; l < 3; ++l) P.ln_inv_n[l] = 1.0f / (float)(c.unet_valid[l] > 0 ? c.unet_valid[l] : c.mul[l]);
+        for (int l = 0; l <= L; ++l) P.ln_inv_n[l] = 1.0f / (float)(c.unet_valid[l] > 0 ? c.unet_valid[l] : c.mul[l]);
         P.ln_pad0 = (float)(c.mul[0] - (c.unet_valid[0] > 0 ? c.unet_valid[0] : c.mul[0]));
         P.W = h->d_node_w.as<float>(); P.W_bytes = (uint32_t)h->d_node_w.bytes;
         const NodeOffsets& o = h->no;
@@ -854,8 +921,8 @@ int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const floa
         P.sc = o.sc;
         P.o_b_proj0 = o.o_b_proj0; P.o_ln_b0 = o.o_ln_b0; P.o_b_f1 = o.o_b_f1; P.o_b_f2 = o.o_b_f2;
         const int ntiles = (n_dst + 31) / 32;
-        if (h->cfg.half_gemm) hipLaunchKernelGGL((k_node<2, false, true, true>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
-        else hipLaunchKernelGGL((k_node<2, false, false, true>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
+        if (h->cfg.half_gemm) hipLaunchKernelGGL((k_node<L, false, true, true>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
+        else hipLaunchKernelGGL((k_node<L, false, false, true>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
     }
     if (h->defer_check) {          // chains of layers: the verdict of the edge-list check is kept on the device for dedf_layer_check
         if (!h->d_sticky.p) {
@@ -872,6 +939,20 @@ int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const floa
     HIPCK(h, hipMemcpy(&bad, h->d_tile.as<int>() + kFlagBadEdges, 4, hipMemcpyDeviceToHost));
     if (bad) return fail(h, DEDF_ERR_INVALID, "edge lists: edge_dst must be sorted ascending and every index inside its cloud");
     return DEDF_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const float* f_src, int n_dst, const float* x_dst, const float* f_dst,
+                       int64_t n_edges, const int64_t* edge_src, const int64_t* edge_dst, float* out, void* stream) {
+    if (!h) return DEDF_ERR_INVALID;
+    if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
+    if (!h->cfg.unet_layer) return fail(h, DEDF_ERR_UNSUPPORTED, "dedf_layer_forward needs a handle created with dedf_config.unet_layer = 1");
+    if (n_src <= 0 || n_dst <= 0 || n_edges < 0 || !x_src || !f_src || !x_dst || !f_dst || !out || (n_edges > 0 && (!edge_src || !edge_dst)))
+        return fail(h, DEDF_ERR_INVALID, "bad arguments");
+    if (h->L == 3) return layer_forward_impl<3>(h, n_src, x_src, f_src, n_dst, x_dst, f_dst, n_edges, edge_src, edge_dst, out, stream);
+    return layer_forward_impl<2>(h, n_src, x_src, f_src, n_dst, x_dst, f_dst, n_edges, edge_src, edge_dst, out, stream);
 }
 
 int dedf_set_radial_table(dedf_handle* h, int on) {
@@ -964,9 +1045,7 @@ int dedf_debug_copy(dedf_handle* h, const char* name, void* host_dst, size_t max
     if (!h || !name) return DEDF_ERR_INVALID;
     if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
     const std::string nm(name);
-    const size_t D = h->L == 1 ? feat_dim<1>() : feat_dim<2>();
-    const size_t REC = h->L == 1 ? edge_rec<1>() : edge_rec<2>();
-    const size_t WN = h->L == 1 ? dtp_wn<1>() : dtp_wn<2>();
+    const size_t D = feat_dim_rt(h->L), REC = edge_rec_rt(h->L), WN = dtp_wn_rt(h->L);      // kernel layout (lmax 3: 16x3e)
     const size_t Nd = (size_t)h->last_nT * h->nQ;
     HIPCK(h, hipDeviceSynchronize());
     int ti[64] = {0};
@@ -976,7 +1055,7 @@ int dedf_debug_copy(dedf_handle* h, const char* name, void* host_dst, size_t max
     size_t n = 0;
     if (nm == "msg") { src = h->d_msg.p; n = (size_t)h->n_keys * D * 4; }
     else if (nm == "qpos") { src = h->d_qpos.p; n = Nd * 3 * 4; }
-    else if (nm == "pose") { src = h->d_pose.p; n = (size_t)h->last_nT * kPoseRec * 4; }
+    else if (nm == "pose") { src = h->d_pose.p; n = (size_t)h->last_nT * pose_rec_rt(h->L) * 4; }
     else if (nm == "tb") { src = h->d_tb.p; n = (size_t)h->last_nT * h->cfg.n_scales * h->cfg.fc_neurons[0] * 4; }
     else if (nm == "edge_src") { src = h->d_esrc.p; n = E * 4; }
     else if (nm == "edge_dst") { src = h->d_edst.p; n = E * 4; }
@@ -1007,14 +1086,21 @@ int dedf_debug_packed(dedf_handle* h, const char* which, const float** ptr, size
 }
 
 // ---- per-node LayerNorm + LinearRS (no handle; current device; device pointers) --------------------------------------------------
+int dedf_linear_rs_lmax(int lmax, const float* f, int n, const float* ln_w, const float* ln_b, const float* W, const float* bias, const int* valid,
+                        float* out, void* stream) {
+    if (!f || !W || !out || n <= 0 || ((ln_w == nullptr) != (ln_b == nullptr)) || (lmax != 2 && lmax != 3)) return DEDF_ERR_INVALID;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int v0 = valid ? valid[0] : 0, v1 = valid ? valid[1] : 0, v2 = valid ? valid[2] : 0, v3 = valid && lmax == 3 ? valid[3] : 0;
+    if (lmax == 3) {
+        if (ln_w) hipLaunchKernelGGL((k_src_message<3, true>), dim3(n), dim3(64), 0, st, f, n, ln_w, ln_b, W, bias, out, v0, v1, v2, v3);
+        else hipLaunchKernelGGL((k_src_message<3, false>), dim3(n), dim3(64), 0, st, f, n, ln_w, ln_b, W, bias, out, 0, 0, 0, 0);
+    } else if (ln_w) hipLaunchKernelGGL((k_src_message<2, true>), dim3(n), dim3(64), 0, st, f, n, ln_w, ln_b, W, bias, out, v0, v1, v2, 0);
+    else hipLaunchKernelGGL((k_src_message<2, false>), dim3(n), dim3(64), 0, st, f, n, ln_w, ln_b, W, bias, out, 0, 0, 0, 0);
+    return hipGetLastError() == hipSuccess ? DEDF_OK : DEDF_ERR_RUNTIME;
+}
 int dedf_linear_rs(const float* f, int n, const float* ln_w, const float* ln_b, const float* W, const float* bias, const int* valid,
                    float* out, void* stream) {
-    if (!f || !W || !out || n <= 0 || ((ln_w == nullptr) != (ln_b == nullptr))) return DEDF_ERR_INVALID;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const int v0 = valid ? valid[0] : 0, v1 = valid ? valid[1] : 0, v2 = valid ? valid[2] : 0;
-    if (ln_w) hipLaunchKernelGGL((k_src_message<2, true>), dim3(n), dim3(64), 0, st, f, n, ln_w, ln_b, W, bias, out, v0, v1, v2);
-    else hipLaunchKernelGGL((k_src_message<2, false>), dim3(n), dim3(64), 0, st, f, n, ln_w, ln_b, W, bias, out, 0, 0, 0);
-    return hipGetLastError() == hipSuccess ? DEDF_OK : DEDF_ERR_RUNTIME;
+    return dedf_linear_rs_lmax(2, f, n, ln_w, ln_b, W, bias, valid, out, stream);
 }
 
 // ---- graph primitives of the feature extractors (no handle; current device; device pointers) ------------------------------------

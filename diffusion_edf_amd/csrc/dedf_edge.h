@@ -85,7 +85,7 @@ template <int L> struct SH {           // spherical harmonics of one edge, non-s
 // (k_edge prologue) and reads them back with broadcast ds_read_b128.  Offsets in floats, layout [tile][half][16] as packed.
 template <int L> struct RowsLds {
     static constexpr int b1 = 0, g1 = 128, be1 = 256, b2 = 384, g2 = 448, be2 = 512, off3 = 576;
-    static constexpr int b0 = off3 + dtp_wn<L>(), val0 = b0 + r0_tiles<L>() * 32, adot = val0 + 64;
+    static constexpr int b0 = off3 + rup(dtp_wn<L>(), 32), val0 = b0 + r0_tiles<L>() * 32, adot = val0 + 64;
     static constexpr int enc = adot + 64, total = enc + 192;      // enc: length-encoder constants of the scale being processed
 };
 template <int L> DEDF_DEV float* rows_lds() {
@@ -161,7 +161,7 @@ DEDF_DEV AItem load_item(const Wave& wv, int o_str) {
         static_for<it.ntile>([&]<int n>() {
             // rows 16-31 of this operand are padding: the 16-channel l = 2 outputs, and the last lin tile (112 = 3.5 x 32 rows)
             constexpr int l3 = dtp_pos_l3<L>(it.pos);
-            constexpr bool half_rows = l3 == 2 || (l3 == 0 && NT0 == r0_tiles<L>() && lin0_rows<L>() % 32 == 16 && 2 * it.t + n == lin0_rows<L>() / 32);
+            constexpr bool half_rows = l3 >= 2 || (l3 == 0 && NT0 == r0_tiles<L>() && lin0_rows<L>() % 32 == 16 && 2 * it.t + n == lin0_rows<L>() / 32);
             const int lv = half_rows ? wv.lane16_r16 : wv.lane16;
             a.h[n] = bld4(wv.w, lv, (o_str + (it.slot + n) * 512) * 4);
             if constexpr (!HP) a.l[n] = bld4(wv.w, lv, (o_str + (it.slot + n) * 512 + 256) * 4);
@@ -176,11 +176,11 @@ DEDF_DEV AItem load_item(const Wave& wv, int o_str) {
 // scalar inputs (one component), one tile per product term, so that consecutive MFMAs still hit different accumulators.
 template <int L, int NT0, int C, bool HP, int PD>
 DEDF_DEV void mfma_chunk(const Wave& wv, int o_str, AItem (&ring)[PD], const BOpsH<L>& bo, f32x16 (&acc0)[NT0], f32x16 (&acc1)[3], f32x16 (&acc2)[5],
-                         f32x16 (&go)[3]) {
+                         f32x16 (&acc3)[7], f32x16 (&go)[3]) {
     constexpr int l3 = dtp_pos_l3<L>(C), I0 = dtp_item_first<L>(C, NT0), NI = l3 == 0 ? cdiv(NT0, 2) : 1;
     if constexpr (dtp_pos_out<L>(C)) {
         constexpr int d1 = 2 * dtp_pos_path<L>(C).l1 + 1;
-        static_assert(d1 == 1 || d1 == 3, "output-side paths of lmax <= 2");
+        static_assert(d1 == 1 || d1 == 3, "output-side paths have input degree 0 or 1");
         constexpr bool first = dtp_pos_path_first<L>(C);
         const AItem a = ring[I0 % PD];
         ring[I0 % PD] = load_item<L, NT0, I0 + PD, HP>(wv, o_str);
@@ -210,7 +210,7 @@ DEDF_DEV void mfma_chunk(const Wave& wv, int o_str, AItem (&ring)[PD], const BOp
             }
         } else {
             constexpr int d3 = 2 * l3 + 1;
-            auto& accm = [&]() -> auto& { if constexpr (l3 == 1) return acc1; else return acc2; }();
+            auto& accm = [&]() -> auto& { if constexpr (l3 == 1) return acc1; else if constexpr (l3 == 2) return acc2; else return acc3; }();
             const h8 ah = __builtin_bit_cast(h8, a.h[0]), al = __builtin_bit_cast(h8, a.l[0]);
             static_for<d3>([&]<int K>() { accm[K] = mfma_h(ah, bo.hi[K], accm[K]); });
             if constexpr (!HP) {
@@ -234,7 +234,7 @@ DEDF_DEV void edge_rows_to_lds(const EdgeParams& P, const Wave& wv) {
     auto cp = [&](int dst, int src, int n) { for (int i = wv.lane; i < n; i += 64) rows[dst + i] = P.W[src + i]; };
     cp(RL::b1, P.o_b_r1, H1); cp(RL::g1, P.o_g_r1, H1); cp(RL::be1, P.o_be_r1, H1);
     cp(RL::b2, P.o_b_r2, H2); cp(RL::g2, P.o_g_r2, H2); cp(RL::be2, P.o_be_r2, H2);
-    cp(RL::off3, P.o_off_r3, dtp_wn<L>()); cp(RL::b0, P.o_b_r0, r0_tiles<L>() * 32);
+    cp(RL::off3, P.o_off_r3, rup(dtp_wn<L>(), 32)); cp(RL::b0, P.o_b_r0, r0_tiles<L>() * 32);
     cp(RL::val0, P.o_b_val0, 64); cp(RL::adot, P.o_alpha_dot, 64);
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -275,7 +275,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     constexpr int D = feat_dim<L>();
     constexpr int REC = edge_rec<L>();
     constexpr int WN = dtp_wn<L>();
-    constexpr int NWT = WN / 32;
+    constexpr int NWT = cdiv(WN, 32);      // (lmax 3: 880 rows = 27.5 tiles, the last half tile is zero rows)
     constexpr int NR0 = r0_tiles<L>();
     const int hi = wv.hi;
     using RL = RowsLds<L>;
@@ -343,7 +343,19 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             Y.y2[3] = s5 * s3 * uy * uz * cns;
             Y.y2[4] = s5 * s3 * 0.5f * (uz * uz - ux * ux) * cns;
         }
-        static_assert(L <= 2, "l = 3 spherical harmonics are a next-row item");
+        if constexpr (L >= 3) {      // e3nn component normalisation, y polar (diffusion_edf_amd/so3.py::spherical_harmonics)
+            const float a = ux * uz, b = 0.5f * (uz * uz - ux * ux), rho = ux * ux + uz * uz;
+            const float c0 = 4.183300132670378f /* sqrt(35/2) */, c1 = 10.246950765959598f /* sqrt(105) */, c2 = 1.620185174601965f /* sqrt(21/8) */,
+                        c3 = 1.3228756555322954f /* sqrt(7)/2 */;
+            Y.y3[0] = c0 * (a * uz + b * ux) * cns;
+            Y.y3[1] = c1 * a * uy * cns;
+            Y.y3[2] = c2 * (4.0f * uy * uy - rho) * ux * cns;
+            Y.y3[3] = c3 * uy * (2.0f * uy * uy - 3.0f * rho) * cns;
+            Y.y3[4] = c2 * uz * (4.0f * uy * uy - rho) * cns;
+            Y.y3[5] = c1 * b * uy * cns;
+            Y.y3[6] = c0 * (b * uz - a * ux) * cns;
+        }
+        static_assert(L <= 3, "spherical harmonics up to l = 3");
     }
 
     constexpr int NPS = park_slots<L>(), SPW = 2 * NPS, NSLOT = SPW + 2;      // SPW: segment softmax weights / normalisers
@@ -485,12 +497,12 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // lin scalars + gates | alpha), then l3 = 1 into acc1, then l3 = 2 into acc2 (one tile per m).
     // When a group is complete its activations (logits, Gate) are computed and the gated features parked in LDS (this
     // wave's private 30 KB) until the second depth-wise TP reads them.
-    f32x16 acc0[NR0], acc1[3], acc2[5];
+    f32x16 acc0[NR0], acc1[3], acc2[5], acc3[7];
     const Buf msgb = make_buf(P.msg, P.msg_bytes);
     const Buf msgd = make_buf(P.msg_dst, P.msg_dst_bytes);      // UNet layer: the destination's message is added (block.py:155)
     // per-l1 lane offsets of the 4 message rows this lane owns inside an 8-row group
-    const int mv0 = src * (D * 4) + hi * 16, mv1 = src * (D * 4) + hi * 48, mv2 = src * (D * 4) + hi * 80;
-    const int dv0 = dst * (D * 4) + hi * 16, dv1 = dst * (D * 4) + hi * 48, dv2 = dst * (D * 4) + hi * 80;
+    const int mv0 = src * (D * 4) + hi * 16, mv1 = src * (D * 4) + hi * 48, mv2 = src * (D * 4) + hi * 80, mv3 = src * (D * 4) + hi * 112;
+    const int dv0 = dst * (D * 4) + hi * 16, dv1 = dst * (D * 4) + hi * 48, dv2 = dst * (D * 4) + hi * 80, dv3 = dst * (D * 4) + hi * 112;
     // LDS parking: the gated features wait here as READY-MADE B operands of the value GEMMs: one 16-byte slot per lane holds the
     // fp16 hi halves of a 16-channel chunk (8 accumulator registers), the next slot their fp16 residuals ([slot][lane][8 halves];
     // chunk q = dedf_net.h::park_slot(degree, component, chunk) -> slots 2q | 2q + 1), lane-private
@@ -512,12 +524,12 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         if constexpr (C < NCHK) {
             constexpr PathInfo pi = dtp_pos_path<L>(C);
             constexpr int l1 = pi.l1, d1 = 2 * l1 + 1, u0 = dtp_pos_u0<L>(C);
-            const int mv = l1 == 0 ? mv0 : (l1 == 1 ? mv1 : mv2);
+            const int mv = l1 == 0 ? mv0 : (l1 == 1 ? mv1 : (l1 == 2 ? mv2 : mv3));
             static_for<2>([&]<int run>() { static_for<d1>([&]<int Q>() {
                 o.x[run][Q] = bld4(msgb, mv, (blk_off(l1) + (u0 + 8 * run) * d1 + 4 * Q) * 4);
             }); });
             if constexpr (UN) {
-                const int dv = l1 == 0 ? dv0 : (l1 == 1 ? dv1 : dv2);
+                const int dv = l1 == 0 ? dv0 : (l1 == 1 ? dv1 : (l1 == 2 ? dv2 : dv3));
                 static_for<2>([&]<int run>() { static_for<d1>([&]<int Q>() {
                     o.xd[run][Q] = bld4(msgd, dv, (blk_off(l1) + (u0 + 8 * run) * d1 + 4 * Q) * 4);
                 }); });
@@ -601,13 +613,15 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     };
     auto dump_w = [&]<int Tw>(const f32x16& w) {      // debug only: back to the e3nn weight order
         if (P.dbg_w != nullptr && valid)
-            static_for<16>([&]<int R>() { P.dbg_w[(size_t)e * WN + dtp_walk_row<L>(Tw * 32 + (R & 3) + 8 * (R >> 2)) + 4 * hi] = w[R] * P.w_unscale; });
+            static_for<16>([&]<int R>() {
+                if constexpr (Tw * 32 + (R & 3) + 8 * (R >> 2) < WN) P.dbg_w[(size_t)e * WN + dtp_walk_row<L>(Tw * 32 + (R & 3) + 8 * (R >> 2)) + 4 * hi] = w[R] * P.w_unscale;
+            });
     };
 
     // Output-side paths (dedf_net.h::dtp_path_out_side): G tiles of the path in flight, VALU-side sums of the contracted results per
     // output degree, and the contraction of a completed path  vacc[k] += (sum_j C_ijk Y_j) G_i  (one region after its last MFMAs).
     f32x16 go[3], gfin[3];
-    float vacc1[3][16], vacc2[5][8];
+    float vacc1[3][16], vacc2[5][8], vacc3[7][8];
     auto contract_out = [&]<int Ce>(f32x16 (&G)[3]) {
         constexpr PathInfo pi = dtp_pos_path<L>(Ce);
         constexpr int l1 = pi.l1, l2 = pi.l2, l3 = pi.l3, d1 = 2 * l1 + 1, d3 = 2 * l3 + 1;
@@ -620,21 +634,22 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             static_for<d3>([&]<int K>() {
                 if constexpr (dtp_pos_opens_vacc<L>(Ce)) o[K] = 0.0f;
                 else if constexpr (l3 == 1) o[K] = vacc1[K][R];
-                else o[K] = vacc2[K][R];
+                else if constexpr (l3 == 2) o[K] = vacc2[K][R];
+                else o[K] = vacc3[K][R];
             });
             if constexpr (d1 == 1) Cg::template acc<0>(HP ? G[0][R] : (G[0][R] + G[1][R]) + G[2][R], m, o);      // the three product terms
             else static_for<d1>([&]<int I>() { Cg::template acc<I>(G[I][R], m, o); });
             static_for<d3>([&]<int K>() {
                 opaque_v(o[K]);      // accumulate here (see the value stage)
-                if constexpr (l3 == 1) vacc1[K][R] = o[K]; else vacc2[K][R] = o[K];
+                if constexpr (l3 == 1) vacc1[K][R] = o[K]; else if constexpr (l3 == 2) vacc2[K][R] = o[K]; else vacc3[K][R] = o[K];
             });
         });
     };
 
     // activations of a completed group ----------------------------------------------------------------------------------
     // (the accumulators carry the power-of-two operand scales: c_lin brings them back, the parked features carry u_scale)
-    float logit[kHeads], g1[16], g2[8];
-    const float cl0 = opaque_s(P.c_lin[0]), us = opaque_s(P.u_scale), cl1 = opaque_s(P.c_lin[1]), cl2 = opaque_s(P.c_lin[L >= 2 ? 2 : 0]);
+    float logit[kHeads], g1[16], g2[8], g3[8];
+    const float cl0 = opaque_s(P.c_lin[0]), us = opaque_s(P.u_scale), cl1 = opaque_s(P.c_lin[1]), cl2 = opaque_s(P.c_lin[L >= 2 ? 2 : 0]), cl3 = opaque_s(P.c_lin[L >= 3 ? 3 : 0]);
     auto finish_group = [&]<int l3>() {
         if constexpr (l3 == 0) {
             // attention logits (graph_attention.py:233-246): heads of sep_alpha -> SmoothLeakyReLU -> . alpha_dot + log cut-off
@@ -677,6 +692,13 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 sigmoid_stage<8>(x8, g2);
                 static_for<8>([&]<int R>() { g2[R] = g2[R] * (kNormSigmoid * (cl2 * us)); });
             }
+            if constexpr (L >= 3) {
+                constexpr int G0 = gate_row(3, 0);
+                float x8[8];
+                static_for<8>([&]<int R>() { x8[R] = acc0[G0 / 32][(G0 % 32) / 2 + R] * cl0; });
+                sigmoid_stage<8>(x8, g3);
+                static_for<8>([&]<int R>() { g3[R] = g3[R] * (kNormSigmoid * (cl3 * us)); });
+            }
         } else if constexpr (l3 == 1) {
             static_for<3>([&]<int K>() { static_for<2>([&]<int hf>() {
                 float v[8];
@@ -686,7 +708,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 });
                 park_chunk.template operator()<park_slot<L>(1, K, hf)>(v);
             }); });
-        } else {
+        } else if constexpr (l3 == 2) {
             static_for<5>([&]<int K>() {      // 16 channels = registers 0-7
                 float v[8];
                 static_for<8>([&]<int J>() {
@@ -694,11 +716,20 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 });
                 park_chunk.template operator()<park_slot<L>(2, K, 0)>(v);
             });
+        } else {
+            static_for<7>([&]<int K>() {      // 16 channels (8 of them the zero padding of 8x3e) = registers 0-7
+                float v[8];
+                static_for<8>([&]<int J>() {
+                    if constexpr (dtp_group_has_out<L>(3)) v[J] = (acc3[K][J] + vacc3[K][J]) * g3[J]; else v[J] = acc3[K][J] * g3[J];
+                });
+                park_chunk.template operator()<park_slot<L>(3, K, 0)>(v);
+            });
         }
     };
     auto start_group = [&]<int l3>() {
         if constexpr (l3 == 1) static_for<3>([&]<int K>() { static_for<16>([&]<int R>() { acc1[K][R] = 0.0f; }); });
         if constexpr (l3 == 2) static_for<5>([&]<int K>() { static_for<16>([&]<int R>() { acc2[K][R] = 0.0f; }); });
+        if constexpr (l3 == 3) static_for<7>([&]<int K>() { static_for<16>([&]<int R>() { acc3[K][R] = 0.0f; }); });
     };
 
     DEDF_STAMP(6);
@@ -756,14 +787,14 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         const BOpsH<L> b_nxt = valu_chunk.template operator()<C + 1>(x_nxt, wbuf[((C + 1) / 2) % 2]);
         constexpr bool fin_out = C >= 1 && dtp_pos_out<L>(C - 1) && dtp_pos_path_last<L>(C - 1);      // an output-side path ended at C - 1
         if constexpr (fin_out) static_for<3>([&]<int a>() { gfin[a] = go[a]; });
-        mfma_chunk<L, NR0, C, HP>(wv, o_S_lin, ring, b_cur, acc0, acc1, acc2, go);
+        mfma_chunk<L, NR0, C, HP>(wv, o_S_lin, ring, b_cur, acc0, acc1, acc2, acc3, go);
         if constexpr (fin_out) contract_out.template operator()<C - 1>(gfin);
         static_for<L + 1>([&]<int g>() { if constexpr (C == dtp_group_end<L>(g)) finish_group.template operator()<g>(); });
         sched_fence();
         if constexpr (Ph % 2 == 1 && T3 < NWT) dump_w.template operator()<T3>(wbuf[T3 % 2]);
         x_nxt = x_nn; b_cur = b_nxt;
         if constexpr (C + 1 == dtp_group_end<L>(0)) DEDF_STAMP(8);
-        if constexpr (L >= 2 && C + 1 == dtp_group_end<L>(1)) DEDF_STAMP(9);
+        if constexpr (L == 2 && C + 1 == dtp_group_end<L>(1)) DEDF_STAMP(9);
     });
     if constexpr (dtp_pos_out<L>(NCHK - 1)) contract_out.template operator()<NCHK - 1>(go);
     finish_group.template operator()<L>();
@@ -786,14 +817,14 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // G_i (one tile per component i of the input degree) are contracted with the edge's SH on the VALU into val0 / val1[m] /
     // val2[m]; paths are walked by output degree, a completed degree goes straight to the segment record.
     // (plain scalars, not 16-register tuples: the VALU updates them element by element)
-    float val0[2][16], val1[3][16], val2[5][8];
+    float val0[2][16], val1[3][16], val2[5][8], val3[7][8];
     static_for<2>([&]<int T>() { const f32x16 b = ldrows_lds(rows, hi, RL::val0, T); static_for<16>([&]<int R>() { val0[T][R] = b[R]; }); });
     // ---- joint-softmax partials --------------------------------------------------------------------------------------------
     // The tile's edges are ordered by destination, so the edges of one destination form a run of lanes ("segment").  Instead
     // of one 976-byte record per edge, the tile emits one per segment: the segment's softmax-weighted mean value and the
     // log-sum-exp of its logits -- k_aggregate merges them exactly as it would merge edges (softmax of softmaxes).  Segmented
     // scans over the 32 edge columns of each half-wave run on ds_bpermute lane shuffles (no LDS memory involved).
-    const float cv0 = opaque_s(P.c_val[0]), cv1 = opaque_s(P.c_val[1]), cv2 = opaque_s(P.c_val[L >= 2 ? 2 : 0]);
+    const float cv0 = opaque_s(P.c_val[0]), cv1 = opaque_s(P.c_val[1]), cv2 = opaque_s(P.c_val[L >= 2 ? 2 : 0]), cv3 = opaque_s(P.c_val[L >= 3 ? 3 : 0]);
     // byte addresses of lane - s / lane + s (s = 1, 2, 4, 8, 16) are formed where they are used (ds_bpermute reads bits 7:2)
     const int lane4 = wv.lane * 4;
     auto sh_up_a = [&](int i) { return lane4 - (4 << i); };
@@ -909,12 +940,22 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 x[n] = x[n] * pw[g];
             }); });
             emit(x, ro, iv);
-        } else {
+        } else if constexpr (l3 == 2) {
             f32x4 x[10]; int ro[10]; float iv[10];
             static_for<5>([&]<int K>() { static_for<2>([&]<int g>() {        // 16 channels: head = 2 g + hi
                 constexpr int n = 2 * K + g;
                 ro[n] = blk_off(2) + K * mul_of(2) + 8 * g + 4 * hi; iv[n] = hi ? inv_s[2 * g + 1] : inv_s[2 * g];
                 x[n] = f32x4{val2[K][4 * g], val2[K][4 * g + 1], val2[K][4 * g + 2], val2[K][4 * g + 3]} * cv2;
+                if (drec != nullptr && valid) st4(drec + ro[n], x[n]);
+                x[n] = x[n] * (hi ? pw[2 * g + 1] : pw[2 * g]);
+            }); });
+            emit(x, ro, iv);
+        } else {
+            f32x4 x[14]; int ro[14]; float iv[14];
+            static_for<7>([&]<int K>() { static_for<2>([&]<int g>() {        // 16 (padded) channels: head = 2 g + hi
+                constexpr int n = 2 * K + g;
+                ro[n] = blk_off(3) + K * mul_of(3) + 8 * g + 4 * hi; iv[n] = hi ? inv_s[2 * g + 1] : inv_s[2 * g];
+                x[n] = f32x4{val3[K][4 * g], val3[K][4 * g + 1], val3[K][4 * g + 2], val3[K][4 * g + 3]} * cv3;
                 if (drec != nullptr && valid) st4(drec + ro[n], x[n]);
                 x[n] = x[n] * (hi ? pw[2 * g + 1] : pw[2 * g]);
             }); });
@@ -986,14 +1027,15 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 if constexpr (l3 == 0) o[K] = val0[it.t][R];
                 else if constexpr (val_item_opens_group<L>(I)) o[K] = 0.0f;
                 else if constexpr (l3 == 1) o[K] = val1[K][R];
-                else o[K] = val2[K][R];
+                else if constexpr (l3 == 2) o[K] = val2[K][R];
+                else o[K] = val3[K][R];
             });
             if constexpr (it.merge) Cg::template acc<0>(G[0][R] + G[1][R], m, o);
             else static_for<it.na>([&]<int a>() { Cg::template acc<it.comp[a]>(G[a][R], m, o); });
             // (opaque: the accumulation happens HERE -- hipcc otherwise defers it to the store of the block and keeps every G tile alive)
             static_for<d3>([&]<int K>() {
                 opaque_v(o[K]);
-                if constexpr (l3 == 0) val0[it.t][R] = o[K]; else if constexpr (l3 == 1) val1[K][R] = o[K]; else val2[K][R] = o[K];
+                if constexpr (l3 == 0) val0[it.t][R] = o[K]; else if constexpr (l3 == 1) val1[K][R] = o[K]; else if constexpr (l3 == 2) val2[K][R] = o[K]; else val3[K][R] = o[K];
             });
             if constexpr (R == NR - 1) tok = o[0];
         });
@@ -1018,7 +1060,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         sched_fence();
         vb_cur = b_nxt;
         if constexpr (F >= 0 && val_item<L>(F).group_end == 0) DEDF_STAMP(10);
-        if constexpr (L >= 2 && F >= 0 && val_item<L>(F).group_end == 1) DEDF_STAMP(13);
+        if constexpr (L == 2 && F >= 0 && val_item<L>(F).group_end == 1) DEDF_STAMP(13);
     });
     DEDF_STAMP(14);
     store_group.template operator()<L>();

@@ -111,5 +111,16 @@ template <int L, bool EBM, bool HP = false, bool UN = false> __global__ __launch
     X(14, void k_edge<2, 128, false, 32, 32, false, 1>(EdgeParams))   \
     X(10, void k_radial_table<2, 128, false, 32, 32>(EdgeParams))     \
     X(15, void k_edge<2, 64, true, 32, 32, true>(EdgeParams))         \
-    X(15, void k_node<2, false, true, true>(NodeParams))
-constexpr int kKernelUnits = 16;
+    X(15, void k_node<2, false, true, true>(NodeParams))               \
+    X(16, void k_edge<3, 128, false>(EdgeParams))                     \
+    X(17, void k_node<3, false, false>(NodeParams))                   \
+    X(18, void k_edge<3, 64, false>(EdgeParams))                      \
+    X(17, void k_node<3, true, false>(NodeParams))                    \
+    X(19, void k_edge<3, 64, false, 32, 32, true>(EdgeParams))        \
+    X(20, void k_node<3, false, false, true>(NodeParams))             \
+    X(21, void k_edge<3, 64, true, 32, 32, true>(EdgeParams))         \
+    X(20, void k_node<3, false, true, true>(NodeParams))              \
+    X(22, void k_edge<3, 128, false, 128, 64, false, 1>(EdgeParams))  \
+    X(23, void k_radial_table<3, 128>(EdgeParams))                    \
+    X(23, void k_edge<3, 64, false, 32, 32>(EdgeParams))
+constexpr int kKernelUnits = 24;

@@ -86,4 +86,45 @@
 #else
 #define DEDF_INST_15(...) DEDF_NOP(__VA_ARGS__)
 #endif
+#if DEDF_KUNIT == 16
+#define DEDF_INST_16(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_16(...) DEDF_NOP(__VA_ARGS__)
+#endif
+#if DEDF_KUNIT == 17
+#define DEDF_INST_17(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_17(...) DEDF_NOP(__VA_ARGS__)
+#endif
+#if DEDF_KUNIT == 18
+#define DEDF_INST_18(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_18(...) DEDF_NOP(__VA_ARGS__)
+#endif
+#if DEDF_KUNIT == 19
+#define DEDF_INST_19(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_19(...) DEDF_NOP(__VA_ARGS__)
+#endif
+#if DEDF_KUNIT == 20
+#define DEDF_INST_20(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_20(...) DEDF_NOP(__VA_ARGS__)
+#endif
+#if DEDF_KUNIT == 21
+#define DEDF_INST_21(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_21(...) DEDF_NOP(__VA_ARGS__)
+#endif
+#if DEDF_KUNIT == 22
+#define DEDF_INST_22(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_22(...) DEDF_NOP(__VA_ARGS__)
+#endif
+#if DEDF_KUNIT == 23
+#define DEDF_INST_23(...) DEDF_SEL(__VA_ARGS__)
+#else
+#define DEDF_INST_23(...) DEDF_NOP(__VA_ARGS__)
+#endif
 DEDF_KERNEL_LIST(DEDF_INST)
+static_assert(kKernelUnits == 24, "one DEDF_INST_n block per unit");

@@ -33,7 +33,7 @@ __device__ inline void wigner_from_angles(float a, float b, float c, float* D /*
         }
     }
     float A[n][n], Bm[n][n];
-    auto Jl = [](int i, int j) { if constexpr (LD == 1) return kJ1[i][j]; else return kJ2[i][j]; };
+    auto Jl = [](int i, int j) { if constexpr (LD == 1) return kJ1[i][j]; else if constexpr (LD == 2) return kJ2[i][j]; else return kJ3[i][j]; };
     // ((((Xa J) Xb) J) Xc)
     // every loop has constant bounds and is unrolled, so that the matrices live in registers (they went to scratch otherwise)
 #define DEDF_MM(OUT, LHS, RHS)                                   \
@@ -59,7 +59,7 @@ __global__ void k_pose_prep(const float* __restrict__ Ts, const double* __restri
     for (int k = 0; k < 7; ++k) T[k] = Ts64 != nullptr ? (float)Ts64[7 * (size_t)t + k] : Ts[7 * (size_t)t + k];
     const float qw = T[0], qi = T[1], qj = T[2], qk = T[3];
     if (threadIdx.x == 0) {
-        float* rec = pose + (size_t)t * kPoseRec;
+        float* rec = pose + (size_t)t * pose_rec<L>();
         rec[0] = qw; rec[1] = qi; rec[2] = qj; rec[3] = qk;
         const float nrm = sqrtf(qw * qw + qi * qi + qj * qj + qk * qk);       // torch.norm
         float r = qw / nrm, i = qi / nrm, j = qj / nrm, k = qk / nrm;
@@ -76,6 +76,7 @@ __global__ void k_pose_prep(const float* __restrict__ Ts, const double* __restri
         const float c = atan2f(R10, -R12);             // _angle_from_tan("Y","X", R[1,:], horizontal=True)
         wigner_from_angles<1>(a, b, c, rec + 4);
         if constexpr (L >= 2) wigner_from_angles<2>(a, b, c, rec + 16);
+        if constexpr (L >= 3) wigner_from_angles<3>(a, b, c, rec + 48);
     }
     for (int q = threadIdx.x; q < nQ; q += blockDim.x) {
         // quaternion_apply(q, p) = (q * (0,p)) * conj(q)   with the reference's raw products (transforms.py:113-165)
@@ -150,25 +151,29 @@ __global__ __launch_bounds__(256) void k_time_bias(TimeParams P) {
 // (gnn_block.py:170-171, layer_norm.py:91-156, tensor_product_rescale.py:176-185).  One block (64 threads) per point.
 // NORM = false: LinearRS only, `bias` may be null (the linear_src / linear_dst of a UNet block: block.py:149-153 overwrites the
 // LayerNorm outputs, so the linears see the raw features).
-// v0..v2: true multiplicities for the LayerNorm statistics of zero-padded models (0 = all channels): the padded channels are exactly 0
+// v0..v3: true multiplicities for the LayerNorm statistics of zero-padded models (0 = all channels): the padded channels are exactly 0
 // and their affine weights are 0; the mean is taken over the true channels and the mean^2 each padded 0e channel adds to the variance
 // sum is taken out again.
-template <int L, bool NORM = true>
+// TRUE_IN (score head at lmax 3): features, LayerNorm affine and weights come in the reference's TRUE shapes (8x3e); the message leaves in
+// the kernel layout (16x3e, true channels at dedf_net.h::pad_pos, the others 0).  Otherwise input and output are both in the kernel layout.
+template <int L, bool NORM = true, bool TRUE_IN = false>
 __global__ void k_src_message(const float* __restrict__ f, int n_pts, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                               const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ msg,
-                              int v0 = 0, int v1 = 0, int v2 = 0) {
-    constexpr int D = feat_dim<L>();
-    __shared__ float x[D], red[2];
+                              int v0 = 0, int v1 = 0, int v2 = 0, int v3 = 0) {
+    constexpr int Din = TRUE_IN ? true_feat_dim<L>() : feat_dim<L>(), Dout = feat_dim<L>();
+    auto m_in = [](int l) { return TRUE_IN ? true_mul(l) : mul_of(l); };
+    auto off_in = [](int l) { return TRUE_IN ? true_blk_off(l) : blk_off(l); };
+    __shared__ float x[Din], red[2];
     const int pt = blockIdx.x, tid = threadIdx.x;
-    const float* fi = f + (size_t)pt * D;
-    for (int i = tid; i < D; i += 64) x[i] = fi[i];
+    const float* fi = f + (size_t)pt * Din;
+    for (int i = tid; i < Din; i += 64) x[i] = fi[i];
     __syncthreads();
     int woff = 0, chan = 0;
     if constexpr (NORM) for (int l = 0; l <= L; ++l) {
-        const int m = mul_of(l), d = 2 * l + 1, off = blk_off(l);
-        // statistics of block l (serial in thread 0: 240 values, runs once per scene)
+        const int m = m_in(l), d = 2 * l + 1, off = off_in(l);
+        // statistics of block l (serial in thread 0: a few hundred values, runs once per scene)
         if (tid == 0) {
-            const int vl = l == 0 ? v0 : (l == 1 ? v1 : v2), mv = vl > 0 ? vl : m;
+            const int vl = l == 0 ? v0 : (l == 1 ? v1 : (l == 2 ? v2 : v3)), mv = vl > 0 ? vl : m;
             float mean = 0.0f;
             if (l == 0) { for (int c = 0; c < m; ++c) mean += x[off + c]; mean /= mv; }
             float v = 0.0f;
@@ -193,31 +198,49 @@ __global__ void k_src_message(const float* __restrict__ f, int n_pts, const floa
         woff += m * m; chan += m;
     }
     woff = 0;
-    float* o = msg + (size_t)pt * D;
+    float* o = msg + (size_t)pt * Dout;
     for (int l = 0; l <= L; ++l) {
-        const int m = mul_of(l), d = 2 * l + 1, off = blk_off(l);
+        const int m = m_in(l), d = 2 * l + 1, off = off_in(l), mo = mul_of(l);
+        if (TRUE_IN && mo != m) for (int i = tid; i < mo * d; i += 64) o[blk_off(l) + i] = 0.0f;      // the padded channels
+        if (TRUE_IN && mo != m) __syncthreads();
         for (int i = tid; i < m * d; i += 64) {
             const int w = i / d, k = i % d;
             float s = (l == 0 && bias != nullptr) ? bias[w] : 0.0f;
             for (int u = 0; u < m; ++u) s += W[woff + u * m + w] * x[off + u * d + k];
-            o[off + i] = s;
+            o[blk_off(l) + (TRUE_IN ? pad_pos(l, w) : w) * d + k] = s;
         }
         woff += m * m;
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------------
-// dedf_field: node features from the node kernel's internal layout [l][m][channel] to the reference layout [l][channel][m]
+// (N, true dim) features in the reference layout -> (N, kernel dim): true channel c of degree l at pad_pos(l, c), the others 0
 template <int L>
-__global__ void k_internal_to_ref(const float* __restrict__ in, float* __restrict__ out, int n) {
-    constexpr int D = feat_dim<L>();
+__global__ void k_pad_features(const float* __restrict__ in, float* __restrict__ out, int n) {
+    constexpr int D = feat_dim<L>(), Dt = true_feat_dim<L>();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)n * D) return;
     const int node = (int)(i / D), k = (int)(i % D);
     int l = 0;
     while (l < L && k >= blk_off(l + 1)) ++l;
     const int d = 2 * l + 1, r = k - blk_off(l), c = r / d, m = r % d;
-    out[i] = in[(size_t)node * D + blk_off(l) + m * mul_of(l) + c];
+    float v = 0.0f;
+    for (int ct = 0; ct < true_mul(l); ++ct) if (pad_pos(l, ct) == c) v = in[(size_t)node * Dt + true_blk_off(l) + ct * d + m];
+    out[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// dedf_field: node features from the node kernel's internal layout [l][m][channel] (kernel multiplicities) to the reference layout
+// [l][channel][m] with the TRUE multiplicities
+template <int L>
+__global__ void k_internal_to_ref(const float* __restrict__ in, float* __restrict__ out, int n) {
+    constexpr int D = feat_dim<L>(), Dt = true_feat_dim<L>();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n * Dt) return;
+    const int node = (int)(i / Dt), k = (int)(i % Dt);
+    int l = 0;
+    while (l < L && k >= true_blk_off(l + 1)) ++l;
+    const int d = 2 * l + 1, r = k - true_blk_off(l), c = r / d, m = r % d;
+    out[i] = in[(size_t)node * D + blk_off(l) + m * mul_of(l) + pad_pos(l, c)];
 }
 
 // dedf_keypoint_weight (keypoint_extractor.py:111-119,185-194): one wave per point, lane = scalar channel
@@ -442,11 +465,16 @@ __global__ void k_aggregate(const float* __restrict__ edge_out, const int* __res
     const int d = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     if (d >= n_dst) return;
     if (tile_info[40]) return;
-    const int ci = 4 * lane;
-    int head = 0;
-    if (ci < blk_off(1)) head = ci / (mul_of(0) / kHeads);
-    else if (L >= 1 && ci < blk_off(2)) head = ((ci - blk_off(1)) % mul_of(1)) / (mul_of(1) / kHeads);
-    else if (L >= 2) head = ((ci - blk_off(2)) % mul_of(2)) / (mul_of(2) / kHeads);
+    // lane p-th float4 of the record: channels ci[p] .. ci[p] + 3 (lmax 3: 88 float4 per record, two per lane)
+    constexpr int NP = (NV + 63) / 64;
+    int ci[NP], head[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        ci[p] = 4 * (lane + 64 * p);
+        int l = 0;
+        while (l < L && ci[p] >= blk_off(l + 1)) ++l;
+        head[p] = ((ci[p] - blk_off(l)) % mul_of(l)) / (mul_of(l) / kHeads);
+    }
     // k_edge left one record per (destination, 32-edge tile) segment at the segment's first edge: the destination's first edge
     // and every tile boundary (scale-relative multiples of 32) inside its edge range.  All scales' counts and offsets are
     // requested first, then the records of all scales form ONE list that is walked U at a time.
@@ -469,7 +497,9 @@ __global__ void k_aggregate(const float* __restrict__ edge_out, const int* __res
     // single pass, online softmax: running max / sum per head, accumulator rescaled when a head's max grows
     float mx[kHeads], sum[kHeads] = {0, 0, 0, 0};
     for (int h = 0; h < kHeads; ++h) mx[h] = -INFINITY;
-    f32x4 acc = {0, 0, 0, 0};
+    f32x4 acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[p] = f32x4{0, 0, 0, 0};
     constexpr int U = 4;          // records per iteration: all their loads are in flight together
     for (int j0 = 0; j0 < total; j0 += 64) {
         // lane k holds the edge index of record j0 + k of the flattened list
@@ -480,15 +510,17 @@ __global__ void k_aggregate(const float* __restrict__ edge_out, const int* __res
             if (k >= pre[n] && k < pre[n + 1]) { const int jj = k - pre[n]; ek = first[n] + (jj == 0 ? 0 : fb[n] + 32 * (jj - 1)); }
         const int jend = min(64, total - j0);
         for (int j = 0; j < jend; j += U) {
-            f32x4 lg[U], v[U];
+            f32x4 lg[U], v[U][NP];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 lg[u] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                v[u] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int p = 0; p < NP; ++p) v[u][p] = f32x4{0, 0, 0, 0};
                 if (j + u < jend) {
                     const float* r = edge_out + (size_t)__builtin_amdgcn_readlane(ek, j + u) * REC;
                     lg[u] = ld4(r + D);
-                    if (lane < NV) v[u] = ld4(r + ci);
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) if (ci[p] < D) v[u][p] = ld4(r + ci[p]);
                 }
             }
             float sc[kHeads], p[U][kHeads];
@@ -503,19 +535,25 @@ __global__ void k_aggregate(const float* __restrict__ edge_out, const int* __res
                 sum[h] = sum[h] * sc[h] + ps;
                 mx[h] = m_new;
             }
-            const float sh = head == 0 ? sc[0] : (head == 1 ? sc[1] : (head == 2 ? sc[2] : sc[3]));
-            acc = acc * sh;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float ph = head == 0 ? p[u][0] : (head == 1 ? p[u][1] : (head == 2 ? p[u][2] : p[u][3]));
-                acc = acc + v[u] * ph;
+            for (int q = 0; q < NP; ++q) {
+                const int hd = head[q];
+                const float sh = hd == 0 ? sc[0] : (hd == 1 ? sc[1] : (hd == 2 ? sc[2] : sc[3]));
+                acc[q] = acc[q] * sh;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float ph = hd == 0 ? p[u][0] : (hd == 1 ? p[u][1] : (hd == 2 ? p[u][2] : p[u][3]));
+                    acc[q] = acc[q] + v[u][q] * ph;
+                }
             }
         }
     }
-    if (lane < NV) {
-        const float s = head == 0 ? sum[0] : (head == 1 ? sum[1] : (head == 2 ? sum[2] : sum[3]));
+#pragma unroll
+    for (int q = 0; q < NP; ++q) if (ci[q] < D) {
+        const int hd = head[q];
+        const float s = hd == 0 ? sum[0] : (hd == 1 ? sum[1] : (hd == 2 ? sum[2] : sum[3]));
         const float inv = s > 0.0f ? 1.0f / s : 0.0f;
-        st4(z + (size_t)d * D + ci, acc * inv);
+        st4(z + (size_t)d * D + ci[q], acc[q] * inv);
     }
 }
 

@@ -1,4 +1,4 @@
-// Compile-time description of the score-head network for irreps  64x0e + 32x1e (+ 16x2e (+ 8x3e)),  SH 0..L.
+// Compile-time description of the score-head network for irreps  64x0e + 32x1e (+ 16x2e (+ 8x3e)),  SH 0..L,  L = 1, 2, 3.
 // Everything here is constexpr and shared by the host weight packers and the device kernels, so the order in which a
 // kernel walks K-steps and the order in which the host lays out the A operands cannot drift apart.
 //
@@ -22,13 +22,26 @@ constexpr int kRtabMinNodes = 8192;        // pose x query nodes below which the
 constexpr int kLenEmb = 64, kTimeEmb = 64, kTimeEnc = 256, kTimeHid = 128;
 constexpr int kMaxScales = 8;
 
-DEDF_HD constexpr int mul_of(int l) { return 64 >> l; }
+// Multiplicities.  The reference's irreps are 64x0e + 32x1e + 16x2e + 8x3e (true_mul).  The kernels work on whole 16-channel chunks
+// (one K = 16 step of the fp16 MFMAs, 8 accumulator registers of each half-wave), so the 8x3e block runs as a ZERO-PADDED 16x3e block
+// (mul_of): an exact embedding -- every operation is linear per channel, a gate / activation that maps 0 to 0, a LayerNorm whose
+// statistics are taken over the true channels, or the per-head softmax -- with the true channels placed per head (pad_pos: the kernels'
+// head of a channel is channel / (mul / 4), the reference's Vec2AttnHeads takes true_mul / 4 consecutive channels per head).  The host
+// builds the zero-padded parameters (dedf_pack.h::pad_params); the C ABI speaks the true shapes.
+DEDF_HD constexpr int mul_of(int l) { return l >= 3 ? 16 : 64 >> l; }
+DEDF_HD constexpr int true_mul(int l) { return 64 >> l; }
+DEDF_HD constexpr int pad_pos(int l, int c) { return (c / (true_mul(l) / 4)) * (mul_of(l) / 4) + c % (true_mul(l) / 4); }
+// hidden multiplicities of the FFN (irreps_mlp_mid x mul): 192 / 96 / 48 / 24 -- the last one runs padded to one 32-row tile
+DEDF_HD constexpr int hid_of(int l) { return l >= 3 ? 32 : 3 * (64 >> l); }
+DEDF_HD constexpr int true_hid(int l) { return 3 * (64 >> l); }
 DEDF_HD constexpr int iabs(int a) { return a < 0 ? -a : a; }
 DEDF_HD constexpr int imin(int a, int b) { return a < b ? a : b; }
 DEDF_HD constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 DEDF_HD constexpr int rup(int a, int b) { return cdiv(a, b) * b; }
 
-template <int L> DEDF_HD constexpr int feat_dim() { int d = 0; for (int l = 0; l <= L; ++l) d += mul_of(l) * (2 * l + 1); return d; }
+template <int L> DEDF_HD constexpr int feat_dim() { int d = 0; for (int l = 0; l <= L; ++l) d += mul_of(l) * (2 * l + 1); return d; }      // 160 / 240 / 352 (kernel layout)
+template <int L> DEDF_HD constexpr int true_feat_dim() { int d = 0; for (int l = 0; l <= L; ++l) d += true_mul(l) * (2 * l + 1); return d; }   // 160 / 240 / 296
+DEDF_HD constexpr int true_blk_off(int l) { int d = 0; for (int i = 0; i < l; ++i) d += true_mul(i) * (2 * i + 1); return d; }
 // offset of irreps block l (same in the reference layout [mul][m] and in the internal layout [m][mul])
 DEDF_HD constexpr int blk_off(int l) { int d = 0; for (int i = 0; i < l; ++i) d += mul_of(i) * (2 * i + 1); return d; }
 template <int L> DEDF_HD constexpr int sum_mul() { int d = 0; for (int l = 0; l <= L; ++l) d += mul_of(l); return d; }
@@ -104,7 +117,8 @@ template <int L> struct DtpWalk { int chunk[64]; PathInfo path[64]; int n; };
 // A path whose input degree is lower than its output degree is evaluated in OUTPUT-SIDE form by the edge kernel's first depth-wise TP
 // as well (see make_val_walk): B operands = per-edge weight x message component (2 l1 + 1 of them per channel instead of the 2 l3 + 1
 // contracted ones), the contraction with the SH follows the GEMM.  Fewer operand splits, MFMAs and Clebsch-Gordan multiply-adds.
-template <int L> DEDF_HD constexpr bool dtp_path_out_side(const PathInfo& pi) { return pi.l1 < pi.l3; }
+// (input degrees 0 and 1 only: one or three G tiles in flight)
+template <int L> DEDF_HD constexpr bool dtp_path_out_side(const PathInfo& pi) { return pi.l1 < pi.l3 && pi.l1 <= 1; }
 template <int L> DEDF_HD constexpr DtpWalk<L> make_dtp_walk() {
     DtpWalk<L> w{};
     int n = 0;
@@ -343,7 +357,7 @@ template <int L> DEDF_HD constexpr int edge_rec() { return feat_dim<L>() + kHead
 // (dedf_pack.h::pack_node, which checks them) and the kernel: no offset ever occupies a scalar register.  (With run-time
 // offsets the fully unrolled score stage kept > 300 scalars alive; hipcc spilled them to VGPR lanes / scratch.)
 template <int L> struct NodeLayout {
-    int A_proj[3], A_proj_l[3], ln_w[3], A_f1[3], A_f1_l[3], A_f2[3], A_f2_l[3];
+    int A_proj[4], A_proj_l[4], ln_w[4], A_f1[4], A_f1_l[4], A_f2[4], A_f2_l[4];
     int b_proj0, ln_b0, b_f1, b_f2;
     int A_s[2][16], A_s_l[2][16], A_sl[2][2], A_sl_l[2][2], b_sl[2];
     int total;
@@ -355,7 +369,7 @@ template <int L> DEDF_HD constexpr NodeLayout<L> make_node_layout() {
     auto img = [&](int O, int K) { const int sz = cdiv(O, 32) * cdiv(K, 16) * 256; const int at = o; o += sz; return at; };   // one hi or lo image
     auto rows = [&](int O) { const int at = o; o += cdiv(O, 32) * 32; return at; };
     for (int l = 0; l <= L; ++l) {
-        const int m = mul_of(l), O1 = (l == 0 ? f1_rows0_fwd<L>() : 3 * m), Kh = 3 * m;
+        const int m = mul_of(l), O1 = (l == 0 ? f1_rows0_fwd<L>() : hid_of(l)), Kh = hid_of(l);
         n.A_proj[l] = img(m, m); n.A_proj_l[l] = img(m, m);
         n.ln_w[l] = rows(m);
         n.A_f1[l] = img(O1, m); n.A_f1_l[l] = img(O1, m);
@@ -377,12 +391,14 @@ template <int L> DEDF_HD constexpr NodeLayout<L> make_node_layout() {
 // accumulator -> true value of the node kernel's split-fp16 GEMMs (each weight matrix carries its own power-of-two scale,
 // the B operands a fixed 2^kNodeBShift; dedf_pack.h::pack_node)
 struct NodeScales { float proj[4], f1[4], f2[4], s[2][16], sl[2][2]; };
+// floats per pose record: raw q [0:4], D^1 [4:13], D^2 [16:41], D^3 [48:97]
+template <int L> DEDF_HD constexpr int pose_rec() { return L >= 3 ? 112 : 64; }
 constexpr int kNodeBShift = 5;      // activation-side operand: typical magnitude 2^5 (dedf_pack.h::kActHeadroomBits)
 constexpr int kMlpMid = 3;
-template <int L> DEDF_HD constexpr int f1_rows0() { int r = kMlpMid * mul_of(0); for (int l = 1; l <= L; ++l) r += kMlpMid * mul_of(l); return r; }  // 336 / 288
+template <int L> DEDF_HD constexpr int f1_rows0() { int r = hid_of(0); for (int l = 1; l <= L; ++l) r += hid_of(l); return r; }  // 288 / 336 / 368
 template <int L> DEDF_HD constexpr int f1_rows0_fwd() { return f1_rows0<L>(); }
 template <int L> inline constexpr NodeLayout<L> kNodeLayout = make_node_layout<L>();
-DEDF_HD constexpr int f1_gate_row(int l, int c) { int r = kMlpMid * mul_of(0); for (int i = 1; i < l; ++i) r += kMlpMid * mul_of(i); return r + c; }
+DEDF_HD constexpr int f1_gate_row(int l, int c) { int r = hid_of(0); for (int i = 1; i < l; ++i) r += hid_of(i); return r + c; }
 
 // internal feature layout: block l at blk_off(l), stored [m][mul]  (reference stores [mul][m])
 DEDF_HD constexpr int int_idx(int l, int c, int m) { return blk_off(l) + m * mul_of(l) + c; }

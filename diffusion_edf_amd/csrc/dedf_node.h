@@ -13,7 +13,7 @@
 
 namespace dedf {
 
-constexpr int kPoseRec = 64;      // floats per pose: [0:4] raw q, [4:13] D^1 row-major, [16:41] D^2 row-major
+constexpr int kPoseRec = 64;      // floats per pose (lmax <= 2; dedf_net.h::pose_rec<L>()): [0:4] raw q, [4:13] D^1 row-major, [16:41] D^2 row-major, lmax 3: [48:97] D^3
 
 struct NodeParams {
     const float* z;  uint32_t z_bytes;        // [N_d][D] softmax-aggregated values, internal layout
@@ -35,7 +35,7 @@ struct NodeParams {
     NodeScales sc;                             // accumulator -> true value, per matrix
     const float* f_dst; uint32_t f_dst_bytes;  // UNet layer only: [N_d][D] destination input features (first skip connection, block.py:165)
     float* feat_out;                           // UNet layer only: [N_d][D] output features, reference layout
-    float ln_inv_n[3], ln_pad0;                // UNet layer only: 1 / (true multiplicity) per degree and the number of padded 0e channels (masked norm_2)
+    float ln_inv_n[4], ln_pad0;                // UNet layer only: 1 / (true multiplicity) per degree and the number of padded 0e channels (masked norm_2)
     float* node_out;                           // [N_d][8]: w*lin_vel (3), w*(ang_orbital + ang_spin) (3), 0, 0
     float* dbg_emb;                            // optional [N_d][D] dumps (internal layout) of the proj output and of the field (tests)
     float* dbg_field;
@@ -45,9 +45,10 @@ template <int L> struct Feat {                 // one node's features in row lay
     f32x16 s[2];                               // 64 scalars
     float v1[3][16];                           // 32x1e, [m][reg]
     float v2[5][8];                            // 16x2e, [m][reg]
+    float v3[7][8];                            // 8x3e zero-padded to 16 channels (dedf_net.h::pad_pos), [m][reg]
 };
 // the same features as split-fp16 B operands: chunks of 16 channels (8 registers of a row-layout tile), scaled by 2^kNodeBShift
-template <int L> struct FeatH { HL s[4], v1[3][2], v2[5][1]; };
+template <int L> struct FeatH { HL s[4], v1[3][2], v2[5][1], v3[7][1]; };
 template <int L> DEDF_DEV FeatH<L> split_feat(const Feat<L>& f) {
     constexpr float sc = (float)(1 << kNodeBShift);
     FeatH<L> o;
@@ -56,12 +57,14 @@ template <int L> DEDF_DEV FeatH<L> split_feat(const Feat<L>& f) {
         float t[8]; static_for<8>([&]<int J>() { t[J] = f.v1[m][8 * c + J]; }); o.v1[m][c] = split8(t, sc); }); });
     if constexpr (L >= 2) static_for<5>([&]<int m>() {
         float t[8]; static_for<8>([&]<int J>() { t[J] = f.v2[m][J]; }); o.v2[m][0] = split8(t, sc); });
+    if constexpr (L >= 3) static_for<7>([&]<int m>() {
+        float t[8]; static_for<8>([&]<int J>() { t[J] = f.v3[m][J]; }); o.v3[m][0] = split8(t, sc); });
     return o;
 }
 
 // per-row vectors (biases, LayerNorm affine) of the node image, copied once per wave into LDS (see dedf_edge.h::RowsLds)
 template <int L> struct NodeRowsLds {
-    static constexpr int b_proj0 = 0, ln_w0 = 64, ln_w1 = 128, ln_w2 = 160, ln_b0 = 192, b_f1 = 256;
+    static constexpr int b_proj0 = 0, ln_w0 = 64, ln_w1 = 128, ln_w2 = 160, ln_b0 = 192, ln_w3 = 256, b_f1 = 288;
     static constexpr int b_f2 = b_f1 + cdiv(f1_rows0<L>(), 32) * 32, b_sl0 = b_f2 + 64, b_sl1 = b_sl0 + 32, total = b_sl1 + 32;
 };
 template <int L> DEDF_DEV float* node_rows_lds() {
@@ -77,6 +80,7 @@ DEDF_DEV void node_rows_to_lds(const NodeParams& P, const Wave& wv) {
     cp(RL::b_proj0, O.b_proj0, 64); cp(RL::ln_w0, O.ln_w[0], 64); cp(RL::ln_b0, O.ln_b0, 64);
     if constexpr (L >= 1) cp(RL::ln_w1, O.ln_w[1], 32);
     if constexpr (L >= 2) cp(RL::ln_w2, O.ln_w[2], 32);
+    if constexpr (L >= 3) cp(RL::ln_w3, O.ln_w[3], 32);
     cp(RL::b_f1, O.b_f1, cdiv(f1_rows0<L>(), 32) * 32); cp(RL::b_f2, O.b_f2, 64);
     if constexpr (!EBM) { cp(RL::b_sl0, O.b_sl[0], 32); cp(RL::b_sl1, O.b_sl[1], 32); }
     __builtin_amdgcn_s_waitcnt(0);
@@ -106,7 +110,8 @@ template <int L> DEDF_DEV void feat_add_ref(Feat<L>& f, const Buf& b, int node_o
             static_for<4>([&]<int j>() { static_for<d>([&]<int I>() {
                 if constexpr (l == 0) f.s[gu / 4][4 * (gu % 4) + j] += xr[j];
                 else if constexpr (l == 1) f.v1[I][4 * gu + j] += xr[j * d + I];
-                else f.v2[I][4 * gu + j] += xr[j * d + I];
+                else if constexpr (l == 2) f.v2[I][4 * gu + j] += xr[j * d + I];
+                else f.v3[I][4 * gu + j] += xr[j * d + I];
             }); });
         });
     });
@@ -120,7 +125,8 @@ template <int L> DEDF_DEV void feat_store_ref(const Feat<L>& f, float* node_ptr,
             static_for<4>([&]<int j>() { static_for<d>([&]<int I>() {
                 if constexpr (l == 0) xr[j] = f.s[gu / 4][4 * (gu % 4) + j];
                 else if constexpr (l == 1) xr[j * d + I] = f.v1[I][4 * gu + j];
-                else xr[j * d + I] = f.v2[I][4 * gu + j];
+                else if constexpr (l == 2) xr[j * d + I] = f.v2[I][4 * gu + j];
+                else xr[j * d + I] = f.v3[I][4 * gu + j];
             }); });
             static_for<d>([&]<int Q>() { st4(o + gu * 8 * d + 4 * Q, f32x4{xr[4 * Q], xr[4 * Q + 1], xr[4 * Q + 2], xr[4 * Q + 3]}); });
         });
@@ -155,6 +161,10 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
             const f32x4 t = bld4(zb, zv, (blk_off(2) + m * 16 + 8 * g) * 4);
             z.v2[m][4 * g] = t[0]; z.v2[m][4 * g + 1] = t[1]; z.v2[m][4 * g + 2] = t[2]; z.v2[m][4 * g + 3] = t[3];
         }); });
+        if constexpr (L >= 3) static_for<7>([&]<int m>() { static_for<2>([&]<int g>() {
+            const f32x4 t = bld4(zb, zv, (blk_off(3) + m * 16 + 8 * g) * 4);
+            z.v3[m][4 * g] = t[0]; z.v3[m][4 * g + 1] = t[1]; z.v3[m][4 * g + 2] = t[2]; z.v3[m][4 * g + 3] = t[3];
+        }); });
     }
 
     // ---- proj: per-l dense matrix (+ bias on 0e); all GEMMs of this kernel are 3-term split-fp16 MFMA products -----------------
@@ -177,6 +187,12 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
             dense_shared_hp<5, 1, 2, HP>(wv, O.A_proj[2], O.A_proj_l[2], 1, 0, a, [&]<int m, int c>() { return zh.v2[m][c]; });
             const float c2 = opaque_s(P.sc.proj[2]);
             static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { emb.v2[m][R] = a[m][R] * c2; }); });
+        }
+        if constexpr (L >= 3) {
+            f32x16 a[7] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}};
+            dense_shared_hp<7, 1, 2, HP>(wv, O.A_proj[3], O.A_proj_l[3], 1, 0, a, [&]<int m, int c>() { return zh.v3[m][c]; });
+            const float c3 = opaque_s(P.sc.proj[3]);
+            static_for<7>([&]<int m>() { static_for<8>([&]<int R>() { emb.v3[m][R] = a[m][R] * c3; }); });
         }
     }
 
@@ -216,6 +232,14 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         const f32x16 w = node_ldrows(rows, hi, NR::ln_w2, 0);
         static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { nrm.v2[m][R] = emb.v2[m][R] * (rs * w[R]); }); });
     }
+    if constexpr (L >= 3) {      // the padded channels are exactly 0: the sum is over the true ones, the mean takes the true count
+        float v = 0.0f;
+        static_for<7>([&]<int m>() { static_for<8>([&]<int R>() { v += emb.v3[m][R] * emb.v3[m][R]; }); });
+        v += xor32(v);
+        const float rs = 1.0f / sqrtf(v * (UN ? P.ln_inv_n[3] * (1.0f / 7) : 1.0f / (7 * true_mul(3))) + 1e-5f);
+        const f32x16 w = node_ldrows(rows, hi, NR::ln_w3, 0);
+        static_for<7>([&]<int m>() { static_for<8>([&]<int R>() { nrm.v3[m][R] = emb.v3[m][R] * (rs * w[R]); }); });
+    }
 
     // ---- FFN: FCTP+SwishGate (D -> 336x0e+96x1e+48x2e) -> Gate -> FCTP (-> D), + residual (gnn_block.py:51-57, 210-216) ----
     Feat<L> fld;
@@ -223,8 +247,8 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     constexpr float kBS = (float)(1 << kNodeBShift);
     // split-fp16 B operands that are reused by several GEMMs are parked in LDS (this wave's 30 KB, slot = one h8 per lane):
     // first the normalised features (FFN), later the field (score tensor products); the registers go to the accumulators
-    constexpr int FS1 = 8, FS2 = FS1 + 12;
-    __shared__ f32x4 fpark[(FS2 + 10) * 64];
+    constexpr int FS1 = 8, FS2 = FS1 + 12, FS3 = FS2 + 10;
+    __shared__ f32x4 fpark[(L >= 3 ? FS3 + 14 : FS2 + 10) * 64];
     f32x4* const fp = fpark + wv.lane;
     auto park = [&](const Feat<L>& f) {
         const FeatH<L> fh = split_feat<L>(f);
@@ -237,9 +261,13 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
             fp[(FS2 + 2 * m) * 64] = __builtin_bit_cast(f32x4, fh.v2[m][0].hi);
             fp[(FS2 + 2 * m + 1) * 64] = __builtin_bit_cast(f32x4, fh.v2[m][0].lo);
         });
+        if constexpr (L >= 3) static_for<7>([&]<int m>() {
+            fp[(FS3 + 2 * m) * 64] = __builtin_bit_cast(f32x4, fh.v3[m][0].hi);
+            fp[(FS3 + 2 * m + 1) * 64] = __builtin_bit_cast(f32x4, fh.v3[m][0].lo);
+        });
     };
     auto parked = [&]<int l, int m, int c>() {       // chunk c of component m of block l
-        constexpr int slot = l == 0 ? 2 * c : (l == 1 ? FS1 + 4 * m + 2 * c : FS2 + 2 * m);
+        constexpr int slot = l == 0 ? 2 * c : (l == 1 ? FS1 + 4 * m + 2 * c : (l == 2 ? FS2 + 2 * m : FS3 + 2 * m));
         HL b;
         b.hi = __builtin_bit_cast(h8, fp[slot * 64]);
         b.lo = __builtin_bit_cast(h8, fp[(slot + 1) * 64]);
@@ -307,6 +335,24 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         const float c2 = opaque_s(P.sc.f2[2]);
         static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { fld.v2[m][R] = o[m][R] * c2 + emb.v2[m][R]; }); });
     }
+    if constexpr (L >= 3) {   // l = 3: hidden 24x3e in ONE 32-row tile; its 32 gate rows start at 0e row 336 = tile 10 row 16 (gate tile 4 upper half, tile 5 lower half)
+        static_assert(f1_gate_row(3, 0) == 10 * 32 + 16, "gate rows of the l = 3 hidden block");
+        f32x16 hh[7];
+        const float c1 = opaque_s(P.sc.f1[3]);
+        static_for<7>([&]<int m>() { static_for<16>([&]<int R>() { hh[m][R] = 0.0f; }); });
+        dense_shared_hp<7, 1, 2, HP>(wv, O.A_f1[3], O.A_f1_l[3], 1, 0, hh, [&]<int m, int c>() { return parked.template operator()<3, m, c>(); });
+        static_for<7>([&]<int m>() { static_for<16>([&]<int R>() {
+            if constexpr (R < 8) hh[m][R] *= gt[4][R + 8] * c1; else hh[m][R] *= gt[5][R - 8] * c1;
+        }); });
+        f32x16 o[7] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}};
+        dense_shared_hp<7, 2, 2, HP>(wv, O.A_f2[3], O.A_f2_l[3], 2, 0, o, [&]<int m, int c>() {
+            float t[8];
+            static_for<8>([&]<int J>() { t[J] = hh[m][8 * c + J]; });
+            return split8(t, kBS);
+        });
+        const float c2 = opaque_s(P.sc.f2[3]);
+        static_for<7>([&]<int m>() { static_for<8>([&]<int R>() { fld.v3[m][R] = o[m][R] * c2 + emb.v3[m][R]; }); });
+    }
     sched_fence();
     // (keep this block: besides serving the stage tests it separates the FFN tail from the score stage -- ROCm 7.2 hipcc was
     //  observed to produce a wrong lmax = 2 score stage when the two end up in one basic block)
@@ -319,6 +365,8 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
                 st4(o + blk_off(1) + m * 32 + 8 * g, f32x4{f.v1[m][4 * g], f.v1[m][4 * g + 1], f.v1[m][4 * g + 2], f.v1[m][4 * g + 3]}); }); });
             if constexpr (L >= 2) static_for<5>([&]<int m>() { static_for<2>([&]<int g>() {
                 st4(o + blk_off(2) + m * 16 + 8 * g, f32x4{f.v2[m][4 * g], f.v2[m][4 * g + 1], f.v2[m][4 * g + 2], f.v2[m][4 * g + 3]}); }); });
+            if constexpr (L >= 3) static_for<7>([&]<int m>() { static_for<2>([&]<int g>() {
+                st4(o + blk_off(3) + m * 16 + 8 * g, f32x4{f.v3[m][4 * g], f.v3[m][4 * g + 1], f.v3[m][4 * g + 2], f.v3[m][4 * g + 3]}); }); });
         };
         dump(P.dbg_emb, emb);
         dump(P.dbg_field, fld);
@@ -331,9 +379,9 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     // ---- score tensor products ------------------------------------------------------------------------------------------------
     const Buf qfb = make_buf(P.qf, P.qf_bytes);
     const Buf pb = make_buf(P.pose, P.pose_bytes);
-    float qraw[4], D1[9], D2[25];
+    float qraw[4], D1[9], D2[25], D3[L >= 3 ? 49 : 1];
     {
-        const int pv = pose * (kPoseRec * 4);
+        const int pv = pose * (pose_rec<L>() * 4);
         const f32x4 t = bld4(pb, pv, 0);
         qraw[0] = t[0]; qraw[1] = t[1]; qraw[2] = t[2]; qraw[3] = t[3];
         static_for<3>([&]<int Q>() {
@@ -344,8 +392,12 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
             const f32x4 d = bld4(pb, pv, (16 + 4 * Q) * 4);
             static_for<4>([&]<int J>() { if constexpr (4 * Q + J < 25) D2[4 * Q + J] = d[J]; });
         });
+        if constexpr (L >= 3) static_for<13>([&]<int Q>() {
+            const f32x4 d = bld4(pb, pv, (48 + 4 * Q) * 4);
+            static_for<4>([&]<int J>() { if constexpr (4 * Q + J < 49) D3[4 * Q + J] = d[J]; });
+        });
     }
-    const int qv0 = q * (D * 4) + hi * 16, qv1 = q * (D * 4) + hi * 48, qv2 = q * (D * 4) + hi * 80;
+    const int qv0 = q * (D * 4) + hi * 16, qv1 = q * (D * 4) + hi * 48, qv2 = q * (D * 4) + hi * 80, qv3 = q * (D * 4) + hi * 112;
     if constexpr (EBM) {
         // ---- EbmScoreModelHead.compute_energy (score_head_ebm.py:171-172): |field - D(q) f_query|^2 / dim, weighted by w_q ----
         float esum = 0.0f;
@@ -353,7 +405,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
             constexpr int d = 2 * l + 1;
             static_for<mul_of(l) / 8>([&]<int gu>() {
                 float xr[4 * d];
-                const int qv = l == 0 ? qv0 : (l == 1 ? qv1 : qv2);
+                const int qv = l == 0 ? qv0 : (l == 1 ? qv1 : (l == 2 ? qv2 : qv3));
                 static_for<d>([&]<int Q>() {
                     const f32x4 t = bld4(qfb, qv, (blk_off(l) + gu * 8 * d + 4 * Q) * 4);
                     xr[4 * Q] = t[0]; xr[4 * Q + 1] = t[1]; xr[4 * Q + 2] = t[2]; xr[4 * Q + 3] = t[3];
@@ -365,10 +417,14 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
                         else if constexpr (l == 1) {
                             g = D1[3 * I] * xr[3 * j] + D1[3 * I + 1] * xr[3 * j + 1] + D1[3 * I + 2] * xr[3 * j + 2];
                             f = fld.v1[I][4 * gu + j];
-                        } else {
+                        } else if constexpr (l == 2) {
                             g = D2[5 * I] * xr[5 * j] + D2[5 * I + 1] * xr[5 * j + 1] + D2[5 * I + 2] * xr[5 * j + 2] +
                                 D2[5 * I + 3] * xr[5 * j + 3] + D2[5 * I + 4] * xr[5 * j + 4];
                             f = fld.v2[I][4 * gu + j];
+                        } else {
+                            g = 0.0f;
+                            static_for<7>([&]<int J>() { g += D3[7 * I + J] * xr[7 * j + J]; });
+                            f = fld.v3[I][4 * gu + j];
                         }
                         esum += (f - g) * (f - g);
                     });
@@ -378,7 +434,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         esum += xor32(esum);
         if (valid && hi == 0) {
             float* out = P.node_out + (size_t)n * 8;
-            st4(out, f32x4{P.qw[q] * (esum * (1.0f / D)), 0.0f, 0.0f, 0.0f});
+            st4(out, f32x4{P.qw[q] * (esum * (1.0f / true_feat_dim<L>())), 0.0f, 0.0f, 0.0f});      // (the padded channels are 0 on both sides)
             st4(out + 4, f32x4{0.0f, 0.0f, 0.0f, 0.0f});
         }
         return;
@@ -415,7 +471,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
                     static_for<2>([&]<int run>() {
                         // query feature rows u0 + 8 run + 4 hi + j (reference layout), rotated by D^{l1}(q)
                         float xr[4 * d1];
-                        const int qv = l1 == 0 ? qv0 : (l1 == 1 ? qv1 : qv2);
+                        const int qv = l1 == 0 ? qv0 : (l1 == 1 ? qv1 : (l1 == 2 ? qv2 : qv3));
                         static_for<d1>([&]<int Q>() {
                             const f32x4 t = bld4(qfb, qv, (blk_off(l1) + (u0 + 8 * run) * d1 + 4 * Q) * 4);
                             xr[4 * Q] = t[0]; xr[4 * Q + 1] = t[1]; xr[4 * Q + 2] = t[2]; xr[4 * Q + 3] = t[3];
@@ -425,9 +481,13 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
                             if constexpr (l1 == 0) x[0] = xr[j];
                             else if constexpr (l1 == 1) static_for<3>([&]<int I>() {
                                 x[I] = D1[3 * I] * xr[3 * j] + D1[3 * I + 1] * xr[3 * j + 1] + D1[3 * I + 2] * xr[3 * j + 2]; });
-                            else static_for<5>([&]<int I>() {
+                            else if constexpr (l1 == 2) static_for<5>([&]<int I>() {
                                 x[I] = D2[5 * I] * xr[5 * j] + D2[5 * I + 1] * xr[5 * j + 1] + D2[5 * I + 2] * xr[5 * j + 2] +
                                        D2[5 * I + 3] * xr[5 * j + 3] + D2[5 * I + 4] * xr[5 * j + 4]; });
+                            else static_for<7>([&]<int I>() {
+                                float t = 0.0f;
+                                static_for<7>([&]<int J>() { t += D3[7 * I + J] * xr[7 * j + J]; });
+                                x[I] = t; });
                             static_for<d2>([&]<int J>() { y[J] = T[J][8 * cc + 4 * run + j]; });
                             C::make(y, m);
                             C::apply(x, m, o);

@@ -30,22 +30,43 @@ struct ParamSpec {
     }
 };
 
-// one UNet layer: state_dict names of the ModuleDict {'radial', 'gnn'} (reference unet_feature_extractor.py:141-156; block.py:62-139,
-// graph_attention.py:11-82).  norm_1_src / norm_1_dst exist in the reference's state dict and are dead (block.py:149-153).
-template <int L>
-inline ParamSpec build_spec_unet_layer(const dedf_config& c) {
-    ParamSpec S;
-    const int nb = c.fc_neurons[0];
-    S.add("radial.mean", nb); S.add("radial.std_logit", nb); S.add("radial.weight_logit", nb);
-    size_t sq = 0;
-    for (int l = 0; l <= L; ++l) sq += (size_t)mul_of(l) * mul_of(l);
-    const std::string g = "gnn";
-    S.add(g + ".norm_1_src.affine_weight", sum_mul<L>()); S.add(g + ".norm_1_src.affine_bias", mul_of(0));
-    S.add(g + ".linear_src.tp.weight", sq);
-    S.add(g + ".norm_1_dst.affine_weight", sum_mul<L>()); S.add(g + ".norm_1_dst.affine_bias", mul_of(0));
-    S.add(g + ".linear_dst.tp.weight", sq); S.add(g + ".linear_dst.bias.0", mul_of(0));
-    const std::string ga = g + ".ga", rad = ga + ".sep_act.dtp_rad.";
-    const int ch[4] = {c.fc_neurons[0], c.fc_neurons[1], c.fc_neurons[2], dtp_wn<L>()};
+// Irreps bookkeeping at run time, for the TRUE shapes of the reference (64x0e+32x1e+16x2e+8x3e: the C ABI's parameter blob) and for the
+// shapes the kernels run (8x3e zero-padded to 16x3e, FFN hidden 24x3e to 32: dedf_net.h::mul_of / hid_of).  Same path construction as
+// dedf_net.h::dtp_path / stp_path (reference equiformer/tensor_product_rescale.py:352-382).
+struct IrrepsRT {
+    int L = 0;
+    int mul[4] = {0, 0, 0, 0}, hid[4] = {0, 0, 0, 0};
+    std::vector<PathInfo> dtp, stp;
+    int dtp_k[4] = {0, 0, 0, 0}, stp_k[2] = {0, 0}, dtp_wn = 0, stp_wn = 0;
+    IrrepsRT(int lmax, bool kernel_shapes) : L(lmax) {
+        for (int l = 0; l <= L; ++l) { mul[l] = kernel_shapes ? mul_of(l) : true_mul(l); hid[l] = kernel_shapes ? hid_of(l) : true_hid(l); }
+        int kc[4] = {0, 0, 0, 0};
+        for (int l1 = 0; l1 <= L; ++l1) for (int l2 = 0; l2 <= L; ++l2)
+            for (int l3 = iabs(l1 - l2); l3 <= imin(L, l1 + l2); ++l3) {
+                dtp.push_back(PathInfo{l1, l2, l3, mul[l1], 1, dtp_wn, kc[l3]});
+                dtp_wn += mul[l1]; kc[l3] += mul[l1];
+            }
+        for (int l = 0; l <= L; ++l) dtp_k[l] = kc[l];
+        int ks[2] = {0, 0};
+        for (int l1 = 0; l1 <= L; ++l1) for (int l2 = 0; l2 <= L; ++l2)
+            for (int l3 = iabs(l1 - l2); l3 <= imin(1, l1 + l2); ++l3) {
+                stp.push_back(PathInfo{l1, l2, l3, mul[l1], mul[l2], stp_wn, ks[l3]});
+                stp_wn += mul[l1] * mul[l2]; ks[l3] += mul[l1];
+            }
+        stp_k[0] = ks[0]; stp_k[1] = ks[1];
+    }
+    int sum_mul() const { int d = 0; for (int l = 0; l <= L; ++l) d += mul[l]; return d; }
+    int gates() const { int g = 0; for (int l = 1; l <= L; ++l) g += mul[l]; return g; }
+    int lin0_rows() const { return mul[0] + gates(); }
+    int f1_rows0() const { int r = 0; for (int l = 0; l <= L; ++l) r += hid[l]; return r; }
+    size_t sq() const { size_t q = 0; for (int l = 0; l <= L; ++l) q += (size_t)mul[l] * mul[l]; return q; }
+};
+
+// the attention block shared by the score head and the UNet layers (state_dict names below `ga` / `blk`)
+inline void spec_block(ParamSpec& S, const IrrepsRT& I, const dedf_config& c, const std::string& blk, const std::string& post_norm) {
+    const std::string ga = blk + ".ga", rad = ga + ".sep_act.dtp_rad.";
+    const int L = I.L;
+    const int ch[4] = {c.fc_neurons[0], c.fc_neurons[1], c.fc_neurons[2], I.dtp_wn};
     S.add(rad + "net.0.weight", (size_t)ch[1] * ch[0]); S.add(rad + "net.0.bias", ch[1]);
     S.add(rad + "net.1.weight", ch[1]); S.add(rad + "net.1.bias", ch[1]);
     S.add(rad + "net.3.weight", (size_t)ch[2] * ch[1]); S.add(rad + "net.3.bias", ch[2]);
@@ -54,29 +75,44 @@ inline ParamSpec build_spec_unet_layer(const dedf_config& c) {
     S.add(rad + "offset", ch[3]);
     size_t lin_n = 0, val_n = 0;
     for (int l = 0; l <= L; ++l) {
-        lin_n += (size_t)dtp_k<L>(l) * (l == 0 ? lin0_rows<L>() : mul_of(l));
-        val_n += (size_t)dtp_k<L>(l) * mul_of(l);
+        lin_n += (size_t)I.dtp_k[l] * (l == 0 ? I.lin0_rows() : I.mul[l]);
+        val_n += (size_t)I.dtp_k[l] * I.mul[l];
     }
-    S.add(ga + ".sep_act.lin.tp.weight", lin_n); S.add(ga + ".sep_act.lin.bias.0", lin0_rows<L>());
-    S.add(ga + ".sep_alpha.tp.weight", (size_t)dtp_k<L>(0) * mul_of(0)); S.add(ga + ".sep_alpha.bias.0", mul_of(0));
-    S.add(ga + ".sep_value.dtp.tp.weight", dtp_wn<L>());
-    S.add(ga + ".sep_value.lin.tp.weight", val_n); S.add(ga + ".sep_value.lin.bias.0", mul_of(0));
-    S.add(ga + ".alpha_dot", mul_of(0));
-    S.add(ga + ".proj.tp.weight", sq); S.add(ga + ".proj.bias.0", mul_of(0));
-    S.add(g + ".norm_2.affine_weight", sum_mul<L>()); S.add(g + ".norm_2.affine_bias", mul_of(0));
+    S.add(ga + ".sep_act.lin.tp.weight", lin_n); S.add(ga + ".sep_act.lin.bias.0", I.lin0_rows());
+    S.add(ga + ".sep_alpha.tp.weight", (size_t)I.dtp_k[0] * I.mul[0]); S.add(ga + ".sep_alpha.bias.0", I.mul[0]);
+    S.add(ga + ".sep_value.dtp.tp.weight", I.dtp_wn);
+    S.add(ga + ".sep_value.lin.tp.weight", val_n); S.add(ga + ".sep_value.lin.bias.0", I.mul[0]);
+    S.add(ga + ".alpha_dot", I.mul[0]);
+    S.add(ga + ".proj.tp.weight", I.sq()); S.add(ga + ".proj.bias.0", I.mul[0]);
+    S.add(post_norm + ".affine_weight", I.sum_mul()); S.add(post_norm + ".affine_bias", I.mul[0]);
     size_t f1 = 0, f2 = 0;
     for (int l = 0; l <= L; ++l) {
-        f1 += (size_t)mul_of(l) * (l == 0 ? f1_rows0<L>() : kMlpMid * mul_of(l));
-        f2 += (size_t)kMlpMid * mul_of(l) * mul_of(l);
+        f1 += (size_t)I.mul[l] * (l == 0 ? I.f1_rows0() : I.hid[l]);
+        f2 += (size_t)I.hid[l] * I.mul[l];
     }
-    S.add(g + ".ffn.fctp_1.tp.weight", f1); S.add(g + ".ffn.fctp_1.bias.0", f1_rows0<L>());
-    S.add(g + ".ffn.fctp_2.tp.weight", f2); S.add(g + ".ffn.fctp_2.bias.0", mul_of(0));
+    S.add(blk + ".ffn.fctp_1.tp.weight", f1); S.add(blk + ".ffn.fctp_1.bias.0", I.f1_rows0());
+    S.add(blk + ".ffn.fctp_2.tp.weight", f2); S.add(blk + ".ffn.fctp_2.bias.0", I.mul[0]);
+}
+
+// one UNet layer: state_dict names of the ModuleDict {'radial', 'gnn'} (reference unet_feature_extractor.py:141-156; block.py:62-139,
+// graph_attention.py:11-82).  norm_1_src / norm_1_dst exist in the reference's state dict and are dead (block.py:149-153).
+// (UNet layers take their parameters in the KERNEL shapes: diffusion_edf_amd/unet_pad.py builds the zero-padded tensors)
+inline ParamSpec build_spec_unet_layer(const IrrepsRT& I, const dedf_config& c) {
+    ParamSpec S;
+    const int nb = c.fc_neurons[0];
+    S.add("radial.mean", nb); S.add("radial.std_logit", nb); S.add("radial.weight_logit", nb);
+    const std::string g = "gnn";
+    S.add(g + ".norm_1_src.affine_weight", I.sum_mul()); S.add(g + ".norm_1_src.affine_bias", I.mul[0]);
+    S.add(g + ".linear_src.tp.weight", I.sq());
+    S.add(g + ".norm_1_dst.affine_weight", I.sum_mul()); S.add(g + ".norm_1_dst.affine_bias", I.mul[0]);
+    S.add(g + ".linear_dst.tp.weight", I.sq()); S.add(g + ".linear_dst.bias.0", I.mul[0]);
+    spec_block(S, I, c, g, g + ".norm_2");
     return S;
 }
 
-template <int L>
-inline ParamSpec build_spec(const dedf_config& c) {
-    if (c.unet_layer) return build_spec_unet_layer<L>(c);
+// canonical parameter list of a handle for irreps `I` (I = true shapes: the C ABI's blob; I = kernel shapes: what the packers read)
+inline ParamSpec build_spec(const IrrepsRT& I, const dedf_config& c) {
+    if (c.unet_layer) return build_spec_unet_layer(I, c);
     ParamSpec S;
     const int* te = c.time_emb_mlp;
     for (int n = 0; n < c.n_scales; ++n) {
@@ -95,45 +131,127 @@ inline ParamSpec build_spec(const dedf_config& c) {
         S.add(pl + "weight", (size_t)F0 * F0); S.add(pl + "bias", F0);
     }
     const std::string blk = ktf + ".gnn_block_init";
-    size_t sq = 0;
-    for (int l = 0; l <= L; ++l) sq += (size_t)mul_of(l) * mul_of(l);
-    S.add(blk + ".prenorm_src.affine_weight", sum_mul<L>()); S.add(blk + ".prenorm_src.affine_bias", mul_of(0));
-    S.add(blk + ".linear_src.tp.weight", sq); S.add(blk + ".linear_src.bias.0", mul_of(0));
-    const std::string ga = blk + ".ga";
-    const int ch[4] = {c.fc_neurons[0], c.fc_neurons[1], c.fc_neurons[2], dtp_wn<L>()};
-    const std::string rad = ga + ".sep_act.dtp_rad.";
-    S.add(rad + "net.0.weight", (size_t)ch[1] * ch[0]); S.add(rad + "net.0.bias", ch[1]);
-    S.add(rad + "net.1.weight", ch[1]); S.add(rad + "net.1.bias", ch[1]);
-    S.add(rad + "net.3.weight", (size_t)ch[2] * ch[1]); S.add(rad + "net.3.bias", ch[2]);
-    S.add(rad + "net.4.weight", ch[2]); S.add(rad + "net.4.bias", ch[2]);
-    S.add(rad + "net.6.weight", (size_t)ch[3] * ch[2]);
-    S.add(rad + "offset", ch[3]);
-    size_t lin_n = 0, val_n = 0;
-    for (int l = 0; l <= L; ++l) {
-        lin_n += (size_t)dtp_k<L>(l) * (l == 0 ? lin0_rows<L>() : mul_of(l));
-        val_n += (size_t)dtp_k<L>(l) * mul_of(l);
-    }
-    S.add(ga + ".sep_act.lin.tp.weight", lin_n); S.add(ga + ".sep_act.lin.bias.0", lin0_rows<L>());
-    S.add(ga + ".sep_alpha.tp.weight", (size_t)dtp_k<L>(0) * mul_of(0)); S.add(ga + ".sep_alpha.bias.0", mul_of(0));
-    S.add(ga + ".sep_value.dtp.tp.weight", dtp_wn<L>());
-    S.add(ga + ".sep_value.lin.tp.weight", val_n); S.add(ga + ".sep_value.lin.bias.0", mul_of(0));
-    S.add(ga + ".alpha_dot", mul_of(0));
-    S.add(ga + ".proj.tp.weight", sq); S.add(ga + ".proj.bias.0", mul_of(0));
-    S.add(blk + ".post_norm.affine_weight", sum_mul<L>()); S.add(blk + ".post_norm.affine_bias", mul_of(0));
-    size_t f1 = 0, f2 = 0;
-    for (int l = 0; l <= L; ++l) {
-        f1 += (size_t)mul_of(l) * (l == 0 ? f1_rows0<L>() : kMlpMid * mul_of(l));
-        f2 += (size_t)kMlpMid * mul_of(l) * mul_of(l);
-    }
-    S.add(blk + ".ffn.fctp_1.tp.weight", f1); S.add(blk + ".ffn.fctp_1.bias.0", f1_rows0<L>());
-    S.add(blk + ".ffn.fctp_2.tp.weight", f2); S.add(blk + ".ffn.fctp_2.bias.0", mul_of(0));
+    S.add(blk + ".prenorm_src.affine_weight", I.sum_mul()); S.add(blk + ".prenorm_src.affine_bias", I.mul[0]);
+    S.add(blk + ".linear_src.tp.weight", I.sq()); S.add(blk + ".linear_src.bias.0", I.mul[0]);
+    spec_block(S, I, c, blk, blk + ".post_norm");
     if (!c.ebm) for (const char* nm : {"lin_vel_tp", "ang_vel_tp"}) {
         const std::string p = std::string(nm);
-        S.add(p + ".dtp.tp.weight", stp_wn<L>());
-        S.add(p + ".lin.tp.weight", (size_t)stp_k<L>(0) * (1 + mul_of(1)) + (size_t)stp_k<L>(1) * mul_of(1));
-        S.add(p + ".lin.bias.0", 1 + mul_of(1));
+        S.add(p + ".dtp.tp.weight", I.stp_wn);
+        S.add(p + ".lin.tp.weight", (size_t)I.stp_k[0] * (1 + I.mul[1]) + (size_t)I.stp_k[1] * I.mul[1]);
+        S.add(p + ".lin.bias.0", 1 + I.mul[1]);
     }
     return S;
+}
+
+// True-shape parameter blob -> kernel-shape blob (only lmax 3 differs: 8x3e -> 16x3e, FFN hidden 24x3e -> 32x3e).  Every tensor that
+// indexes a 3e channel is re-laid with the true channels at dedf_net.h::pad_pos and zeros elsewhere (C++ twin of
+// diffusion_edf_amd/unet_pad.py::expand_layer_params, which does the same for the narrow UNet levels).
+inline std::vector<float> pad_params(const dedf_config& c, const IrrepsRT& T, const ParamSpec& St, const IrrepsRT& K, const ParamSpec& Sk, const float* Bt) {
+    std::vector<float> out(Sk.total, 0.0f);
+    const int L = T.L;
+    auto src = [&](const std::string& n) { return St.get(Bt, n); };
+    auto dst = [&](const std::string& n) { return out.data() + Sk.entries[Sk.index.at(n)].offset; };
+    auto numel = [&](const ParamSpec& S, const std::string& n) { return S.entries[S.index.at(n)].numel; };
+    // index maps true -> kernel
+    auto pos = [&](int l, int ch) { return pad_pos(l, ch); };
+    std::vector<int> wmap(T.dtp_wn);                               // flat depth-wise-TP weight index (creation order)
+    std::vector<std::vector<int>> kmap(L + 1);                     // sorted DTP channel inside the l3 block
+    for (int l = 0; l <= L; ++l) kmap[l].assign(T.dtp_k[l], -1);
+    for (size_t p = 0; p < T.dtp.size(); ++p)
+        for (int u = 0; u < T.dtp[p].mul1; ++u) {
+            wmap[T.dtp[p].wstart + u] = K.dtp[p].wstart + pos(T.dtp[p].l1, u);
+            kmap[T.dtp[p].l3][T.dtp[p].kofs + u] = K.dtp[p].kofs + pos(T.dtp[p].l1, u);
+        }
+    std::vector<int> lin0(T.lin0_rows()), f1r(T.f1_rows0());       // 0e row spaces of sep_act.lin (scalars | gates) and fctp_1 (hidden scalars | gates)
+    {
+        for (int i = 0; i < T.mul[0]; ++i) lin0[i] = i;
+        int ot = T.mul[0], ok = K.mul[0];
+        for (int l = 1; l <= L; ++l) { for (int i = 0; i < T.mul[l]; ++i) lin0[ot + i] = ok + pos(l, i); ot += T.mul[l]; ok += K.mul[l]; }
+        ot = 0; ok = 0;
+        for (int l = 0; l <= L; ++l) { for (int i = 0; i < T.hid[l]; ++i) f1r[ot + i] = ok + i; ot += T.hid[l]; ok += K.hid[l]; }
+    }
+    std::vector<std::vector<int>> smap(2);                         // sorted score-TP channel inside the l3 block
+    smap[0].assign(T.stp_k[0], -1); smap[1].assign(T.stp_k[1], -1);
+    for (size_t p = 0; p < T.stp.size(); ++p)
+        for (int u = 0; u < T.stp[p].mul1; ++u) smap[T.stp[p].l3][T.stp[p].kofs + u] = K.stp[p].kofs + pos(T.stp[p].l1, u);
+    // helpers: vector with an index map; matrix [rows][cols] with row / column maps
+    auto vec = [&](const std::string& n, const std::vector<int>& m) { const float* s_ = src(n); float* d_ = dst(n); for (size_t i = 0; i < m.size(); ++i) d_[m[i]] = s_[i]; };
+    auto mat = [&](const float* s_, float* d_, int R, int Cn, int Ck, auto rmap, auto cmap) {
+        for (int r = 0; r < R; ++r) for (int q = 0; q < Cn; ++q) d_[(size_t)rmap(r) * Ck + cmap(q)] = s_[(size_t)r * Cn + q];
+    };
+    auto ident = [](int i) { return i; };
+    auto per_l_vec = [&](const std::string& n) {          // [sum_l mul_l]
+        const float* s_ = src(n); float* d_ = dst(n);
+        int ot = 0, ok = 0;
+        for (int l = 0; l <= L; ++l) { for (int i = 0; i < T.mul[l]; ++i) d_[ok + pos(l, i)] = s_[ot + i]; ot += T.mul[l]; ok += K.mul[l]; }
+    };
+    auto per_l_sq = [&](const std::string& n) {           // per degree [mul in][mul out]
+        const float* s_ = src(n); float* d_ = dst(n);
+        size_t ot = 0, ok = 0;
+        for (int l = 0; l <= L; ++l) {
+            mat(s_ + ot, d_ + ok, T.mul[l], T.mul[l], K.mul[l], [&](int r) { return pos(l, r); }, [&](int q) { return pos(l, q); });
+            ot += (size_t)T.mul[l] * T.mul[l]; ok += (size_t)K.mul[l] * K.mul[l];
+        }
+    };
+    auto block = [&](const std::string& blk, const std::string& post_norm) {
+        const std::string ga = blk + ".ga", rad = ga + ".sep_act.dtp_rad.";
+        const int H2 = c.fc_neurons[2];
+        mat(src(rad + "net.6.weight"), dst(rad + "net.6.weight"), T.dtp_wn, H2, H2, [&](int r) { return wmap[r]; }, ident);
+        vec(rad + "offset", wmap);
+        vec(ga + ".sep_value.dtp.tp.weight", wmap);
+        {   // sep_act.lin / sep_value.lin: per l3 [k sorted DTP channel][out row]
+            const float *ls = src(ga + ".sep_act.lin.tp.weight"), *vs = src(ga + ".sep_value.lin.tp.weight");
+            float *ld = dst(ga + ".sep_act.lin.tp.weight"), *vd = dst(ga + ".sep_value.lin.tp.weight");
+            size_t lt = 0, lk = 0, vt = 0, vk = 0;
+            for (int l = 0; l <= L; ++l) {
+                const int Ot = l == 0 ? T.lin0_rows() : T.mul[l], Ok = l == 0 ? K.lin0_rows() : K.mul[l];
+                mat(ls + lt, ld + lk, T.dtp_k[l], Ot, Ok, [&](int r) { return kmap[l][r]; }, [&](int q) { return l == 0 ? lin0[q] : pos(l, q); });
+                mat(vs + vt, vd + vk, T.dtp_k[l], T.mul[l], K.mul[l], [&](int r) { return kmap[l][r]; }, [&](int q) { return pos(l, q); });
+                lt += (size_t)T.dtp_k[l] * Ot; lk += (size_t)K.dtp_k[l] * Ok; vt += (size_t)T.dtp_k[l] * T.mul[l]; vk += (size_t)K.dtp_k[l] * K.mul[l];
+            }
+        }
+        vec(ga + ".sep_act.lin.bias.0", lin0);
+        mat(src(ga + ".sep_alpha.tp.weight"), dst(ga + ".sep_alpha.tp.weight"), T.dtp_k[0], T.mul[0], K.mul[0], [&](int r) { return kmap[0][r]; }, ident);
+        per_l_sq(ga + ".proj.tp.weight");
+        per_l_vec(post_norm + ".affine_weight");
+        {   // FFN: fctp_1 per degree [mul in][rows out], fctp_2 per degree [hidden in][mul out]
+            const float *s1 = src(blk + ".ffn.fctp_1.tp.weight"), *s2 = src(blk + ".ffn.fctp_2.tp.weight");
+            float *d1 = dst(blk + ".ffn.fctp_1.tp.weight"), *d2 = dst(blk + ".ffn.fctp_2.tp.weight");
+            size_t t1 = 0, k1 = 0, t2 = 0, k2 = 0;
+            for (int l = 0; l <= L; ++l) {
+                const int Ot = l == 0 ? T.f1_rows0() : T.hid[l], Ok = l == 0 ? K.f1_rows0() : K.hid[l];
+                mat(s1 + t1, d1 + k1, T.mul[l], Ot, Ok, [&](int r) { return pos(l, r); }, [&](int q) { return l == 0 ? f1r[q] : q; });
+                mat(s2 + t2, d2 + k2, T.hid[l], T.mul[l], K.mul[l], ident, [&](int q) { return pos(l, q); });
+                t1 += (size_t)T.mul[l] * Ot; k1 += (size_t)K.mul[l] * Ok; t2 += (size_t)T.hid[l] * T.mul[l]; k2 += (size_t)K.hid[l] * K.mul[l];
+            }
+        }
+        vec(blk + ".ffn.fctp_1.bias.0", f1r);
+    };
+    // 1. everything whose shape does not involve a 3e channel: straight copy
+    for (const ParamEntry& e : St.entries) {
+        auto it = Sk.index.find(e.name);
+        if (it == Sk.index.end()) throw std::runtime_error("pad_params: " + e.name + " missing in the kernel schema");
+        if (Sk.entries[it->second].numel == e.numel) std::copy(Bt + e.offset, Bt + e.offset + e.numel, out.data() + Sk.entries[it->second].offset);
+    }
+    if (L < 3) return out;
+    // 2. the tensors that do
+    const std::string blk = "key_tensor_field.gnn_block_init";
+    per_l_vec(blk + ".prenorm_src.affine_weight");
+    per_l_sq(blk + ".linear_src.tp.weight");
+    block(blk, blk + ".post_norm");
+    if (!c.ebm) for (const char* nm : {"lin_vel_tp", "ang_vel_tp"}) {
+        const std::string p = std::string(nm);
+        const float* s_ = src(p + ".dtp.tp.weight"); float* d_ = dst(p + ".dtp.tp.weight");
+        for (size_t q = 0; q < T.stp.size(); ++q)
+            mat(s_ + T.stp[q].wstart, d_ + K.stp[q].wstart, T.stp[q].mul1, T.stp[q].mul2, K.stp[q].mul2,
+                [&](int r) { return pos(T.stp[q].l1, r); }, [&](int v) { return pos(T.stp[q].l2, v); });
+        const float* ls = src(p + ".lin.tp.weight"); float* ld = dst(p + ".lin.tp.weight");
+        const int O0 = 1 + T.mul[1];
+        mat(ls, ld, T.stp_k[0], O0, O0, [&](int r) { return smap[0][r]; }, ident);
+        mat(ls + (size_t)T.stp_k[0] * O0, ld + (size_t)K.stp_k[0] * O0, T.stp_k[1], T.mul[1], T.mul[1], [&](int r) { return smap[1][r]; }, ident);
+    }
+    (void)numel;
+    return out;
 }
 
 // ---- growing image of packed weights: every block is 16-byte aligned, offsets are in floats --------------------------------
@@ -417,7 +535,7 @@ inline void pack_node(const dedf_config& c, const ParamSpec& S, const float* B, 
     int s_proj0 = 0, s_f10 = 0, s_f20 = 0;
     size_t po = 0, lo = 0, f1o = 0, f2o = 0;
     for (int l = 0; l <= L; ++l) {
-        const int m = mul_of(l), O1 = (l == 0 ? f1_rows0<L>() : kMlpMid * m), Kh = kMlpMid * m;
+        const int m = mul_of(l), O1 = (l == 0 ? f1_rows0<L>() : hid_of(l)), Kh = hid_of(l);
         const float* Wp = pw + po;
         const int sp = push_h(m, m, [&](int oo, int k) { return Wp[k * m + oo]; }, o.o_A_proj[l], o.o_A_proj_l[l]);
         o.o_ln_w[l] = im.push(pack_rows(m, [&](int i) { return lnw[lo + i]; }));

@@ -31,7 +31,7 @@ from .score_head import _register
 from .so3 import irreps_dim, parse_irreps
 
 
-_SHAPES = {(64, 32, 16): "wide", (32, 16, 8): "narrow"}
+_SHAPES = {(64, 32, 16): "wide", (32, 16, 8): "narrow", (64, 32, 16, 8): "wide, lmax 3", (32, 16, 8, 4): "narrow, lmax 3"}
 
 
 class UnetLayer(torch.nn.Module):
@@ -48,17 +48,19 @@ class UnetLayer(torch.nn.Module):
         self.irreps = parse_irreps(irreps)
         self.irreps_src = self.irreps if irreps_src is None else parse_irreps(irreps_src)
         sh = parse_irreps(irreps_edge_attr)
+        L = len(self.irreps) - 1
         for irr in (self.irreps, self.irreps_src):
-            if tuple(m for m, _ in irr) not in _SHAPES or [l for _, l in irr] != [0, 1, 2]:
-                raise NotImplementedError(f"UnetLayer: irreps must be 64x0e+32x1e+16x2e or 32x0e+16x1e+8x2e, not {irr}")
+            if tuple(m for m, _ in irr) not in _SHAPES or [l for _, l in irr] != list(range(L + 1)):
+                raise NotImplementedError(f"UnetLayer: irreps must be 64x0e+32x1e+16x2e(+8x3e) or 32x0e+16x1e+8x2e(+4x3e), source and destination of one lmax, not {irr}")
         if list(fc_neurons) not in ([64, 32, 32], [32, 16, 16]):
             raise NotImplementedError(f"UnetLayer: fc_neurons must be [64, 32, 32] or [32, 16, 16], not {list(fc_neurons)}")
-        if [l for _, l in sh] != [0, 1, 2] or any(m != 1 for m, _ in sh) or num_heads != 4 or irreps_mlp_mid != 3:
-            raise NotImplementedError("UnetLayer: irreps_edge_attr 1x0e+1x1e+1x2e, 4 heads, irreps_mlp_mid 3")
+        if [l for _, l in sh] != list(range(L + 1)) or any(m != 1 for m, _ in sh) or num_heads != 4 or irreps_mlp_mid != 3:
+            raise NotImplementedError("UnetLayer: irreps_edge_attr 1x0e+1x1e+...+1x{lmax}e with lmax that of the features, 4 heads, irreps_mlp_mid 3")
+        self.lmax, self.kdim = L, unet_pad.wide_dim(L)
         self.fc_neurons, self.num_heads, self.radius = list(fc_neurons), num_heads, float(radius)
         self.muls, self.muls_src = [m for m, _ in self.irreps], [m for m, _ in self.irreps_src]
         self.dim, self.dim_src = irreps_dim(self.irreps), irreps_dim(self.irreps_src)
-        spec = unet_layer_param_spec(self.irreps, self.fc_neurons, num_heads, irreps_src=self.irreps_src)
+        spec = unet_layer_param_spec(self.irreps, self.fc_neurons, num_heads, lmax_sh=L, irreps_src=self.irreps_src)
         for name, t in init_from_spec(spec, seed=init_seed).items():
             _register(self, name, t)
         self._handle = None
@@ -105,12 +107,13 @@ class UnetLayer(torch.nn.Module):
                                "(the CPU restatement lives under oracle/ and is test infrastructure).")
         lib = _lib.load()
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        narrow = self.muls != unet_pad.WIDE or self.muls_src != unet_pad.WIDE or self.fc_neurons != unet_pad.WIDE_FC
+        W = unet_pad.wide_of(self.muls)          # (at lmax 3 every shape is "narrow": 8x3e itself runs padded to 16x3e)
+        narrow = self.muls != W or self.muls_src != W or self.fc_neurons != unet_pad.WIDE_FC
         state = {k: v for k, v in self.state_dict().items()}
         if narrow:
             state = unet_pad.expand_layer_params(state, self.muls, self.fc_neurons, self.muls_src)
-        ccfg = _lib.make_unet_layer_config(self.radius, idx, unet_pad.WIDE_FC, unet_pad.WIDE, self.num_heads,
-                                           valid=self.muls if self.muls != unet_pad.WIDE else None,
+        ccfg = _lib.make_unet_layer_config(self.radius, idx, unet_pad.WIDE_FC, W, self.num_heads,
+                                           valid=self.muls if self.muls != W else None,
                                            fc_valid=self.fc_neurons if self.fc_neurons != unet_pad.WIDE_FC else None, half_gemm=self._half)
         blob = _lib.pack_params(ccfg, state)
         h = C.c_void_p()
@@ -142,7 +145,7 @@ class UnetLayer(torch.nn.Module):
         extractors chain, padding once at the input and un-padding once at the outputs.  ``dst_sorted=False`` sorts the edges by destination
         (no device read-back); ``deferred``: do not synchronise, the edge-list verdict is collected later (``check``)."""
         assert node_coord_src.ndim == 2 and node_coord_src.shape[-1] == 3 and node_coord_dst.ndim == 2 and node_coord_dst.shape[-1] == 3
-        assert f_src_wide.shape == (len(node_coord_src), 240) and f_dst_wide.shape == (len(node_coord_dst), 240)
+        assert f_src_wide.shape == (len(node_coord_src), self.kdim) and f_dst_wide.shape == (len(node_coord_dst), self.kdim)
         assert edge_src.ndim == 1 and edge_src.shape == edge_dst.shape
         dev = node_coord_src.device
         self._ensure_handle(dev)
@@ -155,7 +158,7 @@ class UnetLayer(torch.nn.Module):
             order = torch.sort(ed, stable=True).indices
             es, ed = es[order], ed[order]
         es, ed = es.contiguous(), ed.contiguous()
-        out = torch.empty(len(xd), 240, device=dev, dtype=torch.float32)
+        out = torch.empty(len(xd), self.kdim, device=dev, dtype=torch.float32)
         if deferred != self._deferred:
             lib.dedf_layer_defer_check(self._handle, int(deferred))
             self._deferred = deferred
@@ -194,10 +197,13 @@ class NodeLinear(torch.nn.Module):
         self.has_ln, self.prefix = layernorm, prefix
         self.m_in = {l: m for m, l in self.irreps_in}
         self.m_out = _muls(self.irreps_out)
-        assert [l for _, l in self.irreps_out] == [0, 1, 2] and tuple(self.m_out) in _SHAPES
-        assert all(l in (0, 1, 2) for l in self.m_in) and all(self.m_in.get(l, 0) <= unet_pad.WIDE[l] for l in range(3))
+        self.L = L = len(self.m_out) - 1
+        self.W = unet_pad.wide_of(self.m_out)
+        self.kdim = unet_pad.wide_dim(L)
+        assert [l for _, l in self.irreps_out] == list(range(L + 1)) and tuple(self.m_out) in _SHAPES
+        assert all(l in range(L + 1) for l in self.m_in) and all(self.m_in.get(l, 0) <= self.W[l] for l in range(L + 1))
         g = torch.Generator().manual_seed(init_seed)
-        blocks = [(self.m_in.get(l, 0), self.m_out[l]) for l in range(3)]
+        blocks = [(self.m_in.get(l, 0), self.m_out[l]) for l in range(L + 1)]
         w = torch.cat([torch.randn(a * b, generator=g) / max(a, 1) ** 0.5 for a, b in blocks if a > 0])
         lin = prefix + ("skip." if layernorm else "")
         _register(self, lin + "tp.weight", w)
@@ -211,7 +217,7 @@ class NodeLinear(torch.nn.Module):
 
     def _pl_in(self, l):      # placement of the input channels of degree l inside the wide block
         m = self.m_in.get(l, 0)
-        return unet_pad.place(m, unet_pad.WIDE[l]) if (m and m % 4 == 0 and tuple(self.m_in.get(k, 0) for k in range(3)) in _SHAPES) else torch.arange(m)
+        return unet_pad.place(m, self.W[l]) if (m and m % 4 == 0 and tuple(self.m_in.get(k, 0) for k in range(self.L + 1)) in _SHAPES) else torch.arange(m)
 
     def _pl_dev(self, l, dev):
         key = (l, str(dev))
@@ -224,9 +230,9 @@ class NodeLinear(torch.nn.Module):
             return self._dev[1:]
         sd = {k: v.detach().float().cpu() for k, v in self.state_dict().items()}
         lin = self.prefix + ("skip." if self.has_ln else "")
-        M = unet_pad.WIDE
+        M = self.W
         W, o = [], 0
-        for l in range(3):
+        for l in range(self.L + 1):
             a, b = self.m_in.get(l, 0), self.m_out[l]
             full = torch.zeros(M[l], M[l])
             if a:
@@ -239,12 +245,12 @@ class NodeLinear(torch.nn.Module):
         if self.has_ln:
             lnw, lnb, ow = torch.zeros(sum(M)), torch.zeros(M[0]), 0
             it = 0
-            for l in range(3):
+            for l in range(self.L + 1):
                 a = self.m_in.get(l, 0)
                 lnw[ow + self._pl_in(l)] = sd[self.prefix + "layernorm.affine_weight"][it:it + a]
                 it += a; ow += M[l]
             lnb[self._pl_in(0)] = sd[self.prefix + "layernorm.affine_bias"]
-            valid = (C.c_int * 3)(*[self.m_in.get(l, 0) or M[l] for l in range(3)])
+            valid = (C.c_int * 4)(*([self.m_in.get(l, 0) or M[l] for l in range(self.L + 1)] + [0] * (3 - self.L)))
         t = lambda v: None if v is None else v.to(dev).contiguous()
         self._dev = (dev, t(torch.cat(W)), t(bias), t(lnw), t(lnb), valid)
         return self._dev[1:]
@@ -253,10 +259,10 @@ class NodeLinear(torch.nn.Module):
         self._dev = None
 
     def pad_in(self, f: torch.Tensor) -> torch.Tensor:
-        out = f.new_zeros(len(f), 240)
+        out = f.new_zeros(len(f), self.kdim)
         o_t = o_w = 0
-        for l in range(3):
-            a, d, Mw = self.m_in.get(l, 0), 2 * l + 1, unet_pad.WIDE[l]
+        for l in range(self.L + 1):
+            a, d, Mw = self.m_in.get(l, 0), 2 * l + 1, self.W[l]
             if a:
                 out[:, o_w:o_w + Mw * d].view(-1, Mw, d)[:, self._pl_dev(l, f.device), :] = f[:, o_t:o_t + a * d].reshape(-1, a, d)
                 o_t += a * d
@@ -278,8 +284,8 @@ class NodeLinear(torch.nn.Module):
         out = torch.empty_like(x)
         lib = _lib.load()
         with torch.cuda.device(dev):
-            rc = lib.dedf_linear_rs(x.data_ptr(), len(x), None if lnw is None else lnw.data_ptr(), None if lnb is None else lnb.data_ptr(),
-                                    W.data_ptr(), bias.data_ptr(), valid, out.data_ptr(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            rc = lib.dedf_linear_rs_lmax(self.L, x.data_ptr(), len(x), None if lnw is None else lnw.data_ptr(), None if lnb is None else lnb.data_ptr(),
+                                         W.data_ptr(), bias.data_ptr(), valid, out.data_ptr(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         if rc != _lib.OK:
             raise RuntimeError(f"dedf_linear_rs failed ({rc})")
         return out
@@ -337,8 +343,9 @@ class UnetFeatureExtractor(torch.nn.Module):
         assert ns == len(self.irreps_emb) == len(irreps_edge_attr) == len(num_heads) == len(fc_neurons) == len(radius) == len(pool_ratio) == len(n_layers)
         if irreps_input is None:
             raise NotImplementedError("irreps_input=None")
-        if any(str(a).replace(' ', '') not in ('1x0e+1x1e+1x2e',) for a in irreps_edge_attr) or any(h != 4 for h in num_heads):
-            raise NotImplementedError("UnetFeatureExtractor: irreps_edge_attr 1x0e+1x1e+1x2e and 4 heads per level")
+        if any(str(a).replace(' ', '') not in ('1x0e+1x1e+1x2e', '1x0e+1x1e+1x2e+1x3e') for a in irreps_edge_attr) or any(h != 4 for h in num_heads):
+            raise NotImplementedError("UnetFeatureExtractor: irreps_edge_attr 1x0e+1x1e+1x2e(+1x3e) and 4 heads per level")
+        self._edge_attr = [str(a).replace(' ', '') for a in irreps_edge_attr]
         if (pool_method if isinstance(pool_method, str) else pool_method[0]) != 'fps' or (attn_type if isinstance(attn_type, str) else attn_type[0]) != 'mlp':
             raise NotImplementedError
         if irreps_mlp_mid != 3:
@@ -351,7 +358,8 @@ class UnetFeatureExtractor(torch.nn.Module):
         emb, fc = self.irreps_emb, [list(f) for f in fc_neurons]
         self.input_emb = NodeLinear(irreps_input, emb[0], layernorm=False, init_seed=7)
         seeds = iter(range(100, 10 ** 6))
-        mk = lambda n, src, dst: UnetLayer(irreps=dst, irreps_src=src, fc_neurons=fc[n], radius=self.radius[n], init_seed=next(seeds))
+        mk = lambda n, src, dst: UnetLayer(irreps=dst, irreps_src=src, irreps_edge_attr=self._edge_attr[n], fc_neurons=fc[n], radius=self.radius[n],
+                                           init_seed=next(seeds))
         self.down_blocks = torch.nn.ModuleList()
         for n in range(ns):
             blk = torch.nn.ModuleDict()

@@ -22,9 +22,20 @@ import torch
 
 from .params import dtp_paths, dtp_sorted_out
 
-WIDE = [64, 32, 16]          # instantiated multiplicities
+WIDE = [64, 32, 16]          # instantiated multiplicities (lmax 2)
+WIDE3 = [64, 32, 16, 16]     # lmax 3: the reference's widest 3e block, 8x3e, itself runs zero-padded to one 16-channel chunk (csrc/dedf_net.h::mul_of)
+WIDE_HID = [192, 96, 48, 32]   # FFN hidden multiplicities of the kernels (irreps_mlp_mid = 3; 24x3e padded to one 32-row tile: dedf_net.h::hid_of)
 WIDE_FC = [64, 32, 32]
 HEADS = 4
+
+
+def wide_of(muls) -> List[int]:
+    """kernel multiplicities for true multiplicities `muls` (lmax = len(muls) - 1)"""
+    return WIDE3[:len(muls)] if len(muls) == 4 else WIDE[:len(muls)]
+
+
+def wide_dim(L: int) -> int:
+    return sum(M * (2 * l + 1) for l, M in enumerate(WIDE3[:L + 1]))
 
 
 def place(m: int, M: int) -> torch.Tensor:
@@ -49,12 +60,13 @@ def _first(m: int) -> torch.Tensor:
 
 
 def pad_features(f: torch.Tensor, muls: Sequence[int]) -> torch.Tensor:
-    """(N, sum m_l (2l+1)) in the true irreps -> (N, 240) in the wide layout ([mul][m] per block, true channels at `place`)"""
-    if list(muls) == WIDE:
+    """(N, sum m_l (2l+1)) in the true irreps -> (N, 240 | 352) in the wide layout ([mul][m] per block, true channels at `place`)"""
+    W = wide_of(muls)
+    if list(muls) == W:
         return f
-    out = f.new_zeros(f.shape[0], sum(M * (2 * l + 1) for l, M in enumerate(WIDE)))
+    out = f.new_zeros(f.shape[0], sum(M * (2 * l + 1) for l, M in enumerate(W)))
     o_t = o_w = 0
-    for l, (m, M) in enumerate(zip(muls, WIDE)):
+    for l, (m, M) in enumerate(zip(muls, W)):
         d = 2 * l + 1
         idx = place_on(m, M, f.device)
         out[:, o_w:o_w + M * d].view(-1, M, d)[:, idx, :] = f[:, o_t:o_t + m * d].reshape(-1, m, d)
@@ -64,10 +76,11 @@ def pad_features(f: torch.Tensor, muls: Sequence[int]) -> torch.Tensor:
 
 
 def unpad_features(f: torch.Tensor, muls: Sequence[int]) -> torch.Tensor:
-    if list(muls) == WIDE:
+    W = wide_of(muls)
+    if list(muls) == W:
         return f
     parts, o_w = [], 0
-    for l, (m, M) in enumerate(zip(muls, WIDE)):
+    for l, (m, M) in enumerate(zip(muls, W)):
         d = 2 * l + 1
         parts.append(f[:, o_w:o_w + M * d].reshape(-1, M, d)[:, place_on(m, M, f.device), :].reshape(-1, m * d))
         o_w += M * d
@@ -97,8 +110,10 @@ def _vec(v: torch.Tensor, idx: torch.Tensor, n: int, fill: float = 0.0) -> torch
 
 def expand_layer_params(P: Dict[str, torch.Tensor], muls: Sequence[int], fc: Sequence[int], muls_src: Sequence[int]) -> Dict[str, torch.Tensor]:
     """reference-shaped parameters of a {radial, gnn} layer with true multiplicities `muls` (dst / emb), `muls_src` and radial widths `fc`
-    -> the equivalent parameters of the wide schema (``params.unet_layer_param_spec([(64,0),(32,1),(16,2)], [64,32,32])``)"""
-    m, ms, M = list(muls), list(muls_src), WIDE
+    -> the equivalent parameters of the wide schema (``params.unet_layer_param_spec([(64,0),(32,1),(16,2)], [64,32,32])``; at lmax 3 the wide
+    schema is 64x0e+32x1e+16x2e+16x3e with FFN hidden multiplicities 192 / 96 / 48 / 32, the library's ``dedf_param_*`` list)"""
+    m, ms, M = list(muls), list(muls_src), wide_of(list(muls))
+    HID = WIDE_HID[:len(m)]
     nb, h1, h2 = fc
     NB, H1, H2 = WIDE_FC
     L = len(m) - 1
@@ -190,18 +205,18 @@ def expand_layer_params(P: Dict[str, torch.Tensor], muls: Sequence[int], fc: Seq
     Q[f"{g}.norm_2.affine_bias"] = _vec(P[f"{g}.norm_2.affine_bias"], pl[0], M[0])
     # ---- FFN: hidden channels first-part; rows of fctp_1's 0e block: [3 m0 scalars | 3 m1 gates | 3 m2 gates]
     K3 = 3
-    def f1_map(mm, MM):
-        idx, ow = [_first(K3 * mm[0])], K3 * MM[0]
+    def f1_map(mm, HH):
+        idx, ow = [_first(K3 * mm[0])], HH[0]
         for l in range(1, L + 1):
-            idx.append(ow + _first(K3 * mm[l])); ow += K3 * MM[l]
+            idx.append(ow + _first(K3 * mm[l])); ow += HH[l]
         return torch.cat(idx), ow
-    f1o, f1n_w = f1_map(m, M)
+    f1o, f1n_w = f1_map(m, HID)
     f1n_t = K3 * sum(m)
     bl = _blocks(P[f"{g}.ffn.fctp_1.tp.weight"], [(m[0], f1n_t)] + [(m[l], K3 * m[l]) for l in range(1, L + 1)])
     Q[f"{g}.ffn.fctp_1.tp.weight"] = torch.cat([_embed(bl[0], pl[0], f1o, M[0], f1n_w).reshape(-1)] +
-                                                [_embed(bl[l], pl[l], _first(K3 * m[l]), M[l], K3 * M[l]).reshape(-1) for l in range(1, L + 1)])
+                                                [_embed(bl[l], pl[l], _first(K3 * m[l]), M[l], HID[l]).reshape(-1) for l in range(1, L + 1)])
     Q[f"{g}.ffn.fctp_1.bias.0"] = _vec(P[f"{g}.ffn.fctp_1.bias.0"], f1o, f1n_w)
     bl = _blocks(P[f"{g}.ffn.fctp_2.tp.weight"], [(K3 * m[l], m[l]) for l in range(L + 1)])
-    Q[f"{g}.ffn.fctp_2.tp.weight"] = torch.cat([_embed(bl[l], _first(K3 * m[l]), pl[l], K3 * M[l], M[l]).reshape(-1) for l in range(L + 1)])
+    Q[f"{g}.ffn.fctp_2.tp.weight"] = torch.cat([_embed(bl[l], _first(K3 * m[l]), pl[l], HID[l], M[l]).reshape(-1) for l in range(L + 1)])
     Q[f"{g}.ffn.fctp_2.bias.0"] = _vec(P[f"{g}.ffn.fctp_2.bias.0"], pl[0], M[0])
     return Q

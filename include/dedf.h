@@ -52,7 +52,9 @@ extern "C" {
 typedef struct dedf_handle dedf_handle;
 
 typedef struct dedf_config {
-    int lmax;                            /* irreps = 64x0e + 32x1e (+ 16x2e); SH 0..lmax.  Supported: 1, 2 */
+    int lmax;                            /* irreps = 64x0e + 32x1e (+ 16x2e (+ 8x3e)); SH 0..lmax.  Supported: 1, 2, 3.  (lmax 3: the kernels run the 8x3e block
+                                            zero-padded as 16x3e -- an exact embedding, see diffusion_edf_amd/csrc/dedf_net.h; this interface keeps the
+                                            reference's shapes: features are (N, 296), parameters as the reference's state dict has them) */
     int mul[4];                          /* must equal {64,32,16,8}[0..lmax] (every reference config) */
     int num_heads;                       /* 4 */
     int fc_neurons[3];                   /* {64 + time_emb_mlp[2],128,64} ({64,128,64} for the EBM head), {128,32,32} (sapien place_* score heads), or
@@ -83,7 +85,7 @@ typedef struct dedf_config {
                                             irreps_dst = 64x0e+32x1e+16x2e, fc_neurons {64,32,32} (levels 2, 3 and the mid block of every shipped
                                             UNet config); radii[0] = the level's connection radius, n_scales = 1; the time / score fields are
                                             ignored; only dedf_layer_forward is available; half_gemm applies.  0: score / critic head */
-    int unet_valid[3];                   /* UNet layer: true multiplicities of the block's irreps (0 = all of mul[]).  A 32x0e+16x1e+8x2e layer (levels 0-1 of
+    int unet_valid[4];                   /* UNet layer: true multiplicities of the block's irreps (0 = all of mul[]).  A 32x0e+16x1e+8x2e layer (levels 0-1 of
                                             the shipped UNets) runs on the 64/32/16 kernels with zero-padded parameters (diffusion_edf_amd/unet.py
                                             builds them); what the padding cannot express -- LayerNorm statistics over the true channels only -- is told
                                             to the kernels by these counts */
@@ -225,6 +227,10 @@ int dedf_debug_packed(dedf_handle* h, const char* which, const float** ptr, size
  *              statistics (padded models), NULL = full.  All device pointers. */
 int dedf_linear_rs(const float* f, int n, const float* ln_w, const float* ln_b, const float* W, const float* bias, const int* valid,
                    float* out, void* stream);
+/* the same for the kernel layout of `lmax` (2: 240 floats per node as above; 3: 352 = 64x0e+32x1e+16x2e+16x3e, the UNet's lmax-3 layers;
+ * ln_w (128), valid[4]) */
+int dedf_linear_rs_lmax(int lmax, const float* f, int n, const float* ln_w, const float* ln_b, const float* W, const float* bias, const int* valid,
+                        float* out, void* stream);
 int dedf_fps(const float* x, int n, int n_samples, int start, int* idx_out, void* stream);
 int dedf_radius(const float* x_src, int n_src, const float* x_dst, int n_dst, float r, int max_num_neighbors, int exclude_self,
                 int64_t edge_cap, int64_t* edge_dst, int64_t* edge_src, int64_t* n_edges, void* stream);

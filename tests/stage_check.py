@@ -18,15 +18,48 @@ from diffusion_edf_amd.score_head import ScoreModelHead  # noqa: E402
 from oracle import restatement as R  # noqa: E402
 
 
+KERNEL_MULS = [64, 32, 16, 16]       # multiplicities the kernels run (dedf_net.h::mul_of): the reference's 8x3e is zero-padded to 16x3e
+
+
+def pad_pos(l, c, muls):
+    """kernel channel of true channel c of degree l (dedf_net.h::pad_pos: per-head placement)"""
+    tm, km = muls[l] // 4, KERNEL_MULS[l] // 4
+    return (c // tm) * km + c % tm
+
+
 def int_to_ref_perm(muls):
-    """perm such that ref_layout = internal[..., perm]"""
+    """perm such that ref_layout (true multiplicities) = internal[..., perm]; internal = the kernels' [l][m][kernel channel]"""
     perm, off = [], 0
     for l, m in enumerate(muls):
-        d = 2 * l + 1
+        d, M = 2 * l + 1, KERNEL_MULS[l]
         for c in range(m):
             for k in range(d):
-                perm.append(off + k * m + c)
-        off += m * d
+                perm.append(off + k * M + pad_pos(l, c, muls))
+        off += M * d
+    return torch.tensor(perm, dtype=torch.long)
+
+
+def kernel_ref_to_true_perm(muls):
+    """perm such that true ref layout [l][c][m] = kernel ref layout [l][kernel channel][m][..., perm]  (the `msg` buffer)"""
+    perm, off = [], 0
+    for l, m in enumerate(muls):
+        d, M = 2 * l + 1, KERNEL_MULS[l]
+        for c in range(m):
+            for k in range(d):
+                perm.append(off + pad_pos(l, c, muls) * d + k)
+        off += M * d
+    return torch.tensor(perm, dtype=torch.long)
+
+
+def dtp_weight_perm(muls):
+    """perm such that the true flat depth-wise-TP weights (creation order, tensor_product_rescale.py:365-371) = kernel-shape weights[..., perm]"""
+    L = len(muls) - 1
+    perm, off = [], 0
+    for l1 in range(L + 1):
+        for l2 in range(L + 1):
+            for l3 in range(abs(l1 - l2), min(L, l1 + l2) + 1):
+                perm += [off + pad_pos(l1, u, muls) for u in range(muls[l1])]
+                off += KERNEL_MULS[l1]
     return torch.tensor(perm, dtype=torch.long)
 
 
@@ -89,6 +122,7 @@ def stage_report_case(kw, cfg, P, keys, query, Ts, time, verbose=True, half=Fals
     head, ang, lin = gpu_run(kw, P, keys, query, Ts, time, half=half)
     muls = cfg.muls
     D = cfg.dim
+    DK = sum(KERNEL_MULS[l] * (2 * l + 1) for l in range(len(muls)))          # feature width of the kernels' buffers (= D up to lmax 2)
     nQ = len(query.x)
     Nd = nT * nQ
     perm = int_to_ref_perm(muls)
@@ -96,9 +130,9 @@ def stage_report_case(kw, cfg, P, keys, query, Ts, time, verbose=True, half=Fals
     st = head.stats()
     rep['edges_gpu'] = st['n_edges']
     rep['edges_oracle'] = d64['n_edges_per_scale']
-    rep['msg'] = rel(head.debug_buffer('msg').reshape(-1, D), d64['msg_src'])
+    rep['msg'] = rel(head.debug_buffer('msg').reshape(-1, DK)[:, kernel_ref_to_true_perm(muls)], d64['msg_src'])
     rep['qpos'] = rel(head.debug_buffer('qpos').reshape(nT, nQ, 3), d64['x_t'])
-    pose = head.debug_buffer('pose').reshape(nT, 64)
+    pose = head.debug_buffer('pose').reshape(nT, -1)
     # Wigner D^1 against the oracle's rotated features: f_t(l=1 block) = D^1 f
     # edges: map (scale, dst, src) -> row
     es = head.debug_buffer('edge_src', torch.int32).long()
@@ -114,11 +148,13 @@ def stage_report_case(kw, cfg, P, keys, query, Ts, time, verbose=True, half=Fals
         og = torch.argsort(key_g)
         oo = torch.argsort(key_o)
         WN = d64['dtp_weight'].shape[1]
-        w = head.debug_buffer('dbg_w').reshape(-1, WN)[:E]
+        wperm = dtp_weight_perm(muls)
+        assert len(wperm) == WN
+        w = head.debug_buffer('dbg_w').reshape(E, -1)[:, wperm]
         rep['dtp_weight'] = rel(w[og], d64['dtp_weight'][oo])
         rep['dtp_weight_o32'] = rel(d32['dtp_weight'][torch.argsort(d32['edge_dst'] * nkeys + d32['edge_src'])], d64['dtp_weight'][oo])
-        eo = head.debug_buffer('edge_out').reshape(-1, D + 4)[:E]
-        val_ref = eo[:, :D][:, perm]
+        eo = head.debug_buffer('edge_out').reshape(-1, DK + 4)[:E]
+        val_ref = eo[:, :DK][:, perm]
         H = cfg.num_heads
         irreps_head = [(m // H, l) for l, m in enumerate(muls)]
         oval = R.heads2vec(d64['value'], irreps_head)
@@ -128,12 +164,12 @@ def stage_report_case(kw, cfg, P, keys, query, Ts, time, verbose=True, half=Fals
             n = m * (2 * l + 1)
             rep[f'value_l{l}'] = rel(val_ref[og][:, off:off + n], oval[oo][:, off:off + n])
             off += n
-        rep['logits'] = rel(eo[:, D:][og], d64['log_alpha'][oo])
-    z = head.debug_buffer('z').reshape(Nd, D)[:, perm]
+        rep['logits'] = rel(eo[:, DK:][og], d64['log_alpha'][oo])
+    z = head.debug_buffer('z').reshape(Nd, DK)[:, perm]
     rep['attn'] = rel(z, d64['attn'])
     rep['attn_o32'] = rel(d32['attn'], d64['attn'])
     for nm in ('emb', 'field'):          # proj output and the field after post-norm + FFN, per irreps block
-        g = head.debug_buffer(nm).reshape(Nd, D)[:, perm]
+        g = head.debug_buffer(nm).reshape(Nd, DK)[:, perm]
         off = 0
         for l, m in enumerate(muls):
             nn = m * (2 * l + 1)

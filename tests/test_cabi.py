@@ -23,7 +23,7 @@ def test_header_symbols_exported(built_lib):
     assert b"gfx950" in built_lib.dedf_version()
 
 
-@pytest.mark.parametrize("lmax", [1, 2])
+@pytest.mark.parametrize("lmax", [1, 2, 3])
 def test_canonical_parameter_order_matches_reference_schema(built_lib, lmax):
     cfg = params.HeadConfig.from_kwargs(synthetic.score_head_kwargs(lmax))
     cc = _lib.make_config(cfg, -1)
@@ -33,7 +33,7 @@ def test_canonical_parameter_order_matches_reference_schema(built_lib, lmax):
     for k in ("key_tensor_field.gnn_block_init.ga.sep_act.dtp_rad.net.0.weight", "key_tensor_field.gnn_block_init.ga.alpha_dot",
               "key_tensor_field.gnn_block_init.ga.sep_value.dtp.tp.weight", "lin_vel_tp.dtp.tp.weight", "time_mlps_multiscale.3.2.bias"):
         assert k in names
-    assert params.n_params(cfg) == {1: 384130, 2: 429570}[lmax]
+    assert params.n_params(cfg) == {1: 384130, 2: 429570, 3: 466690}[lmax]          # (lmax 3: the reference's TRUE shapes, 8x3e; the library pads internally)
 
 
 def test_ebm_schema(built_lib):
