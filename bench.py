@@ -45,11 +45,11 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-M_EDGE = {1: 105_536, 2: 193_344}          # algorithmic MAC per edge (dense-CG convention)
-M_NODE = {1: 56_320 + 186_560, 2: 68_352 + 343_264}
-M_EDGE_FRONT = {1: 40_960, 2: 40_960}      # of which: edge pre-linear 128x128 + RadialProfile layers 1 (128x128) and 2 (128x64): the part the sampler's
+M_EDGE = {1: 105_536, 2: 193_344, 3: 338_304}          # algorithmic MAC per edge (dense-CG convention; lmax 3: tests/test_lmax3.py re-derives it)
+M_NODE = {1: 56_320 + 186_560, 2: 68_352 + 343_264, 3: 73_024 + 428_784}
+M_EDGE_FRONT = {1: 40_960, 2: 40_960, 3: 40_960}      # of which: edge pre-linear 128x128 + RadialProfile layers 1 (128x128) and 2 (128x64): the part the sampler's
                                            # radial table evaluates per length-grid node (40 k nodes per step) instead of per edge (2 M)
-M_EDGE_CG = {1: 2 * 2_080, 2: 2 * 14_880}   # of which: the two depth-wise TPs (dense-CG convention), VALU work
+M_EDGE_CG = {1: 2 * 2_080, 2: 2 * 14_880, 3: 2 * 55_200}   # of which: the two depth-wise TPs (dense-CG convention), VALU work
 PEAK_FP32_MFMA_TFLOPS = 157.3             # dense fp32 MFMA = fp32 vector peak (MI355X_MICROARCH.md)
 PEAK_FP16_MFMA_TFLOPS = 2500.0            # dense fp16 MFMA
 
@@ -129,7 +129,7 @@ def radial_table_note(args, flops, e_per_launch, edge_ms, peak, per_edge=None):
     time, so the front of the radial network is a function of (scale, edge length): the default path evaluates it once per step on a length
     grid and interpolates per edge -- 40 960 of the 193 344 MAC/edge are then not executed per edge.  This object says so and gives the
     fraction on the FLOP the edge kernel really executes."""
-    on = (args.lmax == 2 and not args.half and not args.no_radial_table)
+    on = (args.lmax in (2, 3) and not args.half and not args.no_radial_table)
     if not on:
         return {"enabled": False}
     ex = 2.0 * e_per_launch * (M_EDGE[args.lmax] - M_EDGE_FRONT[args.lmax])
@@ -146,7 +146,7 @@ def radial_table_note(args, flops, e_per_launch, edge_ms, peak, per_edge=None):
                     "--no-radial-table measures the per-edge path"}
 
 
-def extractor_times(n_scene: int, n_grasp: int, device, reps: int = 5):
+def extractor_times(n_scene: int, n_grasp: int, device, reps: int = 5, lmax: int = 2):
     import numpy as np
     from diffusion_edf_amd import synthetic
     from diffusion_edf_amd.gnn_data import FeaturedPoints
@@ -166,9 +166,11 @@ def extractor_times(n_scene: int, n_grasp: int, device, reps: int = 5):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps * 1e3, out
 
-    unet = UnetFeatureExtractor(**synthetic.unet_kwargs("panda_lowres"), deterministic=True).to(device)
+    unet = UnetFeatureExtractor(**synthetic.unet_kwargs("panda_lowres" + ("_lmax3" if lmax == 3 else "")), deterministic=True).to(device)
     scene = cloud(synthetic.make_scene(n_scene, seed=0))
     ms_u, levels = timed(lambda: unet(scene))
+    if lmax == 3:          # (BASELINE config 5 names the UNet; the keypoint extractor's fields are measured at the shipped lmax 2)
+        return {"unet_scene": ms_u, "unet_levels": [len(l.x) for l in levels], "unet_irreps_output": "64x0e+32x1e+16x2e+8x3e"}
     kp = KeypointExtractor(**synthetic.keypoint_extractor_kwargs(bbox=None), deterministic=True).to(device)
     grasp = cloud(synthetic.make_grasp(n_grasp, seed=0))
     ms_k, q = timed(lambda: kp(grasp))
@@ -256,7 +258,7 @@ def main():
     # The same K steps from the same poses with the sampler's radial table switched OFF (every edge evaluates the whole radial network), timed
     # the same way on every rank: reported next to `value` so that both readings of the workload are in the one JSON line.
     per_edge = None
-    if args.lmax == 2 and not args.half and not args.no_radial_table:
+    if args.lmax in (2, 3) and not args.half and not args.no_radial_table:
         head.set_radial_table(False)
         run(T, 2, first)
         head.profile_enable(True)
@@ -307,8 +309,8 @@ def main():
     # outside the timed region too: the step BEFORE the path on clouds of the workload's sizes -- the UNet key model on
     # the scene cloud and the KeypointExtractor query model on the grasp cloud, once per agent.sample in a deployment
     extract = None
-    if rank == 0 and world == 1 and args.lmax == 2 and not args.no_extractors:
-        extract = extractor_times(args.scene, args.grasp, device)
+    if rank == 0 and world == 1 and args.lmax in (2, 3) and not args.no_extractors:
+        extract = extractor_times(args.scene, args.grasp, device, lmax=args.lmax)
 
     if rank == 0:
         n_ev = max(1, prof["n_evals"])
@@ -319,7 +321,8 @@ def main():
         peak = PEAK_FP16_MFMA_TFLOPS / (1.0 if args.half else 3.0)
         default_workload = (args.lmax, args.scene, args.grasp, args.poses_per_gpu) == (2, 4096, 1024, 1000)
         default_workload = default_workload and not args.half
-        wname = "C2" if default_workload else ("C1" if (args.lmax, args.scene, args.grasp) == (1, 2048, 512) else "custom")
+        wname = "C2" if default_workload else ("C1" if (args.lmax, args.scene, args.grasp) == (1, 2048, 512) else
+                                                ("C2 inputs at lmax 3 (the degree BASELINE config 5 names)" if (args.lmax, args.scene, args.grasp) == (3, 4096, 1024) else "custom"))
         traffic, traffic_src, mfma_issued = None, None, None
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json")), key=os.path.getmtime) if default_workload else []:
             try:
@@ -333,7 +336,7 @@ def main():
         # FLOP the edge kernel EXECUTES per edge: with the sampler's radial table the front of the radial network (40 960 MAC) runs per grid
         # node, not per edge.  `frac` is on the executed count (a hardware utilisation figure); `frac_algorithmic` keeps the reference's
         # algorithmic count of SURVEY 8(d) (what the work is worth, not what the pipes did).
-        table_on = args.lmax == 2 and not args.half and not args.no_radial_table
+        table_on = args.lmax in (2, 3) and not args.half and not args.no_radial_table
         m_exec = M_EDGE[args.lmax] - (M_EDGE_FRONT[args.lmax] if table_on else 0)
         flops_exec = 2.0 * e_per_launch * m_exec
         achieved_exec = flops_exec / (edge_ms * 1e-3) / 1e12 if edge_ms > 0 else 0.0
@@ -354,7 +357,7 @@ def main():
                        "score_fwd_ms_at_t0.5": fixed, "feature_extractors_ms": extract},
             "roofline": {"kernel": "k_edge (fused per-edge pipeline)", "bound": "valu-issue", "achieved": achieved_exec, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved_exec / peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "frac_definition": f"EXECUTED FLOP: 2 x {m_exec} MAC per edge" + (" (193 344 algorithmic - 40 960 that the sampler's radial table evaluates per grid node)" if table_on and args.lmax == 2 else "") + " x edges of the launch / its HIP-event duration / peak",
+                         "frac_definition": f"EXECUTED FLOP: 2 x {m_exec} MAC per edge" + (f" ({M_EDGE[args.lmax]} algorithmic - 40 960 that the sampler's radial table evaluates per grid node)" if table_on else "") + " x edges of the launch / its HIP-event duration / peak",
                          "achieved_algorithmic": achieved, "frac_algorithmic": achieved / peak,
                          "frac_mfma_issued": mfma_issued, "frac_mfma_issued_definition": "SQ_INSTS_MFMA x 32 768 FLOP / launch time in the kernel trace / 2.5 PFLOP/s, from the file `traffic_source` names (the MFMAs the kernel issues, all three split terms counted)",
                          "peak_definition": "dense fp16 MFMA peak 2500 TFLOP/s / 3 (every GEMM is a 3-term split-fp16 product, fp32 accumulate): the hardware matrix peak of the arithmetic the kernel uses, in fp32-equivalent FLOP/s",

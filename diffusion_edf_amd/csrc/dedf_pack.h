@@ -233,7 +233,7 @@ inline std::vector<float> pad_params(const dedf_config& c, const IrrepsRT& T, co
         if (it == Sk.index.end()) throw std::runtime_error("pad_params: " + e.name + " missing in the kernel schema");
         if (Sk.entries[it->second].numel == e.numel) std::copy(Bt + e.offset, Bt + e.offset + e.numel, out.data() + Sk.entries[it->second].offset);
     }
-    if (L < 3) return out;
+    if (L < 3 || c.unet_layer) return out;      // (UNet-layer handles already speak the kernel shapes)
     // 2. the tensors that do
     const std::string blk = "key_tensor_field.gnn_block_init";
     per_l_vec(blk + ".prenorm_src.affine_weight");

@@ -299,8 +299,9 @@ def n_params(cfg: HeadConfig) -> int:
 # one layer of the UNet feature extractor (the whole extractor: unet.py)
 # --------------------------------------------------------------------------------------------------
 
-def unet_layer_param_spec(irreps: Irreps, fc_neurons: List[int], num_heads: int = 4, lmax_sh: int = 2,
-                          irreps_mlp_mid: int = 3, irreps_src: Optional[Irreps] = None) -> List[Tuple[str, Tuple[int, ...], str, float]]:
+def unet_layer_param_spec(irreps: Irreps, fc_neurons: List[int], num_heads: int = 4, lmax_sh: Optional[int] = None,
+                          irreps_mlp_mid: int = 3, irreps_src: Optional[Irreps] = None,
+                          mid_muls: Optional[List[int]] = None) -> List[Tuple[str, Tuple[int, ...], str, float]]:
     """Schema of the ModuleDict {'radial': GaussianRadialBasisLayerFiniteCutoff, 'gnn': block.EquiformerBlock} the reference builds
     for every UNet layer (unet_feature_extractor.py:141-156; names = its state_dict keys below e.g. ``down_blocks.3.pool_layer.``).
     ``irreps`` = irreps_dst = the block's irreps_emb; ``irreps_src`` (default: the same) only shapes norm_1_src / linear_src
@@ -309,6 +310,7 @@ def unet_layer_param_spec(irreps: Irreps, fc_neurons: List[int], num_heads: int 
     muls = [m for m, _ in irreps]
     muls_src = muls if irreps_src is None else [m for m, _ in irreps_src]
     L, n0, nirr = len(muls) - 1, muls[0], sum(muls)
+    lmax_sh = L if lmax_sh is None else lmax_sh
     nb = fc_neurons[0]
     S.append(("radial.mean", (1, nb), 'linspace', 0.0))                                             # radial_func.py:242-243
     S.append(("radial.std_logit", (1, nb), 'const', math.log(math.exp(2.0 / nb) - 1)))              # :248-249
@@ -353,7 +355,7 @@ def unet_layer_param_spec(irreps: Irreps, fc_neurons: List[int], num_heads: int 
     S.append((f"{ga}.proj.tp.weight", (sum(m * m for m in muls),), sq, 0))
     S.append((f"{ga}.proj.bias.0", (n0,), 'zeros', 0))
     S.append((f"{g}.norm_2.affine_weight", (nirr,), 'ones', 0)); S.append((f"{g}.norm_2.affine_bias", (n0,), 'zeros', 0))
-    mid = [m * irreps_mlp_mid for m in muls]
+    mid = [m * irreps_mlp_mid for m in muls] if mid_muls is None else list(mid_muls)       # (mid_muls: the kernels' padded hidden widths, unet_pad.WIDE_HID)
     f1_out = [mid[0] + sum(mid[1:])] + mid[1:]
     S.append((f"{g}.ffn.fctp_1.tp.weight", (sum(a * b for a, b in zip(muls, f1_out)),), 'tp_w:' + ','.join(f"{a*b}:{a}" for a, b in zip(muls, f1_out)), 0))
     S.append((f"{g}.ffn.fctp_1.bias.0", (f1_out[0],), 'zeros', 0))

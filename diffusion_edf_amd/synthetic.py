@@ -131,6 +131,10 @@ def unet_kwargs(kind: str = "panda_lowres") -> dict:
     """the four feature_extractor_kwargs blocks the reference ships (configs/*/*/score_model_configs.yaml)"""
     narrow, wide = "32x0e+16x1e+8x2e", "64x0e+32x1e+16x2e"
     sh = "1x0e+1x1e+1x2e"
+    if kind.endswith("_lmax3"):        # BASELINE config 5: the same networks with one more degree (64x0e+32x1e+16x2e+8x3e, SH up to 3e); no shipped YAML uses it
+        kw = unet_kwargs(kind[:-len("_lmax3")])
+        up = lambda s_: {narrow: narrow + "+4x3e", wide: wide + "+8x3e", sh: sh + "+1x3e"}[s_]
+        return dict(kw, irreps_output=up(kw["irreps_output"]), irreps_emb=[up(i) for i in kw["irreps_emb"]], irreps_edge_attr=[up(i) for i in kw["irreps_edge_attr"]])
     base = dict(irreps_input="3x0e", irreps_output=wide, irreps_mlp_mid=3, attn_type="mlp", alpha_drop=0.1, proj_drop=0.1, drop_path_rate=0.0,
                 pool_method="fps", n_layers_midstream=2)
     if kind == "panda_lowres":         # pool_ratio 0.2 (…/pick_lowres, place_ebm …)

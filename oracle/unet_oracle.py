@@ -43,6 +43,8 @@ class LayerConfig(NamedTuple):
     # shape equals the narrow layer iff the LayerNorms use the true channel counts and the radial basis the true num_basis
     valid: Optional[list] = None               # true multiplicities per degree (norm_2 statistics)
     fc_valid: Optional[list] = None            # true [num_basis, h1, h2]
+    mid_muls: Optional[list] = None            # hidden multiplicities of the FFN when they are not irreps_mlp_mid x mul (the kernels' lmax-3 shape:
+                                               # 24x3e hidden channels padded to 32, not to 3 x 16)
 
 
 def _masked_layer_norm(x: Tensor, n_valid: int, w: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
@@ -165,6 +167,8 @@ def layer_forward(cfg: LayerConfig, P: Dict[str, Tensor], x_src: Tensor, f_src: 
     node_output = f_dst + node_features                                                    # block.py:165
     nf = _norm_v2(node_output, irreps, P, f"{g}.norm_2", cfg.valid)
     mid = R.simplify(R.sort_even_first([(m, l) for _ in range(cfg.irreps_mlp_mid) for m, l in irreps])[0])
+    if cfg.mid_muls is not None:
+        mid = [(int(m), l) for l, m in enumerate(cfg.mid_muls)]
     sc, gt, gd = R.irreps2gate(mid)
     ffn_in = R.simplify(sc + gt + gd)
     y1 = torch.ones_like(nf[:, 0:1])
