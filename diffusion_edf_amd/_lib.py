@@ -19,7 +19,7 @@ SYMBOLS = [
     "dedf_version", "dedf_param_count", "dedf_param_name", "dedf_param_numel", "dedf_create", "dedf_destroy",
     "dedf_last_error", "dedf_set_key_clouds", "dedf_set_key_weights", "dedf_set_query", "dedf_score", "dedf_energy", "dedf_sample", "dedf_get_stats",
     "dedf_debug_enable", "dedf_debug_copy", "dedf_debug_packed", "dedf_profile_enable", "dedf_profile_read",
-    "dedf_fps", "dedf_radius", "dedf_layer_forward", "dedf_linear_rs", "dedf_field", "dedf_keypoint_weight", "dedf_layer_defer_check", "dedf_layer_check", "dedf_set_radial_table", "dedf_linear_rs_lmax",
+    "dedf_fps", "dedf_radius", "dedf_radius_scratch_bytes", "dedf_layer_forward", "dedf_linear_rs", "dedf_field", "dedf_keypoint_weight", "dedf_layer_defer_check", "dedf_layer_check", "dedf_set_radial_table", "dedf_linear_rs_lmax",
 ]
 
 
@@ -40,7 +40,8 @@ class DedfSchedule(C.Structure):
 
 
 class DedfStats(C.Structure):
-    _fields_ = [("n_dst", C.c_int64), ("n_edges", C.c_int64 * MAX_SCALES), ("n_edges_total", C.c_int64), ("overflow", C.c_int), ("nonfinite", C.c_int)]
+    _fields_ = [("n_dst", C.c_int64), ("n_edges", C.c_int64 * MAX_SCALES), ("n_edges_total", C.c_int64), ("overflow", C.c_int), ("nonfinite", C.c_int),
+                ("rtab_err", C.c_float * MAX_SCALES), ("rtab_fallback", C.c_int)]
 
 
 class DedfProfile(C.Structure):
@@ -83,8 +84,9 @@ def load() -> C.CDLL:
     lib.dedf_sample.restype = C.c_int
     lib.dedf_fps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]; lib.dedf_fps.restype = C.c_int
     lib.dedf_radius.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
-                                P(C.c_int64), C.c_void_p]
+                                P(C.c_int64), C.c_void_p, C.c_size_t, C.c_void_p]
     lib.dedf_radius.restype = C.c_int
+    lib.dedf_radius_scratch_bytes.argtypes = [C.c_int]; lib.dedf_radius_scratch_bytes.restype = C.c_size_t
     lib.dedf_layer_forward.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]
     lib.dedf_layer_forward.restype = C.c_int

@@ -55,12 +55,14 @@ def radius(x: torch.Tensor, y: torch.Tensor, r: float, batch_x=None, batch_y=Non
     n = C.c_int64(0)
     full = len(ys) * min(int(max_num_neighbors), len(xs))          # the most there can be; taken at once while it is small (<= 256 MB)
     cap = full if full <= (1 << 24) else 32 * len(ys) + 1024
+    nbytes = int(lib.dedf_radius_scratch_bytes(len(ys)))
+    scratch = torch.empty((nbytes + 7) // 8, device=x.device, dtype=torch.int64)          # caller-owned scratch: the library keeps no state
     while True:
         ed = torch.empty(cap, device=x.device, dtype=torch.int64)
         es = torch.empty(cap, device=x.device, dtype=torch.int64)
         with torch.cuda.device(x.device):
             rc = lib.dedf_radius(xs.data_ptr(), len(xs), ys.data_ptr(), len(ys), float(r), int(max_num_neighbors), int(_exclude_self),
-                                 cap, ed.data_ptr(), es.data_ptr(), C.byref(n), _stream())
+                                 cap, ed.data_ptr(), es.data_ptr(), C.byref(n), scratch.data_ptr(), scratch.numel() * 8, _stream())
         if rc == _lib.OK:
             break
         if rc == _lib.ERR_INVALID and n.value > cap:

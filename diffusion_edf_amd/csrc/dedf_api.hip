@@ -10,8 +10,6 @@
 #include <string>
 #include <vector>
 #include "../../include/dedf.h"
-#include <map>
-#include <mutex>
 #include "dedf_misc.h"
 #include "dedf_pack.h"
 
@@ -81,7 +79,8 @@ struct dedf_handle {
     DevBuf d_tb_steps; const float* tb_step = nullptr;    // dedf_sample: the time-bias rows of ALL steps are computed up front; tb_step = this step's rows
     std::vector<float> h_tsteps;
     int radial_table = 1;         // sampler: tabulate the radial network's front per launch (DEDF_RADIAL_TABLE=0 / dedf_set_radial_table turn it off)
-    DevBuf d_rtab;
+    DevBuf d_rtab, d_rtab_err;    // table rows; per-scale accuracy words (largest |interpolated - exact| activation at the interval midpoints)
+    float rtab_err_bound = 1e-5f; // a scale whose word exceeds it evaluates its front per edge (DEDF_RADIAL_TABLE_BOUND)
     bool defer_check = false;         // dedf_layer_defer_check
     DevBuf d_sticky;
     bool want_field = false;          // dedf_field: the node kernel also writes the field / emb of every node
@@ -312,6 +311,121 @@ void launch_time_bias(dedf_handle* h, hipStream_t st, const float* time, int tim
     hipLaunchKernelGGL(k_time_bias, dim3(rows, c.n_scales), dim3(256), 0, st, tp);
 }
 
+// parameters of the fused edge kernel for the current state of the handle
+template <int L, int F0>
+EdgeParams edge_params(dedf_handle* h, int nT, int time_stride) {
+    constexpr bool EBM = F0 == kLenEmb;
+    constexpr int D = feat_dim<L>();
+    const dedf_config& c = h->cfg;
+    const int ns = c.n_scales;
+    const float* nat = h->d_nat.as<float>();
+    EdgeParams P{};
+    P.key_x = h->d_key_x.as<float>(); P.qpos = h->d_qpos.as<float>(); P.edge_src = h->d_esrc.as<int>(); P.edge_dst = h->d_edst.as<int>();
+    P.tile_info = h->d_tile.as<int>(); P.msg = h->d_msg.as<float>(); P.msg_bytes = (uint32_t)((size_t)h->n_keys * D * 4);
+    if constexpr (EBM) {
+        P.tb = nat + h->nat_brows; P.tb_bytes = (uint32_t)((size_t)ns * F0 * 4); P.tb_pose_stride = 0;
+    } else {
+        P.tb = h->tb_step ? h->tb_step : h->d_tb.as<float>();
+        P.tb_bytes = (uint32_t)((size_t)(time_stride && !h->tb_step ? nT : 1) * ns * F0 * 4);
+        P.tb_pose_stride = time_stride && !h->tb_step ? ns * F0 : 0;
+    }
+    P.nQ = h->nQ; P.n_scales = ns;
+    for (int n = 0; n < ns; ++n) {
+        P.radius[n] = c.radii[n] > 0 ? c.radii[n] : -1.0f;
+        P.cut_begin[n] = (float)(0.8 * (double)c.radii[n]);
+        P.cut_div[n] = (float)(1.0 * (double)c.radii[n] - 0.8 * (double)c.radii[n]);
+    }
+    P.ns_lo = (float)(0.2 * (double)c.r_mincut_nonscalar_sh);
+    P.ns_div = (float)(1.0 * (double)c.r_mincut_nonscalar_sh - 0.2 * (double)c.r_mincut_nonscalar_sh);
+    P.len_enc_max_r = c.length_enc_max_r;
+    P.W = h->d_edge_w.as<float>(); P.W_bytes = (uint32_t)h->d_edge_w.bytes;
+    const EdgeOffsets& o = h->eo;
+    P.o_enc = o.o_enc; P.o_A_pre = o.o_A_pre; P.o_A_pre_l = o.o_A_pre_l; P.o_A_r1_l = o.o_A_r1_l; P.o_A_r2_l = o.o_A_r2_l; P.o_A_r3_l = o.o_A_r3_l; P.o_A_r1 = o.o_A_r1; P.o_b_r1 = o.o_b_r1; P.o_g_r1 = o.o_g_r1; P.o_be_r1 = o.o_be_r1;
+    P.o_A_r2 = o.o_A_r2; P.o_b_r2 = o.o_b_r2; P.o_g_r2 = o.o_g_r2; P.o_be_r2 = o.o_be_r2; P.o_A_r3 = o.o_A_r3; P.o_off_r3 = o.o_off_r3;
+    P.o_S_lin = o.o_S_lin; P.o_S_val = o.o_S_val;
+    P.w_unscale = o.w_unscale; P.u_scale = o.u_scale;
+    for (int l = 0; l < 4; ++l) { P.c_lin[l] = o.c_lin[l]; P.c_val[l] = o.c_val[l]; }
+    P.o_b_r0 = o.o_b_r0; P.o_b_val0 = o.o_b_val0; P.o_alpha_dot = o.o_alpha_dot;
+    P.key_w = h->cfg.use_src_point_attn ? h->d_key_w.as<float>() : nullptr;
+    P.out = h->d_eout.as<float>();
+    P.dbg_w = h->debug ? h->d_dbgw.as<float>() : nullptr;
+    P.dbg_out = (h->debug && h->d_dbgo.ensure((size_t)h->edge_cap * edge_rec<L>() * 4)) ? h->d_dbgo.as<float>() : nullptr;
+    P.phase_prof = nullptr;
+#if defined(DEDF_PHASE_PROF)
+    if (h->d_phase.ensure((size_t)h->n_cu * 4 * 16 * 8)) P.phase_prof = h->d_phase.as<unsigned long long>();
+#endif
+    return P;
+}
+
+// ---- the sampler's radial table (dedf_edge.h: EdgeParams::rtab) ------------------------------------------------------------------------
+// instantiated for the score heads: lmax 2 with fc_neurons {128|192, 128, 64} and {128, 32, 32}; lmax 3 with {128, 128, 64}; full precision
+template <int L, int F0> constexpr bool has_radial_table() { return (L == 2 && (F0 == 128 || F0 == 192)) || (L == 3 && F0 == 128); }
+template <int L, int F0> bool table_instantiated(const dedf_handle* h) {
+    const bool narrow = h->cfg.fc_neurons[1] == 32;
+    return !h->cfg.half_gemm && !h->cfg.ebm && !(narrow && !(L == 2 && F0 == 128));
+}
+// Accuracy bound of scale n: 1e-5 (absolute, on the O(1) activations; the fp32 evaluation's own noise measures ~2e-6 there) for the finite
+// scales, whose Gaussian length encoder is trainable.  The all-pairs scale's sinusoidal encoder has no trainable parameter and its
+// interpolation error is ~1e-7; what the check sees there is the rounding of the fp32 ARGUMENT x = 10 len fr of sin / cos, up to
+// x = 1000 * kRtabInfiniteSpan at the far end of the grid (ulp 1.2e-4 at 1 500: measured deviation 1.2-1.4e-4, the same noise the
+// per-edge evaluation -- and the reference's own fp32 forward -- carries): its bound is two ulps of that argument.
+float radial_table_bound(const dedf_handle* h, int n) {
+    if (h->cfg.radii[n] > 0) return h->rtab_err_bound;
+    const float xmax = 1000.0f * (float)kRtabInfiniteSpan;
+    return std::max(h->rtab_err_bound, 2.0f * (std::nextafter(xmax, 2.0f * xmax) - xmax));
+}
+// grid of every scale + the device buffers (table rows, accuracy words)
+int radial_table_setup(dedf_handle* h, EdgeParams& P) {
+    const dedf_config& c = h->cfg;
+    int row = 0;
+    for (int n = 0; n < c.n_scales; ++n) {
+        const bool fin = c.radii[n] > 0;
+        const int G = fin ? kRtabFinite : kRtabInfinite;
+        const double span = fin ? (double)c.radii[n] : kRtabInfiniteSpan * (double)c.length_enc_max_r;
+        P.rtab_row0[n] = row; P.rtab_n[n] = G;
+        P.rtab_step[n] = (float)(span / G); P.rtab_inv_step[n] = (float)(G / span);
+        row += G + 3;
+    }
+    const size_t bytes = (size_t)row * 64 * 4;
+    if (!h->d_rtab.ensure(bytes)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(radial table) failed");
+    if (!h->d_rtab_err.p) {
+        if (!h->d_rtab_err.ensure(kMaxScales * 4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(radial table) failed");
+        if (hipMemset(h->d_rtab_err.p, 0, kMaxScales * 4) != hipSuccess) return fail(h, DEDF_ERR_RUNTIME, "hipMemset failed");
+    }
+    P.rtab = h->d_rtab.as<float>(); P.rtab_out = h->d_rtab.as<float>(); P.rtab_bytes = (uint32_t)bytes;
+    P.rtab_err = h->d_rtab_err.as<unsigned>();
+    for (int n = 0; n < c.n_scales; ++n) P.rtab_err_bound[n] = radial_table_bound(h, n);
+    return DEDF_OK;
+}
+// the generator (one launch) and, when `check`, the accuracy check of what it produced (a second launch: every interval midpoint)
+template <int L, int F0, int H1, int H2>
+void launch_radial_table(dedf_handle* h, const EdgeParams& P, hipStream_t st, bool check) {
+    int ntab = 0, nchk = 0;
+    for (int n = 0; n < P.n_scales; ++n) { ntab += (P.rtab_n[n] + 3 + 31) / 32; nchk += (P.rtab_n[n] + 31) / 32; }
+    hipLaunchKernelGGL((k_radial_table<L, F0, false, H1, H2>), dim3(std::min(ntab, h->n_cu * 4)), dim3(64), 0, st, P);
+    if (check) hipLaunchKernelGGL((k_radial_check<L, F0, false, H1, H2>), dim3(std::min(nchk, h->n_cu * 4)), dim3(64), 0, st, P);
+}
+// dedf_sample, before its loop: table + check at the time-bias rows h->tb_step (the accuracy words accumulate over the calls)
+template <int L, int F0>
+int radial_table_check(dedf_handle* h, hipStream_t st) {
+    if constexpr (has_radial_table<L, F0>()) {
+        if (!table_instantiated<L, F0>(h)) return DEDF_OK;
+        EdgeParams P = edge_params<L, F0>(h, 1, 0);
+        int rc = radial_table_setup(h, P);
+        if (rc != DEDF_OK) return rc;
+        if (h->cfg.fc_neurons[1] == 32) { if constexpr (L == 2 && F0 == 128) launch_radial_table<L, F0, 32, 32>(h, P, st, true); }
+        else launch_radial_table<L, F0, 128, 64>(h, P, st, true);
+    }
+    return DEDF_OK;
+}
+int radial_table_check_dispatch(dedf_handle* h, hipStream_t st) {
+    const int F0 = h->cfg.fc_neurons[0];
+    if (h->L == 2 && F0 == 128) return radial_table_check<2, 128>(h, st);
+    if (h->L == 2 && F0 == 192) return radial_table_check<2, 192>(h, st);
+    if (h->L == 3 && F0 == 128) return radial_table_check<3, 128>(h, st);
+    return DEDF_OK;
+}
+
 // one evaluation of the score head on poses already in h->d_Ts (f32) with times in h->d_time
 template <int L, int F0>
 int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, hipStream_t st) {
@@ -352,121 +466,51 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     mark();
     // 4. fused edge pipeline
     {
-        EdgeParams P{};
-        P.key_x = h->d_key_x.as<float>(); P.qpos = h->d_qpos.as<float>(); P.edge_src = h->d_esrc.as<int>(); P.edge_dst = h->d_edst.as<int>();
-        P.tile_info = h->d_tile.as<int>(); P.msg = h->d_msg.as<float>(); P.msg_bytes = (uint32_t)((size_t)h->n_keys * D * 4);
-        if constexpr (EBM) {
-            P.tb = nat + h->nat_brows; P.tb_bytes = (uint32_t)((size_t)ns * F0 * 4); P.tb_pose_stride = 0;
-        } else {
-            P.tb = h->tb_step ? h->tb_step : h->d_tb.as<float>();
-            P.tb_bytes = (uint32_t)((size_t)(time_stride && !h->tb_step ? nT : 1) * ns * F0 * 4);
-            P.tb_pose_stride = time_stride && !h->tb_step ? ns * F0 : 0;
-        }
-        P.nQ = nQ; P.n_scales = ns;
-        for (int n = 0; n < ns; ++n) {
-            P.radius[n] = c.radii[n] > 0 ? c.radii[n] : -1.0f;
-            P.cut_begin[n] = (float)(0.8 * (double)c.radii[n]);
-            P.cut_div[n] = (float)(1.0 * (double)c.radii[n] - 0.8 * (double)c.radii[n]);
-        }
-        P.ns_lo = (float)(0.2 * (double)c.r_mincut_nonscalar_sh);
-        P.ns_div = (float)(1.0 * (double)c.r_mincut_nonscalar_sh - 0.2 * (double)c.r_mincut_nonscalar_sh);
-        P.len_enc_max_r = c.length_enc_max_r;
-        P.W = h->d_edge_w.as<float>(); P.W_bytes = (uint32_t)h->d_edge_w.bytes;
-        const EdgeOffsets& o = h->eo;
-        P.o_enc = o.o_enc; P.o_A_pre = o.o_A_pre; P.o_A_pre_l = o.o_A_pre_l; P.o_A_r1_l = o.o_A_r1_l; P.o_A_r2_l = o.o_A_r2_l; P.o_A_r3_l = o.o_A_r3_l; P.o_A_r1 = o.o_A_r1; P.o_b_r1 = o.o_b_r1; P.o_g_r1 = o.o_g_r1; P.o_be_r1 = o.o_be_r1;
-        P.o_A_r2 = o.o_A_r2; P.o_b_r2 = o.o_b_r2; P.o_g_r2 = o.o_g_r2; P.o_be_r2 = o.o_be_r2; P.o_A_r3 = o.o_A_r3; P.o_off_r3 = o.o_off_r3;
-        P.o_S_lin = o.o_S_lin; P.o_S_val = o.o_S_val;
-        P.w_unscale = o.w_unscale; P.u_scale = o.u_scale;
-        for (int l = 0; l < 4; ++l) { P.c_lin[l] = o.c_lin[l]; P.c_val[l] = o.c_val[l]; }
-        P.o_b_r0 = o.o_b_r0; P.o_b_val0 = o.o_b_val0; P.o_alpha_dot = o.o_alpha_dot;
-        P.key_w = h->cfg.use_src_point_attn ? h->d_key_w.as<float>() : nullptr;
-        P.out = h->d_eout.as<float>();
-        P.dbg_w = h->debug ? h->d_dbgw.as<float>() : nullptr;
-        P.dbg_out = (h->debug && h->d_dbgo.ensure((size_t)h->edge_cap * edge_rec<L>() * 4)) ? h->d_dbgo.as<float>() : nullptr;
-        P.phase_prof = nullptr;
-#if defined(DEDF_PHASE_PROF)
-        if (h->d_phase.ensure((size_t)h->n_cu * 4 * 16 * 8)) P.phase_prof = h->d_phase.as<unsigned long long>();
-#endif
+        EdgeParams P = edge_params<L, F0>(h, nT, time_stride);
         static const int wpc = [] { const char* e = getenv("DEDF_EDGE_WAVES_PER_CU"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 4 ? v : 4; }();   // experiments only
-        // half_gemm (the reference's half_precision knob): single-term fp16 products
         const dim3 grid(h->n_cu * wpc), blk(64);
-        const bool hp = h->cfg.half_gemm != 0;
+        const bool hp = h->cfg.half_gemm != 0;             // half_gemm (the reference's half_precision knob): single-term fp16 products
+        const bool narrow = h->cfg.fc_neurons[1] == 32;    // radial MLP [., 32, 32] (sapien place_*, KeypointExtractor fields) instead of [., 128, 64]
         // Sampler (every pose shares the step's time): the front of the radial network is a function of (scale, length) only -- tabulate
         // it once per launch on a fine length grid with the tile's own code and interpolate per edge (dedf_edge.h: EdgeParams::rtab)
         bool use_tab = false;
-        if constexpr (L == 3) {
-            static_assert(F0 == 128 || F0 == 64, "lmax 3 instantiations");
-            if constexpr (F0 == 128) {
-                use_tab = h->radial_table != 0 && P.tb_pose_stride == 0 && !h->debug && (Nd >= kRtabMinNodes || h->radial_table == 2);
-                if (use_tab) {
-                    int row = 0;
-                    for (int n = 0; n < ns; ++n) {
-                        const bool fin = c.radii[n] > 0;
-                        const int G = fin ? kRtabFinite : kRtabInfinite;
-                        const double span = fin ? (double)c.radii[n] : kRtabInfiniteSpan * (double)c.length_enc_max_r;
-                        P.rtab_row0[n] = row; P.rtab_n[n] = G;
-                        P.rtab_step[n] = (float)(span / G); P.rtab_inv_step[n] = (float)(G / span);
-                        row += G + 3;
-                    }
-                    const size_t bytes = (size_t)row * 64 * 4;
-                    if (!h->d_rtab.ensure(bytes)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(radial table) failed");
-                    P.rtab = h->d_rtab.as<float>(); P.rtab_out = h->d_rtab.as<float>(); P.rtab_bytes = (uint32_t)bytes;
-                    int ntab = 0;
-                    for (int n = 0; n < ns; ++n) ntab += (P.rtab_n[n] + 3 + 31) / 32;
-                    hipLaunchKernelGGL((k_radial_table<3, 128>), dim3(std::min(ntab, h->n_cu * 4)), blk, 0, st, P);
-                    hipLaunchKernelGGL((k_edge<3, 128, false, 128, 64, false, 1>), grid, blk, 0, st, P);
-                } else hipLaunchKernelGGL((k_edge<3, 128, false>), grid, blk, 0, st, P);
-            } else if (h->cfg.fc_neurons[1] == 32) hipLaunchKernelGGL((k_edge<3, 64, false, 32, 32>), grid, blk, 0, st, P);
-            else hipLaunchKernelGGL((k_edge<3, 64, false>), grid, blk, 0, st, P);
-            (void)hp;
-        }
-        if constexpr ((F0 == 128 || F0 == 192) && L == 2 && !EBM) {
-            const bool narrow = h->cfg.fc_neurons[1] == 32;
+        if constexpr (has_radial_table<L, F0>()) {
             // (worth its 34 us generator launch from ~6 rounds of edge tiles on: ~20 edges per destination node -> 8 192 nodes)
-            use_tab = h->radial_table != 0 && !hp && P.tb_pose_stride == 0 && !h->debug && !(narrow && F0 == 192) && (Nd >= kRtabMinNodes || h->radial_table == 2);
+            use_tab = table_instantiated<L, F0>(h) && h->radial_table != 0 && P.tb_pose_stride == 0 && !h->debug && (Nd >= kRtabMinNodes || h->radial_table == 2);
             if (use_tab) {
-                int row = 0;
-                for (int n = 0; n < ns; ++n) {
-                    const bool fin = c.radii[n] > 0;
-                    const int G = fin ? kRtabFinite : kRtabInfinite;
-                    const double span = fin ? (double)c.radii[n] : kRtabInfiniteSpan * (double)c.length_enc_max_r;
-                    P.rtab_row0[n] = row; P.rtab_n[n] = G;
-                    P.rtab_step[n] = (float)(span / G); P.rtab_inv_step[n] = (float)(G / span);
-                    row += G + 3;
-                }
-                const size_t bytes = (size_t)row * 64 * 4;
-                if (!h->d_rtab.ensure(bytes)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(radial table) failed");
-                P.rtab = h->d_rtab.as<float>(); P.rtab_out = h->d_rtab.as<float>(); P.rtab_bytes = (uint32_t)bytes;
-                int ntab = 0;
-                for (int n = 0; n < ns; ++n) ntab += (P.rtab_n[n] + 3 + 31) / 32;
-                const dim3 tgrid(std::min(ntab, h->n_cu * 4));
-                if constexpr (F0 == 192) {
-                    hipLaunchKernelGGL((k_radial_table<2, 192>), tgrid, blk, 0, st, P);
-                    hipLaunchKernelGGL((k_edge<2, 192, false, 128, 64, false, 1>), grid, blk, 0, st, P);
-                } else if (narrow) {
-                    hipLaunchKernelGGL((k_radial_table<2, 128, false, 32, 32>), tgrid, blk, 0, st, P);
-                    hipLaunchKernelGGL((k_edge<2, 128, false, 32, 32, false, 1>), grid, blk, 0, st, P);
+                int rc = radial_table_setup(h, P);
+                if (rc != DEDF_OK) return rc;
+                if (narrow) {
+                    if constexpr (L == 2 && F0 == 128) {
+                        launch_radial_table<L, F0, 32, 32>(h, P, st, false);
+                        hipLaunchKernelGGL((k_edge<L, F0, false, 32, 32, false, 1>), grid, blk, 0, st, P);
+                    }
                 } else {
-                    hipLaunchKernelGGL((k_radial_table<2, 128>), tgrid, blk, 0, st, P);
-                    hipLaunchKernelGGL((k_edge<2, 128, false, 128, 64, false, 1>), grid, blk, 0, st, P);
+                    launch_radial_table<L, F0, 128, 64>(h, P, st, false);
+                    hipLaunchKernelGGL((k_edge<L, F0, false, 128, 64, false, 1>), grid, blk, 0, st, P);
                 }
             }
         }
-        if constexpr (L < 3) {
         if (use_tab) {
+        } else if constexpr (L == 3) {          // lmax 3: full precision, [., 128, 64] (score head, EBM critic) or [64, 32, 32] (context-free fields)
+            static_assert(F0 == 128 || F0 == 64, "lmax 3 instantiations");
+            if constexpr (F0 == 64) {
+                if (narrow) hipLaunchKernelGGL((k_edge<3, 64, false, 32, 32>), grid, blk, 0, st, P);
+                else hipLaunchKernelGGL((k_edge<3, 64, false>), grid, blk, 0, st, P);
+            } else hipLaunchKernelGGL((k_edge<3, 128, false>), grid, blk, 0, st, P);
+            (void)hp;
         } else if constexpr (F0 == 128) {
-            if (h->cfg.fc_neurons[1] == 32) {         // narrow radial MLP (sapien place_*)
+            if (narrow) {         // narrow radial MLP (sapien place_*)
                 if (hp) hipLaunchKernelGGL((k_edge<L, F0, true, 32, 32>), grid, blk, 0, st, P);
                 else hipLaunchKernelGGL((k_edge<L, F0, false, 32, 32>), grid, blk, 0, st, P);
             } else if (hp) hipLaunchKernelGGL((k_edge<L, F0, true>), grid, blk, 0, st, P);
             else hipLaunchKernelGGL((k_edge<L, F0>), grid, blk, 0, st, P);
         } else if constexpr (F0 == 64 && L == 2) {
-            if (h->cfg.fc_neurons[1] == 32) hipLaunchKernelGGL((k_edge<L, F0, false, 32, 32>), grid, blk, 0, st, P);      // KeypointExtractor fields
+            if (narrow) hipLaunchKernelGGL((k_edge<L, F0, false, 32, 32>), grid, blk, 0, st, P);      // KeypointExtractor fields
             else if (hp) hipLaunchKernelGGL((k_edge<L, F0, true>), grid, blk, 0, st, P);
             else hipLaunchKernelGGL((k_edge<L, F0>), grid, blk, 0, st, P);
         } else if (hp) hipLaunchKernelGGL((k_edge<L, F0, true>), grid, blk, 0, st, P);
         else hipLaunchKernelGGL((k_edge<L, F0>), grid, blk, 0, st, P);
-        }
     }
     mark();
     // 5. joint softmax + aggregation
@@ -571,6 +615,7 @@ int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, de
     h->L = cfg->lmax;
     h->host_only = cfg->device < 0;
     if (const char* e = getenv("DEDF_RADIAL_TABLE")) h->radial_table = std::max(0, std::min(2, atoi(e)));
+    if (const char* e = getenv("DEDF_RADIAL_TABLE_BOUND")) h->rtab_err_bound = (float)atof(e);
     const IrrepsRT T(h->L, cfg->unet_layer != 0), K(h->L, true);
     h->spec = build_spec(T, h->cfg);
     h->kspec = build_spec(K, h->cfg);
@@ -815,6 +860,21 @@ int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedul
         for (int s = 0; s < sched->n_steps; ++s) h->h_tsteps[s] = (float)sched->t[s];
         HIPCK(h, hipMemcpyAsync(h->d_time.p, h->h_tsteps.data(), (size_t)sched->n_steps * 4, hipMemcpyHostToDevice, st));
         launch_time_bias(h, st, h->d_time.as<float>(), 1, sched->n_steps, h->d_tb_steps.as<float>());
+        // Accuracy guard of the radial table, once per call: the table of the first, the middle and the last step (the time only shifts the
+        // pre-linear's bias rows; what decides the interpolation error is the length encoder) is checked at EVERY interval midpoint of every
+        // scale against the exact evaluation; a scale whose largest deviation exceeds the bound evaluates its front per edge in this call.
+        if (h->radial_table != 0 && ((int64_t)nT * h->nQ >= kRtabMinNodes || h->radial_table == 2) && !h->debug) {
+            if (h->d_rtab_err.p) HIPCK(h, hipMemsetAsync(h->d_rtab_err.p, 0, kMaxScales * 4, st));
+            int last = -1;
+            for (int s : {0, sched->n_steps / 2, sched->n_steps - 1}) {
+                if (s == last) continue;
+                last = s;
+                h->tb_step = h->d_tb_steps.as<float>() + (size_t)s * tb_row;
+                rc = radial_table_check_dispatch(h, st);
+                h->tb_step = nullptr;
+                if (rc != DEDF_OK) return rc;
+            }
+        }
     }
     for (int s = 0; s < sched->n_steps; ++s) {
         // one step = pose prep (reads the f64 state), neighbour count + fill, edge, aggregate, node, reduce + Langevin update
@@ -998,6 +1058,10 @@ int dedf_get_stats(dedf_handle* h, dedf_stats* out) {
     for (int n = 0; n < h->cfg.n_scales; ++n) { out->n_edges[n] = ti[16 + n + 1] - ti[16 + n]; out->n_edges_total += out->n_edges[n]; }
     out->overflow = ti[40] | ti[kFlagOverflow];
     out->nonfinite = ti[kFlagNonFinite];
+    if (h->d_rtab_err.p) {
+        HIPCK(h, hipMemcpy(out->rtab_err, h->d_rtab_err.p, kMaxScales * 4, hipMemcpyDeviceToHost));
+        for (int n = 0; n < h->cfg.n_scales; ++n) if (!(out->rtab_err[n] <= radial_table_bound(h, n))) out->rtab_fallback |= 1 << n;
+    }
     return DEDF_OK;
 }
 
@@ -1119,31 +1183,28 @@ int dedf_fps(const float* x, int n, int n_samples, int start, int* idx_out, void
     return hipGetLastError() == hipSuccess ? DEDF_OK : DEDF_ERR_RUNTIME;
 }
 
+size_t dedf_radius_scratch_bytes(int n_dst) { return n_dst > 0 ? ((size_t)n_dst + 1) * 8 + (size_t)n_dst * 4 : 0; }
+
 int dedf_radius(const float* x_src, int n_src, const float* x_dst, int n_dst, float r, int max_num_neighbors, int exclude_self,
-                int64_t edge_cap, int64_t* edge_dst, int64_t* edge_src, int64_t* n_edges, void* stream) {
+                int64_t edge_cap, int64_t* edge_dst, int64_t* edge_src, int64_t* n_edges, void* scratch, size_t scratch_bytes, void* stream) {
     if (!x_src || !x_dst || n_src <= 0 || n_dst <= 0 || !(r > 0.0f) || max_num_neighbors <= 0 || !n_edges || edge_cap < 0) return DEDF_ERR_INVALID;
     if (edge_cap > 0 && (!edge_dst || !edge_src)) return DEDF_ERR_INVALID;
+    if (!scratch || scratch_bytes < dedf_radius_scratch_bytes(n_dst) || (reinterpret_cast<uintptr_t>(scratch) & 7)) return DEDF_ERR_INVALID;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // scratch (counts, offsets) is kept between calls, one set per device; like a handle, not for concurrent use from several threads
-    static std::mutex mu;
-    static auto* scratch = new std::map<int, std::pair<DevBuf, DevBuf>>();      // never destroyed: no hipFree after the runtime has shut down
-    std::lock_guard<std::mutex> lock(mu);
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return DEDF_ERR_RUNTIME;
-    DevBuf& cnt = (*scratch)[dev].first;
-    DevBuf& off = (*scratch)[dev].second;
-    if (!cnt.ensure((size_t)n_dst * 4) || !off.ensure(((size_t)n_dst + 1) * 8)) return DEDF_ERR_RUNTIME;
+    // caller-owned scratch (device): [n_dst + 1] int64 offsets (the last one = the total) | [n_dst] int32 counts.  No state in the library.
+    int64_t* off = static_cast<int64_t*>(scratch);
+    int* cnt = reinterpret_cast<int*>(off + n_dst + 1);
     const float r2 = r * r;
     const int nblk = (n_dst + kRadBlock / 64 - 1) / (kRadBlock / 64);          // one wave per destination
-    int64_t* total = off.as<int64_t>() + n_dst;
+    int64_t* total = off + n_dst;
     hipLaunchKernelGGL(k_radius<false>, dim3(nblk), dim3(kRadBlock), 0, st, x_src, n_src, x_dst, n_dst, r2, max_num_neighbors, exclude_self,
-                       cnt.as<int>(), (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, cnt.as<int>(), n_dst, off.as<int64_t>(), total);
+                       cnt, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, cnt, n_dst, off, total);
     if (hipMemcpyAsync(n_edges, total, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return DEDF_ERR_RUNTIME;
     if (*n_edges > edge_cap) return DEDF_ERR_INVALID;            // *n_edges holds the size the caller must provide
     if (*n_edges > 0)
         hipLaunchKernelGGL(k_radius<true>, dim3(nblk), dim3(kRadBlock), 0, st, x_src, n_src, x_dst, n_dst, r2, max_num_neighbors, exclude_self,
-                           cnt.as<int>(), off.as<int64_t>(), edge_dst, edge_src);
+                           cnt, off, edge_dst, edge_src);
     if (hipStreamSynchronize(st) != hipSuccess) return DEDF_ERR_RUNTIME;
     return DEDF_OK;
 }

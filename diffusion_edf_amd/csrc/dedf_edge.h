@@ -69,6 +69,12 @@ struct EdgeParams {
     float* rtab_out;
     int rtab_row0[kMaxScales], rtab_n[kMaxScales];
     float rtab_step[kMaxScales], rtab_inv_step[kMaxScales];
+    // Accuracy guard of the table (edge_tile MODE 3, k_radial_check): the front is ALSO evaluated exactly at the midpoint of every grid
+    // interval and compared with what the 4-point interpolation of the table gives there; the largest |interpolated - exact| activation of
+    // a scale accumulates (atomic max on the float's bits) in rtab_err[scale].  The table-reading kernel takes a scale's front from the table
+    // only while rtab_err[scale] <= rtab_err_bound[scale], per edge otherwise (visible in dedf_stats.rtab_fallback).
+    unsigned* rtab_err;
+    float rtab_err_bound[kMaxScales];
 };
 
 template <int L> struct SH {           // spherical harmonics of one edge, non-scalar blocks already cut off
@@ -83,13 +89,17 @@ template <int L> struct SH {           // spherical harmonics of one edge, non-s
 // They are the same for every tile and identical inside a half-wave; read through the vector L1 every tile they were 41
 // row tiles x 4 KiB = 29 % of the kernel's L1 delivery for 5.5 KiB of data.  Each wave copies them once into its own LDS
 // (k_edge prologue) and reads them back with broadcast ds_read_b128.  Offsets in floats, layout [tile][half][16] as packed.
-template <int L> struct RowsLds {
-    static constexpr int b1 = 0, g1 = 128, be1 = 256, b2 = 384, g2 = 448, be2 = 512, off3 = 576;
+// FRONT = false: the rows of the radial network's FRONT (layers 1-2: biases, LayerNorm affine; the length-encoder constants) stay in global
+// memory.  The table-reading kernel at lmax 3 does that: its tiles need them only when they fall back to the per-edge front, and the 3.8 KB
+// are what decides between two and three waves per CU there (46 KB of parked operands per wave).
+template <int L, int MODE> constexpr bool front_rows_in_lds() { return !(L == 3 && MODE == 1); }
+template <int L, bool FRONT = true> struct RowsLds {
+    static constexpr int b1 = 0, g1 = 128, be1 = 256, b2 = 384, g2 = 448, be2 = 512, off3 = FRONT ? 576 : 0;
     static constexpr int b0 = off3 + rup(dtp_wn<L>(), 32), val0 = b0 + r0_tiles<L>() * 32, adot = val0 + 64;
-    static constexpr int enc = adot + 64, total = enc + 192;      // enc: length-encoder constants of the scale being processed
+    static constexpr int enc = adot + 64, total = enc + (FRONT ? 192 : 0);      // enc: length-encoder constants of the scale being processed
 };
-template <int L> DEDF_DEV float* rows_lds() {
-    __shared__ __attribute__((aligned(16))) float rows[RowsLds<L>::total];
+template <int L, bool FRONT = true> DEDF_DEV float* rows_lds() {
+    __shared__ __attribute__((aligned(16))) float rows[RowsLds<L, FRONT>::total];
     return rows;
 }
 // accumulator tile <- 16 per-row values of row tile `tile` of the vector at LDS offset `off`
@@ -111,7 +121,7 @@ DEDF_DEV f32x16 ldrows_lds(const float* rows, int hi, int off, int tile) {
 // contributes exactly mean^2 to sum (x - mean)^2, which is taken out again (inv_n = 1 / n, n_pad = NT * 32 - n); their affine
 // parameters are zero, so they leave as SiLU(0) = 0.
 template <int NT, bool MASKED = false>
-DEDF_DEV void ln_silu(f32x16 (&x)[NT], const Wave& wv, const float* rows, int o_gamma, int o_beta, float inv_n = 0.0f, float n_pad = 0.0f) {
+DEDF_DEV void ln_silu(f32x16 (&x)[NT], const Wave& wv, const float* r_gamma, const float* r_beta, float inv_n = 0.0f, float n_pad = 0.0f) {
     float s = 0.0f;
     static_for<NT>([&]<int T>() { static_for<16>([&]<int R>() { s += x[T][R]; }); });
     s += xor32(s);
@@ -122,7 +132,7 @@ DEDF_DEV void ln_silu(f32x16 (&x)[NT], const Wave& wv, const float* rows, int o_
     if constexpr (MASKED) v = fmaxf(v - n_pad * (mean * mean), 0.0f);
     const float rstd = 1.0f / sqrtf(v * (MASKED ? inv_n : 1.0f / (NT * 32)) + 1e-5f);
     static_for<NT>([&]<int T>() {
-        const f32x16 g = ldrows_lds(rows, wv.hi, o_gamma, T), b = ldrows_lds(rows, wv.hi, o_beta, T);
+        const f32x16 g = ldrows_lds(r_gamma, wv.hi, 0, T), b = ldrows_lds(r_beta, wv.hi, 0, T);
         float y[16];
         static_for<16>([&]<int R>() { y[R] = (x[T][R] - mean) * rstd * g[R] + b[R]; });
         silu_stage<16>(y);
@@ -227,13 +237,15 @@ DEDF_DEV void split_chunk(const float (&v)[2 * l3 + 1][8], BOpsH<L>& o) {
 }
 
 // once per wave, before its first tile: copy the row vectors into LDS
-template <int L, int H1 = 128, int H2 = 64>
+template <int L, int H1 = 128, int H2 = 64, bool FRONT = true>
 DEDF_DEV void edge_rows_to_lds(const EdgeParams& P, const Wave& wv) {
-    using RL = RowsLds<L>;
-    float* rows = rows_lds<L>();
+    using RL = RowsLds<L, FRONT>;
+    float* rows = rows_lds<L, FRONT>();
     auto cp = [&](int dst, int src, int n) { for (int i = wv.lane; i < n; i += 64) rows[dst + i] = P.W[src + i]; };
-    cp(RL::b1, P.o_b_r1, H1); cp(RL::g1, P.o_g_r1, H1); cp(RL::be1, P.o_be_r1, H1);
-    cp(RL::b2, P.o_b_r2, H2); cp(RL::g2, P.o_g_r2, H2); cp(RL::be2, P.o_be_r2, H2);
+    if constexpr (FRONT) {
+        cp(RL::b1, P.o_b_r1, H1); cp(RL::g1, P.o_g_r1, H1); cp(RL::be1, P.o_be_r1, H1);
+        cp(RL::b2, P.o_b_r2, H2); cp(RL::g2, P.o_g_r2, H2); cp(RL::be2, P.o_be_r2, H2);
+    }
     cp(RL::off3, P.o_off_r3, rup(dtp_wn<L>(), 32)); cp(RL::b0, P.o_b_r0, r0_tiles<L>() * 32);
     cp(RL::val0, P.o_b_val0, 64); cp(RL::adot, P.o_alpha_dot, 64);
     __builtin_amdgcn_s_waitcnt(0);
@@ -241,12 +253,14 @@ DEDF_DEV void edge_rows_to_lds(const EdgeParams& P, const Wave& wv) {
 }
 
 // whenever a wave moves on to tiles of another scale: that scale's length-encoder constants (192 floats)
-template <int L>
+template <int L, bool FRONT = true>
 DEDF_DEV void edge_enc_to_lds(const EdgeParams& P, const Wave& wv, int scale) {
-    float* rows = rows_lds<L>();
-    for (int i = wv.lane; i < 192; i += 64) rows[RowsLds<L>::enc + i] = P.W[P.o_enc + scale * 192 + i];
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if constexpr (FRONT) {
+        float* rows = rows_lds<L, FRONT>();
+        for (int i = wv.lane; i < 192; i += 64) rows[RowsLds<L, FRONT>::enc + i] = P.W[P.o_enc + scale * 192 + i];
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
 }
 
 // H1, H2: hidden widths of the radial MLP (fc_neurons[1:]): 128, 64 in the panda_* and sapien pick configs, 32, 32 in sapien place_*
@@ -262,7 +276,8 @@ DEDF_DEV void edge_enc_to_lds(const EdgeParams& P, const Wave& wv, int scale) {
 struct GeoPre { int ok, src, dst; float vx, vy, vz; };
 
 // MODE 0: everything per edge.  MODE 1: the radial network's front comes from the radial table (EdgeParams::rtab) for every tile whose
-// lengths lie inside the table, per edge otherwise (the all-pairs scale has no a-priori bound).  MODE 2: table generator -- "edge" e of
+// lengths lie inside the table, per edge otherwise (the all-pairs scale has no a-priori bound).  MODE 3: accuracy check of the table --
+// "edge" e of the tile is the MIDPOINT of grid interval e of `scale`: exact front there against the interpolated table.  MODE 2: table generator -- "edge" e of
 // the tile is table row e of `scale`; the tile ends after layer 2's activation.
 template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false, int MODE = 0>
 DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, int n_valid, GeoPre& geo, int e_next DEDF_PROF_ARG) {
@@ -278,8 +293,12 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     constexpr int NWT = cdiv(WN, 32);      // (lmax 3: 880 rows = 27.5 tiles, the last half tile is zero rows)
     constexpr int NR0 = r0_tiles<L>();
     const int hi = wv.hi;
-    using RL = RowsLds<L>;
-    const float* const rows = rows_lds<L>();
+    constexpr bool FRONT = front_rows_in_lds<L, MODE>();
+    using RL = RowsLds<L, FRONT>;
+    const float* const rows = rows_lds<L, FRONT>();
+    // the front's row vectors: this wave's LDS copy, or global memory (see RowsLds)
+    const float* const r_b1 = FRONT ? rows + RL::b1 : P.W + P.o_b_r1, * const r_g1 = FRONT ? rows + RL::g1 : P.W + P.o_g_r1, * const r_be1 = FRONT ? rows + RL::be1 : P.W + P.o_be_r1;
+    const float* const r_b2 = FRONT ? rows + RL::b2 : P.W + P.o_b_r2, * const r_g2 = FRONT ? rows + RL::g2 : P.W + P.o_g_r2, * const r_be2 = FRONT ? rows + RL::be2 : P.W + P.o_be_r2;
     // weight-image offsets, re-materialised per tile (see opaque_s)
     const int o_A_r1 = opaque_s(P.o_A_r1), o_A_r2 = opaque_s(P.o_A_r2), o_A_r3 = opaque_s(P.o_A_r3);
     const int o_A_r1_l = opaque_s(P.o_A_r1_l), o_A_r2_l = opaque_s(P.o_A_r2_l), o_A_r3_l = opaque_s(P.o_A_r3_l);
@@ -289,7 +308,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     if constexpr (MODE == 1) {
         if (geo.ok) { src = geo.src; dst = geo.dst; } else { src = P.edge_src[e]; dst = P.edge_dst[e]; }
         pose = dst / P.nQ;
-    } else if constexpr (MODE != 2) { src = P.edge_src[e]; dst = P.edge_dst[e]; pose = dst / P.nQ; }
+    } else if constexpr (MODE < 2) { src = P.edge_src[e]; dst = P.edge_dst[e]; pose = dst / P.nQ; }
     int nsrc = 0, ndst = 0;            // MODE 1: the next tile's indices, requested now
     if constexpr (MODE == 1) { if (e_next >= 0) { nsrc = P.edge_src[e_next]; ndst = P.edge_dst[e_next]; } }
 
@@ -314,6 +333,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // ---- geometry (graph_parser.py:159-215) ---------------------------------------------------------------------
     float vx = 0.0f, vy = 0.0f, vz = 1.0f, len;
     if constexpr (MODE == 2) len = (float)(e - 1) * P.rtab_step[scale];
+    else if constexpr (MODE == 3) len = ((float)e + 0.5f) * P.rtab_step[scale];
     else if (MODE == 1 && geo.ok) { vx = geo.vx; vy = geo.vy; vz = geo.vz; len = sqrtf(vx * vx + vy * vy + vz * vz); }
     else {
         vx = P.key_x[3 * src + 0] - P.qpos[3 * dst + 0];
@@ -368,7 +388,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     if constexpr (MODE == 1) {
         DEDF_STAMP(0);
         const float pos = len * P.rtab_inv_step[scale];
-        tab = __all(!valid || pos < (float)P.rtab_n[scale]) != 0;
+        const bool accurate = __builtin_bit_cast(float, P.rtab_err[scale]) <= P.rtab_err_bound[scale];      // (wave-uniform; NaN compares false)
+        tab = accurate && __all(!valid || pos < (float)P.rtab_n[scale]) != 0;
         if (tab) {
             const float ps = valid ? pos : 0.0f;
             const int i0 = (int)ps;
@@ -413,7 +434,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         // ---- length embedding: this lane's 32 of the 64 channels (k = s + 32*hi) ------------------------------------------
         float eb[32];
         {
-            const f32x4* const enc = reinterpret_cast<const f32x4*>(rows + RL::enc);       // this scale's constants (edge_enc_to_lds)
+            const f32x4* const enc = reinterpret_cast<const f32x4*>(FRONT ? rows + RL::enc : P.W + P.o_enc + scale * 192);       // this scale's constants (edge_enc_to_lds)
             if (radius > 0.0f) {           // GaussianRadialBasis, radial_func.py:208-227
                 // UNet layer (GaussianRadialBasisLayerFiniteCutoff, radial_func.py:262-278): t = (len - offset) / (cutoff - offset); the host
                 // passes cutoff - offset as `radius` and the offset as `cut_begin`
@@ -466,7 +487,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         DEDF_STAMP(1);
         // ---- RadialProfile layers 1, 2 (equiformer/radial_func.py:11-60) ---------------------------------------------------
         f32x16 r1[NT1];
-        static_for<NT1>([&]<int To>() { r1[To] = ldrows_lds(rows, hi, RL::b1, To); });
+        static_for<NT1>([&]<int To>() { r1[To] = ldrows_lds(r_b1, hi, 0, To); });
         if constexpr (UN)        // no pre-linear: layer 1 reads the radial basis (K = 64 = four chunks of this lane's embedding values)
             dense_rot_h<NT1, 4, 2, HP>(wv, o_A_r1, o_A_r1_l, r1, [&]<int c, int j>() { return eb[8 * c + j]; }, ring_r1);
         else
@@ -475,15 +496,36 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         auto ring_r2 = dense_prefetch<NT2, H1 / 16, 2, HP>(wv, o_A_r2, o_A_r2_l);      // layer 2's first operands: under the LayerNorm below
         sched_fence();
         static_for<NT1>([&]<int To>() { to_vgpr(r1[To]); });
-        ln_silu<NT1, UN>(r1, wv, rows, RL::g1, RL::be1, P.ln_inv_n[0], P.ln_pad[0]);
+        ln_silu<NT1, UN>(r1, wv, r_g1, r_be1, P.ln_inv_n[0], P.ln_pad[0]);
         DEDF_STAMP(3);
-        static_for<NT2>([&]<int To>() { r2[To] = ldrows_lds(rows, hi, RL::b2, To); });
+        static_for<NT2>([&]<int To>() { r2[To] = ldrows_lds(r_b2, hi, 0, To); });
         dense_rot_h<NT2, H1 / 16, 2, HP>(wv, o_A_r2, o_A_r2_l, r2, [&]<int c, int j>() { return r1[c / 2][8 * (c % 2) + j]; }, ring_r2);
         DEDF_STAMP(4);
     }
+    if constexpr (MODE == 3) {      // accuracy check: exact activations at the interval midpoint against the interpolation of table rows e .. e + 3
+        static_for<NT2>([&]<int To>() { to_vgpr(r2[To]); });
+        ln_silu<NT2, false>(r2, wv, r_g2, r_be2);
+        const Buf rtb = make_buf(P.rtab, P.rtab_bytes);
+        const int rv = ((P.rtab_row0[scale] + e) * 2 + hi) * 128;
+        // 4-point Lagrange weights at u = 1/2 for the nodes at -1, 0, 1, 2
+        const float w4[4] = {-0.0625f, 0.5625f, 0.5625f, -0.0625f};
+        float err = 0.0f;
+        static_for<4 * NT2>([&]<int Q>() {
+            f32x4 t = bld4(rtb, rv, Q * 16) * w4[0];
+            static_for<3>([&]<int K>() { t = t + bld4(rtb, rv, (K + 1) * 256 + Q * 16) * w4[K + 1]; });
+            static_for<4>([&]<int J>() { err = fmaxf(err, fabsf(t[J] - r2[Q / 4][4 * (Q % 4) + J])); });
+        });
+        if (!valid) err = 0.0f;
+        if (!(err == err)) err = __builtin_inff();         // a NaN anywhere must read as "inaccurate"
+#if defined(__HIP_DEVICE_COMPILE__)
+        for (int o = 32; o >= 1; o >>= 1) err = fmaxf(err, __shfl_xor(err, o, 64));
+        if (wv.lane == 0) atomicMax(P.rtab_err + scale, __builtin_bit_cast(unsigned, err));      // err >= 0: the bit patterns order like the values
+#endif
+        return;
+    }
     if constexpr (MODE == 2) {      // generator: layer 2's activation, one table row per grid node, done
         static_for<NT2>([&]<int To>() { to_vgpr(r2[To]); });
-        ln_silu<NT2, false>(r2, wv, rows, RL::g2, RL::be2);
+        ln_silu<NT2, false>(r2, wv, r_g2, r_be2);
         if (valid) {
             float* const o = P.rtab_out + ((size_t)(P.rtab_row0[scale] + e) * 2 + hi) * 32;
             static_for<4 * NT2>([&]<int Q>() { st4(o + 4 * Q, f32x4{r2[Q / 4][4 * (Q % 4)], r2[Q / 4][4 * (Q % 4) + 1], r2[Q / 4][4 * (Q % 4) + 2], r2[Q / 4][4 * (Q % 4) + 3]}); });
@@ -747,7 +789,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         // layer 2's LayerNorm + SiLU and the split of its output (B operands of layer 3), under the requests above
         if (!tab) {
             static_for<NT2>([&]<int To>() { to_vgpr(r2[To]); });
-            ln_silu<NT2, UN>(r2, wv, rows, RL::g2, RL::be2, P.ln_inv_n[1], P.ln_pad[1]);
+            ln_silu<NT2, UN>(r2, wv, r_g2, r_be2, P.ln_inv_n[1], P.ln_pad[1]);
         } else if constexpr (MODE == 1 && !DEDF_RTAB_COALESCED) {
             static_for<4 * NT2>([&]<int Q>() { static_for<4>([&]<int J>() {
                 r2[Q / 4][4 * (Q % 4) + J] = (tw[0] * trow[0][Q][J] + tw[1] * trow[1][Q][J]) + (tw[2] * trow[2][Q][J] + tw[3] * trow[3][Q][J]);

@@ -15,13 +15,14 @@ template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = f
 #if defined(DEDF_PHASE_PROF)
     unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    edge_rows_to_lds<L, H1, H2>(P, wv);
+    constexpr bool FRONT = front_rows_in_lds<L, MODE>();
+    edge_rows_to_lds<L, H1, H2, FRONT>(P, wv);
     int enc_scale = -1;
     GeoPre geo{};
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         int scale = 0;
         while (t >= ti[scale + 1]) ++scale;
-        if (scale != enc_scale) { edge_enc_to_lds<L>(P, wv, scale); enc_scale = scale; }
+        if (scale != enc_scale) { edge_enc_to_lds<L, FRONT>(P, wv, scale); enc_scale = scale; }
         const int k = t - ti[scale];
         const int ebase = ti[16 + scale], En = ti[16 + scale + 1] - ebase;
         int e_next = -1;               // MODE 1: this lane's edge of the wave's next tile (padding lanes read the tile's first edge)
@@ -70,6 +71,30 @@ template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64> __global__ 
 #endif
     }
 }
+// Accuracy check of the radial table (edge_tile MODE 3): 32 interval midpoints per tile, every interval of every scale.
+template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64> __global__ __launch_bounds__(64, 1) void k_radial_check(EdgeParams P) {
+    const Wave wv = make_wave(P.W, P.W_bytes);
+    edge_rows_to_lds<L, H1, H2>(P, wv);
+    int enc_scale = -1;
+    for (int t = blockIdx.x;; t += gridDim.x) {
+        int scale = 0, base = 0;
+        for (; scale < P.n_scales; ++scale) {
+            const int nt = (P.rtab_n[scale] + 31) / 32;
+            if (t - base < nt) break;
+            base += nt;
+        }
+        if (scale >= P.n_scales) break;
+        if (scale != enc_scale) { edge_enc_to_lds<L>(P, wv, scale); enc_scale = scale; }
+        const int k = t - base;
+        GeoPre geo{};
+#if defined(DEDF_PHASE_PROF)
+        unsigned long long pacc[16];
+        edge_tile<L, F0, HP, H1, H2, false, 3>(P, wv, scale, 32 * k, min(32, P.rtab_n[scale] - 32 * k), geo, -1, pacc);
+#else
+        edge_tile<L, F0, HP, H1, H2, false, 3>(P, wv, scale, 32 * k, min(32, P.rtab_n[scale] - 32 * k), geo, -1);
+#endif
+    }
+}
 template <int L, bool EBM, bool HP = false, bool UN = false> __global__ __launch_bounds__(64, 1) void k_node(NodeParams P) {
     const Wave wv = make_wave(P.W, P.W_bytes);
     const int ntiles = (P.n_nodes + 31) / 32;
@@ -106,10 +131,13 @@ template <int L, bool EBM, bool HP = false, bool UN = false> __global__ __launch
     X(11, void k_edge<2, 64, false, 32, 32>(EdgeParams))              \
     X(12, void k_edge<2, 128, false, 128, 64, false, 1>(EdgeParams))  \
     X(11, void k_radial_table<2, 128>(EdgeParams))                    \
+    X(11, void k_radial_check<2, 128>(EdgeParams))                    \
     X(13, void k_edge<2, 192, false, 128, 64, false, 1>(EdgeParams))  \
     X(10, void k_radial_table<2, 192>(EdgeParams))                    \
+    X(10, void k_radial_check<2, 192>(EdgeParams))                    \
     X(14, void k_edge<2, 128, false, 32, 32, false, 1>(EdgeParams))   \
     X(10, void k_radial_table<2, 128, false, 32, 32>(EdgeParams))     \
+    X(10, void k_radial_check<2, 128, false, 32, 32>(EdgeParams))     \
     X(15, void k_edge<2, 64, true, 32, 32, true>(EdgeParams))         \
     X(15, void k_node<2, false, true, true>(NodeParams))               \
     X(16, void k_edge<3, 128, false>(EdgeParams))                     \
@@ -122,5 +150,6 @@ template <int L, bool EBM, bool HP = false, bool UN = false> __global__ __launch
     X(20, void k_node<3, false, true, true>(NodeParams))              \
     X(22, void k_edge<3, 128, false, 128, 64, false, 1>(EdgeParams))  \
     X(23, void k_radial_table<3, 128>(EdgeParams))                    \
+    X(23, void k_radial_check<3, 128>(EdgeParams))                    \
     X(23, void k_edge<3, 64, false, 32, 32>(EdgeParams))
 constexpr int kKernelUnits = 24;

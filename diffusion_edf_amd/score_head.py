@@ -262,7 +262,10 @@ class ScoreModelHead(torch.nn.Module):
         rc = lib.dedf_get_stats(self._handle, C.byref(st))
         _lib.raise_for(lib, self._handle, rc, "dedf_get_stats")
         return dict(n_dst=st.n_dst, n_edges=[st.n_edges[i] for i in range(self.n_scales)], n_edges_total=st.n_edges_total,
-                    overflow=bool(st.overflow), nonfinite=bool(st.nonfinite))
+                    overflow=bool(st.overflow), nonfinite=bool(st.nonfinite),
+                    # accuracy guard of the sampler's radial table: largest interpolation error per scale, scales that fell back to per-edge
+                    rtab_err=[float(st.rtab_err[i]) for i in range(self.n_scales)],
+                    rtab_fallback=[bool(st.rtab_fallback >> i & 1) for i in range(self.n_scales)])
 
     def profile_enable(self, on: bool = True):
         lib = _lib.load()

@@ -108,6 +108,11 @@ typedef struct dedf_stats {
                                             dedf_sample call (its outputs are NaN from that evaluation on; dedf_sample returns DEDF_ERR_RUNTIME) */
     int nonfinite;                       /* 1 if a score / energy of the last call was not finite: an activation left the fp16 operand range
                                             of the split-fp16 GEMMs, or inputs were not finite (dedf_sample returns DEDF_ERR_RUNTIME) */
+    float rtab_err[DEDF_MAX_SCALES];     /* accuracy guard of the sampler's radial table (dedf_set_radial_table), last dedf_sample call that used it: per
+                                            scale the largest |interpolated - exact| activation over ALL interval midpoints of the grid, checked at the
+                                            call's first, middle and last diffusion time */
+    int rtab_fallback;                   /* bit n set: scale n exceeded its bound (finite scales 1e-5, DEDF_RADIAL_TABLE_BOUND; all-pairs scale 2.4e-4, see
+                                            dedf_set_radial_table) and evaluated its front per edge */
 } dedf_stats;
 
 const char* dedf_version(void);
@@ -163,8 +168,14 @@ int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const floa
  * Batches below 8 192 pose x query nodes evaluate per edge as well (the generator launch would cost more than it saves).
  * on = 1 is this default; on = 0 restores the per-edge evaluation everywhere, on = 2 uses the table at every batch size (tests) -- also through the
  * environment: DEDF_RADIAL_TABLE=0|1|2.  Instantiated for the lmax-2 score heads of the shipped
- * configs in full precision -- fc_neurons {128,128,64}, {192,128,64} (time_emb_mlp {512,256,128}) and {128,32,32}; lmax 1, the half-precision mode,
- * the EBM critic and the UNet layers evaluate per edge. */
+ * configs in full precision -- fc_neurons {128,128,64}, {192,128,64} (time_emb_mlp {512,256,128}) and {128,32,32} -- and for lmax 3 {128,128,64};
+ * lmax 1, the half-precision mode, the EBM critic and the UNet layers evaluate per edge.
+ * Accuracy guard: the length encoder's widths are TRAINABLE (radial_func.py:208-227: std = softplus(std_logit) + 1e-5), so a fixed grid is not
+ * accurate for every checkpoint.  Every dedf_sample call that uses the table first evaluates the front exactly at the midpoint of EVERY grid
+ * interval of every scale (at the call's first, middle and last diffusion time) and compares it with the interpolated table; a scale whose largest
+ * deviation exceeds 1e-5 (absolute, on the O(1) activations; measured at the init widths: 2e-6, at sigma = 3e-3 r: 3e-3, i.e. 1e-4 of the score)
+ * evaluates its front per edge for that call: dedf_stats.rtab_err / rtab_fallback.  The all-pairs scale (parameter-free sinusoidal encoder) is
+ * held to two fp32 ulps of its largest sin / cos argument instead (2.4e-4): that rounding is in the per-edge evaluation just the same. */
 int dedf_set_radial_table(dedf_handle* h, int on);
 
 /* Chains of layers (a whole UNet is 17 of them): with on = 1, dedf_layer_forward returns WITHOUT synchronising; the verdict of its edge-list
@@ -232,8 +243,11 @@ int dedf_linear_rs(const float* f, int n, const float* ln_w, const float* ln_b, 
 int dedf_linear_rs_lmax(int lmax, const float* f, int n, const float* ln_w, const float* ln_b, const float* W, const float* bias, const int* valid,
                         float* out, void* stream);
 int dedf_fps(const float* x, int n, int n_samples, int start, int* idx_out, void* stream);
+/* scratch: caller-owned DEVICE memory of at least dedf_radius_scratch_bytes(n_dst) bytes, 8-byte aligned (counts and offsets of the two
+ * passes): the library keeps no state between calls */
+size_t dedf_radius_scratch_bytes(int n_dst);
 int dedf_radius(const float* x_src, int n_src, const float* x_dst, int n_dst, float r, int max_num_neighbors, int exclude_self,
-                int64_t edge_cap, int64_t* edge_dst, int64_t* edge_src, int64_t* n_edges, void* stream);
+                int64_t edge_cap, int64_t* edge_dst, int64_t* edge_src, int64_t* n_edges, void* scratch, size_t scratch_bytes, void* stream);
 
 #ifdef __cplusplus
 }

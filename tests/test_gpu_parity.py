@@ -770,6 +770,94 @@ def test_full_size_c2_sharded_sampling_equals_single_batch():
     assert moved > 1.0 and float((sharded - full).abs().max()) < 1e-5 * moved, (moved, float((sharded - full).abs().max()))
 
 
+def test_c2_timed_path_with_the_automatic_radial_table_against_the_oracle():
+    """the path bench.py TIMES, anchored on the oracle at its own size: C2 inputs (1000 poses, 820/164/33/7 keys, 103 queries), ONE noise-free
+    sampler step with the radial table in its default (automatic) mode -- 103 000 pose x query nodes, so the table is on.  The displacement of a
+    10-pose subset is compared with `langevin_step` of the fp64 oracle's score for those poses: < 1e-4 of the displacement scale.  The accuracy
+    guard ran (all interval midpoints of every scale) and no scale fell back."""
+    import bench
+    dev = torch.device('cuda:0')
+    kw, cfg, P, keys, query, Ts = bench.build_inputs(2, 4096, 1024, 1000, 0, dev)
+    head = _gpu_head(kw, P, dev)
+    t = 0.5
+    out = ScoreModelBase(head).sample(Ts, keys, query, [[t, t]], [1], [0.04], temperatures=0.0)
+    st = head.stats()
+    assert st['n_dst'] == 103_000 and not any(st['rtab_fallback']) and 0.0 < max(st['rtab_err'][:3]) < 1e-5 and 0.0 < st['rtab_err'][3] < 2.5e-4, st
+    sel = torch.tensor([0, 1, 7, 99, 250, 333, 512, 777, 998, 999])
+    d_gpu = (out[1] - out[0])[sel.to(dev)].cpu()
+    ocfg = R.config_from_kwargs(kw)
+    ok = [R.FeaturedPoints(k.x.cpu().double(), k.f.cpu().double(), k.b.cpu()) for k in keys]
+    oq = R.FeaturedPoints(query.x.cpu().double(), query.f.cpu().double(), query.b.cpu(), query.w.cpu().double())
+    Tsel = Ts[sel.to(dev)].cpu()
+    ang, lin = R.score_head_forward(ocfg, R.cast_params(P, torch.float64), Tsel, ok, oq, torch.full((len(sel),), t, dtype=torch.float64))
+    z = torch.zeros(len(sel), 3, dtype=torch.float64)
+    d_ref = R.langevin_step(ocfg, Tsel, ang, lin, t, 0.04, 0.0, 0.5, 0.5, z, z) - Tsel
+    for sl in (slice(0, 4), slice(4, 7)):          # rotation (quaternion) and translation parts, each against its own scale
+        scale = float(d_ref[:, sl].abs().max())
+        assert scale > 1e-3 and float((d_gpu[:, sl] - d_ref[:, sl]).abs().max()) / scale < 1e-4, (sl, scale, float((d_gpu[:, sl] - d_ref[:, sl]).abs().max()))
+    # and the same step with the table off moves the poses the same way (the per-edge reading of the same workload)
+    head.set_radial_table(False)
+    out_pe = ScoreModelBase(head).sample(Ts, keys, query, [[t, t]], [1], [0.04], temperatures=0.0)
+    moved = float((out[1] - out[0]).abs().max())
+    assert float((out_pe[1] - out[1]).abs().max()) < 1e-5 * moved
+
+
+def test_radial_table_guard_falls_back_for_sharp_length_encoders():
+    """`std = softplus(std_logit) + 1e-5` of the Gaussian length encoder is trainable (radial_func.py:208-227).  With sigma ~ 1e-3 of the radius
+    the 2 048-interval grid no longer resolves the bumps: the accuracy guard (exact front at every interval midpoint against the interpolated
+    table) must catch it and the affected scales must evaluate per edge -- the sampler then agrees with the per-edge path to 1e-5 again, and
+    `stats()` shows which scales fell back.  A control with the init widths keeps the table on every scale."""
+    dev = torch.device('cuda:0')
+    kw, cfg, P, keys, query, Ts, _ = SC.build_case(2, 48, 2048, 256)
+    softplus_inv = lambda y: float(np.log(np.expm1(y)))
+    for sharp in (False, True):
+        Q = {k: v.clone() for k, v in P.items()}
+        if sharp:
+            for n in (0, 2):                      # scales 0 and 2 get sharp bumps, scale 1 keeps its init widths
+                Q[f"key_tensor_field.graph_parsers.{n}.length_enc.param_module.std_logit"][:] = softplus_inv(1e-3)
+        head = _gpu_head(kw, Q, dev)
+        gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
+        gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
+        outs = {}
+        for on in ("always", False):
+            head.set_radial_table(on)
+            outs[on] = ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[0.6, 0.6]], [1], [0.04], temperatures=0.0).cpu()
+            if on == "always":
+                st = head.stats()
+        d_on, d_off = (outs["always"][1] - outs["always"][0])[:, 4:], (outs[False][1] - outs[False][0])[:, 4:]
+        scale = float(d_off.abs().max())
+        assert scale > 1e-3 and float((d_on - d_off).abs().max()) / scale < 1e-5, (sharp, float((d_on - d_off).abs().max()) / scale, st)
+        if sharp:
+            assert st['rtab_fallback'] == [True, False, True, False] and min(st['rtab_err'][0], st['rtab_err'][2]) > 1e-5, st
+        else:
+            assert not any(st['rtab_fallback']) and max(st['rtab_err'][:3]) < 1e-5 and st['rtab_err'][3] < 2.5e-4, st
+
+
+def test_c3_total_batch_on_one_gpu():
+    """config C3's TOTAL batch (8 x 1000 = 8 000 poses of C2's clouds) on one GPU: 3 sampler steps at temperature 1 stay finite and normalised,
+    and the eight 1000-pose shards with their global pose indices (what the 8-GPU run computes, Philox noise keyed by the global index) equal
+    the unsharded run up to the fp32 summation order inside the tiles"""
+    import bench
+    from diffusion_edf_amd import dist as ddist
+    dev = torch.device('cuda:0')
+    kw, cfg, P, keys, query, Ts = bench.build_inputs(2, 4096, 1024, 8000, 0, dev)
+    head = _gpu_head(kw, P, dev)
+    m = ScoreModelBase(head)
+    args = dict(diffusion_schedules=[[1.0, 0.5]], N_steps=[3], timesteps=[0.04], temperatures=1.0, seed=3)
+    full = m.sample(Ts, keys, query, **args)
+    st = head.stats()
+    assert full.shape == (5, 8000, 7) and bool(torch.isfinite(full).all()) and st['n_dst'] == 824_000 and not st['overflow'] and not st['nonfinite']
+    assert st['n_edges_total'] > 10_000_000
+    assert torch.allclose(full[..., :4].norm(dim=-1), torch.ones(5, 8000, dtype=torch.float64, device=dev), atol=1e-12)
+    parts = []
+    for r in range(8):
+        s0, s1 = ddist.shard_range(8000, 8, r)
+        parts.append(m.sample(Ts[s0:s1], keys, query, first_pose_index=s0, **args))
+    sharded = torch.cat(parts, dim=1)
+    moved = float((full[-1] - full[0]).abs().max())
+    assert moved > 1.0 and float((sharded - full).abs().max()) < 1e-5 * moved, (moved, float((sharded - full).abs().max()))
+
+
 # ---- BASELINE config C1 at its real workload ---------------------------------------------------------------------------------
 
 def test_full_size_c1_anchored_on_the_oracle_and_sharded_sampling():
