@@ -16,11 +16,13 @@
 using namespace dedf;
 
 #include "dedf_kernels.h"
+#include "dedf_kernels_occ.h"
 #include "dedf_graph.h"
 #if !defined(DEDF_SINGLE_TU)
 #define DEDF_DECL(unit, ...) extern template __global__ __VA_ARGS__;
 DEDF_KERNEL_LIST(DEDF_DECL)
 #undef DEDF_DECL
+extern template __global__ void k_edge_occ<1, 128, false>(EdgeParams);
 #endif
 __global__ void k_energy_reduce(const float* __restrict__ node_out, int nT, int nQ, float* __restrict__ energy, int* __restrict__ flags) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -81,6 +83,9 @@ struct dedf_handle {
     int radial_table = 1;         // sampler: tabulate the radial network's front per launch (DEDF_RADIAL_TABLE=0 / dedf_set_radial_table turn it off)
     DevBuf d_rtab, d_rtab_err;    // table rows; per-scale accuracy words (largest |interpolated - exact| activation at the interval midpoints)
     float rtab_err_bound = 1e-5f; // a scale whose word exceeds it evaluates its front per edge (DEDF_RADIAL_TABLE_BOUND)
+    DevBuf d_cnt2, d_blk2; int small_parity = 0; int64_t small_layout = -1;      // the two alternating count sets of the small-batch neighbour path
+    bool edge_occ = false;            // DEDF_EDGE_OCC=1: lmax-1 score head on the two-waves-per-SIMD build of the edge kernel (A/B)
+    bool small_batch_path = true;     // N_d <= 8 192: word-parallel neighbour masks + fused pose preparation (DEDF_SMALL_BATCH=0 turns it off: A/B, tests)
     bool defer_check = false;         // dedf_layer_defer_check
     DevBuf d_sticky;
     bool want_field = false;          // dedf_field: the node kernel also writes the field / emb of every node
@@ -311,6 +316,23 @@ void launch_time_bias(dedf_handle* h, hipStream_t st, const float* time, int tim
     hipLaunchKernelGGL(k_time_bias, dim3(rows, c.n_scales), dim3(256), 0, st, tp);
 }
 
+// Persistent grids: as many waves per CU as are RESIDENT at once (4 for the 512-register kernels with <= 40 KB of LDS; the lmax-3 kernels park
+// 44-46 KB per wave and fit 3 or 2).  A grid larger than that runs in rounds and the last, partly filled round costs a whole one.
+template <auto Kernel, int Cap = 4> int waves_per_cu() {
+    static const int n = [] {
+        int v = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, Kernel, 64, 0) != hipSuccess || v < 1) v = 4;
+        return std::min(v, Cap);
+    }();
+    return n;
+}
+#define DEDF_LAUNCH_PERSISTENT(KERNEL, MAX_BLOCKS, ST, ARG) \
+    hipLaunchKernelGGL((KERNEL), dim3(std::min<int>((MAX_BLOCKS), h->n_cu * std::min(edge_wpc_limit(), waves_per_cu<(KERNEL)>()))), dim3(64), 0, ST, ARG)
+inline int edge_wpc_limit() {      // experiments only: DEDF_EDGE_WAVES_PER_CU=1..4
+    static const int wpc = [] { const char* e = getenv("DEDF_EDGE_WAVES_PER_CU"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 4 ? v : 4; }();
+    return wpc;
+}
+
 // parameters of the fused edge kernel for the current state of the handle
 template <int L, int F0>
 EdgeParams edge_params(dedf_handle* h, int nT, int time_stride) {
@@ -442,14 +464,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     };
     if ((size_t)Nd * D * 4 >= (1ull << 32)) return fail(h, DEDF_ERR_INVALID, "nT*nQ too large for one call (z buffer > 4 GiB); split the pose batch");
     mark();
-    // 1. poses: Wigner-D + transformed query positions
-    hipLaunchKernelGGL(k_pose_prep<L>, dim3(nT), dim3(64), 0, st, h->d_Ts.as<float>(), h->fused_step ? h->fused_step->T : (const double*)nullptr, h->d_qx.as<float>(), nQ, h->d_pose.as<float>(), h->d_qpos.as<float>());
-    // 2. time embedding -> pre-linear bias rows (EBM head: constant bias rows, uploaded once)
-    if constexpr (!EBM) {
-        if (h->tb_step == nullptr) launch_time_bias(h, st, h->d_time.as<float>(), time_stride, time_stride ? nT : 1, h->d_tb.as<float>());
-    }
-    mark();
-    // 3. neighbour search
+    // neighbour-search parameters
     NbrParams np{};
     np.key_x = h->d_key_x.as<float>(); np.n_keys = h->n_keys; np.n_scales = ns; np.max_neighbors = c.max_neighbors;
     for (int n = 0; n <= ns; ++n) np.scale_start[n] = h->scale_start[n];
@@ -459,16 +474,52 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     np.word_start[0] = 0;
     for (int n = 0; n < ns; ++n) np.word_start[n + 1] = np.word_start[n] + (h->scale_start[n + 1] - h->scale_start[n] + 31) / 32;
     np.mask = h->d_mask.as<uint32_t>();
-    const int nblk = (Nd + kNbrBlock - 1) / kNbrBlock;
     np.edge_hist = h->profile ? h->d_hist.as<long long>() : nullptr;
+    // small batches: pose preparation + word-parallel masks in one launch, single-workgroup count / scan / fill (dedf_misc.h)
+    bool small = Nd <= kNbrSmallMax && h->small_batch_path;
+    for (int n = 0; n < ns; ++n) if (c.radii[n] > 0 && h->scale_start[n + 1] - h->scale_start[n] > c.max_neighbors) small = false;      // the cap could bind
+    const double* T64 = h->fused_step ? h->fused_step->T : (const double*)nullptr;
+    const int* cnt_used = h->d_cnt.as<int>();
+    if (small) {
+        const int nblk = (Nd + kNbrBlock - 1) / kNbrBlock;
+        const size_t nc = (size_t)ns * Nd, nb = (size_t)ns * nblk;
+        if (!h->d_cnt2.ensure(2 * nc * 4) || !h->d_blk2.ensure(2 * nb * 4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(workspace) failed");
+        const int64_t layout = ((int64_t)Nd << 8) | ns;
+        if (h->small_layout != layout) {        // first evaluation of this shape: both sets start from zero
+            HIPCK(h, hipMemsetAsync(h->d_cnt2.p, 0, h->d_cnt2.bytes, st));
+            HIPCK(h, hipMemsetAsync(h->d_blk2.p, 0, h->d_blk2.bytes, st));
+            h->small_layout = layout; h->small_parity = 0;
+        }
+        const int par = h->small_parity;
+        np.cnt = h->d_cnt2.as<int>() + par * nc; np.blk = h->d_blk2.as<int>() + par * nb;
+        np.zero_cnt = h->d_cnt2.as<int>() + (1 - par) * nc; np.zero_blk = h->d_blk2.as<int>() + (1 - par) * nb;
+        h->small_parity = 1 - par;
+        cnt_used = np.cnt;
+        if constexpr (!EBM) {
+            if (h->tb_step == nullptr) launch_time_bias(h, st, h->d_time.as<float>(), time_stride, time_stride ? nT : 1, h->d_tb.as<float>());
+        }
+        mark();
+        const dim3 g(nblk, np.word_start[ns] + 1);
+        hipLaunchKernelGGL(k_nbr_masks_small<L>, g, dim3(kNbrBlock), 0, st, np, h->d_Ts.as<float>(), T64, h->d_qx.as<float>(), nQ, nT, h->d_pose.as<float>(), h->d_qpos.as<float>());
+        hipLaunchKernelGGL(k_neighbors<true>, dim3(nblk), dim3(kNbrBlock), 0, st, np);
+    } else {
+    // 1. poses: Wigner-D + transformed query positions
+    hipLaunchKernelGGL(k_pose_prep<L>, dim3(nT), dim3(64), 0, st, h->d_Ts.as<float>(), T64, h->d_qx.as<float>(), nQ, h->d_pose.as<float>(), h->d_qpos.as<float>());
+    // 2. time embedding -> pre-linear bias rows (EBM head: constant bias rows, uploaded once)
+    if constexpr (!EBM) {
+        if (h->tb_step == nullptr) launch_time_bias(h, st, h->d_time.as<float>(), time_stride, time_stride ? nT : 1, h->d_tb.as<float>());
+    }
+    mark();
+    // 3. neighbour search
+    const int nblk = (Nd + kNbrBlock - 1) / kNbrBlock;
     hipLaunchKernelGGL(k_neighbors<false>, dim3(nblk), dim3(kNbrBlock), 0, st, np);
     hipLaunchKernelGGL(k_neighbors<true>, dim3(nblk), dim3(kNbrBlock), 0, st, np);
+    }
     mark();
     // 4. fused edge pipeline
     {
         EdgeParams P = edge_params<L, F0>(h, nT, time_stride);
-        static const int wpc = [] { const char* e = getenv("DEDF_EDGE_WAVES_PER_CU"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 4 ? v : 4; }();   // experiments only
-        const dim3 grid(h->n_cu * wpc), blk(64);
+        constexpr int kAll = 1 << 30;
         const bool hp = h->cfg.half_gemm != 0;             // half_gemm (the reference's half_precision knob): single-term fp16 products
         const bool narrow = h->cfg.fc_neurons[1] == 32;    // radial MLP [., 32, 32] (sapien place_*, KeypointExtractor fields) instead of [., 128, 64]
         // Sampler (every pose shares the step's time): the front of the radial network is a function of (scale, length) only -- tabulate
@@ -483,11 +534,11 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
                 if (narrow) {
                     if constexpr (L == 2 && F0 == 128) {
                         launch_radial_table<L, F0, 32, 32>(h, P, st, false);
-                        hipLaunchKernelGGL((k_edge<L, F0, false, 32, 32, false, 1>), grid, blk, 0, st, P);
+                        DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 32, 32, false, 1>), kAll, st, P);
                     }
                 } else {
                     launch_radial_table<L, F0, 128, 64>(h, P, st, false);
-                    hipLaunchKernelGGL((k_edge<L, F0, false, 128, 64, false, 1>), grid, blk, 0, st, P);
+                    DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 128, 64, false, 1>), kAll, st, P);
                 }
             }
         }
@@ -495,26 +546,28 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         } else if constexpr (L == 3) {          // lmax 3: full precision, [., 128, 64] (score head, EBM critic) or [64, 32, 32] (context-free fields)
             static_assert(F0 == 128 || F0 == 64, "lmax 3 instantiations");
             if constexpr (F0 == 64) {
-                if (narrow) hipLaunchKernelGGL((k_edge<3, 64, false, 32, 32>), grid, blk, 0, st, P);
-                else hipLaunchKernelGGL((k_edge<3, 64, false>), grid, blk, 0, st, P);
-            } else hipLaunchKernelGGL((k_edge<3, 128, false>), grid, blk, 0, st, P);
+                if (narrow) DEDF_LAUNCH_PERSISTENT((k_edge<3, 64, false, 32, 32>), kAll, st, P);
+                else DEDF_LAUNCH_PERSISTENT((k_edge<3, 64, false>), kAll, st, P);
+            } else DEDF_LAUNCH_PERSISTENT((k_edge<3, 128, false>), kAll, st, P);
             (void)hp;
         } else if constexpr (F0 == 128) {
             if (narrow) {         // narrow radial MLP (sapien place_*)
-                if (hp) hipLaunchKernelGGL((k_edge<L, F0, true, 32, 32>), grid, blk, 0, st, P);
-                else hipLaunchKernelGGL((k_edge<L, F0, false, 32, 32>), grid, blk, 0, st, P);
-            } else if (hp) hipLaunchKernelGGL((k_edge<L, F0, true>), grid, blk, 0, st, P);
-            else hipLaunchKernelGGL((k_edge<L, F0>), grid, blk, 0, st, P);
+                if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true, 32, 32>), kAll, st, P);
+                else DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 32, 32>), kAll, st, P);
+            } else if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true>), kAll, st, P);
+            else if (L == 1 && h->edge_occ) {      // lmax 1: the two-waves-per-SIMD build of the same tile (dedf_kernels_occ.h)
+                if constexpr (L == 1) hipLaunchKernelGGL((k_edge_occ<1, 128, false>), dim3(h->n_cu * waves_per_cu<(k_edge_occ<1, 128, false>), 8>()), dim3(64), 0, st, P);
+            } else DEDF_LAUNCH_PERSISTENT((k_edge<L, F0>), kAll, st, P);
         } else if constexpr (F0 == 64 && L == 2) {
-            if (narrow) hipLaunchKernelGGL((k_edge<L, F0, false, 32, 32>), grid, blk, 0, st, P);      // KeypointExtractor fields
-            else if (hp) hipLaunchKernelGGL((k_edge<L, F0, true>), grid, blk, 0, st, P);
-            else hipLaunchKernelGGL((k_edge<L, F0>), grid, blk, 0, st, P);
-        } else if (hp) hipLaunchKernelGGL((k_edge<L, F0, true>), grid, blk, 0, st, P);
-        else hipLaunchKernelGGL((k_edge<L, F0>), grid, blk, 0, st, P);
+            if (narrow) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 32, 32>), kAll, st, P);      // KeypointExtractor fields
+            else if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true>), kAll, st, P);
+            else DEDF_LAUNCH_PERSISTENT((k_edge<L, F0>), kAll, st, P);
+        } else if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true>), kAll, st, P);
+        else DEDF_LAUNCH_PERSISTENT((k_edge<L, F0>), kAll, st, P);
     }
     mark();
     // 5. joint softmax + aggregation
-    hipLaunchKernelGGL(k_aggregate<L>, dim3((Nd + 3) / 4), dim3(256), 0, st, h->d_eout.as<float>(), h->d_cnt.as<int>(), h->d_off.as<int>(),
+    hipLaunchKernelGGL(k_aggregate<L>, dim3((Nd + 3) / 4), dim3(256), 0, st, h->d_eout.as<float>(), cnt_used, h->d_off.as<int>(),
                        h->d_tile.as<int>(), Nd, ns, h->d_z.as<float>());
     mark();
     // 6. node epilogue + score tensor products
@@ -541,9 +594,9 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         if ((h->debug || h->want_field) && h->d_dbge.ensure((size_t)Nd * D * 4) && h->d_dbgf.ensure((size_t)Nd * D * 4)) { P.dbg_emb = h->d_dbge.as<float>(); P.dbg_field = h->d_dbgf.as<float>(); }
         else if (h->want_field) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(field) failed");
         const int ntiles = (Nd + 31) / 32;
-        if constexpr (L == 3) hipLaunchKernelGGL((k_node<L, EBM>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
-        else if (h->cfg.half_gemm) hipLaunchKernelGGL((k_node<L, EBM, true>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
-        else hipLaunchKernelGGL((k_node<L, EBM>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
+        if constexpr (L == 3) DEDF_LAUNCH_PERSISTENT((k_node<L, EBM>), ntiles, st, P);
+        else if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_node<L, EBM, true>), ntiles, st, P);
+        else DEDF_LAUNCH_PERSISTENT((k_node<L, EBM>), ntiles, st, P);
     }
     mark();
     // 7. per-pose reduction
@@ -616,6 +669,8 @@ int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, de
     h->host_only = cfg->device < 0;
     if (const char* e = getenv("DEDF_RADIAL_TABLE")) h->radial_table = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("DEDF_RADIAL_TABLE_BOUND")) h->rtab_err_bound = (float)atof(e);
+    if (const char* e = getenv("DEDF_SMALL_BATCH")) h->small_batch_path = atoi(e) != 0;
+    if (const char* e = getenv("DEDF_EDGE_OCC")) h->edge_occ = atoi(e) != 0;
     const IrrepsRT T(h->L, cfg->unet_layer != 0), K(h->L, true);
     h->spec = build_spec(T, h->cfg);
     h->kspec = build_spec(K, h->cfg);
@@ -959,8 +1014,8 @@ int layer_forward_impl(dedf_handle* h, int n_src, const float* x_src, const floa
         P.key_w = nullptr;
         P.out = h->d_eout.as<float>();
         P.dbg_w = nullptr; P.dbg_out = nullptr; P.phase_prof = nullptr;
-        if (h->cfg.half_gemm) hipLaunchKernelGGL((k_edge<L, 64, true, 32, 32, true>), dim3(h->n_cu * 4), dim3(64), 0, st, P);
-        else hipLaunchKernelGGL((k_edge<L, 64, false, 32, 32, true>), dim3(h->n_cu * 4), dim3(64), 0, st, P);
+        if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, true, 32, 32, true>), 1 << 30, st, P);
+        else DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, false, 32, 32, true>), 1 << 30, st, P);
     }
     hipLaunchKernelGGL(k_aggregate<L>, dim3((n_dst + 3) / 4), dim3(256), 0, st, h->d_eout.as<float>(), h->d_cnt.as<int>(), h->d_off.as<int>(),
                        h->d_tile.as<int>(), n_dst, 1, h->d_z.as<float>());
@@ -981,8 +1036,8 @@ int layer_forward_impl(dedf_handle* h, int n_src, const float* x_src, const floa
         P.sc = o.sc;
         P.o_b_proj0 = o.o_b_proj0; P.o_ln_b0 = o.o_ln_b0; P.o_b_f1 = o.o_b_f1; P.o_b_f2 = o.o_b_f2;
         const int ntiles = (n_dst + 31) / 32;
-        if (h->cfg.half_gemm) hipLaunchKernelGGL((k_node<L, false, true, true>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
-        else hipLaunchKernelGGL((k_node<L, false, false, true>), dim3(std::min(ntiles, h->n_cu * 4)), dim3(64), 0, st, P);
+        if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_node<L, false, true, true>), ntiles, st, P);
+        else DEDF_LAUNCH_PERSISTENT((k_node<L, false, false, true>), ntiles, st, P);
     }
     if (h->defer_check) {          // chains of layers: the verdict of the edge-list check is kept on the device for dedf_layer_check
         if (!h->d_sticky.p) {

@@ -99,6 +99,10 @@ template <int L, bool EBM, bool HP = false, bool UN = false> __global__ __launch
     const Wave wv = make_wave(P.W, P.W_bytes);
     const int ntiles = (P.n_nodes + 31) / 32;
     node_rows_to_lds<L, EBM || UN>(P, wv);
+    // (Measured and not kept, round 3: the per-pose reduction + Langevin update as a tail of this kernel -- the wave that completes a pose's
+    //  last node reduces it, found with one atomic counter per pose.  The device-scope release / acquire that the hand-over needs is an L2
+    //  write-back on this multi-XCD part: k_node 0.29 -> 0.45 ms on C2, 56 -> 84 us at 16 poses, against one 5 us launch saved;
+    //  profiles/r03g_fused_reduce_and_single_block_fill_small_batch.log.)
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) node_tile<L, EBM, HP, UN>(P, wv, t * 32);
 }
 

@@ -5,6 +5,7 @@
 #include "dedf_dev.h"
 #include "dedf_net.h"
 #include "dedf_node.h"
+#include "dedf_langevin.h"
 
 namespace dedf {
 
@@ -50,49 +51,57 @@ __device__ inline void wigner_from_angles(float a, float b, float c, float* D /*
 #undef DEDF_MM
 }
 
+// pose record of one pose: raw q, D^1(q), D^2(q) (, D^3(q))
+template <int L>
+__device__ inline void pose_record(const float (&T)[7], float* __restrict__ rec) {
+    const float qw = T[0], qi = T[1], qj = T[2], qk = T[3];
+    rec[0] = qw; rec[1] = qi; rec[2] = qj; rec[3] = qk;
+    const float nrm = sqrtf(qw * qw + qi * qi + qj * qj + qk * qk);       // torch.norm
+    float r = qw / nrm, i = qi / nrm, j = qj / nrm, k = qk / nrm;
+    if (r < 0.0f) { r = -r; i = -i; j = -j; k = -k; }                      // standardize_quaternion
+    const float two_s = 2.0f / (r * r + i * i + j * j + k * k);
+    // rows of R (transforms.py:96-108); only row 1 / column 1 are needed for YXY
+    const float R01 = two_s * (i * j - k * r);
+    const float R10 = two_s * (i * j + k * r);
+    const float R11 = 1.0f - two_s * (i * i + k * k);
+    const float R12 = two_s * (j * k - i * r);
+    const float R21 = two_s * (j * k + i * r);
+    const float a = atan2f(R01, R21);              // _angle_from_tan("Y","X", R[:,1], horizontal=False)
+    const float b = acosf(R11);
+    const float c = atan2f(R10, -R12);             // _angle_from_tan("Y","X", R[1,:], horizontal=True)
+    wigner_from_angles<1>(a, b, c, rec + 4);
+    if constexpr (L >= 2) wigner_from_angles<2>(a, b, c, rec + 16);
+    if constexpr (L >= 3) wigner_from_angles<3>(a, b, c, rec + 48);
+}
+// quaternion_apply(q, p) + t = (q * (0,p)) * conj(q) + t   with the reference's raw products (transforms.py:113-165)
+__device__ inline void pose_apply(const float (&T)[7], float px, float py, float pz, float& ox_, float& oy_, float& oz_) {
+    const float qw = T[0], qi = T[1], qj = T[2], qk = T[3];
+    const float aw = qw, ax = qi, ay = qj, az = qk;
+    const float bw = 0.0f, bx = px, by = py, bz = pz;
+    const float ow = aw * bw - ax * bx - ay * by - az * bz;
+    const float ox = aw * bx + ax * bw + ay * bz - az * by;
+    const float oy = aw * by - ax * bz + ay * bw + az * bx;
+    const float oz = aw * bz + ax * by - ay * bx + az * bw;
+    const float cw = qw, cx = -qi, cy = -qj, cz = -qk;
+    const float rx = ow * cx + ox * cw + oy * cz - oz * cy;
+    const float ry = ow * cy - ox * cz + oy * cw + oz * cx;
+    const float rz = ow * cz + ox * cy - oy * cx + oz * cw;
+    ox_ = rx + T[4]; oy_ = ry + T[5]; oz_ = rz + T[6];
+}
 // Ts64 != nullptr (sampler): the float64 state is read directly and rounded to fp32 here, exactly what a separate cast would give.
+__device__ inline void load_pose(const float* __restrict__ Ts, const double* __restrict__ Ts64, int t, float (&T)[7]) {
+    for (int k = 0; k < 7; ++k) T[k] = Ts64 != nullptr ? (float)Ts64[7 * (size_t)t + k] : Ts[7 * (size_t)t + k];
+}
 template <int L>
 __global__ void k_pose_prep(const float* __restrict__ Ts, const double* __restrict__ Ts64, const float* __restrict__ qx, int nQ,
                             float* __restrict__ pose, float* __restrict__ qpos) {
     const int t = blockIdx.x;
     float T[7];
-    for (int k = 0; k < 7; ++k) T[k] = Ts64 != nullptr ? (float)Ts64[7 * (size_t)t + k] : Ts[7 * (size_t)t + k];
-    const float qw = T[0], qi = T[1], qj = T[2], qk = T[3];
-    if (threadIdx.x == 0) {
-        float* rec = pose + (size_t)t * pose_rec<L>();
-        rec[0] = qw; rec[1] = qi; rec[2] = qj; rec[3] = qk;
-        const float nrm = sqrtf(qw * qw + qi * qi + qj * qj + qk * qk);       // torch.norm
-        float r = qw / nrm, i = qi / nrm, j = qj / nrm, k = qk / nrm;
-        if (r < 0.0f) { r = -r; i = -i; j = -j; k = -k; }                      // standardize_quaternion
-        const float two_s = 2.0f / (r * r + i * i + j * j + k * k);
-        // rows of R (transforms.py:96-108); only row 1 / column 1 are needed for YXY
-        const float R01 = two_s * (i * j - k * r);
-        const float R10 = two_s * (i * j + k * r);
-        const float R11 = 1.0f - two_s * (i * i + k * k);
-        const float R12 = two_s * (j * k - i * r);
-        const float R21 = two_s * (j * k + i * r);
-        const float a = atan2f(R01, R21);              // _angle_from_tan("Y","X", R[:,1], horizontal=False)
-        const float b = acosf(R11);
-        const float c = atan2f(R10, -R12);             // _angle_from_tan("Y","X", R[1,:], horizontal=True)
-        wigner_from_angles<1>(a, b, c, rec + 4);
-        if constexpr (L >= 2) wigner_from_angles<2>(a, b, c, rec + 16);
-        if constexpr (L >= 3) wigner_from_angles<3>(a, b, c, rec + 48);
-    }
+    load_pose(Ts, Ts64, t, T);
+    if (threadIdx.x == 0) pose_record<L>(T, pose + (size_t)t * pose_rec<L>());
     for (int q = threadIdx.x; q < nQ; q += blockDim.x) {
-        // quaternion_apply(q, p) = (q * (0,p)) * conj(q)   with the reference's raw products (transforms.py:113-165)
-        const float px = qx[3 * q], py = qx[3 * q + 1], pz = qx[3 * q + 2];
-        const float aw = qw, ax = qi, ay = qj, az = qk;
-        const float bw = 0.0f, bx = px, by = py, bz = pz;
-        const float ow = aw * bw - ax * bx - ay * by - az * bz;
-        const float ox = aw * bx + ax * bw + ay * bz - az * by;
-        const float oy = aw * by - ax * bz + ay * bw + az * bx;
-        const float oz = aw * bz + ax * by - ay * bx + az * bw;
-        const float cw = qw, cx = -qi, cy = -qj, cz = -qk;
-        const float rx = ow * cx + ox * cw + oy * cz - oz * cy;
-        const float ry = ow * cy - ox * cz + oy * cw + oz * cx;
-        const float rz = ow * cz + ox * cy - oy * cx + oz * cw;
         float* o = qpos + ((size_t)t * nQ + q) * 3;
-        o[0] = rx + T[4]; o[1] = ry + T[5]; o[2] = rz + T[6];
+        pose_apply(T, qx[3 * q], qx[3 * q + 1], qx[3 * q + 2], o[0], o[1], o[2]);
     }
 }
 
@@ -287,10 +296,10 @@ struct NbrParams {
     long long* edge_hist;                 // optional running edge count (statistics)
     int* edge_src; int* edge_dst;
     int64_t cap;
+    int *zero_cnt, *zero_blk;             // small-batch path only: the OTHER parity's count / block-total arrays, cleared by the fill pass for the next step
     uint32_t* mask;                       // [word][n_dst]: neighbour bit masks written by the count pass, 32 keys per word
     int word_start[kMaxScales + 1];       // first mask word of every scale (scale n has ceil(n_keys_n / 32) words)
 };
-constexpr int kFlagOverflow = 41, kFlagNonFinite = 42;      // words of tile_info
 constexpr int kNbrChunk = 1024;
 constexpr int kNbrBlock = 256;
 
@@ -358,6 +367,10 @@ __global__ __launch_bounds__(kNbrBlock) void k_neighbors(NbrParams P) {
         const int w0 = P.word_start[n], nw = P.word_start[n + 1] - w0;
         if (FILL) {
             const int mine = act ? P.cnt[(size_t)n * P.n_dst + d] : 0;
+            if (P.zero_cnt != nullptr) {
+                if (act) P.zero_cnt[(size_t)n * P.n_dst + d] = 0;
+                if (blockIdx.x == 0) for (int i = threadIdx.x; i < (int)gridDim.x; i += kNbrBlock) P.zero_blk[(size_t)n * gridDim.x + i] = 0;
+            }
             int total;
             const int ex = block_exclusive_scan_256(mine, &total);
             const int o = s_pre[n] + ex;
@@ -419,6 +432,66 @@ __global__ __launch_bounds__(kNbrBlock) void k_neighbors(NbrParams P) {
             (void)block_exclusive_scan_256(act ? c : 0, &total);
             if (threadIdx.x == 0) P.blk[(size_t)n * gridDim.x + blockIdx.x] = total;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Small batches (the deployment regime: 10-20 poses x 650-900 steps, reference evaluate_real_mug.ipynb:188-190, configs/panda_mug/server.yaml:2).
+// With a few thousand destination nodes the thread-per-destination count pass above is a serial walk over all keys on a handful of CUs.  Here
+// the count pass is spread over (32-key word, destination) pairs -- every thread builds ONE mask word, 32 distance tests -- and also carries
+// the pose preparation (each thread transforms its own query point; one more grid row builds the Wigner-D records): one short launch instead
+// of two.  Counts and block totals accumulate with integer atomics (order-independent) into arrays that alternate between two sets from step
+// to step: the fill pass (k_neighbors<true>, unchanged) clears the set the NEXT step will accumulate into.  Same masks, same edge order
+// (scale, dst, src) as the two-pass search; requires that the neighbour cap cannot bind (keys of a finite scale <= max_neighbors: the host
+// checks) and N_d <= kNbrSmallMax.
+constexpr int kNbrSmallMax = 32768;
+template <int L>
+__global__ __launch_bounds__(kNbrBlock) void k_nbr_masks_small(NbrParams P, const float* __restrict__ Ts, const double* __restrict__ Ts64,
+                                                               const float* __restrict__ qx, int nQ, int nT, float* __restrict__ pose, float* __restrict__ qpos) {
+    const int d = blockIdx.x * kNbrBlock + threadIdx.x, w = blockIdx.y;
+    const int n_words = P.word_start[P.n_scales];
+    if (w == n_words) {                 // the extra grid row: one thread per pose builds its record
+        if (d < nT) {
+            float T[7];
+            load_pose(Ts, Ts64, d, T);
+            pose_record<L>(T, pose + (size_t)d * pose_rec<L>());
+        }
+        return;
+    }
+    int n = 0;
+    while (w >= P.word_start[n + 1]) ++n;
+    const int g = w - P.word_start[n], k0 = P.scale_start[n] + 32 * g, ni = min(32, P.scale_start[n + 1] - k0);
+    __shared__ f32x4 kx[32];
+    __shared__ int wtot[kNbrBlock / 64];
+    if (threadIdx.x < ni) { const float* kp = P.key_x + (size_t)(k0 + threadIdx.x) * 3; kx[threadIdx.x] = f32x4{kp[0], kp[1], kp[2], 0.0f}; }
+    __syncthreads();
+    int c = 0;
+    if (d < P.n_dst) {
+        const int t = d / nQ, q = d - t * nQ;
+        float T[7], px, py, pz;
+        load_pose(Ts, Ts64, t, T);
+        pose_apply(T, qx[3 * q], qx[3 * q + 1], qx[3 * q + 2], px, py, pz);
+        if (w == 0) { float* o = qpos + (size_t)d * 3; o[0] = px; o[1] = py; o[2] = pz; }
+        const float r2 = P.r2[n];
+        uint32_t word = 0;
+        for (int i = 0; i < ni; ++i) {
+            const f32x4 k = kx[i];
+            const float dx = k[0] - px, dy = k[1] - py, dz = k[2] - pz;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            if ((r2 <= 0.0f) || (d2 < r2)) word |= 1u << i;
+        }
+        P.mask[(size_t)w * P.n_dst + d] = word;
+        c = __builtin_popcount(word);
+        if (c) atomicAdd(P.cnt + (size_t)n * P.n_dst + d, c);
+    }
+    int tot = c;                        // this block's share of the fill pass's block total (same 256 destinations per block)
+    for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    if ((threadIdx.x & 63) == 0) wtot[threadIdx.x >> 6] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tot = 0;
+        for (int i = 0; i < kNbrBlock / 64; ++i) tot += wtot[i];
+        if (tot) atomicAdd(P.blk + (size_t)n * gridDim.x + blockIdx.x, tot);
     }
 }
 
@@ -558,19 +631,6 @@ __global__ void k_aggregate(const float* __restrict__ edge_out, const int* __res
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// Sum over the query points of one pose (score_head.py:207-209), fixed order.
-// One wave per pose: lanes stride over the query points, then a fixed butterfly (deterministic, independent of nT).
-// Status words (tile_info): an edge-workspace overflow anywhere in this API call turns the outputs into NaN (the evaluation that
-// overflowed produced nothing: stale results must never look valid); a non-finite sum (fp16 operand range exceeded, or NaN inputs)
-// raises the sticky non-finite flag.
-__device__ inline bool reduce_status(int* flags, float (&s)[6]) {
-    const bool ovf = flags[kFlagOverflow] != 0;
-    if (ovf) for (int i = 0; i < 6; ++i) s[i] = __builtin_nanf("");
-    bool fin = true;
-    for (int i = 0; i < 6; ++i) fin = fin && (fabsf(s[i]) <= 3.0e38f);
-    if (!fin && !ovf) flags[kFlagNonFinite] = 1;
-    return ovf;
-}
 __global__ __launch_bounds__(64) void k_pose_reduce(const float* __restrict__ node_out, int nT, int nQ, float* __restrict__ ang, float* __restrict__ lin,
                                                     int* __restrict__ flags) {
     const int t = blockIdx.x, lane = threadIdx.x;
@@ -590,101 +650,13 @@ __global__ __launch_bounds__(64) void k_pose_reduce(const float* __restrict__ no
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------------
-// Langevin step on SE(3) in float64 (score_model_base.py:178-193).  Noise: caller-provided standard normals or
-// Philox4x32-10 keyed by (seed, global pose index, step) + Box-Muller, so results do not depend on how poses are sharded.
-__device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-__device__ inline double u01(uint32_t hi, uint32_t lo) {      // (0,1]
-    const uint64_t v = ((uint64_t)hi << 21) ^ (uint64_t)(lo >> 11);   // 53 bits
-    return ((double)(v & ((1ull << 53) - 1)) + 1.0) * (1.0 / 9007199254740992.0);
-}
-struct LangevinParams {
-    double* T;                 // [nT][7] state, updated in place
-    double t, alpha_ang, alpha_lin, temperature, ang_mult, lin_mult;
-    const double* noise;       // [2][nT][3] for this step or nullptr
-    uint64_t seed; int64_t first_pose; int step;
-    double* traj_out;          // [nT][7] slot of this step
-    int nT;
-};
-// update of pose i from its fp32 scores (ang, lin)
-__device__ inline void langevin_update(const LangevinParams& P, int i, const float (&ang)[3], const float (&lin)[3]) {
-    double* T = P.T + 7 * (size_t)i;
-    double na[3], nl[3];
-    if (P.noise) {
-        for (int k = 0; k < 3; ++k) { na[k] = P.noise[(size_t)i * 3 + k]; nl[k] = P.noise[(size_t)(P.nT + i) * 3 + k]; }
-    } else {
-        const uint64_t gp = (uint64_t)(P.first_pose + i);
-        double g[8];
-        for (int b = 0; b < 2; ++b) {
-            uint32_t r[8];
-            philox4x32_10((uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)P.step, (uint32_t)(2 * b), (uint32_t)P.seed, (uint32_t)(P.seed >> 32), r);
-            philox4x32_10((uint32_t)gp, (uint32_t)(gp >> 32), (uint32_t)P.step, (uint32_t)(2 * b + 1), (uint32_t)P.seed, (uint32_t)(P.seed >> 32), r + 4);
-            for (int p = 0; p < 2; ++p) {              // Box-Muller on two uniform pairs
-                const double u1 = u01(r[4 * p], r[4 * p + 1]), u2 = u01(r[4 * p + 2], r[4 * p + 3]);
-                const double rad = sqrt(-2.0 * log(u1)), th = 6.283185307179586476925 * u2;
-                g[4 * b + 2 * p] = rad * cos(th); g[4 * b + 2 * p + 1] = rad * sin(th);
-            }
-        }
-        for (int k = 0; k < 3; ++k) { na[k] = g[k]; nl[k] = g[3 + k]; }
-    }
-    const double st = sqrt(P.t);
-    double da[3], dl[3];
-    for (int k = 0; k < 3; ++k) {
-        const double sa = (double)ang[k] / (P.ang_mult * st);
-        const double sl = (double)lin[k] / (P.lin_mult * st);
-        da[k] = (P.alpha_ang / 2) * sa + sqrt(P.temperature * P.alpha_ang) * na[k];
-        dl[k] = (P.alpha_lin / 2) * sl + sqrt(P.temperature * P.alpha_lin) * nl[k];
-    }
-    const double q0 = T[0], q1 = T[1], q2 = T[2], q3 = T[3];
-    // dq = L da,  L = T[q_indices] * q_factor  (score_model_base.py:31-32, 188-190)
-    double dq[4];
-    dq[0] = -0.5 * q1 * da[0] - 0.5 * q2 * da[1] - 0.5 * q3 * da[2];
-    dq[1] = 0.5 * q0 * da[0] - 0.5 * q3 * da[1] + 0.5 * q2 * da[2];
-    dq[2] = 0.5 * q3 * da[0] + 0.5 * q0 * da[1] - 0.5 * q1 * da[2];
-    dq[3] = -0.5 * q2 * da[0] + 0.5 * q1 * da[1] + 0.5 * q0 * da[2];
-    // dx = quaternion_apply(q, dl) with the pre-update q
-    const double ow = -q1 * dl[0] - q2 * dl[1] - q3 * dl[2];
-    const double ox = q0 * dl[0] + q2 * dl[2] - q3 * dl[1];
-    const double oy = q0 * dl[1] - q1 * dl[2] + q3 * dl[0];
-    const double oz = q0 * dl[2] + q1 * dl[1] - q2 * dl[0];
-    const double rx = -ow * q1 + ox * q0 - oy * q3 + oz * q2;
-    const double ry = -ow * q2 + ox * q3 + oy * q0 - oz * q1;
-    const double rz = -ow * q3 - ox * q2 + oy * q1 + oz * q0;
-    double n0 = q0 + dq[0], n1 = q1 + dq[1], n2 = q2 + dq[2], n3 = q3 + dq[3];
-    const double nn = sqrt(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
-    T[0] = n0 / nn; T[1] = n1 / nn; T[2] = n2 / nn; T[3] = n3 / nn;
-    T[4] += rx; T[5] += ry; T[6] += rz;
-    double* o = P.traj_out + 7 * (size_t)i;
-    for (int k = 0; k < 7; ++k) o[k] = T[k];
-}
 // Sampler: sum over the query points of one pose (k_pose_reduce's order, bit for bit) and the Langevin update of that pose in one
 // launch — one wave per pose, lane 0 carries the float64 update.
 __global__ __launch_bounds__(64) void k_reduce_langevin(const float* __restrict__ node_out, int nQ, float* __restrict__ ang_out,
                                                         float* __restrict__ lin_out, LangevinParams P, int* __restrict__ flags) {
-    const int t = blockIdx.x, lane = threadIdx.x;
+    const int t = blockIdx.x;
     if (t >= P.nT) return;
-    float s[6] = {0, 0, 0, 0, 0, 0};
-    for (int q = lane; q < nQ; q += 64) {
-        const float* o = node_out + ((size_t)t * nQ + q) * 8;
-        const f32x4 a = ld4(o), b = ld4(o + 4);
-        s[0] += a[0]; s[1] += a[1]; s[2] += a[2]; s[3] += a[3]; s[4] += b[0]; s[5] += b[1];
-    }
-    for (int m = 32; m >= 1; m >>= 1)
-        for (int i = 0; i < 6; ++i) s[i] += __shfl_xor(s[i], m, 64);
-    if (lane != 0) return;
-    reduce_status(flags, s);
-    const float lin[3] = {s[0], s[1], s[2]}, ang[3] = {s[3], s[4], s[5]};
-    for (int k = 0; k < 3; ++k) { lin_out[3 * t + k] = lin[k]; ang_out[3 * t + k] = ang[k]; }
-    langevin_update(P, t, ang, lin);
+    reduce_pose_and_step(node_out, nQ, t, (int)threadIdx.x, ang_out, lin_out, P, flags);
 }
 
 }  // namespace dedf

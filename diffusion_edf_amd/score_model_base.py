@@ -22,11 +22,22 @@ from .gnn_data import FeaturedPoints
 from .score_head import ScoreModelHead
 
 
+_SCHEDULE_CACHE: dict = {}
+
+
 def build_schedule(ang_mult: float, lin_mult: float, diffusion_schedules, N_steps, timesteps, temperatures=1.0,
                    log_t_schedule: bool = True, time_exponent_temp: float = 0.5, time_exponent_alpha: float = 0.5):
-    """Per-step (t, alpha_ang, alpha_lin, temperature) in float64 — reference score_model_base.py:131-171."""
+    """Per-step (t, alpha_ang, alpha_lin, temperature) in float64 — reference score_model_base.py:131-171.
+    The powers are torch's own scalar float64 ``pow`` (its vectorised form and libm's differ from it in the last bit for a few per cent of
+    the arguments); the products around them are plain IEEE double multiplications in the reference's order, done on Python floats.  A
+    deployment calls ``sample`` with the same schedule over and over: results are memoised."""
     if isinstance(temperatures, (int, float)):
         temperatures = [float(temperatures) for _ in range(len(diffusion_schedules))]
+    key = (float(ang_mult), float(lin_mult), tuple(tuple(float(v) for v in s_) for s_ in diffusion_schedules), tuple(int(n) for n in N_steps),
+           tuple(float(v) for v in timesteps), tuple(float(v) for v in temperatures), bool(log_t_schedule), float(time_exponent_temp), float(time_exponent_alpha))
+    hit = _SCHEDULE_CACHE.get(key)
+    if hit is not None:
+        return hit
     temperatures = torch.tensor(temperatures, dtype=torch.float64)
     sched = torch.tensor(diffusion_schedules, dtype=torch.float64)
     ts, aa, al, tt = [], [], [], []
@@ -36,14 +47,18 @@ def build_schedule(ang_mult: float, lin_mult: float, diffusion_schedules, N_step
                                         base=torch.e, dtype=torch.float64)
         else:
             t_schedule = torch.linspace(start=schedule[0], end=schedule[1], steps=N_steps[n], dtype=torch.float64)
-        for i in range(len(t_schedule)):
-            t = t_schedule[i]
+        temp_n, dt_n = float(temperatures[n]), timesteps[n]
+        for t in t_schedule.unbind(0):
+            p_alpha = float(torch.pow(t, time_exponent_alpha))
+            p_temp = p_alpha if time_exponent_temp == time_exponent_alpha else float(torch.pow(t, time_exponent_temp))
             ts.append(float(t))
-            tt.append(float(temperatures[n] * torch.pow(t, time_exponent_temp)))
-            aa.append(float((ang_mult ** 2) * torch.pow(t, time_exponent_alpha) * timesteps[n]))
-            al.append(float((lin_mult ** 2) * torch.pow(t, time_exponent_alpha) * timesteps[n]))
-    return (np.asarray(ts, dtype=np.float64), np.asarray(aa, dtype=np.float64), np.asarray(al, dtype=np.float64),
-            np.asarray(tt, dtype=np.float64))
+            tt.append(temp_n * p_temp)
+            aa.append((ang_mult ** 2) * p_alpha * dt_n)
+            al.append((lin_mult ** 2) * p_alpha * dt_n)
+    out = (np.asarray(ts, dtype=np.float64), np.asarray(aa, dtype=np.float64), np.asarray(al, dtype=np.float64), np.asarray(tt, dtype=np.float64))
+    if len(_SCHEDULE_CACHE) < 64:
+        _SCHEDULE_CACHE[key] = out
+    return out
 
 
 class ScoreModelBase(torch.nn.Module):
