@@ -1,6 +1,8 @@
 """Graph construction of the feature extractors — mirrors reference ``diffusion_edf/connectivity.py`` (``RadiusGraph`` :8-30,
 ``RadiusConnect`` :34-49, ``FpsPool`` :53-80) on the HIP primitives ``dedf_fps`` / ``dedf_radius`` instead of torch_cluster /
-torch_scatter.  Single cloud (every shipped config has all batch indices 0); inputs must live on the GPU — there is no CPU path.
+torch_scatter.  Inputs must live on the GPU — there is no CPU path.  Several clouds in one batch vector (``batch`` sorted, as torch_cluster
+requires; reference connectivity.py:62 passes ``batch`` to ``fps``, :43 ``batch_x`` / ``batch_y`` to ``radius``) are handled cloud by cloud on
+the same primitives; every shipped config has all batch indices 0, which is the fast path (no host round trip per graph).
 The UNet / keypoint extractors that consume these graphs: ``unet.py``, ``keypoint_extractor.py``."""
 from __future__ import annotations
 
@@ -18,18 +20,32 @@ def _stream() -> C.c_void_p:
 
 
 def _check_cloud(x: torch.Tensor, batch: Optional[torch.Tensor]):
+    """-> None for a single cloud, else [(batch id, start, end)] of the clouds of a SORTED batch vector (reads back from the device)"""
     assert x.ndim == 2 and x.shape[-1] == 3, f"{tuple(x.shape)}"
     if not x.is_cuda:
         raise RuntimeError("diffusion_edf_amd.connectivity needs GPU tensors: the product has no CPU path")
-    if batch is not None and batch.numel() and int(batch.max()) != int(batch.min()):
-        raise NotImplementedError("several clouds in one batch vector (every shipped config uses a single cloud)")
+    if batch is None or batch.numel() == 0:
+        return None
+    assert batch.ndim == 1 and len(batch) == len(x), f"{tuple(batch.shape)}"
+    ids, counts = torch.unique_consecutive(batch, return_counts=True)
+    if len(ids) == 1:
+        return None
+    ids, counts = ids.tolist(), counts.tolist()
+    if any(b <= a for a, b in zip(ids, ids[1:])):
+        raise ValueError("batch vector must be sorted (torch_cluster's requirement)")
+    segs, s0 = [], 0
+    for b, c in zip(ids, counts):
+        segs.append((b, s0, s0 + c))
+        s0 += c
+    return segs
 
 
 def fps(src: torch.Tensor, batch: Optional[torch.Tensor] = None, ratio: float = 0.5, random_start: bool = True, _trusted: bool = False) -> torch.Tensor:
     """torch_cluster.fps as connectivity.py:62 calls it: ``ceil(ratio * N)`` indices in selection order.
     (``_trusted``: the caller has already checked that the batch vector holds one cloud — the check reads back from the device.)"""
-    if not _trusted:
-        _check_cloud(src, batch)
+    segs = None if _trusted else _check_cloud(src, batch)
+    if segs is not None:              # cloud by cloud: ceil(ratio * n_b) points of each, indices into the concatenated cloud
+        return torch.cat([fps(src[a:b], None, ratio=ratio, random_start=random_start, _trusted=True) + a for _, a, b in segs])
     n = len(src)
     k = int(math.ceil(ratio * n))
     start = int(torch.randint(n, (1,)).item()) if random_start else 0
@@ -47,8 +63,21 @@ def radius(x: torch.Tensor, y: torch.Tensor, r: float, batch_x=None, batch_y=Non
            _exclude_self: bool = False, _trusted: bool = False) -> torch.Tensor:
     """torch_cluster.radius: for every point of ``y`` the points of ``x`` within ``r`` -> ``(2, E)`` = [y index, x index]."""
     if not _trusted:
-        _check_cloud(x, batch_x)
-        _check_cloud(y, batch_y)
+        sx, sy = _check_cloud(x, batch_x), _check_cloud(y, batch_y)
+        if sx is not None or sy is not None:      # pairs exist inside a cloud only: cloud by cloud, sorted by y index like the single-cloud result
+            if sx is None:
+                sx = [(int(batch_x[0]) if batch_x is not None and len(batch_x) else 0, 0, len(x))]
+            if sy is None:
+                sy = [(int(batch_y[0]) if batch_y is not None and len(batch_y) else 0, 0, len(y))]
+            xseg = {b: (a, e) for b, a, e in sx}
+            parts = []
+            for b, a, e in sy:
+                if b not in xseg:
+                    continue
+                xa, xe = xseg[b]
+                edge = radius(x[xa:xe], y[a:e], r, None, None, max_num_neighbors, _exclude_self=_exclude_self, _trusted=True)
+                parts.append(torch.stack([edge[0] + a, edge[1] + xa], dim=0))
+            return torch.cat(parts, dim=1) if parts else torch.zeros(2, 0, dtype=torch.int64, device=x.device)
     xs = x.detach().to(torch.float32).contiguous()
     ys = y.detach().to(torch.float32).contiguous()
     lib = _lib.load()
@@ -73,9 +102,8 @@ def radius(x: torch.Tensor, y: torch.Tensor, r: float, batch_x=None, batch_y=Non
 
 
 def radius_graph(x: torch.Tensor, r: float, batch=None, loop: bool = False, max_num_neighbors: int = 32, _trusted: bool = False) -> torch.Tensor:
-    if not _trusted:
-        _check_cloud(x, batch)
-    return radius(x, x, r, batch, batch, max_num_neighbors, _exclude_self=not loop, _trusted=True)
+    # (loop=False: a point's own index is excluded -- the indices of x and y coincide cloud by cloud as well)
+    return radius(x, x, r, batch, batch, max_num_neighbors, _exclude_self=not loop, _trusted=_trusted)
 
 
 def _in_degree(edge_dst: torch.Tensor, n_nodes: int) -> torch.Tensor:
@@ -122,7 +150,7 @@ class FpsPool(torch.nn.Module):
     def forward(self, node_coord_src: torch.Tensor, node_feature_src: torch.Tensor, batch_src: torch.Tensor, _trusted: bool = False):
         picked = fps(node_coord_src, batch_src, ratio=self.ratio, random_start=self.random_start, _trusted=_trusted)
         coord, feat, batch = node_coord_src[picked], node_feature_src[picked], batch_src[picked]
-        src, dst = self.radius_connect(node_coord_src, batch_src, coord, batch, _trusted=True)      # (a sub-sample of a single cloud is one)
+        src, dst = self.radius_connect(node_coord_src, batch_src, coord, batch, _trusted=_trusted)      # (a sub-sample of a single cloud is one)
         other = picked[dst] != src                      # drop the edge from a pooled node to the source point it was sampled from
         src, dst = src[other], dst[other]
         return feat, coord, src, dst, _in_degree(dst, len(picked)), batch

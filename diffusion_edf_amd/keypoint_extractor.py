@@ -57,8 +57,8 @@ class MultiscaleTensorField(torch.nn.Module):
         self.cfg = HeadConfig.from_kwargs(dict(ebm=True, max_time=1.0, time_emb_mlp=[256, 128, 64], key_tensor_field_kwargs=tf,
                                                irreps_query_edf=str(irreps_input), lin_mult=1.0, ang_mult=1.0, edge_time_encoding=False,
                                                query_time_encoding=False))
-        if self.cfg.lmax != 2:
-            raise NotImplementedError("context-free fields are instantiated for lmax 2")
+        if self.cfg.lmax not in (2, 3):
+            raise NotImplementedError("context-free fields are instantiated for lmax 2 and 3")
         self.n_scales, self.dim = self.cfg.n_scales, self.cfg.dim
         full = init_params(self.cfg, seed=init_seed)
         self._unused = {k: torch.zeros_like(v) for k, v in full.items() if not k.startswith(_KTF)}      # the head's time MLPs: not part of a field
@@ -148,11 +148,14 @@ class MultiscaleTensorField(torch.nn.Module):
             if self.scalar_out:                       # FFN output + skip_2(emb), skip_2 = LinearRS(emb -> 64x0e, bias) on the HIP per-node linear
                 sd = self.state_dict()
                 muls = self.cfg.muls
+                from . import unet_pad
+                kmuls = unet_pad.wide_of(muls)                 # the per-node linear works in the kernel layout (lmax 3: 8x3e padded to 16x3e)
                 W = torch.cat([sd["gnn_block_init.skip_2.skip.tp.weight"].detach().float().reshape(-1).cpu(),
-                               torch.zeros(sum(m * m for m in muls[1:]))]).to(dev).contiguous()
+                               torch.zeros(sum(m * m for m in kmuls[1:]))]).to(dev).contiguous()
                 b = sd["gnn_block_init.skip_2.skip.bias.0"].detach().float().to(dev).contiguous()
-                skip = torch.empty_like(emb)
-                rc = lib.dedf_linear_rs(emb.data_ptr(), len(emb), None, None, W.data_ptr(), b.data_ptr(), None, skip.data_ptr(), stream)
+                emb_k = unet_pad.pad_features(emb, muls).contiguous()
+                skip = torch.empty_like(emb_k)
+                rc = lib.dedf_linear_rs_lmax(len(muls) - 1, emb_k.data_ptr(), len(emb_k), None, None, W.data_ptr(), b.data_ptr(), None, skip.data_ptr(), stream)
                 if rc != _lib.OK:
                     raise RuntimeError(f"dedf_linear_rs failed ({rc})")
                 f_out = field[:, :64] - emb[:, :64] + skip[:, :64]

@@ -151,7 +151,12 @@ def unet_kwargs(kind: str = "panda_lowres") -> dict:
 
 
 def keypoint_extractor_kwargs(radii=(5.0, 10.0, 20.0, 40.0), bbox=((-30.0, 30.0), (-30.0, 30.0), (8.0, 100.0)), unet="panda_highres", pool_ratio=0.1):
-    """the query_kwargs block of configs/panda_*/place_*/score_model_configs.yaml"""
+    """the query_kwargs block of configs/panda_*/place_*/score_model_configs.yaml (``unet`` ending in ``_lmax3``: the same with one more degree)"""
+    if unet.endswith("_lmax3"):
+        kw = keypoint_extractor_kwargs(radii, bbox, unet[:-len("_lmax3")], pool_ratio)
+        kw["feature_extractor_kwargs"] = unet_kwargs(unet)
+        kw["tensor_field_kwargs"] = dict(kw["tensor_field_kwargs"], irreps_output='64x0e+32x1e+16x2e+8x3e', irreps_sh="1x0e+1x1e+1x2e+1x3e")
+        return kw
     return dict(weight_activation="sigmoid", weight_mult=None,
                 keypoint_kwargs=dict(pool_ratio=pool_ratio, weight_pre_emb_dim=64, bbox=None if bbox is None else [list(b) for b in bbox]),
                 feature_extractor_kwargs=unet_kwargs(unet),

@@ -393,7 +393,7 @@ class UnetFeatureExtractor(torch.nn.Module):
         assert f.ndim == 2 and x.ndim == 2 and b.ndim == 1 and len(f) == len(x) == len(b)
         if not f.is_cuda:
             raise RuntimeError("diffusion_edf_amd.unet needs GPU tensors: the product has no CPU path")
-        CN._check_cloud(x, b)
+        single = CN._check_cloud(x, b) is None       # several clouds in one batch vector: the graphs are built cloud by cloud (connectivity.py)
         dt = f.dtype
         x = x.detach().float().contiguous()
         run = lambda layer, xs, fs, xd, fd, es, ed, srt: layer.forward_wide(xs, fs, xd, fd, es, ed, dst_sorted=srt, deferred=True)
@@ -401,13 +401,13 @@ class UnetFeatureExtractor(torch.nn.Module):
         f = self.input_emb.forward_wide(self.input_emb.pad_in(f.detach().float()))
         down_out, down_edges, scale_out, used = [(f, x, b)], [], [], []
         for blk in self.down_blocks:
-            f_dst, x_dst, es, ed, _, b_dst = blk['pool'](x, f, b, _trusted=True)                     # :279-282
+            f_dst, x_dst, es, ed, _, b_dst = blk['pool'](x, f, b, _trusted=single)                     # :279-282
             f_dst = lin(blk['pool_proj'], f_dst)
             f = run(blk['pool_layer'], x, f, x_dst, f_dst, es, ed, True)
             used.append(blk['pool_layer'])
             x, b = x_dst, b_dst
             down_out.append((f, x, b)); down_edges.append((es, ed))
-            _, _, es, ed, _, _ = blk['radius_graph'](x, f, b, _trusted=True)                          # :306-311
+            _, _, es, ed, _, _ = blk['radius_graph'](x, f, b, _trusted=single)                          # :306-311
             for layer in blk['layer_stack']:
                 f = run(layer, x, f, x, f, es, ed, True)
                 used.append(layer)

@@ -55,3 +55,30 @@ def radius(x_src: np.ndarray, x_dst: np.ndarray, r: float, max_num_neighbors: in
         ed.append(di + s)
         es.append(si)
     return np.concatenate(ed).astype(np.int64), np.concatenate(es).astype(np.int64)
+
+
+# ---- several clouds in one (sorted) batch vector: torch_cluster builds its graphs cloud by cloud ----------------------------------
+def _segments(batch: np.ndarray):
+    batch = np.asarray(batch)
+    assert np.all(np.diff(batch) >= 0), "batch vector must be sorted"
+    ids, starts = np.unique(batch, return_index=True)
+    ends = list(starts[1:]) + [len(batch)]
+    return [(int(b), int(a), int(e)) for b, a, e in zip(ids, starts, ends)]
+
+
+def fps_batched(x: np.ndarray, batch: np.ndarray, ratio: float) -> np.ndarray:
+    """fps(src, batch, ratio, random_start=False): ceil(ratio * n_b) points of every cloud b, first pick = the cloud's first point"""
+    return np.concatenate([fps(x[a:e], ratio) + a for _, a, e in _segments(batch)])
+
+
+def radius_batched(x_src, x_dst, r, batch_src, batch_dst, max_num_neighbors, exclude_self: bool = False):
+    """radius(x, y, r, batch_x, batch_y, ...): pairs exist inside one cloud only -> (edge_dst, edge_src), sorted by dst then src"""
+    seg_s = {b: (a, e) for b, a, e in _segments(batch_src)}
+    ed, es = [np.zeros(0, np.int64)], [np.zeros(0, np.int64)]
+    for b, a, e in _segments(batch_dst):
+        if b not in seg_s:
+            continue
+        sa, se = seg_s[b]
+        d, s_ = radius(x_src[sa:se], x_dst[a:e], r, max_num_neighbors, exclude_self)
+        ed.append(d + a); es.append(s_ + sa)
+    return np.concatenate(ed), np.concatenate(es)

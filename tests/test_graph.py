@@ -107,3 +107,57 @@ def test_connectivity_modules_match_oracle():
     assert np.array_equal(xo.cpu().numpy(), x[idx]) and np.array_equal(fo[:, 0].cpu().numpy(), idx.astype(np.float32))
     assert np.array_equal(ed.cpu().numpy(), rd[keep]) and np.array_equal(es.cpu().numpy(), rs[keep])
     assert np.array_equal(deg.cpu().numpy(), np.bincount(rd[keep], minlength=len(idx))) and len(bo) == len(idx)
+
+
+# ---- several clouds in one batch vector (reference connectivity.py:62 fps(batch=...), :43 radius(batch_x, batch_y)) -----------------------
+def _three_clouds():
+    xs = [_cloud(700, 11), _cloud(64, 12) + np.float32(3.0), _cloud(1500, 13)]
+    x = np.concatenate(xs).astype(np.float32)
+    batch = np.concatenate([np.full(len(c), b) for c, b in zip(xs, (0, 1, 4))])
+    return xs, x, batch
+
+
+def test_batched_oracle_is_the_per_cloud_oracle():
+    xs, x, batch = _three_clouds()
+    idx = G.fps_batched(x, batch, 0.1)
+    off = np.cumsum([0] + [len(c) for c in xs])
+    assert np.array_equal(idx, np.concatenate([G.fps(c, 0.1) + o for c, o in zip(xs, off)])) and len(idx) == 70 + 7 + 150
+    ed, es = G.radius_batched(x, x[idx], 6.0, batch, batch[idx], 1000)
+    assert np.all(batch[es] == batch[idx][ed]) and np.all(np.diff(ed) >= 0)                    # no pair crosses clouds; sorted by destination
+    # the clouds overlap in space: without the batch vector there would be cross-cloud pairs
+    ed1, es1 = G.radius(x, x[idx], 6.0, 1000)
+    assert len(ed1) > len(ed)
+    # a destination cloud whose id has no source cloud gets no edges
+    ed2, _ = G.radius_batched(x[:700], x[idx], 6.0, batch[:700], batch[idx], 1000)
+    assert set(np.unique(batch[idx][ed2]).tolist()) == {0}
+
+
+@pytest.mark.gpu
+def test_batched_graphs_bit_exact_and_unet_on_two_clouds():
+    from diffusion_edf_amd import connectivity as K
+    from diffusion_edf_amd.gnn_data import FeaturedPoints
+    from diffusion_edf_amd.unet import UnetFeatureExtractor
+    xs, x, batch = _three_clouds()
+    tx, tb = torch.from_numpy(x).cuda(), torch.from_numpy(batch).cuda()
+    idx = K.fps(tx, tb, ratio=0.1, random_start=False)
+    assert np.array_equal(idx.cpu().numpy(), G.fps_batched(x, batch, 0.1))
+    e = K.radius(tx, tx[idx], 6.0, tb, tb[idx], max_num_neighbors=1000)
+    ed, es = G.radius_batched(x, x[idx.cpu().numpy()], 6.0, batch, batch[idx.cpu().numpy()], 1000)
+    assert np.array_equal(e[0].cpu().numpy(), ed) and np.array_equal(e[1].cpu().numpy(), es)
+    g = K.radius_graph(tx, 2.0, tb, loop=False, max_num_neighbors=1000)
+    gd, gs = G.radius_batched(x, x, 2.0, batch, batch, 1000, exclude_self=True)
+    assert np.array_equal(g[0].cpu().numpy(), gd) and np.array_equal(g[1].cpu().numpy(), gs)
+    with pytest.raises(ValueError, match="sorted"):
+        K.fps(tx, torch.flip(tb, dims=[0]), ratio=0.1, random_start=False)
+    # the whole extractor on two clouds in one batch vector = the two clouds one after the other
+    m = UnetFeatureExtractor(**synthetic.unet_kwargs("panda_lowres"), deterministic=True).cuda()
+    a, b = torch.from_numpy(_cloud(1200, 21)).cuda(), torch.from_numpy(_cloud(800, 22)).cuda()
+    fa, fb = torch.rand(len(a), 3, device="cuda"), torch.rand(len(b), 3, device="cuda")
+    z = lambda n, v: torch.full((n,), v, dtype=torch.long, device="cuda")
+    both = m(FeaturedPoints(x=torch.cat([a, b]), f=torch.cat([fa, fb]), b=torch.cat([z(len(a), 0), z(len(b), 1)]), w=None))
+    oa, ob = m(FeaturedPoints(x=a, f=fa, b=z(len(a), 0), w=None)), m(FeaturedPoints(x=b, f=fb, b=z(len(b), 0), w=None))
+    for lv, (pa, pb) in enumerate(zip(oa, ob)):
+        na = len(pa.x)
+        assert torch.equal(both[lv].x[:na], pa.x) and torch.equal(both[lv].x[na:], pb.x) and int(both[lv].b[:na].sum()) == 0 and bool((both[lv].b[na:] == 1).all())
+        ref = torch.cat([pa.f, pb.f])
+        assert float((both[lv].f - ref).abs().max()) <= 1e-5 * float(ref.abs().max())

@@ -348,3 +348,36 @@ def test_unet_feature_extractor_lmax3_matches_the_oracle(n_points, half):
             err = float((got[:, off:off + d] - fr[:, off:off + d]).abs().max()) / max(float(fr[:, off:off + d].abs().max()), 1e-3 * float(fr.abs().max()))
             assert err < (5e-3 if half else 2e-4), (len(xr), l, err)
             off += d
+
+
+@pytest.mark.gpu
+def test_keypoint_extractor_lmax3_matches_the_oracle():
+    """the place tasks' query model at lmax 3: UNet + FPS key points + tensor_field / weight_field (context-free MultiscaleTensorFields with the
+    [64, 32, 32] radial MLP) + the weight head, against the fp64 restatement: coordinates bit-exact, features 2e-4, weights 2e-4 absolute"""
+    from diffusion_edf_amd.keypoint_extractor import KeypointExtractor
+    from diffusion_edf_amd.so3 import parse_irreps
+    dev = torch.device("cuda:0")
+    radii = (5.0, 10.0, 20.0, 40.0)
+    qk = synthetic.keypoint_extractor_kwargs(radii, unet="panda_highres_lmax3")
+    m = KeypointExtractor(**qk, deterministic=True)
+    _randomized(m, seed=2)
+    x = synthetic.make_scene(2500, seed=6).astype(np.float32)
+    x = (x - x.mean(0)) * 0.5
+    x[:, 2] += 14.0 - x[:, 2].min()
+    x = torch.from_numpy(x.astype(np.float32))
+    f = torch.rand(len(x), 3, generator=torch.Generator().manual_seed(0))
+    kw = m.feature_extractor._ctor
+    ucfg = U.UnetConfig(irreps_input=parse_irreps(kw["irreps_input"]), irreps_output=parse_irreps(kw["irreps_output"]),
+                        irreps_emb=[parse_irreps(i) for i in kw["irreps_emb"]], fc_neurons=[list(v) for v in kw["fc_neurons"]],
+                        n_layers=list(kw["n_layers"]), pool_ratio=list(kw["pool_ratio"]), radius=list(m.feature_extractor.radius),
+                        n_layers_midstream=kw["n_layers_midstream"], irreps_sh=SH3)
+    fcfg = R.Config(irreps=IRREPS3, irreps_sh=SH3, num_heads=4, fc_neurons=[64, 32, 32], length_emb_dim=64, r_cluster_multiscale=list(radii),
+                    r_mincut_nonscalar_sh=0.01 * radii[0], length_enc_max_r=None, time_emb_mlp=[256, 128, 64], max_time=1.0, time_enc_n=10000.0,
+                    lin_mult=1.0, ang_mult=1.0, edge_time_encoding=False)
+    P = R.cast_params({k: v.cpu() for k, v in m.state_dict().items()}, torch.float64)
+    xq, fq, wq = U.keypoint_extractor_forward(ucfg, fcfg, P, x, f.double(), 0.1, bbox=qk["keypoint_kwargs"]["bbox"])
+    m.to(dev)
+    out = m(FeaturedPoints(x=x.to(dev), f=f.to(dev), b=torch.zeros(len(x), dtype=torch.long, device=dev), w=None))
+    assert torch.equal(out.x.cpu(), xq) and out.f.shape == fq.shape == (len(xq), 296) and len(xq) > 20
+    assert float((out.f.cpu().double() - fq).abs().max()) < 2e-4 * float(fq.abs().max())
+    assert float((out.w.cpu().double() - wq).abs().max()) < 2e-4 and float(wq.max() - wq.min()) > 1e-3
