@@ -476,7 +476,8 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     np.mask = h->d_mask.as<uint32_t>();
     np.edge_hist = h->profile ? h->d_hist.as<long long>() : nullptr;
     // small batches: pose preparation + word-parallel masks in one launch, single-workgroup count / scan / fill (dedf_misc.h)
-    bool small = Nd <= kNbrSmallMax && h->small_batch_path;
+    static const int small_max = [] { const char* e = getenv("DEDF_SMALL_BATCH_MAX"); return e ? atoi(e) : kNbrSmallMax; }();      // (experiments)
+    bool small = Nd <= small_max && h->small_batch_path;
     for (int n = 0; n < ns; ++n) if (c.radii[n] > 0 && h->scale_start[n + 1] - h->scale_start[n] > c.max_neighbors) small = false;      // the cap could bind
     const double* T64 = h->fused_step ? h->fused_step->T : (const double*)nullptr;
     const int* cnt_used = h->d_cnt.as<int>();
