@@ -17,12 +17,15 @@ using namespace dedf;
 
 #include "dedf_kernels.h"
 #include "dedf_kernels_occ.h"
+#include "dedf_edge16.h"
+#include "dedf_pack16.h"
 #include "dedf_graph.h"
 #if !defined(DEDF_SINGLE_TU)
 #define DEDF_DECL(unit, ...) extern template __global__ __VA_ARGS__;
 DEDF_KERNEL_LIST(DEDF_DECL)
 #undef DEDF_DECL
 extern template __global__ void k_edge_occ<1, 128, false>(EdgeParams);
+extern template __global__ void dedf::k_edge16<2>(Edge16Params);
 #endif
 __global__ void k_energy_reduce(const float* __restrict__ node_out, int nT, int nQ, float* __restrict__ energy, int* __restrict__ flags) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -84,6 +87,9 @@ struct dedf_handle {
     DevBuf d_rtab, d_rtab_err;    // table rows; per-scale accuracy words (largest |interpolated - exact| activation at the interval midpoints)
     float rtab_err_bound = 1e-5f; // a scale whose word exceeds it evaluates its front per edge (DEDF_RADIAL_TABLE_BOUND)
     DevBuf d_cnt2, d_blk2; int small_parity = 0; int64_t small_layout = -1;      // the two alternating count sets of the small-batch neighbour path
+    Image edge16_img; Edge16Offsets e16{}; DevBuf d_edge16_w;      // the 16-edge tile's weight image (dedf_pack16.h), lmax-2 score heads
+    int edge16 = 0;                   // DEDF_EDGE16=1: the sampler's table path on the 16-edge / two-waves-per-SIMD kernel (dedf_edge16.h)
+    bool edge16_used = false;
     bool edge_occ = false;            // DEDF_EDGE_OCC=1: lmax-1 score head on the two-waves-per-SIMD build of the edge kernel (A/B)
     bool small_batch_path = true;     // N_d <= 8 192: word-parallel neighbour masks + fused pose preparation (DEDF_SMALL_BATCH=0 turns it off: A/B, tests)
     bool defer_check = false;         // dedf_layer_defer_check
@@ -119,7 +125,7 @@ struct DeviceGuard {
     DeviceGuard dev_guard__((h)->cfg.device);              \
     if (!dev_guard__.ok) return fail(h, DEDF_ERR_RUNTIME, "hipSetDevice failed")
 // clears the sticky status words (overflow, non-finite) at the start of an API call
-#define DEDF_CLEAR_FLAGS(h, st) HIPCK(h, hipMemsetAsync((h)->d_tile.as<int>() + kFlagOverflow, 0, 2 * sizeof(int), st))
+#define DEDF_CLEAR_FLAGS(h, st) HIPCK(h, hipMemsetAsync((h)->d_tile.as<int>() + kFlagOverflow, 0, (kFlagEdge16Redo + 1 - kFlagOverflow) * sizeof(int), st))
 
 int fail(dedf_handle* h, int code, const std::string& msg) {
     if (h) h->err = msg;
@@ -215,6 +221,10 @@ int upload_weights(dedf_handle* h) {
         return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(weights) failed");
     HIPCK(h, hipMemcpy(h->d_edge_w.p, h->edge_img.data.data(), h->edge_img.data.size() * 4, hipMemcpyHostToDevice));
     HIPCK(h, hipMemcpy(h->d_node_w.p, h->node_img.data.data(), h->node_img.data.size() * 4, hipMemcpyHostToDevice));
+    if (h->e16.ok) {
+        if (!h->d_edge16_w.ensure(h->edge16_img.data.size() * 4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(weights) failed");
+        HIPCK(h, hipMemcpy(h->d_edge16_w.p, h->edge16_img.data.data(), h->edge16_img.data.size() * 4, hipMemcpyHostToDevice));
+    }
     // natural-layout weights for the small kernels
     std::vector<float> nat;
     auto put = [&](const float* p, size_t n) { size_t o = nat.size(); nat.insert(nat.end(), p, p + n); return o; };
@@ -539,7 +549,21 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
                     }
                 } else {
                     launch_radial_table<L, F0, 128, 64>(h, P, st, false);
-                    DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 128, 64, false, 1>), kAll, st, P);
+                    bool on16 = false;
+                    if constexpr (L == 2 && F0 == 128) on16 = h->edge16 != 0 && h->e16.ok && !c.use_src_point_attn;
+                    if (on16) {
+                        if constexpr (L == 2 && F0 == 128) {
+                            Edge16Params Q{};
+                            Q.E = P; Q.W = h->d_edge16_w.as<float>(); Q.W_bytes = (uint32_t)h->d_edge16_w.bytes;
+                            const Edge16Offsets& o = h->e16;
+                            Q.o_A3 = o.o_A3; Q.o_A3_l = o.o_A3_l; Q.o_off3 = o.o_off3; Q.o_S_lin = o.o_S_lin; Q.o_b0 = o.o_b0; Q.o_S_val = o.o_S_val;
+                            Q.o_bval0 = o.o_bval0; Q.o_adot = o.o_adot; Q.w_unscale = o.w_unscale; Q.u_scale = o.u_scale;
+                            for (int l = 0; l < 4; ++l) { Q.c_lin[l] = o.c_lin[l]; Q.c_val[l] = o.c_val[l]; }
+                            Q.redo = h->d_tile.as<int>() + kFlagEdge16Redo;
+                            hipLaunchKernelGGL((k_edge16<2>), dim3(h->n_cu * waves_per_cu<(k_edge16<2>), 8>()), dim3(64), 0, st, Q);
+                            h->edge16_used = true;
+                        }
+                    } else DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 128, 64, false, 1>), kAll, st, P);
                 }
             }
         }
@@ -568,8 +592,12 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     }
     mark();
     // 5. joint softmax + aggregation
+    if (h->edge16_used) hipLaunchKernelGGL((k_aggregate<L, 16>), dim3((Nd + 3) / 4), dim3(256), 0, st, h->d_eout.as<float>(), cnt_used, h->d_off.as<int>(),
+                                           h->d_tile.as<int>(), Nd, ns, h->d_z.as<float>());
+    else
     hipLaunchKernelGGL(k_aggregate<L>, dim3((Nd + 3) / 4), dim3(256), 0, st, h->d_eout.as<float>(), cnt_used, h->d_off.as<int>(),
                        h->d_tile.as<int>(), Nd, ns, h->d_z.as<float>());
+    h->edge16_used = false;
     mark();
     // 6. node epilogue + score tensor products
     {
@@ -672,6 +700,7 @@ int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, de
     if (const char* e = getenv("DEDF_RADIAL_TABLE_BOUND")) h->rtab_err_bound = (float)atof(e);
     if (const char* e = getenv("DEDF_SMALL_BATCH")) h->small_batch_path = atoi(e) != 0;
     if (const char* e = getenv("DEDF_EDGE_OCC")) h->edge_occ = atoi(e) != 0;
+    if (const char* e = getenv("DEDF_EDGE16")) h->edge16 = atoi(e);
     const IrrepsRT T(h->L, cfg->unet_layer != 0), K(h->L, true);
     h->spec = build_spec(T, h->cfg);
     h->kspec = build_spec(K, h->cfg);
@@ -687,6 +716,7 @@ int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, de
     try {
         h->kparams = pad_params(h->cfg, T, h->spec, K, h->kspec, h->params.data());
         if (h->L == 1) pack_all<1>(h.get()); else if (h->L == 2) pack_all<2>(h.get()); else pack_all<3>(h.get());
+        if (h->L == 2 && !cfg->unet_layer && !cfg->ebm && cfg->fc_neurons[0] == 128) pack_edge16<2>(h->cfg, h->kspec, h->kparams.data(), h->edge16_img, h->e16);
     } catch (const std::exception& e) {
         fprintf(stderr, "dedf_create: %s\n", e.what());
         return DEDF_ERR_INVALID;
@@ -954,6 +984,11 @@ int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedul
     int flags[2] = {0, 0};
     if (sched->n_steps > 0) HIPCK(h, hipMemcpy(flags, h->d_tile.as<int>() + kFlagOverflow, sizeof(flags), hipMemcpyDeviceToHost));
     if (flags[0]) return fail(h, DEDF_ERR_RUNTIME, "edge workspace overflow: raise dedf_config.max_edges");
+    if (h->edge16) {
+        int redo = 0;
+        HIPCK(h, hipMemcpy(&redo, h->d_tile.as<int>() + kFlagEdge16Redo, 4, hipMemcpyDeviceToHost));
+        if (redo) return fail(h, DEDF_ERR_RUNTIME, "DEDF_EDGE16: an edge tile lay outside the radial table (the 16-edge kernel has no per-edge front): unset DEDF_EDGE16");
+    }
     if (flags[1]) return fail(h, DEDF_ERR_RUNTIME, "non-finite score: an activation left the fp16 operand range of the split-fp16 GEMMs "
                                                    "(or the inputs / poses were not finite)");
     return DEDF_OK;

@@ -300,6 +300,7 @@ struct NbrParams {
     uint32_t* mask;                       // [word][n_dst]: neighbour bit masks written by the count pass, 32 keys per word
     int word_start[kMaxScales + 1];       // first mask word of every scale (scale n has ceil(n_keys_n / 32) words)
 };
+constexpr int kFlagEdge16Redo = 44;      // word of tile_info, sticky over a dedf_sample call: the 16-edge kernel met a tile outside the radial table (dedf_edge16.h)
 constexpr int kNbrChunk = 1024;
 constexpr int kNbrBlock = 256;
 
@@ -529,7 +530,8 @@ __global__ void k_or_flag(const int* __restrict__ flag, int* __restrict__ sticky
 // Joint softmax over ALL scales' edges of one destination node + weighted aggregation (graph_attention.py:253-266;
 // scatter_logsumexp / scatter restated: max-shifted, empty segments give 0).  One wave per destination, lane = float4 of
 // the value record; deterministic (fixed edge order, no atomics).
-template <int L>
+// TILE: edges per tile of the edge kernel that wrote the records (32: dedf_edge.h, 16: dedf_edge16.h)
+template <int L, int TILE = 32>
 __global__ void k_aggregate(const float* __restrict__ edge_out, const int* __restrict__ cnt, const int* __restrict__ off,
                             const int* __restrict__ tile_info, int n_dst, int n_scales, float* __restrict__ z) {
     constexpr int D = feat_dim<L>(), REC = edge_rec<L>(), NV = D / 4;
@@ -561,8 +563,8 @@ __global__ void k_aggregate(const float* __restrict__ edge_out, const int* __res
             const int c = cnt[(size_t)n * n_dst + d];
             const int o = off[(size_t)n * n_dst + d];
             first[n] = tile_info[16 + n] + o;        // edge index of the destination's first record
-            fb[n] = 32 - (o & 31);                   // distance (in edges) to the next tile boundary
-            nr = c == 0 ? 0 : 1 + (fb[n] < c ? (c - fb[n] + 31) / 32 : 0);
+            fb[n] = TILE - (o & (TILE - 1));         // distance (in edges) to the next tile boundary
+            nr = c == 0 ? 0 : 1 + (fb[n] < c ? (c - fb[n] + TILE - 1) / TILE : 0);
         }
         pre[n + 1] = pre[n] + nr;
     }
@@ -580,7 +582,7 @@ __global__ void k_aggregate(const float* __restrict__ edge_out, const int* __res
         int ek = 0;
 #pragma unroll
         for (int n = 0; n < kMaxScales; ++n)
-            if (k >= pre[n] && k < pre[n + 1]) { const int jj = k - pre[n]; ek = first[n] + (jj == 0 ? 0 : fb[n] + 32 * (jj - 1)); }
+            if (k >= pre[n] && k < pre[n + 1]) { const int jj = k - pre[n]; ek = first[n] + (jj == 0 ? 0 : fb[n] + TILE * (jj - 1)); }
         const int jend = min(64, total - j0);
         for (int j = 0; j < jend; j += U) {
             f32x4 lg[U], v[U][NP];

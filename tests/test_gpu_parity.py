@@ -167,6 +167,45 @@ def test_radial_table_of_the_sampler_against_the_per_edge_evaluation():
                 assert e_on < 1e-4 and e_on < e_off + 5e-6, (t, e_on, e_off)
 
 
+def test_sixteen_edge_tile_of_the_sampler_against_the_oracle(monkeypatch):
+    """DEDF_EDGE16=1: the sampler's table path on the 16-edge tile (v_mfma_f32_16x16x32_f16, two waves per SIMD; csrc/dedf_edge16.h) -- an A/B
+    build of the same arithmetic (it is slower: profiles/r03j16_*).  One noise-free step against the fp64 oracle (1e-4 of the displacement
+    scale, rotation and translation) and against the 32-edge kernel (same 3-term products in another summation order: 1e-5), finite scales
+    and the all-pairs scale, partial tiles included (edge counts are not multiples of 16).  Lengths beyond the table are an error in this
+    mode (the tile has no per-edge front), not a silent fallback."""
+    dev = torch.device('cuda:0')
+    for radii, nT in (((5., 10., 20., None), 12), ((3.5, 5., 6.5, 8.), 40)):
+        kw, cfg, P, keys, query, Ts, _ = SC.build_case(2, nT, 1024, 128, radii=radii)
+        gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
+        gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
+        t, outs = 0.5, {}
+        for e16 in (0, 1):
+            monkeypatch.setenv("DEDF_EDGE16", str(e16))          # read by dedf_create
+            head = ScoreModelHead(**kw); head.load_state_dict(P); head.to(dev); head.set_radial_table("always")
+            outs[e16] = ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[t, t]], [1], [0.04], temperatures=0.0).cpu()
+        d0, d1 = outs[0][1] - outs[0][0], outs[1][1] - outs[1][0]
+        sq, sx = float(d0[:, :4].abs().max()), float(d0[:, 4:].abs().max())
+        dq, dx = float((d1 - d0)[:, :4].abs().max()) / sq, float((d1 - d0)[:, 4:].abs().max()) / sx
+        assert 0.0 < max(dq, dx) < 1e-5, (radii, dq, dx)         # (> 0: the other kernel really ran)
+        ocfg = R.config_from_kwargs(kw)
+        k64 = [R.FeaturedPoints(k.x.double(), k.f.double(), k.b, None) for k in keys]
+        q64 = R.FeaturedPoints(query.x.double(), query.f.double(), query.b, query.w.double())
+        ang, lin = R.score_head_forward(ocfg, R.cast_params(P, torch.float64), Ts, k64, q64, torch.full((len(Ts),), t, dtype=torch.float64))
+        z = torch.zeros(len(Ts), 3, dtype=torch.float64)
+        dr = R.langevin_step(ocfg, Ts, ang, lin, t, 0.04, 0.0, 0.5, 0.5, z, z) - Ts
+        eq, ex = float((d1 - dr)[:, :4].abs().max()) / sq, float((d1 - dr)[:, 4:].abs().max()) / sx
+        assert eq < 1e-4 and ex < 1e-4, (radii, eq, ex)
+    # far poses: all-pairs lengths leave the table -> reported
+    monkeypatch.setenv("DEDF_EDGE16", "1")
+    kw, cfg, P, keys, query, Ts, _ = SC.build_case(2, 12, 1024, 128, radii=(5., 10., 20., None))
+    Ts = Ts.clone(); Ts[::3, 4:] += torch.tensor([120.0, 60.0, 40.0], dtype=Ts.dtype)
+    head = ScoreModelHead(**kw); head.load_state_dict(P); head.to(dev); head.set_radial_table("always")
+    gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
+    gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
+    with pytest.raises(RuntimeError, match="DEDF_EDGE16"):
+        ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[0.5, 0.5]], [1], [0.04], temperatures=0.0)
+
+
 @pytest.mark.parametrize("shape", ["time_emb_128", "narrow_radial_mlp"])
 def test_radial_table_other_score_head_shapes(shape):
     """the table path of the two other lmax-2 score-head shapes the reference ships: pre-linear 192 wide (time_emb_mlp [512,256,128], sapien
