@@ -135,6 +135,293 @@ __global__ __launch_bounds__(BLOCK) void k_fps(const float* __restrict__ x, int 
     }
 }
 
+// ---- bucketed FPS (clouds of 1 025 .. 16 384 points) -----------------------------------------------------------------------------------
+// The plain kernel above touches every point for every sample although, once a few dozen samples exist, a new sample only lowers the running
+// minimum of the points NEAR it.  Here the cloud is first put into Morton order (counting sort in LDS) and cut into buckets of 128 consecutive points;
+// bucket b lives in slot b / 4 of wave b % 4 (neighbouring buckets on different waves), one point pair per lane, coordinates and minima in
+// registers (one wave per SIMD: 512 registers per lane).  Per bucket the wave keeps the bounding box, the largest running minimum and the
+// point that holds it (lane j of the wave holds the record of slot j).  Per sample:
+//   1. lane j tests its bucket: if the squared distance from the sample to the box (rounded down) is >= the bucket's largest minimum, no
+//      point of the bucket can change (its distance to the sample is at least its current minimum) and the bucket is skipped -- the
+//      result is therefore IDENTICAL to the exhaustive update, whatever the buckets look like;
+//   2. the wave walks its active buckets: packed distance update (same rounding sequence as the oracle), DPP maximum, the owner of the
+//      maximum (ties: smallest original index) leaves its coordinates in LDS;
+//   3. the best bucket of the wave goes with its coordinates into a double-buffered exchange slot; ONE barrier; every thread reads the four
+//      slots and knows the next sample and its coordinates.
+// The loop is a serial chain run by one wave per SIMD, where a TAKEN branch costs about as much as fifteen instructions (measured: the
+// first version, with a branch per rare case, spent 1 000 cycles per active bucket on 60 instructions): the hot path is written to fall through.
+// Measured (tests/probe/fps_bucket_probe.hip, synthetic scene, ratio 0.2): 16 384 points 6.4 -> 4.2 ms (set-up 0.09 ms; late in the run 5 of
+// the 128 buckets are active per sample and a sample costs 1.2 us: 0.4 us test + exchange, 0.1 us the wave's best bucket, the rest the
+// active buckets of the busiest wave at ~0.3 us each -- a serial chain of ~70 dependent instructions per bucket on a lone wave).  At 8 000
+// points it ties with the exhaustive kernel (1.97 against 2.05 ms), at 4 096 it loses (1.03 against 0.88 ms): dedf_fps uses it above 8 192.
+__device__ __forceinline__ float wave_max_f32(float v) {
+    auto step = [&]<int CTRL, int ROW_MASK>() {
+        const int b = __float_as_int(v);
+        v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(b, b, CTRL, ROW_MASK, 0xf, false)));
+    };
+    step.template operator()<0xB1, 0xf>(); step.template operator()<0x4E, 0xf>(); step.template operator()<0x141, 0xf>();
+    step.template operator()<0x140, 0xf>(); step.template operator()<0x142, 0xa>(); step.template operator()<0x143, 0xc>();
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// maximum of a signed int over the wave, one DPP instruction per step (the running minima are >= 0 or the padding value -1: as floats
+// they order like their bit patterns read as signed integers, and the integer maximum needs no NaN canonicalisation)
+__device__ __forceinline__ int wave_max_i32(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+#endif
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_min_i32_dpp(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+#endif
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// f.operator()<j>() for a wave-uniform j < N <= 32: ONE switch, so that every case leaves through the same join (a recursive if / else tree
+// leaves through one join block per level, each a taken branch)
+template <int N, class F> __device__ __forceinline__ void fps_dispatch(int j, F&& f) {
+#define DEDF_FPS_CASE(J) case J: if constexpr (J < N) f.template operator()<J>(); break;
+    switch (j) {
+        DEDF_FPS_CASE(0) DEDF_FPS_CASE(1) DEDF_FPS_CASE(2) DEDF_FPS_CASE(3) DEDF_FPS_CASE(4) DEDF_FPS_CASE(5) DEDF_FPS_CASE(6) DEDF_FPS_CASE(7)
+        DEDF_FPS_CASE(8) DEDF_FPS_CASE(9) DEDF_FPS_CASE(10) DEDF_FPS_CASE(11) DEDF_FPS_CASE(12) DEDF_FPS_CASE(13) DEDF_FPS_CASE(14) DEDF_FPS_CASE(15)
+        DEDF_FPS_CASE(16) DEDF_FPS_CASE(17) DEDF_FPS_CASE(18) DEDF_FPS_CASE(19) DEDF_FPS_CASE(20) DEDF_FPS_CASE(21) DEDF_FPS_CASE(22) DEDF_FPS_CASE(23)
+        DEDF_FPS_CASE(24) DEDF_FPS_CASE(25) DEDF_FPS_CASE(26) DEDF_FPS_CASE(27) DEDF_FPS_CASE(28) DEDF_FPS_CASE(29) DEDF_FPS_CASE(30) DEDF_FPS_CASE(31)
+        default: break;
+    }
+#undef DEDF_FPS_CASE
+}
+__device__ __forceinline__ unsigned morton5(unsigned v) {      // 5 bits -> every third bit
+    v &= 0x1f;
+    v = (v | (v << 8)) & 0x100f; v = (v | (v << 4)) & 0x10c3; v = (v | (v << 2)) & 0x1249;
+    return v;
+}
+
+constexpr int kFpsBucketBlock = 256;
+template <int PPT>      // points per thread: the cloud has at most 256 * PPT points (PPT = 16, 32, 64)
+__global__ __launch_bounds__(kFpsBucketBlock) void k_fps_bucketed(const float* __restrict__ x, int n, int n_samples, int start, int* __restrict__ idx_out) {
+#pragma clang fp contract(off)
+    constexpr int BLOCK = kFpsBucketBlock, NW = BLOCK / 64, NP = PPT / 2, NPAD = BLOCK * PPT;
+    static_assert(NP <= 32 && NPAD <= 16384, "bucket masks are 32 bits wide; original indices are kept in 16 bits");
+    constexpr int kBins = 32768;
+    __shared__ unsigned s_hist[kBins / 2];                  // set-up only: cell counters / offsets, two 16-bit halves per word
+    __shared__ unsigned short s_perm[NPAD];                 // set-up only: original index of sorted position p
+    __shared__ unsigned s_part[BLOCK];
+    __shared__ float4 s_cand[NW][NP];                       // per bucket: coordinates (+ original index) of the point with the largest minimum
+    __shared__ float4 s_exch[2][NW];                        // per wave: (bits of its largest minimum, coordinates of the point that holds it)
+    __shared__ int s_exch_idx[2][NW];                       //           and that point's original index
+    __shared__ float s_box[2][NW][3];
+    __shared__ int s_out[NW][BLOCK];                        // (every wave keeps the list: no wave branches around an empty store)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- Morton order of the cloud: counting sort on a 15-bit code (5 bits per axis) ----------------------------------------------------
+    // (the order INSIDE a cell is whatever the LDS atomics produce: the buckets only decide which updates are skipped, never the result)
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = tid; i < n; i += BLOCK)
+        for (int k = 0; k < 3; ++k) { const float v = x[3 * i + k]; lo[k] = fminf(lo[k], v); hi[k] = fmaxf(hi[k], v); }
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = -wave_max_f32(-lo[k]); hi[k] = wave_max_f32(hi[k]);
+        if (lane == 0) { s_box[0][wave][k] = lo[k]; s_box[1][wave][k] = hi[k]; }
+    }
+    for (int i = tid; i < kBins / 2; i += BLOCK) s_hist[i] = 0u;
+    __syncthreads();
+    float qs[3];
+    for (int k = 0; k < 3; ++k) {
+        for (int w = 0; w < NW; ++w) { lo[k] = fminf(lo[k], s_box[0][w][k]); hi[k] = fmaxf(hi[k], s_box[1][w][k]); }
+        const float ext = hi[k] - lo[k];
+        qs[k] = ext > 0.0f ? 31.999f / ext : 0.0f;
+    }
+    auto cell = [&](int i) {
+        unsigned q[3];
+        for (int k = 0; k < 3; ++k) q[k] = (unsigned)min(31, max(0, (int)((x[3 * i + k] - lo[k]) * qs[k])));
+        return morton5(q[0]) | (morton5(q[1]) << 1) | (morton5(q[2]) << 2);
+    };
+    // two 16-bit counters per word (n <= 16 384 < 65 536: a half never carries into its neighbour)
+    for (int i = tid; i < n; i += BLOCK) { const unsigned c = cell(i); atomicAdd(&s_hist[c >> 1], 1u << (16 * (c & 1u))); }
+    __syncthreads();
+    {   // exclusive scan: every thread owns kBins / BLOCK consecutive cells
+        constexpr int WPT = kBins / 2 / BLOCK;
+        unsigned sum = 0;
+        for (int i = 0; i < WPT; ++i) { const unsigned w = s_hist[tid * WPT + i]; sum += (w & 0xffffu) + (w >> 16); }
+        s_part[tid] = sum;
+        __syncthreads();
+        unsigned run = 0;
+        for (int t = 0; t < tid; ++t) run += s_part[t];
+        for (int i = 0; i < WPT; ++i) {
+            const unsigned w = s_hist[tid * WPT + i];
+            const unsigned c0 = w & 0xffffu, c1 = w >> 16;
+            s_hist[tid * WPT + i] = run | ((run + c0) << 16);
+            run += c0 + c1;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += BLOCK) {
+        const unsigned c = cell(i), sh = 16 * (c & 1u);
+        const unsigned pos = (atomicAdd(&s_hist[c >> 1], 1u << sh) >> sh) & 0xffffu;
+        s_perm[pos] = (unsigned short)i;
+    }
+    __syncthreads();
+
+    // ---- this thread's points: slot j of the wave is bucket 4 j + wave = sorted positions 128 (4 j + wave) + {lane, 64 + lane} -----------
+    fps_f2 px[NP], py[NP], pz[NP], md[NP];
+    unsigned pidx[NP];                                      // original indices of the pair, 16 bits each
+    float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};      // lane j: box of slot j
+    float bmax = -1.0f;                                     // lane j: largest running minimum of slot j (-1: no point)
+    int bidx = 0;                                           // lane j: original index of the point that holds it
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int p0 = 128 * (NW * j + wave) + lane, p1 = p0 + 64;
+        const bool v0 = p0 < n, v1 = p1 < n;
+        // padding slots read the last sorted point and their minimum is pinned at -1 below.  NOT a guarded load: with `v0 ? s_perm[p0] : 0` the
+        // -fno-slp-vectorize build (ROCm 7.2 hipcc, 42 SGPRs spilled to VGPR lanes around the masked loads) left every lane whose first point
+        // is padding disabled for the rest of the kernel -- its points were never selected and its share of the output never stored
+        // (tests/probe/fps_bucket_probe.hip reproduces it; the default flags and the 16 384-point case were fine)
+        const int i0 = (int)s_perm[min(p0, n - 1)], i1 = (int)s_perm[min(p1, n - 1)];
+        px[j] = fps_f2{x[3 * i0], x[3 * i1]}; py[j] = fps_f2{x[3 * i0 + 1], x[3 * i1 + 1]}; pz[j] = fps_f2{x[3 * i0 + 2], x[3 * i1 + 2]};
+        md[j] = fps_f2{v0 ? INFINITY : -1.0f, v1 ? INFINITY : -1.0f};
+        pidx[j] = (unsigned)i0 | ((unsigned)i1 << 16);
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int p0 = 128 * (NW * j + wave) + lane;
+        const bool v0 = p0 < n, v1 = p0 + 64 < n;
+        const float c[3][2] = {{px[j].x, px[j].y}, {py[j].x, py[j].y}, {pz[j].x, pz[j].y}};
+        for (int k = 0; k < 3; ++k) {
+            const float mn = -wave_max_f32(-fminf(v0 ? c[k][0] : INFINITY, v1 ? c[k][1] : INFINITY));
+            const float mx = wave_max_f32(fmaxf(v0 ? c[k][0] : -INFINITY, v1 ? c[k][1] : -INFINITY));
+            if (lane == j) { blo[k] = mn; bhi[k] = mx; }
+        }
+        const bool any_valid = __any(v0) != 0;              // (every lane takes part: the bucket's first half fills first)
+        if (lane == j && any_valid) bmax = INFINITY;
+    }
+
+    int cur = start;
+    float cx = x[3 * cur], cy = x[3 * cur + 1], cz = x[3 * cur + 2];
+    // the wave's best bucket, kept while no bucket of the wave changes
+    int wmd = __float_as_int(-1.0f), widx = 0x7fffffff;
+    float wx = 0.0f, wy = 0.0f, wz = 0.0f;
+    for (int s = 0; s < n_samples; ++s) {
+        if (lane == 0) s_out[wave][s & (BLOCK - 1)] = cur;
+#if defined(DEDF_FPS_STATS)
+        const long long tk0 = __builtin_readcyclecounter();
+#endif
+        // 1. which buckets of this wave can change
+        const float ddx = fmaxf(fmaxf(blo[0] - cx, cx - bhi[0]), 0.0f), ddy = fmaxf(fmaxf(blo[1] - cy, cy - bhi[1]), 0.0f),
+                    ddz = fmaxf(fmaxf(blo[2] - cz, cz - bhi[2]), 0.0f);
+        const float lb2 = ((ddx * ddx + ddy * ddy) + ddz * ddz) * (1.0f - 4e-6f);      // below every distance the update would compute
+        unsigned mask = (unsigned)__ballot(lane < NP && !(lb2 >= bmax));
+        // 2. active buckets
+#if defined(DEDF_FPS_STATS)
+        if (lane == 0) { atomicAdd(&g_fps_stats[0], (unsigned long long)__builtin_popcount(mask)); atomicAdd(&g_fps_stats[1], mask != 0u ? 1ull : 0ull); }
+        const long long tk05 = __builtin_readcyclecounter();
+        if (tid == 64) { atomicAdd(&g_fps_stats[7], (unsigned long long)(tk05 - tk0)); }
+#endif
+#if defined(DEDF_FPS_SKIP) && DEDF_FPS_SKIP >= 1
+        if (s > 0) mask = 0u;          // timing experiment (wrong results): no bucket updates after the first sample
+#endif
+        while (mask) {
+            const int ja = __builtin_ctz(mask);
+            mask &= mask - 1u;
+#if defined(DEDF_FPS_SKIP) && DEDF_FPS_SKIP == 3
+            fps_dispatch<1>(ja & 0, [&]<int J>() {      // timing experiment (wrong results): every active bucket runs slot 0's code
+#else
+            fps_dispatch<NP>(ja, [&]<int J>() {
+#endif
+                // (opaque copy of the sample: hipcc otherwise hoists the distance arithmetic of ALL slots out of the dispatch and computes it
+                // for every sample -- the exhaustive update again)
+                float ox = cx, oy = cy, oz = cz;
+                asm volatile("" : "+v"(ox), "+v"(oy), "+v"(oz));
+                const fps_f2 c_x = fps_f2{ox, ox}, c_y = fps_f2{oy, oy}, c_z = fps_f2{oz, oz};
+                const fps_f2 dx = px[J] - c_x, dy = py[J] - c_y, dz = pz[J] - c_z;
+                const fps_f2 d2 = (dx * dx + dy * dy) + dz * dz;
+                fps_f2 m = md[J];
+                m.x = fminf(m.x, d2.x); m.y = fminf(m.y, d2.y);
+                md[J] = m;
+                const int b0 = __float_as_int(m.x), b1 = __float_as_int(m.y);
+                const int i0 = (int)(pidx[J] & 0xffffu), i1 = (int)(pidx[J] >> 16);
+                // the lane's better point (larger minimum, then smaller original index) and its coordinates: independent of the reduction
+                const bool sel1 = b1 > b0 || (b1 == b0 && i1 < i0);
+                const int lb = sel1 ? b1 : b0, li = sel1 ? i1 : i0;
+                const float4 lc = float4{sel1 ? px[J].y : px[J].x, sel1 ? py[J].y : py[J].x, sel1 ? pz[J].y : pz[J].x, 0.0f};
+                const int wmi = wave_max_i32(lb);                                         // wave-uniform
+                const float wm = __int_as_float(wmi);
+                // (a taken branch costs a lone wave about as much as fifteen instructions: ties are resolved by a second reduction, always)
+                const int win = wave_min_i32_dpp(lb == wmi ? li : 0x7fffffff);
+                if (li == win && lb == wmi && wmi >= 0) s_cand[wave][J] = lc;
+                if (lane == J) { bmax = wm; bidx = win; }
+            });
+        }
+#if defined(DEDF_FPS_STATS)
+        const long long tk1 = __builtin_readcyclecounter();
+#endif
+        // 3. best bucket of the wave: largest minimum, ties to the smaller original index (recomputed every sample: cheaper than branching
+        //    around it, and a wave without work is not the one the others wait for)
+#if defined(DEDF_FPS_SKIP) && DEDF_FPS_SKIP >= 2
+        if (s == 0)
+#endif
+        {
+            const int kb = lane < NP ? __float_as_int(bmax) : -1;
+            const int best = wave_max_i32(kb);
+            const int bi = wave_min_i32_dpp(kb == best ? bidx : 0x7fffffff);
+            const int jb = __builtin_ctzll(__ballot(kb == best && bidx == bi));
+            wmd = best; widx = bi;
+            const float4 c = s_cand[wave][jb < NP ? jb : 0];
+            wx = c.x; wy = c.y; wz = c.z;
+        }
+        const int buf = s & 1;
+        if (lane == 0) { s_exch[buf][wave] = float4{__int_as_float(wmd), wx, wy, wz}; s_exch_idx[buf][wave] = widx; }
+#if defined(DEDF_FPS_STATS)
+        const long long tk2 = __builtin_readcyclecounter();
+#endif
+        __syncthreads();
+#if defined(DEDF_FPS_STATS)
+        const long long tk3 = __builtin_readcyclecounter();
+#endif
+        if (__builtin_expect((s & (BLOCK - 1)) == BLOCK - 1 || s == n_samples - 1, 0)) {
+            const int base = s & ~(BLOCK - 1);
+            if (base + tid <= s) idx_out[base + tid] = s_out[0][tid];
+        }
+        // all four slots are read before anything is compared (left to itself hipcc reads them one by one behind branches: four LDS
+        // round trips in a row), then a two-level knock-out without branches
+        static_assert(NW == 4, "the knock-out below is written for four waves");
+        float4 e[NW]; int ei[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { e[w] = s_exch[buf][w]; ei[w] = s_exch_idx[buf][w]; }
+        asm volatile("" : "+v"(e[0].x), "+v"(e[1].x), "+v"(e[2].x), "+v"(e[3].x), "+v"(ei[0]), "+v"(ei[1]), "+v"(ei[2]), "+v"(ei[3]));
+        auto better = [](const float4& a, int ai, const float4& b, int bi) {      // is b ahead of a
+            const int am = __float_as_int(a.x), bm = __float_as_int(b.x);
+            return bm > am || (bm == am && bi < ai);
+        };
+        const bool s01 = better(e[0], ei[0], e[1], ei[1]), s23 = better(e[2], ei[2], e[3], ei[3]);
+        const float4 a01 = float4{s01 ? e[1].x : e[0].x, s01 ? e[1].y : e[0].y, s01 ? e[1].z : e[0].z, s01 ? e[1].w : e[0].w};
+        const float4 a23 = float4{s23 ? e[3].x : e[2].x, s23 ? e[3].y : e[2].y, s23 ? e[3].z : e[2].z, s23 ? e[3].w : e[2].w};
+        const int i01 = s01 ? ei[1] : ei[0], i23 = s23 ? ei[3] : ei[2];
+        const bool sf = better(a01, i01, a23, i23);
+        cur = sf ? i23 : i01;
+        cx = sf ? a23.y : a01.y; cy = sf ? a23.z : a01.z; cz = sf ? a23.w : a01.w;
+#if defined(DEDF_FPS_STATS)
+        if (tid == 64) {      // wave 1
+            const long long tk4 = __builtin_readcyclecounter();
+            atomicAdd(&g_fps_stats[3], (unsigned long long)(tk1 - tk0)); atomicAdd(&g_fps_stats[4], (unsigned long long)(tk2 - tk1));
+            atomicAdd(&g_fps_stats[5], (unsigned long long)(tk3 - tk2)); atomicAdd(&g_fps_stats[6], (unsigned long long)(tk4 - tk3));
+        }
+#endif
+    }
+}
+
 // Radius search, one WAVE per destination point: the 64 lanes test 64 consecutive sources per step, a ballot counts them and
 // orders the hits (ascending source index for free); at most `cap` neighbours per destination (the first ones).
 // FILL = false: cnt[d];  FILL = true: edges at off[d] (exclusive scan of cnt).

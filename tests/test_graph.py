@@ -62,6 +62,47 @@ def test_fps_bit_exact(n, ratio):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["grid_ties", "duplicates", "n1025", "n4097", "n8192", "n12000_padding", "n16383", "line", "start_mid"])
+def test_fps_bucketed_kernel_bit_exact(case):
+    """the bucketed kernel (Morton buckets skipped when the sample cannot lower any of their minima, dedf_graph.h::k_fps_bucketed; default
+    above 8 192 points, here forced from 1 025 points on in a subprocess so that every register layout -- 16 / 32 / 64 points per thread --
+    runs): identical to the exhaustive arg-max of the oracle, exact ties (grid, duplicated points), padding in the last bucket, degenerate
+    extents, a start point in the middle"""
+    import os, subprocess, sys
+    if os.environ.get("DEDF_FPS_BUCKETED") != "2":
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", f"{os.path.abspath(__file__)}::test_fps_bucketed_kernel_bit_exact[{case}]"],
+                           cwd=root, env=dict(os.environ, DEDF_FPS_BUCKETED="2"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        return
+    from diffusion_edf_amd import connectivity as K
+    from diffusion_edf_amd import _lib
+    rng = np.random.default_rng(5)
+    ratio, start = 0.2, 0
+    if case == "grid_ties":
+        x = np.stack(np.meshgrid(np.arange(16.), np.arange(16.), np.arange(8.), indexing="ij"), -1).reshape(-1, 3).astype(np.float32); ratio = 0.5
+    elif case == "duplicates":
+        base = _cloud(700, 3)
+        x = base[rng.integers(0, 700, 5000)]; ratio = 0.3           # every point several times: ties at 0 and between copies
+    elif case == "line":
+        x = np.zeros((3000, 3), np.float32); x[:, 1] = rng.permutation(3000).astype(np.float32) * 0.25      # zero extent in two axes
+    elif case == "start_mid":
+        x = _cloud(6000, 9); start = 4321
+    else:
+        n = int(case[1:].split("_")[0])
+        x = _cloud(n, n)
+    ref = G.fps(x, ratio, start=start)
+    if start == 0:
+        got = K.fps(torch.from_numpy(x).cuda(), None, ratio=ratio, random_start=False).cpu().numpy()
+    else:
+        lib = _lib.load()
+        xd = torch.from_numpy(x).cuda(); out = torch.empty(len(ref), dtype=torch.int32, device="cuda")
+        assert lib.dedf_fps(xd.data_ptr(), len(x), len(ref), start, out.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+        got = out.cpu().numpy().astype(np.int64)
+    assert np.array_equal(got, ref), (case, int(np.argmax(got != ref)))
+
+
+@pytest.mark.gpu
 def test_fps_ties_and_limits():
     from diffusion_edf_amd import connectivity as K
     grid = np.stack(np.meshgrid(np.arange(12.), np.arange(12.), np.arange(3.), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)   # many exact ties
