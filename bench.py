@@ -312,6 +312,22 @@ def main():
     if rank == 0 and world == 1 and args.lmax in (2, 3) and not args.no_extractors:
         extract = extractor_times(args.scene, args.grasp, device, lmax=args.lmax)
 
+    # outside the timed region as well: the deployment regime of the reference (N_samples = 10 / 20 poses per call, evaluate_real_mug.ipynb:188-190)
+    # -- the same scene, the first 16 / 64 / 256 of the seeded poses, 50 steps of the same schedule; latency-bound (one round of edge tiles)
+    small = None
+    if rank == 0 and world == 1 and not args.half:
+        small = {}
+        for n_small in (16, 64, 256):
+            if n_small >= args.poses_per_gpu:
+                continue
+            run(Ts[:n_small], 5, 0)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            run(Ts[:n_small], 50, 0)
+            torch.cuda.synchronize()
+            dt_s = time.perf_counter() - ts
+            small[f"{n_small} poses"] = {"ms_per_step": dt_s / 50 * 1e3, "pose_steps_per_s": n_small * 50 / dt_s}
+
     if rank == 0:
         n_ev = max(1, prof["n_evals"])
         edge_ms = prof["ms"]["edge"] / n_ev
@@ -324,7 +340,8 @@ def main():
         wname = "C2" if default_workload else ("C1" if (args.lmax, args.scene, args.grasp) == (1, 2048, 512) else
                                                 ("C2 inputs at lmax 3 (the degree BASELINE config 5 names)" if (args.lmax, args.scene, args.grasp) == (3, 4096, 1024) else "custom"))
         traffic, traffic_src, mfma_issued = None, None, None
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json")), key=os.path.getmtime) if default_workload else []:
+        # (files are named per round, r01i < r02h < r03i ...: the last one in name order that holds the HBM passes of the headline kernel wins)
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9][a-z]_pmc_summary.json"))) if default_workload else []:
             try:
                 doc = json.load(open(f))
                 v = doc.get("edge_kernel_hbm_bytes_per_launch")
@@ -354,7 +371,7 @@ def main():
                                    f"{len(query.x)} query pts, lmax={args.lmax}, {args.poses_per_gpu} poses per GPU, t 1->0.15 log-spaced, dt 0.04",
                        "poses_total": n_total, "parallelism": f"pose-parallel dp{world}, one RCCL all-gather at the end",
                        "edges_per_step_rank0": e_per_launch, "full_trajectories_per_s_at_50_steps": n_total * args.steps / el / 50.0,
-                       "score_fwd_ms_at_t0.5": fixed, "feature_extractors_ms": extract},
+                       "score_fwd_ms_at_t0.5": fixed, "feature_extractors_ms": extract, "small_batches_50_steps": small},
             "roofline": {"kernel": "k_edge (fused per-edge pipeline)", "bound": "valu-issue", "achieved": achieved_exec, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved_exec / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "frac_definition": f"EXECUTED FLOP: 2 x {m_exec} MAC per edge" + (f" ({M_EDGE[args.lmax]} algorithmic - 40 960 that the sampler's radial table evaluates per grid node)" if table_on else "") + " x edges of the launch / its HIP-event duration / peak",
