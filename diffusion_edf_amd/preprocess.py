@@ -40,9 +40,15 @@ def rescale(obj, rescale_factor: float):
 def crop_bbox(obj, bbox: Sequence[Sequence[float]], targets: Optional[Sequence[str]] = None, role: Optional[str] = None):
     """keep the points inside ``[[x0,x1],[y0,y1],[z0,z1]]``.  ``targets`` names the inputs the crop applies to (the sapien task
     files crop ``['scene_pcd']`` only); ``role`` is what the caller says the object is (``'scene_pcd'``, ``'grasp_pcd'``,
-    ``'poses'``) -- with ``targets`` given and a role outside it, the object passes through; without a role the crop applies."""
-    if not isinstance(obj, FeaturedPoints) or (targets is not None and role is not None and role not in targets):
+    ``'poses'``) -- with ``targets`` given and a role outside it, the object passes through.  With ``targets`` given and NO role the call is
+    ambiguous (a grasp cloud cropped to the scene's box comes back empty): it raises instead of guessing."""
+    if not isinstance(obj, FeaturedPoints):
         return obj
+    if targets is not None:
+        if role is None:
+            raise ValueError(f"crop_bbox: this proc applies to {list(targets)} only -- pass role='scene_pcd' | 'grasp_pcd' (DiffusionEdfAgent.sample does)")
+        if role not in targets:
+            return obj
     lo = torch.tensor([b[0] for b in bbox], dtype=obj.x.dtype, device=obj.x.device)
     hi = torch.tensor([b[1] for b in bbox], dtype=obj.x.dtype, device=obj.x.device)
     keep = ((obj.x >= lo) & (obj.x <= hi)).all(dim=-1)

@@ -219,6 +219,11 @@ def test_preprocess_procs_of_the_shipped_yaml():
     assert torch.allclose(centre.x, torch.tensor([[-0.005, 0.005, 0.005], [0.005, 0.005, 0.005], [0.015, 0.005, 0.005]]))
     crop = PP.crop_bbox(pcd, bbox=[[0.0, 0.02], [0.0, 0.01], [0.0, 0.01]])
     assert len(crop.x) == 4
+    # a crop that names its targets (the sapien task files: ['scene_pcd']) refuses to guess what an unlabelled cloud is
+    box = dict(bbox=[[0.0, 0.02], [0.0, 0.01], [0.0, 0.01]], targets=["scene_pcd"])
+    assert len(PP.crop_bbox(pcd, role="scene_pcd", **box).x) == 4 and len(PP.crop_bbox(pcd, role="grasp_pcd", **box).x) == len(pcd.x)
+    with pytest.raises(ValueError):
+        PP.crop_bbox(pcd, **box)
     # two clouds in one batch vector are downsampled separately
     two = FeaturedPoints(x=torch.cat([x, x]), f=torch.cat([f, f]), b=torch.tensor([0] * 5 + [1] * 5))
     assert torch.equal(PP.downsample(two, 0.01).b, torch.tensor([0, 0, 0, 1, 1, 1]))
