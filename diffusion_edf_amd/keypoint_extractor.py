@@ -121,9 +121,10 @@ class MultiscaleTensorField(torch.nn.Module):
         self._handle, self._handle_device = h, device
 
     @torch.no_grad()
-    def forward(self, query_points: FeaturedPoints, input_points_multiscale: Sequence[FeaturedPoints], context_emb=None,
-                max_neighbors: int = 1000) -> FeaturedPoints:
-        assert len(input_points_multiscale) == self.n_scales and context_emb is None
+    def field_and_emb(self, query_points: FeaturedPoints, input_points_multiscale: Sequence[FeaturedPoints], max_neighbors: int = 1000):
+        """the block's output and its ``emb`` (kernel-side ``dedf_field``), without the ``64x0e`` post-processing of ``forward``: what
+        ``KeypointExtractor`` hands to ``dedf_keypoint_weight`` (which forms ``FFN + skip_2(emb)`` itself)"""
+        assert len(input_points_multiscale) == self.n_scales
         assert query_points.x.ndim == 2 and query_points.x.shape[-1] == 3
         if max_neighbors != self.cfg.max_neighbors:
             raise NotImplementedError("max_neighbors is fixed at 1000 (every call site of the reference)")
@@ -145,6 +146,17 @@ class MultiscaleTensorField(torch.nn.Module):
             emb = torch.empty_like(field)
             rc = lib.dedf_field(self._handle, len(xq), xq.data_ptr(), field.data_ptr(), emb.data_ptr(), stream)
             _lib.raise_for(lib, self._handle, rc, "dedf_field")
+        return field, emb
+
+    @torch.no_grad()
+    def forward(self, query_points: FeaturedPoints, input_points_multiscale: Sequence[FeaturedPoints], context_emb=None,
+                max_neighbors: int = 1000) -> FeaturedPoints:
+        assert context_emb is None
+        field, emb = self.field_and_emb(query_points, input_points_multiscale, max_neighbors)
+        dev = query_points.x.device
+        lib = _lib.load()
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):
             if self.scalar_out:                       # FFN output + skip_2(emb), skip_2 = LinearRS(emb -> 64x0e, bias) on the HIP per-node linear
                 sd = self.state_dict()
                 muls = self.cfg.muls
@@ -159,7 +171,6 @@ class MultiscaleTensorField(torch.nn.Module):
                 if rc != _lib.OK:
                     raise RuntimeError(f"dedf_linear_rs failed ({rc})")
                 f_out = field[:, :64] - emb[:, :64] + skip[:, :64]
-                self.last_field, self.last_emb = field, emb
             else:
                 f_out = field
         return FeaturedPoints(x=query_points.x, f=f_out.to(query_points.x.dtype), b=query_points.b, w=query_points.w)
@@ -269,7 +280,7 @@ class KeypointExtractor(torch.nn.Module):
         query_points = self.get_query_points(input_points)
         out = self.tensor_field(query_points=query_points, input_points_multiscale=multiscale, context_emb=None, max_neighbors=max_neighbors)
         wf = self.weight_field
-        wf(query_points=query_points, input_points_multiscale=multiscale, context_emb=None, max_neighbors=max_neighbors)
+        w_field, w_emb = wf.field_and_emb(query_points, multiscale, max_neighbors)      # (not wf.forward: the weight head below forms FFN + skip_2(emb) itself)
         dev = query_points.x.device
         sd = {k: v.detach().float().to(dev).contiguous() for k, v in wf.state_dict().items() if k.startswith("gnn_block_init.skip_2.")}
         ln, lin = self.weight_post[0], self.weight_post[2]
@@ -280,7 +291,7 @@ class KeypointExtractor(torch.nn.Module):
         weights = torch.empty(n, device=dev, dtype=torch.float32)
         lib = _lib.load()
         with torch.cuda.device(dev):
-            rc = lib.dedf_keypoint_weight(wf.last_field.data_ptr(), wf.last_emb.data_ptr(), n, wf.dim,
+            rc = lib.dedf_keypoint_weight(w_field.data_ptr(), w_emb.data_ptr(), n, wf.dim,
                                           sd["gnn_block_init.skip_2.skip.tp.weight"].data_ptr(), sd["gnn_block_init.skip_2.skip.bias.0"].data_ptr(),
                                           ln_w.data_ptr(), ln_b.data_ptr(), lin_w.data_ptr(), float(lin.bias), int(self.weight_sigmoid), mult,
                                           weights.data_ptr(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))

@@ -109,6 +109,7 @@ def test_fps_ties_and_limits():
     assert np.array_equal(K.fps(torch.from_numpy(grid).cuda(), None, ratio=0.5, random_start=False).cpu().numpy(), G.fps(grid, 0.5))
     z = torch.zeros(5, 3, device="cuda")
     assert K.fps(z, None, ratio=1.0, random_start=False).tolist() == [0, 0, 0, 0, 0]
+    assert K.fps(torch.zeros(9000, 3, device="cuda"), None, ratio=0.01, random_start=False).tolist() == [0] * 90      # (bucketed kernel: zero extent in every axis)
     with pytest.raises(NotImplementedError):
         K.fps(torch.zeros(70000, 3, device="cuda"), None, ratio=0.001, random_start=False)
     with pytest.raises(RuntimeError):
