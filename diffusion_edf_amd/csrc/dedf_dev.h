@@ -220,6 +220,27 @@ DEDF_DEV HL split8(const float (&x)[8]) {
     return r;
 }
 
+// Four values -> one 16-byte word {hi(0,1), hi(2,3), lo(0,1), lo(2,3)}: the packed form of a parked chunk whose other four registers are
+// structural zeros (the 8x3e block inside its 16-channel chunk, dedf_edge.h::park_chunk).  Same halves as split8 gives for these values.
+DEDF_DEV f32x4 split4pk(const float (&x)[4]) {
+#if defined(__HIP_DEVICE_COMPILE__) && DEDF_SPLIT_MIX
+    unsigned hp[2], lp[2];
+#define DEDF_SPLIT_PAIR(Q)                                                                          \
+    asm volatile("v_cvt_pk_f16_f32 %0, %2, %3\n\t"                                                   \
+                 "v_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"             \
+                 "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"                 \
+                 : "=&v"(hp[Q]), "=&v"(lp[Q]) : "v"(x[2 * Q]), "v"(x[2 * Q + 1]))
+    DEDF_SPLIT_PAIR(0); DEDF_SPLIT_PAIR(1);
+#undef DEDF_SPLIT_PAIR
+    return __builtin_bit_cast(f32x4, u32x4{hp[0], hp[1], lp[0], lp[1]});
+#else
+    const float y[8] = {x[0], x[1], 0.0f, 0.0f, x[2], x[3], 0.0f, 0.0f};
+    const HL sp = split8(y);
+    const u32x4 h = __builtin_bit_cast(u32x4, sp.hi), l = __builtin_bit_cast(u32x4, sp.lo);
+    return __builtin_bit_cast(f32x4, u32x4{h[0], h[2], l[0], l[2]});
+#endif
+}
+
 // A finished accumulator tile that the VALU reads next: pin it to architectural VGPRs here, so that the MFMAs write it there
 // directly instead of into AGPRs followed by 16 v_accvgpr_read copies.
 DEDF_DEV void to_vgpr(f32x16& t) {

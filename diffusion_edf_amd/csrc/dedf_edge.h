@@ -90,12 +90,15 @@ template <int L> struct SH {           // spherical harmonics of one edge, non-s
 // row tiles x 4 KiB = 29 % of the kernel's L1 delivery for 5.5 KiB of data.  Each wave copies them once into its own LDS
 // (k_edge prologue) and reads them back with broadcast ds_read_b128.  Offsets in floats, layout [tile][half][16] as packed.
 // FRONT = false: the rows of the radial network's FRONT (layers 1-2: biases, LayerNorm affine; the length-encoder constants) stay in global
-// memory.  The table-reading kernel at lmax 3 does that: its tiles need them only when they fall back to the per-edge front, and the 3.8 KB
-// are what decides between two and three waves per CU there (46 KB of parked operands per wave).
-template <int L, int MODE> constexpr bool front_rows_in_lds() { return !(L == 3 && MODE == 1); }
+// memory; big_rows_in_lds = false: so do the layer-3 offsets (3.5 KB at lmax 3) and the lin / sep_alpha biases.  The lmax-3 kernels do both:
+// with the parked operands at 39 KB per wave (dedf_net.h::park_phys) only val0 / alpha_dot (512 B) fit beside them if FOUR waves are to share
+// a CU's 160 KB -- with the rows in LDS it was three, i.e. one SIMD of every CU idle.
+template <int L, int MODE> constexpr bool front_rows_in_lds() { return L < 3; }
+template <int L> constexpr bool big_rows_in_lds() { return L < 3; }
 template <int L, bool FRONT = true> struct RowsLds {
+    static constexpr bool BIG = big_rows_in_lds<L>();
     static constexpr int b1 = 0, g1 = 128, be1 = 256, b2 = 384, g2 = 448, be2 = 512, off3 = FRONT ? 576 : 0;
-    static constexpr int b0 = off3 + rup(dtp_wn<L>(), 32), val0 = b0 + r0_tiles<L>() * 32, adot = val0 + 64;
+    static constexpr int b0 = off3 + (BIG ? rup(dtp_wn<L>(), 32) : 0), val0 = b0 + (BIG ? r0_tiles<L>() * 32 : 0), adot = val0 + 64;
     static constexpr int enc = adot + 64, total = enc + (FRONT ? 192 : 0);      // enc: length-encoder constants of the scale being processed
 };
 template <int L, bool FRONT = true> DEDF_DEV float* rows_lds() {
@@ -246,7 +249,7 @@ DEDF_DEV void edge_rows_to_lds(const EdgeParams& P, const Wave& wv) {
         cp(RL::b1, P.o_b_r1, H1); cp(RL::g1, P.o_g_r1, H1); cp(RL::be1, P.o_be_r1, H1);
         cp(RL::b2, P.o_b_r2, H2); cp(RL::g2, P.o_g_r2, H2); cp(RL::be2, P.o_be_r2, H2);
     }
-    cp(RL::off3, P.o_off_r3, rup(dtp_wn<L>(), 32)); cp(RL::b0, P.o_b_r0, r0_tiles<L>() * 32);
+    if constexpr (RL::BIG) { cp(RL::off3, P.o_off_r3, rup(dtp_wn<L>(), 32)); cp(RL::b0, P.o_b_r0, r0_tiles<L>() * 32); }
     cp(RL::val0, P.o_b_val0, 64); cp(RL::adot, P.o_alpha_dot, 64);
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -378,7 +381,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         static_assert(L <= 3, "spherical harmonics up to l = 3");
     }
 
-    constexpr int NPS = park_slots<L>(), SPW = 2 * NPS, NSLOT = SPW + 2;      // SPW: segment softmax weights / normalisers
+    constexpr int SPW = park_phys_slots<L>(), NSLOT = SPW + 2;      // SPW: segment softmax weights / normalisers
     __shared__ f32x4 park[NSLOT * 64];         // (declared here: the table path stages its rows in it before the parking starts)
     f32x16 r2[NT2];
     f32x4 trow[MODE == 1 ? 4 : 1][8];      // MODE 1: this lane's halves of the four table rows around its length (16 * NT2 floats of the 32 are used:
@@ -550,9 +553,14 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // chunk q = dedf_net.h::park_slot(degree, component, chunk) -> slots 2q | 2q + 1), lane-private
     f32x4* const pk = park + wv.lane;
     auto park_chunk = [&]<int Q>(const float (&v)[8]) {
-        const HL sp = split8(v);
-        pk[(2 * Q) * 64] = __builtin_bit_cast(f32x4, sp.hi);
-        if constexpr (!HP) pk[(2 * Q + 1) * 64] = __builtin_bit_cast(f32x4, sp.lo);
+        if constexpr (park_packed<L>(Q)) {      // registers 2, 3, 6, 7 are the zero padding of 8x3e: hi and lo of the other four in one slot
+            const float v4[4] = {v[0], v[1], v[4], v[5]};
+            pk[park_phys<L>(Q) * 64] = split4pk(v4);
+        } else {
+            const HL sp = split8(v);
+            pk[park_phys<L>(Q) * 64] = __builtin_bit_cast(f32x4, sp.hi);
+            if constexpr (!HP) pk[(park_phys<L>(Q) + 1) * 64] = __builtin_bit_cast(f32x4, sp.lo);
+        }
     };
 
     // Software pipeline over the WN/16 chunks (16 weight rows = half a weight tile).  Region C issues, in one scheduling
@@ -639,7 +647,12 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         });
         return o;
     };
-    auto load_off = [&]<int T>() { f32x16 o{}; if constexpr (T < NWT) o = ldrows_lds(rows, hi, RL::off3, T); return o; };
+    const int o_off_r3 = opaque_s(P.o_off_r3);
+    auto load_off = [&]<int T>() {
+        f32x16 o{};
+        if constexpr (T < NWT) { if constexpr (RL::BIG) o = ldrows_lds(rows, hi, RL::off3, T); else o = ldrows(wv, o_off_r3, T); }
+        return o;
+    };
     auto run_l3 = [&]<int Ph>(const L3Half& a, const f32x16& init, f32x16& w) {
         if constexpr (Ph < 2 * NWT) {
             constexpr int c0 = KC == 4 ? 2 * (Ph % 2) : 0;
@@ -801,7 +814,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             static_for<8>([&]<int J>() { t[J] = r2[c / 2][8 * (c % 2) + J]; });
             r2s[c] = split8(t);
         });
-        static_for<NR0>([&]<int T>() { acc0[T] = ldrows_lds(rows, hi, RL::b0, T); });      // accumulator init: lin / sep_alpha biases
+        static_for<NR0>([&]<int T>() {      // accumulator init: lin / sep_alpha biases
+            if constexpr (RL::BIG) acc0[T] = ldrows_lds(rows, hi, RL::b0, T); else acc0[T] = ldrows(wv, P.o_b_r0, T);
+        });
         sched_fence();
         l3n = load_l3.template operator()<3>();
         offn = load_off.template operator()<2>();
@@ -1038,8 +1053,14 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             constexpr VItem it = val_item<L>(I);
             const f32x4* const pkt = park + lane_t;
             static_for<it.na>([&]<int a>() {
-                o.h[a] = pkt[(2 * it.bq[a]) * 64];
-                if constexpr (!HP) o.l[a] = pkt[(2 * it.bq[a] + 1) * 64];
+                if constexpr (park_packed<L>(it.bq[a])) {      // one slot: {hi(0,1), hi(4,5), lo(0,1), lo(4,5)}, the other registers are zeros
+                    const f32x4 s = pkt[park_phys<L>(it.bq[a]) * 64];
+                    o.h[a] = f32x4{s[0], 0.0f, s[1], 0.0f};
+                    if constexpr (!HP) o.l[a] = f32x4{s[2], 0.0f, s[3], 0.0f};
+                } else {
+                    o.h[a] = pkt[park_phys<L>(it.bq[a]) * 64];
+                    if constexpr (!HP) o.l[a] = pkt[(park_phys<L>(it.bq[a]) + 1) * 64];
+                }
             });
         }
         return o;

@@ -204,6 +204,16 @@ template <int L> DEDF_HD constexpr int park_slot(int l, int i, int c) {
     return q + i * (mul_of(l) / 16) + c;
 }
 template <int L> DEDF_HD constexpr int park_slots() { return park_slot<L>(L + 1, 0, 0); }          // 15 (L = 2), 10 (L = 1)
+// LDS slots (16 bytes per lane) of parked chunk q: the hi halves in slot park_phys(q), the residuals in the next one -- except the l = 3
+// chunks at lmax 3: four of a lane's eight registers are the zero padding of 8x3e (pad_pos puts a head's two true channels first in its group
+// of four: registers 0, 1, 4, 5 of either half-wave), so hi and lo of the four real ones share ONE slot (dedf_dev.h::split4pk).  7 KB less per
+// wave, which is part of what lets four lmax-3 waves share a CU's 160 KB.
+template <int L> DEDF_HD constexpr bool park_packed(int q) { return L == 3 && q >= park_slot<L>(3, 0, 0); }
+template <int L> DEDF_HD constexpr int park_phys(int q) {
+    if (L == 3 && q >= park_slot<L>(3, 0, 0)) return 2 * park_slot<L>(3, 0, 0) + (q - park_slot<L>(3, 0, 0));
+    return 2 * q;
+}
+template <int L> DEDF_HD constexpr int park_phys_slots() { return park_phys<L>(park_slots<L>()); }      // 30 (L = 2), 20 (L = 1), 37 (L = 3)
 // Work item of the value GEMMs: up to three independent accumulator tiles (consecutive MFMAs never hit the same one):
 //   l1 = 0 : one component, two K-chunks at a time (partial sums, merged before the contraction)
 //   l1 = 1 : the three components of one K-chunk          l1 = 2 : components {0,1,2}, then {3,4}, of the only K-chunk
