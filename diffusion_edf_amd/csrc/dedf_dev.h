@@ -133,6 +133,7 @@ struct Wave {            // per-lane constants of the transposed-GEMM layout
     int hi64;            // byte offset of this lane's half inside a row-packed tile (2 x 16 floats)
     int lane16_r16;      // lane16 for lanes that hold rows 0-15 of a tile, out of range for the others: operands whose rows 16-31
                          // are padding are then fetched by half the lanes only (an out-of-range buffer load returns 0 without a fetch)
+    int lane16_r16up;    // the same 16 rows placed as rows 16-31 of the tile: lanes of rows 16-31 fetch what the lane 16 below them would
     Buf w;               // all packed weights / row vectors of the launch
 };
 DEDF_DEV Wave make_wave(const void* wbuf, uint32_t wbytes) {
@@ -140,6 +141,7 @@ DEDF_DEV Wave make_wave(const void* wbuf, uint32_t wbytes) {
     wv.lane = lane_id(); wv.col = wv.lane & 31; wv.hi = wv.lane >> 5;
     wv.lane16 = wv.lane * 16; wv.hi64 = wv.hi * 64;
     wv.lane16_r16 = wv.col < 16 ? wv.lane16 : 0x7ffffff0;
+    wv.lane16_r16up = wv.col >= 16 ? wv.lane16 - 256 : 0x7ffffff0;
     wv.w = make_buf(wbuf, wbytes);
     return wv;
 }

@@ -178,6 +178,10 @@ DEDF_DEV AItem load_item(const Wave& wv, int o_str) {
             const int lv = half_rows ? wv.lane16_r16 : wv.lane16;
             a.h[n] = bld4(wv.w, lv, (o_str + (it.slot + n) * 512) * 4);
             if constexpr (!HP) a.l[n] = bld4(wv.w, lv, (o_str + (it.slot + n) * 512 + 256) * 4);
+            if constexpr (acc_paired<L>(l3) && !dtp_pos_out<L>(it.pos)) {      // the same 16 rows once more, as rows 16-31 of the tile (odd components)
+                a.h[1] = bld4(wv.w, wv.lane16_r16up, (o_str + it.slot * 512) * 4);
+                if constexpr (!HP) a.l[1] = bld4(wv.w, wv.lane16_r16up, (o_str + it.slot * 512 + 256) * 4);
+            }
         });
     }
     return a;
@@ -225,10 +229,26 @@ DEDF_DEV void mfma_chunk(const Wave& wv, int o_str, AItem (&ring)[PD], const BOp
             constexpr int d3 = 2 * l3 + 1;
             auto& accm = [&]() -> auto& { if constexpr (l3 == 1) return acc1; else if constexpr (l3 == 2) return acc2; else return acc3; }();
             const h8 ah = __builtin_bit_cast(h8, a.h[0]), al = __builtin_bit_cast(h8, a.l[0]);
+            if constexpr (acc_paired<L>(l3)) {
+                // Two components per accumulator tile: a 16-channel output block fills rows 0-15 only, so component 2 k goes to rows 0-15 of
+                // tile k (A = [W; 0]) and component 2 k + 1 to rows 16-31 (A = [0; W]: the same operand bytes requested by the other half
+                // of the lanes).  Same MFMAs, (d3 + 1) / 2 instead of d3 live accumulator tiles.  Even components first: consecutive MFMAs
+                // hit different tiles.
+                const h8 bh = __builtin_bit_cast(h8, a.h[1]), bl = __builtin_bit_cast(h8, a.l[1]);
+                static_for<d3>([&]<int K>() { if constexpr (K % 2 == 0) accm[K / 2] = mfma_h(ah, bo.hi[K], accm[K / 2]); });
+                static_for<d3>([&]<int K>() { if constexpr (K % 2 == 1) accm[K / 2] = mfma_h(bh, bo.hi[K], accm[K / 2]); });
+                if constexpr (!HP) {
+                    static_for<d3>([&]<int K>() { if constexpr (K % 2 == 0) accm[K / 2] = mfma_h(ah, bo.lo[K], accm[K / 2]); });
+                    static_for<d3>([&]<int K>() { if constexpr (K % 2 == 1) accm[K / 2] = mfma_h(bh, bo.lo[K], accm[K / 2]); });
+                    static_for<d3>([&]<int K>() { if constexpr (K % 2 == 0) accm[K / 2] = mfma_h(al, bo.hi[K], accm[K / 2]); });
+                    static_for<d3>([&]<int K>() { if constexpr (K % 2 == 1) accm[K / 2] = mfma_h(bl, bo.hi[K], accm[K / 2]); });
+                }
+            } else {
             static_for<d3>([&]<int K>() { accm[K] = mfma_h(ah, bo.hi[K], accm[K]); });
             if constexpr (!HP) {
                 static_for<d3>([&]<int K>() { accm[K] = mfma_h(ah, bo.lo[K], accm[K]); });
                 static_for<d3>([&]<int K>() { accm[K] = mfma_h(al, bo.hi[K], accm[K]); });
+            }
             }
         }
     });
@@ -767,7 +787,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             static_for<5>([&]<int K>() {      // 16 channels = registers 0-7
                 float v[8];
                 static_for<8>([&]<int J>() {
-                    if constexpr (dtp_group_has_out<L>(2)) v[J] = (acc2[K][J] + vacc2[K][J]) * g2[J]; else v[J] = acc2[K][J] * g2[J];
+                    constexpr int T = acc_paired<L>(2) ? K / 2 : K, R = acc_paired<L>(2) ? 8 * (K % 2) + J : J;      // (paired: see mfma_chunk)
+                    if constexpr (dtp_group_has_out<L>(2)) v[J] = (acc2[T][R] + vacc2[K][J]) * g2[J]; else v[J] = acc2[T][R] * g2[J];
                 });
                 park_chunk.template operator()<park_slot<L>(2, K, 0)>(v);
             });
@@ -775,7 +796,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             static_for<7>([&]<int K>() {      // 16 channels (8 of them the zero padding of 8x3e) = registers 0-7
                 float v[8];
                 static_for<8>([&]<int J>() {
-                    if constexpr (dtp_group_has_out<L>(3)) v[J] = (acc3[K][J] + vacc3[K][J]) * g3[J]; else v[J] = acc3[K][J] * g3[J];
+                    constexpr int T = acc_paired<L>(3) ? K / 2 : K, R = acc_paired<L>(3) ? 8 * (K % 2) + J : J;
+                    if constexpr (dtp_group_has_out<L>(3)) v[J] = (acc3[T][R] + vacc3[K][J]) * g3[J]; else v[J] = acc3[T][R] * g3[J];
                 });
                 park_chunk.template operator()<park_slot<L>(3, K, 0)>(v);
             });
@@ -783,8 +805,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     };
     auto start_group = [&]<int l3>() {
         if constexpr (l3 == 1) static_for<3>([&]<int K>() { static_for<16>([&]<int R>() { acc1[K][R] = 0.0f; }); });
-        if constexpr (l3 == 2) static_for<5>([&]<int K>() { static_for<16>([&]<int R>() { acc2[K][R] = 0.0f; }); });
-        if constexpr (l3 == 3) static_for<7>([&]<int K>() { static_for<16>([&]<int R>() { acc3[K][R] = 0.0f; }); });
+        if constexpr (l3 == 2) static_for<acc_paired<L>(2) ? 3 : 5>([&]<int K>() { static_for<16>([&]<int R>() { acc2[K][R] = 0.0f; }); });
+        if constexpr (l3 == 3) static_for<acc_paired<L>(3) ? 4 : 7>([&]<int K>() { static_for<16>([&]<int R>() { acc3[K][R] = 0.0f; }); });
     };
 
     DEDF_STAMP(6);
