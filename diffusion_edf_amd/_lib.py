@@ -19,7 +19,7 @@ SYMBOLS = [
     "dedf_version", "dedf_param_count", "dedf_param_name", "dedf_param_numel", "dedf_create", "dedf_destroy",
     "dedf_last_error", "dedf_set_key_clouds", "dedf_set_key_weights", "dedf_set_query", "dedf_score", "dedf_energy", "dedf_sample", "dedf_get_stats",
     "dedf_debug_enable", "dedf_debug_copy", "dedf_debug_packed", "dedf_profile_enable", "dedf_profile_read",
-    "dedf_fps", "dedf_radius", "dedf_radius_scratch_bytes", "dedf_layer_forward", "dedf_linear_rs", "dedf_field", "dedf_keypoint_weight", "dedf_layer_defer_check", "dedf_layer_check", "dedf_set_radial_table", "dedf_linear_rs_lmax",
+    "dedf_fps", "dedf_radius", "dedf_radius_scratch_bytes", "dedf_layer_forward", "dedf_linear_rs", "dedf_field", "dedf_keypoint_weight", "dedf_layer_defer_check", "dedf_layer_check", "dedf_layer_share_workspace", "dedf_set_radial_table", "dedf_linear_rs_lmax",
 ]
 
 
@@ -97,6 +97,7 @@ def load() -> C.CDLL:
     lib.dedf_set_radial_table.argtypes = [C.c_void_p, C.c_int]; lib.dedf_set_radial_table.restype = C.c_int
     lib.dedf_layer_defer_check.argtypes = [C.c_void_p, C.c_int]; lib.dedf_layer_defer_check.restype = C.c_int
     lib.dedf_layer_check.argtypes = [C.c_void_p, C.c_void_p]; lib.dedf_layer_check.restype = C.c_int
+    lib.dedf_layer_share_workspace.argtypes = [C.c_void_p, C.c_void_p]; lib.dedf_layer_share_workspace.restype = C.c_int
     lib.dedf_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]; lib.dedf_field.restype = C.c_int
     lib.dedf_keypoint_weight.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_float, C.c_int, C.c_float, C.c_void_p, C.c_void_p]

@@ -94,6 +94,8 @@ struct dedf_handle {
     bool small_batch_path = true;     // N_d <= 8 192: word-parallel neighbour masks + fused pose preparation (DEDF_SMALL_BATCH=0 turns it off: A/B, tests)
     bool defer_check = false;         // dedf_layer_defer_check
     DevBuf d_sticky;
+    dedf_handle* ws_owner = nullptr;  // dedf_layer_share_workspace: the UNet-layer handle whose per-call workspace (messages, edge lists, segment
+                                      // records, aggregate, flags) this layer uses instead of its own
     bool want_field = false;          // dedf_field: the node kernel also writes the field / emb of every node
     DevBuf d_Ts, d_time, d_tb, d_pose, d_qpos, d_cnt, d_off, d_blk, d_tile, d_esrc, d_edst, d_eout, d_z, d_nout, d_ang, d_lin, d_T64, d_dbgw, d_dbge, d_dbgf, d_dbgo, d_mask;
     int64_t edge_cap = 0;
@@ -1005,30 +1007,31 @@ int layer_forward_impl(dedf_handle* h, int n_src, const float* x_src, const floa
         return fail(h, DEDF_ERR_INVALID, "graph too large for one call");
     hipStream_t st = static_cast<hipStream_t>(stream);
     DEDF_ON_DEVICE(h);
+    dedf_handle* const w = h->ws_owner ? h->ws_owner : h;      // whose workspace this call runs in (dedf_layer_share_workspace)
     const size_t E = (size_t)std::max<int64_t>(n_edges, 1);
-    bool ok = h->d_msg.ensure((size_t)n_src * D * 4) && h->d_msg_dst.ensure((size_t)n_dst * D * 4) && h->d_tile.ensure(64 * 4) &&
-              h->d_esrc.ensure(E * 4) && h->d_edst.ensure(E * 4) && h->d_cnt.ensure((size_t)n_dst * 4) && h->d_off.ensure((size_t)n_dst * 4) &&
-              h->d_eout.ensure(E * REC * 4) && h->d_z.ensure((size_t)n_dst * D * 4);
+    bool ok = w->d_msg.ensure((size_t)n_src * D * 4) && w->d_msg_dst.ensure((size_t)n_dst * D * 4) && w->d_tile.ensure(64 * 4) &&
+              w->d_esrc.ensure(E * 4) && w->d_edst.ensure(E * 4) && w->d_cnt.ensure((size_t)n_dst * 4) && w->d_off.ensure((size_t)n_dst * 4) &&
+              w->d_eout.ensure(E * REC * 4) && w->d_z.ensure((size_t)n_dst * D * 4);
     if (!ok) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(workspace) failed");
-    HIPCK(h, hipMemsetAsync(h->d_tile.p, 0, 64 * 4, st));
+    HIPCK(h, hipMemsetAsync(w->d_tile.p, 0, 64 * 4, st));
     const float* nat = h->d_nat.as<float>();
     // messages: linear_src(f_src), linear_dst(f_dst) -- no LayerNorm in front of them (block.py:149-153)
     hipLaunchKernelGGL((k_src_message<L, false>), dim3(n_src), dim3(64), 0, st, f_src, n_src, (const float*)nullptr, (const float*)nullptr,
-                       nat + h->nat_wsrc, (const float*)nullptr, h->d_msg.as<float>());
+                       nat + h->nat_wsrc, (const float*)nullptr, w->d_msg.as<float>());
     hipLaunchKernelGGL((k_src_message<L, false>), dim3(n_dst), dim3(64), 0, st, f_dst, n_dst, (const float*)nullptr, (const float*)nullptr,
-                       nat + h->nat_wdst, nat + h->nat_bdst, h->d_msg_dst.as<float>());
+                       nat + h->nat_wdst, nat + h->nat_bdst, w->d_msg_dst.as<float>());
     {
         const int64_t work = std::max<int64_t>(n_edges, n_dst);
         hipLaunchKernelGGL(k_edge_lists, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, edge_src, edge_dst, n_edges, n_src, n_dst,
-                           h->d_esrc.as<int>(), h->d_edst.as<int>(), h->d_cnt.as<int>(), h->d_off.as<int>(), h->d_tile.as<int>());
+                           w->d_esrc.as<int>(), w->d_edst.as<int>(), w->d_cnt.as<int>(), w->d_off.as<int>(), w->d_tile.as<int>());
     }
     const dedf_config& c = h->cfg;
     {
         EdgeParams P{};
-        P.key_x = x_src; P.qpos = x_dst; P.edge_src = h->d_esrc.as<int>(); P.edge_dst = h->d_edst.as<int>();
-        P.tile_info = h->d_tile.as<int>();
-        P.msg = h->d_msg.as<float>(); P.msg_bytes = (uint32_t)((size_t)n_src * D * 4);
-        P.msg_dst = h->d_msg_dst.as<float>(); P.msg_dst_bytes = (uint32_t)((size_t)n_dst * D * 4);
+        P.key_x = x_src; P.qpos = x_dst; P.edge_src = w->d_esrc.as<int>(); P.edge_dst = w->d_edst.as<int>();
+        P.tile_info = w->d_tile.as<int>();
+        P.msg = w->d_msg.as<float>(); P.msg_bytes = (uint32_t)((size_t)n_src * D * 4);
+        P.msg_dst = w->d_msg_dst.as<float>(); P.msg_dst_bytes = (uint32_t)((size_t)n_dst * D * 4);
         P.tb = nullptr; P.tb_bytes = 0; P.tb_pose_stride = 0;
         P.nQ = 1; P.n_scales = 1;
         for (int i = 0; i < 2; ++i) {      // masked LayerNorms of the radial MLP (true widths of a padded model)
@@ -1048,16 +1051,16 @@ int layer_forward_impl(dedf_handle* h, int n_src, const float* x_src, const floa
         for (int l = 0; l < 4; ++l) { P.c_lin[l] = o.c_lin[l]; P.c_val[l] = o.c_val[l]; }
         P.o_b_r0 = o.o_b_r0; P.o_b_val0 = o.o_b_val0; P.o_alpha_dot = o.o_alpha_dot;
         P.key_w = nullptr;
-        P.out = h->d_eout.as<float>();
+        P.out = w->d_eout.as<float>();
         P.dbg_w = nullptr; P.dbg_out = nullptr; P.phase_prof = nullptr;
         if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, true, 32, 32, true>), 1 << 30, st, P);
         else DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, false, 32, 32, true>), 1 << 30, st, P);
     }
-    hipLaunchKernelGGL(k_aggregate<L>, dim3((n_dst + 3) / 4), dim3(256), 0, st, h->d_eout.as<float>(), h->d_cnt.as<int>(), h->d_off.as<int>(),
-                       h->d_tile.as<int>(), n_dst, 1, h->d_z.as<float>());
+    hipLaunchKernelGGL(k_aggregate<L>, dim3((n_dst + 3) / 4), dim3(256), 0, st, w->d_eout.as<float>(), w->d_cnt.as<int>(), w->d_off.as<int>(),
+                       w->d_tile.as<int>(), n_dst, 1, w->d_z.as<float>());
     {
         NodeParams P{};
-        P.z = h->d_z.as<float>(); P.z_bytes = (uint32_t)((size_t)n_dst * D * 4);
+        P.z = w->d_z.as<float>(); P.z_bytes = (uint32_t)((size_t)n_dst * D * 4);
         P.f_dst = f_dst; P.f_dst_bytes = (uint32_t)((size_t)n_dst * D * 4);
         P.feat_out = out;
         P.nQ = 1; P.n_nodes = n_dst; P.lin_mult = 1.0f;
@@ -1076,18 +1079,18 @@ int layer_forward_impl(dedf_handle* h, int n_src, const float* x_src, const floa
         else DEDF_LAUNCH_PERSISTENT((k_node<L, false, false, true>), ntiles, st, P);
     }
     if (h->defer_check) {          // chains of layers: the verdict of the edge-list check is kept on the device for dedf_layer_check
-        if (!h->d_sticky.p) {
-            if (!h->d_sticky.ensure(4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(flag) failed");
-            HIPCK(h, hipMemsetAsync(h->d_sticky.p, 0, 4, st));
+        if (!w->d_sticky.p) {
+            if (!w->d_sticky.ensure(4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(flag) failed");
+            HIPCK(h, hipMemsetAsync(w->d_sticky.p, 0, 4, st));
         }
-        hipLaunchKernelGGL(k_or_flag, dim3(1), dim3(1), 0, st, h->d_tile.as<int>() + kFlagBadEdges, h->d_sticky.as<int>());
+        hipLaunchKernelGGL(k_or_flag, dim3(1), dim3(1), 0, st, w->d_tile.as<int>() + kFlagBadEdges, w->d_sticky.as<int>());
         if (hipGetLastError() != hipSuccess) return fail(h, DEDF_ERR_RUNTIME, "kernel launch failed");
         return DEDF_OK;
     }
     if (hipGetLastError() != hipSuccess) return fail(h, DEDF_ERR_RUNTIME, "kernel launch failed");
     HIPCK(h, hipStreamSynchronize(st));
     int bad = 0;
-    HIPCK(h, hipMemcpy(&bad, h->d_tile.as<int>() + kFlagBadEdges, 4, hipMemcpyDeviceToHost));
+    HIPCK(h, hipMemcpy(&bad, w->d_tile.as<int>() + kFlagBadEdges, 4, hipMemcpyDeviceToHost));
     if (bad) return fail(h, DEDF_ERR_INVALID, "edge lists: edge_dst must be sorted ascending and every index inside its cloud");
     return DEDF_OK;
 }
@@ -1120,18 +1123,35 @@ int dedf_layer_defer_check(dedf_handle* h, int on) {
     return DEDF_OK;
 }
 
+int dedf_layer_share_workspace(dedf_handle* h, dedf_handle* owner) {
+    if (!h) return DEDF_ERR_INVALID;
+    if (!h->cfg.unet_layer) return fail(h, DEDF_ERR_UNSUPPORTED, "UNet-layer handles only");
+    if (owner == nullptr || owner == h) { h->ws_owner = nullptr; return DEDF_OK; }
+    if (!owner->cfg.unet_layer || owner->host_only || h->host_only) return fail(h, DEDF_ERR_INVALID, "dedf_layer_share_workspace: the owner must be a UNet-layer handle with a device");
+    if (owner->cfg.device != h->cfg.device) return fail(h, DEDF_ERR_INVALID, "dedf_layer_share_workspace: both handles must live on one device");
+    if (owner->ws_owner) return fail(h, DEDF_ERR_INVALID, "dedf_layer_share_workspace: the owner itself borrows a workspace");
+    h->ws_owner = owner;
+    // this layer's own per-call buffers are no longer needed
+    for (DevBuf* b : {&h->d_msg, &h->d_msg_dst, &h->d_esrc, &h->d_edst, &h->d_cnt, &h->d_off, &h->d_eout, &h->d_z}) {
+        if (b->p) (void)hipFree(b->p);
+        b->p = nullptr; b->bytes = 0;
+    }
+    return DEDF_OK;
+}
+
 int dedf_layer_check(dedf_handle* h, void* stream) {
     if (!h) return DEDF_ERR_INVALID;
     if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
     if (!h->cfg.unet_layer) return fail(h, DEDF_ERR_UNSUPPORTED, "UNet-layer handles only");
-    if (!h->d_sticky.p) return DEDF_OK;                 // nothing has run in deferred mode
+    dedf_handle* const w = h->ws_owner ? h->ws_owner : h;      // layers that share a workspace share the verdict word: one check covers them all
+    if (!w->d_sticky.p) return DEDF_OK;                 // nothing has run in deferred mode
     hipStream_t st = static_cast<hipStream_t>(stream);
     DEDF_ON_DEVICE(h);
     int bad = 0;
-    HIPCK(h, hipMemcpyAsync(&bad, h->d_sticky.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCK(h, hipMemcpyAsync(&bad, w->d_sticky.p, 4, hipMemcpyDeviceToHost, st));
     HIPCK(h, hipStreamSynchronize(st));
     if (bad) {
-        HIPCK(h, hipMemsetAsync(h->d_sticky.p, 0, 4, st));
+        HIPCK(h, hipMemsetAsync(w->d_sticky.p, 0, 4, st));
         return fail(h, DEDF_ERR_INVALID, "edge lists: edge_dst must be sorted ascending and every index inside its cloud");
     }
     return DEDF_OK;

@@ -178,7 +178,7 @@ DEDF_DEV AItem load_item(const Wave& wv, int o_str) {
             const int lv = half_rows ? wv.lane16_r16 : wv.lane16;
             a.h[n] = bld4(wv.w, lv, (o_str + (it.slot + n) * 512) * 4);
             if constexpr (!HP) a.l[n] = bld4(wv.w, lv, (o_str + (it.slot + n) * 512 + 256) * 4);
-            if constexpr (acc_paired<L>(l3) && !dtp_pos_out<L>(it.pos)) {      // the same 16 rows once more, as rows 16-31 of the tile (odd components)
+            if constexpr (acc_paired<L>(l3)) {      // the same 16 rows once more, as rows 16-31 of the tile (odd components / second tile half)
                 a.h[1] = bld4(wv.w, wv.lane16_r16up, (o_str + it.slot * 512) * 4);
                 if constexpr (!HP) a.l[1] = bld4(wv.w, wv.lane16_r16up, (o_str + it.slot * 512 + 256) * 4);
             }
@@ -203,7 +203,23 @@ DEDF_DEV void mfma_chunk(const Wave& wv, int o_str, AItem (&ring)[PD], const BOp
         ring[I0 % PD] = load_item<L, NT0, I0 + PD, HP>(wv, o_str);
         const h8 ah = __builtin_bit_cast(h8, a.h[0]), al = __builtin_bit_cast(h8, a.l[0]);
         const f32x16 zero = {};
-        if constexpr (d1 == 1) {
+        if constexpr (acc_paired<L>(l3)) {
+            // 16-row outputs: two G tiles instead of three (see the input-side branch below).  d1 = 3: components 0 | 1 share tile 0, component 2
+            // has tile 1;  d1 = 1: the product terms hi*hi | hi*lo share tile 0, lo*hi has tile 1.  contract_out reads them accordingly.
+            const h8 bh = __builtin_bit_cast(h8, a.h[1]), bl = __builtin_bit_cast(h8, a.l[1]);
+            if constexpr (d1 == 1) {
+                go[0] = mfma_h(ah, bo.hi[0], first ? zero : go[0]);
+                if constexpr (!HP) { go[1] = mfma_h(al, bo.hi[0], first ? zero : go[1]); go[0] = mfma_h(bh, bo.lo[0], go[0]); }
+            } else {
+                go[0] = mfma_h(ah, bo.hi[0], first ? zero : go[0]);
+                go[1] = mfma_h(ah, bo.hi[2], first ? zero : go[1]);
+                go[0] = mfma_h(bh, bo.hi[1], go[0]);
+                if constexpr (!HP) {
+                    go[0] = mfma_h(ah, bo.lo[0], go[0]); go[1] = mfma_h(ah, bo.lo[2], go[1]); go[0] = mfma_h(bh, bo.lo[1], go[0]);
+                    go[0] = mfma_h(al, bo.hi[0], go[0]); go[1] = mfma_h(al, bo.hi[2], go[1]); go[0] = mfma_h(bl, bo.hi[1], go[0]);
+                }
+            }
+        } else if constexpr (d1 == 1) {
             go[0] = mfma_h(ah, bo.hi[0], first ? zero : go[0]);
             if constexpr (!HP) { go[1] = mfma_h(ah, bo.lo[0], first ? zero : go[1]); go[2] = mfma_h(al, bo.hi[0], first ? zero : go[2]); }
         } else {
@@ -712,6 +728,10 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 else if constexpr (l3 == 2) o[K] = vacc2[K][R];
                 else o[K] = vacc3[K][R];
             });
+            if constexpr (acc_paired<L>(l3)) {      // (two G tiles: mfma_chunk)
+                if constexpr (d1 == 1) Cg::template acc<0>(HP ? G[0][R] : (G[0][R] + G[0][8 + R]) + G[1][R], m, o);
+                else static_for<d1>([&]<int I>() { Cg::template acc<I>(I == 2 ? G[1][R] : G[0][8 * I + R], m, o); });
+            } else
             if constexpr (d1 == 1) Cg::template acc<0>(HP ? G[0][R] : (G[0][R] + G[1][R]) + G[2][R], m, o);      // the three product terms
             else static_for<d1>([&]<int I>() { Cg::template acc<I>(G[I][R], m, o); });
             static_for<d3>([&]<int K>() {
@@ -865,7 +885,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         else run_l3.template operator()<Ph>(l3c, wbuf[T3 % 2], wbuf[T3 % 2]);
         const BOpsH<L> b_nxt = valu_chunk.template operator()<C + 1>(x_nxt, wbuf[((C + 1) / 2) % 2]);
         constexpr bool fin_out = C >= 1 && dtp_pos_out<L>(C - 1) && dtp_pos_path_last<L>(C - 1);      // an output-side path ended at C - 1
-        if constexpr (fin_out) static_for<3>([&]<int a>() { gfin[a] = go[a]; });
+        if constexpr (fin_out) static_for<acc_paired<L>(dtp_pos_l3<L>(C >= 1 ? C - 1 : 0)) ? 2 : 3>([&]<int a>() { gfin[a] = go[a]; });
         mfma_chunk<L, NR0, C, HP>(wv, o_S_lin, ring, b_cur, acc0, acc1, acc2, acc3, go);
         if constexpr (fin_out) contract_out.template operator()<C - 1>(gfin);
         static_for<L + 1>([&]<int g>() { if constexpr (C == dtp_group_end<L>(g)) finish_group.template operator()<g>(); });
@@ -873,7 +893,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         if constexpr (Ph % 2 == 1 && T3 < NWT) dump_w.template operator()<T3>(wbuf[T3 % 2]);
         x_nxt = x_nn; b_cur = b_nxt;
         if constexpr (C + 1 == dtp_group_end<L>(0)) DEDF_STAMP(8);
-        if constexpr (L == 2 && C + 1 == dtp_group_end<L>(1)) DEDF_STAMP(9);
+        if constexpr (L >= 2 && C + 1 == dtp_group_end<L>(1)) DEDF_STAMP(9);
+        if constexpr (L == 3 && C + 1 == dtp_group_end<L>(2)) DEDF_STAMP(15);
     });
     if constexpr (dtp_pos_out<L>(NCHK - 1)) contract_out.template operator()<NCHK - 1>(go);
     finish_group.template operator()<L>();
@@ -1145,7 +1166,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         sched_fence();
         vb_cur = b_nxt;
         if constexpr (F >= 0 && val_item<L>(F).group_end == 0) DEDF_STAMP(10);
-        if constexpr (L == 2 && F >= 0 && val_item<L>(F).group_end == 1) DEDF_STAMP(13);
+        if constexpr (L >= 2 && F >= 0 && val_item<L>(F).group_end == 1) DEDF_STAMP(13);
+        if constexpr (L == 3 && F >= 0 && val_item<L>(F).group_end == 2) DEDF_STAMP(2);      // (slot 2 is free in the table-reading kernel)
     });
     DEDF_STAMP(14);
     store_group.template operator()<L>();

@@ -206,7 +206,10 @@ template <int L> DEDF_HD constexpr int park_slot(int l, int i, int c) {
 template <int L> DEDF_HD constexpr int park_slots() { return park_slot<L>(L + 1, 0, 0); }          // 15 (L = 2), 10 (L = 1)
 // The l3 >= 2 accumulators of the first depth-wise TP's linear at lmax 3 hold two components per 32-row tile (dedf_edge.h::mfma_chunk):
 // 48 + 64 instead of 80 + 112 accumulator registers in the groups where k_edge<3> spills.
-template <int L> DEDF_HD constexpr bool acc_paired(int l3) { return L == 3 && l3 >= 2; }
+#ifndef DEDF_PAIR_L2
+#define DEDF_PAIR_L2 0      // measured at lmax 2: see DESIGN.md section 5.0
+#endif
+template <int L> DEDF_HD constexpr bool acc_paired(int l3) { return (L == 3 || (L == 2 && DEDF_PAIR_L2)) && l3 >= 2; }
 // LDS slots (16 bytes per lane) of parked chunk q: the hi halves in slot park_phys(q), the residuals in the next one -- except the l = 3
 // chunks at lmax 3: four of a lane's eight registers are the zero padding of 8x3e (pad_pos puts a head's two true channels first in its group
 // of four: registers 0, 1, 4, 5 of either half-wave), so hi and lo of the four real ones share ONE slot (dedf_dev.h::split4pk).  7 KB less per

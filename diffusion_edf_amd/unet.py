@@ -21,6 +21,7 @@ embedding, see ``unet_pad.py`` — at the price of the padded arithmetic.  Graph
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -67,13 +68,47 @@ class UnetLayer(torch.nn.Module):
         self._handle_device: Optional[torch.device] = None
         self._deferred = False
         self._half = False
+        self._ws_box = [None]                      # share_workspace: [the layer whose per-call workspace this one runs in] (boxed: not a submodule) ...
+        self._ws_link = None                       # ... and the owner's handle the link was made with
+        self._ws_borrowers = weakref.WeakSet()     # layers that run in THIS layer's workspace
         self.register_load_state_dict_post_hook(UnetLayer._after_load)
 
     # ------------------------------------------------------------------------------------------------------------------
     def _release(self):
         if self._handle is not None:
-            _lib.load().dedf_destroy(self._handle)
+            lib = _lib.load()
+            for b in list(self._ws_borrowers):     # nobody may keep a pointer to a workspace that is about to go
+                if b._handle is not None and b._ws_link is not None:
+                    lib.dedf_layer_share_workspace(b._handle, None)
+                b._ws_link = None
+            lib.dedf_destroy(self._handle)
             self._handle = None
+        self._ws_link = None
+
+    def share_workspace(self, owner: Optional["UnetLayer"]):
+        """run in ``owner``'s per-call workspace (``dedf_layer_share_workspace``: messages, edge lists, segment records, aggregate, verdict word)
+        instead of an own one — the layers of an extractor run one after the other on one stream.  ``None`` detaches.  The link is (re)made
+        lazily, whenever either handle is (re)built."""
+        old = self._ws_box[0]
+        if old is not None and old is not owner:
+            old._ws_borrowers.discard(self)
+            if self._handle is not None and self._ws_link is not None:
+                _lib.load().dedf_layer_share_workspace(self._handle, None)
+            self._ws_link = None
+        self._ws_box[0] = owner if owner is not self else None
+        if self._ws_box[0] is not None:
+            self._ws_box[0]._ws_borrowers.add(self)
+
+    def _link_workspace(self, device):
+        o = self._ws_box[0]
+        if o is None:
+            return
+        o._ensure_handle(device)
+        if self._ws_link != o._handle.value:
+            lib = _lib.load()
+            rc = lib.dedf_layer_share_workspace(self._handle, o._handle)
+            _lib.raise_for(lib, self._handle, rc, "dedf_layer_share_workspace")
+            self._ws_link = o._handle.value
 
     # (the packed device image is rebuilt on next use after ANY load: a post hook also fires when a parent module loads a checkpoint,
     #  which never calls the children's load_state_dict)
@@ -149,6 +184,7 @@ class UnetLayer(torch.nn.Module):
         assert edge_src.ndim == 1 and edge_src.shape == edge_dst.shape
         dev = node_coord_src.device
         self._ensure_handle(dev)
+        self._link_workspace(dev)
         lib = _lib.load()
         f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
         xs, xd, fs, fd = f32(node_coord_src), f32(node_coord_dst), f32(f_src_wide), f32(f_dst_wide)
@@ -381,6 +417,10 @@ class UnetFeatureExtractor(torch.nn.Module):
         self.project_outputs = torch.nn.ModuleList(
             [NodeLinear(emb[n], irreps_output, layernorm=True) if parse_irreps(emb[n]) != parse_irreps(irreps_output) else torch.nn.Identity()
              for n in range(ns)])
+        # the layers run one after the other: ONE per-call workspace (and one verdict word) for all of them, the first layer's
+        layers = [m for m in self.modules() if isinstance(m, UnetLayer)]
+        for m in layers[1:]:
+            m.share_workspace(layers[0])
 
     @torch.no_grad()
     def forward(self, pcd):
@@ -441,8 +481,8 @@ class UnetFeatureExtractor(torch.nn.Module):
             if s in self.output_scalespace:
                 fo = unet_pad.unpad_features(lin(self.project_outputs[s], scale_out[s][0]), _muls(parse_irreps(self.irreps_output)))
                 outs.append(FeaturedPoints(x=scale_out[s][1].to(pcd.x.dtype), f=fo.to(dt), b=scale_out[s][2], w=None))
-        for layer in used:
-            layer.check()
+        if used:
+            used[0].check()          # the layers share one workspace and one deferred verdict word (UnetLayer.share_workspace): one read-back
         return outs
 
 

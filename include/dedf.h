@@ -184,6 +184,14 @@ int dedf_set_radial_table(dedf_handle* h, int on);
 int dedf_layer_defer_check(dedf_handle* h, int on);
 int dedf_layer_check(dedf_handle* h, void* stream);
 
+/* The layers of one extractor run one after the other, so they can work in ONE per-call workspace (source / destination messages, int32 edge
+ * lists, segment records E x 244 floats, aggregate, status words) instead of one each: after dedf_layer_share_workspace(h, owner) the calls of
+ * `h` use the workspace and the deferred verdict word of `owner` (another UNet-layer handle on the same device; owner = NULL or h detaches),
+ * and h's own per-call buffers are released.  A 4-scale UNet has 17-25 layers; on the 16 384-point scene their own workspaces add up to ~2 GB
+ * that are used one at a time.  Contract: calls of handles that share a workspace are issued on ONE stream (or otherwise ordered), `owner`
+ * outlives the link (detach before dedf_destroy(owner)), and one dedf_layer_check -- on any of them -- collects the verdict of all. */
+int dedf_layer_share_workspace(dedf_handle* h, dedf_handle* owner);
+
 /* MultiscaleTensorField.forward(query_points, input_points_multiscale, context_emb=None) (multiscale_tensor_field.py:192-260) for a field
  * without context encoding and without query features -- the key field of an EBM-type handle (dedf_config.ebm = 1), which is also what
  * KeypointExtractor.tensor_field / .weight_field are (keypoint_extractor.py:97-112: irreps_query = None, edge_context_emb_dim = None).

@@ -6,7 +6,8 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import bench
 from diffusion_edf_amd.score_head import ScoreModelHead
 dev = torch.device('cuda:0')
-kw, cfg, P, keys, query, Ts = bench.build_inputs(2, 4096, 1024, 1000, 0, dev)
+LMAX = int(os.environ.get('LMAX', '2'))          # LMAX=3: build unit 22 (sampler) / 16 (score forward) with -DDEDF_PHASE_PROF
+kw, cfg, P, keys, query, Ts = bench.build_inputs(LMAX, 4096, 1024, 1000, 0, dev)
 head = ScoreModelHead(**kw); head.load_state_dict(P); head.to(dev)
 t = torch.full((1000,), 0.5, device=dev)
 if os.environ.get("SAMPLE"):          # the sampler's path (shared time: radial table) instead of the score forward
@@ -25,7 +26,8 @@ raw0 = buf.numpy().view(np.uint64).reshape(-1, 16).copy()
 run(); torch.cuda.synchronize()
 raw1 = head.debug_buffer('phase_prof').numpy().view(np.uint64).reshape(-1, 16)
 d = (raw1 - raw0).astype(np.float64)
-names = ["geom+enc", "prelin+silu", "L1 mfma", "L1 LN+silu", "L2 mfma", "L2 LN+silu", "accinit", "E prologue(wt0)", "E l3=0 chunks", "E l3=1 chunks", "F l3=0 chunks", "stores+end", "E l3=2 chunks", "F l3=1 chunks", "F l3=2 chunks", "-"]
+names = ["geom+enc", "prelin+silu", "L1 mfma", "L1 LN+silu", "L2 mfma", "L2 LN+silu", "accinit", "E prologue(wt0)", "E l3=0 chunks", "E l3=1 chunks", "F l3=0 chunks", "stores+end", "E l3=2 chunks" if LMAX == 2 else "E l3=3 chunks", "F l3=1 chunks", "F l3=2 chunks" if LMAX == 2 else "F l3=3 chunks", "-" if LMAX == 2 else "E l3=2 chunks"]
+if LMAX == 3: names[2] = "F l3=2 chunks"
 tot = d[:, :16].sum(1).mean()
 E = head.stats()['n_edges_total']; tiles = sum((e + 31)//32 for e in head.stats()['n_edges'])
 print("edges", E, "tiles", tiles, "tiles/wave", tiles / d.shape[0])
