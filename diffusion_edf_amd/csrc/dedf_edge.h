@@ -603,7 +603,14 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // region so that hipcc interleaves them:  the source-message loads of chunk C+2,  the layer-3 MFMAs of the NEXT weight
     // tile,  the lane-local Clebsch-Gordan VALU work + hi/lo split of chunk C+1 (-> its B operands),  the activations of a
     // group completed by chunk C-1,  and the lin / sep_alpha MFMAs of chunk C (A operands through a ring, PDA items ahead).
-    constexpr int NCHK = WN / 16, PDA = 3;
+#ifndef DEDF_PDA3
+#define DEDF_PDA3 2      // lmax 3: operand ring of the lin / sep_alpha stream two items deep (3: 143.3 k, 2: 149.0 k, 1: 148.4 k pose-steps/s;
+                         // 76 / 66 / 54 spilled registers -- profiles/r03p_pda_lmax3_ab.log)
+#endif
+#ifndef DEDF_R2S_LDS3
+#define DEDF_R2S_LDS3 1
+#endif
+    constexpr int NCHK = WN / 16, PDA = L == 3 ? DEDF_PDA3 : 3;
     struct XOps { f32x4 x[2][2 * L + 1]; f32x4 xd[UN ? 2 : 1][2 * L + 1]; };
     auto load_X = [&]<int C>() {      // this lane's 2 x 4 source-message rows of the chunk (contiguous runs in the reference layout)
         XOps o{};
@@ -668,6 +675,11 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // A operands (hi and lo image) form one global stream over all tiles.
     constexpr int KC = H2 / 16;
     HL r2s[KC];
+    // lmax 3: the split layer-2 activations (the B operands of all 28 layer-3 weight tiles: 32 registers for the whole stage) wait in LDS instead,
+    // in the slots of the l = 3 chunks and of the segment weights, which are only written when the last weight tile is done (finish_group<3>
+    // runs in the last region, the layer-3 halves end three regions earlier)
+    constexpr bool R2S_LDS = L == 3 && DEDF_R2S_LDS3 && 2 * KC <= park_phys_slots<L>() + 2 - 2 * park_slot<L>(L, 0, 0);
+    constexpr int R2S_SLOT = 2 * park_slot<L>(L, 0, 0);
     // Layer-3 work unit = half a weight tile (2 of the 4 K-chunks, 6 MFMAs).  Half P = 2 T + half of tile T runs in pipeline
     // region P - 3 into wbuf[T % 2]; its operands (and the tile's offset rows, the accumulator init) are requested one region
     // earlier, across a scheduling fence, so that the request cannot sink next to its use.  With the 32-wide MLP a tile has
@@ -695,8 +707,13 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             f32x16 t = init;
             static_for<l3_nk.template operator()<Ph>()>([&]<int k>() {
                 const h8 ah = __builtin_bit_cast(h8, a.h[k]), al = __builtin_bit_cast(h8, a.l[k]);
-                t = mfma_h(ah, r2s[c0 + k].hi, t);
-                if constexpr (!HP) { t = mfma_h(ah, r2s[c0 + k].lo, t); t = mfma_h(al, r2s[c0 + k].hi, t); }
+                HL b;
+                if constexpr (R2S_LDS) {
+                    b.hi = __builtin_bit_cast(h8, pk[(R2S_SLOT + 2 * (c0 + k)) * 64]);
+                    if constexpr (!HP) b.lo = __builtin_bit_cast(h8, pk[(R2S_SLOT + 2 * (c0 + k) + 1) * 64]);
+                } else b = r2s[c0 + k];
+                t = mfma_h(ah, b.hi, t);
+                if constexpr (!HP) { t = mfma_h(ah, b.lo, t); t = mfma_h(al, b.hi, t); }
             });
             w = t;
             if constexpr (Ph % 2 == 1) to_vgpr(w);      // finished tile: the VALU stage reads it
@@ -855,6 +872,10 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             float t[8];
             static_for<8>([&]<int J>() { t[J] = r2[c / 2][8 * (c % 2) + J]; });
             r2s[c] = split8(t);
+            if constexpr (R2S_LDS) {
+                pk[(R2S_SLOT + 2 * c) * 64] = __builtin_bit_cast(f32x4, r2s[c].hi);
+                if constexpr (!HP) pk[(R2S_SLOT + 2 * c + 1) * 64] = __builtin_bit_cast(f32x4, r2s[c].lo);
+            }
         });
         static_for<NR0>([&]<int T>() {      // accumulator init: lin / sep_alpha biases
             if constexpr (RL::BIG) acc0[T] = ldrows_lds(rows, hi, RL::b0, T); else acc0[T] = ldrows(wv, P.o_b_r0, T);
