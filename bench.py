@@ -188,6 +188,7 @@ def main():
     ap.add_argument("--grasp", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extractors", action="store_true", help="skip the (untimed) feature-extractor measurement")
+    ap.add_argument("--no-small-batches", action="store_true", help="skip the (untimed) 16 / 64 / 256-pose rows: profiles/collect.sh, so that per-kernel averages of a trace are those of the timed launches")
     ap.add_argument("--no-radial-table", action="store_true", help="evaluate the radial network's front per edge in the sampler too (A/B; the default tabulates it per step)")
     ap.add_argument("--half", action="store_true", help="half-precision GEMM mode (model.half(), the reference's half_precision knob); NOT the headline configuration")
     args = ap.parse_args()
@@ -315,7 +316,7 @@ def main():
     # outside the timed region as well: the deployment regime of the reference (N_samples = 10 / 20 poses per call, evaluate_real_mug.ipynb:188-190)
     # -- the same scene, the first 16 / 64 / 256 of the seeded poses, 50 steps of the same schedule; latency-bound (one round of edge tiles)
     small = None
-    if rank == 0 and world == 1 and not args.half:
+    if rank == 0 and world == 1 and not args.half and not args.no_small_batches:
         small = {}
         for n_small in (16, 64, 256):
             if n_small >= args.poses_per_gpu:

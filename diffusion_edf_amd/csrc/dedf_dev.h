@@ -222,6 +222,26 @@ DEDF_DEV HL split8(const float (&x)[8]) {
     return r;
 }
 
+// split8 of eight values whose elements 2, 3, 6, 7 are structural zeros (dedf_net.h::pad_reg): only the two live pairs are converted
+DEDF_DEV HL split8z(const float (&x)[8]) {
+#if defined(__HIP_DEVICE_COMPILE__) && DEDF_SPLIT_MIX
+    unsigned hp[2], lp[2];
+#define DEDF_SPLIT_PAIR(Q, A)                                                                       \
+    asm volatile("v_cvt_pk_f16_f32 %0, %2, %3\n\t"                                                   \
+                 "v_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"             \
+                 "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"                 \
+                 : "=&v"(hp[Q]), "=&v"(lp[Q]) : "v"(x[A]), "v"(x[A + 1]))
+    DEDF_SPLIT_PAIR(0, 0); DEDF_SPLIT_PAIR(1, 4);
+#undef DEDF_SPLIT_PAIR
+    HL r;
+    r.hi = __builtin_bit_cast(h8, u32x4{hp[0], 0u, hp[1], 0u});
+    r.lo = __builtin_bit_cast(h8, u32x4{lp[0], 0u, lp[1], 0u});
+    return r;
+#else
+    const float y[8] = {x[0], x[1], 0.0f, 0.0f, x[4], x[5], 0.0f, 0.0f};
+    return split8(y);
+#endif
+}
 // Four values -> one 16-byte word {hi(0,1), hi(2,3), lo(0,1), lo(2,3)}: the packed form of a parked chunk whose other four registers are
 // structural zeros (the 8x3e block inside its 16-channel chunk, dedf_edge.h::park_chunk).  Same halves as split8 gives for these values.
 DEDF_DEV f32x4 split4pk(const float (&x)[4]) {

@@ -270,9 +270,14 @@ DEDF_DEV void mfma_chunk(const Wave& wv, int o_str, AItem (&ring)[PD], const BOp
     });
 }
 // split the chunk's fp32 products v[m][8] into B operands
-template <int L, int l3>
+// (PADZ: elements 2, 3, 6, 7 are the zero padding of the chunk's input channels, dedf_net.h::pad_reg)
+template <int L, int l3, bool PADZ = false>
 DEDF_DEV void split_chunk(const float (&v)[2 * l3 + 1][8], BOpsH<L>& o) {
-    static_for<2 * l3 + 1>([&]<int K>() { const HL sp = split8(v[K]); o.hi[K] = sp.hi; o.lo[K] = sp.lo; });
+    static_for<2 * l3 + 1>([&]<int K>() {
+        HL sp;
+        if constexpr (PADZ) sp = split8z(v[K]); else sp = split8(v[K]);
+        o.hi[K] = sp.hi; o.lo[K] = sp.lo;
+    });
 }
 
 // once per wave, before its first tile: copy the row vectors into LDS
@@ -610,6 +615,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
 #ifndef DEDF_R2S_LDS3
 #define DEDF_R2S_LDS3 1
 #endif
+#ifndef DEDF_R2S_LDS2
+#define DEDF_R2S_LDS2 0
+#endif
     constexpr int NCHK = WN / 16, PDA = L == 3 ? DEDF_PDA3 : 3;
     struct XOps { f32x4 x[2][2 * L + 1]; f32x4 xd[UN ? 2 : 1][2 * L + 1]; };
     auto load_X = [&]<int C>() {      // this lane's 2 x 4 source-message rows of the chunk (contiguous runs in the reference layout)
@@ -658,12 +666,15 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                     if constexpr (UN) xr[4 * Q + i] = xo.x[run][Q][i] + xo.xd[run][Q][i]; else xr[4 * Q + i] = xo.x[run][Q][i];
                 }); });
                 static_for<4>([&]<int j>() {
+                    if constexpr (pad_reg<L>(l1, j)) static_for<d3>([&]<int K>() { v[K][4 * run + j] = 0.0f; });      // a zero-padding channel of the source rows
+                    else {
                     float t[d3];
                     Cg::apply(&xr[j * d1], m, t);
                     static_for<d3>([&]<int K>() { v[K][4 * run + j] = t[K] * wtile[8 * c2 + 4 * run + j]; });
+                    }
                 });
             });
-            split_chunk<L, l3>(v, o);
+            split_chunk<L, l3, pad_reg<L>(l1, 2)>(v, o);
             }
         }
         return o;
@@ -678,7 +689,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // lmax 3: the split layer-2 activations (the B operands of all 28 layer-3 weight tiles: 32 registers for the whole stage) wait in LDS instead,
     // in the slots of the l = 3 chunks and of the segment weights, which are only written when the last weight tile is done (finish_group<3>
     // runs in the last region, the layer-3 halves end three regions earlier)
-    constexpr bool R2S_LDS = L == 3 && DEDF_R2S_LDS3 && 2 * KC <= park_phys_slots<L>() + 2 - 2 * park_slot<L>(L, 0, 0);
+    constexpr bool R2S_LDS = ((L == 3 && DEDF_R2S_LDS3) || (L == 2 && DEDF_R2S_LDS2)) && 2 * KC <= park_phys_slots<L>() + 2 - 2 * park_slot<L>(L, 0, 0);
     constexpr int R2S_SLOT = 2 * park_slot<L>(L, 0, 0);
     // Layer-3 work unit = half a weight tile (2 of the 4 K-chunks, 6 MFMAs).  Half P = 2 T + half of tile T runs in pipeline
     // region P - 3 into wbuf[T % 2]; its operands (and the tile's offset rows, the accumulator init) are requested one region
@@ -738,6 +749,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         float m[Cg::NM];
         Cg::make(Y.template get<l2>(), m);
         static_for<NR>([&]<int R>() {
+            if constexpr (pad_reg<L>(l3, R)) {      // a zero-padding output channel: nothing to contract
+                if constexpr (dtp_pos_opens_vacc<L>(Ce)) static_for<d3>([&]<int K>() { if constexpr (l3 == 3) vacc3[K][R] = 0.0f; });
+            } else {
             float o[d3];
             static_for<d3>([&]<int K>() {
                 if constexpr (dtp_pos_opens_vacc<L>(Ce)) o[K] = 0.0f;
@@ -755,6 +769,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 opaque_v(o[K]);      // accumulate here (see the value stage)
                 if constexpr (l3 == 1) vacc1[K][R] = o[K]; else if constexpr (l3 == 2) vacc2[K][R] = o[K]; else vacc3[K][R] = o[K];
             });
+            }
         });
     };
 
@@ -1148,7 +1163,11 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         using Cg = CG<l1, l2, l3>;
         float m[Cg::NM];
         Cg::make(Y.template get<l2>(), m);
+        constexpr int R_LAST = pad_reg<L>(l3, NR - 1) ? NR - 3 : NR - 1;      // last register that holds a true channel
         static_for<NR>([&]<int R>() {
+            if constexpr (pad_reg<L>(l3, R)) {      // a zero-padding output channel: nothing to contract
+                if constexpr (val_item_opens_group<L>(I)) static_for<d3>([&]<int K>() { if constexpr (l3 == 3) val3[K][R] = 0.0f; });
+            } else {
             float o[d3];
             static_for<d3>([&]<int K>() {
                 if constexpr (l3 == 0) o[K] = val0[it.t][R];
@@ -1164,7 +1183,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 opaque_v(o[K]);
                 if constexpr (l3 == 0) val0[it.t][R] = o[K]; else if constexpr (l3 == 1) val1[K][R] = o[K]; else if constexpr (l3 == 2) val2[K][R] = o[K]; else val3[K][R] = o[K];
             });
-            if constexpr (R == NR - 1) tok = o[0];
+            if constexpr (R == R_LAST) tok = o[0];
+            }
         });
     };
     static_for<PDV>([&]<int I>() { load_A_of.template operator()<I>(); });

@@ -204,6 +204,11 @@ template <int L> DEDF_HD constexpr int park_slot(int l, int i, int c) {
     return q + i * (mul_of(l) / 16) + c;
 }
 template <int L> DEDF_HD constexpr int park_slots() { return park_slot<L>(L + 1, 0, 0); }          // 15 (L = 2), 10 (L = 1)
+// Zero padding inside a 16-channel block (lmax 3: 8x3e as 16x3e, true channels at pad_pos = the first two of every group of four): of the 8
+// registers that hold a 16-row block in either half-wave, and of the 4 channels of a lane's run of source rows, those with index % 4 >= 2 are
+// padding -- exactly 0 in every operand and result (and in every narrower UNet level, whose true channels are a subset).  The lane-local
+// Clebsch-Gordan work skips them.
+template <int L> DEDF_HD constexpr bool pad_reg(int l, int r) { return L == 3 && mul_of(l) != true_mul(l) && (r % 4) >= true_mul(l) / 4; }
 // The l3 >= 2 accumulators of the first depth-wise TP's linear at lmax 3 hold two components per 32-row tile (dedf_edge.h::mfma_chunk):
 // 48 + 64 instead of 80 + 112 accumulator registers in the groups where k_edge<3> spills.
 #ifndef DEDF_PAIR_L2

@@ -1,7 +1,12 @@
 # scratch driver of one gpurun call (edited per session): results under gpurun_out/
 mkdir -p gpurun_out
-python -m pytest tests/test_lmax3.py -m gpu -x -q 2>&1 | tail -5 > gpurun_out/r03q_test_lmax3.log; tail -3 gpurun_out/r03q_test_lmax3.log
-python bench.py --lmax 3 --no-cpu-baseline > gpurun_out/r03q_lmax3_bench.json 2> gpurun_out/r03q_lmax3_bench.err
-python -c "
-import json
-d=json.loads(open('gpurun_out/r03q_lmax3_bench.json').read().strip().splitlines()[-1]); print('lmax3', d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['config'].get('score_fwd_ms_at_t0.5'), d['config'].get('feature_extractors_ms'), d['config'].get('small_batches_50_steps'))"
+R=${GRAFT_REPO_ROOT:-/root/repo}
+bash profiles/collect.sh r03s "trace fetch write sq sq2 sq3 tcp bench"
+CMD="python $R/bench.py --lmax 3 --steps 5 --warmup 1 --no-cpu-baseline --no-extractors --no-small-batches" bash profiles/collect.sh r03s_lmax3 "trace fetch write sq sq2"
+cd $R
+python profiles/summarize.py r03s > gpurun_out/r03s_summarize.log 2>&1
+python profiles/summarize.py r03s_lmax3 > gpurun_out/r03s_lmax3_summarize.log 2>&1
+cp profiles/r03s* gpurun_out/ 2>/dev/null
+du -sh gpurun_out
+rm -rf gpurun_out/*_trace gpurun_out/*_pmc_fetch gpurun_out/*_pmc_write gpurun_out/*_pmc_sq gpurun_out/*_pmc_sq2 gpurun_out/*_pmc_sq3 gpurun_out/*_pmc_tcp
+du -sh gpurun_out; ls gpurun_out

@@ -32,8 +32,8 @@ def timed(fn, reps):
 
 
 fp = lambda x, f: FeaturedPoints(x=x.to(dev), f=f.to(dev), b=torch.zeros(len(x), dtype=torch.long, device=dev), w=None)
-for kind in ("panda_lowres", "sapien_lowres"):
-    m = UnetFeatureExtractor(**_unet_kwargs(kind), deterministic=True).to(dev)
+for kind in ("panda_lowres", "sapien_lowres", "panda_lowres_lmax3"):      # the last one: BASELINE config 5 as written (16 k points, lmax 3)
+    m = UnetFeatureExtractor(**(synthetic.unet_kwargs(kind) if kind.endswith("_lmax3") else _unet_kwargs(kind)), deterministic=True).to(dev)
     x = torch.from_numpy(synthetic.make_scene(n_scene, seed=0).astype(np.float32))
     pcd = fp(x, torch.rand(n_scene, 3))
     t0 = time.perf_counter(); m(pcd); torch.cuda.synchronize()
