@@ -342,7 +342,9 @@ def main():
                                                 ("C2 inputs at lmax 3 (the degree BASELINE config 5 names)" if (args.lmax, args.scene, args.grasp) == (3, 4096, 1024) else "custom"))
         traffic, traffic_src, mfma_issued = None, None, None
         # (files are named per round, r01i < r02h < r03i ...: the last one in name order that holds the HBM passes of the headline kernel wins)
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9][a-z]_pmc_summary.json"))) if default_workload else []:
+        lmax3_workload = (args.lmax, args.scene, args.grasp, args.poses_per_gpu) == (3, 4096, 1024, 1000) and not args.half and not args.no_radial_table
+        pmc_glob = "r[0-9][0-9][a-z]_pmc_summary.json" if default_workload else ("r[0-9][0-9][a-z]_lmax3_pmc_summary.json" if lmax3_workload else None)
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pmc_glob))) if pmc_glob else []:
             try:
                 doc = json.load(open(f))
                 v = doc.get("edge_kernel_hbm_bytes_per_launch")
