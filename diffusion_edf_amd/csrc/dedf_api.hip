@@ -340,6 +340,16 @@ template <auto Kernel, int Cap = 4> int waves_per_cu() {
 }
 #define DEDF_LAUNCH_PERSISTENT(KERNEL, MAX_BLOCKS, ST, ARG) \
     hipLaunchKernelGGL((KERNEL), dim3(std::min<int>((MAX_BLOCKS), h->n_cu * std::min(edge_wpc_limit(), waves_per_cu<(KERNEL)>()))), dim3(64), 0, ST, ARG)
+// A grid whose tile count is known on the host (the node kernel): the persistent waves run ceil(tiles / resident waves) rounds either way, so
+// launch only as many waves as fill those rounds EVENLY (C2: 3 219 node tiles on 1 024 resident waves = 4 rounds, the last one a seventh full;
+// 805 waves run the same 4 rounds with 3.1 instead of 4 waves per CU sharing the L1: k_node 0.292 -> 0.285 ms, profiles/r03t_node_balanced_ab.log).
+// DEDF_NODE_BALANCED=0 restores the full grid (A/B).
+inline int balanced_blocks(int tiles, int cap) {
+    static const bool on = [] { const char* e = getenv("DEDF_NODE_BALANCED"); return !(e && atoi(e) == 0); }();
+    if (!on || tiles <= cap) return tiles;
+    const int rounds = (tiles + cap - 1) / cap;
+    return (tiles + rounds - 1) / rounds;
+}
 inline int edge_wpc_limit() {      // experiments only: DEDF_EDGE_WAVES_PER_CU=1..4
     static const int wpc = [] { const char* e = getenv("DEDF_EDGE_WAVES_PER_CU"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 4 ? v : 4; }();
     return wpc;
@@ -625,9 +635,9 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         if ((h->debug || h->want_field) && h->d_dbge.ensure((size_t)Nd * D * 4) && h->d_dbgf.ensure((size_t)Nd * D * 4)) { P.dbg_emb = h->d_dbge.as<float>(); P.dbg_field = h->d_dbgf.as<float>(); }
         else if (h->want_field) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(field) failed");
         const int ntiles = (Nd + 31) / 32;
-        if constexpr (L == 3) DEDF_LAUNCH_PERSISTENT((k_node<L, EBM>), ntiles, st, P);
-        else if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_node<L, EBM, true>), ntiles, st, P);
-        else DEDF_LAUNCH_PERSISTENT((k_node<L, EBM>), ntiles, st, P);
+        if constexpr (L == 3) DEDF_LAUNCH_PERSISTENT((k_node<L, EBM>), ntiles, st, P);      // (balanced grid measured at lmax 3: 0.477 -> 0.482 ms, not used)
+        else if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_node<L, EBM, true>), balanced_blocks(ntiles, h->n_cu * waves_per_cu<(k_node<L, EBM, true>)>()), st, P);
+        else DEDF_LAUNCH_PERSISTENT((k_node<L, EBM>), balanced_blocks(ntiles, h->n_cu * waves_per_cu<(k_node<L, EBM>)>()), st, P);
     }
     mark();
     // 7. per-pose reduction
@@ -1075,8 +1085,8 @@ int layer_forward_impl(dedf_handle* h, int n_src, const float* x_src, const floa
         P.sc = o.sc;
         P.o_b_proj0 = o.o_b_proj0; P.o_ln_b0 = o.o_ln_b0; P.o_b_f1 = o.o_b_f1; P.o_b_f2 = o.o_b_f2;
         const int ntiles = (n_dst + 31) / 32;
-        if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_node<L, false, true, true>), ntiles, st, P);
-        else DEDF_LAUNCH_PERSISTENT((k_node<L, false, false, true>), ntiles, st, P);
+        if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_node<L, false, true, true>), balanced_blocks(ntiles, h->n_cu * waves_per_cu<(k_node<L, false, true, true>)>()), st, P);
+        else DEDF_LAUNCH_PERSISTENT((k_node<L, false, false, true>), balanced_blocks(ntiles, h->n_cu * waves_per_cu<(k_node<L, false, false, true>)>()), st, P);
     }
     if (h->defer_check) {          // chains of layers: the verdict of the edge-list check is kept on the device for dedf_layer_check
         if (!w->d_sticky.p) {

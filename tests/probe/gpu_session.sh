@@ -1,12 +1,6 @@
 # scratch driver of one gpurun call (edited per session): results under gpurun_out/
 mkdir -p gpurun_out
-R=${GRAFT_REPO_ROOT:-/root/repo}
-bash profiles/collect.sh r03s "trace fetch write sq sq2 sq3 tcp bench"
-CMD="python $R/bench.py --lmax 3 --steps 5 --warmup 1 --no-cpu-baseline --no-extractors --no-small-batches" bash profiles/collect.sh r03s_lmax3 "trace fetch write sq sq2"
-cd $R
-python profiles/summarize.py r03s > gpurun_out/r03s_summarize.log 2>&1
-python profiles/summarize.py r03s_lmax3 > gpurun_out/r03s_lmax3_summarize.log 2>&1
-cp profiles/r03s* gpurun_out/ 2>/dev/null
-du -sh gpurun_out
-rm -rf gpurun_out/*_trace gpurun_out/*_pmc_fetch gpurun_out/*_pmc_write gpurun_out/*_pmc_sq gpurun_out/*_pmc_sq2 gpurun_out/*_pmc_sq3 gpurun_out/*_pmc_tcp
-du -sh gpurun_out; ls gpurun_out
+run() { DEDF_NODE_BALANCED=$1 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extractors --no-small-batches 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['roofline'].get('kernel_ms_per_step') or {}; print('balanced=$1', round(d['value']), round(d['ms_per_step'],4), {a: round(b,4) for a,b in k.items()})"; }
+for i in 1 2 3; do run 0; run 1; done 2>&1 | tee gpurun_out/r03t_node_balanced_ab.log
+run3() { DEDF_NODE_BALANCED=$1 python bench.py --lmax 3 --steps 20 --warmup 3 --no-cpu-baseline --no-extractors --no-small-batches 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['roofline'].get('kernel_ms_per_step') or {}; print('lmax3 balanced=$1', round(d['value']), round(d['ms_per_step'],4), {a: round(b,4) for a,b in k.items()})"; }
+for i in 1 2; do run3 0; run3 1; done 2>&1 | tee -a gpurun_out/r03t_node_balanced_ab.log
