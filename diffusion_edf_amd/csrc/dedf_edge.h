@@ -618,7 +618,10 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
 #ifndef DEDF_R2S_LDS2
 #define DEDF_R2S_LDS2 0
 #endif
-    constexpr int NCHK = WN / 16, PDA = L == 3 ? DEDF_PDA3 : 3;
+#ifndef DEDF_PDA2
+#define DEDF_PDA2 3
+#endif
+    constexpr int NCHK = WN / 16, PDA = L == 3 ? DEDF_PDA3 : DEDF_PDA2;
     struct XOps { f32x4 x[2][2 * L + 1]; f32x4 xd[UN ? 2 : 1][2 * L + 1]; };
     auto load_X = [&]<int C>() {      // this lane's 2 x 4 source-message rows of the chunk (contiguous runs in the reference layout)
         XOps o{};
