@@ -1053,7 +1053,11 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         const float cross = (col >= 16 && seg_start < 16) ? 1.0f : 0.0f;
         static_for<NS>([&]<int n>() { scan_step.template operator()<4>(x[n], cross); });
         float* const orec = orec_of();
+#if defined(DEDF_TIMING_NO_RECORDS)      // timing experiment only (wrong results): everything is computed, no segment record leaves the kernel
+        if (seg_last && P.nQ < 0) static_for<NS>([&]<int n>() { st4(orec + rec_off[n], f32x4{x[n][0], x[n][1], x[n][2], x[n][3]} * inv[n]); });
+#else
         if (seg_last) static_for<NS>([&]<int n>() { st4(orec + rec_off[n], f32x4{x[n][0], x[n][1], x[n][2], x[n][3]} * inv[n]); });
+#endif
     };
     auto store_group = [&]<int l3>() {       // value in internal layout [l][m][channel]; head of a channel = channel / (mul / 4)
         const f32x4 pwv = pk[SPW * 64], ivv = pk[(SPW + 1) * 64];
