@@ -328,8 +328,8 @@ void launch_time_bias(dedf_handle* h, hipStream_t st, const float* time, int tim
     hipLaunchKernelGGL(k_time_bias, dim3(rows, c.n_scales), dim3(256), 0, st, tp);
 }
 
-// Persistent grids: as many waves per CU as are RESIDENT at once (4 for the 512-register kernels with <= 40 KB of LDS; the lmax-3 kernels park
-// 44-46 KB per wave and fit 3 or 2).  A grid larger than that runs in rounds and the last, partly filled round costs a whole one.
+// Persistent grids: as many waves per CU as are RESIDENT at once (4 for the 512-register kernels with <= 40 KB of LDS -- every k_edge / k_node
+// since the lmax-3 edge kernels went from 52 to 39.5 KB; the occupancy query stays: it is what sized their grids at 3 and 2 before).  A grid larger than that runs in rounds and the last, partly filled round costs a whole one.
 template <auto Kernel, int Cap = 4> int waves_per_cu() {
     static const int n = [] {
         int v = 0;
