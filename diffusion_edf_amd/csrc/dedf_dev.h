@@ -135,6 +135,9 @@ struct Wave {            // per-lane constants of the transposed-GEMM layout
                          // are padding are then fetched by half the lanes only (an out-of-range buffer load returns 0 without a fetch)
     int lane16_r16up;    // the same 16 rows placed as rows 16-31 of the tile: lanes of rows 16-31 fetch what the lane 16 below them would
     Buf w;               // all packed weights / row vectors of the launch
+#if defined(DEDF_TIMING_W_NONE)
+    f32x4 dummy;         // timing experiment: stands in for every weight operand
+#endif
 };
 DEDF_DEV Wave make_wave(const void* wbuf, uint32_t wbytes) {
     Wave wv;
@@ -143,7 +146,27 @@ DEDF_DEV Wave make_wave(const void* wbuf, uint32_t wbytes) {
     wv.lane16_r16 = wv.col < 16 ? wv.lane16 : 0x7ffffff0;
     wv.lane16_r16up = wv.col >= 16 ? wv.lane16 - 256 : 0x7ffffff0;
     wv.w = make_buf(wbuf, wbytes);
+#if defined(DEDF_TIMING_W_NONE) && defined(__HIP_DEVICE_COMPILE__)
+    wv.dummy = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+    asm volatile("" : "+v"(wv.dummy));
+#endif
     return wv;
+}
+// A operand of the fused stage's weight streams (layer 3, lin / sep_alpha, value).  Two timing-only builds (wrong results) bound what ANY redesign
+// of the weight path could gain: DEDF_TIMING_W_SAME -- every request reads the first KiB of the image (same instruction count, same bytes
+// through the vector L1, no L2 -> L1 traffic); DEDF_TIMING_W_NONE -- no request at all, the operand is a register the wave already holds.
+DEDF_DEV f32x4 bldw(const Wave& wv, int voff_bytes, int soff_bytes) {
+#if defined(DEDF_TIMING_W_NONE) && defined(__HIP_DEVICE_COMPILE__)
+    (void)voff_bytes; (void)soff_bytes;
+    return wv.dummy;
+#elif defined(DEDF_TIMING_W_SAME) && defined(__HIP_DEVICE_COMPILE__)
+    int z = 0;
+    asm volatile("" : "+s"(z));      // (opaque: the requests must not be merged)
+    (void)soff_bytes;
+    return bld4(wv.w, voff_bytes, z);
+#else
+    return bld4(wv.w, voff_bytes, soff_bytes);
+#endif
 }
 // A operands of 4 consecutive K-steps (group g) of out tile To; matrix at float offset `off`, nG groups per tile
 DEDF_DEV f32x4 lda(const Wave& wv, int off, int nG, int To, int g) {

@@ -176,11 +176,11 @@ DEDF_DEV AItem load_item(const Wave& wv, int o_str) {
             constexpr int l3 = dtp_pos_l3<L>(it.pos);
             constexpr bool half_rows = l3 >= 2 || (l3 == 0 && NT0 == r0_tiles<L>() && lin0_rows<L>() % 32 == 16 && 2 * it.t + n == lin0_rows<L>() / 32);
             const int lv = half_rows ? wv.lane16_r16 : wv.lane16;
-            a.h[n] = bld4(wv.w, lv, (o_str + (it.slot + n) * 512) * 4);
-            if constexpr (!HP) a.l[n] = bld4(wv.w, lv, (o_str + (it.slot + n) * 512 + 256) * 4);
+            a.h[n] = bldw(wv, lv, (o_str + (it.slot + n) * 512) * 4);
+            if constexpr (!HP) a.l[n] = bldw(wv, lv, (o_str + (it.slot + n) * 512 + 256) * 4);
             if constexpr (acc_paired<L>(l3)) {      // the same 16 rows once more, as rows 16-31 of the tile (odd components / second tile half)
-                a.h[1] = bld4(wv.w, wv.lane16_r16up, (o_str + it.slot * 512) * 4);
-                if constexpr (!HP) a.l[1] = bld4(wv.w, wv.lane16_r16up, (o_str + it.slot * 512 + 256) * 4);
+                a.h[1] = bldw(wv, wv.lane16_r16up, (o_str + it.slot * 512) * 4);
+                if constexpr (!HP) a.l[1] = bldw(wv, wv.lane16_r16up, (o_str + it.slot * 512 + 256) * 4);
             }
         });
     }
@@ -587,7 +587,12 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     const Buf msgb = make_buf(P.msg, P.msg_bytes);
     const Buf msgd = make_buf(P.msg_dst, P.msg_dst_bytes);      // UNet layer: the destination's message is added (block.py:155)
     // per-l1 lane offsets of the 4 message rows this lane owns inside an 8-row group
-    const int mv0 = src * (D * 4) + hi * 16, mv1 = src * (D * 4) + hi * 48, mv2 = src * (D * 4) + hi * 80, mv3 = src * (D * 4) + hi * 112;
+#if defined(DEDF_TIMING_X_SAME)      // timing experiment only (wrong results): every edge gathers the source rows of key 0 (L1-resident)
+    const int srcx = 0;
+#else
+    const int srcx = src;
+#endif
+    const int mv0 = srcx * (D * 4) + hi * 16, mv1 = srcx * (D * 4) + hi * 48, mv2 = srcx * (D * 4) + hi * 80, mv3 = srcx * (D * 4) + hi * 112;
     const int dv0 = dst * (D * 4) + hi * 16, dv1 = dst * (D * 4) + hi * 48, dv2 = dst * (D * 4) + hi * 80, dv3 = dst * (D * 4) + hi * 112;
     // LDS parking: the gated features wait here as READY-MADE B operands of the value GEMMs: one 16-byte slot per lane holds the
     // fp16 hi halves of a 16-channel chunk (8 accumulator registers), the next slot their fp16 residuals ([slot][lane][8 halves];
@@ -704,8 +709,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         L3Half o{};
         if constexpr (Ph < 2 * NWT) static_for<l3_nk.template operator()<Ph>()>([&]<int k>() {
             constexpr int unit = KC == 4 ? 2 * Ph + k : 2 * (Ph / 2) + k;
-            o.h[k] = bld4(wv.w, wv.lane16, (o_A_r3 + unit * 256) * 4);
-            if constexpr (!HP) o.l[k] = bld4(wv.w, wv.lane16, (o_A_r3_l + unit * 256) * 4);
+            o.h[k] = bldw(wv, wv.lane16, (o_A_r3 + unit * 256) * 4);
+            if constexpr (!HP) o.l[k] = bldw(wv, wv.lane16, (o_A_r3_l + unit * 256) * 4);
         });
         return o;
     };
@@ -928,6 +933,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         mfma_chunk<L, NR0, C, HP>(wv, o_S_lin, ring, b_cur, acc0, acc1, acc2, acc3, go);
         if constexpr (fin_out) contract_out.template operator()<C - 1>(gfin);
         static_for<L + 1>([&]<int g>() { if constexpr (C == dtp_group_end<L>(g)) finish_group.template operator()<g>(); });
+#if defined(DEDF_SGB) && defined(__HIP_DEVICE_COMPILE__)      // experiment: ask hipcc for one MFMA per DEDF_SGB VALU instructions inside the region
+        static_for<28>([&]<int i>() { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, DEDF_SGB, 0); });
+#endif
         sched_fence();
         if constexpr (Ph % 2 == 1 && T3 < NWT) dump_w.template operator()<T3>(wbuf[T3 % 2]);
         x_nxt = x_nn; b_cur = b_nxt;
@@ -1126,8 +1134,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     auto load_A = [&]<int S>() {
         if constexpr (S < val_num_slots<L>()) {
             const int lv = mul_of(val_slot_l3<L>(S)) < 32 ? lane16_r16_t : lane16_t;      // rows 16-31 are padding: half the lanes fetch
-            aring[S % RS].h = bld4(wv.w, lv, (o_S_val + S * 512) * 4);
-            if constexpr (!HP) aring[S % RS].l = bld4(wv.w, lv, (o_S_val + S * 512 + 256) * 4);
+            aring[S % RS].h = bldw(wv, lv, (o_S_val + S * 512) * 4);
+            if constexpr (!HP) aring[S % RS].l = bldw(wv, lv, (o_S_val + S * 512 + 256) * 4);
         }
     };
     auto load_A_of = [&]<int I>() {
@@ -1211,6 +1219,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             constexpr int ge = val_item<L>(F).group_end;
             if constexpr (ge >= 0 && ge < L) store_group.template operator()<ge>();
         }
+#if defined(DEDF_SGB) && defined(__HIP_DEVICE_COMPILE__)
+        static_for<10>([&]<int i>() { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, DEDF_SGB, 0); });
+#endif
         sched_fence();
         vb_cur = b_nxt;
         if constexpr (F >= 0 && val_item<L>(F).group_end == 0) DEDF_STAMP(10);
