@@ -445,8 +445,40 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         f32x16 gacc = node_ldrows(rows, hi, tp == 0 ? NR::b_sl0 : NR::b_sl1, 0);
         f32x16 vacc[3];
         static_for<3>([&]<int K>() { static_for<16>([&]<int R>() { vacc[K][R] = 0.0f; }); });
+#ifndef DEDF_NODE_HOIST_ROT
+#define DEDF_NODE_HOIST_ROT 1
+#endif
+        // The query feature rows of one degree, rotated by D^{l1}(q), are the same for every path with that input degree: the paths are walked
+        // grouped by l1 and the rotation (9 / 25 / 49 multiply-adds per channel) is done once per group instead of once per path.
+        static_for<(DEDF_NODE_HOIST_ROT ? L + 1 : 1)>([&]<int l1h>() {
+        constexpr int dh = 2 * l1h + 1, NToh = cdiv(mul_of(l1h), 32);
+        float xq[DEDF_NODE_HOIST_ROT ? NToh : 1][2][2][4][DEDF_NODE_HOIST_ROT ? dh : 1];
+        if constexpr (DEDF_NODE_HOIST_ROT) {
+            const int qv = l1h == 0 ? qv0 : (l1h == 1 ? qv1 : (l1h == 2 ? qv2 : qv3));
+            static_for<NToh>([&]<int To>() { static_for<imin(2, (mul_of(l1h) - 32 * To) / 16)>([&]<int cc>() { static_for<2>([&]<int run>() {
+                constexpr int u0 = 32 * To + 16 * cc;
+                float xr[4 * dh];
+                static_for<dh>([&]<int Q>() {
+                    const f32x4 t = bld4(qfb, qv, (blk_off(l1h) + (u0 + 8 * run) * dh + 4 * Q) * 4);
+                    xr[4 * Q] = t[0]; xr[4 * Q + 1] = t[1]; xr[4 * Q + 2] = t[2]; xr[4 * Q + 3] = t[3];
+                });
+                static_for<4>([&]<int j>() {
+                    if constexpr (l1h == 0) xq[To][cc][run][j][0] = xr[j];
+                    else if constexpr (l1h == 1) static_for<3>([&]<int I>() {
+                        xq[To][cc][run][j][I] = D1[3 * I] * xr[3 * j] + D1[3 * I + 1] * xr[3 * j + 1] + D1[3 * I + 2] * xr[3 * j + 2]; });
+                    else if constexpr (l1h == 2) static_for<5>([&]<int I>() {
+                        xq[To][cc][run][j][I] = D2[5 * I] * xr[5 * j] + D2[5 * I + 1] * xr[5 * j + 1] + D2[5 * I + 2] * xr[5 * j + 2] +
+                                                D2[5 * I + 3] * xr[5 * j + 3] + D2[5 * I + 4] * xr[5 * j + 4]; });
+                    else static_for<7>([&]<int I>() {
+                        float t = 0.0f;
+                        static_for<7>([&]<int J>() { t += D3[7 * I + J] * xr[7 * j + J]; });
+                        xq[To][cc][run][j][I] = t; });
+                });
+            }); }); });
+        }
         static_for<stp_num_paths<L>()>([&]<int p>() {
             constexpr PathInfo pi = stp_path<L>(p);
+            if constexpr (!DEDF_NODE_HOIST_ROT || pi.l1 == l1h) {
             constexpr int l1 = pi.l1, l2 = pi.l2, l3 = pi.l3;
             constexpr int d1 = 2 * l1 + 1, d2 = 2 * l2 + 1, d3 = 2 * l3 + 1;
             constexpr int NCK = pi.mul2 / 16;             // K chunks over v
@@ -471,13 +503,17 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
                     static_for<2>([&]<int run>() {
                         // query feature rows u0 + 8 run + 4 hi + j (reference layout), rotated by D^{l1}(q)
                         float xr[4 * d1];
+                        if constexpr (!DEDF_NODE_HOIST_ROT) {
                         const int qv = l1 == 0 ? qv0 : (l1 == 1 ? qv1 : (l1 == 2 ? qv2 : qv3));
                         static_for<d1>([&]<int Q>() {
                             const f32x4 t = bld4(qfb, qv, (blk_off(l1) + (u0 + 8 * run) * d1 + 4 * Q) * 4);
                             xr[4 * Q] = t[0]; xr[4 * Q + 1] = t[1]; xr[4 * Q + 2] = t[2]; xr[4 * Q + 3] = t[3];
                         });
+                        }
                         static_for<4>([&]<int j>() {
                             float x[d1], y[d2], m[C::NM], o[d3];
+                            if constexpr (DEDF_NODE_HOIST_ROT) static_for<d1>([&]<int I>() { x[I] = xq[To][cc][run][j][I]; });
+                            else
                             if constexpr (l1 == 0) x[0] = xr[j];
                             else if constexpr (l1 == 1) static_for<3>([&]<int I>() {
                                 x[I] = D1[3 * I] * xr[3 * j] + D1[3 * I + 1] * xr[3 * j + 1] + D1[3 * I + 2] * xr[3 * j + 2]; });
@@ -512,6 +548,8 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
                 (void)NCL;
                 sched_fence();
             });
+            }
+        });
         });
         // Gate (sigmoid on the 32 gates) and mean over the 32 1e channels (score_head.py:196-199)
         const float cg = opaque_s(P.sc.sl[tp][0]), cvv = opaque_s(P.sc.sl[tp][1]) * (1.0f / 32);
