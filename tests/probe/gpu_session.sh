@@ -1,5 +1,12 @@
 # scratch driver of one gpurun call (edited per session): results under gpurun_out/
 mkdir -p gpurun_out
-DEDF_LIB=diffusion_edf_amd/csrc/libdedf_nodehoist.so python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "score_parity or sampler_parity or full_size_c2_anchored or half_precision_mode or randomised" 2>&1 | tail -4
-run() { DEDF_LIB=diffusion_edf_amd/csrc/libdedf$1.so python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extractors 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['roofline']['kernel_ms_per_step']; print('lib$1', round(d['value']), round(d['ms_per_step'],4), 'node', round(k['node'],4), d['config']['small_batches_50_steps']['16 poses']['ms_per_step'])"; }
-for i in 1 2 3; do run ""; run _nodehoist; done 2>&1 | tee gpurun_out/r03u_node_hoist_ab.log
+python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/r03u_gpu_suite.log; tail -3 gpurun_out/r03u_gpu_suite.log
+python bench.py > gpurun_out/r03u_bench.json 2> gpurun_out/r03u_bench.err
+python bench.py --lmax 3 > gpurun_out/r03u_lmax3_bench.json 2> gpurun_out/r03u_lmax3_bench.err
+python bench.py --lmax 1 --scene 2048 --grasp 512 --poses-per-gpu 256 --steps 50 --no-cpu-baseline > gpurun_out/r03u_c1_bench.json 2> gpurun_out/r03u_c1_bench.err
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r03u_smoke.log 2>&1; tail -2 gpurun_out/r03u_smoke.log
+python tests/probe/small_batch.py > gpurun_out/r03u_small_batch.log 2>&1; tail -5 gpurun_out/r03u_small_batch.log
+python -c "
+import json
+for f in ['gpurun_out/r03u_bench.json','gpurun_out/r03u_lmax3_bench.json','gpurun_out/r03u_c1_bench.json']:
+    d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['roofline'].get('kernel_ms_per_step'), d['config'].get('small_batches_50_steps'))"
