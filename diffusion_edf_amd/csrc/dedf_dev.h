@@ -170,7 +170,7 @@ DEDF_DEV f32x4 bldw(const Wave& wv, int voff_bytes, int soff_bytes) {
 }
 // A operands of 4 consecutive K-steps (group g) of out tile To; matrix at float offset `off`, nG groups per tile
 DEDF_DEV f32x4 lda(const Wave& wv, int off, int nG, int To, int g) {
-    return bld4(wv.w, wv.lane16, (off + (To * nG + g) * 256) * 4);
+    return bldw(wv, wv.lane16, (off + (To * nG + g) * 256) * 4);
 }
 // acc tile <- 16 per-row values stored [tile][hi][r] at float offset `off`
 DEDF_DEV f32x16 ldrows(const Buf& b, int voff_hi64, int off, int tile) {
@@ -338,8 +338,8 @@ DEDF_DEV void dense_rot_h(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[NT
         if constexpr (c + PD < NCH) {
             const int lv = tie(wv.lane16, __builtin_bit_cast(f32x4, b.hi)[0]);
             static_for<NTO>([&]<int To>() {
-                ring.h[c % PD][To] = bld4(wv.w, lv, (off_h + (To * NCH + c + PD) * 256) * 4);
-                if constexpr (!HP) ring.l[c % PD][To] = bld4(wv.w, lv, (off_l + (To * NCH + c + PD) * 256) * 4);
+                ring.h[c % PD][To] = bldw(wv, lv, (off_h + (To * NCH + c + PD) * 256) * 4);
+                if constexpr (!HP) ring.l[c % PD][To] = bldw(wv, lv, (off_l + (To * NCH + c + PD) * 256) * 4);
             });
         }
         static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, ch[To]), b.hi, acc[To]); });
@@ -376,8 +376,8 @@ DEDF_DEV void dense_rot_hp(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[N
         if constexpr (c + PD < NCH) {
             const int lv = tie(wv.lane16, __builtin_bit_cast(f32x4, b.hi)[0]);
             static_for<NTO>([&]<int To>() {
-                rh[c % PD][To] = bld4(wv.w, lv, (off_h + (To * NCH + c + PD) * 256) * 4);
-                if constexpr (!HP) rl[c % PD][To] = bld4(wv.w, lv, (off_l + (To * NCH + c + PD) * 256) * 4);
+                rh[c % PD][To] = bldw(wv, lv, (off_h + (To * NCH + c + PD) * 256) * 4);
+                if constexpr (!HP) rl[c % PD][To] = bldw(wv, lv, (off_l + (To * NCH + c + PD) * 256) * 4);
             });
         }
         static_for<NTO>([&]<int To>() { acc[To] = mfma_h(__builtin_bit_cast(h8, ch[To]), b.hi, acc[To]); });
@@ -395,7 +395,7 @@ DEDF_DEV void dense_shared_hp(const Wave& wv, int off_h, int off_l, int nCH, int
     f32x4 rh[PD], rl[PD] = {};
     sched_fence();
     static_for<PD>([&]<int k>() { if constexpr (k < NCH) {
-        rh[k] = bld4(wv.w, wv.lane16, (off_h + (To * nCH + k) * 256) * 4); if constexpr (!HP) rl[k] = bld4(wv.w, wv.lane16, (off_l + (To * nCH + k) * 256) * 4); } });
+        rh[k] = bldw(wv, wv.lane16, (off_h + (To * nCH + k) * 256) * 4); if constexpr (!HP) rl[k] = bldw(wv, wv.lane16, (off_l + (To * nCH + k) * 256) * 4); } });
     static_for<NCH>([&]<int c>() {
         const h8 ch = __builtin_bit_cast(h8, rh[c % PD]), cl = __builtin_bit_cast(h8, rl[c % PD]);
         sched_fence();
@@ -403,8 +403,8 @@ DEDF_DEV void dense_shared_hp(const Wave& wv, int off_h, int off_l, int nCH, int
         static_for<NM>([&]<int m>() { b[m] = bh.template operator()<m, c>(); });
         if constexpr (c + PD < NCH) {
             const int lv = tie(wv.lane16, __builtin_bit_cast(f32x4, b[0].hi)[0]);
-            rh[c % PD] = bld4(wv.w, lv, (off_h + (To * nCH + c + PD) * 256) * 4);
-            if constexpr (!HP) rl[c % PD] = bld4(wv.w, lv, (off_l + (To * nCH + c + PD) * 256) * 4);
+            rh[c % PD] = bldw(wv, lv, (off_h + (To * nCH + c + PD) * 256) * 4);
+            if constexpr (!HP) rl[c % PD] = bldw(wv, lv, (off_l + (To * nCH + c + PD) * 256) * 4);
         }
         static_for<NM>([&]<int m>() { acc[m] = mfma_h(ch, b[m].hi, acc[m]); });
         if constexpr (!HP) {
@@ -459,10 +459,10 @@ DEDF_DEV void dense_shared(const Wave& wv, int off, int nG, int To, int g0, f32x
 template <int N, int PD, class SoffF, class BodyF>
 DEDF_DEV void a_stream(const Wave& wv, SoffF&& soff, BodyF&& body) {
     f32x4 ring[PD];
-    static_for<PD>([&]<int I>() { if constexpr (I < N) ring[I] = bld4(wv.w, wv.lane16, soff.template operator()<I>()); });
+    static_for<PD>([&]<int I>() { if constexpr (I < N) ring[I] = bldw(wv, wv.lane16, soff.template operator()<I>()); });
     static_for<N>([&]<int I>() {
         const f32x4 a = ring[I % PD];
-        if constexpr (I + PD < N) ring[I % PD] = bld4(wv.w, wv.lane16, soff.template operator()<I + PD>());
+        if constexpr (I + PD < N) ring[I % PD] = bldw(wv, wv.lane16, soff.template operator()<I + PD>());
         sched_fence();
         body.template operator()<I>(a);
         sched_fence();
