@@ -1,8 +1,11 @@
 # scratch driver of one gpurun call (edited per session): results under gpurun_out/
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/r03v_gpu_suite.log; tail -3 gpurun_out/r03v_gpu_suite.log
-python bench.py > gpurun_out/r03v_bench.json 2> gpurun_out/r03v_bench.err
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r03v_smoke.log 2>&1; tail -2 gpurun_out/r03v_smoke.log
-python -c "
-import json
-d=json.loads(open('gpurun_out/r03v_bench.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['roofline'].get('kernel_ms_per_step'))"
+R=${GRAFT_REPO_ROOT:-/root/repo}
+bash profiles/collect.sh r03v "trace fetch write sq sq2 sq3 tcp"
+CMD="python $R/bench.py --lmax 3 --steps 5 --warmup 1 --no-cpu-baseline --no-extractors --no-small-batches" bash profiles/collect.sh r03v_lmax3 "trace fetch write sq sq2"
+cd $R
+python profiles/summarize.py r03v > gpurun_out/r03v_summarize.log 2>&1
+python profiles/summarize.py r03v_lmax3 > gpurun_out/r03v_lmax3_summarize.log 2>&1
+cp profiles/r03v_kernel_stats.txt profiles/r03v_pmc_summary.json profiles/r03v_lmax3_kernel_stats.txt profiles/r03v_lmax3_pmc_summary.json gpurun_out/ 2>/dev/null
+rm -rf gpurun_out/*_trace gpurun_out/*_pmc_fetch gpurun_out/*_pmc_write gpurun_out/*_pmc_sq gpurun_out/*_pmc_sq2 gpurun_out/*_pmc_sq3 gpurun_out/*_pmc_tcp
+ls gpurun_out | head -30
