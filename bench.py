@@ -77,6 +77,38 @@ def build_inputs(lmax, n_scene, n_grasp, n_poses, first_pose, device):
     return kw, cfg, P, keys, query, Ts
 
 
+def build_config5(n_scene, n_grasp, device, reps=3):
+    """BASELINE config 5 as ONE model (synthetic.config5_model_kwargs: reference multiscale_score_model.py:27-112 at lmax 3): the scene cloud goes
+    through the UNet key model, the grasp cloud through the KeypointExtractor query model -- both on the HIP kernels, seeded random-init weights --
+    and the sampler runs on what they return.  Also returns the extractors' ms per forward (outside the timed region)."""
+    import numpy as np
+    from diffusion_edf_amd import agent, synthetic
+    from diffusion_edf_amd.gnn_data import FeaturedPoints
+    model = agent.MultiscaleScoreModel(**synthetic.config5_model_kwargs(), deterministic=True).to(device).eval()
+
+    def cloud(x, seed):
+        x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(device)
+        f = torch.rand(len(x), 3, generator=torch.Generator().manual_seed(seed)).to(device)
+        return FeaturedPoints(x=x, f=f, b=torch.zeros(len(x), dtype=torch.long, device=device), w=None)
+
+    scene, grasp = cloud(synthetic.make_scene(n_scene, seed=0), 0), cloud(synthetic.make_grasp(n_grasp, seed=0), 1)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3, out
+
+    ms_k, keys = timed(lambda: model.get_key_pcd_multiscale(scene))
+    ms_q, query = timed(lambda: model.get_query_pcd(grasp))
+    extract = {"unet_scene": ms_k, "unet_levels": [len(k.x) for k in keys], "keypoint_grasp": ms_q, "keypoints": len(query.x),
+               "irreps": "64x0e+32x1e+16x2e+8x3e", "note": "the model's own key / query extractors at lmax 3 on the workload's clouds"}
+    return model, keys, query, extract
+
+
 def physical_cores():
     """physical cores of this host from lscpu (sockets x cores per socket); None when lscpu is missing"""
     try:
@@ -104,7 +136,7 @@ def cpu_baseline(lmax, n_scene, n_grasp, n_sample_poses=32, t=0.5, budget_s=8.0)
     try:
         for n_thr in sorted({1, min(16, phys), phys}):
             torch.set_num_threads(n_thr)
-            n_p = 4 if n_thr == 1 else n_sample_poses          # the single-thread leg runs a smaller sample (same inputs)
+            n_p = min(4, max(1, n_sample_poses // 4)) if n_thr == 1 else n_sample_poses          # the single-thread leg runs a smaller sample (same inputs)
             R.sample(ocfg, P, Ts[:2], ok, oq, [[t, t]], [1], [0.04], noise=noise[:, :, :2])          # warm-up (builds caches)
             reps, t0 = 0, time.perf_counter()
             while True:
@@ -120,7 +152,7 @@ def cpu_baseline(lmax, n_scene, n_grasp, n_sample_poses=32, t=0.5, budget_s=8.0)
     return dict(value=legs[best]["value"], unit="pose-steps/s", cores=best, kind="port",
                 physical_cores=phys, single_thread_value=legs[1]["value"],
                 legs={str(k): v for k, v in legs.items()},
-                sample=f"1 denoise step at t={t} of the same C2 inputs, fp32 CPU restatement (oracle/restatement.py): "
+                sample=f"1 denoise step at t={t} of the same inputs ({n_scene}-pt scene, lmax {lmax}), fp32 CPU restatement (oracle/restatement.py): "
                        + "; ".join(f"{k} thread(s): {v['reps']} x {v['poses']} poses in {v['seconds']} s" for k, v in legs.items()))
 
 
@@ -190,8 +222,12 @@ def main():
     ap.add_argument("--no-extractors", action="store_true", help="skip the (untimed) feature-extractor measurement")
     ap.add_argument("--no-small-batches", action="store_true", help="skip the (untimed) 16 / 64 / 256-pose rows: profiles/collect.sh, so that per-kernel averages of a trace are those of the timed launches")
     ap.add_argument("--no-radial-table", action="store_true", help="evaluate the radial network's front per edge in the sampler too (A/B; the default tabulates it per step)")
+    ap.add_argument("--config5", action="store_true", help="BASELINE config 5 as one assembled model: lmax 3, 16 384-point scene -> UNet key model -> key clouds 3277/656/132/27, "
+                                                          "1 024-point grasp -> KeypointExtractor -> query EDF, then the sampler; NOT the headline configuration (C2)")
     ap.add_argument("--half", action="store_true", help="half-precision GEMM mode (model.half(), the reference's half_precision knob); NOT the headline configuration")
     args = ap.parse_args()
+    if args.config5:
+        args.lmax, args.scene = 3, 16384
 
     import torch.distributed as dist
     from diffusion_edf_amd import dist as ddist
@@ -214,15 +250,24 @@ def main():
 
     n_total = args.poses_per_gpu * world
     first, _ = ddist.shard_range(n_total, world, rank)
-    kw, cfg, P, keys, query, Ts = build_inputs(args.lmax, args.scene, args.grasp, args.poses_per_gpu, first, device)
-    head = ScoreModelHead(**kw)
-    head.load_state_dict(P)
-    head.to(device)
-    if args.half:
-        head.half()
+    extract5 = None
+    if args.config5:
+        from diffusion_edf_amd import synthetic
+        model, keys, query, extract5 = build_config5(args.scene, args.grasp, device)
+        head = model.score_head
+        Ts = synthetic.make_poses(args.poses_per_gpu, seed=1, first_pose_index=first).to(device)
+        if args.half:
+            head.half()
+    else:
+        kw, cfg, P, keys, query, Ts = build_inputs(args.lmax, args.scene, args.grasp, args.poses_per_gpu, first, device)
+        head = ScoreModelHead(**kw)
+        head.load_state_dict(P)
+        head.to(device)
+        if args.half:
+            head.half()
+        model = ScoreModelBase(head)
     if args.no_radial_table:
         head.set_radial_table(False)
-    model = ScoreModelBase(head)
     head.set_key_clouds(keys)
     head.set_query(query)
 
@@ -310,7 +355,9 @@ def main():
     # outside the timed region too: the step BEFORE the path on clouds of the workload's sizes -- the UNet key model on
     # the scene cloud and the KeypointExtractor query model on the grasp cloud, once per agent.sample in a deployment
     extract = None
-    if rank == 0 and world == 1 and args.lmax in (2, 3) and not args.no_extractors:
+    if extract5 is not None:
+        extract = extract5
+    elif rank == 0 and world == 1 and args.lmax in (2, 3) and not args.no_extractors:
         extract = extractor_times(args.scene, args.grasp, device, lmax=args.lmax)
 
     # outside the timed region as well: the deployment regime of the reference (N_samples = 10 / 20 poses per call, evaluate_real_mug.ipynb:188-190)
@@ -323,11 +370,15 @@ def main():
                 continue
             run(Ts[:n_small], 5, 0)
             torch.cuda.synchronize()
-            ts = time.perf_counter()
-            run(Ts[:n_small], 50, 0)
-            torch.cuda.synchronize()
-            dt_s = time.perf_counter() - ts
-            small[f"{n_small} poses"] = {"ms_per_step": dt_s / 50 * 1e3, "pose_steps_per_s": n_small * 50 / dt_s}
+            reps = []
+            for _ in range(7):          # 7 repetitions of the 50-step call; the median is the figure, the spread is reported beside it
+                ts = time.perf_counter()
+                run(Ts[:n_small], 50, 0)
+                torch.cuda.synchronize()
+                reps.append((time.perf_counter() - ts) / 50 * 1e3)
+            reps.sort()
+            med = reps[len(reps) // 2]
+            small[f"{n_small} poses"] = {"ms_per_step": med, "pose_steps_per_s": n_small / med * 1e3, "min_ms": reps[0], "max_ms": reps[-1], "repetitions": len(reps)}
 
     if rank == 0:
         n_ev = max(1, prof["n_evals"])
@@ -338,12 +389,14 @@ def main():
         peak = PEAK_FP16_MFMA_TFLOPS / (1.0 if args.half else 3.0)
         default_workload = (args.lmax, args.scene, args.grasp, args.poses_per_gpu) == (2, 4096, 1024, 1000)
         default_workload = default_workload and not args.half
-        wname = "C2" if default_workload else ("C1" if (args.lmax, args.scene, args.grasp) == (1, 2048, 512) else
+        wname = "config 5 (one assembled model: UNet key model + KeypointExtractor query model + lmax-3 score head)" if args.config5 else "C2" if default_workload else ("C1" if (args.lmax, args.scene, args.grasp) == (1, 2048, 512) else
                                                 ("C2 inputs at lmax 3 (the degree BASELINE config 5 names)" if (args.lmax, args.scene, args.grasp) == (3, 4096, 1024) else "custom"))
         traffic, traffic_src, mfma_issued = None, None, None
         # (files are named per round, r01i < r02h < r03i ...: the last one in name order that holds the HBM passes of the headline kernel wins)
         lmax3_workload = (args.lmax, args.scene, args.grasp, args.poses_per_gpu) == (3, 4096, 1024, 1000) and not args.half and not args.no_radial_table
         pmc_glob = "r[0-9][0-9][a-z]_pmc_summary.json" if default_workload else ("r[0-9][0-9][a-z]_lmax3_pmc_summary.json" if lmax3_workload else None)
+        if args.config5:
+            pmc_glob = "r[0-9][0-9][a-z]_config5_pmc_summary.json" if (args.poses_per_gpu == 1000 and not args.half and not args.no_radial_table) else None
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pmc_glob))) if pmc_glob else []:
             try:
                 doc = json.load(open(f))
@@ -389,7 +442,9 @@ def main():
                          "kernel_ms_per_step": {k: v / n_ev for k, v in prof["ms"].items()}},
         }
         if not args.no_cpu_baseline and world == 1:           # the CPU reference leg is timed at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(args.lmax, args.scene, args.grasp)
+            # (config 5: same key / query cloud SIZES and positions from the synthetic generator, random features -- the CPU leg's time does not depend on
+            #  the feature values; a smaller pose sample, ~95 edges per node at this scene)
+            out["cpu_baseline"] = cpu_baseline(args.lmax, args.scene, args.grasp, n_sample_poses=8 if args.scene > 8192 else 32)
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

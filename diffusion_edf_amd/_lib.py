@@ -14,9 +14,10 @@ _LIB_PATH = os.environ.get("DEDF_LIB") or os.path.join(os.path.dirname(os.path.a
 MAX_SCALES = 8
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_RUNTIME = 0, 1, 2, 3
+ABI_VERSION = 3          # DEDF_ABI_VERSION of include/dedf.h this binding mirrors
 
 SYMBOLS = [
-    "dedf_version", "dedf_param_count", "dedf_param_name", "dedf_param_numel", "dedf_create", "dedf_destroy",
+    "dedf_version", "dedf_abi_version", "dedf_struct_size", "dedf_param_count", "dedf_param_name", "dedf_param_numel", "dedf_create", "dedf_destroy",
     "dedf_last_error", "dedf_set_key_clouds", "dedf_set_key_weights", "dedf_set_query", "dedf_score", "dedf_energy", "dedf_sample", "dedf_get_stats",
     "dedf_debug_enable", "dedf_debug_copy", "dedf_debug_packed", "dedf_profile_enable", "dedf_profile_read",
     "dedf_fps", "dedf_radius", "dedf_radius_scratch_bytes", "dedf_layer_forward", "dedf_linear_rs", "dedf_field", "dedf_keypoint_weight", "dedf_layer_defer_check", "dedf_layer_check", "dedf_layer_share_workspace", "dedf_set_radial_table", "dedf_linear_rs_lmax",
@@ -68,6 +69,17 @@ def load() -> C.CDLL:
     lib = C.CDLL(_LIB_PATH)
     P = C.POINTER
     lib.dedf_version.restype = C.c_char_p
+    # the structs below are mirrored by hand: refuse a library built from another version of include/dedf.h (dedf_get_stats and
+    # dedf_profile_read write sizeof(struct) bytes into the caller's memory)
+    if not hasattr(lib, "dedf_abi_version"):
+        raise RuntimeError(f"{_LIB_PATH} predates dedf_abi_version (ABI < 3); rebuild it")
+    lib.dedf_abi_version.restype = C.c_int
+    lib.dedf_struct_size.argtypes = [C.c_int]; lib.dedf_struct_size.restype = C.c_size_t
+    if lib.dedf_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{_LIB_PATH} has ABI version {lib.dedf_abi_version()}, this binding mirrors {ABI_VERSION}; rebuild the library")
+    for which, cls in enumerate((DedfConfig, DedfSchedule, DedfStats, DedfProfile)):
+        if lib.dedf_struct_size(which) != C.sizeof(cls):
+            raise RuntimeError(f"{cls.__name__}: the library's struct has {lib.dedf_struct_size(which)} bytes, the ctypes mirror {C.sizeof(cls)}")
     lib.dedf_param_count.argtypes = [P(DedfConfig)]; lib.dedf_param_count.restype = C.c_int
     lib.dedf_param_name.argtypes = [P(DedfConfig), C.c_int]; lib.dedf_param_name.restype = C.c_char_p
     lib.dedf_param_numel.argtypes = [P(DedfConfig), C.c_int]; lib.dedf_param_numel.restype = C.c_size_t

@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++20 -shared -fPIC -DDEDF_SINGLE_TU dedf_api.hip -o libdedf.so   (gfx950 only, no fallbacks)
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -91,14 +92,19 @@ struct dedf_handle {
     int edge16 = 0;                   // DEDF_EDGE16=1: the sampler's table path on the 16-edge / two-waves-per-SIMD kernel (dedf_edge16.h)
     bool edge16_used = false;
     bool edge_occ = false;            // DEDF_EDGE_OCC=1: lmax-1 score head on the two-waves-per-SIMD build of the edge kernel (A/B)
-    bool small_batch_path = true;     // N_d <= 8 192: word-parallel neighbour masks + fused pose preparation (DEDF_SMALL_BATCH=0 turns it off: A/B, tests)
+    bool small_batch_path = true;     // N_d <= kNbrSmallMax (32 768): word-parallel neighbour masks + fused pose preparation (DEDF_SMALL_BATCH=0 turns it off: A/B, tests)
     bool defer_check = false;         // dedf_layer_defer_check
     DevBuf d_sticky;
     dedf_handle* ws_owner = nullptr;  // dedf_layer_share_workspace: the UNet-layer handle whose per-call workspace (messages, edge lists, segment
                                       // records, aggregate, flags) this layer uses instead of its own
+    std::vector<dedf_handle*> ws_borrowers;   // ... and, on the owner's side, the handles that currently borrow it (detached by dedf_destroy(owner))
     bool want_field = false;          // dedf_field: the node kernel also writes the field / emb of every node
     DevBuf d_Ts, d_time, d_tb, d_pose, d_qpos, d_cnt, d_off, d_blk, d_tile, d_esrc, d_edst, d_eout, d_z, d_nout, d_ang, d_lin, d_T64, d_dbgw, d_dbge, d_dbgf, d_dbgo, d_mask;
     int64_t edge_cap = 0;
+    double est_degree = 0.0;          // dedf_set_key_clouds: sum over the scales of the key points' mean self-degree (k_self_degree) = the edges a query
+                                      // point on the scene surface has; sizes the automatic edge workspace
+    int64_t auto_per_dst = 96;        // automatic edge workspace: edges per destination node (grown by dedf_sample when a call overflowed)
+    DevBuf d_deg;
     int last_nT = 0;
     bool debug = false;
     hipStream_t last_stream = nullptr;
@@ -127,7 +133,7 @@ struct DeviceGuard {
     DeviceGuard dev_guard__((h)->cfg.device);              \
     if (!dev_guard__.ok) return fail(h, DEDF_ERR_RUNTIME, "hipSetDevice failed")
 // clears the sticky status words (overflow, non-finite) at the start of an API call
-#define DEDF_CLEAR_FLAGS(h, st) HIPCK(h, hipMemsetAsync((h)->d_tile.as<int>() + kFlagOverflow, 0, (kFlagEdge16Redo + 1 - kFlagOverflow) * sizeof(int), st))
+#define DEDF_CLEAR_FLAGS(h, st) HIPCK(h, hipMemsetAsync((h)->d_tile.as<int>() + kFlagOverflow, 0, (kFlagTimeVaries + 1 - kFlagOverflow) * sizeof(int), st))
 
 int fail(dedf_handle* h, int code, const std::string& msg) {
     if (h) h->err = msg;
@@ -159,10 +165,10 @@ int check_config(const dedf_config* c, std::string& why) {
     if (c->lmax < 1 || c->lmax > 3) { why = "lmax must be 1, 2 or 3"; return DEDF_ERR_UNSUPPORTED; }
     for (int l = 0; l <= c->lmax; ++l)
         if (c->mul[l] != true_mul(l)) { why = "irreps must be 64x0e+32x1e(+16x2e(+8x3e))"; return DEDF_ERR_UNSUPPORTED; }
-    if (c->lmax == 3) {      // instantiated at lmax 3: the score head and the EBM critic / context-free field of the panda shapes, full precision
-        const bool ok3 = !c->half_gemm && c->fc_neurons[1] == kFc1 && c->fc_neurons[2] == kFc2 && (c->ebm || c->time_emb_mlp[2] == 64);
-        const bool kp3 = !c->half_gemm && c->ebm && c->fc_neurons[1] == 32 && c->fc_neurons[2] == 32;       // KeypointExtractor fields
-        if (!ok3 && !kp3) { why = "lmax 3 is instantiated for fc_neurons [64 + 64, 128, 64] (score head), [64, 128, 64] / [64, 32, 32] (EBM critic / context-free field), full precision"; return DEDF_ERR_UNSUPPORTED; }
+    if (c->lmax == 3) {      // instantiated at lmax 3: the score head and the EBM critic / context-free field of the panda shapes, full and half precision
+        const bool ok3 = c->fc_neurons[1] == kFc1 && c->fc_neurons[2] == kFc2 && (c->ebm || c->time_emb_mlp[2] == 64);
+        const bool kp3 = c->ebm && c->fc_neurons[1] == 32 && c->fc_neurons[2] == 32;       // KeypointExtractor fields
+        if (!ok3 && !kp3) { why = "lmax 3 is instantiated for fc_neurons [64 + 64, 128, 64] (score head), [64, 128, 64] / [64, 32, 32] (EBM critic / context-free field)"; return DEDF_ERR_UNSUPPORTED; }
     }
     if (c->num_heads != kHeads) { why = "num_heads must be 4"; return DEDF_ERR_UNSUPPORTED; }
     const bool t_small = c->time_emb_mlp[0] == 256 && c->time_emb_mlp[1] == 128 && c->time_emb_mlp[2] == 64;
@@ -172,8 +178,8 @@ int check_config(const dedf_config* c, std::string& why) {
     const bool mlp_narrow = c->fc_neurons[1] == 32 && c->fc_neurons[2] == 32;       // sapien place_* score heads
     if (c->fc_neurons[0] != (c->ebm ? kLenEmb : kLenEmb + c->time_emb_mlp[2]) || !(mlp_wide || mlp_narrow)) {
         why = "fc_neurons must resolve to [64 + time_emb, 128, 64] or [64 + time_emb, 32, 32] (score head), or [64,128,64] / [64,32,32] (EBM head / context-free field, no time encoding)"; return DEDF_ERR_UNSUPPORTED; }
-    if (mlp_narrow && c->ebm && (c->lmax < 2 || c->half_gemm)) {
-        why = "the context-free field with the 32-wide radial MLP (KeypointExtractor) is instantiated for lmax 2 and 3, full precision only"; return DEDF_ERR_UNSUPPORTED; }
+    if (mlp_narrow && c->ebm && c->lmax < 2) {
+        why = "the context-free field with the 32-wide radial MLP (KeypointExtractor) is instantiated for lmax 2 and 3"; return DEDF_ERR_UNSUPPORTED; }
     if (mlp_narrow && !c->ebm && c->fc_neurons[0] != 128) {
         why = "the 32-wide radial MLP is instantiated for the score head with the 128-wide pre-linear only"; return DEDF_ERR_UNSUPPORTED; }
     if (c->length_emb_dim != kLenEmb) { why = "length_emb_dim must be 64"; return DEDF_ERR_UNSUPPORTED; }
@@ -293,7 +299,8 @@ int ensure_workspace(dedf_handle* h, int nT) {
     }
     int64_t cap = (int64_t)Nd * per_dst;
     if (h->cfg.max_edges > 0) cap = std::min(cap, h->cfg.max_edges);
-    else cap = std::min(cap, std::max<int64_t>((int64_t)Nd * 96, 1 << 20));    // auto: 96 edges per destination node
+    else cap = std::min(cap, std::max<int64_t>((int64_t)Nd * h->auto_per_dst, 1 << 20));    // auto: 96 edges per destination node, or 1.5 x the degree of a query
+                                                                                            // point on the scene surface where that is more (dedf_set_key_clouds)
     cap = std::min<int64_t>(cap, 0x7fffffff - 64);
     cap = std::max<int64_t>(cap, 64);
     h->edge_cap = cap;
@@ -316,7 +323,7 @@ int ensure_workspace(dedf_handle* h, int nT) {
 }
 
 // Time embedding -> pre-linear bias rows tb[row][scale][F0] for `rows` times read at time[row * time_stride]
-void launch_time_bias(dedf_handle* h, hipStream_t st, const float* time, int time_stride, int rows, float* tb) {
+void launch_time_bias(dedf_handle* h, hipStream_t st, const float* time, int time_stride, int rows, float* tb, int* varies = nullptr) {
     const dedf_config& c = h->cfg;
     const float* nat = h->d_nat.as<float>();
     TimeParams tp{};
@@ -324,7 +331,7 @@ void launch_time_bias(dedf_handle* h, hipStream_t st, const float* time, int tim
     tp.w1 = nat + h->nat_tw1; tp.b1 = nat + h->nat_tb1; tp.w2 = nat + h->nat_tw2; tp.b2 = nat + h->nat_tb2;
     tp.wpre = nat + h->nat_wpre; tp.bpre = nat + h->nat_bpre; tp.tfreq = nat + h->nat_tfreq;
     tp.E = c.time_emb_mlp[0]; tp.H = c.time_emb_mlp[1]; tp.TE = c.time_emb_mlp[2];
-    tp.max_time = c.max_time; tp.time_enc_n = c.time_enc_n; tp.tb = tb;
+    tp.max_time = c.max_time; tp.time_enc_n = c.time_enc_n; tp.tb = tb; tp.varies = varies;
     hipLaunchKernelGGL(k_time_bias, dim3(rows, c.n_scales), dim3(256), 0, st, tp);
 }
 
@@ -519,7 +526,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         h->small_parity = 1 - par;
         cnt_used = np.cnt;
         if constexpr (!EBM) {
-            if (h->tb_step == nullptr) launch_time_bias(h, st, h->d_time.as<float>(), time_stride, time_stride ? nT : 1, h->d_tb.as<float>());
+            if (h->tb_step == nullptr) launch_time_bias(h, st, h->d_time.as<float>(), time_stride, time_stride ? nT : 1, h->d_tb.as<float>(), time_stride ? h->d_tile.as<int>() + kFlagTimeVaries : nullptr);
         }
         mark();
         const dim3 g(nblk, np.word_start[ns] + 1);
@@ -530,7 +537,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     hipLaunchKernelGGL(k_pose_prep<L>, dim3(nT), dim3(64), 0, st, h->d_Ts.as<float>(), T64, h->d_qx.as<float>(), nQ, h->d_pose.as<float>(), h->d_qpos.as<float>());
     // 2. time embedding -> pre-linear bias rows (EBM head: constant bias rows, uploaded once)
     if constexpr (!EBM) {
-        if (h->tb_step == nullptr) launch_time_bias(h, st, h->d_time.as<float>(), time_stride, time_stride ? nT : 1, h->d_tb.as<float>());
+        if (h->tb_step == nullptr) launch_time_bias(h, st, h->d_time.as<float>(), time_stride, time_stride ? nT : 1, h->d_tb.as<float>(), time_stride ? h->d_tile.as<int>() + kFlagTimeVaries : nullptr);
     }
     mark();
     // 3. neighbour search
@@ -579,14 +586,41 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
                 }
             }
         }
+        // dedf_score (one time PER pose): when all the times are equal -- the reference's own callers evaluate a batch at ONE diffusion time
+        // (score_model_base.py:174-177, warmup) -- the table applies just the same.  The times are on the device, so both forms are enqueued behind
+        // a launch gate: k_time_bias left tile_info[kFlagTimeVaries] = 1 if a pose's time differs from pose 0's; the table generator, its accuracy
+        // check and the table-reading kernel run when it is 0, the per-pose-time kernel below when it is 1; the other one returns at once.
+        if constexpr (has_radial_table<L, F0>()) {
+            const bool gated = !use_tab && time_stride != 0 && h->tb_step == nullptr && table_instantiated<L, F0>(h) && h->radial_table != 0 && !h->debug &&
+                               (Nd >= kRtabMinNodes || h->radial_table == 2);
+            if (gated) {
+                EdgeParams Q = P;
+                Q.tb_pose_stride = 0; Q.tb_bytes = (uint32_t)((size_t)ns * F0 * 4);      // pose 0's rows stand for all
+                Q.gate = h->d_tile.as<int>() + kFlagTimeVaries; Q.gate_want = 0;
+                int rc = radial_table_setup(h, Q);
+                if (rc != DEDF_OK) return rc;
+                HIPCK(h, hipMemsetAsync(h->d_rtab_err.p, 0, kMaxScales * 4, st));
+                if (narrow) {
+                    if constexpr (L == 2 && F0 == 128) {
+                        launch_radial_table<L, F0, 32, 32>(h, Q, st, true);
+                        DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 32, 32, false, 1>), kAll, st, Q);
+                    }
+                } else {
+                    launch_radial_table<L, F0, 128, 64>(h, Q, st, true);
+                    DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 128, 64, false, 1>), kAll, st, Q);
+                }
+                P.gate = Q.gate; P.gate_want = 1;
+            }
+        }
         if (use_tab) {
         } else if constexpr (L == 3) {          // lmax 3: full precision, [., 128, 64] (score head, EBM critic) or [64, 32, 32] (context-free fields)
             static_assert(F0 == 128 || F0 == 64, "lmax 3 instantiations");
             if constexpr (F0 == 64) {
-                if (narrow) DEDF_LAUNCH_PERSISTENT((k_edge<3, 64, false, 32, 32>), kAll, st, P);
+                if (narrow) { if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<3, 64, true, 32, 32>), kAll, st, P); else DEDF_LAUNCH_PERSISTENT((k_edge<3, 64, false, 32, 32>), kAll, st, P); }
+                else if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<3, 64, true>), kAll, st, P);
                 else DEDF_LAUNCH_PERSISTENT((k_edge<3, 64, false>), kAll, st, P);
-            } else DEDF_LAUNCH_PERSISTENT((k_edge<3, 128, false>), kAll, st, P);
-            (void)hp;
+            } else if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<3, 128, true>), kAll, st, P);
+            else DEDF_LAUNCH_PERSISTENT((k_edge<3, 128, false>), kAll, st, P);
         } else if constexpr (F0 == 128) {
             if (narrow) {         // narrow radial MLP (sapien place_*)
                 if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true, 32, 32>), kAll, st, P);
@@ -596,7 +630,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
                 if constexpr (L == 1) hipLaunchKernelGGL((k_edge_occ<1, 128, false>), dim3(h->n_cu * waves_per_cu<(k_edge_occ<1, 128, false>), 8>()), dim3(64), 0, st, P);
             } else DEDF_LAUNCH_PERSISTENT((k_edge<L, F0>), kAll, st, P);
         } else if constexpr (F0 == 64 && L == 2) {
-            if (narrow) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 32, 32>), kAll, st, P);      // KeypointExtractor fields
+            if (narrow) { if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true, 32, 32>), kAll, st, P); else DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 32, 32>), kAll, st, P); }      // KeypointExtractor fields
             else if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true>), kAll, st, P);
             else DEDF_LAUNCH_PERSISTENT((k_edge<L, F0>), kAll, st, P);
         } else if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true>), kAll, st, P);
@@ -635,8 +669,10 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         if ((h->debug || h->want_field) && h->d_dbge.ensure((size_t)Nd * D * 4) && h->d_dbgf.ensure((size_t)Nd * D * 4)) { P.dbg_emb = h->d_dbge.as<float>(); P.dbg_field = h->d_dbgf.as<float>(); }
         else if (h->want_field) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(field) failed");
         const int ntiles = (Nd + 31) / 32;
-        if constexpr (L == 3) DEDF_LAUNCH_PERSISTENT((k_node<L, EBM>), ntiles, st, P);      // (balanced grid measured at lmax 3: 0.477 -> 0.482 ms, not used)
-        else if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_node<L, EBM, true>), balanced_blocks(ntiles, h->n_cu * waves_per_cu<(k_node<L, EBM, true>)>()), st, P);
+        if constexpr (L == 3) {      // (balanced grid measured at lmax 3: 0.477 -> 0.482 ms, not used)
+            if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_node<L, EBM, true>), ntiles, st, P);
+            else DEDF_LAUNCH_PERSISTENT((k_node<L, EBM>), ntiles, st, P);
+        } else if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_node<L, EBM, true>), balanced_blocks(ntiles, h->n_cu * waves_per_cu<(k_node<L, EBM, true>)>()), st, P);
         else DEDF_LAUNCH_PERSISTENT((k_node<L, EBM>), balanced_blocks(ntiles, h->n_cu * waves_per_cu<(k_node<L, EBM>)>()), st, P);
     }
     mark();
@@ -674,7 +710,17 @@ int score_dispatch(dedf_handle* h, int nT, int time_stride, float* ang, float* l
 // ===========================================================================================================================
 extern "C" {
 
-const char* dedf_version(void) { return "dedf 0.1.0 (gfx950)"; }
+const char* dedf_version(void) { return "dedf 0.4.0 (gfx950)"; }
+int dedf_abi_version(void) { return DEDF_ABI_VERSION; }
+size_t dedf_struct_size(int which) {
+    switch (which) {
+        case 0: return sizeof(dedf_config);
+        case 1: return sizeof(dedf_schedule);
+        case 2: return sizeof(dedf_stats);
+        case 3: return sizeof(dedf_profile);
+        default: return 0;
+    }
+}
 
 int dedf_param_count(const dedf_config* cfg) {
     std::string why;
@@ -760,7 +806,17 @@ int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, de
     return DEDF_OK;
 }
 
-void dedf_destroy(dedf_handle* h) { delete h; }
+void dedf_destroy(dedf_handle* h) {
+    if (!h) return;
+    // workspace links (dedf_layer_share_workspace): a destroyed owner detaches its borrowers (they allocate their own workspace on their next
+    // call instead of touching freed memory), a destroyed borrower leaves its owner's list
+    for (dedf_handle* b : h->ws_borrowers) b->ws_owner = nullptr;
+    if (h->ws_owner) {
+        auto& v = h->ws_owner->ws_borrowers;
+        v.erase(std::remove(v.begin(), v.end(), h), v.end());
+    }
+    delete h;
+}
 
 const char* dedf_last_error(const dedf_handle* h) { return h ? h->err.c_str() : "null handle"; }
 
@@ -799,7 +855,27 @@ int dedf_set_key_clouds(dedf_handle* h, int n_scales, const int* n_pts, const fl
     else
         hipLaunchKernelGGL((k_src_message<3, true, true>), dim3(total), dim3(64), 0, st, h->d_key_f.as<float>(), total, nat + h->nat_lnw, nat + h->nat_lnb,
                            nat + h->nat_wsrc, nat + h->nat_bsrc, h->d_msg.as<float>(), 0, 0, 0, 0);
-    HIPCK(h, hipStreamSynchronize(st));
+    // edge-workspace sizing: the mean number of same-scale key points within the scale's radius of a key point, summed over the scales
+    {
+        const int ns = n_scales;
+        if (!h->d_deg.ensure((size_t)kMaxScales * (8 + 4 + 4) + 16)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(key clouds) failed");
+        unsigned long long* deg = h->d_deg.as<unsigned long long>();
+        int* sstart = reinterpret_cast<int*>(deg + kMaxScales);
+        float* r2 = reinterpret_cast<float*>(sstart + kMaxScales + 1);
+        float hr2[kMaxScales];
+        for (int n = 0; n < ns; ++n) hr2[n] = h->cfg.radii[n] > 0 ? h->cfg.radii[n] * h->cfg.radii[n] : -1.0f;
+        HIPCK(h, hipMemsetAsync(deg, 0, kMaxScales * 8, st));
+        HIPCK(h, hipMemcpyAsync(sstart, h->scale_start, (ns + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCK(h, hipMemcpyAsync(r2, hr2, ns * sizeof(float), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_self_degree, dim3((total + 255) / 256), dim3(256), 0, st, h->d_key_x.as<float>(), total, ns, sstart, r2, h->cfg.max_neighbors, deg);
+        unsigned long long hdeg[kMaxScales];
+        HIPCK(h, hipMemcpyAsync(hdeg, deg, kMaxScales * 8, hipMemcpyDeviceToHost, st));
+        HIPCK(h, hipStreamSynchronize(st));
+        double est = 0.0;
+        for (int n = 0; n < ns; ++n) if (n_pts[n] > 0) est += (double)hdeg[n] / (double)n_pts[n];
+        h->est_degree = est;
+        h->auto_per_dst = std::max<int64_t>(96, (int64_t)std::ceil(1.5 * est));
+    }
     h->have_keys = true;
     h->have_key_w = false;
     return DEDF_OK;
@@ -933,8 +1009,8 @@ int dedf_keypoint_weight(const float* field, const float* emb, int n, int stride
     return hipGetLastError() == hipSuccess ? DEDF_OK : DEDF_ERR_RUNTIME;
 }
 
-int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedule* sched, uint64_t seed, int64_t first_pose_index,
-                const double* noise, double* Ts_out, void* stream) {
+static int sample_once(dedf_handle* h, int nT, const double* T_seed, const dedf_schedule* sched, uint64_t seed, int64_t first_pose_index,
+                       const double* noise, double* Ts_out, void* stream, bool* overflowed) {
     if (!h) return DEDF_ERR_INVALID;
     if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
     if (!h->have_keys || !h->have_query) return fail(h, DEDF_ERR_INVALID, "set_key_clouds / set_query must be called first");
@@ -995,7 +1071,7 @@ int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedul
     // from that step on, never stale scores)
     int flags[2] = {0, 0};
     if (sched->n_steps > 0) HIPCK(h, hipMemcpy(flags, h->d_tile.as<int>() + kFlagOverflow, sizeof(flags), hipMemcpyDeviceToHost));
-    if (flags[0]) return fail(h, DEDF_ERR_RUNTIME, "edge workspace overflow: raise dedf_config.max_edges");
+    if (flags[0]) { *overflowed = true; return fail(h, DEDF_ERR_RUNTIME, "edge workspace overflow: raise dedf_config.max_edges"); }
     if (h->edge16) {
         int redo = 0;
         HIPCK(h, hipMemcpy(&redo, h->d_tile.as<int>() + kFlagEdge16Redo, 4, hipMemcpyDeviceToHost));
@@ -1004,6 +1080,20 @@ int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedul
     if (flags[1]) return fail(h, DEDF_ERR_RUNTIME, "non-finite score: an activation left the fp16 operand range of the split-fp16 GEMMs "
                                                    "(or the inputs / poses were not finite)");
     return DEDF_OK;
+}
+
+// The automatic edge workspace (dedf_config.max_edges = 0) is sized from the scene (dedf_set_key_clouds: 1.5 x the degree of a query point on the
+// scene surface, at least 96 edges per destination node).  A call whose poses crowd a denser spot than that overflows in some step; the call
+// is then repeated from its (untouched) seed poses with twice the room -- same seed, same noise, same result as a call that had the room from
+// the start.  An explicit max_edges is never overridden.
+int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedule* sched, uint64_t seed, int64_t first_pose_index,
+                const double* noise, double* Ts_out, void* stream) {
+    for (int attempt = 0;; ++attempt) {
+        bool overflowed = false;
+        const int rc = sample_once(h, nT, T_seed, sched, seed, first_pose_index, noise, Ts_out, stream, &overflowed);
+        if (!overflowed || h->cfg.max_edges > 0 || attempt >= 3) return rc;
+        h->auto_per_dst *= 2;
+    }
 }
 
 }  // extern "C"
@@ -1136,11 +1226,32 @@ int dedf_layer_defer_check(dedf_handle* h, int on) {
 int dedf_layer_share_workspace(dedf_handle* h, dedf_handle* owner) {
     if (!h) return DEDF_ERR_INVALID;
     if (!h->cfg.unet_layer) return fail(h, DEDF_ERR_UNSUPPORTED, "UNet-layer handles only");
-    if (owner == nullptr || owner == h) { h->ws_owner = nullptr; return DEDF_OK; }
+    auto unlink = [&]() {
+        if (!h->ws_owner) return;
+        auto& v = h->ws_owner->ws_borrowers;
+        v.erase(std::remove(v.begin(), v.end(), h), v.end());
+        h->ws_owner = nullptr;
+    };
+    if (owner == nullptr || owner == h) { unlink(); return DEDF_OK; }
     if (!owner->cfg.unet_layer || owner->host_only || h->host_only) return fail(h, DEDF_ERR_INVALID, "dedf_layer_share_workspace: the owner must be a UNet-layer handle with a device");
     if (owner->cfg.device != h->cfg.device) return fail(h, DEDF_ERR_INVALID, "dedf_layer_share_workspace: both handles must live on one device");
     if (owner->ws_owner) return fail(h, DEDF_ERR_INVALID, "dedf_layer_share_workspace: the owner itself borrows a workspace");
+    if (!h->ws_borrowers.empty()) return fail(h, DEDF_ERR_INVALID, "dedf_layer_share_workspace: this handle lends its own workspace to others");
+    unlink();
+    // a verdict this layer still holds from deferred calls of its own moves to the owner's word (one dedf_layer_check collects all)
+    if (h->d_sticky.p) {
+        DEDF_ON_DEVICE(h);
+        if (!owner->d_sticky.p) {
+            if (!owner->d_sticky.ensure(4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(flag) failed");
+            HIPCK(h, hipMemset(owner->d_sticky.p, 0, 4));
+        }
+        HIPCK(h, hipDeviceSynchronize());
+        hipLaunchKernelGGL(k_or_flag, dim3(1), dim3(1), 0, nullptr, h->d_sticky.as<int>(), owner->d_sticky.as<int>());
+        HIPCK(h, hipMemsetAsync(h->d_sticky.p, 0, 4, nullptr));
+        HIPCK(h, hipDeviceSynchronize());
+    }
     h->ws_owner = owner;
+    owner->ws_borrowers.push_back(h);
     // this layer's own per-call buffers are no longer needed
     for (DevBuf* b : {&h->d_msg, &h->d_msg_dst, &h->d_esrc, &h->d_edst, &h->d_cnt, &h->d_off, &h->d_eout, &h->d_z}) {
         if (b->p) (void)hipFree(b->p);

@@ -75,7 +75,13 @@ struct EdgeParams {
     // only while rtab_err[scale] <= rtab_err_bound[scale], per edge otherwise (visible in dedf_stats.rtab_fallback).
     unsigned* rtab_err;
     float rtab_err_bound[kMaxScales];
+    // Launch gate (dedf_score with one time for all poses): when `gate` is set the kernel runs only if (*gate != 0) == (gate_want != 0).  The word is
+    // tile_info[kFlagTimeVaries], written by k_time_bias: dedf_score enqueues the table path (gate_want 0) AND the per-pose-time path (gate_want 1)
+    // without reading the times back; the one that does not apply returns at once.
+    const int* gate;
+    int gate_want;
 };
+DEDF_DEV bool edge_gate_closed(const EdgeParams& P) { return P.gate != nullptr && (*P.gate != 0) != (P.gate_want != 0); }
 
 template <int L> struct SH {           // spherical harmonics of one edge, non-scalar blocks already cut off
     float y0[1], y1[3], y2[5], y3[7];
@@ -554,13 +560,15 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         // 4-point Lagrange weights at u = 1/2 for the nodes at -1, 0, 1, 2
         const float w4[4] = {-0.0625f, 0.5625f, 0.5625f, -0.0625f};
         float err = 0.0f;
+        bool bad = false;
         static_for<4 * NT2>([&]<int Q>() {
             f32x4 t = bld4(rtb, rv, Q * 16) * w4[0];
             static_for<3>([&]<int K>() { t = t + bld4(rtb, rv, (K + 1) * 256 + Q * 16) * w4[K + 1]; });
-            static_for<4>([&]<int J>() { err = fmaxf(err, fabsf(t[J] - r2[Q / 4][4 * (Q % 4) + J])); });
+            // (fmaxf drops a NaN operand: a NaN in the table or in the exact activation is tracked on its own and must read as "inaccurate")
+            static_for<4>([&]<int J>() { const float d = fabsf(t[J] - r2[Q / 4][4 * (Q % 4) + J]); bad = bad || !(d == d); err = fmaxf(err, d); });
         });
+        if (bad) err = __builtin_inff();
         if (!valid) err = 0.0f;
-        if (!(err == err)) err = __builtin_inff();         // a NaN anywhere must read as "inaccurate"
 #if defined(__HIP_DEVICE_COMPILE__)
         for (int o = 32; o >= 1; o >>= 1) err = fmaxf(err, __shfl_xor(err, o, 64));
         if (wv.lane == 0) atomicMax(P.rtab_err + scale, __builtin_bit_cast(unsigned, err));      // err >= 0: the bit patterns order like the values

@@ -9,6 +9,7 @@
 using namespace dedf;
 
 template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false, int MODE = 0> __global__ __launch_bounds__(64, 1) void k_edge(EdgeParams P) {
+    if (edge_gate_closed(P)) return;
     const int* ti = P.tile_info;
     const int ntiles = ti[P.n_scales];
     const Wave wv = make_wave(P.W, P.W_bytes);
@@ -48,8 +49,10 @@ template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = f
 // Radial table of the sampler (EdgeParams::rtab): the front of the radial network on the length grid of every scale, computed by the edge
 // tile's own code (edge_tile MODE 2), 32 grid nodes per tile.
 template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64> __global__ __launch_bounds__(64, 1) void k_radial_table(EdgeParams P) {
+    if (edge_gate_closed(P)) return;
     const Wave wv = make_wave(P.W, P.W_bytes);
-    edge_rows_to_lds<L, H1, H2>(P, wv);
+    constexpr bool FRONT = front_rows_in_lds<L, 2>();      // (the LDS array edge_tile<..., MODE 2> reads)
+    edge_rows_to_lds<L, H1, H2, FRONT>(P, wv);
     int enc_scale = -1;
     for (int t = blockIdx.x;; t += gridDim.x) {
         int scale = 0, base = 0;
@@ -59,7 +62,7 @@ template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64> __global__ 
             base += nt;
         }
         if (scale >= P.n_scales) break;
-        if (scale != enc_scale) { edge_enc_to_lds<L>(P, wv, scale); enc_scale = scale; }
+        if (scale != enc_scale) { edge_enc_to_lds<L, FRONT>(P, wv, scale); enc_scale = scale; }
         const int k = t - base, nrows = P.rtab_n[scale] + 3;
 #if defined(DEDF_PHASE_PROF)
         unsigned long long pacc[16];
@@ -73,8 +76,10 @@ template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64> __global__ 
 }
 // Accuracy check of the radial table (edge_tile MODE 3): 32 interval midpoints per tile, every interval of every scale.
 template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64> __global__ __launch_bounds__(64, 1) void k_radial_check(EdgeParams P) {
+    if (edge_gate_closed(P)) return;
     const Wave wv = make_wave(P.W, P.W_bytes);
-    edge_rows_to_lds<L, H1, H2>(P, wv);
+    constexpr bool FRONT = front_rows_in_lds<L, 3>();
+    edge_rows_to_lds<L, H1, H2, FRONT>(P, wv);
     int enc_scale = -1;
     for (int t = blockIdx.x;; t += gridDim.x) {
         int scale = 0, base = 0;
@@ -84,7 +89,7 @@ template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64> __global__ 
             base += nt;
         }
         if (scale >= P.n_scales) break;
-        if (scale != enc_scale) { edge_enc_to_lds<L>(P, wv, scale); enc_scale = scale; }
+        if (scale != enc_scale) { edge_enc_to_lds<L, FRONT>(P, wv, scale); enc_scale = scale; }
         const int k = t - base;
         GeoPre geo{};
 #if defined(DEDF_PHASE_PROF)
@@ -106,54 +111,4 @@ template <int L, bool EBM, bool HP = false, bool UN = false> __global__ __launch
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) node_tile<L, EBM, HP, UN>(P, wv, t * 32);
 }
 
-// every instantiation the library launches: X(unit, declaration)
-#define DEDF_KERNEL_LIST(X)                                           \
-    X(0, void k_edge<2, 128, false>(EdgeParams))                      \
-    X(1, void k_edge<2, 128, true>(EdgeParams))                       \
-    X(2, void k_edge<2, 64, false>(EdgeParams))                       \
-    X(3, void k_edge<2, 192, false>(EdgeParams))                      \
-    X(4, void k_edge<1, 64, false>(EdgeParams))                       \
-    X(4, void k_edge<1, 128, false>(EdgeParams))                      \
-    X(4, void k_edge<1, 128, true>(EdgeParams))                       \
-    X(7, void k_edge<2, 128, false, 32, 32>(EdgeParams))              \
-    X(7, void k_edge<1, 128, false, 32, 32>(EdgeParams))              \
-    X(8, void k_edge<2, 192, true>(EdgeParams))                       \
-    X(8, void k_edge<2, 64, true>(EdgeParams))                        \
-    X(9, void k_edge<2, 128, true, 32, 32>(EdgeParams))               \
-    X(9, void k_edge<1, 64, true>(EdgeParams))                        \
-    X(9, void k_edge<1, 128, true, 32, 32>(EdgeParams))               \
-    X(9, void k_node<2, true, true>(NodeParams))                      \
-    X(9, void k_node<1, true, true>(NodeParams))                      \
-    X(5, void k_node<2, false, false>(NodeParams))                    \
-    X(5, void k_node<2, false, true>(NodeParams))                     \
-    X(6, void k_node<2, true, false>(NodeParams))                     \
-    X(6, void k_node<1, false, false>(NodeParams))                    \
-    X(6, void k_node<1, false, true>(NodeParams))                     \
-    X(6, void k_node<1, true, false>(NodeParams))                     \
-    X(10, void k_edge<2, 64, false, 32, 32, true>(EdgeParams))        \
-    X(10, void k_node<2, false, false, true>(NodeParams))             \
-    X(11, void k_edge<2, 64, false, 32, 32>(EdgeParams))              \
-    X(12, void k_edge<2, 128, false, 128, 64, false, 1>(EdgeParams))  \
-    X(11, void k_radial_table<2, 128>(EdgeParams))                    \
-    X(11, void k_radial_check<2, 128>(EdgeParams))                    \
-    X(13, void k_edge<2, 192, false, 128, 64, false, 1>(EdgeParams))  \
-    X(10, void k_radial_table<2, 192>(EdgeParams))                    \
-    X(10, void k_radial_check<2, 192>(EdgeParams))                    \
-    X(14, void k_edge<2, 128, false, 32, 32, false, 1>(EdgeParams))   \
-    X(10, void k_radial_table<2, 128, false, 32, 32>(EdgeParams))     \
-    X(10, void k_radial_check<2, 128, false, 32, 32>(EdgeParams))     \
-    X(15, void k_edge<2, 64, true, 32, 32, true>(EdgeParams))         \
-    X(15, void k_node<2, false, true, true>(NodeParams))               \
-    X(16, void k_edge<3, 128, false>(EdgeParams))                     \
-    X(17, void k_node<3, false, false>(NodeParams))                   \
-    X(18, void k_edge<3, 64, false>(EdgeParams))                      \
-    X(17, void k_node<3, true, false>(NodeParams))                    \
-    X(19, void k_edge<3, 64, false, 32, 32, true>(EdgeParams))        \
-    X(20, void k_node<3, false, false, true>(NodeParams))             \
-    X(21, void k_edge<3, 64, true, 32, 32, true>(EdgeParams))         \
-    X(20, void k_node<3, false, true, true>(NodeParams))              \
-    X(22, void k_edge<3, 128, false, 128, 64, false, 1>(EdgeParams))  \
-    X(23, void k_radial_table<3, 128>(EdgeParams))                    \
-    X(23, void k_radial_check<3, 128>(EdgeParams))                    \
-    X(23, void k_edge<3, 64, false, 32, 32>(EdgeParams))
-constexpr int kKernelUnits = 24;
+#include "dedf_kernel_list.h"

@@ -117,13 +117,16 @@ struct TimeParams {
     int E, H, TE;                                   // time_emb_mlp = [E, H, TE]: [256,128,64] or [512,256,128]
     float max_time, time_enc_n;
     float* tb;
+    int* varies;          // optional: set to 1 when a row's time differs from row 0's (tile_info[kFlagTimeVaries]: dedf_score's launch gate)
 };
+constexpr int kFlagTimeVaries = 45;      // word of tile_info, cleared at the start of every API call
 constexpr int kTimeMaxEnc = 512, kTimeMaxHid = 256, kTimeMaxEmb = 128;
 __global__ __launch_bounds__(256) void k_time_bias(TimeParams P) {
     __shared__ float enc[kTimeMaxEnc], hid[kTimeMaxHid], emb[kTimeMaxEmb];
     const int p = blockIdx.x, n = blockIdx.y, n_scales = gridDim.y, tid = threadIdx.x;
     const int E = P.E, H = P.H, TE = P.TE, F0 = kLenEmb + TE;
     const float t = P.time[p * P.time_stride];
+    if (P.varies != nullptr && n == 0 && tid == 0 && !(t == P.time[0])) *P.varies = 1;       // (a NaN time reads as "varies")
     // SinusoidalPositionEmbeddings(dim E, max_val, n) — radial_func.py:305-316
     const float x = t / P.max_time * P.time_enc_n;
     for (int i = tid; i < E / 2; i += blockDim.x) {
@@ -520,6 +523,28 @@ __global__ void k_edge_lists(const int64_t* __restrict__ src64, const int64_t* _
         const int64_t a = lb(i), b = lb(i + 1);
         off[i] = (int)a; cnt[i] = (int)(b - a);
     }
+}
+
+// Edge-workspace sizing (dedf_set_key_clouds): how many key points of its own scale lie within that scale's radius of a key point, summed per
+// scale -- the degree a query point ON the scene surface would see, which is where the denoised poses end up.  One thread per key point.
+__global__ void k_self_degree(const float* __restrict__ key_x, int n_keys, int n_scales, const int* __restrict__ scale_start, const float* __restrict__ r2,
+                              int max_neighbors, unsigned long long* __restrict__ deg_sum) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_keys) return;
+    int n = 0;
+    while (n + 1 < n_scales && i >= scale_start[n + 1]) ++n;
+    const int a = scale_start[n], b = scale_start[n + 1];
+    int c = b - a;
+    if (r2[n] > 0.0f) {
+        const float x = key_x[3 * i], y = key_x[3 * i + 1], z = key_x[3 * i + 2];
+        c = 0;
+        for (int j = a; j < b; ++j) {
+            const float dx = key_x[3 * j] - x, dy = key_x[3 * j + 1] - y, dz = key_x[3 * j + 2] - z;
+            c += dx * dx + dy * dy + dz * dz < r2[n] ? 1 : 0;
+        }
+        c = min(c, max_neighbors);
+    }
+    atomicAdd(deg_sum + n, (unsigned long long)c);
 }
 
 __global__ void k_or_flag(const int* __restrict__ flag, int* __restrict__ sticky) {

@@ -98,6 +98,17 @@ class MultiscaleTensorField(torch.nn.Module):
     def _after_load(self, *_):          # also when a parent module loads a checkpoint
         self._release()
 
+    def half(self):
+        """half-precision GEMM mode of the field's two fused kernels (``dedf_config.half_gemm``); parameters stay fp32 master copies"""
+        self.cfg.half_gemm = True
+        self._release()
+        return self
+
+    def float(self):
+        self.cfg.half_gemm = False
+        self._release()
+        return self
+
     def __del__(self):
         try:
             self._release()
@@ -245,12 +256,17 @@ class KeypointExtractor(torch.nn.Module):
         self.irreps_output = str(tensor_field_kwargs['irreps_output'])
 
     def half(self):
-        """``model.half()``: the UNet's layers switch to single-product fp16 GEMMs; the two fields and the weight head stay in full precision"""
+        """``model.half()`` (reference agent.py:50-51): the UNet's layers and the two fields switch to single-product fp16 GEMMs (fp32 accumulate,
+        everything else fp32); the per-node projections and the 64-channel weight head stay in full precision"""
         self.feature_extractor.half()
+        self.tensor_field.half()
+        self.weight_field.half()
         return self
 
     def float(self):
         self.feature_extractor.float()
+        self.tensor_field.float()
+        self.weight_field.float()
         return self
 
     @torch.no_grad()

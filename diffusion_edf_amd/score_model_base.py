@@ -56,6 +56,8 @@ def build_schedule(ang_mult: float, lin_mult: float, diffusion_schedules, N_step
             aa.append((ang_mult ** 2) * p_alpha * dt_n)
             al.append((lin_mult ** 2) * p_alpha * dt_n)
     out = (np.asarray(ts, dtype=np.float64), np.asarray(aa, dtype=np.float64), np.asarray(al, dtype=np.float64), np.asarray(tt, dtype=np.float64))
+    for a in out:
+        a.setflags(write=False)          # the memoised arrays are shared by every later caller: an in-place edit must raise, not corrupt them
     if len(_SCHEDULE_CACHE) < 64:
         _SCHEDULE_CACHE[key] = out
     return out

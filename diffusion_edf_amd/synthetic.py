@@ -162,3 +162,19 @@ def keypoint_extractor_kwargs(radii=(5.0, 10.0, 20.0, 40.0), bbox=((-30.0, 30.0)
                 feature_extractor_kwargs=unet_kwargs(unet),
                 tensor_field_kwargs=dict(irreps_output='64x0e+32x1e+16x2e', irreps_sh="1x0e+1x1e+1x2e", num_heads=4, fc_neurons=[-1, 32, 32], length_emb_dim=64,
                                          r_cluster_multiscale=list(radii), n_scales=len(radii)))
+
+
+def config5_model_kwargs(radii=(5., 10., 20., None), field_radii=(5.0, 10.0, 20.0, 40.0)) -> dict:
+    """BASELINE config 5 as ONE model: the ``model_kwargs`` block of a ``score_model_configs.yaml`` in the reference's schema
+    (configs/panda_mug/place_lowres/score_model_configs.yaml: UNet key model, KeypointExtractor query model, MultiscaleScoreModel head) with one
+    more degree everywhere -- irreps 64x0e+32x1e+16x2e+8x3e (narrow UNet levels 32x0e+16x1e+8x2e+4x3e), SH up to 3e.  No shipped YAML uses
+    lmax 3; the shapes are the shipped ones plus the l = 3 block.  The keys multiscale_score_model.py:79-93 injects are absent, as in the file."""
+    import copy
+    sh = copy.deepcopy(score_head_kwargs(3, radii))
+    sh.pop('irreps_query_edf')
+    for k in ('irreps_input', 'use_src_point_attn'):
+        sh['key_tensor_field_kwargs'].pop(k, None)
+    return dict(score_head_kwargs=sh,
+                key_kwargs=dict(feature_extractor_name='UnetFeatureExtractor', feature_extractor_kwargs=unet_kwargs("panda_lowres_lmax3")),
+                query_model='KeypointExtractor',
+                query_kwargs=keypoint_extractor_kwargs(field_radii, bbox=None, unet="panda_highres_lmax3"))

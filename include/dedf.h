@@ -117,6 +117,16 @@ typedef struct dedf_stats {
 
 const char* dedf_version(void);
 
+/* ABI version of this header: bumped whenever a struct below changes its size or field order, or an entry point its arguments.  A binding
+ * built against another version must not call into the library: dedf_get_stats / dedf_profile_read write sizeof(struct) bytes into caller
+ * memory.  dedf_abi_version() is what the LOADED library was built with; dedf_struct_size(which) gives its sizeof of the struct
+ * dedf_config [which = 0], dedf_schedule [1], dedf_stats [2], dedf_profile [3] for bindings that mirror the structs by hand (diffusion_edf_amd/_lib.py checks both).
+ *   1  rounds 1-2.   2  round 3: dedf_config.unet_valid[4] (was [3]), dedf_stats.rtab_err / rtab_fallback, dedf_radius scratch arguments.
+ *   3  round 4: dedf_abi_version / dedf_struct_size themselves; no struct change. */
+#define DEDF_ABI_VERSION 3
+int dedf_abi_version(void);
+size_t dedf_struct_size(int which);
+
 /* canonical parameter order = order of the flat `params` blob of dedf_create; names are the reference state_dict keys
  * below `score_head.` (reference trainer.py:141-147) */
 int dedf_param_count(const dedf_config* cfg);

@@ -776,6 +776,10 @@ def test_full_size_c2_anchored_on_the_oracle_through_pose_independence():
     sel = torch.tensor([0, 1, 7, 99, 250, 333, 512, 777, 998, 999], device=dev)
     t_all = torch.full((1000,), 0.5, device=dev)
     ang_all, lin_all = head(Ts.float(), keys, query, t_all)
+    st = head.stats()
+    # one time for every pose: `forward` took the radial table behind its launch gate, and the guard ran on it (review item 5 of round 3)
+    assert 0.0 < max(st['rtab_err'][:3]) < 1e-5 and not any(st['rtab_fallback']), st
+    head.set_radial_table("always")          # (the 10-pose subset would evaluate per edge on its own: the table differs from that by ~3e-6)
     ang_s, lin_s = head(Ts[sel].float(), keys, query, t_all[:len(sel)])
     scale = float(max(ang_all.abs().max(), lin_all.abs().max()))
     assert float((ang_all[sel] - ang_s).abs().max()) / scale < 2e-6 and float((lin_all[sel] - lin_s).abs().max()) / scale < 2e-6
@@ -787,6 +791,82 @@ def test_full_size_c2_anchored_on_the_oracle_through_pose_independence():
     assert sum(d['n_edges_per_scale']) > 10_000
     s64 = float(max(ang64.abs().max(), lin64.abs().max()))
     assert float((ang_all[sel].cpu().double() - ang64).abs().max()) / s64 < TOL and float((lin_all[sel].cpu().double() - lin64).abs().max()) / s64 < TOL
+
+
+def test_forward_with_one_time_for_all_poses_takes_the_radial_table_and_mixed_times_do_not():
+    """`dedf_score` takes one time PER pose (score_head.py:150), but the reference's own callers evaluate a batch at ONE diffusion time
+    (score_model_base.py:174-177; `warmup`).  The times live on the device, so both forms are enqueued behind a launch gate set by k_time_bias:
+    equal times -> table generator + guard + table-reading kernel, anything else -> the per-pose-time kernel.  Checked on C2's inputs: (1) equal
+    times: the guard ran, the scores agree with the per-edge evaluation to 1e-5 of the score scale; (2) two different times in the batch: the
+    guard did NOT run, the scores equal the per-edge run's bit for bit, and a subset agrees with the fp64 oracle at its own times."""
+    import bench
+    dev = torch.device('cuda:0')
+    kw, cfg, P, keys, query, Ts = bench.build_inputs(2, 4096, 1024, 1000, 0, dev)
+    head = _gpu_head(kw, P, dev)
+    t_one = torch.full((1000,), 0.37, device=dev)
+    ang_t, lin_t = head(Ts.float(), keys, query, t_one)
+    st = head.stats()
+    assert 0.0 < max(st['rtab_err'][:3]) < 1e-5 and 0.0 < st['rtab_err'][3] < 2.5e-4 and not any(st['rtab_fallback']), st
+    t_mix = t_one.clone()
+    t_mix[1::2] = 0.61
+    ang_m, lin_m = head(Ts.float(), keys, query, t_mix)
+    assert max(head.stats()['rtab_err']) == 0.0          # gate closed: neither the generator nor the guard ran
+    head.set_radial_table(False)
+    ang_e, lin_e = head(Ts.float(), keys, query, t_one)
+    ang_me, lin_me = head(Ts.float(), keys, query, t_mix)
+    scale = float(max(ang_e.abs().max(), lin_e.abs().max()))
+    dev_t = max(float((ang_t - ang_e).abs().max()), float((lin_t - lin_e).abs().max())) / scale
+    assert 0.0 < dev_t < 1e-5, dev_t
+    assert torch.equal(ang_m, ang_me) and torch.equal(lin_m, lin_me)
+    assert float((ang_m[0::2] - ang_e[0::2]).abs().max()) / scale < 2e-6          # the poses that kept t = 0.37 do not depend on their neighbours' times
+    sel = torch.tensor([0, 1, 250, 333, 777, 998])
+    ocfg = R.config_from_kwargs(kw)
+    ok = [R.FeaturedPoints(k.x.cpu().double(), k.f.cpu().double(), k.b.cpu()) for k in keys]
+    oq = R.FeaturedPoints(query.x.cpu().double(), query.f.cpu().double(), query.b.cpu(), query.w.cpu().double())
+    for t_vec, a_gpu, l_gpu in ((t_mix, ang_m, lin_m), (t_one, ang_t, lin_t)):
+        a64, l64 = R.score_head_forward(ocfg, R.cast_params(P, torch.float64), Ts[sel.to(dev)].cpu(), ok, oq, t_vec[sel.to(dev)].cpu().double())
+        s64 = float(max(a64.abs().max(), l64.abs().max()))
+        assert float((a_gpu[sel.to(dev)].cpu().double() - a64).abs().max()) / s64 < TOL and float((l_gpu[sel.to(dev)].cpu().double() - l64).abs().max()) / s64 < TOL
+
+
+def test_automatic_edge_workspace_follows_the_scene_density_and_grows_on_overflow():
+    """the automatic edge workspace (dedf_config.max_edges = 0): dedf_set_key_clouds sizes it from the scene (1.5 x the mean degree of a query point
+    on the scene surface, at least 96 per node), and dedf_sample repeats a call that overflowed with twice the room (same seed, same result).
+    (1) a uniformly dense scene -- every key point a neighbour of every query, 4 x 250 = 1 000 edges per node: sized right at once;
+    (2) a scene whose MEAN density is low (800 isolated key points per scale) with one dense clump the poses sit in (200 per scale = 800 edges per
+        node against an estimate of ~245): the call overflows, is repeated twice and gives what a roomy workspace gives."""
+    from diffusion_edf_amd.gnn_data import FeaturedPoints as FP
+    kw, cfg, P, _, query, Ts, time = SC.build_case(1, 64, 1024, 1000, radii=(20., 20., 20., 20.), identity_pose=False)
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(0)
+    # (64 poses x 80 query points = 5 120 nodes: above the 2^20-edge floor of the automatic workspace, so its per-node figure is what decides)
+    query = FP(x=query.x[:80] * 0.1, f=query.f[:80], b=query.b[:80], w=query.w[:80])
+    Ts = Ts.clone(); Ts[:, 4:] = torch.randn(len(Ts), 3, generator=g, dtype=torch.float64)
+    mk = lambda x: FP(x=x, f=torch.randn(len(x), cfg.dim, generator=g), b=torch.zeros(len(x), dtype=torch.long))
+    dense = [mk(torch.randn(250, 3, generator=g) * 1.5) for _ in range(4)]
+    grid = torch.stack(torch.meshgrid(torch.arange(10.), torch.arange(10.), torch.arange(8.), indexing='ij'), -1).reshape(-1, 3) * 50.0 + 200.0
+    clumped = [mk(torch.cat([torch.randn(200, 3, generator=g), grid])) for _ in range(4)]
+    gq = _to_dev(dense, query, dev)[1]
+    args = ([[1.0, 0.5]], [2], [0.04])
+    head = _gpu_head(kw, P, dev)
+    out = ScoreModelBase(head).sample(Ts.to(dev), _to_dev(dense, query, dev)[0], gq, *args, seed=5)
+    st = head.stats()
+    assert torch.isfinite(out).all() and not st['overflow'] and st['n_edges_total'] == 1000 * st['n_dst'], st
+    gk = _to_dev(clumped, query, dev)[0]
+    out_c = ScoreModelBase(head).sample(Ts.to(dev), gk, gq, *args, seed=5)
+    st = head.stats()
+    assert torch.isfinite(out_c).all() and not st['overflow'] and st['n_edges_total'] == 800 * st['n_dst'], st
+    roomy = _gpu_head(kw, P, dev, max_edges=1000 * 64 * 80)
+    out_r = ScoreModelBase(roomy).sample(Ts.to(dev), gk, gq, *args, seed=5)
+    assert torch.equal(out_c, out_r)
+    # `forward` cannot repeat itself (it never synchronises): on a fresh handle the same scene overflows there and says so
+    fresh = _gpu_head(kw, P, dev)
+    ang, _ = fresh(Ts.to(dev).float(), gk, gq, time.to(dev).float())
+    assert fresh.stats()['overflow'] and torch.isnan(ang).all()
+    # a pinned workspace that is too small is reported, never grown (an explicit max_edges is the caller's decision)
+    small = _gpu_head(kw, P, dev, max_edges=5000)
+    with pytest.raises(RuntimeError, match="overflow"):
+        ScoreModelBase(small).sample(Ts.to(dev), gk, gq, *args, seed=5)
 
 
 def test_full_size_c2_sharded_sampling_equals_single_batch():

@@ -172,6 +172,8 @@ def test_full_size_c2_lmax3_anchored_on_the_oracle_through_pose_independence():
     t_all = torch.full((1000,), 0.5, device=dev)
     ang_all, lin_all = head(Ts.float(), keys, query, t_all)
     assert head.stats()['n_edges_total'] > 1_000_000 and not head.stats()['overflow']
+    assert max(head.stats()['rtab_err']) > 0.0          # one time for every pose: forward took the radial table behind its launch gate (and the guard ran)
+    head.set_radial_table("always")                     # (the small subset would evaluate per edge on its own: the table differs from that by ~3e-6)
     ang_s, lin_s = head(Ts[sel].float(), keys, query, t_all[:len(sel)])
     scale = float(max(ang_all.abs().max(), lin_all.abs().max()))
     assert float((ang_all[sel] - ang_s).abs().max()) / scale < 2e-6 and float((lin_all[sel] - lin_s).abs().max()) / scale < 2e-6
@@ -234,6 +236,52 @@ def test_ebm_energy_parity_lmax3():
     assert float((e - e64).abs().max()) / float(e64.abs().max()) < TOL
     order = torch.argsort(e64)                    # the ranking agent.py:172-173 sorts by: the oracle's order is non-decreasing on the GPU values too (ties: isolated poses)
     assert bool((e[order][1:] - e[order][:-1] > -1e-4 * float(e64.abs().max())).all())
+
+
+@pytest.mark.gpu
+def test_half_precision_mode_lmax3_score_head_critic_and_field():
+    """`model.half()` (reference agent.py:50-51) at lmax 3: the score head, the EBM critic and the context-free [64, 32, 32] field with every GEMM
+    as ONE fp16 MFMA product (k_edge<3, ., true> / k_node<3, ., true>), against the fp64 oracle at the half mode's stated 5e-3 -- and really
+    different from the full-precision mode"""
+    from diffusion_edf_amd.score_head import EbmScoreModelHead
+    rep = SC.stage_report(lmax=3, nT=5, n_scene=512, n_grasp=100, verbose=False, half=True)
+    assert rep['edges_gpu'] == rep['edges_oracle'] and rep['edge_set_equal']
+    assert rep['final_ang'] < 5e-3 and rep['final_lin'] < 5e-3, rep
+    assert max(rep['final_ang'], rep['final_lin']) > 3e-5, rep
+    # the critic
+    dev = torch.device('cuda:0')
+    kw = synthetic.ebm_head_kwargs(3)
+    cfg = params.HeadConfig.from_kwargs(kw)
+    P = params.init_params(cfg, seed=4, randomize_all=True)
+    keys = synthetic.make_key_clouds(cfg, 600, seed=2)
+    query = synthetic.make_query(cfg, 80, seed=2)
+    Ts = synthetic.make_poses(9, seed=5, near_object=True)
+    head = _gpu_head({k: v for k, v in kw.items() if k != 'ebm'}, P, dev, cls=EbmScoreModelHead)
+    head.half()
+    gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
+    gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
+    e = head.compute_energy(Ts.float().to(dev), gk, gq, torch.zeros(len(Ts), device=dev)).cpu().double()
+    ok = [R.FeaturedPoints(k.x.double(), k.f.double(), k.b) for k in keys]
+    oq = R.FeaturedPoints(query.x.double(), query.f.double(), query.b, query.w.double())
+    e64 = R.compute_energy(R.config_from_kwargs(kw), R.cast_params(P, torch.float64), Ts, ok, oq, torch.zeros(len(Ts), dtype=torch.float64))
+    err = float((e - e64).abs().max()) / float(e64.abs().max())
+    assert 3e-6 < err < 5e-3, err
+    # the field (KeypointExtractor.tensor_field's shape) at both degrees: half against full precision of the same module
+    from diffusion_edf_amd.keypoint_extractor import MultiscaleTensorField
+    for lmax in (2, 3):
+        irr = '+'.join(['64x0e', '32x1e', '16x2e', '8x3e'][:lmax + 1])
+        sh = '+'.join(['1x0e', '1x1e', '1x2e', '1x3e'][:lmax + 1])
+        tf = MultiscaleTensorField(irreps_input=irr, irreps_output=irr, irreps_sh=sh, num_heads=4, fc_neurons=[-1, 32, 32], length_emb_dim=64,
+                                   irreps_query=None, r_cluster_multiscale=[5.0, 10.0], edge_context_emb_dim=None, n_scales=2, init_seed=5).to(dev)
+        kc = params.HeadConfig.from_kwargs(synthetic.score_head_kwargs(lmax, radii=(5., 10.)))
+        kk = synthetic.make_key_clouds(kc, 1500, seed=3)
+        gkk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in kk]
+        qp = FeaturedPoints(x=gkk[0].x[:200] + 0.3, f=torch.empty(200, 0, device=dev), b=torch.zeros(200, dtype=torch.long, device=dev), w=None)
+        full = tf(qp, gkk).f
+        tf.half()
+        hf = tf(qp, gkk).f
+        errf = float((hf - full).abs().max()) / float(full.abs().max())
+        assert 1e-6 < errf < 5e-3, (lmax, errf)
 
 
 # ---- GPU: the UNet feature extractor at lmax 3 (BASELINE config 5) ------------------------------------------------------------------
