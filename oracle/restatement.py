@@ -594,6 +594,72 @@ def time_embeddings(cfg: Config, P, time: Tensor) -> List[Tensor]:
     return outs
 
 
+def equiformer_block(cfg: Config, P, blk: str, src_f: Tensor, edge_src: Tensor, edge_dst: Tensor, edge_attr: Tensor, edge_scalars: Tensor,
+                     edge_logits: Tensor, N_dst: int, src_w: Optional[Tensor] = None, irreps_output: Optional[Irreps] = None):
+    """EquiformerBlock.forward for ``use_dst_feature=False`` (gnn_block.py:164-218) + GraphAttentionMLP2.forward (graph_attention.py:218-273) on a
+    given bipartite graph: source features, edge lists and the per-edge attributes / scalars / pre-attention logits.  ``blk``: the block's prefix
+    in the state dict.  Returns (output features, intermediates)."""
+    irreps, irreps_sh, H = cfg.irreps, cfg.irreps_sh, cfg.num_heads
+    # ---- EquiformerBlock (use_dst_feature=False: no dst message, skip_1=None) --------------------
+    msg_src = equivariant_layer_norm_v2(src_f, irreps, P, f"{blk}.prenorm_src")
+    msg_src = linear_rs(msg_src, irreps, irreps, P, f"{blk}.linear_src", bias=True)
+    message = msg_src[edge_src]
+
+    # ---- GraphAttentionMLP2 ------------------------------------------------------------------------
+    ga = f"{blk}.ga"
+    irreps_head = [(m // H, l) for m, l in irreps]
+    mul_alpha = irreps[0][0]
+    assert irreps[0][1] == 0
+    dtp1, dtp1_out_simpl, lin1_out, gate1 = separable_fctp_dtp_lin(irreps, irreps_sh, irreps, True)
+    weight = radial_profile(edge_scalars, P, f"{ga}.sep_act.dtp_rad", len(cfg.fc_neurons))
+    m1 = dtp1(message, edge_attr, weight)                                   # (E, 1568)
+    log_alpha = linear_rs(m1, dtp1.irout, [(mul_alpha, 0)], P, f"{ga}.sep_alpha")   # un-simplified input irreps
+    log_alpha = vec2heads(log_alpha, [(mul_alpha // H, 0)], H)              # (E, H, 16)
+    value = linear_rs(m1, dtp1_out_simpl, lin1_out, P, f"{ga}.sep_act.lin")
+    value = gate(value, *gate1)                                             # (E, 240)
+    dtp2, dtp2_out_simpl, lin2_out, _ = separable_fctp_dtp_lin(irreps, irreps_sh, irreps, False)
+    v2 = dtp2(value, edge_attr, P[f"{ga}.sep_value.dtp.tp.weight"])
+    value = linear_rs(v2, dtp2_out_simpl, lin2_out, P, f"{ga}.sep_value.lin")
+    log_alpha = smooth_leaky_relu_n(log_alpha)
+    log_alpha = torch.einsum('ehk,hk->eh', log_alpha, P[f"{ga}.alpha_dot"].squeeze(0))
+    log_alpha = log_alpha + edge_logits.unsqueeze(-1)
+    value = vec2heads(value, irreps_head, H)                                # (E, H, 60)
+    # scatter_logsumexp / scatter-sum over dst (torch_scatter restated; empty segments -> 0)
+    mx = torch.full((N_dst, H), -float('inf'), dtype=log_alpha.dtype)
+    mx = mx.scatter_reduce(0, edge_dst[:, None].expand(-1, H), log_alpha, reduce='amax', include_self=True)
+    mx_safe = torch.where(torch.isinf(mx), torch.zeros_like(mx), mx)
+    ssum = torch.zeros((N_dst, H), dtype=log_alpha.dtype).index_add_(0, edge_dst, torch.exp(log_alpha - mx_safe[edge_dst]))
+    log_Z = torch.log(ssum) + mx_safe
+    alpha = torch.exp(log_alpha - log_Z[edge_dst])
+    if cfg.use_src_point_attn:                                   # gnn_block.py:190-194, graph_attention.py:257-258: after the softmax
+        assert isinstance(src_w, Tensor)
+        alpha = alpha * src_w[edge_src].unsqueeze(-1)
+    attn = value * alpha.unsqueeze(-1)
+    attn = torch.zeros((N_dst,) + attn.shape[1:], dtype=attn.dtype).index_add_(0, edge_dst, attn)
+    attn = heads2vec(attn, irreps_head)
+    emb = linear_rs(attn, irreps, irreps, P, f"{ga}.proj")
+
+    # ---- post-norm + FFN + skip_2 (Identity) ----------------------------------------------------------
+    out = equivariant_layer_norm_v2(emb, irreps, P, f"{blk}.post_norm")
+    mid = simplify(sort_even_first([(m, l) for _ in range(cfg.irreps_mlp_mid) for m, l in irreps])[0])
+    sc, gt, gd = irreps2gate(mid)
+    ffn_in = simplify(sc + gt + gd)
+    y1 = torch.ones_like(out[:, 0:1])
+    t1 = fctp(irreps, [(1, 0)], ffn_in)
+    h = t1(out, y1, P[f"{blk}.ffn.fctp_1.tp.weight"])
+    h = add_bias(h, ffn_in, P, f"{blk}.ffn.fctp_1")
+    h = gate(h, sc, gt, gd)
+    ir_out = irreps if irreps_output is None else irreps_output
+    t2 = fctp(mid, [(1, 0)], ir_out)
+    o = t2(h, y1, P[f"{blk}.ffn.fctp_2.tp.weight"])
+    o = add_bias(o, ir_out, P, f"{blk}.ffn.fctp_2")
+    if list(ir_out) == list(irreps):
+        o = o + emb                                               # skip_2 = Identity
+    else:
+        o = o + linear_rs(emb, irreps, ir_out, P, f"{blk}.skip_2.skip", bias=True)      # ProjectIfMismatch(layernorm=False)
+    return o, dict(msg_src=msg_src, dtp_weight=weight, log_alpha=log_alpha, value=value, attn=attn, emb=emb)
+
+
 def key_tensor_field(cfg: Config, P, query_x: Tensor, key_pcd_multiscale: Sequence[FeaturedPoints],
                      context_emb: List[Tensor], dbg: Optional[Debug] = None, pre: str = "key_tensor_field",
                      irreps_output: Optional[Irreps] = None) -> Tensor:
@@ -639,66 +705,13 @@ def key_tensor_field(cfg: Config, P, query_x: Tensor, key_pcd_multiscale: Sequen
     src_f = torch.cat([kp.f for kp in key_pcd_multiscale], dim=0)
     N_dst = query_x.shape[0]
 
-    # ---- EquiformerBlock (use_dst_feature=False: no dst message, skip_1=None) --------------------
-    blk = f"{pre}.gnn_block_init"
-    msg_src = equivariant_layer_norm_v2(src_f, irreps, P, f"{blk}.prenorm_src")
-    msg_src = linear_rs(msg_src, irreps, irreps, P, f"{blk}.linear_src", bias=True)
-    message = msg_src[edge_src]
-
-    # ---- GraphAttentionMLP2 ------------------------------------------------------------------------
-    ga = f"{blk}.ga"
-    irreps_head = [(m // H, l) for m, l in irreps]
-    mul_alpha = irreps[0][0]
-    assert irreps[0][1] == 0
-    dtp1, dtp1_out_simpl, lin1_out, gate1 = separable_fctp_dtp_lin(irreps, irreps_sh, irreps, True)
-    weight = radial_profile(edge_scalars, P, f"{ga}.sep_act.dtp_rad", len(cfg.fc_neurons))
-    m1 = dtp1(message, edge_attr, weight)                                   # (E, 1568)
-    log_alpha = linear_rs(m1, dtp1.irout, [(mul_alpha, 0)], P, f"{ga}.sep_alpha")   # un-simplified input irreps
-    log_alpha = vec2heads(log_alpha, [(mul_alpha // H, 0)], H)              # (E, H, 16)
-    value = linear_rs(m1, dtp1_out_simpl, lin1_out, P, f"{ga}.sep_act.lin")
-    value = gate(value, *gate1)                                             # (E, 240)
-    dtp2, dtp2_out_simpl, lin2_out, _ = separable_fctp_dtp_lin(irreps, irreps_sh, irreps, False)
-    v2 = dtp2(value, edge_attr, P[f"{ga}.sep_value.dtp.tp.weight"])
-    value = linear_rs(v2, dtp2_out_simpl, lin2_out, P, f"{ga}.sep_value.lin")
-    log_alpha = smooth_leaky_relu_n(log_alpha)
-    log_alpha = torch.einsum('ehk,hk->eh', log_alpha, P[f"{ga}.alpha_dot"].squeeze(0))
-    log_alpha = log_alpha + edge_logits.unsqueeze(-1)
-    value = vec2heads(value, irreps_head, H)                                # (E, H, 60)
-    # scatter_logsumexp / scatter-sum over dst (torch_scatter restated; empty segments -> 0)
-    mx = torch.full((N_dst, H), -float('inf'), dtype=log_alpha.dtype)
-    mx = mx.scatter_reduce(0, edge_dst[:, None].expand(-1, H), log_alpha, reduce='amax', include_self=True)
-    mx_safe = torch.where(torch.isinf(mx), torch.zeros_like(mx), mx)
-    ssum = torch.zeros((N_dst, H), dtype=log_alpha.dtype).index_add_(0, edge_dst, torch.exp(log_alpha - mx_safe[edge_dst]))
-    log_Z = torch.log(ssum) + mx_safe
-    alpha = torch.exp(log_alpha - log_Z[edge_dst])
-    if cfg.use_src_point_attn:                                   # gnn_block.py:190-194, graph_attention.py:257-258: after the softmax
+    src_w = None
+    if cfg.use_src_point_attn:                                   # gnn_block.py:190-194: the key points' weights
         for kp in key_pcd_multiscale:
             assert isinstance(kp.w, Tensor)
         src_w = torch.cat([kp.w for kp in key_pcd_multiscale], dim=0)
-        alpha = alpha * src_w[edge_src].unsqueeze(-1)
-    attn = value * alpha.unsqueeze(-1)
-    attn = torch.zeros((N_dst,) + attn.shape[1:], dtype=attn.dtype).index_add_(0, edge_dst, attn)
-    attn = heads2vec(attn, irreps_head)
-    emb = linear_rs(attn, irreps, irreps, P, f"{ga}.proj")
-
-    # ---- post-norm + FFN + skip_2 (Identity) ----------------------------------------------------------
-    out = equivariant_layer_norm_v2(emb, irreps, P, f"{blk}.post_norm")
-    mid = simplify(sort_even_first([(m, l) for _ in range(cfg.irreps_mlp_mid) for m, l in irreps])[0])
-    sc, gt, gd = irreps2gate(mid)
-    ffn_in = simplify(sc + gt + gd)
-    y1 = torch.ones_like(out[:, 0:1])
-    t1 = fctp(irreps, [(1, 0)], ffn_in)
-    h = t1(out, y1, P[f"{blk}.ffn.fctp_1.tp.weight"])
-    h = add_bias(h, ffn_in, P, f"{blk}.ffn.fctp_1")
-    h = gate(h, sc, gt, gd)
-    ir_out = irreps if irreps_output is None else irreps_output
-    t2 = fctp(mid, [(1, 0)], ir_out)
-    o = t2(h, y1, P[f"{blk}.ffn.fctp_2.tp.weight"])
-    o = add_bias(o, ir_out, P, f"{blk}.ffn.fctp_2")
-    if list(ir_out) == list(irreps):
-        o = o + emb                                               # skip_2 = Identity
-    else:
-        o = o + linear_rs(emb, irreps, ir_out, P, f"{blk}.skip_2.skip", bias=True)      # ProjectIfMismatch(layernorm=False)
+    o, mid_ = equiformer_block(cfg, P, f"{pre}.gnn_block_init", src_f, edge_src, edge_dst, edge_attr, edge_scalars, edge_logits, N_dst, src_w, irreps_output)
+    msg_src, weight, log_alpha, value, attn, emb = (mid_[k] for k in ("msg_src", "dtp_weight", "log_alpha", "value", "attn", "emb"))
     if dbg is not None:
         dbg.update(edge_src=edge_src, edge_dst=edge_dst, edge_attr=edge_attr, edge_scalars=edge_scalars,
                    edge_logits=edge_logits, edge_length=torch.cat(E_len), msg_src=msg_src, dtp_weight=weight,
