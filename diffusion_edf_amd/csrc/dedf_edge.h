@@ -746,8 +746,12 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             if constexpr (Ph % 2 == 1) to_vgpr(w);      // finished tile: the VALU stage reads it
         }
     };
+    // Debug hooks (stage tests): compiled into the per-edge instantiations only.  The table-reading kernel (MODE 1) is never launched in debug mode
+    // (dedf_api.hip: use_tab requires !debug); there the hooks were 15 exec-masked store blocks in the hot loop and 4 in the value stage, each a
+    // basic-block boundary in the middle of a pipeline region.
+    constexpr bool DBG = MODE != 1;
     auto dump_w = [&]<int Tw>(const f32x16& w) {      // debug only: back to the e3nn weight order
-        if (P.dbg_w != nullptr && valid)
+        if constexpr (DBG) if (P.dbg_w != nullptr && valid)
             static_for<16>([&]<int R>() {
                 if constexpr (Tw * 32 + (R & 3) + 8 * (R >> 2) < WN) P.dbg_w[(size_t)e * WN + dtp_walk_row<L>(Tw * 32 + (R & 3) + 8 * (R >> 2)) + 4 * hi] = w[R] * P.w_unscale;
             });
@@ -1032,7 +1036,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         pk[(SPW + 1) * 64] = f32x4{inv_s[0], inv_s[1], inv_s[2], inv_s[3]};
     }
     auto orec_of = [&]() { return P.out + (size_t)(e0 + seg_start) * REC; };
-    auto drec_of = [&]() { return P.dbg_out != nullptr ? P.dbg_out + (size_t)e * REC : nullptr; };
+    auto drec_of = [&]() -> float* { if constexpr (DBG) return P.dbg_out != nullptr ? P.dbg_out + (size_t)e * REC : nullptr; else return nullptr; };
     // The 240 values are reduced with DPP row shifts (VALU only): an inclusive segmented scan inside each 16-lane row
     // (row_shr 1, 2, 4, 8; sources outside the row read 0), then lane 15 of the lower row is added to the lanes of the upper
     // row whose segment began in the lower row (row_bcast:15).  Steps beyond the longest segment of the tile are skipped.
@@ -1084,9 +1088,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             static_for<2>([&]<int T>() { static_for<4>([&]<int g>() {
                 constexpr int hd = 2 * T + g / 2, n = 4 * T + g;
                 ro[n] = T * 32 + 8 * g + 4 * hi; iv[n] = inv_s[hd];
-                x[n] = f32x4{val0[T][4 * g], val0[T][4 * g + 1], val0[T][4 * g + 2], val0[T][4 * g + 3]} * cv0;
-                if (drec != nullptr && valid) st4(drec + ro[n], x[n]);
-                x[n] = x[n] * pw[hd];
+                x[n] = f32x4{val0[T][4 * g], val0[T][4 * g + 1], val0[T][4 * g + 2], val0[T][4 * g + 3]};
+                if constexpr (DBG) { x[n] = x[n] * cv0; if (drec != nullptr && valid) st4(drec + ro[n], x[n]); x[n] = x[n] * pw[hd]; }
+                else x[n] = x[n] * (cv0 * pw[hd]);          // (one product per value: the power-of-two operand scale folds into the softmax weight exactly)
             }); });
             emit(x, ro, iv);
         } else if constexpr (l3 == 1) {
@@ -1094,9 +1098,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             static_for<3>([&]<int K>() { static_for<4>([&]<int g>() {
                 constexpr int n = 4 * K + g;
                 ro[n] = blk_off(1) + K * mul_of(1) + 8 * g + 4 * hi; iv[n] = inv_s[g];
-                x[n] = f32x4{val1[K][4 * g], val1[K][4 * g + 1], val1[K][4 * g + 2], val1[K][4 * g + 3]} * cv1;
-                if (drec != nullptr && valid) st4(drec + ro[n], x[n]);
-                x[n] = x[n] * pw[g];
+                x[n] = f32x4{val1[K][4 * g], val1[K][4 * g + 1], val1[K][4 * g + 2], val1[K][4 * g + 3]};
+                if constexpr (DBG) { x[n] = x[n] * cv1; if (drec != nullptr && valid) st4(drec + ro[n], x[n]); x[n] = x[n] * pw[g]; }
+                else x[n] = x[n] * (cv1 * pw[g]);
             }); });
             emit(x, ro, iv);
         } else if constexpr (l3 == 2) {
@@ -1104,9 +1108,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             static_for<5>([&]<int K>() { static_for<2>([&]<int g>() {        // 16 channels: head = 2 g + hi
                 constexpr int n = 2 * K + g;
                 ro[n] = blk_off(2) + K * mul_of(2) + 8 * g + 4 * hi; iv[n] = hi ? inv_s[2 * g + 1] : inv_s[2 * g];
-                x[n] = f32x4{val2[K][4 * g], val2[K][4 * g + 1], val2[K][4 * g + 2], val2[K][4 * g + 3]} * cv2;
-                if (drec != nullptr && valid) st4(drec + ro[n], x[n]);
-                x[n] = x[n] * (hi ? pw[2 * g + 1] : pw[2 * g]);
+                x[n] = f32x4{val2[K][4 * g], val2[K][4 * g + 1], val2[K][4 * g + 2], val2[K][4 * g + 3]};
+                if constexpr (DBG) { x[n] = x[n] * cv2; if (drec != nullptr && valid) st4(drec + ro[n], x[n]); x[n] = x[n] * (hi ? pw[2 * g + 1] : pw[2 * g]); }
+                else x[n] = x[n] * (cv2 * (hi ? pw[2 * g + 1] : pw[2 * g]));
             }); });
             emit(x, ro, iv);
         } else {
@@ -1114,9 +1118,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             static_for<7>([&]<int K>() { static_for<2>([&]<int g>() {        // 16 (padded) channels: head = 2 g + hi
                 constexpr int n = 2 * K + g;
                 ro[n] = blk_off(3) + K * mul_of(3) + 8 * g + 4 * hi; iv[n] = hi ? inv_s[2 * g + 1] : inv_s[2 * g];
-                x[n] = f32x4{val3[K][4 * g], val3[K][4 * g + 1], val3[K][4 * g + 2], val3[K][4 * g + 3]} * cv3;
-                if (drec != nullptr && valid) st4(drec + ro[n], x[n]);
-                x[n] = x[n] * (hi ? pw[2 * g + 1] : pw[2 * g]);
+                x[n] = f32x4{val3[K][4 * g], val3[K][4 * g + 1], val3[K][4 * g + 2], val3[K][4 * g + 3]};
+                if constexpr (DBG) { x[n] = x[n] * cv3; if (drec != nullptr && valid) st4(drec + ro[n], x[n]); x[n] = x[n] * (hi ? pw[2 * g + 1] : pw[2 * g]); }
+                else x[n] = x[n] * (cv3 * (hi ? pw[2 * g + 1] : pw[2 * g]));
             }); });
             emit(x, ro, iv);
         }
@@ -1238,7 +1242,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     });
     DEDF_STAMP(14);
     store_group.template operator()<L>();
-    if (P.dbg_out != nullptr && valid && hi == 0) st4(drec_of() + D, f32x4{logit[0], logit[1], logit[2], logit[3]});
+    if constexpr (DBG) if (P.dbg_out != nullptr && valid && hi == 0) st4(drec_of() + D, f32x4{logit[0], logit[1], logit[2], logit[3]});
     if constexpr (MODE == 1) {
         geo.ok = e_next >= 0; geo.src = nsrc; geo.dst = ndst;
         geo.vx = nk[0] - nq[0]; geo.vy = nk[1] - nq[1]; geo.vz = nk[2] - nq[2];
