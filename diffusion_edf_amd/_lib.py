@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("DEDF_LIB") or os.path.join(os.path.dirname(os.path.a
 MAX_SCALES = 8
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_RUNTIME = 0, 1, 2, 3
-ABI_VERSION = 3          # DEDF_ABI_VERSION of include/dedf.h this binding mirrors
+ABI_VERSION = 4          # DEDF_ABI_VERSION of include/dedf.h this binding mirrors
 
 SYMBOLS = [
     "dedf_version", "dedf_abi_version", "dedf_struct_size", "dedf_param_count", "dedf_param_name", "dedf_param_numel", "dedf_create", "dedf_destroy",
@@ -31,7 +31,7 @@ class DedfConfig(C.Structure):
         ("radii", C.c_float * MAX_SCALES), ("r_mincut_nonscalar_sh", C.c_float), ("length_enc_max_r", C.c_float),
         ("max_time", C.c_float), ("time_enc_n", C.c_float), ("lin_mult", C.c_float), ("ang_mult", C.c_float),
         ("max_neighbors", C.c_int), ("device", C.c_int), ("max_edges", C.c_int64), ("ebm", C.c_int), ("half_gemm", C.c_int), ("use_src_point_attn", C.c_int),
-        ("unet_layer", C.c_int), ("unet_valid", C.c_int * 4), ("unet_fc_valid", C.c_int * 3),
+        ("unet_layer", C.c_int), ("unet_valid", C.c_int * 4), ("unet_fc_valid", C.c_int * 3), ("unet_narrow", C.c_int),
     ]
 
 
@@ -155,7 +155,7 @@ def make_config(cfg: HeadConfig, device: int, max_edges: int = 0) -> DedfConfig:
 
 
 def make_unet_layer_config(radius: float, device: int, fc_neurons=(64, 32, 32), muls=(64, 32, 16), num_heads: int = 4,
-                           irreps_mlp_mid: int = 3, valid=None, fc_valid=None, half_gemm: bool = False) -> DedfConfig:
+                           irreps_mlp_mid: int = 3, valid=None, fc_valid=None, half_gemm: bool = False, narrow: bool = False) -> DedfConfig:
     """dedf_config of ONE UNet layer (dedf_config.unet_layer = 1): irreps 64x0e+32x1e+16x2e, radial MLP [64,32,32]; `valid` / `fc_valid`:
     true multiplicities / radial widths of a narrower model that runs zero-padded (dedf.h: unet_valid, unet_fc_valid)"""
     c = DedfConfig()
@@ -173,6 +173,7 @@ def make_unet_layer_config(radius: float, device: int, fc_neurons=(64, 32, 32), 
     c.device = device
     c.unet_layer = 1
     c.half_gemm = int(bool(half_gemm))
+    c.unet_narrow = int(bool(narrow))
     for i in range(len(muls)):
         c.unet_valid[i] = 0 if valid is None else int(valid[i])
     for i in range(3):

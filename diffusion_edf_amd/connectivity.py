@@ -119,9 +119,10 @@ class RadiusGraph(torch.nn.Module):
         super().__init__()
         self.r, self.max_num_neighbors = r, max_num_neighbors
 
-    def forward(self, node_coord_src: torch.Tensor, node_feature_src: torch.Tensor, batch_src: torch.Tensor, _trusted: bool = False):
+    def forward(self, node_coord_src: torch.Tensor, node_feature_src: torch.Tensor, batch_src: torch.Tensor, _trusted: bool = False, _need_degree: bool = True):
         dst, src = radius_graph(node_coord_src, self.r, batch_src, loop=False, max_num_neighbors=self.max_num_neighbors, _trusted=_trusted)
-        return node_feature_src, node_coord_src, src, dst, _in_degree(dst, len(node_coord_src)), batch_src
+        # (`_need_degree=False`: callers that drop the degree -- the UNet's layers count their edges themselves -- skip its device work)
+        return node_feature_src, node_coord_src, src, dst, (_in_degree(dst, len(node_coord_src)) if _need_degree else None), batch_src
 
 
 class RadiusConnect(torch.nn.Module):
@@ -147,10 +148,20 @@ class FpsPool(torch.nn.Module):
         self.ratio, self.random_start, self.r, self.max_num_neighbors = ratio, random_start, r, max_num_neighbors
         self.radius_connect = RadiusConnect(r=r, max_num_neighbors=max_num_neighbors)
 
-    def forward(self, node_coord_src: torch.Tensor, node_feature_src: torch.Tensor, batch_src: torch.Tensor, _trusted: bool = False):
-        picked = fps(node_coord_src, batch_src, ratio=self.ratio, random_start=self.random_start, _trusted=_trusted)
+    def forward(self, node_coord_src: torch.Tensor, node_feature_src: torch.Tensor, batch_src: torch.Tensor, _trusted: bool = False,
+                _fps_ordered: bool = False, _need_degree: bool = True):
+        """``_fps_ordered``: the caller vouches that ``node_coord_src`` is ONE cloud in the selection order of a farthest point sampling that
+        started at ITS first point (the previous level of a deterministic FPS cascade).  Sampling such a cloud from its first point again returns its
+        own prefix: sample j + 1 of the parent run maximises the distance to samples 1 .. j over the whole parent cloud, hence over the sub-cloud
+        too (same distances, bit for bit), and among points tied at that maximum it is the one the parent run took first, i.e. the smallest index
+        of the sub-cloud.  ``tests/test_graph.py::test_fps_of_an_fps_ordered_cloud_is_its_prefix`` checks it on the oracle and on the kernels."""
+        if _fps_ordered and not self.random_start:
+            import math
+            picked = torch.arange(int(math.ceil(self.ratio * len(node_coord_src))), device=node_coord_src.device)
+        else:
+            picked = fps(node_coord_src, batch_src, ratio=self.ratio, random_start=self.random_start, _trusted=_trusted)
         coord, feat, batch = node_coord_src[picked], node_feature_src[picked], batch_src[picked]
         src, dst = self.radius_connect(node_coord_src, batch_src, coord, batch, _trusted=_trusted)      # (a sub-sample of a single cloud is one)
         other = picked[dst] != src                      # drop the edge from a pooled node to the source point it was sampled from
         src, dst = src[other], dst[other]
-        return feat, coord, src, dst, _in_degree(dst, len(picked)), batch
+        return feat, coord, src, dst, (_in_degree(dst, len(picked)) if _need_degree else None), batch

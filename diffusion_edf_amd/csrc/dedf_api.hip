@@ -160,6 +160,9 @@ int check_config(const dedf_config* c, std::string& why) {
         if (c->lmax == 3 && (c->unet_valid[3] == 0 || c->unet_valid[3] > 8)) { why = "UNet layer, lmax 3: unet_valid[3] must name the true 3e multiplicity (8 or 4)"; return DEDF_ERR_INVALID; }
         for (int l = 0; l < 3; ++l)
             if (c->unet_fc_valid[l] < 0 || c->unet_fc_valid[l] > c->fc_neurons[l]) { why = "UNet layer: unet_fc_valid out of range"; return DEDF_ERR_INVALID; }
+        if (c->unet_narrow)
+            for (int l = 0; l <= c->lmax; ++l)
+                if (c->unet_valid[l] != (32 >> l)) { why = "UNet layer: unet_narrow needs unet_valid = {32, 16, 8 (, 4)}"; return DEDF_ERR_INVALID; }
         return DEDF_OK;
     }
     if (c->lmax < 1 || c->lmax > 3) { why = "lmax must be 1, 2 or 3"; return DEDF_ERR_UNSUPPORTED; }
@@ -1153,7 +1156,11 @@ int layer_forward_impl(dedf_handle* h, int n_src, const float* x_src, const floa
         P.key_w = nullptr;
         P.out = w->d_eout.as<float>();
         P.dbg_w = nullptr; P.dbg_out = nullptr; P.phase_prof = nullptr;
-        if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, true, 32, 32, true>), 1 << 30, st, P);
+        static const bool nw_on = [] { const char* e = getenv("DEDF_UNET_NARROW"); return !(e && atoi(e) == 0); }();      // DEDF_UNET_NARROW=0: the general kernels (A/B)
+        if (h->cfg.unet_narrow && nw_on) {      // narrow level: the instantiations that skip the structurally zero channels (dedf_net.h::pad_live)
+            if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, true, 32, 32, true, 0, true>), 1 << 30, st, P);
+            else DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, false, 32, 32, true, 0, true>), 1 << 30, st, P);
+        } else if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, true, 32, 32, true>), 1 << 30, st, P);
         else DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, false, 32, 32, true>), 1 << 30, st, P);
     }
     hipLaunchKernelGGL(k_aggregate<L>, dim3((n_dst + 3) / 4), dim3(256), 0, st, w->d_eout.as<float>(), w->d_cnt.as<int>(), w->d_off.as<int>(),

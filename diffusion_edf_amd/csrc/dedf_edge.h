@@ -329,11 +329,24 @@ struct GeoPre { int ok, src, dst; float vx, vy, vz; };
 // lengths lie inside the table, per edge otherwise (the all-pairs scale has no a-priori bound).  MODE 3: accuracy check of the table --
 // "edge" e of the tile is the MIDPOINT of grid interval e of `scale`: exact front there against the interpolated table.  MODE 2: table generator -- "edge" e of
 // the tile is table row e of `scale`; the tile ends after layer 2's activation.
-template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false, int MODE = 0>
+// NW: narrow UNet level (dedf_net.h::pad_live): the lane-local work on the structurally zero channels is skipped
+template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false, int MODE = 0, bool NW = false>
 DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, int n_valid, GeoPre& geo, int e_next DEDF_PROF_ARG) {
     static_assert((H1 == 128 && H2 == 64) || (H1 == 32 && H2 == 32), "radial MLP widths of the shipped configs");
     static_assert(!UN || F0 == 64, "UNet layer: the radial MLP reads the 64 radial-basis channels");
     static_assert(MODE == 0 || !UN, "the radial table is the sampler's");
+    static_assert(!NW || UN, "NW is a UNet-layer shape");
+    // activation stage on the registers of a run that hold true channels only (the others are structural zeros and stay 0)
+    auto on_live = [&]<int l, int N, class St>(float (&v)[N], St&& st) {
+        constexpr int NL = live_count<L, NW>(l, N);
+        if constexpr (NL == N) st.template operator()<N>(v);
+        else {
+            float w[NL];
+            static_for<N>([&]<int R>() { if constexpr (!pad_reg<L, NW>(l, R)) w[live_count<L, NW>(l, R)] = v[R]; });
+            st.template operator()<NL>(w);
+            static_for<N>([&]<int R>() { if constexpr (pad_reg<L, NW>(l, R)) v[R] = 0.0f; else v[R] = w[live_count<L, NW>(l, R)]; });
+        }
+    };
 #if defined(DEDF_PHASE_PROF) && defined(__HIP_DEVICE_COMPILE__)
     unsigned long long t_last = __builtin_readcyclecounter();
 #endif
@@ -606,12 +619,13 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // fp16 hi halves of a 16-channel chunk (8 accumulator registers), the next slot their fp16 residuals ([slot][lane][8 halves];
     // chunk q = dedf_net.h::park_slot(degree, component, chunk) -> slots 2q | 2q + 1), lane-private
     f32x4* const pk = park + wv.lane;
-    auto park_chunk = [&]<int Q>(const float (&v)[8]) {
+    auto park_chunk = [&]<int Q, bool PADZ = false>(const float (&v)[8]) {
         if constexpr (park_packed<L>(Q)) {      // registers 2, 3, 6, 7 are the zero padding of 8x3e: hi and lo of the other four in one slot
             const float v4[4] = {v[0], v[1], v[4], v[5]};
             pk[park_phys<L>(Q) * 64] = split4pk(v4);
         } else {
-            const HL sp = split8(v);
+            HL sp;
+            if constexpr (PADZ) sp = split8z(v); else sp = split8(v);
             pk[park_phys<L>(Q) * 64] = __builtin_bit_cast(f32x4, sp.hi);
             if constexpr (!HP) pk[(park_phys<L>(Q) + 1) * 64] = __builtin_bit_cast(f32x4, sp.lo);
         }
@@ -666,12 +680,15 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                     static_for<d1>([&]<int Q>() { static_for<4>([&]<int i>() {
                         // element 4 Q + i of the run = component (4 Q + i) % d1 of channel (4 Q + i) / d1
                         constexpr int ch = (4 * Q + i) / d1, cmp = (4 * Q + i) % d1;
+                        if constexpr (pad_reg<L, NW>(l1, ch)) v[cmp][4 * run + ch] = 0.0f;      // a zero-padding channel of the source rows
+                        else {
                         float x;
                         if constexpr (UN) x = xo.x[run][Q][i] + xo.xd[run][Q][i]; else x = xo.x[run][Q][i];
                         v[cmp][4 * run + ch] = x * wtile[8 * c2 + 4 * run + ch];
+                        }
                     }); });
                 });
-                static_for<d1>([&]<int I>() { const HL sp = split8(v[I]); o.hi[I] = sp.hi; o.lo[I] = sp.lo; });
+                static_for<d1>([&]<int I>() { HL sp; if constexpr (pad_reg<L, NW>(l1, 2)) sp = split8z(v[I]); else sp = split8(v[I]); o.hi[I] = sp.hi; o.lo[I] = sp.lo; });
             } else {
             float m[Cg::NM];
             Cg::make(Y.template get<l2>(), m);
@@ -682,7 +699,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                     if constexpr (UN) xr[4 * Q + i] = xo.x[run][Q][i] + xo.xd[run][Q][i]; else xr[4 * Q + i] = xo.x[run][Q][i];
                 }); });
                 static_for<4>([&]<int j>() {
-                    if constexpr (pad_reg<L>(l1, j)) static_for<d3>([&]<int K>() { v[K][4 * run + j] = 0.0f; });      // a zero-padding channel of the source rows
+                    if constexpr (pad_reg<L, NW>(l1, j)) static_for<d3>([&]<int K>() { v[K][4 * run + j] = 0.0f; });      // a zero-padding channel of the source rows
                     else {
                     float t[d3];
                     Cg::apply(&xr[j * d1], m, t);
@@ -690,7 +707,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                     }
                 });
             });
-            split_chunk<L, l3, pad_reg<L>(l1, 2)>(v, o);
+            split_chunk<L, l3, pad_reg<L, NW>(l1, 2)>(v, o);
             }
         }
         return o;
@@ -749,7 +766,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // Debug hooks (stage tests): compiled into the per-edge instantiations only.  The table-reading kernel (MODE 1) is never launched in debug mode
     // (dedf_api.hip: use_tab requires !debug); there the hooks were 15 exec-masked store blocks in the hot loop and 4 in the value stage, each a
     // basic-block boundary in the middle of a pipeline region.
-    constexpr bool DBG = MODE != 1;
+    constexpr bool DBG = MODE != 1 && !UN;      // (UNet layers are never run in debug mode either: dedf_api.hip::layer_forward_impl)
     auto dump_w = [&]<int Tw>(const f32x16& w) {      // debug only: back to the e3nn weight order
         if constexpr (DBG) if (P.dbg_w != nullptr && valid)
             static_for<16>([&]<int R>() {
@@ -769,8 +786,10 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         float m[Cg::NM];
         Cg::make(Y.template get<l2>(), m);
         static_for<NR>([&]<int R>() {
-            if constexpr (pad_reg<L>(l3, R)) {      // a zero-padding output channel: nothing to contract
-                if constexpr (dtp_pos_opens_vacc<L>(Ce)) static_for<d3>([&]<int K>() { if constexpr (l3 == 3) vacc3[K][R] = 0.0f; });
+            if constexpr (pad_reg<L, NW>(l3, R)) {      // a zero-padding output channel: nothing to contract
+                if constexpr (dtp_pos_opens_vacc<L>(Ce)) static_for<d3>([&]<int K>() {
+                    if constexpr (l3 == 1) vacc1[K][R] = 0.0f; else if constexpr (l3 == 2) vacc2[K][R] = 0.0f; else if constexpr (l3 == 3) vacc3[K][R] = 0.0f;
+                });
             } else {
             float o[d3];
             static_for<d3>([&]<int K>() {
@@ -806,14 +825,15 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 const f32x4* adp = reinterpret_cast<const f32x4*>(rows + RL::adot + (hd >> 1) * 32 + hi * 16 + r0);
                 const f32x4 d0 = adp[0], d1v = adp[1];
                 // SmoothLeakyReLU(0.2) x normalize2mom (dedf_dev.h::slrelu_n), eight values stage by stage
-                float x8[8], s8[8];
+                float x8[8];
                 static_for<8>([&]<int R>() { x8[R] = acc0[T][r0 + R] * cl0; });
-                sigmoid_stage<8>(x8, s8);
-                float sum = 0.0f;
-                static_for<8>([&]<int R>() {
-                    const float v = (0.6f * x8[R] + 0.4f * x8[R] * (2.0f * s8[R] - 1.0f)) * kNormSlrelu;
-                    sum += v * (R < 4 ? d0[R & 3] : d1v[R & 3]);
+                on_live.template operator()<0>(x8, [&]<int N>(float (&x)[N]) {      // x <- slrelu_n(x); padded alpha rows stay 0
+                    float sg[N];
+                    sigmoid_stage<N>(x, sg);
+                    static_for<N>([&]<int R>() { x[R] = (0.6f * x[R] + 0.4f * x[R] * (2.0f * sg[R] - 1.0f)) * kNormSlrelu; });
                 });
+                float sum = 0.0f;
+                static_for<8>([&]<int R>() { if constexpr (!pad_reg<L, NW>(0, R)) sum += x8[R] * (R < 4 ? d0[R & 3] : d1v[R & 3]); });
                 sum += xor32(sum);
                 logit[hd] = sum + logit0;
             });
@@ -821,55 +841,51 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             static_for<2>([&]<int T>() { static_for<2>([&]<int hf>() {
                 float v[8];
                 static_for<8>([&]<int J>() { v[J] = acc0[T][8 * hf + J] * cl0; });
-                silu_stage<8>(v);
-                static_for<8>([&]<int J>() { v[J] = v[J] * (kNormSilu * us); });
-                park_chunk.template operator()<park_slot<L>(0, 0, 2 * T + hf)>(v);
+                on_live.template operator()<0>(v, [&]<int N>(float (&x)[N]) { silu_stage<N>(x); static_for<N>([&]<int J>() { x[J] = x[J] * (kNormSilu * us); }); });
+                park_chunk.template operator()<park_slot<L>(0, 0, 2 * T + hf), pad_reg<L, NW>(0, 2)>(v);
             }); });
             if constexpr (L >= 1) {
                 constexpr int G0 = gate_row(1, 0);
-                float x16[16];
-                static_for<16>([&]<int R>() { x16[R] = acc0[G0 / 32][(G0 % 32) / 2 + R] * cl0; });
-                sigmoid_stage<16>(x16, g1);
-                static_for<16>([&]<int R>() { g1[R] = g1[R] * (kNormSigmoid * (cl1 * us)); });
+                static_for<16>([&]<int R>() { g1[R] = acc0[G0 / 32][(G0 % 32) / 2 + R] * cl0; });
+                on_live.template operator()<1>(g1, [&]<int N>(float (&x)[N]) { float sg[N]; sigmoid_stage<N>(x, sg); static_for<N>([&]<int R>() { x[R] = sg[R] * (kNormSigmoid * (cl1 * us)); }); });
             }
             if constexpr (L >= 2) {
                 constexpr int G0 = gate_row(2, 0);
-                float x8[8];
-                static_for<8>([&]<int R>() { x8[R] = acc0[G0 / 32][(G0 % 32) / 2 + R] * cl0; });
-                sigmoid_stage<8>(x8, g2);
-                static_for<8>([&]<int R>() { g2[R] = g2[R] * (kNormSigmoid * (cl2 * us)); });
+                static_for<8>([&]<int R>() { g2[R] = acc0[G0 / 32][(G0 % 32) / 2 + R] * cl0; });
+                on_live.template operator()<2>(g2, [&]<int N>(float (&x)[N]) { float sg[N]; sigmoid_stage<N>(x, sg); static_for<N>([&]<int R>() { x[R] = sg[R] * (kNormSigmoid * (cl2 * us)); }); });
             }
             if constexpr (L >= 3) {
                 constexpr int G0 = gate_row(3, 0);
-                float x8[8];
-                static_for<8>([&]<int R>() { x8[R] = acc0[G0 / 32][(G0 % 32) / 2 + R] * cl0; });
-                sigmoid_stage<8>(x8, g3);
-                static_for<8>([&]<int R>() { g3[R] = g3[R] * (kNormSigmoid * (cl3 * us)); });
+                static_for<8>([&]<int R>() { g3[R] = acc0[G0 / 32][(G0 % 32) / 2 + R] * cl0; });
+                on_live.template operator()<3>(g3, [&]<int N>(float (&x)[N]) { float sg[N]; sigmoid_stage<N>(x, sg); static_for<N>([&]<int R>() { x[R] = sg[R] * (kNormSigmoid * (cl3 * us)); }); });
             }
         } else if constexpr (l3 == 1) {
             static_for<3>([&]<int K>() { static_for<2>([&]<int hf>() {
                 float v[8];
                 static_for<8>([&]<int J>() {
-                    if constexpr (dtp_group_has_out<L>(1)) v[J] = (acc1[K][8 * hf + J] + vacc1[K][8 * hf + J]) * g1[8 * hf + J];
+                    if constexpr (pad_reg<L, NW>(1, J)) v[J] = 0.0f;
+                    else if constexpr (dtp_group_has_out<L>(1)) v[J] = (acc1[K][8 * hf + J] + vacc1[K][8 * hf + J]) * g1[8 * hf + J];
                     else v[J] = acc1[K][8 * hf + J] * g1[8 * hf + J];
                 });
-                park_chunk.template operator()<park_slot<L>(1, K, hf)>(v);
+                park_chunk.template operator()<park_slot<L>(1, K, hf), pad_reg<L, NW>(1, 2)>(v);
             }); });
         } else if constexpr (l3 == 2) {
             static_for<5>([&]<int K>() {      // 16 channels = registers 0-7
                 float v[8];
                 static_for<8>([&]<int J>() {
                     constexpr int T = acc_paired<L>(2) ? K / 2 : K, R = acc_paired<L>(2) ? 8 * (K % 2) + J : J;      // (paired: see mfma_chunk)
-                    if constexpr (dtp_group_has_out<L>(2)) v[J] = (acc2[T][R] + vacc2[K][J]) * g2[J]; else v[J] = acc2[T][R] * g2[J];
+                    if constexpr (pad_reg<L, NW>(2, J)) v[J] = 0.0f;
+                    else if constexpr (dtp_group_has_out<L>(2)) v[J] = (acc2[T][R] + vacc2[K][J]) * g2[J]; else v[J] = acc2[T][R] * g2[J];
                 });
-                park_chunk.template operator()<park_slot<L>(2, K, 0)>(v);
+                park_chunk.template operator()<park_slot<L>(2, K, 0), pad_reg<L, NW>(2, 2)>(v);
             });
         } else {
             static_for<7>([&]<int K>() {      // 16 channels (8 of them the zero padding of 8x3e) = registers 0-7
                 float v[8];
                 static_for<8>([&]<int J>() {
                     constexpr int T = acc_paired<L>(3) ? K / 2 : K, R = acc_paired<L>(3) ? 8 * (K % 2) + J : J;
-                    if constexpr (dtp_group_has_out<L>(3)) v[J] = (acc3[T][R] + vacc3[K][J]) * g3[J]; else v[J] = acc3[T][R] * g3[J];
+                    if constexpr (pad_reg<L, NW>(3, J)) v[J] = 0.0f;
+                    else if constexpr (dtp_group_has_out<L>(3)) v[J] = (acc3[T][R] + vacc3[K][J]) * g3[J]; else v[J] = acc3[T][R] * g3[J];
                 });
                 park_chunk.template operator()<park_slot<L>(3, K, 0)>(v);
             });
@@ -1190,10 +1206,12 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         using Cg = CG<l1, l2, l3>;
         float m[Cg::NM];
         Cg::make(Y.template get<l2>(), m);
-        constexpr int R_LAST = pad_reg<L>(l3, NR - 1) ? NR - 3 : NR - 1;      // last register that holds a true channel
+        constexpr int R_LAST = NR - 4 + pad_live<L, NW>(l3) - 1;      // last register that holds a true channel
         static_for<NR>([&]<int R>() {
-            if constexpr (pad_reg<L>(l3, R)) {      // a zero-padding output channel: nothing to contract
-                if constexpr (val_item_opens_group<L>(I)) static_for<d3>([&]<int K>() { if constexpr (l3 == 3) val3[K][R] = 0.0f; });
+            if constexpr (pad_reg<L, NW>(l3, R)) {      // a zero-padding output channel: nothing to contract (l3 = 0: the accumulator keeps its zero bias)
+                if constexpr (val_item_opens_group<L>(I)) static_for<d3>([&]<int K>() {
+                    if constexpr (l3 == 1) val1[K][R] = 0.0f; else if constexpr (l3 == 2) val2[K][R] = 0.0f; else if constexpr (l3 == 3) val3[K][R] = 0.0f;
+                });
             } else {
             float o[d3];
             static_for<d3>([&]<int K>() {

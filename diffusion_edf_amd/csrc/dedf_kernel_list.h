@@ -56,5 +56,9 @@
     X(26, void k_edge<3, 64, true, 32, 32>(EdgeParams))               \
     X(25, void k_node<3, false, true>(NodeParams))                    \
     X(26, void k_node<3, true, true>(NodeParams))                     \
-    X(27, void k_edge<2, 64, true, 32, 32>(EdgeParams))
-constexpr int kKernelUnits = 28;
+    X(27, void k_edge<2, 64, true, 32, 32>(EdgeParams))               \
+    X(28, void k_edge<2, 64, false, 32, 32, true, 0, true>(EdgeParams)) \
+    X(29, void k_edge<3, 64, false, 32, 32, true, 0, true>(EdgeParams)) \
+    X(30, void k_edge<2, 64, true, 32, 32, true, 0, true>(EdgeParams))  \
+    X(31, void k_edge<3, 64, true, 32, 32, true, 0, true>(EdgeParams))
+constexpr int kKernelUnits = 32;

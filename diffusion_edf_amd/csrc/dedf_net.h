@@ -208,7 +208,15 @@ template <int L> DEDF_HD constexpr int park_slots() { return park_slot<L>(L + 1,
 // registers that hold a 16-row block in either half-wave, and of the 4 channels of a lane's run of source rows, those with index % 4 >= 2 are
 // padding -- exactly 0 in every operand and result (and in every narrower UNet level, whose true channels are a subset).  The lane-local
 // Clebsch-Gordan work skips them.
-template <int L> DEDF_HD constexpr bool pad_reg(int l, int r) { return L == 3 && mul_of(l) != true_mul(l) && (r % 4) >= true_mul(l) / 4; }
+// NW ("narrow"): a UNet layer whose source AND destination irreps are the narrow level shape 32x0e+16x1e+8x2e(+4x3e) (levels 0-1 of the panda
+// UNets, unet_feature_extractor.py:141-202 with configs/panda_mug/pick_lowres/score_model_configs.yaml:33-55) embedded in the kernel shapes with
+// its true channels at the positions p with p % 4 < pad_live (diffusion_edf_amd/unet_pad.py::place): HALF of every block of degree <= 2 and a
+// QUARTER of the l = 3 block are structural zeros, and the narrow instantiations (k_edge<..., NW = true>) skip the lane-local work on them
+// like the lmax-3 kernels skip the padding of 8x3e.  The matrix products still run on the padded shapes (K = 16 steps, 32-row tiles).
+template <int L, bool NW = false> DEDF_HD constexpr int pad_live(int l) { return NW ? (l >= 3 ? 1 : 2) : ((L == 3 && l == 3) ? 2 : 4); }
+template <int L, bool NW = false> DEDF_HD constexpr bool pad_reg(int l, int r) { return (r % 4) >= pad_live<L, NW>(l); }
+// of the first n registers of a run that starts at a multiple of four: how many hold true channels / the index of register r among them
+template <int L, bool NW> DEDF_HD constexpr int live_count(int l, int n) { int c = 0; for (int r = 0; r < n; ++r) c += pad_reg<L, NW>(l, r) ? 0 : 1; return c; }
 // The l3 >= 2 accumulators of the first depth-wise TP's linear at lmax 3 hold two components per 32-row tile (dedf_edge.h::mfma_chunk):
 // 48 + 64 instead of 80 + 112 accumulator registers in the groups where k_edge<3> spills.
 #ifndef DEDF_PAIR_L2

@@ -147,9 +147,12 @@ class UnetLayer(torch.nn.Module):
         state = {k: v for k, v in self.state_dict().items()}
         if narrow:
             state = unet_pad.expand_layer_params(state, self.muls, self.fc_neurons, self.muls_src)
+        # both node sets in the narrow level shape (levels 0-1 of the panda UNets): the narrow instantiations of the layer kernels, which skip the
+        # lane-local work on the structurally zero channels (`unet_pad.place` puts the true ones where the kernels expect them)
+        nw = list(self.muls) == list(self.muls_src) == unet_pad.NARROW3[:len(self.muls)]
         ccfg = _lib.make_unet_layer_config(self.radius, idx, unet_pad.WIDE_FC, W, self.num_heads,
                                            valid=self.muls if self.muls != W else None,
-                                           fc_valid=self.fc_neurons if self.fc_neurons != unet_pad.WIDE_FC else None, half_gemm=self._half)
+                                           fc_valid=self.fc_neurons if self.fc_neurons != unet_pad.WIDE_FC else None, half_gemm=self._half, narrow=nw)
         blob = _lib.pack_params(ccfg, state)
         h = C.c_void_p()
         rc = lib.dedf_create(C.byref(ccfg), blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, C.byref(h))
@@ -440,14 +443,15 @@ class UnetFeatureExtractor(torch.nn.Module):
         lin = lambda mod, v: v if isinstance(mod, torch.nn.Identity) else mod.forward_wide(v)
         f = self.input_emb.forward_wide(self.input_emb.pad_in(f.detach().float()))
         down_out, down_edges, scale_out, used = [(f, x, b)], [], [], []
-        for blk in self.down_blocks:
-            f_dst, x_dst, es, ed, _, b_dst = blk['pool'](x, f, b, _trusted=single)                     # :279-282
+        for n_blk, blk in enumerate(self.down_blocks):
+            # (deterministic cascade: from the second level on the cloud is the previous level's FPS order, whose re-sampling is its own prefix)
+            f_dst, x_dst, es, ed, _, b_dst = blk['pool'](x, f, b, _trusted=single, _fps_ordered=single and self.deterministic and n_blk > 0, _need_degree=False)      # :279-282
             f_dst = lin(blk['pool_proj'], f_dst)
             f = run(blk['pool_layer'], x, f, x_dst, f_dst, es, ed, True)
             used.append(blk['pool_layer'])
             x, b = x_dst, b_dst
             down_out.append((f, x, b)); down_edges.append((es, ed))
-            _, _, es, ed, _, _ = blk['radius_graph'](x, f, b, _trusted=single)                          # :306-311
+            _, _, es, ed, _, _ = blk['radius_graph'](x, f, b, _trusted=single, _need_degree=False)                          # :306-311
             for layer in blk['layer_stack']:
                 f = run(layer, x, f, x, f, es, ed, True)
                 used.append(layer)

@@ -26,6 +26,7 @@ WIDE = [64, 32, 16]          # instantiated multiplicities (lmax 2)
 WIDE3 = [64, 32, 16, 16]     # lmax 3: the reference's widest 3e block, 8x3e, itself runs zero-padded to one 16-channel chunk (csrc/dedf_net.h::mul_of)
 WIDE_HID = [192, 96, 48, 32]   # FFN hidden multiplicities of the kernels (irreps_mlp_mid = 3; 24x3e padded to one 32-row tile: dedf_net.h::hid_of)
 WIDE_FC = [64, 32, 32]
+NARROW3 = [32, 16, 8, 4]       # the narrow level shape of the panda UNets (levels 0-1), per degree: dedf_config.unet_narrow
 HEADS = 4
 
 
@@ -39,9 +40,17 @@ def wide_dim(L: int) -> int:
 
 
 def place(m: int, M: int) -> torch.Tensor:
-    """index map true channel -> wide channel of one irreps block (per-head interleave; identity when m == M)"""
+    """index map true channel -> wide channel of one irreps block (identity when m == M).  Head h's m / 4 channels stay inside the head's M / 4 wide
+    channels (the kernels' head of a channel is channel // (M / 4)); inside a head they go to the positions p with p % 4 < q, q = 4 m / M
+    (half-filled blocks: 0, 1, 4, 5, 8, 9, ...; quarter-filled: 0, 4, 8, ...), so that every group of four wide channels holds the same number of
+    true ones: the narrow / lmax-3 instantiations of the kernels skip the lane-local work on the others (csrc/dedf_net.h::pad_live)."""
     c = torch.arange(m)
-    return (c // (m // HEADS)) * (M // HEADS) + c % (m // HEADS)
+    if m == M:
+        return c
+    q = 4 * m // M
+    assert m % HEADS == 0 and M % (4 * HEADS) == 0 and q in (1, 2) and 4 * m == q * M, (m, M)
+    k = c % (m // HEADS)
+    return (c // (m // HEADS)) * (M // HEADS) + 4 * (k // q) + k % q
 
 
 _PLACE_DEV = {}
@@ -183,13 +192,13 @@ def expand_layer_params(P: Dict[str, torch.Tensor], muls: Sequence[int], fc: Seq
     Q[f"{ga}.sep_act.lin.tp.weight"] = torch.cat([_embed(bl[0], kmap[0], o0, k_w[0], n0_w).reshape(-1)] +
                                                  [_embed(bl[l], kmap[l], pl[l], k_w[l], M[l]).reshape(-1) for l in range(1, L + 1)])
     Q[f"{ga}.sep_act.lin.bias.0"] = _vec(P[f"{ga}.sep_act.lin.bias.0"], o0, n0_w)
-    # sep_alpha: one block per scalar path (un-simplified input), alpha channel a = h * (m0/4) + k -> h * (M0/4) + k  (= place)
+    # sep_alpha: one block per scalar path (un-simplified input), alpha channel a = h * (m0/4) + k -> place(m0, M0)[a]
     a_t = [(paths_t[p][3], m[0]) for p in by_t[0]]
     bl = _blocks(P[f"{ga}.sep_alpha.tp.weight"], a_t)
     Q[f"{ga}.sep_alpha.tp.weight"] = torch.cat([_embed(b_, pl[paths_t[p][0]], pl[0], paths_w[p][3], M[0]).reshape(-1) for b_, p in zip(bl, by_t[0])])
     Q[f"{ga}.sep_alpha.bias.0"] = _vec(P[f"{ga}.sep_alpha.bias.0"], pl[0], M[0])
     ad = P[f"{ga}.alpha_dot"].reshape(HEADS, m[0] // HEADS)
-    adw = torch.zeros(HEADS, M[0] // HEADS); adw[:, : m[0] // HEADS] = ad
+    adw = torch.zeros(HEADS, M[0] // HEADS); adw[:, pl[0][: m[0] // HEADS]] = ad          # (head 0's positions inside a head: `place`)
     Q[f"{ga}.alpha_dot"] = adw.reshape(1, HEADS, M[0] // HEADS)
     bl = _blocks(P[f"{ga}.sep_value.lin.tp.weight"], [(k_t[l], m[l]) for l in range(L + 1)])
     Q[f"{ga}.sep_value.lin.tp.weight"] = torch.cat([_embed(bl[l], kmap[l], pl[l], k_w[l], M[l]).reshape(-1) for l in range(L + 1)])

@@ -90,6 +90,11 @@ typedef struct dedf_config {
                                             builds them); what the padding cannot express -- LayerNorm statistics over the true channels only -- is told
                                             to the kernels by these counts */
     int unet_fc_valid[3];                /* UNet layer: true {num_basis, h1, h2} of the radial network when narrower than fc_neurons (0 = fc_neurons) */
+    int unet_narrow;                     /* UNet layer, 1: BOTH node sets carry the narrow level shape 32x0e+16x1e+8x2e(+4x3e) (levels 0-1 of the panda UNets,
+                                            configs/panda_mug/pick_lowres/score_model_configs.yaml:33-55) with every true channel c of a block of m in M kernel
+                                            channels at head * (M / 4) + 4 * (k / q) + k % q, k = c % (m / 4), q = 4 m / M (diffusion_edf_amd/unet_pad.py::place):
+                                            the narrow instantiations of the layer kernels skip the lane-local work on the structurally zero channels.
+                                            Requires unet_valid = {32, 16, 8 (, 4)}.  0: any zero-padded embedding (the padding is computed like data) */
 } dedf_config;
 
 typedef struct dedf_schedule {           /* host arrays, one entry per denoising step (score_model_base.py:146-171) */
@@ -122,8 +127,8 @@ const char* dedf_version(void);
  * memory.  dedf_abi_version() is what the LOADED library was built with; dedf_struct_size(which) gives its sizeof of the struct
  * dedf_config [which = 0], dedf_schedule [1], dedf_stats [2], dedf_profile [3] for bindings that mirror the structs by hand (diffusion_edf_amd/_lib.py checks both).
  *   1  rounds 1-2.   2  round 3: dedf_config.unet_valid[4] (was [3]), dedf_stats.rtab_err / rtab_fallback, dedf_radius scratch arguments.
- *   3  round 4: dedf_abi_version / dedf_struct_size themselves; no struct change. */
-#define DEDF_ABI_VERSION 3
+ *   3  round 4: dedf_abi_version / dedf_struct_size themselves; no struct change.   4  round 4: dedf_config.unet_narrow (appended). */
+#define DEDF_ABI_VERSION 4
 int dedf_abi_version(void);
 size_t dedf_struct_size(int which);
 

@@ -33,6 +33,28 @@ def test_fps_oracle_properties():
     assert G.fps(np.zeros((4, 3), np.float32), 1.0).tolist() == [0, 0, 0, 0]
 
 
+@pytest.mark.parametrize("case", ["random", "grid_ties", "duplicates"])
+def test_fps_of_an_fps_ordered_cloud_is_its_prefix_on_the_oracle(case):
+    """what lets a deterministic FPS cascade (UNet levels 1.., `FpsPool(_fps_ordered=True)`) skip its re-sampling: FPS of a cloud given in the
+    selection order of an FPS that started at its first point returns 0, 1, 2, ... -- with exact distance ties (grid, duplicated points) too"""
+    rng = np.random.default_rng(3)
+    if case == "random":
+        x = rng.normal(size=(3000, 3)).astype(np.float32)
+    elif case == "grid_ties":
+        g = np.arange(12, dtype=np.float32)
+        x = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+        x = x[rng.permutation(len(x))]
+    else:
+        x = rng.normal(size=(800, 3)).astype(np.float32)
+        x = np.concatenate([x, x[:300], x[100:200]], 0)
+    for ratio in (0.2, 0.5):
+        p0 = G.fps(x, ratio)
+        sub = x[p0]
+        for r1 in (0.2, 0.37, 1.0):
+            p1 = G.fps(sub, r1)
+            assert np.array_equal(p1, np.arange(len(p1))), (case, ratio, r1)
+
+
 def test_radius_oracle_properties():
     x, y = _cloud(300, 1), _cloud(120, 2)
     ed, es = G.radius(x, y, 9.0, 1000)
@@ -100,6 +122,27 @@ def test_fps_bucketed_kernel_bit_exact(case):
         assert lib.dedf_fps(xd.data_ptr(), len(x), len(ref), start, out.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
         got = out.cpu().numpy().astype(np.int64)
     assert np.array_equal(got, ref), (case, int(np.argmax(got != ref)))
+
+
+@pytest.mark.gpu
+def test_fps_of_an_fps_ordered_cloud_is_its_prefix():
+    """the same on the kernels (plain and bucketed FPS), and FpsPool(_fps_ordered=True) against the sampled pool"""
+    from diffusion_edf_amd import connectivity as CN
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(4)
+    g = np.arange(10, dtype=np.float32)
+    grid = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    for x in (rng.normal(size=(16384, 3)).astype(np.float32), grid[rng.permutation(len(grid))], synthetic.make_scene(9000, seed=2).astype(np.float32)):
+        xt = torch.from_numpy(x).to(dev)
+        p0 = CN.fps(xt, None, ratio=0.2, random_start=False)
+        sub = xt[p0]
+        p1 = CN.fps(sub, None, ratio=0.2, random_start=False)
+        assert torch.equal(p1.cpu(), torch.arange(len(p1)))
+        b = torch.zeros(len(sub), dtype=torch.long, device=dev)
+        f = torch.randn(len(sub), 5, device=dev)
+        pool = CN.FpsPool(ratio=0.2, random_start=False, r=2.5, max_num_neighbors=1000)
+        a, c = pool(sub, f, b), pool(sub, f, b, _fps_ordered=True)
+        assert all(torch.equal(u, v) for u, v in zip(a, c))
 
 
 @pytest.mark.gpu
