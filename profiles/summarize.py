@@ -48,7 +48,13 @@ def main(tag):
     # the kernel of bench.py's TIMED region: the sampler's table-reading instantiation (`..., false, 1>`) when it ran, else the per-edge one
     # (which also serves the untimed score-forward figure of the same command)
     edge_names = [n for n in pmc if n.startswith("void k_edge")]
-    timed = [n for n in edge_names if n.rstrip().split("(")[0].endswith(", 1>")] or edge_names
+    def mode_of(name):          # k_edge<L, F0, HP, H1, H2, UN, MODE[, NW]>: template argument 6
+        args = name.split("<", 1)[1].rsplit(">", 1)[0].split(",") if "<" in name else []
+        return args[6].strip() if len(args) > 6 else "0"
+    def is_unet(name):
+        args = name.split("<", 1)[1].rsplit(">", 1)[0].split(",") if "<" in name else []
+        return len(args) > 5 and args[5].strip() == "true"
+    timed = [n for n in edge_names if mode_of(n) == "1"] or [n for n in edge_names if not is_unet(n)] or edge_names
     summary["edge_kernel_name"] = timed[-1] if timed else None
     # average duration of the timed kernel in the kernel trace of the same command, and the MFMA issue fraction that follows from it:
     # SQ_INSTS_MFMA x 32 768 FLOP (one v_mfma_f32_32x32x16_f16) / launch time / 2.5 PFLOP/s dense fp16
