@@ -221,6 +221,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extractors", action="store_true", help="skip the (untimed) feature-extractor measurement")
     ap.add_argument("--no-small-batches", action="store_true", help="skip the (untimed) 16 / 64 / 256-pose rows: profiles/collect.sh, so that per-kernel averages of a trace are those of the timed launches")
+    ap.add_argument("--no-score-fwd", action="store_true", help="skip the (untimed) score-forward figure at t = 0.5: profiles/collect.sh, so that a kernel trace holds the sampler's launches only")
     ap.add_argument("--no-radial-table", action="store_true", help="evaluate the radial network's front per edge in the sampler too (A/B; the default tabulates it per step)")
     ap.add_argument("--config5", action="store_true", help="BASELINE config 5 as one assembled model: lmax 3, 16 384-point scene -> UNet key model -> key clouds 3277/656/132/27, "
                                                           "1 024-point grasp -> KeypointExtractor -> query EDF, then the sampler; NOT the headline configuration (C2)")
@@ -333,7 +334,7 @@ def main():
     # outside the timed region: the score forward alone on the SEEDED poses at the fixed time t = 0.5 --
     # a figure that does not depend on --steps (the edge count of a trajectory drifts with the number of steps taken)
     fixed = None
-    if rank == 0:
+    if rank == 0 and not args.no_score_fwd:
         Tf = Ts.float()
         tf = torch.full((len(Tf),), 0.5, device=device)
         for _ in range(2):

@@ -6,7 +6,7 @@ set -u
 TAG=${1:-r01}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
-CMD=${CMD:-"python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extractors --no-small-batches"}      # e.g. CMD="python $ROOT/bench.py --lmax 3 --steps 5 --warmup 1 --no-cpu-baseline --no-extractors --no-small-batches" for another workload
+CMD=${CMD:-"python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extractors --no-small-batches --no-score-fwd"}      # e.g. CMD="python $ROOT/bench.py --lmax 3 --steps 5 --warmup 1 --no-cpu-baseline --no-extractors --no-small-batches" for another workload
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 PASSES=${2:-"trace fetch write sq sq2 sq3 tcp bench"}     # each PMC pass costs ~3.5 min of box time

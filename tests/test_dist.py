@@ -120,3 +120,55 @@ def test_agent_cascade_sharded_equals_single_process():
     assert ref.shape == (8, n_poses, 7)
     for rank, out in res:
         assert torch.equal(out, ref)
+
+
+# ---- the product under RCCL (one MI355X: world size 1) ----------------------------------------------------------------------------------------
+
+def _nccl_worker(port, q):
+    """one rank, backend "nccl" (= RCCL on ROCm): the REAL sampler through dist.sample_sharded -- process-group init on the device, the pose
+    shard of the rank, the closing all-gather on the GPU stream -- against the plain single-process call"""
+    import sys
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import stage_check as SC
+        from diffusion_edf_amd.gnn_data import FeaturedPoints
+        from diffusion_edf_amd.score_head import ScoreModelHead
+        from diffusion_edf_amd.score_model_base import ScoreModelBase
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        kw, cfg, P, keys, query, Ts, _ = SC.build_case(2, 9, 512, 60)
+        head = ScoreModelHead(**kw); head.load_state_dict(P); head.to(dev)
+        m = ScoreModelBase(head)
+        gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
+        gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
+        args = dict(diffusion_schedules=[[1.0, 0.5]], N_steps=[3], timesteps=[0.04], temperatures=1.0)
+        ref = m.sample(Ts.to(dev), gk, gq, seed=7, **args)
+        final = ddist.sample_sharded(m, Ts.to(dev), gk, gq, seed=7, **args)
+        traj = ddist.sample_sharded(m, Ts.to(dev), gk, gq, seed=7, gather_trajectory=True, **args)
+        dist.barrier()
+        ok = bool(torch.equal(final, ref[-1]) and torch.equal(traj, ref) and final.is_cuda and torch.isfinite(traj).all())
+        q.put(("ok" if ok else "mismatch", dist.get_backend()))
+        dist.destroy_process_group()
+    except Exception as e:          # noqa: BLE001
+        q.put(("error: " + repr(e), ""))
+
+
+@pytest.mark.gpu
+def test_real_sampler_under_rccl_world_size_one():
+    """the product (not a stand-in) under `torch.distributed` with the nccl backend -- RCCL init, shard, sampler, all-gather -- in a spawned rank"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(port, q))
+    p.start()
+    res, backend = q.get(timeout=600)
+    p.join(timeout=120)
+    assert res == "ok" and backend == "nccl", (res, backend)
+    assert p.exitcode == 0
