@@ -87,6 +87,18 @@ struct dedf_handle {
     int radial_table = 1;         // sampler: tabulate the radial network's front per launch (DEDF_RADIAL_TABLE=0 / dedf_set_radial_table turn it off)
     DevBuf d_rtab, d_rtab_err;    // table rows; per-scale accuracy words (largest |interpolated - exact| activation at the interval midpoints)
     float rtab_err_bound = 1e-5f; // a scale whose word exceeds it evaluates its front per edge (DEDF_RADIAL_TABLE_BOUND)
+    // dedf_sample, round 4, OPT-IN (DEDF_RTAB_ASYNC=1) -- built, correct (the sampler tests pass on it), and SLOWER: the tables of the coming steps are
+    // generated on a SIDE stream into a ring of kRtabRing tables while the main stream runs the current step (a step's table depends on its time
+    // only), which takes the 34 us generator off the step's dependent chain and lets batches below kRtabMinNodes use the table.  Measured
+    // (profiles/r04j_*): C2 341.4 k -> 330.5 k pose-steps/s (k_edge 2.39 -> 2.48 ms: the generator's 1 217 workgroups take wave slots from the
+    // persistent edge grid, whose displaced waves then run a round of their own), 16 poses 0.156 -> 0.197 ms per step (the generator competes with
+    // the single-round, latency-bound kernels of a small step).  The default generates every table on the main stream, as rounds 2-3 did.
+    static constexpr int kRtabRing = 4;
+    hipStream_t side = nullptr;
+    hipEvent_t rt_tab[kRtabRing] = {nullptr, nullptr, nullptr, nullptr}, rt_used[kRtabRing] = {nullptr, nullptr, nullptr, nullptr}, rt_ready = nullptr;
+    DevBuf d_rtab_ring;
+    int tab_slot = -1;            // >= 0 inside dedf_sample's loop: the ring slot that holds THIS step's table
+    bool rtab_async = false;      // DEDF_RTAB_ASYNC=1 turns the side-stream generation on (A/B)
     DevBuf d_cnt2, d_blk2; int small_parity = 0; int64_t small_layout = -1;      // the two alternating count sets of the small-batch neighbour path
     Image edge16_img; Edge16Offsets e16{}; DevBuf d_edge16_w;      // the 16-edge tile's weight image (dedf_pack16.h), lmax-2 score heads
     int edge16 = 0;                   // DEDF_EDGE16=1: the sampler's table path on the 16-edge / two-waves-per-SIMD kernel (dedf_edge16.h)
@@ -114,7 +126,12 @@ struct dedf_handle {
     size_t ev_used = 0;
     int64_t prof_evals = 0, prof_dst = 0;
     DevBuf d_hist, d_phase;
-    ~dedf_handle() { for (auto e : ev) (void)hipEventDestroy(e); }
+    ~dedf_handle() {
+        for (auto e : ev) (void)hipEventDestroy(e);
+        for (int i = 0; i < kRtabRing; ++i) { if (rt_tab[i]) (void)hipEventDestroy(rt_tab[i]); if (rt_used[i]) (void)hipEventDestroy(rt_used[i]); }
+        if (rt_ready) (void)hipEventDestroy(rt_ready);
+        if (side) (void)hipStreamDestroy(side);
+    }
 };
 
 namespace {
@@ -459,6 +476,39 @@ void launch_radial_table(dedf_handle* h, const EdgeParams& P, hipStream_t st, bo
     hipLaunchKernelGGL((k_radial_table<L, F0, false, H1, H2>), dim3(std::min(ntab, h->n_cu * 4)), dim3(64), 0, st, P);
     if (check) hipLaunchKernelGGL((k_radial_check<L, F0, false, H1, H2>), dim3(std::min(nchk, h->n_cu * 4)), dim3(64), 0, st, P);
 }
+constexpr int kRtabAsyncMinNodes = 1024;      // with the generator off the step's dependent chain the table pays from ~one round of edge tiles on
+size_t radial_table_rows(const dedf_handle* h) {
+    size_t row = 0;
+    for (int n = 0; n < h->cfg.n_scales; ++n) row += (h->cfg.radii[n] > 0 ? kRtabFinite : kRtabInfinite) + 3;
+    return row;
+}
+// side stream: the table of the step whose time-bias rows are h->tb_step, into ring slot `slot`
+template <int L, int F0>
+int radial_table_async(dedf_handle* h, int slot) {
+    if constexpr (has_radial_table<L, F0>()) {
+        EdgeParams P = edge_params<L, F0>(h, 1, 0);
+        int rc = radial_table_setup(h, P);
+        if (rc != DEDF_OK) return rc;
+        P.rtab_out = h->d_rtab_ring.as<float>() + (size_t)slot * radial_table_rows(h) * 64;
+        if (h->cfg.fc_neurons[1] == 32) { if constexpr (L == 2 && F0 == 128) launch_radial_table<L, F0, 32, 32>(h, P, h->side, false); }
+        else launch_radial_table<L, F0, 128, 64>(h, P, h->side, false);
+    }
+    return DEDF_OK;
+}
+int radial_table_async_dispatch(dedf_handle* h, int slot) {
+    const int F0 = h->cfg.fc_neurons[0];
+    if (h->L == 2 && F0 == 128) return radial_table_async<2, 128>(h, slot);
+    if (h->L == 2 && F0 == 192) return radial_table_async<2, 192>(h, slot);
+    if (h->L == 3 && F0 == 128) return radial_table_async<3, 128>(h, slot);
+    return DEDF_OK;
+}
+bool radial_table_instantiated_rt(const dedf_handle* h) {
+    const int F0 = h->cfg.fc_neurons[0];
+    if (h->L == 2 && F0 == 128) return table_instantiated<2, 128>(h);
+    if (h->L == 2 && F0 == 192) return table_instantiated<2, 192>(h);
+    if (h->L == 3 && F0 == 128) return table_instantiated<3, 128>(h);
+    return false;
+}
 // dedf_sample, before its loop: table + check at the time-bias rows h->tb_step (the accuracy words accumulate over the calls)
 template <int L, int F0>
 int radial_table_check(dedf_handle* h, hipStream_t st) {
@@ -560,17 +610,23 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         bool use_tab = false;
         if constexpr (has_radial_table<L, F0>()) {
             // (worth its 34 us generator launch from ~6 rounds of edge tiles on: ~20 edges per destination node -> 8 192 nodes)
-            use_tab = table_instantiated<L, F0>(h) && h->radial_table != 0 && P.tb_pose_stride == 0 && !h->debug && (Nd >= kRtabMinNodes || h->radial_table == 2);
+            const bool async_tab = h->tab_slot >= 0;      // dedf_sample: this step's table was generated on the side stream (ring slot h->tab_slot)
+            use_tab = table_instantiated<L, F0>(h) && h->radial_table != 0 && P.tb_pose_stride == 0 && !h->debug && (Nd >= kRtabMinNodes || h->radial_table == 2 || async_tab);
             if (use_tab) {
                 int rc = radial_table_setup(h, P);
                 if (rc != DEDF_OK) return rc;
+                if (async_tab) {
+                    P.rtab = h->d_rtab_ring.as<float>() + (size_t)h->tab_slot * radial_table_rows(h) * 64;
+                    P.rtab_out = const_cast<float*>(P.rtab);
+                    HIPCK(h, hipStreamWaitEvent(st, h->rt_tab[h->tab_slot], 0));
+                }
                 if (narrow) {
                     if constexpr (L == 2 && F0 == 128) {
-                        launch_radial_table<L, F0, 32, 32>(h, P, st, false);
+                        if (!async_tab) launch_radial_table<L, F0, 32, 32>(h, P, st, false);
                         DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 32, 32, false, 1>), kAll, st, P);
                     }
                 } else {
-                    launch_radial_table<L, F0, 128, 64>(h, P, st, false);
+                    if (!async_tab) launch_radial_table<L, F0, 128, 64>(h, P, st, false);
                     bool on16 = false;
                     if constexpr (L == 2 && F0 == 128) on16 = h->edge16 != 0 && h->e16.ok && !c.use_src_point_attn;
                     if (on16) {
@@ -587,6 +643,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
                         }
                     } else DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 128, 64, false, 1>), kAll, st, P);
                 }
+                if (async_tab) HIPCK(h, hipEventRecord(h->rt_used[h->tab_slot], st));      // the slot may be refilled once this edge kernel is done
             }
         }
         // dedf_score (one time PER pose): when all the times are equal -- the reference's own callers evaluate a batch at ONE diffusion time
@@ -760,6 +817,7 @@ int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, de
     if (const char* e = getenv("DEDF_RADIAL_TABLE")) h->radial_table = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("DEDF_RADIAL_TABLE_BOUND")) h->rtab_err_bound = (float)atof(e);
     if (const char* e = getenv("DEDF_SMALL_BATCH")) h->small_batch_path = atoi(e) != 0;
+    if (const char* e = getenv("DEDF_RTAB_ASYNC")) h->rtab_async = atoi(e) != 0;
     if (const char* e = getenv("DEDF_EDGE_OCC")) h->edge_occ = atoi(e) != 0;
     if (const char* e = getenv("DEDF_EDGE16")) h->edge16 = atoi(e);
     const IrrepsRT T(h->L, cfg->unet_layer != 0), K(h->L, true);
@@ -1030,6 +1088,7 @@ static int sample_once(dedf_handle* h, int nT, const double* T_seed, const dedf_
     HIPCK(h, hipMemcpyAsync(Ts_out, T_seed, row * 8, hipMemcpyDeviceToDevice, st));
     // every pose shares the step's time: the time-bias rows of all steps come from ONE launch before the loop
     const size_t tb_row = (size_t)h->cfg.n_scales * h->cfg.fc_neurons[0];
+    bool use_async = false;
     if (sched->n_steps > 0) {
         if (!h->d_tb_steps.ensure((size_t)sched->n_steps * tb_row * 4) || !h->d_time.ensure((size_t)std::max(nT, sched->n_steps) * 4))
             return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(time rows) failed");
@@ -1040,7 +1099,9 @@ static int sample_once(dedf_handle* h, int nT, const double* T_seed, const dedf_
         // Accuracy guard of the radial table, once per call: the table of the first, the middle and the last step (the time only shifts the
         // pre-linear's bias rows; what decides the interpolation error is the length encoder) is checked at EVERY interval midpoint of every
         // scale against the exact evaluation; a scale whose largest deviation exceeds the bound evaluates its front per edge in this call.
-        if (h->radial_table != 0 && ((int64_t)nT * h->nQ >= kRtabMinNodes || h->radial_table == 2) && !h->debug) {
+        const int64_t Nd_call = (int64_t)nT * h->nQ;
+        use_async = h->rtab_async && h->radial_table != 0 && !h->debug && radial_table_instantiated_rt(h) && (Nd_call >= kRtabAsyncMinNodes || h->radial_table == 2);
+        if (h->radial_table != 0 && (Nd_call >= kRtabMinNodes || h->radial_table == 2 || use_async) && !h->debug) {
             if (h->d_rtab_err.p) HIPCK(h, hipMemsetAsync(h->d_rtab_err.p, 0, kMaxScales * 4, st));
             int last = -1;
             for (int s : {0, sched->n_steps / 2, sched->n_steps - 1}) {
@@ -1053,6 +1114,29 @@ static int sample_once(dedf_handle* h, int nT, const double* T_seed, const dedf_
             }
         }
     }
+    constexpr int R = dedf_handle::kRtabRing;
+    auto gen_ahead = [&](int step, bool wait_used) -> int {      // side stream: the table of `step` into slot step % R
+        const int slot = step % R;
+        if (wait_used) HIPCK(h, hipStreamWaitEvent(h->side, h->rt_used[slot], 0));
+        h->tb_step = h->d_tb_steps.as<float>() + (size_t)step * tb_row;
+        const int rc2 = radial_table_async_dispatch(h, slot);
+        h->tb_step = nullptr;
+        if (rc2 != DEDF_OK) return rc2;
+        HIPCK(h, hipEventRecord(h->rt_tab[slot], h->side));
+        return DEDF_OK;
+    };
+    if (use_async) {
+        if (!h->side) {
+            HIPCK(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+            for (int i = 0; i < R; ++i) { HIPCK(h, hipEventCreateWithFlags(&h->rt_tab[i], hipEventDisableTiming)); HIPCK(h, hipEventCreateWithFlags(&h->rt_used[i], hipEventDisableTiming)); }
+            HIPCK(h, hipEventCreateWithFlags(&h->rt_ready, hipEventDisableTiming));
+        }
+        if (!h->d_rtab_ring.ensure((size_t)R * radial_table_rows(h) * 64 * 4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(radial table ring) failed");
+        // the side stream starts behind the time-bias rows and the guard's launches of the main stream
+        HIPCK(h, hipEventRecord(h->rt_ready, st));
+        HIPCK(h, hipStreamWaitEvent(h->side, h->rt_ready, 0));
+        for (int s = 0; s < std::min(R, sched->n_steps); ++s) { rc = gen_ahead(s, false); if (rc != DEDF_OK) return rc; }
+    }
     for (int s = 0; s < sched->n_steps; ++s) {
         // one step = pose prep (reads the f64 state), neighbour count + fill, edge, aggregate, node, reduce + Langevin update
         LangevinParams lp{};
@@ -1064,9 +1148,11 @@ static int sample_once(dedf_handle* h, int nT, const double* T_seed, const dedf_
         lp.traj_out = Ts_out + (size_t)(s + 1) * row; lp.nT = nT;
         h->tb_step = h->d_tb_steps.as<float>() + (size_t)s * tb_row;
         h->fused_step = &lp;
+        h->tab_slot = use_async ? s % R : -1;
         rc = score_dispatch(h, nT, 0, h->d_ang.as<float>(), h->d_lin.as<float>(), st);
-        h->tb_step = nullptr; h->fused_step = nullptr;
+        h->tb_step = nullptr; h->fused_step = nullptr; h->tab_slot = -1;
         if (rc != DEDF_OK) return rc;
+        if (use_async && s + R < sched->n_steps) { rc = gen_ahead(s + R, true); if (rc != DEDF_OK) return rc; }
     }
     HIPCK(h, hipMemcpyAsync(Ts_out + (size_t)(sched->n_steps + 1) * row, h->d_T64.p, row * 8, hipMemcpyDeviceToDevice, st));
     HIPCK(h, hipStreamSynchronize(st));

@@ -648,7 +648,16 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
 #ifndef DEDF_PDA2
 #define DEDF_PDA2 3
 #endif
-    constexpr int NCHK = WN / 16, PDA = L == 3 ? DEDF_PDA3 : DEDF_PDA2;
+    // (round 4, after the debug hooks left the table-reading kernel with 27 spare registers: its two operand rings one step deeper each -- lin / alpha
+    //  stream 6 items, value stream 3 -- k_edge 2.92 -> 2.85 ms at 2.37 M edges in three interleaved A/B rounds, profiles/r04h_edge_variants_ab.log;
+    //  512 registers, no scratch.  The per-edge kernels and lmax 3 keep their depths: 6 / 3 spill there or change nothing, r04i_*)
+#ifndef DEDF_PDA2_TAB
+#define DEDF_PDA2_TAB 6
+#endif
+#ifndef DEDF_V_PDA_TAB
+#define DEDF_V_PDA_TAB 3
+#endif
+    constexpr int NCHK = WN / 16, PDA = L == 3 ? DEDF_PDA3 : ((L == 2 && MODE == 1 && F0 == 128) ? DEDF_PDA2_TAB : DEDF_PDA2);
     struct XOps { f32x4 x[2][2 * L + 1]; f32x4 xd[UN ? 2 : 1][2 * L + 1]; };
     auto load_X = [&]<int C>() {      // this lane's 2 x 4 source-message rows of the chunk (contiguous runs in the reference layout)
         XOps o{};
@@ -1092,7 +1101,11 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
 #if defined(DEDF_TIMING_NO_RECORDS)      // timing experiment only (wrong results): everything is computed, no segment record leaves the kernel
         if (seg_last && P.nQ < 0) static_for<NS>([&]<int n>() { st4(orec + rec_off[n], f32x4{x[n][0], x[n][1], x[n][2], x[n][3]} * inv[n]); });
 #else
+#if defined(DEDF_NO_PK)      // experiment: four scalar products instead of the packed pair hipcc makes of `f32x4 * float`
+        if (seg_last) static_for<NS>([&]<int n>() { st4(orec + rec_off[n], f32x4{x[n][0] * inv[n], x[n][1] * inv[n], x[n][2] * inv[n], x[n][3] * inv[n]}); });
+#else
         if (seg_last) static_for<NS>([&]<int n>() { st4(orec + rec_off[n], f32x4{x[n][0], x[n][1], x[n][2], x[n][3]} * inv[n]); });
+#endif
 #endif
     };
     auto store_group = [&]<int l3>() {       // value in internal layout [l][m][channel]; head of a channel = channel / (mul / 4)
@@ -1106,7 +1119,14 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 ro[n] = T * 32 + 8 * g + 4 * hi; iv[n] = inv_s[hd];
                 x[n] = f32x4{val0[T][4 * g], val0[T][4 * g + 1], val0[T][4 * g + 2], val0[T][4 * g + 3]};
                 if constexpr (DBG) { x[n] = x[n] * cv0; if (drec != nullptr && valid) st4(drec + ro[n], x[n]); x[n] = x[n] * pw[hd]; }
-                else x[n] = x[n] * (cv0 * pw[hd]);          // (one product per value: the power-of-two operand scale folds into the softmax weight exactly)
+                else {
+                    const float sc_ = cv0 * pw[hd];
+#if defined(DEDF_NO_PK)
+                    x[n] = f32x4{x[n][0] * sc_, x[n][1] * sc_, x[n][2] * sc_, x[n][3] * sc_};
+#else
+                    x[n] = x[n] * sc_;
+#endif
+                }          // (one product per value: the power-of-two operand scale folds into the softmax weight exactly)
             }); });
             emit(x, ro, iv);
         } else if constexpr (l3 == 1) {
@@ -1116,7 +1136,14 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 ro[n] = blk_off(1) + K * mul_of(1) + 8 * g + 4 * hi; iv[n] = inv_s[g];
                 x[n] = f32x4{val1[K][4 * g], val1[K][4 * g + 1], val1[K][4 * g + 2], val1[K][4 * g + 3]};
                 if constexpr (DBG) { x[n] = x[n] * cv1; if (drec != nullptr && valid) st4(drec + ro[n], x[n]); x[n] = x[n] * pw[g]; }
-                else x[n] = x[n] * (cv1 * pw[g]);
+                else {
+                    const float sc_ = cv1 * pw[g];
+#if defined(DEDF_NO_PK)
+                    x[n] = f32x4{x[n][0] * sc_, x[n][1] * sc_, x[n][2] * sc_, x[n][3] * sc_};
+#else
+                    x[n] = x[n] * sc_;
+#endif
+                }
             }); });
             emit(x, ro, iv);
         } else if constexpr (l3 == 2) {
@@ -1126,7 +1153,14 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 ro[n] = blk_off(2) + K * mul_of(2) + 8 * g + 4 * hi; iv[n] = hi ? inv_s[2 * g + 1] : inv_s[2 * g];
                 x[n] = f32x4{val2[K][4 * g], val2[K][4 * g + 1], val2[K][4 * g + 2], val2[K][4 * g + 3]};
                 if constexpr (DBG) { x[n] = x[n] * cv2; if (drec != nullptr && valid) st4(drec + ro[n], x[n]); x[n] = x[n] * (hi ? pw[2 * g + 1] : pw[2 * g]); }
-                else x[n] = x[n] * (cv2 * (hi ? pw[2 * g + 1] : pw[2 * g]));
+                else {
+                    const float sc_ = cv2 * (hi ? pw[2 * g + 1] : pw[2 * g]);
+#if defined(DEDF_NO_PK)
+                    x[n] = f32x4{x[n][0] * sc_, x[n][1] * sc_, x[n][2] * sc_, x[n][3] * sc_};
+#else
+                    x[n] = x[n] * sc_;
+#endif
+                }
             }); });
             emit(x, ro, iv);
         } else {
@@ -1136,7 +1170,14 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 ro[n] = blk_off(3) + K * mul_of(3) + 8 * g + 4 * hi; iv[n] = hi ? inv_s[2 * g + 1] : inv_s[2 * g];
                 x[n] = f32x4{val3[K][4 * g], val3[K][4 * g + 1], val3[K][4 * g + 2], val3[K][4 * g + 3]};
                 if constexpr (DBG) { x[n] = x[n] * cv3; if (drec != nullptr && valid) st4(drec + ro[n], x[n]); x[n] = x[n] * (hi ? pw[2 * g + 1] : pw[2 * g]); }
-                else x[n] = x[n] * (cv3 * (hi ? pw[2 * g + 1] : pw[2 * g]));
+                else {
+                    const float sc_ = cv3 * (hi ? pw[2 * g + 1] : pw[2 * g]);
+#if defined(DEDF_NO_PK)
+                    x[n] = f32x4{x[n][0] * sc_, x[n][1] * sc_, x[n][2] * sc_, x[n][3] * sc_};
+#else
+                    x[n] = x[n] * sc_;
+#endif
+                }
             }); });
             emit(x, ro, iv);
         }
@@ -1149,7 +1190,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
 #ifndef DEDF_V_LAG
 #define DEDF_V_LAG 1
 #endif
-    constexpr int NVI = val_num_items<L>(), PDV = DEDF_V_PDA, RS = 2 * (PDV + 1), LAG = DEDF_V_LAG;
+    constexpr int NVI = val_num_items<L>(), PDV = (L == 2 && MODE == 1 && F0 == 128) ? DEDF_V_PDA_TAB : DEDF_V_PDA, RS = 2 * (PDV + 1), LAG = DEDF_V_LAG;
     const int o_S_val = opaque_s(P.o_S_val);
     struct ASlot { f32x4 h, l; };
     struct BSet { f32x4 h[3], l[3]; };
@@ -1234,7 +1275,10 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     };
     static_for<PDV>([&]<int I>() { load_A_of.template operator()<I>(); });
     BSet vb_cur = load_B.template operator()<0>();
-    f32x16 G[3], Gfin[3];
+    // G: the accumulator tiles of the item in flight; Gq: the tiles of completed items waiting for their contraction, LAG regions behind the MFMAs that
+    // finished them (a ring of LAG sets: the contraction of region I reads what item I - LAG left, so with LAG >= 2 no VALU instruction of a region
+    // waits for an MFMA of the region before)
+    f32x16 G[3], Gq[LAG > 0 ? LAG : 1][3];
     static_for<NVI + LAG>([&]<int I>() {
         lane16_t = tie(wv.lane16, tok); lane16_r16_t = tie(wv.lane16_r16, tok); lane_t = tie(wv.lane, tok);
         load_A_of.template operator()<I + PDV>();
@@ -1242,10 +1286,10 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         sched_fence();
         constexpr int F = I - LAG;                       // item whose accumulators are contracted in this region
         constexpr bool fin = F >= 0 && val_item<L>(F).last;
-        if constexpr (LAG && fin) static_for<3>([&]<int a>() { Gfin[a] = G[a]; });
+        if constexpr (LAG > 0 && I >= 1 && I - 1 < NVI) { if constexpr (val_item<L>(I - 1).last) static_for<3>([&]<int a>() { Gq[(I - 1) % (LAG > 0 ? LAG : 1)][a] = G[a]; }); }
         if constexpr (I < NVI) run_item.template operator()<I>(vb_cur, G);
         if constexpr (fin) {
-            if constexpr (LAG) contract.template operator()<F>(Gfin); else contract.template operator()<F>(G);
+            if constexpr (LAG > 0) contract.template operator()<F>(Gq[F % (LAG > 0 ? LAG : 1)]); else contract.template operator()<F>(G);
             constexpr int ge = val_item<L>(F).group_end;
             if constexpr (ge >= 0 && ge < L) store_group.template operator()<ge>();
         }

@@ -8,7 +8,8 @@ from diffusion_edf_amd.score_head import ScoreModelHead
 from diffusion_edf_amd.score_model_base import ScoreModelBase
 dev = torch.device("cuda:0")
 NP = int(os.environ.get('POSES', '1000'))          # POSES=16: the small-batch regime (one round of tiles per kernel)
-kw, cfg, P, keys, query, Ts = bench.build_inputs(2, 4096, 1024, NP, 0, dev)
+LMAX = int(os.environ.get("LMAX", "2"))
+kw, cfg, P, keys, query, Ts = bench.build_inputs(LMAX, 4096, 1024, NP, 0, dev)
 head = ScoreModelHead(**kw); head.load_state_dict(P); head.to(dev)
 m = ScoreModelBase(head)
 def run():

@@ -1,13 +1,13 @@
 # scratch driver of one gpurun call (edited per session): results under gpurun_out/
 mkdir -p gpurun_out
-T=r04d
-python tests/probe/call_overhead.py > gpurun_out/${T}_call_overhead.log 2>&1; grep lmax gpurun_out/${T}_call_overhead.log
-bash profiles/collect.sh ${T} "trace fetch write sq sq2 sq3 bench" > gpurun_out/${T}_collect.log 2>&1
-DEDF_SUMMARY_DIR=gpurun_out python profiles/summarize.py ${T} > gpurun_out/${T}_summarize.log 2>&1; grep -v per_kernel gpurun_out/${T}_summarize.log | tail -40
-CMD="python $GRAFT_REPO_ROOT/bench.py --lmax 3 --steps 5 --warmup 1 --no-cpu-baseline --no-extractors --no-small-batches" bash profiles/collect.sh ${T}_lmax3 "trace sq2" > gpurun_out/${T}_lmax3_collect.log 2>&1
-DEDF_SUMMARY_DIR=gpurun_out python profiles/summarize.py ${T}_lmax3 > gpurun_out/${T}_lmax3_summarize.log 2>&1; grep -v per_kernel gpurun_out/${T}_lmax3_summarize.log | tail -12
-CMD="python $GRAFT_REPO_ROOT/bench.py --config5 --steps 5 --warmup 1 --no-cpu-baseline --no-small-batches" bash profiles/collect.sh ${T}_config5 "trace fetch write sq2" > gpurun_out/${T}_config5_collect.log 2>&1
-DEDF_SUMMARY_DIR=gpurun_out python profiles/summarize.py ${T}_config5 > gpurun_out/${T}_config5_summarize.log 2>&1; grep -v per_kernel gpurun_out/${T}_config5_summarize.log | tail -12
-find gpurun_out -maxdepth 1 -type d -name "${T}*" -exec rm -rf {} +      # the rocpd databases (hundreds of MB) stay on the box: the summaries travel
-grep lmax gpurun_out/${T}_call_overhead.log
-du -sh gpurun_out
+T=r04j
+python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "sampler or radial or table or c2 or c1 or c3 or overflow or workspace or philox or tiny or zero_edge" > gpurun_out/${T}_tests_sampler.log 2>&1; tail -4 gpurun_out/${T}_tests_sampler.log
+python -m pytest tests/test_lmax3.py -m gpu -q -x -k "sampler" > gpurun_out/${T}_tests_lmax3.log 2>&1; tail -3 gpurun_out/${T}_tests_lmax3.log
+python tests/probe/small_batch.py 2 200 2>&1 | grep lmax > gpurun_out/${T}_small_batch.log; cat gpurun_out/${T}_small_batch.log
+DEDF_RTAB_ASYNC=0 python tests/probe/small_batch.py 2 200 2>&1 | grep lmax > gpurun_out/${T}_small_batch_sync_tables.log; cat gpurun_out/${T}_small_batch_sync_tables.log
+for i in 1 2; do
+python bench.py --no-cpu-baseline --no-extractors > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err; python -c "
+import json; d=json.loads(open('gpurun_out/${T}_bench.json').read().strip().splitlines()[-1]); r=d['roofline']; print('async ', round(d['value']), round(d['ms_per_step'],4), 'edge', round(r['avg_launch_ms'],4), r['kernel_ms_per_step'], d['config']['small_batches_50_steps'])"
+DEDF_RTAB_ASYNC=0 python bench.py --no-cpu-baseline --no-extractors > gpurun_out/${T}_bench_sync.json 2> gpurun_out/${T}_bench_sync.err; python -c "
+import json; d=json.loads(open('gpurun_out/${T}_bench_sync.json').read().strip().splitlines()[-1]); r=d['roofline']; print('sync  ', round(d['value']), round(d['ms_per_step'],4), 'edge', round(r['avg_launch_ms'],4), r['kernel_ms_per_step'], d['config']['small_batches_50_steps'])"
+done
