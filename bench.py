@@ -172,7 +172,7 @@ def radial_table_note(args, flops, e_per_launch, edge_ms, peak, per_edge=None):
         pe["frac"] = (flops / (per_edge["k_edge_ms"] * 1e-3) / 1e12) / peak if per_edge["k_edge_ms"] > 0 else 0.0
     return {"enabled": True, "without_table": pe, "executed_flop_per_launch": ex, "achieved_on_executed_flop": ach, "frac_on_executed_flop": ach / peak,
             "what": "front of the radial network (length encoding, edge pre-linear, RadialProfile layers 1-2) tabulated per step on 2 048 (finite "
-                    "scale) / 32 768 (all-pairs scale) length intervals by the edge tile's own code, 4-point Lagrange interpolation per edge; the "
+                    "scale) / 16 384 (all-pairs scale) length intervals by the edge tile's own code, 4-point Lagrange interpolation per edge; the "
                     "generator's time is inside avg_launch_ms; deviation from the per-edge evaluation <= 4e-6 of the score, both 3e-6..2e-5 from "
                     "the fp64 oracle (tests/test_gpu_parity.py::test_radial_table_of_the_sampler_against_the_per_edge_evaluation); "
                     "--no-radial-table measures the per-edge path"}

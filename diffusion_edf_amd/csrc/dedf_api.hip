@@ -97,6 +97,7 @@ struct dedf_handle {
     hipStream_t side = nullptr;
     hipEvent_t rt_tab[kRtabRing] = {nullptr, nullptr, nullptr, nullptr}, rt_used[kRtabRing] = {nullptr, nullptr, nullptr, nullptr}, rt_ready = nullptr;
     DevBuf d_rtab_ring;
+    int rtab_fin = kRtabFinite, rtab_inf = kRtabInfinite;      // grid intervals per finite / all-pairs scale (DEDF_RTAB_FIN / DEDF_RTAB_INF: experiments)
     int tab_slot = -1;            // >= 0 inside dedf_sample's loop: the ring slot that holds THIS step's table
     bool rtab_async = false;      // DEDF_RTAB_ASYNC=1 turns the side-stream generation on (A/B)
     DevBuf d_cnt2, d_blk2; int small_parity = 0; int64_t small_layout = -1;      // the two alternating count sets of the small-batch neighbour path
@@ -451,7 +452,7 @@ int radial_table_setup(dedf_handle* h, EdgeParams& P) {
     int row = 0;
     for (int n = 0; n < c.n_scales; ++n) {
         const bool fin = c.radii[n] > 0;
-        const int G = fin ? kRtabFinite : kRtabInfinite;
+        const int G = fin ? h->rtab_fin : h->rtab_inf;
         const double span = fin ? (double)c.radii[n] : kRtabInfiniteSpan * (double)c.length_enc_max_r;
         P.rtab_row0[n] = row; P.rtab_n[n] = G;
         P.rtab_step[n] = (float)(span / G); P.rtab_inv_step[n] = (float)(G / span);
@@ -479,7 +480,7 @@ void launch_radial_table(dedf_handle* h, const EdgeParams& P, hipStream_t st, bo
 constexpr int kRtabAsyncMinNodes = 1024;      // with the generator off the step's dependent chain the table pays from ~one round of edge tiles on
 size_t radial_table_rows(const dedf_handle* h) {
     size_t row = 0;
-    for (int n = 0; n < h->cfg.n_scales; ++n) row += (h->cfg.radii[n] > 0 ? kRtabFinite : kRtabInfinite) + 3;
+    for (int n = 0; n < h->cfg.n_scales; ++n) row += (h->cfg.radii[n] > 0 ? h->rtab_fin : h->rtab_inf) + 3;
     return row;
 }
 // side stream: the table of the step whose time-bias rows are h->tb_step, into ring slot `slot`
@@ -818,6 +819,8 @@ int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, de
     if (const char* e = getenv("DEDF_RADIAL_TABLE_BOUND")) h->rtab_err_bound = (float)atof(e);
     if (const char* e = getenv("DEDF_SMALL_BATCH")) h->small_batch_path = atoi(e) != 0;
     if (const char* e = getenv("DEDF_RTAB_ASYNC")) h->rtab_async = atoi(e) != 0;
+    if (const char* e = getenv("DEDF_RTAB_FIN")) h->rtab_fin = std::max(64, atoi(e));
+    if (const char* e = getenv("DEDF_RTAB_INF")) h->rtab_inf = std::max(64, atoi(e));
     if (const char* e = getenv("DEDF_EDGE_OCC")) h->edge_occ = atoi(e) != 0;
     if (const char* e = getenv("DEDF_EDGE16")) h->edge16 = atoi(e);
     const IrrepsRT T(h->L, cfg->unet_layer != 0), K(h->L, true);

@@ -15,7 +15,10 @@ constexpr int kHeads = 4;
 constexpr int kFc0 = 128, kFc1 = 128, kFc2 = 64;     // fc_neurons of every shipped config (resolved)
 // radial table of the sampler (dedf_edge.h: EdgeParams::rtab): grid intervals of a finite scale over [0, r) and of the all-pairs scale over
 // [0, kRtabInfiniteSpan * length_enc_max_r) (longer edges fall back to the per-edge evaluation)
-constexpr int kRtabFinite = 2048, kRtabInfinite = 32768;
+// (round 4: the all-pairs grid 32 768 -> 16 384 intervals: its 4-point interpolation error stays far below the encoder's own fp32 argument noise --
+//  guard word 5e-5 against 1.1e-4, table vs per-edge step 6.5e-6 against 5.4e-6 of the displacement -- and the generator fits one round of
+//  workgroups: 705 tiles instead of 1 217; 8 192 intervals sit at the guard's bound: profiles/r04l_rtab_grid.log)
+constexpr int kRtabFinite = 2048, kRtabInfinite = 16384;
 constexpr double kRtabInfiniteSpan = 1.5;
 constexpr int kRtabMinNodes = 8192;        // pose x query nodes below which the sampler evaluates the front per edge (small batches: the
                                            // table's generator launch costs more than it saves)

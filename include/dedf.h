@@ -178,7 +178,7 @@ int dedf_layer_forward(dedf_handle* h, int n_src, const float* x_src, const floa
  * pose), everything in front of layer 3 of the radial network -- length encoding, edge pre-linear with the time embedding, RadialProfile layers
  * 1 and 2 with their LayerNorm + SiLU (multiscale_tensor_field.py:225-234, equiformer/radial_func.py:11-60) -- depends on (scale, edge length)
  * only.  By default dedf_sample evaluates it once per step on a fine length grid per scale (2 048 intervals over [0, r) for a finite scale,
- * 32 768 over [0, 1.5 length_enc_max_r) for the all-pairs scale; longer edges are evaluated per edge) with the edge kernel's own code, and the
+ * 16 384 over [0, 1.5 length_enc_max_r) for the all-pairs scale; longer edges are evaluated per edge) with the edge kernel's own code, and the
  * edge kernel interpolates the 64 activations per edge (4-point Lagrange; measured deviation from the per-edge evaluation: see DESIGN.md section 5).
  * Batches below 8 192 pose x query nodes evaluate per edge as well (the generator launch would cost more than it saves).
  * on = 1 is this default; on = 0 restores the per-edge evaluation everywhere, on = 2 uses the table at every batch size (tests) -- also through the

@@ -1,13 +1,32 @@
 # scratch driver of one gpurun call (edited per session): results under gpurun_out/
 mkdir -p gpurun_out
-T=r04j
-python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "sampler or radial or table or c2 or c1 or c3 or overflow or workspace or philox or tiny or zero_edge" > gpurun_out/${T}_tests_sampler.log 2>&1; tail -4 gpurun_out/${T}_tests_sampler.log
-python -m pytest tests/test_lmax3.py -m gpu -q -x -k "sampler" > gpurun_out/${T}_tests_lmax3.log 2>&1; tail -3 gpurun_out/${T}_tests_lmax3.log
-python tests/probe/small_batch.py 2 200 2>&1 | grep lmax > gpurun_out/${T}_small_batch.log; cat gpurun_out/${T}_small_batch.log
-DEDF_RTAB_ASYNC=0 python tests/probe/small_batch.py 2 200 2>&1 | grep lmax > gpurun_out/${T}_small_batch_sync_tables.log; cat gpurun_out/${T}_small_batch_sync_tables.log
-for i in 1 2; do
-python bench.py --no-cpu-baseline --no-extractors > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err; python -c "
-import json; d=json.loads(open('gpurun_out/${T}_bench.json').read().strip().splitlines()[-1]); r=d['roofline']; print('async ', round(d['value']), round(d['ms_per_step'],4), 'edge', round(r['avg_launch_ms'],4), r['kernel_ms_per_step'], d['config']['small_batches_50_steps'])"
-DEDF_RTAB_ASYNC=0 python bench.py --no-cpu-baseline --no-extractors > gpurun_out/${T}_bench_sync.json 2> gpurun_out/${T}_bench_sync.err; python -c "
-import json; d=json.loads(open('gpurun_out/${T}_bench_sync.json').read().strip().splitlines()[-1]); r=d['roofline']; print('sync  ', round(d['value']), round(d['ms_per_step'],4), 'edge', round(r['avg_launch_ms'],4), r['kernel_ms_per_step'], d['config']['small_batches_50_steps'])"
-done
+T=r04m
+python -m pytest tests -m gpu -q -x > gpurun_out/${T}_gpu_suite.log 2>&1; tail -4 gpurun_out/${T}_gpu_suite.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${T}_smoke.log 2>&1; tail -2 gpurun_out/${T}_smoke.log
+python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
+python bench.py --lmax 3 --no-cpu-baseline > gpurun_out/${T}_lmax3_bench.json 2> gpurun_out/${T}_lmax3_bench.err
+python bench.py --config5 > gpurun_out/${T}_config5_bench.json 2> gpurun_out/${T}_config5_bench.err
+python bench.py --lmax 1 --scene 2048 --grasp 512 --poses-per-gpu 256 --steps 50 --no-cpu-baseline --no-extractors > gpurun_out/${T}_c1_bench.json 2> gpurun_out/${T}_c1_bench.err
+python bench.py --half --no-cpu-baseline --no-extractors > gpurun_out/${T}_half_bench.json 2> gpurun_out/${T}_half_bench.err
+python - <<'PY'
+import json
+for f in ("", "lmax3_", "config5_", "c1_", "half_"):
+    try:
+        d=json.loads(open(f"gpurun_out/r04m_{f}bench.json").read().strip().splitlines()[-1]); r=d["roofline"]
+        print(f or "C2", round(d["value"]), round(d["ms_per_step"],4), "edge", round(r["avg_launch_ms"],4), "edges", round(d["config"]["edges_per_step_rank0"]), "frac", round(r["frac"],4), "fwd", d["config"]["score_fwd_ms_at_t0.5"], "small", {k:round(v["ms_per_step"],4) for k,v in (d["config"]["small_batches_50_steps"] or {}).items()}, "ext", d["config"]["feature_extractors_ms"])
+    except Exception as e: print(f, "ERR", e)
+PY
+bash profiles/collect.sh ${T} "trace fetch write sq sq2 sq3" > gpurun_out/${T}_collect.log 2>&1
+DEDF_SUMMARY_DIR=gpurun_out python profiles/summarize.py ${T} > gpurun_out/${T}_summarize.log 2>&1
+CMD="python $GRAFT_REPO_ROOT/bench.py --lmax 3 --steps 5 --warmup 1 --no-cpu-baseline --no-extractors --no-small-batches --no-score-fwd" bash profiles/collect.sh ${T}_lmax3 "trace fetch write sq2" > gpurun_out/${T}_lmax3_collect.log 2>&1
+DEDF_SUMMARY_DIR=gpurun_out python profiles/summarize.py ${T}_lmax3 > gpurun_out/${T}_lmax3_summarize.log 2>&1
+CMD="python $GRAFT_REPO_ROOT/bench.py --config5 --steps 5 --warmup 1 --no-cpu-baseline --no-small-batches --no-score-fwd" bash profiles/collect.sh ${T}_config5 "trace fetch write sq2" > gpurun_out/${T}_config5_collect.log 2>&1
+DEDF_SUMMARY_DIR=gpurun_out python profiles/summarize.py ${T}_config5 > gpurun_out/${T}_config5_summarize.log 2>&1
+find gpurun_out -maxdepth 1 -type d -name "${T}*" -exec rm -rf {} +
+python - <<'PY'
+import json
+for t in ("r04m","r04m_lmax3","r04m_config5"):
+    d=json.load(open(f"gpurun_out/{t}_pmc_summary.json"))
+    print(t, {k:(round(v,4) if isinstance(v,float) else v) for k,v in d.items() if k!="per_kernel" and not k.endswith("definition")})
+PY
+du -sh gpurun_out
