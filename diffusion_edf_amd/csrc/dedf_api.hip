@@ -367,7 +367,7 @@ template <auto Kernel, int Cap = 4> int waves_per_cu() {
     return n;
 }
 #define DEDF_LAUNCH_PERSISTENT(KERNEL, MAX_BLOCKS, ST, ARG) \
-    hipLaunchKernelGGL((KERNEL), dim3(std::min<int>((MAX_BLOCKS), h->n_cu * std::min(edge_wpc_limit(), waves_per_cu<(KERNEL)>()))), dim3(64), 0, ST, ARG)
+    hipLaunchKernelGGL((KERNEL), dim3(std::min<int>((MAX_BLOCKS), h->n_cu * std::min(edge_wpc_limit(), waves_per_cu<(KERNEL), 8>()))), dim3(64), 0, ST, ARG)
 // A grid whose tile count is known on the host (the node kernel): the persistent waves run ceil(tiles / resident waves) rounds either way, so
 // launch only as many waves as fill those rounds EVENLY (C2: 3 219 node tiles on 1 024 resident waves = 4 rounds, the last one a seventh full;
 // 805 waves run the same 4 rounds with 3.1 instead of 4 waves per CU sharing the L1: k_node 0.292 -> 0.285 ms, profiles/r03t_node_balanced_ab.log).
@@ -379,7 +379,7 @@ inline int balanced_blocks(int tiles, int cap) {
     return (tiles + rounds - 1) / rounds;
 }
 inline int edge_wpc_limit() {      // experiments only: DEDF_EDGE_WAVES_PER_CU=1..4
-    static const int wpc = [] { const char* e = getenv("DEDF_EDGE_WAVES_PER_CU"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 4 ? v : 4; }();
+    static const int wpc = [] { const char* e = getenv("DEDF_EDGE_WAVES_PER_CU"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 8 ? v : 4; }();      // (8: the two-waves-per-SIMD timing builds)
     return wpc;
 }
 

@@ -441,7 +441,18 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         static_assert(L <= 3, "spherical harmonics up to l = 3");
     }
 
+    // Timing experiments only (wrong results, same instruction stream; DESIGN.md section 5.R4, "two waves per SIMD, costed"):
+    //   -DDEDF_TIMING_LDS_ALIAS   every parked operand lands in one of six LDS slots, so that a wave needs 8 KB instead of 32 KB and EIGHT waves fit a CU
+    //   -DDEDF_TIMING_STAGE1      the tile ends after the first depth-wise TP + lin / alpha stage (no value stage, no records): the "producer wave"
+    //   -DDEDF_TIMING_STAGE2      the first stage's chunk loop is skipped (the value stage reads whatever the LDS holds): the "consumer wave"
+    //   -DDEDF_EDGE_WPS=2         __launch_bounds__(64, 2): at most 256 registers per wave (dedf_kernels.h)
+#if defined(DEDF_TIMING_LDS_ALIAS)
+#define DEDF_PSLOT(s) ((s) % 6)
+    constexpr int SPW = 6, NSLOT = 8;
+#else
+#define DEDF_PSLOT(s) (s)
     constexpr int SPW = park_phys_slots<L>(), NSLOT = SPW + 2;      // SPW: segment softmax weights / normalisers
+#endif
     __shared__ f32x4 park[NSLOT * 64];         // (declared here: the table path stages its rows in it before the parking starts)
     f32x16 r2[NT2];
     f32x4 trow[MODE == 1 ? 4 : 1][8];      // MODE 1: this lane's halves of the four table rows around its length (16 * NT2 floats of the 32 are used:
@@ -622,12 +633,12 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     auto park_chunk = [&]<int Q, bool PADZ = false>(const float (&v)[8]) {
         if constexpr (park_packed<L>(Q)) {      // registers 2, 3, 6, 7 are the zero padding of 8x3e: hi and lo of the other four in one slot
             const float v4[4] = {v[0], v[1], v[4], v[5]};
-            pk[park_phys<L>(Q) * 64] = split4pk(v4);
+            pk[DEDF_PSLOT(park_phys<L>(Q)) * 64] = split4pk(v4);
         } else {
             HL sp;
             if constexpr (PADZ) sp = split8z(v); else sp = split8(v);
-            pk[park_phys<L>(Q) * 64] = __builtin_bit_cast(f32x4, sp.hi);
-            if constexpr (!HP) pk[(park_phys<L>(Q) + 1) * 64] = __builtin_bit_cast(f32x4, sp.lo);
+            pk[DEDF_PSLOT(park_phys<L>(Q)) * 64] = __builtin_bit_cast(f32x4, sp.hi);
+            if constexpr (!HP) pk[DEDF_PSLOT(park_phys<L>(Q) + 1) * 64] = __builtin_bit_cast(f32x4, sp.lo);
         }
     };
 
@@ -762,8 +773,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 const h8 ah = __builtin_bit_cast(h8, a.h[k]), al = __builtin_bit_cast(h8, a.l[k]);
                 HL b;
                 if constexpr (R2S_LDS) {
-                    b.hi = __builtin_bit_cast(h8, pk[(R2S_SLOT + 2 * (c0 + k)) * 64]);
-                    if constexpr (!HP) b.lo = __builtin_bit_cast(h8, pk[(R2S_SLOT + 2 * (c0 + k) + 1) * 64]);
+                    b.hi = __builtin_bit_cast(h8, pk[DEDF_PSLOT(R2S_SLOT + 2 * (c0 + k)) * 64]);
+                    if constexpr (!HP) b.lo = __builtin_bit_cast(h8, pk[DEDF_PSLOT(R2S_SLOT + 2 * (c0 + k) + 1) * 64]);
                 } else b = r2s[c0 + k];
                 t = mfma_h(ah, b.hi, t);
                 if constexpr (!HP) { t = mfma_h(ah, b.lo, t); t = mfma_h(al, b.hi, t); }
@@ -907,6 +918,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     };
 
     DEDF_STAMP(6);
+#if defined(DEDF_TIMING_STAGE2)      // consumer-only timing build: no first stage; the value stage reads whatever the LDS holds
+    static_for<kHeads>([&]<int hd>() { logit[hd] = logit0 + r2[0][hd]; });
+#else
     // prologue: weight tile 0 and the first half of tile 1, source rows of chunks 0 / 1, B operands of chunk 0
     f32x16 wbuf[2];
     XOps x_nxt = load_X.template operator()<1>();
@@ -933,8 +947,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             static_for<8>([&]<int J>() { t[J] = r2[c / 2][8 * (c % 2) + J]; });
             r2s[c] = split8(t);
             if constexpr (R2S_LDS) {
-                pk[(R2S_SLOT + 2 * c) * 64] = __builtin_bit_cast(f32x4, r2s[c].hi);
-                if constexpr (!HP) pk[(R2S_SLOT + 2 * c + 1) * 64] = __builtin_bit_cast(f32x4, r2s[c].lo);
+                pk[DEDF_PSLOT(R2S_SLOT + 2 * c) * 64] = __builtin_bit_cast(f32x4, r2s[c].hi);
+                if constexpr (!HP) pk[DEDF_PSLOT(R2S_SLOT + 2 * c + 1) * 64] = __builtin_bit_cast(f32x4, r2s[c].lo);
             }
         });
         static_for<NR0>([&]<int T>() {      // accumulator init: lin / sep_alpha biases
@@ -982,8 +996,15 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     });
     if constexpr (dtp_pos_out<L>(NCHK - 1)) contract_out.template operator()<NCHK - 1>(go);
     finish_group.template operator()<L>();
+#endif
     sched_fence();
     DEDF_STAMP(12);
+#if defined(DEDF_TIMING_STAGE1)
+    // the producer's tile ends here (the value stage is not compiled); one word could leave so that the logits are not dead
+    if (P.nQ == 0x7ffffff0) P.out[e] = (logit[0] + logit[1]) + (logit[2] + logit[3]);
+    if constexpr (MODE == 1) geo.ok = 0;
+    return;
+#endif
     float nk[3] = {0.0f, 0.0f, 0.0f}, nq[3] = {0.0f, 0.0f, 0.0f};       // MODE 1: the next tile's coordinates, requested here
     if constexpr (MODE == 1) {
         if (e_next >= 0) {
@@ -1217,12 +1238,12 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             const f32x4* const pkt = park + lane_t;
             static_for<it.na>([&]<int a>() {
                 if constexpr (park_packed<L>(it.bq[a])) {      // one slot: {hi(0,1), hi(4,5), lo(0,1), lo(4,5)}, the other registers are zeros
-                    const f32x4 s = pkt[park_phys<L>(it.bq[a]) * 64];
+                    const f32x4 s = pkt[DEDF_PSLOT(park_phys<L>(it.bq[a])) * 64];
                     o.h[a] = f32x4{s[0], 0.0f, s[1], 0.0f};
                     if constexpr (!HP) o.l[a] = f32x4{s[2], 0.0f, s[3], 0.0f};
                 } else {
-                    o.h[a] = pkt[park_phys<L>(it.bq[a]) * 64];
-                    if constexpr (!HP) o.l[a] = pkt[(park_phys<L>(it.bq[a]) + 1) * 64];
+                    o.h[a] = pkt[DEDF_PSLOT(park_phys<L>(it.bq[a])) * 64];
+                    if constexpr (!HP) o.l[a] = pkt[DEDF_PSLOT(park_phys<L>(it.bq[a]) + 1) * 64];
                 }
             });
         }

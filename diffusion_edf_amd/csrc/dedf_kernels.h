@@ -8,7 +8,10 @@
 
 using namespace dedf;
 
-template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false, int MODE = 0, bool NW = false> __global__ __launch_bounds__(64, 1) void k_edge(EdgeParams P) {
+#ifndef DEDF_EDGE_WPS
+#define DEDF_EDGE_WPS 1      // waves per SIMD the edge kernel is compiled for (2: at most 256 registers per wave -- timing experiments only)
+#endif
+template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false, int MODE = 0, bool NW = false> __global__ __launch_bounds__(64, DEDF_EDGE_WPS) void k_edge(EdgeParams P) {
     if (edge_gate_closed(P)) return;
     const int* ti = P.tile_info;
     const int ntiles = ti[P.n_scales];

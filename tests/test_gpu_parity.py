@@ -707,7 +707,7 @@ def test_randomised_shapes_and_sizes():
     """a short run of tests/stress_parity.py (model shape, scales, radii, cap, cloud sizes, poses all drawn at random; 490 such cases
     were run clean on the GPU box during round 1): final score within the tolerance and identical edge counts in every case"""
     import stress_parity
-    assert stress_parity.run_cases(24, seed=2) == []
+    assert stress_parity.run_cases(16, seed=2) == []
 
 
 def test_randomised_sampler_critic_and_half_precision_cases():
@@ -715,7 +715,7 @@ def test_randomised_sampler_critic_and_half_precision_cases():
     noise against the oracle's float64 loop, the EBM critic's energies, and the score head in half-precision GEMM mode at its stated 5e-3"""
     import numpy as np
     import stress_parity
-    for fn, n, seed in ((stress_parity.run_sample_case, 8, 11), (stress_parity.run_ebm_case, 8, 12), (stress_parity.run_half_case, 8, 13)):
+    for fn, n, seed in ((stress_parity.run_sample_case, 5, 11), (stress_parity.run_ebm_case, 5, 12), (stress_parity.run_half_case, 5, 13)):
         rng = np.random.default_rng(seed)
         res = [fn(i, rng) for i in range(n)]
         assert all(r[1] for r in res), (fn.__name__, [r for r in res if not r[1]])
