@@ -786,7 +786,11 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // Debug hooks (stage tests): compiled into the per-edge instantiations only.  The table-reading kernel (MODE 1) is never launched in debug mode
     // (dedf_api.hip: use_tab requires !debug); there the hooks were 15 exec-masked store blocks in the hot loop and 4 in the value stage, each a
     // basic-block boundary in the middle of a pipeline region.
-    constexpr bool DBG = MODE != 1 && !UN;      // (UNet layers are never run in debug mode either: dedf_api.hip::layer_forward_impl)
+#if defined(DEDF_NO_DBG)      // (experiment: what the stage tests' hooks cost the per-edge instantiations)
+    constexpr bool DBG = false;
+#else
+    constexpr bool DBG = MODE != 1 && !UN;
+#endif      // (UNet layers are never run in debug mode either: dedf_api.hip::layer_forward_impl)
     auto dump_w = [&]<int Tw>(const f32x16& w) {      // debug only: back to the e3nn weight order
         if constexpr (DBG) if (P.dbg_w != nullptr && valid)
             static_for<16>([&]<int R>() {
