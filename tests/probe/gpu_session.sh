@@ -1,6 +1,4 @@
-# scratch driver of one gpurun call (edited per session): results under gpurun_out/
 mkdir -p gpurun_out
-T=r04p
-( DEDF_STRESS_LMAX3=1 python tests/stress_parity.py 90 71; DEDF_STRESS_LMAX3=1 python tests/stress_parity.py 30 72 sample; DEDF_STRESS_LMAX3=1 python tests/stress_parity.py 30 73 ebm; python tests/stress_parity.py 30 74 half ) > gpurun_out/${T}_stress.log 2>&1
-grep "ALL OK\|FAIL\|Traceback" gpurun_out/${T}_stress.log
-python tests/stress_extractors.py > gpurun_out/${T}_stress_extractors.log 2>&1; tail -3 gpurun_out/${T}_stress_extractors.log
+T=r04q
+python tests/probe/unet_torchprof.py 16384 panda_lowres_lmax3 > gpurun_out/${T}_unet_torchprof.log 2>&1
+grep -v "^\[W\|amdgpu.ids\|_warn_once\|UserWarning" gpurun_out/${T}_unet_torchprof.log | head -60 | cut -c1-175
