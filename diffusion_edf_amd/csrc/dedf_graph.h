@@ -210,6 +210,9 @@ __device__ __forceinline__ unsigned morton5(unsigned v) {      // 5 bits -> ever
     return v;
 }
 
+#ifndef DEDF_FPS_TIE_BALLOT
+#define DEDF_FPS_TIE_BALLOT 0      // (measured, round 4: the index of a unique maximum by one v_readlane instead of the second reduction -- 4.196 against 4.20 ms at 16 384 points, bit-exact, no gain: profiles/r04r_fps_time.log)
+#endif
 constexpr int kFpsBucketBlock = 256;
 template <int PPT>      // points per thread: the cloud has at most 256 * PPT points (PPT = 16, 32, 64)
 __global__ __launch_bounds__(kFpsBucketBlock) void k_fps_bucketed(const float* __restrict__ x, int n, int n_samples, int start, int* __restrict__ idx_out) {
@@ -359,7 +362,16 @@ __global__ __launch_bounds__(kFpsBucketBlock) void k_fps_bucketed(const float* _
                 const int wmi = wave_max_i32(lb);                                         // wave-uniform
                 const float wm = __int_as_float(wmi);
                 // (a taken branch costs a lone wave about as much as fifteen instructions: ties are resolved by a second reduction, always)
+#if DEDF_FPS_TIE_BALLOT
+                // ties are rare: when exactly one lane holds the maximum (the fall-through path) its index comes from one v_readlane instead of a
+                // second six-step reduction; exact ties take the reduction (round 4)
+                const unsigned long long tied = __ballot(lb == wmi);
+                int win;
+                if (__builtin_expect(__builtin_popcountll(tied) == 1, 1)) win = __builtin_amdgcn_readlane(li, __builtin_ctzll(tied));
+                else win = wave_min_i32_dpp(lb == wmi ? li : 0x7fffffff);
+#else
                 const int win = wave_min_i32_dpp(lb == wmi ? li : 0x7fffffff);
+#endif
                 if (li == win && lb == wmi && wmi >= 0) s_cand[wave][J] = lc;
                 if (lane == J) { bmax = wm; bidx = win; }
             });
@@ -375,8 +387,15 @@ __global__ __launch_bounds__(kFpsBucketBlock) void k_fps_bucketed(const float* _
         {
             const int kb = lane < NP ? __float_as_int(bmax) : -1;
             const int best = wave_max_i32(kb);
+#if DEDF_FPS_TIE_BALLOT
+            const unsigned long long tiedb = __ballot(kb == best);
+            int bi, jb;
+            if (__builtin_expect(__builtin_popcountll(tiedb) == 1, 1)) { jb = __builtin_ctzll(tiedb); bi = __builtin_amdgcn_readlane(bidx, jb); }
+            else { bi = wave_min_i32_dpp(kb == best ? bidx : 0x7fffffff); jb = __builtin_ctzll(__ballot(kb == best && bidx == bi)); }
+#else
             const int bi = wave_min_i32_dpp(kb == best ? bidx : 0x7fffffff);
             const int jb = __builtin_ctzll(__ballot(kb == best && bidx == bi));
+#endif
             wmd = best; widx = bi;
             const float4 c = s_cand[wave][jb < NP ? jb : 0];
             wx = c.x; wy = c.y; wz = c.z;
