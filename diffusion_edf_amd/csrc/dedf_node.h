@@ -445,6 +445,9 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         f32x16 gacc = node_ldrows(rows, hi, tp == 0 ? NR::b_sl0 : NR::b_sl1, 0);
         f32x16 vacc[3];
         static_for<3>([&]<int K>() { static_for<16>([&]<int R>() { vacc[K][R] = 0.0f; }); });
+#ifndef DEDF_NODE_SPD
+#define DEDF_NODE_SPD 2      // operand prefetch depth of the score tensor products' first-stage GEMMs (experiments: 3, 4)
+#endif
 #ifndef DEDF_NODE_HOIST_ROT
 #define DEDF_NODE_HOIST_ROT 1
 #endif
@@ -496,7 +499,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
                 });
                 f32x16 T[d2];
                 static_for<d2>([&]<int j>() { static_for<16>([&]<int R>() { T[j][R] = 0.0f; }); });
-                dense_shared_hp<d2, NCK, 2, HP>(wv, O.A_s[tp][p], O.A_s_l[tp][p], NCK, To, T, [&]<int j, int c>() { return parked.template operator()<l2, j, c>(); });
+                dense_shared_hp<d2, NCK, DEDF_NODE_SPD, HP>(wv, O.A_s[tp][p], O.A_s_l[tp][p], NCK, To, T, [&]<int j, int c>() { return parked.template operator()<l2, j, c>(); });
                 static_for<NC2>([&]<int cc>() {
                     constexpr int u0 = 32 * To + 16 * cc;
                     float a[d3][8];
