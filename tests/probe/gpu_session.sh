@@ -1,11 +1,12 @@
-# scratch driver of one gpurun call (edited per session): results under gpurun_out/
 mkdir -p gpurun_out
-T=r04t
-python -m pytest tests -m gpu -q -x > gpurun_out/${T}_gpu_suite.log 2>&1; tail -3 gpurun_out/${T}_gpu_suite.log
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${T}_smoke.log 2>&1; tail -1 gpurun_out/${T}_smoke.log
-python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
+T=r04u
+for n in 2000 4000 8000; do python bench.py --poses-per-gpu $n --no-cpu-baseline --no-extractors --no-small-batches --no-score-fwd --steps 10 > gpurun_out/${T}_poses${n}_bench.json 2>/dev/null; done
+python bench.py --config5 --half --no-cpu-baseline --no-small-batches > gpurun_out/${T}_config5_half_bench.json 2> gpurun_out/${T}_config5_half.err
 python - <<'PY'
-import json
-d=json.loads(open("gpurun_out/r04t_bench.json").read().strip().splitlines()[-1]); r=d["roofline"]
-print("C2", round(d["value"]), round(d["ms_per_step"],4), "edge", round(r["avg_launch_ms"],4), "frac", round(r["frac"],4), "fwd", d["config"]["score_fwd_ms_at_t0.5"], {k:round(v["ms_per_step"],4) for k,v in d["config"]["small_batches_50_steps"].items()}, "cpu", d["cpu_baseline"]["value"], "traffic", r["traffic"], r["traffic_source"])
+import json,glob
+for f in sorted(glob.glob("gpurun_out/r04u_*bench.json")):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); r=d["roofline"]
+        print(f.split("/")[-1], round(d["value"]), round(d["ms_per_step"],3), "edge", round(r["avg_launch_ms"],3), "edges", round(d["config"]["edges_per_step_rank0"]), "frac", round(r["frac"],4))
+    except Exception as e: print(f, "ERR", e)
 PY
