@@ -18,14 +18,15 @@ TOL = 1e-4
 def _check(rep, stages=True):
     assert rep['edges_gpu'] == rep['edges_oracle']
     assert rep['edge_set_equal']
+    print("TOLPROBE stages:", max((v, k) for k, v in rep.items() if isinstance(v, float) and k != 'logits'))
     assert rep['final_ang'] < TOL and rep['final_lin'] < TOL, rep
     if stages:
         for k in ('msg', 'qpos', 'dtp_weight', 'value', 'attn', 'node_lin'):
-            assert rep[k] < 2e-4, (k, rep[k])
+            assert rep[k] < 1e-4, (k, rep[k])
         # per-irreps-block stages (each relative to its own block maximum): edge value, proj output, field after the FFN
         for k, v in rep.items():
             if k.startswith(('value_l', 'emb_l', 'field_l')):
-                assert v < 2e-4, (k, v)
+                assert v < 1e-4, (k, v)
 
 
 def test_fake_input_runs_through_warmup():
@@ -104,7 +105,8 @@ def test_sampler_parity_injected_noise():
     assert out.shape == ref.shape == (sum(n_steps) + 2, len(Ts), 7)
     assert torch.equal(out[0], Ts) and torch.equal(out[-1], out[-2])
     # poses move by O(1) cm per step; agreement is limited by the f32 score (1e-5 relative), not by the f64 update
-    assert float((out - ref).abs().max()) < 2e-4, float((out - ref).abs().max())
+    print(f"TOLPROBE sample trajectory: {float((out - ref).abs().max()):.2e}")
+    assert float((out - ref).abs().max()) < 5e-5, float((out - ref).abs().max())
     assert torch.allclose(out[..., :4].norm(dim=-1), torch.ones(out.shape[:2], dtype=torch.float64), atol=1e-12)
 
 
@@ -482,8 +484,9 @@ def test_full_size_c2_bi_equivariance_and_determinism():
     Ts2 = torch.cat([R.quaternion_raw_multiply(g.expand(len(Tc), 4), Tc[:, :4]), R.quaternion_apply(g, Tc[:, 4:]) + gt], -1).to(dev)
     ang2, lin2 = head(Ts2.float(), keys2, query, t)
     scale = float(max(ang.abs().max(), lin.abs().max()))
-    assert float((ang2 - ang).abs().max()) / scale < 2e-4, float((ang2 - ang).abs().max()) / scale
-    assert float((lin2 - lin).abs().max()) / scale < 2e-4
+    print(f"TOLPROBE equivariance: {float((ang2 - ang).abs().max()) / scale:.2e} {float((lin2 - lin).abs().max()) / scale:.2e}")
+    assert float((ang2 - ang).abs().max()) / scale < 5e-5, float((ang2 - ang).abs().max()) / scale
+    assert float((lin2 - lin).abs().max()) / scale < 5e-5
 
 
 # ---- EBM critic head -------------------------------------------------------------------------------------
@@ -656,8 +659,9 @@ def test_agent_cascade_and_critic_ranking_match_oracle():
     assert out.shape == ref.shape == (3 + 2 + 4 + 2, nT, 7) and out.dtype == torch.float64
     e = info["energy"].cpu()
     assert bool((e[1:] >= e[:-1]).all())
-    assert float((e - e_ref).abs().max() / e_ref.abs().max()) < 5e-4, (e, e_ref)
-    assert float((out.cpu() - ref).abs().max()) < 5e-4, float((out.cpu() - ref).abs().max())
+    print(f"TOLPROBE cascade: energy {float((e - e_ref).abs().max() / e_ref.abs().max()):.2e} poses {float((out.cpu() - ref).abs().max()):.2e}")
+    assert float((e - e_ref).abs().max() / e_ref.abs().max()) < 5e-5, (e, e_ref)
+    assert float((out.cpu() - ref).abs().max()) < 5e-5, float((out.cpu() - ref).abs().max())
     # the second model starts where the first one ended; the seed row of the whole cascade is a permutation of the input
     assert torch.equal(out[4], out[5])
     assert torch.equal(torch.sort(out[0, :, 6]).values, torch.sort(Ts[:, 6].to(dev)).values)
@@ -772,7 +776,8 @@ def test_zero_edge_warning_like_the_reference():
         out = ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[1.0, 0.5]], [1], [0.04], noise=noise).cpu()
     ok = [R.FeaturedPoints(k.x, k.f, k.b) for k in keys]
     ref = R.sample(R.config_from_kwargs(kw), P, Ts, ok, R.FeaturedPoints(query.x, query.f, query.b, query.w), [[1.0, 0.5]], [1], [0.04], noise=noise)
-    assert float((out - ref).abs().max()) < 2e-4
+    print(f"TOLPROBE zero-edge sample: {float((out - ref).abs().max()):.2e}")
+    assert float((out - ref).abs().max()) < 5e-5
 
 
 def test_full_size_c2_anchored_on_the_oracle_through_pose_independence():

@@ -144,9 +144,11 @@ def test_keypoint_extractor_matches_the_oracle(n_points, bbox):
     for mul, l in R.parse_irreps(WIDE):
         d = mul * (2 * l + 1)
         err = float((got[:, off:off + d] - fr[:, off:off + d]).abs().max()) / float(fr[:, off:off + d].abs().max())
-        assert err < 2e-4, (l, err)
+        print(f"TOLPROBE keypoint f l={l}: {err:.2e}")
+        assert err < 5e-5, (l, err)
         off += d
-    assert float((out.w.cpu().double() - wr).abs().max()) < 2e-4
+    print(f"TOLPROBE keypoint w: {float((out.w.cpu().double() - wr).abs().max()):.2e}")
+    assert float((out.w.cpu().double() - wr).abs().max()) < 5e-5
     assert float(wr.max() - wr.min()) > 1e-3                       # the weights are not a constant
 
 
@@ -186,8 +188,10 @@ def test_whole_place_model_from_clouds_to_scores():
                                               bbox=doc["query_kwargs"]["keypoint_kwargs"]["bbox"])
     assert [len(k.x) for k in key] == [len(k[0]) for k in key_ref] and torch.equal(query.x.cpu(), xq)
     for k, (xr, fr) in zip(key, key_ref):
-        assert float((k.f.cpu().double() - fr).abs().max()) < 2e-4 * float(fr.abs().max())
-    assert float((query.f.cpu().double() - fq).abs().max()) < 2e-4 * float(fq.abs().max()) and float((query.w.cpu().double() - wq).abs().max()) < 2e-4
+        print(f"TOLPROBE model keys: {float((k.f.cpu().double() - fr).abs().max()) / float(fr.abs().max()):.2e}")
+        assert float((k.f.cpu().double() - fr).abs().max()) < 5e-5 * float(fr.abs().max())
+    print(f"TOLPROBE model query: {float((query.f.cpu().double() - fq).abs().max()) / float(fq.abs().max()):.2e} {float((query.w.cpu().double() - wq).abs().max()):.2e}")
+    assert float((query.f.cpu().double() - fq).abs().max()) < 5e-5 * float(fq.abs().max()) and float((query.w.cpu().double() - wq).abs().max()) < 5e-5
     nT = 24
     q = torch.randn(nT, 4, generator=g, dtype=torch.float64)
     Ts = torch.cat([q / q.norm(dim=-1, keepdim=True), torch.randn(nT, 3, generator=g, dtype=torch.float64) * 6.0 + torch.tensor([0.0, 0.0, 4.0])], -1)
@@ -248,7 +252,8 @@ def test_whole_point_attentive_model_from_clouds_to_scores():
     assert len(key) == 1 and len(key[0].x) == 200 and key[0].w is not None and len(query.x) == 2
     Pk = R.cast_params({k: v.cpu() for k, v in m.key_model.state_dict().items()}, torch.float64)
     xk, fk, wk = U.keypoint_extractor_forward(_oracle_cfg(m.key_model.feature_extractor), _field_cfg(radii), Pk, scene, fs.double(), 0.05, bbox=None)
-    assert torch.equal(key[0].x.cpu(), xk) and float((key[0].w.cpu().double() - wk).abs().max()) < 2e-4
+    print(f"TOLPROBE key w: {float((key[0].w.cpu().double() - wk).abs().max()):.2e}")
+    assert torch.equal(key[0].x.cpu(), xk) and float((key[0].w.cpu().double() - wk).abs().max()) < 5e-5
     nT = 16
     q = torch.randn(nT, 4, generator=g, dtype=torch.float64)
     Ts = torch.cat([q / q.norm(dim=-1, keepdim=True), torch.randn(nT, 3, generator=g, dtype=torch.float64) * 6.0 + torch.tensor([0.0, 0.0, 4.0])], -1)

@@ -132,12 +132,13 @@ def _gpu_head(kw, P, dev, cls=None):
 
 def _check(rep):
     assert rep['edges_gpu'] == rep['edges_oracle'] and rep['edge_set_equal']
+    print("stage errors lmax3:", {k: f"{v:.1e}" for k, v in rep.items() if isinstance(v, float)})
     assert rep['final_ang'] < TOL and rep['final_lin'] < TOL, rep
     for k in ('msg', 'qpos', 'dtp_weight', 'value', 'attn', 'node_lin'):
-        assert rep[k] < 2e-4, (k, rep[k])
+        assert rep[k] < 1e-4, (k, rep[k])
     for k, v in rep.items():
         if k.startswith(('value_l', 'emb_l', 'field_l')):
-            assert v < 2e-4, (k, v)
+            assert v < 1e-4, (k, v)
     assert 'value_l3' in rep and 'field_l3' in rep
 
 
@@ -203,7 +204,8 @@ def test_sampler_lmax3_against_the_oracle_loop_with_and_without_the_radial_table
     for on in ("always", False):
         head.set_radial_table(on)
         outs[on] = ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[0.8, 0.3]], [3], [0.04], temperatures=1.0, noise=noise).cpu()
-        assert outs[on].shape == ref.shape and float((outs[on] - ref).abs().max()) < 2e-4, (on, float((outs[on] - ref).abs().max()))
+        print(f"lmax3 sample, table={on}: {float((outs[on] - ref).abs().max()):.2e}")
+        assert outs[on].shape == ref.shape and float((outs[on] - ref).abs().max()) < 2e-5, (on, float((outs[on] - ref).abs().max()))
     # one noise-free step: displacement difference = score difference; the table path stays within 1e-5 of the per-edge path
     d = {}
     for on in ("always", False):
@@ -360,12 +362,16 @@ def _randomized(module, seed):
     return sd
 
 
+_UNET_REF = {}
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_points,half", [(16384, False), (3000, True)])
+@pytest.mark.parametrize("n_points,half", [(16384, False), (16384, True), (3000, True)])
 def test_unet_feature_extractor_lmax3_matches_the_oracle(n_points, half):
     """BASELINE config 5 as written: the full UNet feature extractor on the 16 384-point scene at lmax 3 (levels 3277 / 656 / 132 / 27, 17 layers,
     SH up to 3e, parity-inverted up path) against the fp64 restatement -- coordinates bit-exact, features per output scale and irreps block within
-    2e-4 of the scale's magnitude; and its fp16-GEMM mode (5e-3) on a smaller scene"""
+    2e-5 of the block's magnitude (measured 5.5e-7 .. 2.3e-6, which is what the restatement itself shows when it runs in fp32:
+    profiles/r04v_unet_lmax3_err.log); and its fp16-GEMM mode at the same size (measured 0.8 .. 4.1e-3, held to 8e-3) and on a smaller scene (5e-3)"""
     from diffusion_edf_amd.so3 import parse_irreps
     from diffusion_edf_amd.unet import UnetFeatureExtractor
     dev = torch.device("cuda:0")
@@ -379,12 +385,15 @@ def test_unet_feature_extractor_lmax3_matches_the_oracle(n_points, half):
                         n_layers_midstream=kw["n_layers_midstream"], irreps_sh=SH3)
     x = torch.from_numpy(synthetic.make_scene(n_points, seed=0).astype(np.float32))
     f = torch.rand(n_points, 3, generator=torch.Generator().manual_seed(1))
-    ref = U.unet_forward(ocfg, R.cast_params(sd, torch.float64), x, f.double())
+    if n_points not in _UNET_REF:      # (same weights and scene for both modes: one 140 s fp64 pass)
+        _UNET_REF[n_points] = U.unet_forward(ocfg, R.cast_params(sd, torch.float64), x, f.double())
+    ref = _UNET_REF[n_points]
     m.to(dev)
     if half:
         m.half()
     out = m(FeaturedPoints(x=x.to(dev), f=f.to(dev), b=torch.zeros(n_points, dtype=torch.long, device=dev), w=None))
     assert len(out) == len(ref) == 4
+    tol = ((8e-3 if n_points > 3000 else 5e-3) if half else 2e-5)
     if n_points == 16384:
         assert [len(o.x) for o in out] == [3277, 656, 132, 27]
     for o, (xr, fr) in zip(out, ref):
@@ -394,14 +403,15 @@ def test_unet_feature_extractor_lmax3_matches_the_oracle(n_points, half):
         for mul, l in IRREPS3:
             d = mul * (2 * l + 1)
             err = float((got[:, off:off + d] - fr[:, off:off + d]).abs().max()) / max(float(fr[:, off:off + d].abs().max()), 1e-3 * float(fr.abs().max()))
-            assert err < (5e-3 if half else 2e-4), (len(xr), l, err)
+            print(f"unet lmax3 n={n_points} half={half} scale {len(xr)} l={l}: {err:.2e}")
+            assert err < tol, (len(xr), l, err)
             off += d
 
 
 @pytest.mark.gpu
 def test_keypoint_extractor_lmax3_matches_the_oracle():
     """the place tasks' query model at lmax 3: UNet + FPS key points + tensor_field / weight_field (context-free MultiscaleTensorFields with the
-    [64, 32, 32] radial MLP) + the weight head, against the fp64 restatement: coordinates bit-exact, features 2e-4, weights 2e-4 absolute"""
+    [64, 32, 32] radial MLP) + the weight head, against the fp64 restatement: coordinates bit-exact, features 2e-5, weights 2e-5 absolute (measured 9.5e-7 / 1.2e-7)"""
     from diffusion_edf_amd.keypoint_extractor import KeypointExtractor
     from diffusion_edf_amd.so3 import parse_irreps
     dev = torch.device("cuda:0")
@@ -427,5 +437,6 @@ def test_keypoint_extractor_lmax3_matches_the_oracle():
     m.to(dev)
     out = m(FeaturedPoints(x=x.to(dev), f=f.to(dev), b=torch.zeros(len(x), dtype=torch.long, device=dev), w=None))
     assert torch.equal(out.x.cpu(), xq) and out.f.shape == fq.shape == (len(xq), 296) and len(xq) > 20
-    assert float((out.f.cpu().double() - fq).abs().max()) < 2e-4 * float(fq.abs().max())
-    assert float((out.w.cpu().double() - wq).abs().max()) < 2e-4 and float(wq.max() - wq.min()) > 1e-3
+    print(f"keypoint extractor lmax3: f {float((out.f.cpu().double() - fq).abs().max()) / float(fq.abs().max()):.2e}  w {float((out.w.cpu().double() - wq).abs().max()):.2e}")
+    assert float((out.f.cpu().double() - fq).abs().max()) < 2e-5 * float(fq.abs().max())
+    assert float((out.w.cpu().double() - wq).abs().max()) < 2e-5 and float(wq.max() - wq.min()) > 1e-3
