@@ -265,6 +265,18 @@ DEDF_DEV HL split8z(const float (&x)[8]) {
     return split8(y);
 #endif
 }
+// float(half HALF of `hi_pair`) + float(half HALF of `lo_pair`): a split value back in fp32 (exact: the sum of a hi / lo pair IS the 22-bit operand)
+// in ONE mixed-precision FMA -- hipcc turns (float)h + (float)l into two conversions and an add.
+template <int HALF> DEDF_DEV float unsplit(unsigned hi_pair, unsigned lo_pair) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    if constexpr (HALF == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hi_pair), "v"(lo_pair));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hi_pair), "v"(lo_pair));
+    return r;
+#else
+    (void)hi_pair; (void)lo_pair; return 0.0f;
+#endif
+}
 // Four values -> one 16-byte word {hi(0,1), hi(2,3), lo(0,1), lo(2,3)}: the packed form of a parked chunk whose other four registers are
 // structural zeros (the 8x3e block inside its 16-channel chunk, dedf_edge.h::park_chunk).  Same halves as split8 gives for these values.
 DEDF_DEV f32x4 split4pk(const float (&x)[4]) {

@@ -1235,12 +1235,75 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     auto load_A_of = [&]<int I>() {
         if constexpr (I < NVI) static_for<val_item<L>(I).new_slots>([&]<int n>() { load_A.template operator()<val_item_slot0<L>(I) + n>(); });
     };
+    // INPUT-side items (dedf_net.h: the chained l3 = 0 group at every lmax; at lmax 3 the paths l1 = 3 -> l3 <= 2): B_k = the Clebsch-Gordan contraction
+    // of the parked components of a K-chunk with the SH, split like every other B operand.  The components come back from their parked halves
+    // (hi + lo, one v_fma_mix each); those of the packed 8x3e block (registers 0, 1, 4, 5 of the chunk) are kept over a run of such items.
+    float uin[7][4];
     auto load_B = [&]<int I>() {
         BSet o{};
-        if constexpr (I < NVI) {
+        if constexpr (I < NVI && val_item<L>(I < NVI ? I : 0).in_side) {
+            constexpr VItem it = val_item<L>(I);
+            constexpr PathInfo pi = dtp_path<L>(it.p);
+            constexpr int l1 = pi.l1, d1 = 2 * l1 + 1, d3 = 2 * pi.l3 + 1;
+            using Cg = CG<pi.l1, pi.l2, pi.l3>;
+            float m[Cg::NM];
+            Cg::make(Y.template get<pi.l2>(), m);
+            const f32x4* const pkt = park + lane_t;
+            if constexpr (park_packed<L>(it.bq[0])) {
+                static_assert(L == 3 && l1 == 3);
+                constexpr VItem prev = val_item<L>(I - 1);
+                if constexpr (!(prev.in_side && dtp_path<L>(prev.p >= 0 ? prev.p : 0).l1 == 3 && I >= 1)) {
+                    static_for<7>([&]<int i>() {
+                        const u32x4 s = __builtin_bit_cast(u32x4, pkt[DEDF_PSLOT(park_phys<L>(park_slot<L>(3, i, 0))) * 64]);      // {hi(0,1), hi(4,5), lo(0,1), lo(4,5)}
+                        static_for<4>([&]<int c>() { uin[i][c] = unsplit<c % 2>(s[c / 2], s[2 + c / 2]); });
+                    });
+                }
+                float t[4][d3];
+                static_for<4>([&]<int c>() {
+                    if constexpr (pad_reg<L, NW>(3, c & 1)) static_for<d3>([&]<int K>() { t[c][K] = 0.0f; });      // (narrow UNet level: one true channel per pair)
+                    else {
+                        const float x[7] = {uin[0][c], uin[1][c], uin[2][c], uin[3][c], uin[4][c], uin[5][c], uin[6][c]};
+                        Cg::apply(x, m, t[c]);
+                    }
+                });
+                static_for<it.chain ? 1 : it.na>([&]<int a>() {
+                    constexpr int K = it.comp[a];
+                    const float v4[4] = {t[0][K], t[1][K], t[2][K], t[3][K]};
+                    const f32x4 s = split4pk(v4);
+                    o.h[a] = f32x4{s[0], 0.0f, s[1], 0.0f};
+                    if constexpr (!HP) o.l[a] = f32x4{s[2], 0.0f, s[3], 0.0f};
+                });
+            } else {      // a 16-channel chunk of degree 1 or 2 (chained l3 = 0 items only): hi halves in one slot, residuals in the next
+                static_assert(it.chain && d3 == 1 && l1 >= 1 && l1 <= 2);
+                constexpr int KCH = mul_of(l1) / 16;      // park_slot(l, i, c) = park_slot(l, 0, c) + i * KCH
+                float u[d1][8];
+                static_for<d1>([&]<int i>() {
+                    const h8 hh = __builtin_bit_cast(h8, pkt[DEDF_PSLOT(park_phys<L>(it.bq[0] + i * KCH)) * 64]);
+                    if constexpr (HP) static_for<8>([&]<int r>() { u[i][r] = (float)hh[r]; });
+                    else {
+                        const u32x4 hw = __builtin_bit_cast(u32x4, hh), lw = __builtin_bit_cast(u32x4, pkt[DEDF_PSLOT(park_phys<L>(it.bq[0] + i * KCH) + 1) * 64]);
+                        static_for<8>([&]<int r>() { if constexpr (!pad_reg<L, NW>(l1, r)) u[i][r] = unsplit<r % 2>(hw[r / 2], lw[r / 2]); else u[i][r] = 0.0f; });
+                    }
+                });
+                float v[8];
+                static_for<8>([&]<int r>() {
+                    if constexpr (pad_reg<L, NW>(l1, r)) v[r] = 0.0f;
+                    else {
+                        float x[d1], t[1];
+                        static_for<d1>([&]<int i>() { x[i] = u[i][r]; });
+                        Cg::apply(x, m, t);
+                        v[r] = t[0];
+                    }
+                });
+                HL sp;
+                if constexpr (pad_reg<L, NW>(l1, 2)) sp = split8z(v); else sp = split8(v);
+                o.h[0] = __builtin_bit_cast(f32x4, sp.hi);
+                if constexpr (!HP) o.l[0] = __builtin_bit_cast(f32x4, sp.lo);
+            }
+        } else if constexpr (I < NVI) {
             constexpr VItem it = val_item<L>(I);
             const f32x4* const pkt = park + lane_t;
-            static_for<it.na>([&]<int a>() {
+            static_for<it.chain ? 1 : it.na>([&]<int a>() {
                 if constexpr (park_packed<L>(it.bq[a])) {      // one slot: {hi(0,1), hi(4,5), lo(0,1), lo(4,5)}, the other registers are zeros
                     const f32x4 s = pkt[DEDF_PSLOT(park_phys<L>(it.bq[a])) * 64];
                     o.h[a] = f32x4{s[0], 0.0f, s[1], 0.0f};
@@ -1256,12 +1319,12 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     auto run_item = [&]<int I>(const BSet& b, f32x16 (&G)[3]) {
         constexpr VItem it = val_item<L>(I);
         const f32x16 zero = {};
-        static_for<it.na>([&]<int a>() {
-            G[a] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].h), __builtin_bit_cast(h8, b.h[a]), it.first ? zero : G[a]);
+        static_for<it.na>([&]<int a>() {      // (chained items: one B operand, accumulator a = output tile a)
+            G[a] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].h), __builtin_bit_cast(h8, b.h[it.chain ? 0 : a]), it.first ? zero : G[a]);
         });
         if constexpr (!HP) {
-            static_for<it.na>([&]<int a>() { G[a] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].h), __builtin_bit_cast(h8, b.l[a]), G[a]); });
-            static_for<it.na>([&]<int a>() { G[a] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].l), __builtin_bit_cast(h8, b.h[a]), G[a]); });
+            static_for<it.na>([&]<int a>() { G[a] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].h), __builtin_bit_cast(h8, b.l[it.chain ? 0 : a]), G[a]); });
+            static_for<it.na>([&]<int a>() { G[a] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].l), __builtin_bit_cast(h8, b.h[it.chain ? 0 : a]), G[a]); });
         }
     };
     auto contract = [&]<int I>(f32x16 (&G)[3]) {      // value[.., k] += (sum_j C_ijk Y_j) G_i   for the components this item completed
@@ -1273,6 +1336,19 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         float m[Cg::NM];
         Cg::make(Y.template get<l2>(), m);
         constexpr int R_LAST = NR - 4 + pad_live<L, NW>(l3) - 1;      // last register that holds a true channel
+        if constexpr (it.in_side || it.chain) {      // the accumulators ARE output components: add them
+            static_assert((it.chain || !val_item_opens_group<L>(I)) && l3 <= 2);
+            static_for<NR>([&]<int R>() {
+                if constexpr (!pad_reg<L, NW>(l3, R)) static_for<it.na>([&]<int a>() {
+                    constexpr int K = it.comp[a];
+                    float o;
+                    if constexpr (l3 == 0) o = val0[it.chain ? a : it.t][R] + G[a][R]; else if constexpr (l3 == 1) o = val1[K][R] + G[a][R]; else o = val2[K][R] + G[a][R];
+                    opaque_v(o);
+                    if constexpr (l3 == 0) val0[it.chain ? a : it.t][R] = o; else if constexpr (l3 == 1) val1[K][R] = o; else val2[K][R] = o;
+                    if constexpr (R == R_LAST && a == 0) tok = o;
+                });
+            });
+        } else
         static_for<NR>([&]<int R>() {
             if constexpr (pad_reg<L, NW>(l3, R)) {      // a zero-padding output channel: nothing to contract (l3 = 0: the accumulator keeps its zero bias)
                 if constexpr (val_item_opens_group<L>(I)) static_for<d3>([&]<int K>() {

@@ -249,7 +249,25 @@ struct VItem {
     bool merge;            // l1 = 0: accumulators 0 and 1 are partial sums of component 0
     int group_end;         // output degree completed by this item's contraction, or -1
     int new_slots;         // A slots this item is the first to use (they follow the previous item's in the stream)
+    bool in_side;          // INPUT-side item (val_path_in_side): comp[] are OUTPUT components, the B operands are contracted features formed on the fly
+    bool chain;            // l3 = 0 group in chained form (DEDF_VAL_CHAIN0): accumulator a = output tile a, ONE B operand for all of them, the accumulators run on
+                           // from item to item through every path of the group and are added to the value once, by the group's last item
 };
+// lmax 3, the six value paths from l1 = 3 into l3 <= 2 in INPUT-side form: the seven parked components of the 8x3e block (4 true channels per
+// lane) are contracted with the SH first, B_k[u] = sum_ij C_ijk u[u,i] Y[j], and the GEMM yields the 2 l3 + 1 output components directly:
+// 1 / 3 / 5 accumulator tiles per path instead of 7, and the Clebsch-Gordan multiply-adds run on 4 registers per lane instead of the 32 / 16 / 8
+// that hold the output rows.  Same A operands in the same order (one slot per (path, tile, K-chunk)): the host packing does not change.
+#ifndef DEDF_VAL_INSIDE3
+#define DEDF_VAL_INSIDE3 1
+#endif
+// The scalar outputs (l3 = 0; paths (l, l, 0)) in CHAINED input-side form at every lmax: value0[o] = sum_l sum_u W2[(l,l,0),u,o] B_l[u] with
+// B_0 = the parked scalars as they are and B_l[u] = sum_i C_ii0 u[u,i] Y_l[i] -- ONE contracted operand per K-chunk whatever the degree, so the
+// group is a single GEMM over all its K-chunks into the two output tiles: 14 instead of 30 MFMA triples at lmax 2, no accumulator is read before the
+// group ends, and the Clebsch-Gordan multiply-adds run on the 8 registers of a K-chunk instead of the 32 that hold the output rows.
+#ifndef DEDF_VAL_CHAIN0
+#define DEDF_VAL_CHAIN0 1
+#endif
+template <int L> DEDF_HD constexpr bool val_path_in_side(const PathInfo& pi) { return DEDF_VAL_INSIDE3 && L == 3 && pi.l1 == 3 && pi.l3 <= 2; }
 template <int L> DEDF_HD constexpr int val_tiles(int l3) { return l3 == 0 ? mul_of(0) / 32 : 1; }
 template <int L> struct ValWalk { VItem item[96]; int n, n_slots; };
 template <int L> DEDF_HD constexpr ValWalk<L> make_val_walk() {
@@ -261,6 +279,18 @@ template <int L> DEDF_HD constexpr ValWalk<L> make_val_walk() {
             const PathInfo pi = dtp_path<L>(p);
             if (pi.l3 != l3) continue;
             const int kc = mul_of(pi.l1) / 16, d1 = 2 * pi.l1 + 1;
+            if (DEDF_VAL_CHAIN0 && l3 == 0) {
+                for (int c = 0; c < kc; ++c) {
+                    VItem it{};
+                    it.p = p; it.t = 0; it.na = val_tiles<L>(0); it.merge = false; it.group_end = -1; it.chain = true; it.in_side = pi.l1 > 0;
+                    for (int a = 0; a < it.na; ++a) { it.comp[a] = 0; it.bq[a] = park_slot<L>(pi.l1, 0, c); it.aslot[a] = slot + a; }
+                    it.first = last_of_group < 0 && c == 0; it.last = false; it.new_slots = it.na;
+                    slot += it.na;
+                    w.item[n++] = it;
+                }
+                last_of_group = n - 1;
+                continue;
+            }
             for (int t = 0; t < val_tiles<L>(l3); ++t) {
                 if (pi.l1 == 0) {
                     for (int c = 0; c < kc; c += 2) {
@@ -270,6 +300,18 @@ template <int L> DEDF_HD constexpr ValWalk<L> make_val_walk() {
                         it.first = c == 0; it.last = c + 2 >= kc; it.new_slots = 2;
                         slot += 2;
                         w.item[n++] = it;
+                    }
+                } else if (val_path_in_side<L>(pi)) {
+                    for (int c = 0; c < kc; ++c) {
+                        for (int k0 = 0; k0 < 2 * l3 + 1; k0 += 3) {
+                            VItem it{};
+                            it.p = p; it.t = t; it.merge = false; it.group_end = -1; it.in_side = true;
+                            it.na = imin(3, 2 * l3 + 1 - k0);
+                            for (int a = 0; a < it.na; ++a) { it.comp[a] = k0 + a; it.bq[a] = park_slot<L>(pi.l1, 0, c); it.aslot[a] = slot; }
+                            it.first = c == 0; it.last = c == kc - 1; it.new_slots = k0 == 0 ? 1 : 0;
+                            w.item[n++] = it;
+                        }
+                        slot += 1;
                     }
                 } else {
                     for (int c = 0; c < kc; ++c) {
@@ -287,7 +329,7 @@ template <int L> DEDF_HD constexpr ValWalk<L> make_val_walk() {
             }
             last_of_group = n - 1;
         }
-        if (last_of_group >= 0) w.item[last_of_group].group_end = l3;
+        if (last_of_group >= 0) { w.item[last_of_group].group_end = l3; if (w.item[last_of_group].chain) w.item[last_of_group].last = true; }
     }
     w.n = n; w.n_slots = slot;
     return w;
