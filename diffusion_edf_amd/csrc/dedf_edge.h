@@ -1266,15 +1266,15 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                         Cg::apply(x, m, t[c]);
                     }
                 });
-                static_for<it.chain ? 1 : it.na>([&]<int a>() {
+                static_for<it.share_b ? 1 : it.na>([&]<int a>() {
                     constexpr int K = it.comp[a];
                     const float v4[4] = {t[0][K], t[1][K], t[2][K], t[3][K]};
                     const f32x4 s = split4pk(v4);
                     o.h[a] = f32x4{s[0], 0.0f, s[1], 0.0f};
                     if constexpr (!HP) o.l[a] = f32x4{s[2], 0.0f, s[3], 0.0f};
                 });
-            } else {      // a 16-channel chunk of degree 1 or 2 (chained l3 = 0 items only): hi halves in one slot, residuals in the next
-                static_assert(it.chain && d3 == 1 && l1 >= 1 && l1 <= 2);
+            } else {      // a 16-channel chunk of degree 1 or 2 (chained items only): hi halves in one slot, residuals in the next
+                static_assert(it.chain && l1 >= 1 && l1 <= 2);
                 constexpr int KCH = mul_of(l1) / 16;      // park_slot(l, i, c) = park_slot(l, 0, c) + i * KCH
                 float u[d1][8];
                 static_for<d1>([&]<int i>() {
@@ -1285,25 +1285,27 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                         static_for<8>([&]<int r>() { if constexpr (!pad_reg<L, NW>(l1, r)) u[i][r] = unsplit<r % 2>(hw[r / 2], lw[r / 2]); else u[i][r] = 0.0f; });
                     }
                 });
-                float v[8];
+                float v[d3][8];
                 static_for<8>([&]<int r>() {
-                    if constexpr (pad_reg<L, NW>(l1, r)) v[r] = 0.0f;
+                    if constexpr (pad_reg<L, NW>(l1, r)) static_for<d3>([&]<int K>() { v[K][r] = 0.0f; });
                     else {
-                        float x[d1], t[1];
+                        float x[d1], t[d3];
                         static_for<d1>([&]<int i>() { x[i] = u[i][r]; });
                         Cg::apply(x, m, t);
-                        v[r] = t[0];
+                        static_for<d3>([&]<int K>() { v[K][r] = t[K]; });
                     }
                 });
-                HL sp;
-                if constexpr (pad_reg<L, NW>(l1, 2)) sp = split8z(v); else sp = split8(v);
-                o.h[0] = __builtin_bit_cast(f32x4, sp.hi);
-                if constexpr (!HP) o.l[0] = __builtin_bit_cast(f32x4, sp.lo);
+                static_for<it.share_b ? 1 : it.na>([&]<int a>() {
+                    HL sp;
+                    if constexpr (pad_reg<L, NW>(l1, 2)) sp = split8z(v[it.comp[a]]); else sp = split8(v[it.comp[a]]);
+                    o.h[a] = __builtin_bit_cast(f32x4, sp.hi);
+                    if constexpr (!HP) o.l[a] = __builtin_bit_cast(f32x4, sp.lo);
+                });
             }
         } else if constexpr (I < NVI) {
             constexpr VItem it = val_item<L>(I);
             const f32x4* const pkt = park + lane_t;
-            static_for<it.chain ? 1 : it.na>([&]<int a>() {
+            static_for<it.share_b ? 1 : it.na>([&]<int a>() {
                 if constexpr (park_packed<L>(it.bq[a])) {      // one slot: {hi(0,1), hi(4,5), lo(0,1), lo(4,5)}, the other registers are zeros
                     const f32x4 s = pkt[DEDF_PSLOT(park_phys<L>(it.bq[a])) * 64];
                     o.h[a] = f32x4{s[0], 0.0f, s[1], 0.0f};
@@ -1320,11 +1322,11 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         constexpr VItem it = val_item<L>(I);
         const f32x16 zero = {};
         static_for<it.na>([&]<int a>() {      // (chained items: one B operand, accumulator a = output tile a)
-            G[a] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].h), __builtin_bit_cast(h8, b.h[it.chain ? 0 : a]), it.first ? zero : G[a]);
+            G[a] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].h), __builtin_bit_cast(h8, b.h[it.share_b ? 0 : a]), it.first ? zero : G[a]);
         });
         if constexpr (!HP) {
-            static_for<it.na>([&]<int a>() { G[a] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].h), __builtin_bit_cast(h8, b.l[it.chain ? 0 : a]), G[a]); });
-            static_for<it.na>([&]<int a>() { G[a] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].l), __builtin_bit_cast(h8, b.h[it.chain ? 0 : a]), G[a]); });
+            static_for<it.na>([&]<int a>() { G[a] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].h), __builtin_bit_cast(h8, b.l[it.share_b ? 0 : a]), G[a]); });
+            static_for<it.na>([&]<int a>() { G[a] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].l), __builtin_bit_cast(h8, b.h[it.share_b ? 0 : a]), G[a]); });
         }
     };
     auto contract = [&]<int I>(f32x16 (&G)[3]) {      // value[.., k] += (sum_j C_ijk Y_j) G_i   for the components this item completed
@@ -1337,14 +1339,14 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         Cg::make(Y.template get<l2>(), m);
         constexpr int R_LAST = NR - 4 + pad_live<L, NW>(l3) - 1;      // last register that holds a true channel
         if constexpr (it.in_side || it.chain) {      // the accumulators ARE output components: add them
-            static_assert((it.chain || !val_item_opens_group<L>(I)) && l3 <= 2);
+            static_assert((l3 == 0 || !val_item_opens_group<L>(I)) && l3 <= 2);
             static_for<NR>([&]<int R>() {
                 if constexpr (!pad_reg<L, NW>(l3, R)) static_for<it.na>([&]<int a>() {
                     constexpr int K = it.comp[a];
                     float o;
-                    if constexpr (l3 == 0) o = val0[it.chain ? a : it.t][R] + G[a][R]; else if constexpr (l3 == 1) o = val1[K][R] + G[a][R]; else o = val2[K][R] + G[a][R];
+                    if constexpr (l3 == 0) o = val0[it.share_b ? a : it.t][R] + G[a][R]; else if constexpr (l3 == 1) o = val1[K][R] + G[a][R]; else o = val2[K][R] + G[a][R];
                     opaque_v(o);
-                    if constexpr (l3 == 0) val0[it.chain ? a : it.t][R] = o; else if constexpr (l3 == 1) val1[K][R] = o; else val2[K][R] = o;
+                    if constexpr (l3 == 0) val0[it.share_b ? a : it.t][R] = o; else if constexpr (l3 == 1) val1[K][R] = o; else val2[K][R] = o;
                     if constexpr (R == R_LAST && a == 0) tok = o;
                 });
             });

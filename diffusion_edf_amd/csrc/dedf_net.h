@@ -250,8 +250,9 @@ struct VItem {
     int group_end;         // output degree completed by this item's contraction, or -1
     int new_slots;         // A slots this item is the first to use (they follow the previous item's in the stream)
     bool in_side;          // INPUT-side item (val_path_in_side): comp[] are OUTPUT components, the B operands are contracted features formed on the fly
-    bool chain;            // l3 = 0 group in chained form (DEDF_VAL_CHAIN0): accumulator a = output tile a, ONE B operand for all of them, the accumulators run on
-                           // from item to item through every path of the group and are added to the value once, by the group's last item
+    bool chain;            // chained items (DEDF_VAL_CHAIN0 / 1): the accumulators ARE output tiles / components and run on from item to item through every
+                           // chained path of the group; they are added to the value once, by the group's last item
+    bool share_b;          // chained l3 = 0 items: accumulator a = output tile a, ONE B operand for all of them
 };
 // lmax 3, the six value paths from l1 = 3 into l3 <= 2 in INPUT-side form: the seven parked components of the 8x3e block (4 true channels per
 // lane) are contracted with the SH first, B_k[u] = sum_ij C_ijk u[u,i] Y[j], and the GEMM yields the 2 l3 + 1 output components directly:
@@ -267,6 +268,13 @@ struct VItem {
 #ifndef DEDF_VAL_CHAIN0
 #define DEDF_VAL_CHAIN0 1
 #endif
+// The vector outputs (l3 = 1) of the paths where the input side is the narrow one, chained the same way behind the group's output-side paths:
+// (1, 0, 1) -- its B operands are the parked components themselves, no VALU work at all -- and every path from l1 >= 2 (8 registers of a K-chunk
+// against the 16 that hold the output rows, 3 accumulator tiles instead of 5 / 7).
+#ifndef DEDF_VAL_CHAIN1
+#define DEDF_VAL_CHAIN1 1
+#endif
+DEDF_HD constexpr bool val_path_chain1(const PathInfo& pi) { return DEDF_VAL_CHAIN1 && pi.l3 == 1 && ((pi.l1 == 1 && pi.l2 == 0) || pi.l1 >= 2); }
 template <int L> DEDF_HD constexpr bool val_path_in_side(const PathInfo& pi) { return DEDF_VAL_INSIDE3 && L == 3 && pi.l1 == 3 && pi.l3 <= 2; }
 template <int L> DEDF_HD constexpr int val_tiles(int l3) { return l3 == 0 ? mul_of(0) / 32 : 1; }
 template <int L> struct ValWalk { VItem item[96]; int n, n_slots; };
@@ -275,14 +283,29 @@ template <int L> DEDF_HD constexpr ValWalk<L> make_val_walk() {
     int n = 0, slot = 0;
     for (int l3 = 0; l3 <= L; ++l3) {
         int last_of_group = -1;
+        bool chain_open = false;
+        for (int pass = 0; pass < 2; ++pass)
         for (int p = 0; p < dtp_num_paths<L>(); ++p) {
             const PathInfo pi = dtp_path<L>(p);
-            if (pi.l3 != l3) continue;
+            if (pi.l3 != l3 || val_path_chain1(pi) != (pass == 1)) continue;
             const int kc = mul_of(pi.l1) / 16, d1 = 2 * pi.l1 + 1;
+            if (val_path_chain1(pi)) {
+                for (int c = 0; c < kc; ++c) {
+                    VItem it{};
+                    it.p = p; it.t = 0; it.na = 3; it.merge = false; it.group_end = -1; it.chain = true; it.in_side = !(pi.l1 == 1 && pi.l2 == 0);
+                    for (int a = 0; a < 3; ++a) { it.comp[a] = a; it.bq[a] = park_slot<L>(pi.l1, it.in_side ? 0 : a, c); it.aslot[a] = slot; }
+                    it.first = !chain_open; it.last = false; it.new_slots = 1;
+                    chain_open = true;
+                    slot += 1;
+                    w.item[n++] = it;
+                }
+                last_of_group = n - 1;
+                continue;
+            }
             if (DEDF_VAL_CHAIN0 && l3 == 0) {
                 for (int c = 0; c < kc; ++c) {
                     VItem it{};
-                    it.p = p; it.t = 0; it.na = val_tiles<L>(0); it.merge = false; it.group_end = -1; it.chain = true; it.in_side = pi.l1 > 0;
+                    it.p = p; it.t = 0; it.na = val_tiles<L>(0); it.merge = false; it.group_end = -1; it.chain = true; it.share_b = true; it.in_side = pi.l1 > 0;
                     for (int a = 0; a < it.na; ++a) { it.comp[a] = 0; it.bq[a] = park_slot<L>(pi.l1, 0, c); it.aslot[a] = slot + a; }
                     it.first = last_of_group < 0 && c == 0; it.last = false; it.new_slots = it.na;
                     slot += it.na;

@@ -353,7 +353,7 @@ inline std::vector<float> pack_val_stream(WAt W) {
             const int c = it.bq[a] - park_slot<L>(pi.l1, it.in_side ? 0 : it.comp[a], 0);      // (input-side items: bq = component 0 of their chunk)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j) {
-                    const int o = (it.chain ? a : it.t) * 32 + (lane & 31), u = 16 * c + rowmap(j, lane >> 5);
+                    const int o = (it.share_b ? a : it.t) * 32 + (lane & 31), u = 16 * c + rowmap(j, lane >> 5);
                     if (o >= mul_of(pi.l3)) continue;
                     const float w = W(it.p, o, u);
                     const size_t hi_idx = (size_t)slot * 1024 + (size_t)lane * 8 + j;
