@@ -663,7 +663,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     //  stream 6 items, value stream 3 -- k_edge 2.92 -> 2.85 ms at 2.37 M edges in three interleaved A/B rounds, profiles/r04h_edge_variants_ab.log;
     //  512 registers, no scratch.  The per-edge kernels and lmax 3 keep their depths: 6 / 3 spill there or change nothing, r04i_*)
 #ifndef DEDF_PDA2_TAB
-#define DEDF_PDA2_TAB 6
+#define DEDF_PDA2_TAB 5      // (6 until the MFMAs of the fused stage were spaced out, SGB1 below: 6 then leaves 16 B of scratch for the same time, r04z_sgb_rings_ab.log)
 #endif
 #ifndef DEDF_V_PDA_TAB
 #define DEDF_V_PDA_TAB 3
@@ -988,8 +988,18 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         mfma_chunk<L, NR0, C, HP>(wv, o_S_lin, ring, b_cur, acc0, acc1, acc2, acc3, go);
         if constexpr (fin_out) contract_out.template operator()<C - 1>(gfin);
         static_for<L + 1>([&]<int g>() { if constexpr (C == dtp_group_end<L>(g)) finish_group.template operator()<g>(); });
-#if defined(DEDF_SGB) && defined(__HIP_DEVICE_COMPILE__)      // experiment: ask hipcc for one MFMA per DEDF_SGB VALU instructions inside the region
-        static_for<28>([&]<int i>() { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, DEDF_SGB, 0); });
+        // One MFMA per SGB1 VALU instructions inside the region.  hipcc's own schedule issues the region's 15-27 ready MFMAs in bursts, and a lone in-order
+        // wave issues nothing while a burst drains (32 cycles per MFMA); spaced by the Clebsch-Gordan / split work of the next chunk they run under it.
+        // Round 4, the sampler's two timed instantiations only (interleaved A/B at 2.37 M edges, profiles/r04z_sgb*_ab.log): lmax 2 2.697 -> 2.624 ms
+        // with 5 (3 / 4: slower, 6 - 8: 2.64 - 2.68), lmax 3 5.53 -> 5.27 ms with 7 (5: 5.30, 9: 5.35, 12: 5.32); the per-edge lmax-2 kernel spills
+        // 224 B with it, the value stage's regions gain nothing (their bursts have no VALU partner).
+#if defined(DEDF_SGB)
+        constexpr int SGB1 = DEDF_SGB;
+#else
+        constexpr int SGB1 = (MODE == 1 && F0 == 128 && H1 == 128 && H2 == 64 && !HP && !UN) ? (L == 3 ? 7 : (L == 2 ? 5 : 0)) : 0;
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (SGB1 > 0) static_for<28>([&]<int i>() { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, SGB1, 0); });
 #endif
         sched_fence();
         if constexpr (Ph % 2 == 1 && T3 < NWT) dump_w.template operator()<T3>(wbuf[T3 % 2]);
@@ -1385,8 +1395,15 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     static_for<NVI + LAG>([&]<int I>() {
         lane16_t = tie(wv.lane16, tok); lane16_r16_t = tie(wv.lane16_r16, tok); lane_t = tie(wv.lane, tok);
         load_A_of.template operator()<I + PDV>();
-        const BSet b_nxt = load_B.template operator()<I + 1>();
+        // (input-side operands are FORMED, not just fetched: that VALU work belongs into the region of this item's MFMAs, behind the fence)
+#ifndef DEDF_VAL_LATE_B
+#define DEDF_VAL_LATE_B 1
+#endif
+        constexpr bool late_b = DEDF_VAL_LATE_B && I + 1 < NVI && val_item<L>(I + 1 < NVI ? I + 1 : 0).in_side;
+        BSet b_nxt{};
+        if constexpr (!late_b) b_nxt = load_B.template operator()<I + 1>();
         sched_fence();
+        if constexpr (late_b) b_nxt = load_B.template operator()<I + 1>();
         constexpr int F = I - LAG;                       // item whose accumulators are contracted in this region
         constexpr bool fin = F >= 0 && val_item<L>(F).last;
         if constexpr (LAG > 0 && I >= 1 && I - 1 < NVI) { if constexpr (val_item<L>(I - 1).last) static_for<3>([&]<int a>() { Gq[(I - 1) % (LAG > 0 ? LAG : 1)][a] = G[a]; }); }
@@ -1396,8 +1413,14 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             constexpr int ge = val_item<L>(F).group_end;
             if constexpr (ge >= 0 && ge < L) store_group.template operator()<ge>();
         }
-#if defined(DEDF_SGB) && defined(__HIP_DEVICE_COMPILE__)
-        static_for<10>([&]<int i>() { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, DEDF_SGB, 0); });
+#if defined(DEDF_SGB_CHAIN) && defined(__HIP_DEVICE_COMPILE__)      // experiment: the MFMAs of a chained item one by one between the VALU work that forms the next item's operand
+        if constexpr (I < NVI) { if constexpr (val_item<L>(I < NVI ? I : 0).chain) static_for<9>([&]<int i>() { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, DEDF_SGB_CHAIN, 0); }); }
+#endif
+#if defined(DEDF_SGB) && !defined(DEDF_SGBV)
+#define DEDF_SGBV DEDF_SGB
+#endif
+#if defined(DEDF_SGBV) && DEDF_SGBV > 0 && defined(__HIP_DEVICE_COMPILE__)
+        static_for<10>([&]<int i>() { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, DEDF_SGBV, 0); });
 #endif
         sched_fence();
         vb_cur = b_nxt;
