@@ -1399,7 +1399,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
 #ifndef DEDF_VAL_LATE_B
 #define DEDF_VAL_LATE_B 1
 #endif
-        constexpr bool late_b = DEDF_VAL_LATE_B && I + 1 < NVI && val_item<L>(I + 1 < NVI ? I + 1 : 0).in_side;
+        // (the sampler's timed instantiations only: -0.5 % / -1.6 % at lmax 2 / 3; the lmax-3 UNet layer kernel pays 32 B more scratch for it: 10.5 -> 11-12.7 ms per forward)
+        constexpr bool late_b = DEDF_VAL_LATE_B && MODE == 1 && I + 1 < NVI && val_item<L>(I + 1 < NVI ? I + 1 : 0).in_side;
         BSet b_nxt{};
         if constexpr (!late_b) b_nxt = load_B.template operator()<I + 1>();
         sched_fence();
