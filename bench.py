@@ -395,10 +395,12 @@ def main():
         traffic, traffic_src, mfma_issued = None, None, None
         # (files are named per round, r01i < r02h < r03i ...: the last one in name order that holds the HBM passes of the headline kernel wins)
         lmax3_workload = (args.lmax, args.scene, args.grasp, args.poses_per_gpu) == (3, 4096, 1024, 1000) and not args.half and not args.no_radial_table
-        pmc_glob = "r[0-9][0-9][a-z]_pmc_summary.json" if default_workload else ("r[0-9][0-9][a-z]_lmax3_pmc_summary.json" if lmax3_workload else None)
+        # (tags: rNN + one or two letters)
+        pmc_re = r"r\d\d[a-z]{1,2}_pmc_summary\.json" if default_workload else (r"r\d\d[a-z]{1,2}_lmax3_pmc_summary\.json" if lmax3_workload else None)
         if args.config5:
-            pmc_glob = "r[0-9][0-9][a-z]_config5_pmc_summary.json" if (args.poses_per_gpu == 1000 and not args.half and not args.no_radial_table) else None
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pmc_glob))) if pmc_glob else []:
+            pmc_re = r"r\d\d[a-z]{1,2}_config5_pmc_summary\.json" if (args.poses_per_gpu == 1000 and not args.half and not args.no_radial_table) else None
+        import re as _re
+        for f in sorted(g for g in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")) if _re.fullmatch(pmc_re, os.path.basename(g))) if pmc_re else []:
             try:
                 doc = json.load(open(f))
                 v = doc.get("edge_kernel_hbm_bytes_per_launch")
