@@ -405,7 +405,7 @@ def main():
                 doc = json.load(open(f))
                 v = doc.get("edge_kernel_hbm_bytes_per_launch")
                 if v is not None:
-                    traffic, traffic_src = v, "profiles/" + os.path.basename(f) + " (separate rocprofv3 --pmc passes of `bench.py --steps 5 --warmup 1`)"
+                    traffic, traffic_src = v, "profiles/" + os.path.basename(f) + " (separate rocprofv3 --pmc passes of the bench command profiles/collect.sh names)"
                     mfma_issued = doc.get("edge_kernel_frac_mfma_issued")
             except Exception:
                 pass

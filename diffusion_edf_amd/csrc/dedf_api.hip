@@ -105,6 +105,14 @@ struct dedf_handle {
     int edge16 = 0;                   // DEDF_EDGE16=1: the sampler's table path on the 16-edge / two-waves-per-SIMD kernel (dedf_edge16.h)
     bool edge16_used = false;
     bool edge_occ = false;            // DEDF_EDGE_OCC=1: lmax-1 score head on the two-waves-per-SIMD build of the edge kernel (A/B)
+    // Verdict of the last dedf_score / dedf_energy call (they never synchronise): the status words are copied to pinned host memory behind the
+    // call's kernels; the NEXT entry point of this handle looks at them (check_pending) and fails if the call overflowed its edge workspace or
+    // produced a non-finite result -- so that a caller who never reads dedf_get_stats does not keep working with NaN scores.
+    int* h_flags = nullptr;           // pinned, 64 ints (the tile_info block)
+    hipEvent_t ev_flags = nullptr;
+    bool flags_pending = false;
+    bool so2 = false;                 // the edge kernels of this handle run both depth-wise TPs in the edge-aligned frame (dedf_edge.h: SO2; its own
+                                      // packed image, dedf_pack.h::pack_edge<L, true>).  DEDF_SO2=0 keeps the general form (A/B, tests)
     bool small_batch_path = true;     // N_d <= kNbrSmallMax (32 768): word-parallel neighbour masks + fused pose preparation (DEDF_SMALL_BATCH=0 turns it off: A/B, tests)
     bool defer_check = false;         // dedf_layer_defer_check
     DevBuf d_sticky;
@@ -162,6 +170,32 @@ int fail(dedf_handle* h, int code, const std::string& msg) {
         hipError_t e__ = (call);                                                                                \
         if (e__ != hipSuccess) return fail(h, DEDF_ERR_RUNTIME, std::string(#call) + ": " + hipGetErrorString(e__)); \
     } while (0)
+
+// dedf_score / dedf_energy enqueue and return; this hands their verdict to the host without a synchronisation of its own
+int post_flags(dedf_handle* h, hipStream_t st) {
+    if (!h->h_flags) {
+        HIPCK(h, hipHostMalloc((void**)&h->h_flags, 64 * sizeof(int), hipHostMallocDefault));
+        HIPCK(h, hipEventCreateWithFlags(&h->ev_flags, hipEventDisableTiming));
+    }
+    HIPCK(h, hipMemcpyAsync(h->h_flags, h->d_tile.p, 64 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCK(h, hipEventRecord(h->ev_flags, st));
+    h->flags_pending = true;
+    return DEDF_OK;
+}
+// block = false: only if the previous call has already completed (an entry point that does not synchronise stays that way)
+int check_pending(dedf_handle* h, bool block) {
+    if (!h->flags_pending) return DEDF_OK;
+    if (block) HIPCK(h, hipEventSynchronize(h->ev_flags));
+    else if (hipEventQuery(h->ev_flags) != hipSuccess) return DEDF_OK;
+    h->flags_pending = false;
+    if (h->h_flags[40] | h->h_flags[kFlagOverflow])
+        return fail(h, DEDF_ERR_RUNTIME, "the previous dedf_score / dedf_energy call overflowed its edge workspace: its outputs are NaN (dedf_config.max_edges, or let "
+                                         "dedf_sample grow the automatic workspace); reported by the next call because dedf_score never synchronises");
+    if (h->h_flags[kFlagNonFinite])
+        return fail(h, DEDF_ERR_RUNTIME, "the previous dedf_score / dedf_energy call produced a non-finite result (an operand left the fp16 window of the split GEMMs, "
+                                         "or the inputs were not finite): its outputs are NaN; reported by the next call because dedf_score never synchronises");
+    return DEDF_OK;
+}
 
 int check_config(const dedf_config* c, std::string& why) {
     if (!c) { why = "null config"; return DEDF_ERR_INVALID; }
@@ -225,8 +259,14 @@ template <int L> bool irreps_consistent(const IrrepsRT& K) {
     for (int p = 0; ok && p < stp_num_paths<L>(); ++p) ok = K.stp[p].wstart == stp_path<L>(p).wstart && K.stp[p].kofs == stp_path<L>(p).kofs;
     return ok;
 }
+// shapes with an edge-aligned-frame instantiation (dedf_kernel_list.h): the full-precision lmax-2 score head with the [128, 128, 64] radial network
+bool so2_instantiated(const dedf_config& c) {
+    return c.lmax == 2 && !c.unet_layer && !c.ebm && !c.half_gemm && c.fc_neurons[0] == 128 && c.fc_neurons[1] == 128 && c.fc_neurons[2] == 64;
+}
 template <int L> void pack_all(dedf_handle* h) {
-    pack_edge<L>(h->cfg, h->kspec, h->kparams.data(), h->edge_img, h->eo);
+    bool done = false;
+    if constexpr (L == 2) if (h->so2) { pack_edge<L, true>(h->cfg, h->kspec, h->kparams.data(), h->edge_img, h->eo); done = true; }
+    if (!done) pack_edge<L>(h->cfg, h->kspec, h->kparams.data(), h->edge_img, h->eo);
     pack_node<L>(h->cfg, h->kspec, h->kparams.data(), h->node_img, h->no);
 }
 
@@ -642,6 +682,8 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
                             hipLaunchKernelGGL((k_edge16<2>), dim3(h->n_cu * waves_per_cu<(k_edge16<2>), 8>()), dim3(64), 0, st, Q);
                             h->edge16_used = true;
                         }
+                    } else if (h->so2) {
+                        if constexpr (L == 2 && F0 == 128) DEDF_LAUNCH_PERSISTENT((k_edge<2, 128, false, 128, 64, false, 1, false, true>), kAll, st, P);
                     } else DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 128, 64, false, 1>), kAll, st, P);
                 }
                 if (async_tab) HIPCK(h, hipEventRecord(h->rt_used[h->tab_slot], st));      // the slot may be refilled once this edge kernel is done
@@ -668,7 +710,8 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
                     }
                 } else {
                     launch_radial_table<L, F0, 128, 64>(h, Q, st, true);
-                    DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 128, 64, false, 1>), kAll, st, Q);
+                    if (h->so2) { if constexpr (L == 2 && F0 == 128) DEDF_LAUNCH_PERSISTENT((k_edge<2, 128, false, 128, 64, false, 1, false, true>), kAll, st, Q); }
+                    else DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 128, 64, false, 1>), kAll, st, Q);
                 }
                 P.gate = Q.gate; P.gate_want = 1;
             }
@@ -687,7 +730,9 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
                 if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true, 32, 32>), kAll, st, P);
                 else DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 32, 32>), kAll, st, P);
             } else if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true>), kAll, st, P);
-            else if (L == 1 && h->edge_occ) {      // lmax 1: the two-waves-per-SIMD build of the same tile (dedf_kernels_occ.h)
+            else if (h->so2) {
+                if constexpr (L == 2) DEDF_LAUNCH_PERSISTENT((k_edge<2, 128, false, 128, 64, false, 0, false, true>), kAll, st, P);
+            } else if (L == 1 && h->edge_occ) {      // lmax 1: the two-waves-per-SIMD build of the same tile (dedf_kernels_occ.h)
                 if constexpr (L == 1) hipLaunchKernelGGL((k_edge_occ<1, 128, false>), dim3(h->n_cu * waves_per_cu<(k_edge_occ<1, 128, false>), 8>()), dim3(64), 0, st, P);
             } else DEDF_LAUNCH_PERSISTENT((k_edge<L, F0>), kAll, st, P);
         } else if constexpr (F0 == 64 && L == 2) {
@@ -823,6 +868,8 @@ int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, de
     if (const char* e = getenv("DEDF_RTAB_INF")) h->rtab_inf = std::max(64, atoi(e));
     if (const char* e = getenv("DEDF_EDGE_OCC")) h->edge_occ = atoi(e) != 0;
     if (const char* e = getenv("DEDF_EDGE16")) h->edge16 = atoi(e);
+    h->so2 = so2_instantiated(*cfg);
+    if (const char* e = getenv("DEDF_SO2")) h->so2 = h->so2 && atoi(e) != 0;
     const IrrepsRT T(h->L, cfg->unet_layer != 0), K(h->L, true);
     h->spec = build_spec(T, h->cfg);
     h->kspec = build_spec(K, h->cfg);
@@ -874,6 +921,7 @@ void dedf_destroy(dedf_handle* h) {
     if (!h) return;
     // workspace links (dedf_layer_share_workspace): a destroyed owner detaches its borrowers (they allocate their own workspace on their next
     // call instead of touching freed memory), a destroyed borrower leaves its owner's list
+    if (h->h_flags) { (void)hipHostFree(h->h_flags); (void)hipEventDestroy(h->ev_flags); }
     for (dedf_handle* b : h->ws_borrowers) b->ws_owner = nullptr;
     if (h->ws_owner) {
         auto& v = h->ws_owner->ws_borrowers;
@@ -891,6 +939,7 @@ int dedf_set_key_clouds(dedf_handle* h, int n_scales, const int* n_pts, const fl
     if (n_scales != h->cfg.n_scales) return fail(h, DEDF_ERR_INVALID, "len(key_pcd_multiscale) != n_scales");
     hipStream_t st = static_cast<hipStream_t>(stream);
     DEDF_ON_DEVICE(h);
+    { const int rcp = check_pending(h, true); if (rcp != DEDF_OK) return rcp; }      // (this entry point synchronises anyway)
     const size_t D = feat_dim_rt(h->L), Dt = true_feat_dim_rt(h->L);      // key features arrive in the true shapes; the message leaves in the kernel layout
     int total = 0;
     for (int n = 0; n < n_scales; ++n) {
@@ -970,6 +1019,7 @@ int dedf_set_query(dedf_handle* h, int nQ, const float* x, const float* f, const
     if (!w) return fail(h, DEDF_ERR_INVALID, "query_pcd.w is required (score_head.py:156-157)");
     hipStream_t st = static_cast<hipStream_t>(stream);
     DEDF_ON_DEVICE(h);
+    { const int rcp = check_pending(h, true); if (rcp != DEDF_OK) return rcp; }
     const size_t D = feat_dim_rt(h->L), Dt = true_feat_dim_rt(h->L);
     if (!h->d_qx.ensure((size_t)nQ * 3 * 4) || !h->d_qf.ensure((size_t)nQ * D * 4) || !h->d_qw.ensure((size_t)nQ * 4))
         return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(query) failed");
@@ -998,12 +1048,15 @@ int dedf_score(dedf_handle* h, int nT, const float* Ts, const float* time, float
                                                           "which needs a backward pass and is not on the accelerated path; use dedf_energy");
     hipStream_t st = static_cast<hipStream_t>(stream);
     DEDF_ON_DEVICE(h);
-    int rc = ensure_workspace(h, nT);
+    int rc = check_pending(h, false);
+    if (rc != DEDF_OK) return rc;
+    rc = ensure_workspace(h, nT);
     if (rc != DEDF_OK) return rc;
     DEDF_CLEAR_FLAGS(h, st);
     HIPCK(h, hipMemcpyAsync(h->d_Ts.p, Ts, (size_t)nT * 7 * 4, hipMemcpyDeviceToDevice, st));
     HIPCK(h, hipMemcpyAsync(h->d_time.p, time, (size_t)nT * 4, hipMemcpyDeviceToDevice, st));
-    return score_dispatch(h, nT, 1, ang, lin, st);
+    rc = score_dispatch(h, nT, 1, ang, lin, st);
+    return rc != DEDF_OK ? rc : post_flags(h, st);
 }
 
 int dedf_energy(dedf_handle* h, int nT, const float* Ts, const float* time, float* energy, void* stream) {
@@ -1016,11 +1069,14 @@ int dedf_energy(dedf_handle* h, int nT, const float* Ts, const float* time, floa
     (void)time;   // the critic has no time encoding (configs/*/pick_ebm/score_model_configs.yaml:8-9; agent.py:170)
     hipStream_t st = static_cast<hipStream_t>(stream);
     DEDF_ON_DEVICE(h);
-    int rc = ensure_workspace(h, nT);
+    int rc = check_pending(h, false);
+    if (rc != DEDF_OK) return rc;
+    rc = ensure_workspace(h, nT);
     if (rc != DEDF_OK) return rc;
     DEDF_CLEAR_FLAGS(h, st);
     HIPCK(h, hipMemcpyAsync(h->d_Ts.p, Ts, (size_t)nT * 7 * 4, hipMemcpyDeviceToDevice, st));
-    return score_dispatch(h, nT, 0, energy, nullptr, st);
+    rc = score_dispatch(h, nT, 0, energy, nullptr, st);
+    return rc != DEDF_OK ? rc : post_flags(h, st);
 }
 
 int dedf_field(dedf_handle* h, int n, const float* x, float* field_out, float* emb_out, void* stream) {
@@ -1180,6 +1236,11 @@ static int sample_once(dedf_handle* h, int nT, const double* T_seed, const dedf_
 // the start.  An explicit max_edges is never overridden.
 int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedule* sched, uint64_t seed, int64_t first_pose_index,
                 const double* noise, double* Ts_out, void* stream) {
+    if (h && !h->host_only && h->flags_pending) {
+        DeviceGuard dev_guard__(h->cfg.device);
+        const int rcp = check_pending(h, true);
+        if (rcp != DEDF_OK) return rcp;
+    }
     for (int attempt = 0;; ++attempt) {
         bool overflowed = false;
         const int rc = sample_once(h, nT, T_seed, sched, seed, first_pose_index, noise, Ts_out, stream, &overflowed);
@@ -1378,6 +1439,7 @@ int dedf_get_stats(dedf_handle* h, dedf_stats* out) {
     if (!h || !out) return DEDF_ERR_INVALID;
     if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
     memset(out, 0, sizeof(*out));
+    h->flags_pending = false;      // the caller reads the verdict himself
     if (h->last_nT == 0) return DEDF_OK;
     HIPCK(h, hipStreamSynchronize(h->last_stream));
     int ti[64];

@@ -172,19 +172,19 @@ DEDF_DEV void ln_silu(f32x16 (&x)[NT], const Wave& wv, const float* r_gamma, con
 // into hi / lo halves (B operands), the weights come as a pre-split A-operand stream, every product is hi*hi + hi*lo + lo*hi.
 template <int L> struct BOpsH { h8 hi[2 * L + 1], lo[2 * L + 1]; };
 struct AItem { f32x4 h[2], l[2]; };
-template <int L, int NT0, int I, bool HP = false>
+template <int L, int NT0, int I, bool HP = false, bool S = false>
 DEDF_DEV AItem load_item(const Wave& wv, int o_str) {
     AItem a{};
-    constexpr DtpItem it = dtp_item<L>(I, NT0);
+    constexpr DtpItem it = dtp_item<L, S>(I, NT0);
     if constexpr (it.ntile > 0) {
         static_for<it.ntile>([&]<int n>() {
             // rows 16-31 of this operand are padding: the 16-channel l = 2 outputs, and the last lin tile (112 = 3.5 x 32 rows)
-            constexpr int l3 = dtp_pos_l3<L>(it.pos);
+            constexpr int l3 = dtp_pos_l3<L, S>(it.pos);
             constexpr bool half_rows = l3 >= 2 || (l3 == 0 && NT0 == r0_tiles<L>() && lin0_rows<L>() % 32 == 16 && 2 * it.t + n == lin0_rows<L>() / 32);
             const int lv = half_rows ? wv.lane16_r16 : wv.lane16;
             a.h[n] = bldw(wv, lv, (o_str + (it.slot + n) * 512) * 4);
             if constexpr (!HP) a.l[n] = bldw(wv, lv, (o_str + (it.slot + n) * 512 + 256) * 4);
-            if constexpr (acc_paired<L>(l3)) {      // the same 16 rows once more, as rows 16-31 of the tile (odd components / second tile half)
+            if constexpr (acc_paired<L>(l3) && !S) {      // the same 16 rows once more, as rows 16-31 of the tile (odd components / second tile half)
                 a.h[1] = bldw(wv, wv.lane16_r16up, (o_str + it.slot * 512) * 4);
                 if constexpr (!HP) a.l[1] = bldw(wv, wv.lane16_r16up, (o_str + it.slot * 512 + 256) * 4);
             }
@@ -197,16 +197,32 @@ DEDF_DEV AItem load_item(const Wave& wv, int o_str) {
 // term-major so that consecutive MFMAs hit different accumulators.
 // Output-side chunks (dedf_net.h::dtp_path_out_side) accumulate G_i = W . (w x_i) into `go`: one tile per input component i -- or, for
 // scalar inputs (one component), one tile per product term, so that consecutive MFMAs still hit different accumulators.
-template <int L, int NT0, int C, bool HP, int PD>
+template <int L, int NT0, int C, bool HP, int PD, bool S = false>
 DEDF_DEV void mfma_chunk(const Wave& wv, int o_str, AItem (&ring)[PD], const BOpsH<L>& bo, f32x16 (&acc0)[NT0], f32x16 (&acc1)[3], f32x16 (&acc2)[5],
                          f32x16 (&acc3)[7], f32x16 (&go)[3]) {
-    constexpr int l3 = dtp_pos_l3<L>(C), I0 = dtp_item_first<L>(C, NT0), NI = l3 == 0 ? cdiv(NT0, 2) : 1;
-    if constexpr (dtp_pos_out<L>(C)) {
-        constexpr int d1 = 2 * dtp_pos_path<L>(C).l1 + 1;
-        static_assert(d1 == 1 || d1 == 3, "output-side paths have input degree 0 or 1");
-        constexpr bool first = dtp_pos_path_first<L>(C);
+    constexpr int l3 = dtp_pos_l3<L, S>(C), I0 = dtp_item_first<L, S>(C, NT0), NI = l3 == 0 ? cdiv(NT0, 2) : 1;
+    if constexpr (S && l3 >= 1) {
+        // edge-aligned frame (dedf_net.h::make_dtp_walk_so2): term t of the path is ONE product  acc[k_t] += A . B_t  with the chunk's single A slot
+        // (the path's reference coefficient folded in); term-major like the general form, so that consecutive MFMAs hit different accumulators
+        static_assert(!acc_paired<L>(l3), "edge-frame form: one accumulator tile per output component");
+        constexpr PathInfo pi = dtp_pos_path<L, S>(C);
+        constexpr int NTm = kSo2NT[pi.l1][pi.l2][pi.l3];
         const AItem a = ring[I0 % PD];
-        ring[I0 % PD] = load_item<L, NT0, I0 + PD, HP>(wv, o_str);
+        ring[I0 % PD] = load_item<L, NT0, I0 + PD, HP, S>(wv, o_str);
+        const h8 ah = __builtin_bit_cast(h8, a.h[0]), al = __builtin_bit_cast(h8, a.l[0]);
+        auto& accm = [&]() -> auto& { if constexpr (l3 == 1) return acc1; else if constexpr (l3 == 2) return acc2; else return acc3; }();
+        static_for<NTm>([&]<int t>() { constexpr int K = kSo2K[pi.l1][pi.l2][pi.l3][t]; accm[K] = mfma_h(ah, bo.hi[t], accm[K]); });
+        if constexpr (!HP) {
+            static_for<NTm>([&]<int t>() { constexpr int K = kSo2K[pi.l1][pi.l2][pi.l3][t]; accm[K] = mfma_h(ah, bo.lo[t], accm[K]); });
+            static_for<NTm>([&]<int t>() { constexpr int K = kSo2K[pi.l1][pi.l2][pi.l3][t]; accm[K] = mfma_h(al, bo.hi[t], accm[K]); });
+        }
+    } else
+    if constexpr (dtp_pos_out<L, S>(C)) {
+        constexpr int d1 = 2 * dtp_pos_path<L, S>(C).l1 + 1;
+        static_assert(d1 == 1 || d1 == 3, "output-side paths have input degree 0 or 1");
+        constexpr bool first = dtp_pos_path_first<L, S>(C);
+        const AItem a = ring[I0 % PD];
+        ring[I0 % PD] = load_item<L, NT0, I0 + PD, HP, S>(wv, o_str);
         const h8 ah = __builtin_bit_cast(h8, a.h[0]), al = __builtin_bit_cast(h8, a.l[0]);
         const f32x16 zero = {};
         if constexpr (acc_paired<L>(l3)) {
@@ -239,9 +255,9 @@ DEDF_DEV void mfma_chunk(const Wave& wv, int o_str, AItem (&ring)[PD], const BOp
     static_for<NI>([&]<int t>() {
         constexpr int I = I0 + t;
         const AItem a = ring[I % PD];
-        ring[I % PD] = load_item<L, NT0, I + PD, HP>(wv, o_str);
+        ring[I % PD] = load_item<L, NT0, I + PD, HP, S>(wv, o_str);
         if constexpr (l3 == 0) {
-            constexpr int nt = dtp_item<L>(I, NT0).ntile;
+            constexpr int nt = dtp_item<L, S>(I, NT0).ntile;
             static_for<nt>([&]<int n>() { acc0[2 * t + n] = mfma_h(__builtin_bit_cast(h8, a.h[n]), bo.hi[0], acc0[2 * t + n]); });
             if constexpr (!HP) {
                 static_for<nt>([&]<int n>() { acc0[2 * t + n] = mfma_h(__builtin_bit_cast(h8, a.h[n]), bo.lo[0], acc0[2 * t + n]); });
@@ -330,9 +346,16 @@ struct GeoPre { int ok, src, dst; float vx, vy, vz; };
 // "edge" e of the tile is the MIDPOINT of grid interval e of `scale`: exact front there against the interpolated table.  MODE 2: table generator -- "edge" e of
 // the tile is table row e of `scale`; the tile ends after layer 2's activation.
 // NW: narrow UNet level (dedf_net.h::pad_live): the lane-local work on the structurally zero channels is skipped
-template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false, int MODE = 0, bool NW = false>
+// SO2: both depth-wise TPs in the edge-aligned frame (diffusion_edf_amd/so2.py; dedf_net.h::make_dtp_walk_so2 / make_sval_walk): the gathered source
+//      rows are rotated so that the edge is the polar axis (Rot<l>::in: X(gamma) J X(beta) J on cos / sin of m gamma, m beta), where the SH has only
+//      its m = 0 component and every path is one product per output component; lin, Gate, lin2 and sep_alpha commute with the rotation, the value
+//      is rotated back (Rot<l>::out) before the segmented reduction.  Same result as the general form up to fp32 rounding; needs the image packed
+//      for it (dedf_pack.h::pack_edge<L, true>).
+template <int L> struct Trig { float cg[L], sg[L], cb[L], sb[L]; };
+template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false, int MODE = 0, bool NW = false, bool SO2 = false>
 DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, int n_valid, GeoPre& geo, int e_next DEDF_PROF_ARG) {
     static_assert((H1 == 128 && H2 == 64) || (H1 == 32 && H2 == 32), "radial MLP widths of the shipped configs");
+    static_assert(!SO2 || (L <= 2 && !UN && !NW && MODE <= 1), "edge-frame form: the lmax <= 2 score-head kernels");
     static_assert(!UN || F0 == 64, "UNet layer: the radial MLP reads the 64 radial-basis channels");
     static_assert(MODE == 0 || !UN, "the radial table is the sampler's");
     static_assert(!NW || UN, "NW is a UNet-layer shape");
@@ -439,6 +462,24 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             Y.y3[6] = c0 * (b * uz - a * ux) * cns;
         }
         static_assert(L <= 3, "spherical harmonics up to l = 3");
+    }
+    // SO2: the rotation g = R_x(beta) R_y(gamma) that takes the edge direction to the polar axis y (diffusion_edf_amd/so2.py::frame_angles):
+    // cos gamma = z / rho, sin gamma = -x / rho (gamma = 0 when rho = 0), cos beta = y, sin beta = -rho; multiples by the addition theorems.
+    // A zero-length edge takes the identity (its non-scalar SH vanish with the cut-off, any frame serves the (l, 0, l) paths).
+    Trig<L> tg{};
+    if constexpr (SO2) {
+        const float inv = 1.0f / fmaxf(len, 1e-12f);
+        const float ux = vx * inv, uy = vy * inv, uz = vz * inv;
+        const float rho2 = ux * ux + uz * uz;
+        const bool planar = rho2 > 0.0f;
+        const float rho = sqrtf(rho2), ir = planar ? 1.0f / rho : 0.0f;
+        const bool real = len > 0.0f;
+        tg.cg[0] = planar ? uz * ir : 1.0f; tg.sg[0] = planar ? -ux * ir : 0.0f;
+        tg.cb[0] = real ? uy : 1.0f; tg.sb[0] = real ? -rho : 0.0f;
+        static_for<L - 1>([&]<int m>() {
+            tg.cg[m + 1] = tg.cg[m] * tg.cg[0] - tg.sg[m] * tg.sg[0]; tg.sg[m + 1] = tg.sg[m] * tg.cg[0] + tg.cg[m] * tg.sg[0];
+            tg.cb[m + 1] = tg.cb[m] * tg.cb[0] - tg.sb[m] * tg.sb[0]; tg.sb[m + 1] = tg.sb[m] * tg.cb[0] + tg.cb[m] * tg.sb[0];
+        });
     }
 
     // Timing experiments only (wrong results, same instruction stream; DESIGN.md section 5.R4, "two waves per SIMD, costed"):
@@ -673,8 +714,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     auto load_X = [&]<int C>() {      // this lane's 2 x 4 source-message rows of the chunk (contiguous runs in the reference layout)
         XOps o{};
         if constexpr (C < NCHK) {
-            constexpr PathInfo pi = dtp_pos_path<L>(C);
-            constexpr int l1 = pi.l1, d1 = 2 * l1 + 1, u0 = dtp_pos_u0<L>(C);
+            constexpr PathInfo pi = dtp_pos_path<L, SO2>(C);
+            constexpr int l1 = pi.l1, d1 = 2 * l1 + 1, u0 = dtp_pos_u0<L, SO2>(C);
             const int mv = l1 == 0 ? mv0 : (l1 == 1 ? mv1 : (l1 == 2 ? mv2 : mv3));
             static_for<2>([&]<int run>() { static_for<d1>([&]<int Q>() {
                 o.x[run][Q] = bld4(msgb, mv, (blk_off(l1) + (u0 + 8 * run) * d1 + 4 * Q) * 4);
@@ -688,13 +729,50 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         }
         return o;
     };
+    // SO2: this lane's 2 x 4 source channels of the current (input degree, channel range) in the edge frame; rotated once, read by every path of that range
+    float xrot[8][2 * L + 1];
     auto valu_chunk = [&]<int C>(const XOps& xo, const f32x16& wtile) {
         BOpsH<L> o{};
         if constexpr (C < NCHK) {
-            constexpr PathInfo pi = dtp_pos_path<L>(C);
+            constexpr PathInfo pi = dtp_pos_path<L, SO2>(C);
             constexpr int l1 = pi.l1, l2 = pi.l2, l3 = pi.l3, d1 = 2 * l1 + 1, d3 = 2 * l3 + 1, c2 = C % 2;
             using Cg = CG<l1, l2, l3>;
-            if constexpr (dtp_pos_out<L>(C)) {      // output-side: B_i = w x_i, no contraction here
+            if constexpr (SO2 && l3 >= 1) {
+                // edge frame: B_t = (w . c_t / c_ref . cut-off) x'[i_t] for the terms (k_t, i_t, c_t) of the path (dedf_tables.h::kSo2*); c_ref rides on the A slot
+                constexpr bool newx = C == 0 || dtp_pos_l3<L, SO2>(C > 0 ? C - 1 : 0) == 0 || !dtp_pos_same_x<L, SO2>(C, C - 1);
+                if constexpr (newx) static_for<2>([&]<int run>() { static_for<4>([&]<int j>() {
+                    if constexpr (!pad_reg<L, NW>(l1, j)) {
+                        float v[d1];
+                        static_for<d1>([&]<int m>() { constexpr int el = j * d1 + m; v[m] = xo.x[run][el / 4][el % 4]; });
+                        Rot<l1>::in(v, tg);
+                        static_for<d1>([&]<int m>() { xrot[4 * run + j][m] = v[m]; });
+                    }
+                }); });
+                constexpr int NTm = kSo2NT[l1][l2][l3];
+                constexpr float ref = kSo2Ref[l1][l2][l3];
+                float wr[NTm][8];
+                static_for<NTm>([&]<int t>() {
+                    constexpr float ratio = kSo2C[l1][l2][l3][t] / ref, ar = ratio < 0.0f ? -ratio : ratio;
+                    constexpr int rp = [&]() { for (int q = 0; q < t; ++q) { const float rq = kSo2C[l1][l2][l3][q] / ref; if ((rq < 0.0f ? -rq : rq) == ar) return q; } return t; }();
+                    if constexpr (rp != t) static_for<8>([&]<int jj>() { wr[t][jj] = wr[rp][jj]; });
+                    else if constexpr (l2 == 0 && ar == 1.0f) static_for<8>([&]<int jj>() { wr[t][jj] = wtile[8 * c2 + jj]; });
+                    else {
+                        const float kk = l2 == 0 ? ar : ar * cns;
+                        static_for<8>([&]<int jj>() { wr[t][jj] = wtile[8 * c2 + jj] * kk; });
+                    }
+                    constexpr int I = kSo2I[l1][l2][l3][t];
+                    float v[8];
+                    static_for<8>([&]<int jj>() {
+                        if constexpr (pad_reg<L, NW>(l1, jj % 4)) v[jj] = 0.0f;
+                        else if constexpr (ratio < 0.0f) v[jj] = -(wr[t][jj] * xrot[jj][I]);
+                        else v[jj] = wr[t][jj] * xrot[jj][I];
+                    });
+                    HL sp;
+                    if constexpr (pad_reg<L, NW>(l1, 2)) sp = split8z(v); else sp = split8(v);
+                    o.hi[t] = sp.hi; o.lo[t] = sp.lo;
+                });
+            } else
+            if constexpr (dtp_pos_out<L, SO2>(C)) {      // output-side: B_i = w x_i, no contraction here
                 float v[d1][8];
                 static_for<2>([&]<int run>() {
                     static_for<d1>([&]<int Q>() { static_for<4>([&]<int i>() {
@@ -734,7 +812,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     };
     const int o_S_lin = opaque_s(P.o_S_lin);
     AItem ring[PDA];
-    static_for<PDA>([&]<int I>() { ring[I] = load_item<L, NR0, I, HP>(wv, o_S_lin); });
+    static_for<PDA>([&]<int I>() { ring[I] = load_item<L, NR0, I, HP, SO2>(wv, o_S_lin); });
     // layer 3 on split-fp16 MFMAs: r2 (H2 rows = KC chunks) is split once per edge tile; per weight tile KC chunks x 3 MFMAs.
     // A operands (hi and lo image) form one global stream over all tiles.
     constexpr int KC = H2 / 16;
@@ -794,7 +872,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     auto dump_w = [&]<int Tw>(const f32x16& w) {      // debug only: back to the e3nn weight order
         if constexpr (DBG) if (P.dbg_w != nullptr && valid)
             static_for<16>([&]<int R>() {
-                if constexpr (Tw * 32 + (R & 3) + 8 * (R >> 2) < WN) P.dbg_w[(size_t)e * WN + dtp_walk_row<L>(Tw * 32 + (R & 3) + 8 * (R >> 2)) + 4 * hi] = w[R] * P.w_unscale;
+                if constexpr (Tw * 32 + (R & 3) + 8 * (R >> 2) < WN) P.dbg_w[(size_t)e * WN + dtp_walk_row<L, SO2>(Tw * 32 + (R & 3) + 8 * (R >> 2)) + 4 * hi] = w[R] * P.w_unscale;
             });
     };
 
@@ -888,7 +966,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 float v[8];
                 static_for<8>([&]<int J>() {
                     if constexpr (pad_reg<L, NW>(1, J)) v[J] = 0.0f;
-                    else if constexpr (dtp_group_has_out<L>(1)) v[J] = (acc1[K][8 * hf + J] + vacc1[K][8 * hf + J]) * g1[8 * hf + J];
+                    else if constexpr (dtp_group_has_out<L, SO2>(1)) v[J] = (acc1[K][8 * hf + J] + vacc1[K][8 * hf + J]) * g1[8 * hf + J];
                     else v[J] = acc1[K][8 * hf + J] * g1[8 * hf + J];
                 });
                 park_chunk.template operator()<park_slot<L>(1, K, hf), pad_reg<L, NW>(1, 2)>(v);
@@ -899,7 +977,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 static_for<8>([&]<int J>() {
                     constexpr int T = acc_paired<L>(2) ? K / 2 : K, R = acc_paired<L>(2) ? 8 * (K % 2) + J : J;      // (paired: see mfma_chunk)
                     if constexpr (pad_reg<L, NW>(2, J)) v[J] = 0.0f;
-                    else if constexpr (dtp_group_has_out<L>(2)) v[J] = (acc2[T][R] + vacc2[K][J]) * g2[J]; else v[J] = acc2[T][R] * g2[J];
+                    else if constexpr (dtp_group_has_out<L, SO2>(2)) v[J] = (acc2[T][R] + vacc2[K][J]) * g2[J]; else v[J] = acc2[T][R] * g2[J];
                 });
                 park_chunk.template operator()<park_slot<L>(2, K, 0), pad_reg<L, NW>(2, 2)>(v);
             });
@@ -909,7 +987,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 static_for<8>([&]<int J>() {
                     constexpr int T = acc_paired<L>(3) ? K / 2 : K, R = acc_paired<L>(3) ? 8 * (K % 2) + J : J;
                     if constexpr (pad_reg<L, NW>(3, J)) v[J] = 0.0f;
-                    else if constexpr (dtp_group_has_out<L>(3)) v[J] = (acc3[T][R] + vacc3[K][J]) * g3[J]; else v[J] = acc3[T][R] * g3[J];
+                    else if constexpr (dtp_group_has_out<L, SO2>(3)) v[J] = (acc3[T][R] + vacc3[K][J]) * g3[J]; else v[J] = acc3[T][R] * g3[J];
                 });
                 park_chunk.template operator()<park_slot<L>(3, K, 0)>(v);
             });
@@ -973,21 +1051,22 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     static_for<NCHK>([&]<int C>() {
         constexpr int Ph = C + 3, T3 = Ph / 2;       // layer-3 half of this region
         XOps x_nn = x_nxt;                        // chunks that read the same source rows share the request
-        if constexpr (!dtp_pos_same_x<L>(C + 2, C + 1)) x_nn = load_X.template operator()<C + 2>();
+        if constexpr (!dtp_pos_same_x<L, SO2>(C + 2, C + 1)) x_nn = load_X.template operator()<C + 2>();
         const L3Half l3c = l3n;
         const f32x16 offc = offn;
         l3n = load_l3.template operator()<Ph + 1>();
         if constexpr ((Ph + 1) % 2 == 0) offn = load_off.template operator()<(Ph + 1) / 2>();
-        static_for<L + 1>([&]<int g>() { if constexpr (g >= 1 && C == dtp_group_end<L>(g - 1)) start_group.template operator()<g>(); });
+        // (SO2: every output degree >= 1 is live from the end of the scalar group to the end of the walk)
+        static_for<L + 1>([&]<int g>() { if constexpr (g >= 1 && C == dtp_group_end<L>(SO2 ? 0 : g - 1)) start_group.template operator()<g>(); });
         sched_fence();
         if constexpr (Ph % 2 == 0) run_l3.template operator()<Ph>(l3c, offc, wbuf[T3 % 2]);
         else run_l3.template operator()<Ph>(l3c, wbuf[T3 % 2], wbuf[T3 % 2]);
         const BOpsH<L> b_nxt = valu_chunk.template operator()<C + 1>(x_nxt, wbuf[((C + 1) / 2) % 2]);
-        constexpr bool fin_out = C >= 1 && dtp_pos_out<L>(C - 1) && dtp_pos_path_last<L>(C - 1);      // an output-side path ended at C - 1
-        if constexpr (fin_out) static_for<acc_paired<L>(dtp_pos_l3<L>(C >= 1 ? C - 1 : 0)) ? 2 : 3>([&]<int a>() { gfin[a] = go[a]; });
-        mfma_chunk<L, NR0, C, HP>(wv, o_S_lin, ring, b_cur, acc0, acc1, acc2, acc3, go);
+        constexpr bool fin_out = C >= 1 && dtp_pos_out<L, SO2>(C - 1) && dtp_pos_path_last<L, SO2>(C - 1);      // an output-side path ended at C - 1
+        if constexpr (fin_out) static_for<acc_paired<L>(dtp_pos_l3<L, SO2>(C >= 1 ? C - 1 : 0)) ? 2 : 3>([&]<int a>() { gfin[a] = go[a]; });
+        mfma_chunk<L, NR0, C, HP, PDA, SO2>(wv, o_S_lin, ring, b_cur, acc0, acc1, acc2, acc3, go);
         if constexpr (fin_out) contract_out.template operator()<C - 1>(gfin);
-        static_for<L + 1>([&]<int g>() { if constexpr (C == dtp_group_end<L>(g)) finish_group.template operator()<g>(); });
+        static_for<L + 1>([&]<int g>() { if constexpr (C == dtp_group_end<L>(g) && (!SO2 || g == 0)) finish_group.template operator()<g>(); });
         // One MFMA per SGB1 VALU instructions inside the region.  hipcc's own schedule issues the region's 15-27 ready MFMAs in bursts, and a lone in-order
         // wave issues nothing while a burst drains (32 cycles per MFMA); spaced by the Clebsch-Gordan / split work of the next chunk they run under it.
         // Round 4, the sampler's two timed instantiations only (interleaved A/B at 2.37 M edges, profiles/r04z_sgb*_ab.log): lmax 2 2.697 -> 2.624 ms
@@ -996,7 +1075,10 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
 #if defined(DEDF_SGB)
         constexpr int SGB1 = DEDF_SGB;
 #else
-        constexpr int SGB1 = (MODE == 1 && F0 == 128 && H1 == 128 && H2 == 64 && !HP && !UN) ? (L == 3 ? 7 : (L == 2 ? 5 : 0)) : 0;
+#ifndef DEDF_SGB_SO2
+#define DEDF_SGB_SO2 0
+#endif
+        constexpr int SGB1 = SO2 ? DEDF_SGB_SO2 : ((MODE == 1 && F0 == 128 && H1 == 128 && H2 == 64 && !HP && !UN) ? (L == 3 ? 7 : (L == 2 ? 5 : 0)) : 0);
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (SGB1 > 0) static_for<28>([&]<int i>() { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, SGB1, 0); });
@@ -1008,8 +1090,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         if constexpr (L >= 2 && C + 1 == dtp_group_end<L>(1)) DEDF_STAMP(9);
         if constexpr (L == 3 && C + 1 == dtp_group_end<L>(2)) DEDF_STAMP(15);
     });
-    if constexpr (dtp_pos_out<L>(NCHK - 1)) contract_out.template operator()<NCHK - 1>(go);
-    finish_group.template operator()<L>();
+    if constexpr (dtp_pos_out<L, SO2>(NCHK - 1)) contract_out.template operator()<NCHK - 1>(go);
+    if constexpr (SO2) static_for<L>([&]<int g>() { finish_group.template operator()<g + 1>(); });
+    else finish_group.template operator()<L>();
 #endif
     sched_fence();
     DEDF_STAMP(12);
@@ -1037,7 +1120,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // val2[m]; paths are walked by output degree, a completed degree goes straight to the segment record.
     // (plain scalars, not 16-register tuples: the VALU updates them element by element)
     float val0[2][16], val1[3][16], val2[5][8], val3[7][8];
-    static_for<2>([&]<int T>() { const f32x16 b = ldrows_lds(rows, hi, RL::val0, T); static_for<16>([&]<int R>() { val0[T][R] = b[R]; }); });
+    if constexpr (!SO2) static_for<2>([&]<int T>() { const f32x16 b = ldrows_lds(rows, hi, RL::val0, T); static_for<16>([&]<int R>() { val0[T][R] = b[R]; }); });
     // ---- joint-softmax partials --------------------------------------------------------------------------------------------
     // The tile's edges are ordered by destination, so the edges of one destination form a run of lanes ("segment").  Instead
     // of one 976-byte record per edge, the tile emits one per segment: the segment's softmax-weighted mean value and the
@@ -1217,6 +1300,110 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             emit(x, ro, iv);
         }
     };
+    if constexpr (SO2) {
+    // ---- the value in the edge frame (dedf_net.h::make_sval_walk) ----------------------------------------------------------------------------
+    // Every item is a run of plain GEMM terms: A slot (coefficient class folded in) x parked component (as it is, or with its sign bits flipped)
+    // into the tile of its output component; set 0 collects the paths with l2 = 0, set 1 those that carry the non-scalar cut-off.  A completed
+    // degree is read once, value' = set0 + cns . set1, rotated back to the global frame and handed to the segmented reduction.
+#ifndef DEDF_V_PDA_SO2
+#define DEDF_V_PDA_SO2 3
+#endif
+    constexpr int NVI = sval_num_items<L>(), PDV = DEDF_V_PDA_SO2, RS = 2 * (PDV + 1), NB = 2 * L + 1;
+    const int o_S_val = opaque_s(P.o_S_val);
+    struct ASlot { f32x4 h, l; };
+    struct SB { f32x4 h[NB], l[NB]; };
+    ASlot aring[RS];
+    float tok = logit0;
+    int lane16_t = wv.lane16, lane16_r16_t = wv.lane16_r16, lane_t = wv.lane;
+    auto load_A = [&]<int S>() {
+        if constexpr (S < sval_num_slots<L>()) {
+            const int lv = mul_of(sval_slot_l3<L>(S)) < 32 ? lane16_r16_t : lane16_t;      // rows 16-31 are padding: half the lanes fetch
+            aring[S % RS].h = bldw(wv, lv, (o_S_val + S * 512) * 4);
+            if constexpr (!HP) aring[S % RS].l = bldw(wv, lv, (o_S_val + S * 512 + 256) * 4);
+        }
+    };
+    auto load_A_of = [&]<int I>() {
+        if constexpr (I < NVI) static_for<sval_item<L>(I).new_slots>([&]<int n>() { load_A.template operator()<sval_item_slot0<L>(I) + n>(); });
+    };
+    auto load_B = [&]<int I>() {
+        SB o{};
+        if constexpr (I < NVI) {
+            constexpr SItem it = sval_item<L>(I);
+            const f32x4* const pkt = park + lane_t;
+            static_for<(it.l3 == 0 ? 1 : it.na)>([&]<int a>() {      // (scalar outputs: one B operand for both tiles)
+                o.h[a] = pkt[DEDF_PSLOT(park_phys<L>(it.bq[a])) * 64];
+                if constexpr (!HP) o.l[a] = pkt[DEDF_PSLOT(park_phys<L>(it.bq[a]) + 1) * 64];
+                if constexpr (it.neg[a]) {
+                    o.h[a] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, o.h[a]) ^ 0x80008000u);
+                    if constexpr (!HP) o.l[a] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, o.l[a]) ^ 0x80008000u);
+                }
+            });
+        }
+        return o;
+    };
+    f32x16 V0[2][2], V1[2][3], V2[2][5];
+    auto run_item = [&]<int I>(const SB& b) {
+        constexpr SItem it = sval_item<L>(I);
+        auto& V = [&]() -> auto& { if constexpr (it.l3 == 0) return V0; else if constexpr (it.l3 == 1) return V1; else return V2; }();
+        static_for<it.na>([&]<int a>() {
+            f32x16 init = {};
+            if constexpr (it.first[a] && it.l3 == 0 && it.set == 0) init = ldrows_lds(rows, hi, RL::val0, it.acc[a]);      // sep_value.lin's bias
+            V[it.set][it.acc[a]] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].h), __builtin_bit_cast(h8, b.h[it.l3 == 0 ? 0 : a]), it.first[a] ? init : V[it.set][it.acc[a]]);
+        });
+        if constexpr (!HP) {
+            static_for<it.na>([&]<int a>() { V[it.set][it.acc[a]] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].h), __builtin_bit_cast(h8, b.l[it.l3 == 0 ? 0 : a]), V[it.set][it.acc[a]]); });
+            static_for<it.na>([&]<int a>() { V[it.set][it.acc[a]] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].l), __builtin_bit_cast(h8, b.h[it.l3 == 0 ? 0 : a]), V[it.set][it.acc[a]]); });
+        }
+    };
+    // a completed degree: set0 + cns . set1, back to the global frame, into val<l3> (what store_group reads)
+    auto finish_value = [&]<int l3>() {
+        if constexpr (l3 == 0) {
+            static_for<2>([&]<int T>() { static_for<16>([&]<int R>() {
+                float v = sval_acc_used<L>(0, 0, T) ? V0[0][T][R] : 0.0f;
+                if constexpr (sval_acc_used<L>(0, 1, T)) v += cns * V0[1][T][R];
+                val0[T][R] = v;
+            }); });
+        } else {
+            constexpr int d3 = 2 * l3 + 1, NR = mul_of(l3) >= 32 ? 16 : mul_of(l3) / 2;
+            auto& V = [&]() -> auto& { if constexpr (l3 == 1) return V1; else return V2; }();
+            static_for<NR>([&]<int R>() {
+                float v[d3];
+                static_for<d3>([&]<int K>() {
+                    float x = 0.0f;
+                    if constexpr (sval_acc_used<L>(l3, 0, K)) x = V[0][K][R];
+                    if constexpr (sval_acc_used<L>(l3, 1, K)) x += cns * V[1][K][R];
+                    v[K] = x;
+                });
+                Rot<l3>::out(v, tg);
+                static_for<d3>([&]<int K>() { if constexpr (l3 == 1) val1[K][R] = v[K]; else val2[K][R] = v[K]; });
+                if constexpr (R == NR - 1) tok = v[0];
+            });
+        }
+    };
+    static_for<PDV>([&]<int I>() { load_A_of.template operator()<I>(); });
+    SB vb_cur = load_B.template operator()<0>();
+    static_for<NVI + 1>([&]<int I>() {
+        // (operand requests anchored to the stream: dedf_dev.h::tie on a word of the B operand this region's MFMAs read)
+        if constexpr (I < NVI) tok = __builtin_bit_cast(f32x4, vb_cur.h[0])[0];
+        lane16_t = tie(wv.lane16, tok); lane16_r16_t = tie(wv.lane16_r16, tok); lane_t = tie(wv.lane, tok);
+        load_A_of.template operator()<I + PDV>();
+        const SB b_nxt = load_B.template operator()<I + 1>();
+        sched_fence();
+        if constexpr (I < NVI) run_item.template operator()<I>(vb_cur);
+        constexpr int F = I - 1;                         // item whose group (if it ended one) is finished in this region
+        if constexpr (F >= 0) {
+            constexpr int ge = sval_item<L>(F).group_end;
+            if constexpr (ge >= 0) {
+                finish_value.template operator()<ge>();
+                if constexpr (ge < L) store_group.template operator()<ge>();
+            }
+        }
+        sched_fence();
+        vb_cur = b_nxt;
+        if constexpr (F >= 0 && sval_item<L>(F >= 0 ? F : 0).group_end == 0) DEDF_STAMP(10);
+        if constexpr (L >= 2 && F >= 0 && sval_item<L>(F >= 0 ? F : 0).group_end == 1) DEDF_STAMP(13);
+    });
+    } else {
     // Software pipeline over the work items: region I requests the A slots of item I + 2 and the parked B chunks of item I + 1,
     // runs the MFMAs of item I and, beside them, the contraction of the accumulators item I - 1 completed.
 #ifndef DEDF_V_PDA
@@ -1429,6 +1616,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         if constexpr (L >= 2 && F >= 0 && val_item<L>(F).group_end == 1) DEDF_STAMP(13);
         if constexpr (L == 3 && F >= 0 && val_item<L>(F).group_end == 2) DEDF_STAMP(2);      // (slot 2 is free in the table-reading kernel)
     });
+    }
     DEDF_STAMP(14);
     store_group.template operator()<L>();
     if constexpr (DBG) if (P.dbg_out != nullptr && valid && hi == 0) st4(drec_of() + D, f32x4{logit[0], logit[1], logit[2], logit[3]});

@@ -60,5 +60,7 @@
     X(28, void k_edge<2, 64, false, 32, 32, true, 0, true>(EdgeParams)) \
     X(29, void k_edge<3, 64, false, 32, 32, true, 0, true>(EdgeParams)) \
     X(30, void k_edge<2, 64, true, 32, 32, true, 0, true>(EdgeParams))  \
-    X(31, void k_edge<3, 64, true, 32, 32, true, 0, true>(EdgeParams))
-constexpr int kKernelUnits = 32;
+    X(31, void k_edge<3, 64, true, 32, 32, true, 0, true>(EdgeParams))  \
+    X(32, void k_edge<2, 128, false, 128, 64, false, 0, false, true>(EdgeParams)) \
+    X(33, void k_edge<2, 128, false, 128, 64, false, 1, false, true>(EdgeParams))
+constexpr int kKernelUnits = 34;

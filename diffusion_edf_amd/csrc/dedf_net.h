@@ -8,6 +8,7 @@
 //   LinearRS / FCTP          equiformer/tensor_product_rescale.py:155-185
 #pragma once
 #include "dedf_layout.h"
+#include "dedf_tables.h"
 
 namespace dedf {
 
@@ -145,21 +146,47 @@ template <int L> DEDF_HD constexpr DtpWalk<L> make_dtp_walk() {
     for (int i = n; i < 64; ++i) { w.chunk[i] = dtp_wn<L>() / 16; w.path[i] = PathInfo{-1, -1, -1, 0, 0, 0, 0}; }
     return w;
 }
-template <int L> inline constexpr DtpWalk<L> kDtpWalk = make_dtp_walk<L>();
-template <int L> DEDF_HD constexpr int dtp_pos_chunk(int p) { return p < 64 ? kDtpWalk<L>.chunk[p] : dtp_wn<L>() / 16; }
-template <int L> DEDF_HD constexpr PathInfo dtp_pos_path(int p) { return p < 64 ? kDtpWalk<L>.path[p] : PathInfo{-1, -1, -1, 0, 0, 0, 0}; }
-template <int L> DEDF_HD constexpr int dtp_pos_l3(int p) { return dtp_pos_path<L>(p).l3; }
+// Edge-aligned-frame ("SO(2)") form of the first depth-wise TP (S = true; diffusion_edf_amd/so2.py, dedf_tables.h::kSo2*): the source rows are
+// rotated into the frame whose polar axis is the edge, where every path reaches output component k from ONE source component (|m| equal) --
+// B operand = per-edge weight x rotated component, no Clebsch-Gordan sum, no output-side paths.  The scalar outputs (l3 = 0) are frame
+// independent and keep the general form; ALL chunks with l3 >= 1 form one group walked by (input degree, channel range), so that a chunk of
+// source rows is rotated once and serves every path that reads it (five at l1 = 1, 2 of lmax 2).  The l3 >= 1 accumulators are live together.
+template <int L> DEDF_HD constexpr DtpWalk<L> make_dtp_walk_so2() {
+    DtpWalk<L> w{};
+    int n = 0;
+    for (int l1 = 0; l1 <= L; ++l1)
+        for (int c = 0; c < mul_of(l1) / 16; ++c)
+            for (int q = 0; q < dtp_num_paths<L>(); ++q) {
+                const PathInfo pi = dtp_path<L>(q);
+                if (pi.l3 != 0 || pi.l1 != l1) continue;
+                w.chunk[n] = pi.wstart / 16 + c; w.path[n] = pi; ++n;
+            }
+    for (int l1 = 0; l1 <= L; ++l1)
+        for (int c = 0; c < mul_of(l1) / 16; ++c)
+            for (int q = 0; q < dtp_num_paths<L>(); ++q) {
+                const PathInfo pi = dtp_path<L>(q);
+                if (pi.l3 == 0 || pi.l1 != l1) continue;
+                w.chunk[n] = pi.wstart / 16 + c; w.path[n] = pi; ++n;
+            }
+    w.n = n;
+    for (int i = n; i < 64; ++i) { w.chunk[i] = dtp_wn<L>() / 16; w.path[i] = PathInfo{-1, -1, -1, 0, 0, 0, 0}; }
+    return w;
+}
+template <int L, bool S = false> inline constexpr DtpWalk<L> kDtpWalk = S ? make_dtp_walk_so2<L>() : make_dtp_walk<L>();
+template <int L, bool S = false> DEDF_HD constexpr int dtp_pos_chunk(int p) { return p < 64 ? kDtpWalk<L, S>.chunk[p] : dtp_wn<L>() / 16; }
+template <int L, bool S = false> DEDF_HD constexpr PathInfo dtp_pos_path(int p) { return p < 64 ? kDtpWalk<L, S>.path[p] : PathInfo{-1, -1, -1, 0, 0, 0, 0}; }
+template <int L, bool S = false> DEDF_HD constexpr int dtp_pos_l3(int p) { return dtp_pos_path<L, S>(p).l3; }
 // first channel of the chunk inside its path (u0) / inside the l3 block of the sorted DTP output
-template <int L> DEDF_HD constexpr int dtp_pos_u0(int p) { return dtp_pos_chunk<L>(p) * 16 - dtp_pos_path<L>(p).wstart; }
-template <int L> DEDF_HD constexpr int dtp_pos_channel(int p, int k16) { return dtp_pos_path<L>(p).kofs + dtp_pos_u0<L>(p) + chunk_row(k16); }
+template <int L, bool S = false> DEDF_HD constexpr int dtp_pos_u0(int p) { return dtp_pos_chunk<L, S>(p) * 16 - dtp_pos_path<L, S>(p).wstart; }
+template <int L, bool S = false> DEDF_HD constexpr int dtp_pos_channel(int p, int k16) { return dtp_pos_path<L, S>(p).kofs + dtp_pos_u0<L, S>(p) + chunk_row(k16); }
 // chunks p and q read the same input channels (same l1, same channel range)
-template <int L> DEDF_HD constexpr bool dtp_pos_same_x(int p, int q) {
-    return p >= 0 && q >= 0 && p < dtp_wn<L>() / 16 && q < dtp_wn<L>() / 16 && dtp_pos_path<L>(p).l1 == dtp_pos_path<L>(q).l1 && dtp_pos_u0<L>(p) == dtp_pos_u0<L>(q);
+template <int L, bool S = false> DEDF_HD constexpr bool dtp_pos_same_x(int p, int q) {
+    return p >= 0 && q >= 0 && p < dtp_wn<L>() / 16 && q < dtp_wn<L>() / 16 && dtp_pos_path<L, S>(p).l1 == dtp_pos_path<L, S>(q).l1 && dtp_pos_u0<L, S>(p) == dtp_pos_u0<L, S>(q);
 }
 // output-side chunk at walk position p?  first / last chunk of its path?
-template <int L> DEDF_HD constexpr bool dtp_pos_out(int p) { return p >= 0 && p < dtp_wn<L>() / 16 && dtp_path_out_side<L>(dtp_pos_path<L>(p)); }
-template <int L> DEDF_HD constexpr bool dtp_pos_path_first(int p) { return dtp_pos_u0<L>(p) == 0; }
-template <int L> DEDF_HD constexpr bool dtp_pos_path_last(int p) { return dtp_pos_u0<L>(p) + 16 == dtp_pos_path<L>(p).mul1; }
+template <int L, bool S = false> DEDF_HD constexpr bool dtp_pos_out(int p) { return !S && p >= 0 && p < dtp_wn<L>() / 16 && dtp_path_out_side<L>(dtp_pos_path<L, S>(p)); }
+template <int L, bool S = false> DEDF_HD constexpr bool dtp_pos_path_first(int p) { return dtp_pos_u0<L, S>(p) == 0; }
+template <int L, bool S = false> DEDF_HD constexpr bool dtp_pos_path_last(int p) { return dtp_pos_u0<L, S>(p) + 16 == dtp_pos_path<L, S>(p).mul1; }
 // the output-side path ending at p is the first of its output degree to be contracted (the VALU-side accumulators start there)
 template <int L> DEDF_HD constexpr bool dtp_pos_opens_vacc(int p) {
     if (!dtp_pos_out<L>(p) || !dtp_pos_path_last<L>(p)) return false;
@@ -167,33 +194,36 @@ template <int L> DEDF_HD constexpr bool dtp_pos_opens_vacc(int p) {
         if (dtp_pos_out<L>(q) && dtp_pos_path_last<L>(q) && dtp_pos_l3<L>(q) == dtp_pos_l3<L>(p)) return false;
     return true;
 }
-template <int L> DEDF_HD constexpr bool dtp_group_has_out(int l3) {
-    for (int q = 0; q < dtp_wn<L>() / 16; ++q) if (dtp_pos_out<L>(q) && dtp_pos_l3<L>(q) == l3) return true;
+template <int L, bool S = false> DEDF_HD constexpr bool dtp_group_has_out(int l3) {
+    for (int q = 0; q < dtp_wn<L>() / 16; ++q) if (dtp_pos_out<L, S>(q) && dtp_pos_l3<L, S>(q) == l3) return true;
     return false;
 }
 // e3nn weight row held by row r of the (walk-ordered) last radial layer
-template <int L> DEDF_HD constexpr int dtp_walk_row(int r) { return dtp_pos_chunk<L>(r / 16) * 16 + r % 16; }
+template <int L, bool S = false> DEDF_HD constexpr int dtp_walk_row(int r) { return dtp_pos_chunk<L, S>(r / 16) * 16 + r % 16; }
 // number of chunks with output degree <= l3 (= position one past the end of group l3)
 template <int L> DEDF_HD constexpr int dtp_group_end(int l3) { return (dtp_k<L>(0) + (l3 >= 1 ? dtp_k<L>(1) : 0) + (l3 >= 2 ? dtp_k<L>(2) : 0) + (l3 >= 3 ? dtp_k<L>(3) : 0)) / 16; }
 // A-operand stream of a linear layer fed by the depth-wise TP: chunks in walk order; an l3 = 0 chunk feeds nt0 output
 // tiles (one 512-float slot each, consumed in items of two tiles), an l3 >= 1 chunk one tile.  Slot = hi image | lo image.
 struct DtpItem { int pos, t, slot, ntile; };      // chunk position, item inside the chunk, first slot, tiles in the item
-template <int L> DEDF_HD constexpr DtpItem dtp_item(int I, int nt0) {
+template <int L, bool S = false> DEDF_HD constexpr DtpItem dtp_item(int I, int nt0) {
     int i = 0, slot = 0;
     for (int p = 0; p < dtp_wn<L>() / 16; ++p) {
-        const bool z = dtp_pos_l3<L>(p) == 0;
+        const bool z = dtp_pos_l3<L, S>(p) == 0;
         const int ni = z ? cdiv(nt0, 2) : 1;
         if (I < i + ni) { const int t = I - i; return DtpItem{p, t, slot + 2 * t, z ? imin(2, nt0 - 2 * t) : 1}; }
         i += ni; slot += z ? nt0 : 1;
     }
     return DtpItem{dtp_wn<L>() / 16, 0, slot, 0};
 }
-template <int L> DEDF_HD constexpr int dtp_item_first(int p, int nt0) {
+template <int L, bool S = false> DEDF_HD constexpr int dtp_item_first(int p, int nt0) {
     int i = 0;
-    for (int c = 0; c < p; ++c) i += dtp_pos_l3<L>(c) == 0 ? cdiv(nt0, 2) : 1;
+    for (int c = 0; c < p; ++c) i += dtp_pos_l3<L, S>(c) == 0 ? cdiv(nt0, 2) : 1;
     return i;
 }
-template <int L> DEDF_HD constexpr int dtp_num_slots(int nt0) { return dtp_item<L>(1 << 20, nt0).slot; }
+template <int L, bool S = false> DEDF_HD constexpr int dtp_num_slots(int nt0) { return dtp_item<L, S>(1 << 20, nt0).slot; }
+// (S: one A slot per chunk as in the general form -- the path's reference coefficient kSo2Ref is folded into the slot by the host packer, the
+//  kernel multiplies the per-edge weights by the compile-time ratios of the other terms)
+template <int L> DEDF_HD constexpr float so2_ref(const PathInfo& pi) { return kSo2Ref[pi.l1][pi.l2][pi.l3]; }
 
 // ---- second depth-wise TP (attention value) in OUTPUT-SIDE form -----------------------------------------------------------
 // value[o,k] = sum_p sum_u W2[p,u,o] sum_ij C^p_ijk u[u,i] Y[j]  is evaluated as  G^p_i[o] = sum_u W2[p,u,o] u[u,i]  (a GEMM whose
@@ -380,6 +410,98 @@ template <int L> DEDF_HD constexpr int val_item_slot0(int I) {
     int s = 0;
     for (int i = 0; i < I && i < kValWalk<L>.n; ++i) s += kValWalk<L>.item[i].new_slots;
     return s;
+}
+
+// ---- second depth-wise TP (attention value) in the EDGE FRAME (S = true; see make_dtp_walk_so2) -----------------------------------------------
+// The gated features are parked in the edge frame, where  value'[o, k] = sum_p sum_u (c^p_k W2[p, u, o]) u'[u, i_p(k)]:  every term is a plain GEMM
+// whose B operand is a parked component AS IT IS and whose A operand carries the term's coefficient (folded by the host: one A slot per
+// (path, K-chunk, coefficient class); terms whose coefficient is minus the class's take the B operand with its sign bits flipped).  No
+// Clebsch-Gordan work, no operand forming, no accumulator is read before its output degree is complete.  Paths with l2 >= 1 carry the per-edge
+// cut-off factor of the non-scalar SH (graph_parser.py:194-198), which cannot be folded: they accumulate into a second set of tiles,
+// value' = set0 + cns * set1.  The value leaves the edge frame (Rot<l3>::out) when its degree is complete.
+struct SItem {
+    int p, c;              // path (dtp_path), K-chunk of its input block
+    int l3, set;           // output degree; accumulator set (0: l2 = 0, 1: l2 >= 1)
+    int na;                // MFMA triples
+    int acc[7];            // accumulator inside (l3, set): output tile (l3 = 0) / output component k
+    int bq[7];             // parked chunk of the B operand (park_slot)
+    bool neg[7];           // the B operand enters negated
+    int aslot[7];
+    bool first[7];         // first accumulation into that accumulator
+    int new_slots;
+    int group_end;         // output degree completed by this item, or -1
+    float coef;            // what the host folds into this item's A slot(s)
+};
+template <int L> struct SValWalk { SItem item[96]; int n, n_slots; };
+template <int L> DEDF_HD constexpr SValWalk<L> make_sval_walk() {
+    SValWalk<L> w{};
+    int n = 0, slot = 0;
+    for (int l3 = 0; l3 <= L; ++l3) {
+        bool seen[2][7] = {{false, false, false, false, false, false, false}, {false, false, false, false, false, false, false}};
+        for (int set = 0; set < 2; ++set)
+        for (int p = 0; p < dtp_num_paths<L>(); ++p) {
+            const PathInfo pi = dtp_path<L>(p);
+            if (pi.l3 != l3 || (pi.l2 > 0) != (set == 1)) continue;
+            const int nt = kSo2NT[pi.l1][pi.l2][pi.l3];
+            for (int c = 0; c < mul_of(pi.l1) / 16; ++c) {
+                if (l3 == 0) {      // one term (k = 0 from the source's m = 0 component), val_tiles output tiles with their own A slots
+                    SItem it{};
+                    it.p = p; it.c = c; it.l3 = 0; it.set = set; it.na = val_tiles<L>(0); it.group_end = -1; it.coef = kSo2C[pi.l1][pi.l2][0][0];
+                    for (int a = 0; a < it.na; ++a) {
+                        it.acc[a] = a; it.bq[a] = park_slot<L>(pi.l1, kSo2I[pi.l1][pi.l2][0][0], c); it.neg[a] = false; it.aslot[a] = slot + a;
+                        it.first[a] = !seen[set][a]; seen[set][a] = true;
+                    }
+                    it.new_slots = it.na; slot += it.na;
+                    w.item[n++] = it;
+                    continue;
+                }
+                bool done[7] = {false, false, false, false, false, false, false};
+                for (int t0 = 0; t0 < nt; ++t0) {      // coefficient classes: terms with |c| equal share the A slot
+                    if (done[t0]) continue;
+                    const float c0 = kSo2C[pi.l1][pi.l2][pi.l3][t0];
+                    SItem it{};
+                    it.p = p; it.c = c; it.l3 = l3; it.set = set; it.na = 0; it.group_end = -1; it.coef = c0; it.new_slots = 1;
+                    for (int t = t0; t < nt; ++t) {
+                        const float ct = kSo2C[pi.l1][pi.l2][pi.l3][t];
+                        if (done[t] || !(ct == c0 || ct == -c0)) continue;
+                        done[t] = true;
+                        const int a = it.na++, k = kSo2K[pi.l1][pi.l2][pi.l3][t];
+                        it.acc[a] = k; it.bq[a] = park_slot<L>(pi.l1, kSo2I[pi.l1][pi.l2][pi.l3][t], c); it.neg[a] = ct != c0; it.aslot[a] = slot;
+                        it.first[a] = !seen[set][k]; seen[set][k] = true;
+                    }
+                    slot += 1;
+                    w.item[n++] = it;
+                }
+            }
+        }
+        w.item[n - 1].group_end = l3;
+    }
+    w.n = n; w.n_slots = slot;
+    return w;
+}
+template <int L> inline constexpr SValWalk<L> kSValWalk = make_sval_walk<L>();
+template <int L> DEDF_HD constexpr int sval_num_items() { return kSValWalk<L>.n; }
+template <int L> DEDF_HD constexpr int sval_num_slots() { return kSValWalk<L>.n_slots; }
+template <int L> DEDF_HD constexpr SItem sval_item(int I) { return I >= 0 && I < kSValWalk<L>.n ? kSValWalk<L>.item[I] : SItem{}; }
+template <int L> DEDF_HD constexpr int sval_slot_l3(int S) {
+    for (int i = 0; i < kSValWalk<L>.n; ++i)
+        for (int a = 0; a < kSValWalk<L>.item[i].na; ++a)
+            if (kSValWalk<L>.item[i].aslot[a] == S) return kSValWalk<L>.item[i].l3;
+    return 0;
+}
+template <int L> DEDF_HD constexpr int sval_item_slot0(int I) {
+    int s = 0;
+    for (int i = 0; i < I && i < kSValWalk<L>.n; ++i) s += kSValWalk<L>.item[i].new_slots;
+    return s;
+}
+// set `set` of output degree l3 receives anything at all / accumulator `a` of it does
+template <int L> DEDF_HD constexpr bool sval_acc_used(int l3, int set, int a) {
+    for (int i = 0; i < kSValWalk<L>.n; ++i) {
+        const SItem& it = kSValWalk<L>.item[i];
+        if (it.l3 != l3 || it.set != set) continue;
+        for (int q = 0; q < it.na; ++q) if (it.acc[q] == a) return true;
+    }
+    return false;
 }
 
 // ---- score tensor products: in1 = rotated query feature, in2 = field, outputs l3 in {0, 1} ------------------------

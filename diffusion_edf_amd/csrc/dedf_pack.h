@@ -300,9 +300,9 @@ inline int pow2_scale(float maxabs, int lo, int hi) {
 // edge kernel consumes them.  Slot = 512 floats: hi image (256) | lo image (256) of one (output tile x chunk) operand,
 // [lane 64][8 halves] for v_mfma_f32_32x32x16_f16 (row lane & 31, k16 = 8 (lane >> 5) + j); rows past rows[l] are zero.
 //   W(l, o, k) -> weight of output row o of block l for sorted DTP channel k;  rows[l] = valid output rows
-template <int L, class WAt>
+template <int L, bool S = false, class WAt>
 inline std::vector<float> pack_dtp_stream(int nt0, const int* rows, WAt W) {
-    std::vector<uint16_t> img((size_t)dtp_num_slots<L>(nt0) * 1024, 0);
+    std::vector<uint16_t> img((size_t)dtp_num_slots<L, S>(nt0) * 1024, 0);
     auto put = [&](size_t half_idx, float w) {
         const _Float16 hh = (_Float16)w;
         __builtin_memcpy(&img[half_idx], &hh, 2);
@@ -310,14 +310,14 @@ inline std::vector<float> pack_dtp_stream(int nt0, const int* rows, WAt W) {
     };
     size_t slot = 0;
     for (int pos = 0; pos < dtp_wn<L>() / 16; ++pos) {
-        const int l3 = dtp_pos_l3<L>(pos);
+        const int l3 = dtp_pos_l3<L, S>(pos);
         const int nt = l3 == 0 ? nt0 : 1;
         for (int To = 0; To < nt; ++To, ++slot)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j) {
                     const int o = To * 32 + (lane & 31), k16 = 8 * (lane >> 5) + j;
                     if (o >= rows[l3]) continue;
-                    const float w = W(l3, o, dtp_pos_channel<L>(pos, k16));
+                    const float w = W(l3, o, dtp_pos_channel<L, S>(pos, k16));
                     const size_t hi_idx = slot * 1024 + (size_t)lane * 8 + j;
                     const float h = put(hi_idx, w);
                     put(hi_idx + 512, w - h);
@@ -367,7 +367,44 @@ inline std::vector<float> pack_val_stream(WAt W) {
     return out;
 }
 
-template <int L>
+// Split-fp16 A-operand stream of the attention value in the edge frame (dedf_net.h::make_sval_walk): one slot per (path, K-chunk, coefficient
+// class) -- per output tile for the scalar outputs -- in the order the items use them, the class's coefficient folded in.
+//   W(p, o, u) -> weight from input channel u of path p to output row o of the l3 block
+template <int L, class WAt>
+inline std::vector<float> pack_sval_stream(WAt W) {
+    std::vector<uint16_t> img((size_t)sval_num_slots<L>() * 1024, 0);
+    auto put = [&](size_t half_idx, float w) {
+        const _Float16 hh = (_Float16)w;
+        __builtin_memcpy(&img[half_idx], &hh, 2);
+        return (float)hh;
+    };
+    std::vector<char> done(sval_num_slots<L>(), 0);
+    for (int I = 0; I < sval_num_items<L>(); ++I) {
+        const SItem it = sval_item<L>(I);
+        const PathInfo pi = dtp_path<L>(it.p);
+        for (int a = 0; a < it.na; ++a) {
+            const int slot = it.aslot[a];
+            if (done[slot]) continue;
+            done[slot] = 1;
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int o = (it.l3 == 0 ? it.acc[a] : 0) * 32 + (lane & 31), u = 16 * it.c + rowmap(j, lane >> 5);
+                    if (o >= mul_of(pi.l3)) continue;
+                    const float w = W(it.p, o, u) * it.coef;
+                    const size_t hi_idx = (size_t)slot * 1024 + (size_t)lane * 8 + j;
+                    const float h = put(hi_idx, w);
+                    put(hi_idx + 512, w - h);
+                }
+        }
+    }
+    std::vector<float> out(img.size() / 2);
+    __builtin_memcpy(out.data(), img.data(), img.size() * 2);
+    return out;
+}
+
+// SO2: the image of the edge-aligned-frame kernels (dedf_net.h::make_dtp_walk_so2 / make_sval_walk): the last radial layer's rows and the lin /
+// sep_alpha stream in that walk's order with kSo2Ref folded into the l3 >= 1 slots, the value stream per coefficient class
+template <int L, bool SO2 = false>
 inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, Image& im, EdgeOffsets& o) {
     const bool un = c.unet_layer != 0;
     const std::string ktf = "key_tensor_field", blk = un ? std::string("gnn") : ktf + ".gnn_block_init", ga = blk + ".ga", rad = ga + ".sep_act.dtp_rad.";
@@ -442,9 +479,9 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
         for (int i = 0; i < dtp_wn<L>(); ++i) m3 = std::fmax(m3, std::fabs(off3[i]));
         s3 = pow2_scale(m3, -16, 8 + kActHeadroomBits) - kActHeadroomBits;
         const float f3 = std::ldexp(1.0f, s3);
-        pack_A_h(dtp_wn<L>(), H2 / 16, [&](int oo, int k) { return W3[dtp_walk_row<L>(oo) * H2 + k] * f3; }, [&](int cc, int j, int h) { return chain_k(H2, cc, j, h); }, ih, il);
+        pack_A_h(dtp_wn<L>(), H2 / 16, [&](int oo, int k) { return W3[dtp_walk_row<L, SO2>(oo) * H2 + k] * f3; }, [&](int cc, int j, int h) { return chain_k(H2, cc, j, h); }, ih, il);
         o.o_A_r3 = im.push(ih); o.o_A_r3_l = im.push(il);
-        o.o_off_r3 = im.push(pack_rows(dtp_wn<L>(), [&](int i) { return off3[dtp_walk_row<L>(i)] * f3; }));
+        o.o_off_r3 = im.push(pack_rows(dtp_wn<L>(), [&](int i) { return off3[dtp_walk_row<L, SO2>(i)] * f3; }));
         o.w_unscale = std::ldexp(1.0f, -s3);
     }
     {   // sep_act.lin (+ sep_alpha on the l3 = 0 K-steps) and sep_value.lin (shared DTP weights folded in)
@@ -474,29 +511,38 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
         }
         const int a0 = alpha_row0<L>(), O0 = lin0_rows<L>();
         // sep_act.lin rows, then (from row a0) the sep_alpha rows, share the l3 = 0 chunks
+        // SO2: the reference coefficient of the chunk's path (dedf_tables.h::kSo2Ref) rides on the lin weights of the l3 >= 1 blocks; the value
+        // stream folds its coefficients per class (pack_sval_stream), val_w_max bounds them for the power-of-two scale
+        auto path_of = [&](int l, int k) { return dtp_path<L>(dtp_path_of_row<L>(wflat(l, k))); };
         auto lin_w = [&](int l, int oo, int k) {
             if (l == 0) return oo < O0 ? lw[lofs[0] + (size_t)k * O0 + oo] : (oo >= a0 ? aw[(size_t)k * mul_of(0) + (oo - a0)] : 0.0f);
-            return lw[lofs[l] + (size_t)k * mul_of(l) + oo];
+            return lw[lofs[l] + (size_t)k * mul_of(l) + oo] * (SO2 ? so2_ref<L>(path_of(l, k)) : 1.0f);
         };
         auto val_w = [&](int l, int oo, int k) { return vw[vofs[l] + (size_t)k * mul_of(l) + oo] * w2[wflat(l, k)]; };
+        auto so2_cmax = [&](int l, int k) {
+            float m = 1.0f;
+            if (SO2) { const PathInfo pi = path_of(l, k); m = 0.0f; for (int t = 0; t < kSo2NT[pi.l1][pi.l2][pi.l3]; ++t) m = std::fmax(m, std::fabs(kSo2C[pi.l1][pi.l2][pi.l3][t])); }
+            return m;
+        };
         const int su = 8 - kActHeadroomBits;
         int sl[4] = {0, 0, 0, 0}, sv[4] = {0, 0, 0, 0};
         for (int l = 0; l <= L; ++l) {
             float ml = 0.0f, mv = 0.0f;
             for (int k = 0; k < dtp_k<L>(l); ++k) {
                 for (int oo = 0; oo < lrows[l]; ++oo) ml = std::fmax(ml, std::fabs(lin_w(l, oo, k)));
-                for (int oo = 0; oo < vrows[l]; ++oo) mv = std::fmax(mv, std::fabs(val_w(l, oo, k)));
+                for (int oo = 0; oo < vrows[l]; ++oo) mv = std::fmax(mv, std::fabs(val_w(l, oo, k)) * so2_cmax(l, k));
             }
             sl[l] = pow2_scale(ml, 0, 20); sv[l] = pow2_scale(mv, 0, 20);
             o.c_lin[l] = std::ldexp(1.0f, -(sl[l] + s3));
             o.c_val[l] = std::ldexp(1.0f, -(sv[l] + su));
         }
         o.u_scale = std::ldexp(1.0f, su);
-        o.o_S_lin = im.push(pack_dtp_stream<L>(r0_tiles<L>(), lrows, [&](int l, int oo, int k) { return std::ldexp(lin_w(l, oo, k), sl[l]); }));
-        o.o_S_val = im.push(pack_val_stream<L>([&](int p, int oo, int u) {
+        o.o_S_lin = im.push(pack_dtp_stream<L, SO2>(r0_tiles<L>(), lrows, [&](int l, int oo, int k) { return std::ldexp(lin_w(l, oo, k), sl[l]); }));
+        auto val_at = [&](int p, int oo, int u) {
             const PathInfo pi = dtp_path<L>(p);
             return std::ldexp(val_w(pi.l3, oo, pi.kofs + u), sv[pi.l3]);
-        }));
+        };
+        if constexpr (SO2) o.o_S_val = im.push(pack_sval_stream<L>(val_at)); else o.o_S_val = im.push(pack_val_stream<L>(val_at));
         {
             const float* lb = S.get(B, ga + ".sep_act.lin.bias.0");
             const float* ab = S.get(B, ga + ".sep_alpha.bias.0");

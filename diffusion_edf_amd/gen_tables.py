@@ -22,7 +22,7 @@ import os
 
 import numpy as np
 
-from . import so3
+from . import so2, so3
 
 LMAX = 3
 
@@ -62,6 +62,75 @@ def gen_cg(l1: int, l2: int, l3: int) -> str:
     return "\n".join(out)
 
 
+def gen_so2_tables() -> str:
+    """Edge-aligned-frame form of the depth-wise TPs (diffusion_edf_amd/so2.py): per path the (output component k, source component i,
+    coefficient c) terms as constexpr tables shared by the host packers (which fold kSo2Ref into the linear layers' weights) and the
+    kernels (which keep the compile-time ratio c / ref, +-1 for most terms)."""
+    n = LMAX + 1
+    NT = np.zeros((n, n, n), dtype=int)
+    K = np.zeros((n, n, n, 7), dtype=int)
+    I = np.zeros((n, n, n, 7), dtype=int)
+    C = np.zeros((n, n, n, 7))
+    R = np.ones((n, n, n))
+    for l1 in range(n):
+        for l2 in range(n):
+            for l3 in range(abs(l1 - l2), min(LMAX, l1 + l2) + 1):
+                t = so2.so2_terms(l1, l2, l3)
+                NT[l1, l2, l3] = len(t)
+                R[l1, l2, l3] = so2.so2_ref(l1, l2, l3)
+                for e, (k, i, c) in enumerate(t):
+                    K[l1, l2, l3, e], I[l1, l2, l3, e], C[l1, l2, l3, e] = k, i, c
+
+    def arr(a, fmt):
+        if a.ndim == 1:
+            return "{" + ", ".join(fmt(v) for v in a) + "}"
+        return "{" + ", ".join(arr(b, fmt) for b in a) + "}"
+    out = ["// ---- edge-aligned-frame (SO(2)) form of the depth-wise TPs: out'[k] = c x'[i] per term, see diffusion_edf_amd/so2.py ----",
+           f"constexpr int kSo2NT[{n}][{n}][{n}] = {arr(NT, lambda v: str(int(v)))};",
+           f"constexpr int kSo2K[{n}][{n}][{n}][7] = {arr(K, lambda v: str(int(v)))};",
+           f"constexpr int kSo2I[{n}][{n}][{n}][7] = {arr(I, lambda v: str(int(v)))};",
+           f"constexpr float kSo2C[{n}][{n}][{n}][7] = {arr(C, _lit)};",
+           f"constexpr float kSo2Ref[{n}][{n}][{n}] = {arr(R, _lit)};"]
+    return "\n".join(out)
+
+
+def gen_rot(l: int) -> str:
+    """Straight-line device code of D^l(g) (rotate into the edge frame) and its transpose: X(gamma), J, X(beta), J as in so2.rot_in_program.
+    T carries cos / sin of m gamma and m beta (m = 1 .. l) as cg[m-1], sg[m-1], cb[m-1], sb[m-1]."""
+    d = 2 * l + 1
+    J = so3.J_matrix(l)
+
+    def stage(st):
+        if st[0] == 'J':
+            rows = []
+            for r in range(d):
+                terms = []
+                for c in range(d):
+                    if J[r, c] == 0:
+                        continue
+                    if abs(abs(J[r, c]) - 1.0) < 1e-14:
+                        terms.append(("-" if J[r, c] < 0 else "") + f"v[{c}]")
+                    else:
+                        terms.append(f"{_lit(J[r, c])} * v[{c}]")
+                rows.append(" + ".join(terms).replace("+ -", "- "))
+            return "        { const float u[%d] = {%s}; %s }" % (d, ", ".join(rows), " ".join(f"v[{r}] = u[{r}];" for r in range(d)))
+        which, sgn = st[1], st[2]
+        parts = []
+        for m in range(1, l + 1):
+            i, j = l - m, l + m
+            c, s = f"t.c{which}[{m - 1}]", f"t.s{which}[{m - 1}]"
+            op1, op2 = ("+", "-") if sgn > 0 else ("-", "+")
+            parts.append(f"{{ const float a = v[{i}], b = v[{j}]; v[{i}] = {c} * a {op1} {s} * b; v[{j}] = {c} * b {op2} {s} * a; }}")
+        return "        " + " ".join(parts)
+    out = [f"template <> struct Rot<{l}> {{",
+           f"    template <class T> DEDF_DEV static void in(float (&v)[{d}], const T& t) {{"]
+    out += [stage(st) for st in so2.rot_in_program(l)]
+    out += ["    }", f"    template <class T> DEDF_DEV static void out(float (&v)[{d}], const T& t) {{"]
+    out += [stage(st) for st in so2.rot_out_program(l)]
+    out += ["    }", "};"]
+    return "\n".join(out)
+
+
 def gen_header() -> str:
     parts = ["// GENERATED by diffusion_edf_amd/gen_tables.py — do not edit.",
              "// Wigner-3j (real basis, e3nn construction) x sqrt(2 l3 + 1), J matrices, normalize2mom constants.",
@@ -83,6 +152,11 @@ def gen_header() -> str:
         d = 2 * l + 1
         rows = ", ".join("{" + ", ".join(_lit(J[i, j]) for j in range(d)) + "}" for i in range(d))
         parts.append(f"constexpr float kJ{l}[{d}][{d}] = {{{rows}}};")
+    parts.append(gen_so2_tables())
+    parts.append("template <int L> struct Rot;")
+    parts.append("template <> struct Rot<0> { template <class T> DEDF_DEV static void in(float (&)[1], const T&) {} template <class T> DEDF_DEV static void out(float (&)[1], const T&) {} };")
+    for l in range(1, LMAX + 1):
+        parts.append(gen_rot(l))
     parts.append("}  // namespace dedf")
     return "\n".join(parts) + "\n"
 

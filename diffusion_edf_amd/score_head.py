@@ -220,6 +220,12 @@ class ScoreModelHead(torch.nn.Module):
     @torch.no_grad()
     def forward(self, Ts: torch.Tensor, key_pcd_multiscale: List[FeaturedPoints], query_pcd: FeaturedPoints,
                 time: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """``(ang, lin)`` like reference ``score_head.py:142-211``.  The call is enqueued on the current stream and never synchronises.
+        If an evaluation overflows its edge workspace or an operand leaves the fp16 window of the split GEMMs, its outputs are NaN
+        and the NEXT call on this module that finds the evaluation complete (``forward``, ``set_key_clouds`` / ``set_query``,
+        ``sample``) raises ``RuntimeError`` for it -- unless ``stats()`` was read in between (then the caller has seen
+        ``overflow`` / ``nonfinite`` himself).  A batch whose poses all share one time takes the sampler's radial table
+        (scores differ from the mixed-time evaluation of the same pose by ~1e-5 of the score scale, both within the tolerance)."""
         assert Ts.ndim == 2 and Ts.shape[-1] == 7, f"{Ts.shape}"                      # reference score_head.py:149
         assert time.ndim == 1 and len(time) == len(Ts), f"{time.shape}"               # :150
         assert query_pcd.f.ndim == 2 and query_pcd.f.shape[-1] == self.query_edf_dim, f"{query_pcd.f.shape}"   # :151

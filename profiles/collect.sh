@@ -6,7 +6,9 @@ set -u
 TAG=${1:-r01}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
-CMD=${CMD:-"python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extractors --no-small-batches --no-score-fwd"}      # e.g. CMD="python $ROOT/bench.py --lmax 3 --steps 5 --warmup 1 --no-cpu-baseline --no-extractors --no-small-batches" for another workload
+# the DRIVER's command (bench.py --gpus 1 --steps 20 --warmup 5) without the legs that add other kernels / minutes to a trace: the profile must
+# reproduce the driver's bench line (round-4 review: the 5-step profile sat 8 % below it -- one cold launch in five, a colder clock)
+CMD=${CMD:-"python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extractors --no-small-batches --no-score-fwd"}      # e.g. CMD="python $ROOT/bench.py --lmax 3 --steps 5 --warmup 1 --no-cpu-baseline --no-extractors --no-small-batches" for another workload
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 PASSES=${2:-"trace fetch write sq sq2 sq3 tcp bench"}     # each PMC pass costs ~3.5 min of box time
@@ -22,5 +24,5 @@ pass sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WA
 pass sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_RD
 pass sq3 SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_INST_LDS SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INSTS_SALU
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
-has bench && python $ROOT/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+has bench && python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo done

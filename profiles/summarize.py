@@ -109,6 +109,24 @@ def main(tag):
                 summary["edge_kernel_mfma_insts_per_launch"] = n_mfma
                 us = summary.get("edge_kernel_steady_avg_us_in_trace") or summary["edge_kernel_avg_us_in_trace"]
                 summary["edge_kernel_frac_mfma_issued"] = n_mfma * 32768.0 / (us * 1e-6) / 2.5e15
+    # the four ratios of the issue profile of the timed kernel (round-4 review: computed by hand until now)
+    for name, c in pmc.items():
+        if timed and name == timed[-1]:
+            g = lambda n: c.get(n, {}).get("avg")
+            if g("SQ_INSTS_VALU") and g("SQ_INSTS_MFMA"):
+                summary["edge_kernel_valu_per_mfma"] = g("SQ_INSTS_VALU") / g("SQ_INSTS_MFMA")
+            if g("SQ_WAVE_CYCLES"):
+                wc = g("SQ_WAVE_CYCLES")          # quad-cycles, like SQ_ACTIVE_INST_* and SQ_WAIT_*; SQ_VALU_MFMA_*_CYCLES count cycles (MI355X_MICROARCH.md)
+                if g("SQ_ACTIVE_INST_VALU"):
+                    summary["edge_kernel_valu_active_frac_of_wave_time"] = g("SQ_ACTIVE_INST_VALU") / wc
+                if g("SQ_VALU_MFMA_BUSY_CYCLES"):
+                    summary["edge_kernel_mfma_busy_frac_of_wave_time"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / (4.0 * wc)
+                if g("SQ_WAIT_INST_ANY"):
+                    summary["edge_kernel_wait_inst_any_frac"] = g("SQ_WAIT_INST_ANY") / wc
+                if g("SQ_WAIT_ANY"):
+                    summary["edge_kernel_wait_any_frac"] = g("SQ_WAIT_ANY") / wc
+            if g("SQ_VALU_MFMA_COEXEC_CYCLES") and g("SQ_VALU_MFMA_BUSY_CYCLES"):
+                summary["edge_kernel_coexec_frac_of_mfma_busy"] = g("SQ_VALU_MFMA_COEXEC_CYCLES") / g("SQ_VALU_MFMA_BUSY_CYCLES")
     for name, c in pmc.items():
         if timed and name == timed[-1]:
             f = c.get("FETCH_SIZE", {}).get("avg")

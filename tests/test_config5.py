@@ -87,7 +87,12 @@ def test_config5_chain_scene_to_denoised_poses_against_the_oracle():
     # ---- the chain oracle, stage by stage, fp64 ----
     Pk = R.cast_params({k: v.cpu() for k, v in m.key_model.state_dict().items()}, torch.float64)
     Pq = R.cast_params({k: v.cpu() for k, v in m.query_model.state_dict().items()}, torch.float64)
-    key_ref = U.unet_forward(_unet_cfg(m.key_model), Pk, scene, fs.double())
+    # (the key model IS the lmax-3 UNet of tests/test_lmax3.py with the same seeded weights, scene and features: one fp64 pass serves both tests)
+    from test_lmax3 import unet_lmax3_reference
+    rf = unet_lmax3_reference(16384)
+    assert torch.equal(rf["x"], scene) and torch.equal(rf["f"], fs) and set(rf["sd"]) == set(Pk)
+    assert all(torch.equal(rf["sd"][k].double(), Pk[k]) for k in Pk)
+    key_ref = rf["ref"]
     radii = kw["query_kwargs"]["tensor_field_kwargs"]["r_cluster_multiscale"]
     xq, fq, wq = U.keypoint_extractor_forward(_unet_cfg(m.query_model.feature_extractor), _field_cfg(radii), Pq, grasp, fg.double(), 0.1, bbox=None)
     assert [len(k.x) for k in key] == [len(k[0]) for k in key_ref] and torch.equal(query.x.cpu(), xq)

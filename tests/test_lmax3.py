@@ -365,6 +365,26 @@ def _randomized(module, seed):
 _UNET_REF = {}
 
 
+def unet_lmax3_reference(n_points):
+    """The lmax-3 panda_lowres UNet with the weights of BASELINE config 5's key model (tests/test_config5.py::build_config5: seeded init, `_randomized`
+    with seed 1) on the synthetic scene with config 5's features, and its fp64 restatement -- ONE ~140 s pass per scene size, shared by the
+    UNet tests here and the config-5 chain test (which checks that its model's weights are these)."""
+    from diffusion_edf_amd.so3 import parse_irreps
+    from diffusion_edf_amd.unet import UnetFeatureExtractor
+    if n_points not in _UNET_REF:
+        m = UnetFeatureExtractor(**synthetic.unet_kwargs("panda_lowres_lmax3"), deterministic=True)
+        sd = _randomized(m, seed=1)
+        kw = m._ctor
+        ocfg = U.UnetConfig(irreps_input=parse_irreps(kw["irreps_input"]), irreps_output=parse_irreps(kw["irreps_output"]),
+                            irreps_emb=[parse_irreps(i) for i in kw["irreps_emb"]], fc_neurons=[list(f) for f in kw["fc_neurons"]],
+                            n_layers=list(kw["n_layers"]), pool_ratio=list(kw["pool_ratio"]), radius=list(m.radius),
+                            n_layers_midstream=kw["n_layers_midstream"], irreps_sh=SH3)
+        x = torch.from_numpy(synthetic.make_scene(n_points, seed=0).astype(np.float32))
+        f = torch.rand(n_points, 3, generator=torch.Generator().manual_seed(0))
+        _UNET_REF[n_points] = dict(sd=sd, x=x, f=f, ref=U.unet_forward(ocfg, R.cast_params(sd, torch.float64), x, f.double()))
+    return _UNET_REF[n_points]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_points,half", [(16384, False), (16384, True), (3000, True)])
 def test_unet_feature_extractor_lmax3_matches_the_oracle(n_points, half):
@@ -372,22 +392,12 @@ def test_unet_feature_extractor_lmax3_matches_the_oracle(n_points, half):
     SH up to 3e, parity-inverted up path) against the fp64 restatement -- coordinates bit-exact, features per output scale and irreps block within
     2e-5 of the block's magnitude (measured 5.5e-7 .. 2.3e-6, which is what the restatement itself shows when it runs in fp32:
     profiles/r04v_unet_lmax3_err.log); and its fp16-GEMM mode at the same size (measured 0.8 .. 4.1e-3, held to 8e-3) and on a smaller scene (5e-3)"""
-    from diffusion_edf_amd.so3 import parse_irreps
     from diffusion_edf_amd.unet import UnetFeatureExtractor
     dev = torch.device("cuda:0")
-    kwu = synthetic.unet_kwargs("panda_lowres_lmax3")
-    m = UnetFeatureExtractor(**kwu, deterministic=True)
-    sd = _randomized(m, seed=5)
-    kw = m._ctor
-    ocfg = U.UnetConfig(irreps_input=parse_irreps(kw["irreps_input"]), irreps_output=parse_irreps(kw["irreps_output"]),
-                        irreps_emb=[parse_irreps(i) for i in kw["irreps_emb"]], fc_neurons=[list(f) for f in kw["fc_neurons"]],
-                        n_layers=list(kw["n_layers"]), pool_ratio=list(kw["pool_ratio"]), radius=list(m.radius),
-                        n_layers_midstream=kw["n_layers_midstream"], irreps_sh=SH3)
-    x = torch.from_numpy(synthetic.make_scene(n_points, seed=0).astype(np.float32))
-    f = torch.rand(n_points, 3, generator=torch.Generator().manual_seed(1))
-    if n_points not in _UNET_REF:      # (same weights and scene for both modes: one 140 s fp64 pass)
-        _UNET_REF[n_points] = U.unet_forward(ocfg, R.cast_params(sd, torch.float64), x, f.double())
-    ref = _UNET_REF[n_points]
+    rf = unet_lmax3_reference(n_points)
+    m = UnetFeatureExtractor(**synthetic.unet_kwargs("panda_lowres_lmax3"), deterministic=True)
+    m.load_state_dict(rf["sd"])
+    x, f, ref = rf["x"], rf["f"], rf["ref"]
     m.to(dev)
     if half:
         m.half()
