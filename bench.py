@@ -77,6 +77,19 @@ def build_inputs(lmax, n_scene, n_grasp, n_poses, first_pose, device):
     return kw, cfg, P, keys, query, Ts
 
 
+def edge_frame_gemm_mac(lmax):
+    """dense-GEMM multiply-adds per edge of the edge-aligned-frame kernels (kernel shapes: 8x3e runs as 16x3e), front of the radial network excluded:
+    last radial layer, lin / sep_alpha and the value linear with one term per (path, reachable output component)"""
+    from diffusion_edf_amd import so2
+    mul = lambda l: 16 if l >= 3 else 64 >> l
+    paths = [(a, b, c) for a in range(lmax + 1) for b in range(lmax + 1) for c in range(abs(a - b), min(lmax, a + b) + 1)]
+    wn = sum(mul(p[0]) for p in paths)
+    gates = sum(mul(l) for l in range(1, lmax + 1))
+    k0 = sum(mul(p[0]) for p in paths if p[2] == 0)
+    terms = sum(len(so2.so2_terms(*p)) * mul(p[0]) * mul(p[2]) for p in paths if p[2] >= 1)
+    return wn * 64 + k0 * (64 + gates + 64) + terms + k0 * 64 + terms
+
+
 def build_config5(n_scene, n_grasp, device, reps=3):
     """BASELINE config 5 as ONE model (synthetic.config5_model_kwargs: reference multiscale_score_model.py:27-112 at lmax 3): the scene cloud goes
     through the UNet key model, the grasp cloud through the KeypointExtractor query model -- both on the HIP kernels, seeded random-init weights --
@@ -225,6 +238,7 @@ def main():
     ap.add_argument("--no-radial-table", action="store_true", help="evaluate the radial network's front per edge in the sampler too (A/B; the default tabulates it per step)")
     ap.add_argument("--config5", action="store_true", help="BASELINE config 5 as one assembled model: lmax 3, 16 384-point scene -> UNet key model -> key clouds 3277/656/132/27, "
                                                           "1 024-point grasp -> KeypointExtractor -> query EDF, then the sampler; NOT the headline configuration (C2)")
+    ap.add_argument("--drift", action="store_true", help="config 5 only: the Langevin step size of the other configs (0.04) instead of holding the poses at their seeded positions")
     ap.add_argument("--half", action="store_true", help="half-precision GEMM mode (model.half(), the reference's half_precision knob); NOT the headline configuration")
     args = ap.parse_args()
     if args.config5:
@@ -272,9 +286,15 @@ def main():
     head.set_key_clouds(keys)
     head.set_query(query)
 
+    # Config 5 holds the poses where they were seeded (uniform in the workspace: SURVEY 8(d), ~55-95 edges per node on the 16 k-point scene): the
+    # full step runs -- score, noise, SE(3) update -- with a step size of 1e-6, so that the line measures the 16 k-point / lmax-3 cost per step and
+    # not where a random-init network happens to push the poses (with dt = 0.04 they drift into the dense plane within a few steps: 15-23 M edges
+    # per step, +-30 % between runs; --drift restores that).
+    dt = 1e-6 if (args.config5 and not args.drift) else 0.04
+
     def run(T0, n_steps, first_idx):
         # t: 1 -> 0.15 log-spaced, dt 0.04, temperature 1 (configs C1/C2 of BASELINE.md)
-        return model.sample(T0, keys, query, [[1.0, 0.15]], [n_steps], [0.04], temperatures=1.0, seed=3, first_pose_index=first_idx)
+        return model.sample(T0, keys, query, [[1.0, 0.15]], [n_steps], [dt], temperatures=1.0, seed=3, first_pose_index=first_idx)
 
     def barrier():
         if use_dist:
@@ -414,6 +434,13 @@ def main():
         # algorithmic count of SURVEY 8(d) (what the work is worth, not what the pipes did).
         table_on = args.lmax in (2, 3) and not args.half and not args.no_radial_table
         m_exec = M_EDGE[args.lmax] - (M_EDGE_FRONT[args.lmax] if table_on else 0)
+        # Round 5: the edge-aligned-frame kernels (DEDF_SO2 != 0, full precision) execute fewer multiply-adds than that for the same result -- per
+        # path one product per output component instead of the Clebsch-Gordan sum, and no GEMM terms for components a path cannot reach.  `frac`
+        # stays on the SAME constant as rounds 2-4 (SURVEY 8(d)'s algorithmic work minus what the table serves): it is the edge rate in fixed
+        # units, comparable across rounds; what the pipes really did is `gemm_mac_per_edge_executed` / `frac_gemm_executed` and `frac_mfma_issued`.
+        so2_on = os.environ.get("DEDF_SO2", "1") != "0" and not args.half
+        gemm_general = M_EDGE[args.lmax] - M_EDGE_CG[args.lmax] - (M_EDGE_FRONT[args.lmax] if table_on else 0)      # (true shapes, as SURVEY counts them)
+        gemm_exec = (edge_frame_gemm_mac(args.lmax) + (0 if table_on else M_EDGE_FRONT[args.lmax])) if so2_on else gemm_general
         flops_exec = 2.0 * e_per_launch * m_exec
         achieved_exec = flops_exec / (edge_ms * 1e-3) / 1e12 if edge_ms > 0 else 0.0
         out = {
@@ -433,8 +460,12 @@ def main():
                        "score_fwd_ms_at_t0.5": fixed, "feature_extractors_ms": extract, "small_batches_50_steps": small},
             "roofline": {"kernel": "k_edge (fused per-edge pipeline)", "bound": "valu-issue", "achieved": achieved_exec, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved_exec / peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "frac_definition": f"EXECUTED FLOP: 2 x {m_exec} MAC per edge" + (f" ({M_EDGE[args.lmax]} algorithmic - 40 960 that the sampler's radial table evaluates per grid node)" if table_on else "") + " x edges of the launch / its HIP-event duration / peak",
+                         "frac_definition": f"2 x {m_exec} MAC per edge (the constant of rounds 2-4" + (f": {M_EDGE[args.lmax]} algorithmic - 40 960 that the sampler's radial table evaluates per grid node" if table_on else "") + "; what the general form of the kernel executes) x edges of the launch / its HIP-event duration / peak -- with the edge-frame kernels an edge RATE in fixed units, see frac_gemm_executed for the executed GEMM work",
                          "achieved_algorithmic": achieved, "frac_algorithmic": achieved / peak,
+                         "edge_frame_kernels": so2_on,
+                         "gemm_mac_per_edge_executed": gemm_exec, "gemm_mac_per_edge_general_form": gemm_general,
+                         "frac_gemm_executed": (2.0 * e_per_launch * gemm_exec / (edge_ms * 1e-3) / 1e12 / peak) if edge_ms > 0 else 0.0,
+                         "frac_gemm_executed_definition": "2 x the dense-GEMM multiply-adds the launched kernels really execute per edge (kernel shapes, padding included; the lane-local VALU work -- rotations, operand forming, activations, softmax partials -- not counted) x edges / launch time / peak",
                          "frac_mfma_issued": mfma_issued, "frac_mfma_issued_definition": "SQ_INSTS_MFMA x 32 768 FLOP / launch time in the kernel trace / 2.5 PFLOP/s, from the file `traffic_source` names (the MFMAs the kernel issues, all three split terms counted)",
                          "peak_definition": "dense fp16 MFMA peak 2500 TFLOP/s / 3 (every GEMM is a 3-term split-fp16 product, fp32 accumulate): the hardware matrix peak of the arithmetic the kernel uses, in fp32-equivalent FLOP/s",
                          "dtype": "f16 x3 split (22-bit operands), f32 accumulate",

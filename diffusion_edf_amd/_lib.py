@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("DEDF_LIB") or os.path.join(os.path.dirname(os.path.a
 MAX_SCALES = 8
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_RUNTIME = 0, 1, 2, 3
-ABI_VERSION = 4          # DEDF_ABI_VERSION of include/dedf.h this binding mirrors
+ABI_VERSION = 5          # DEDF_ABI_VERSION of include/dedf.h this binding mirrors
 
 SYMBOLS = [
     "dedf_version", "dedf_abi_version", "dedf_struct_size", "dedf_param_count", "dedf_param_name", "dedf_param_numel", "dedf_create", "dedf_destroy",
@@ -42,7 +42,7 @@ class DedfSchedule(C.Structure):
 
 class DedfStats(C.Structure):
     _fields_ = [("n_dst", C.c_int64), ("n_edges", C.c_int64 * MAX_SCALES), ("n_edges_total", C.c_int64), ("overflow", C.c_int), ("nonfinite", C.c_int),
-                ("rtab_err", C.c_float * MAX_SCALES), ("rtab_fallback", C.c_int)]
+                ("rtab_err", C.c_float * MAX_SCALES), ("rtab_fallback", C.c_int), ("sample_retries", C.c_int), ("edges_per_dst_capacity", C.c_int)]
 
 
 class DedfProfile(C.Structure):

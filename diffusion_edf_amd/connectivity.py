@@ -157,7 +157,18 @@ class FpsPool(torch.nn.Module):
         of the sub-cloud.  ``tests/test_graph.py::test_fps_of_an_fps_ordered_cloud_is_its_prefix`` checks it on the oracle and on the kernels."""
         if _fps_ordered and not self.random_start:
             import math
+            import os
             picked = torch.arange(int(math.ceil(self.ratio * len(node_coord_src))), device=node_coord_src.device)
+            # The argument above needs every sample of the prefix to have been at NON-ZERO distance from the samples before it when the parent
+            # run took it.  Once a run has exhausted the distinct points (clouds with exact duplicates, more samples than distinct points) all
+            # remaining distances are 0 and the kernel's smallest-index arg-max returns index 0 again, not the next prefix index: the shortcut
+            # does not hold there.  The UNet cascades never get there (ratio 0.2-0.25 of voxel-filtered clouds); DEDF_FPS_CHECK=1 runs the real
+            # sampling next to the shortcut and raises on any difference (debugging, tests).
+            if os.environ.get("DEDF_FPS_CHECK"):
+                real = fps(node_coord_src, batch_src, ratio=self.ratio, random_start=False, _trusted=_trusted)
+                if not torch.equal(real.to(picked.device), picked):
+                    raise RuntimeError("FpsPool(_fps_ordered=True): the cloud is not in the selection order of a start-0 farthest point sampling "
+                                       "with distinct samples; its re-sampling is not its prefix")
         else:
             picked = fps(node_coord_src, batch_src, ratio=self.ratio, random_start=self.random_start, _trusted=_trusted)
         coord, feat, batch = node_coord_src[picked], node_feature_src[picked], batch_src[picked]

@@ -84,6 +84,11 @@ struct dedf_handle {
     const LangevinParams* fused_step = nullptr;           // dedf_sample: the per-pose reduction also carries this step's Langevin update
     DevBuf d_tb_steps; const float* tb_step = nullptr;    // dedf_sample: the time-bias rows of ALL steps are computed up front; tb_step = this step's rows
     std::vector<float> h_tsteps;
+    // Pinned host block of dedf_sample (round 5: per-call overhead): [0, 64) ints = the tile_info block of the finished call, [64, 72) = the radial
+    // table's guard words, [128, ...) = the step times on their way up.  The status words come down with ONE asynchronous copy in front of the call's
+    // final synchronisation (they were two blocking copies behind it), and dedf_get_stats right after a dedf_sample reads them from here.
+    int* h_pin = nullptr; size_t h_pin_floats = 0;
+    bool stats_fresh = false;         // h_pin holds the status of the last finished call and nothing was enqueued since
     int radial_table = 1;         // sampler: tabulate the radial network's front per launch (DEDF_RADIAL_TABLE=0 / dedf_set_radial_table turn it off)
     DevBuf d_rtab, d_rtab_err;    // table rows; per-scale accuracy words (largest |interpolated - exact| activation at the interval midpoints)
     float rtab_err_bound = 1e-5f; // a scale whose word exceeds it evaluates its front per edge (DEDF_RADIAL_TABLE_BOUND)
@@ -124,6 +129,7 @@ struct dedf_handle {
     int64_t edge_cap = 0;
     double est_degree = 0.0;          // dedf_set_key_clouds: sum over the scales of the key points' mean self-degree (k_self_degree) = the edges a query
                                       // point on the scene surface has; sizes the automatic edge workspace
+    int sample_retries = 0;           // repeats of the last dedf_sample call (dedf_stats)
     int64_t auto_per_dst = 96;        // automatic edge workspace: edges per destination node (grown by dedf_sample when a call overflowed)
     DevBuf d_deg;
     int last_nT = 0;
@@ -261,13 +267,21 @@ template <int L> bool irreps_consistent(const IrrepsRT& K) {
 }
 // shapes with an edge-aligned-frame instantiation (dedf_kernel_list.h): the full-precision lmax-2 score head with the [128, 128, 64] radial network
 bool so2_instantiated(const dedf_config& c) {
-    return c.lmax == 2 && !c.unet_layer && !c.ebm && !c.half_gemm && c.fc_neurons[0] == 128 && c.fc_neurons[1] == 128 && c.fc_neurons[2] == 64;
+    if (c.unet_layer || c.half_gemm) return false;
+    const int F0 = c.fc_neurons[0];
+    const bool wide = c.fc_neurons[1] == 128 && c.fc_neurons[2] == 64, narrow = c.fc_neurons[1] == 32 && c.fc_neurons[2] == 32;
+    if (c.lmax == 3) return (F0 == 128 && wide) || (F0 == 64 && (wide || narrow));
+    if (c.lmax == 2) return ((F0 == 128 || F0 == 64) && (wide || narrow)) || (F0 == 192 && wide);
+    return ((F0 == 128 || F0 == 64) && wide) || (F0 == 128 && narrow);
 }
 template <int L> void pack_all(dedf_handle* h) {
     bool done = false;
-    if constexpr (L == 2) if (h->so2) { pack_edge<L, true>(h->cfg, h->kspec, h->kparams.data(), h->edge_img, h->eo); done = true; }
+    if (h->so2) { pack_edge<L, true>(h->cfg, h->kspec, h->kparams.data(), h->edge_img, h->eo); done = true; }
     if (!done) pack_edge<L>(h->cfg, h->kspec, h->kparams.data(), h->edge_img, h->eo);
-    pack_node<L>(h->cfg, h->kspec, h->kparams.data(), h->node_img, h->no);
+    pack_node<L>(h->cfg, h->kspec, h->kparams.data(), h->node_img, h->no, h->cfg.unet_layer ? 0.0f : h->eo.est_value);
+    if (getenv("DEDF_SCALE_DEBUG"))
+        fprintf(stderr, "dedf scales: s3 %d (msg x %g) su %d est_value %.3g | node bz %g bn %g bh %g %g %g bf %g bt %g %g\n", h->eo.s3, h->eo.msg_scale, h->eo.su, h->eo.est_value, h->no.sc.bz, h->no.sc.bn,
+                h->no.sc.bh[0], h->no.sc.bh[1], h->no.sc.bh[2], h->no.sc.bf, h->no.sc.bt[0], h->no.sc.bt[1]);
 }
 
 // the C ABI's canonical parameter list: TRUE shapes for the score / critic heads; UNet-layer handles take the kernel shapes (the caller pads)
@@ -421,6 +435,23 @@ inline int balanced_blocks(int tiles, int cap) {
 inline int edge_wpc_limit() {      // experiments only: DEDF_EDGE_WAVES_PER_CU=1..4
     static const int wpc = [] { const char* e = getenv("DEDF_EDGE_WAVES_PER_CU"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 8 ? v : 4; }();      // (8: the two-waves-per-SIMD timing builds)
     return wpc;
+}
+// Shapes with an edge-aligned-frame instantiation (dedf_kernel_list.h; dedf_edge.h: SO2): the full-precision score heads / critics / context-free
+// fields of lmax <= 2.  launch_edge picks it when the handle's image was packed for it (dedf_handle::so2).
+template <int L, int F0, bool HP, int H1, int H2, int MODE> constexpr bool so2_shape() {
+    if (HP) return false;
+    if (L == 3) return MODE == 1 ? (F0 == 128 && H1 == 128) : ((F0 == 128 && H1 == 128) || F0 == 64);
+    if (MODE == 1) return L == 2 && ((F0 == 128 && ((H1 == 128 && H2 == 64) || (H1 == 32 && H2 == 32))) || (F0 == 192 && H1 == 128 && H2 == 64));
+    if (L == 2) return (F0 == 128 || F0 == 64) ? true : (F0 == 192 && H1 == 128);
+    return (F0 == 128 || F0 == 64) && H1 == 128 ? true : (F0 == 128 && H1 == 32);      // lmax 1
+}
+template <int L, int F0, bool HP, int H1, int H2, int MODE>
+void launch_edge(dedf_handle* h, hipStream_t st, const EdgeParams& P) {
+    constexpr int kAll = 1 << 30;
+    if constexpr (so2_shape<L, F0, HP, H1, H2, MODE>()) {
+        if (h->so2) { DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, HP, H1, H2, false, MODE, false, true>), kAll, st, P); return; }
+    }
+    DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, HP, H1, H2, false, MODE>), kAll, st, P);
 }
 
 // parameters of the fused edge kernel for the current state of the handle
@@ -664,7 +695,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
                 if (narrow) {
                     if constexpr (L == 2 && F0 == 128) {
                         if (!async_tab) launch_radial_table<L, F0, 32, 32>(h, P, st, false);
-                        DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 32, 32, false, 1>), kAll, st, P);
+                        launch_edge<L, F0, false, 32, 32, 1>(h, st, P);
                     }
                 } else {
                     if (!async_tab) launch_radial_table<L, F0, 128, 64>(h, P, st, false);
@@ -682,9 +713,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
                             hipLaunchKernelGGL((k_edge16<2>), dim3(h->n_cu * waves_per_cu<(k_edge16<2>), 8>()), dim3(64), 0, st, Q);
                             h->edge16_used = true;
                         }
-                    } else if (h->so2) {
-                        if constexpr (L == 2 && F0 == 128) DEDF_LAUNCH_PERSISTENT((k_edge<2, 128, false, 128, 64, false, 1, false, true>), kAll, st, P);
-                    } else DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 128, 64, false, 1>), kAll, st, P);
+                    } else launch_edge<L, F0, false, 128, 64, 1>(h, st, P);
                 }
                 if (async_tab) HIPCK(h, hipEventRecord(h->rt_used[h->tab_slot], st));      // the slot may be refilled once this edge kernel is done
             }
@@ -706,12 +735,11 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
                 if (narrow) {
                     if constexpr (L == 2 && F0 == 128) {
                         launch_radial_table<L, F0, 32, 32>(h, Q, st, true);
-                        DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 32, 32, false, 1>), kAll, st, Q);
+                        launch_edge<L, F0, false, 32, 32, 1>(h, st, Q);
                     }
                 } else {
                     launch_radial_table<L, F0, 128, 64>(h, Q, st, true);
-                    if (h->so2) { if constexpr (L == 2 && F0 == 128) DEDF_LAUNCH_PERSISTENT((k_edge<2, 128, false, 128, 64, false, 1, false, true>), kAll, st, Q); }
-                    else DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 128, 64, false, 1>), kAll, st, Q);
+                    launch_edge<L, F0, false, 128, 64, 1>(h, st, Q);
                 }
                 P.gate = Q.gate; P.gate_want = 1;
             }
@@ -720,27 +748,25 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         } else if constexpr (L == 3) {          // lmax 3: full precision, [., 128, 64] (score head, EBM critic) or [64, 32, 32] (context-free fields)
             static_assert(F0 == 128 || F0 == 64, "lmax 3 instantiations");
             if constexpr (F0 == 64) {
-                if (narrow) { if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<3, 64, true, 32, 32>), kAll, st, P); else DEDF_LAUNCH_PERSISTENT((k_edge<3, 64, false, 32, 32>), kAll, st, P); }
+                if (narrow) { if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<3, 64, true, 32, 32>), kAll, st, P); else launch_edge<3, 64, false, 32, 32, 0>(h, st, P); }
                 else if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<3, 64, true>), kAll, st, P);
-                else DEDF_LAUNCH_PERSISTENT((k_edge<3, 64, false>), kAll, st, P);
+                else launch_edge<3, 64, false, 128, 64, 0>(h, st, P);
             } else if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<3, 128, true>), kAll, st, P);
-            else DEDF_LAUNCH_PERSISTENT((k_edge<3, 128, false>), kAll, st, P);
+            else launch_edge<3, 128, false, 128, 64, 0>(h, st, P);
         } else if constexpr (F0 == 128) {
             if (narrow) {         // narrow radial MLP (sapien place_*)
                 if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true, 32, 32>), kAll, st, P);
-                else DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 32, 32>), kAll, st, P);
+                else launch_edge<L, F0, false, 32, 32, 0>(h, st, P);
             } else if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true>), kAll, st, P);
-            else if (h->so2) {
-                if constexpr (L == 2) DEDF_LAUNCH_PERSISTENT((k_edge<2, 128, false, 128, 64, false, 0, false, true>), kAll, st, P);
-            } else if (L == 1 && h->edge_occ) {      // lmax 1: the two-waves-per-SIMD build of the same tile (dedf_kernels_occ.h)
+            else if (L == 1 && h->edge_occ) {      // lmax 1: the two-waves-per-SIMD build of the same tile (dedf_kernels_occ.h)
                 if constexpr (L == 1) hipLaunchKernelGGL((k_edge_occ<1, 128, false>), dim3(h->n_cu * waves_per_cu<(k_edge_occ<1, 128, false>), 8>()), dim3(64), 0, st, P);
-            } else DEDF_LAUNCH_PERSISTENT((k_edge<L, F0>), kAll, st, P);
+            } else launch_edge<L, F0, false, 128, 64, 0>(h, st, P);
         } else if constexpr (F0 == 64 && L == 2) {
-            if (narrow) { if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true, 32, 32>), kAll, st, P); else DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 32, 32>), kAll, st, P); }      // KeypointExtractor fields
+            if (narrow) { if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true, 32, 32>), kAll, st, P); else launch_edge<L, F0, false, 32, 32, 0>(h, st, P); }      // KeypointExtractor fields
             else if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true>), kAll, st, P);
-            else DEDF_LAUNCH_PERSISTENT((k_edge<L, F0>), kAll, st, P);
+            else launch_edge<L, F0, false, 128, 64, 0>(h, st, P);
         } else if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true>), kAll, st, P);
-        else DEDF_LAUNCH_PERSISTENT((k_edge<L, F0>), kAll, st, P);
+        else launch_edge<L, F0, false, 128, 64, 0>(h, st, P);
     }
     mark();
     // 5. joint softmax + aggregation
@@ -791,6 +817,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     if (hipGetLastError() != hipSuccess) return fail(h, DEDF_ERR_RUNTIME, "kernel launch failed");
     h->last_nT = nT;
     h->last_stream = st;
+    h->stats_fresh = false;
     return DEDF_OK;
 }
 
@@ -868,7 +895,7 @@ int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, de
     if (const char* e = getenv("DEDF_RTAB_INF")) h->rtab_inf = std::max(64, atoi(e));
     if (const char* e = getenv("DEDF_EDGE_OCC")) h->edge_occ = atoi(e) != 0;
     if (const char* e = getenv("DEDF_EDGE16")) h->edge16 = atoi(e);
-    h->so2 = so2_instantiated(*cfg);
+    h->so2 = so2_instantiated(*cfg) && !(cfg->lmax == 1 && h->edge_occ);
     if (const char* e = getenv("DEDF_SO2")) h->so2 = h->so2 && atoi(e) != 0;
     const IrrepsRT T(h->L, cfg->unet_layer != 0), K(h->L, true);
     h->spec = build_spec(T, h->cfg);
@@ -885,7 +912,7 @@ int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, de
     try {
         h->kparams = pad_params(h->cfg, T, h->spec, K, h->kspec, h->params.data());
         if (h->L == 1) pack_all<1>(h.get()); else if (h->L == 2) pack_all<2>(h.get()); else pack_all<3>(h.get());
-        if (h->L == 2 && !cfg->unet_layer && !cfg->ebm && cfg->fc_neurons[0] == 128) pack_edge16<2>(h->cfg, h->kspec, h->kparams.data(), h->edge16_img, h->e16);
+        if (h->L == 2 && !cfg->unet_layer && !cfg->ebm && cfg->fc_neurons[0] == 128) pack_edge16<2>(h->cfg, h->kspec, h->kparams.data(), h->edge16_img, h->e16, (int)std::lround(std::log2(h->eo.msg_scale)));
     } catch (const std::exception& e) {
         fprintf(stderr, "dedf_create: %s\n", e.what());
         return DEDF_ERR_INVALID;
@@ -922,6 +949,7 @@ void dedf_destroy(dedf_handle* h) {
     // workspace links (dedf_layer_share_workspace): a destroyed owner detaches its borrowers (they allocate their own workspace on their next
     // call instead of touching freed memory), a destroyed borrower leaves its owner's list
     if (h->h_flags) { (void)hipHostFree(h->h_flags); (void)hipEventDestroy(h->ev_flags); }
+    if (h->h_pin) (void)hipHostFree(h->h_pin);
     for (dedf_handle* b : h->ws_borrowers) b->ws_owner = nullptr;
     if (h->ws_owner) {
         auto& v = h->ws_owner->ws_borrowers;
@@ -961,13 +989,13 @@ int dedf_set_key_clouds(dedf_handle* h, int n_scales, const int* n_pts, const fl
     const float* nat = h->d_nat.as<float>();
     if (h->L == 1)
         hipLaunchKernelGGL(k_src_message<1>, dim3(total), dim3(64), 0, st, h->d_key_f.as<float>(), total, nat + h->nat_lnw, nat + h->nat_lnb,
-                           nat + h->nat_wsrc, nat + h->nat_bsrc, h->d_msg.as<float>());
+                           nat + h->nat_wsrc, nat + h->nat_bsrc, h->d_msg.as<float>(), 0, 0, 0, 0, h->eo.msg_scale);
     else if (h->L == 2)
         hipLaunchKernelGGL(k_src_message<2>, dim3(total), dim3(64), 0, st, h->d_key_f.as<float>(), total, nat + h->nat_lnw, nat + h->nat_lnb,
-                           nat + h->nat_wsrc, nat + h->nat_bsrc, h->d_msg.as<float>());
+                           nat + h->nat_wsrc, nat + h->nat_bsrc, h->d_msg.as<float>(), 0, 0, 0, 0, h->eo.msg_scale);
     else
         hipLaunchKernelGGL((k_src_message<3, true, true>), dim3(total), dim3(64), 0, st, h->d_key_f.as<float>(), total, nat + h->nat_lnw, nat + h->nat_lnb,
-                           nat + h->nat_wsrc, nat + h->nat_bsrc, h->d_msg.as<float>(), 0, 0, 0, 0);
+                           nat + h->nat_wsrc, nat + h->nat_bsrc, h->d_msg.as<float>(), 0, 0, 0, 0, h->eo.msg_scale);
     // edge-workspace sizing: the mean number of same-scale key points within the scale's radius of a key point, summed over the scales
     {
         const int ns = n_scales;
@@ -1141,6 +1169,13 @@ static int sample_once(dedf_handle* h, int nT, const double* T_seed, const dedf_
     DEDF_ON_DEVICE(h);
     int rc = ensure_workspace(h, nT);
     if (rc != DEDF_OK) return rc;
+    h->stats_fresh = false;
+    if (h->h_pin_floats < (size_t)128 + std::max(sched->n_steps, 1)) {
+        if (h->h_pin) (void)hipHostFree(h->h_pin);
+        h->h_pin = nullptr;
+        h->h_pin_floats = (size_t)128 + std::max(sched->n_steps, 1) + 256;
+        HIPCK(h, hipHostMalloc((void**)&h->h_pin, h->h_pin_floats * 4, hipHostMallocDefault));
+    }
     const size_t row = (size_t)nT * 7;
     DEDF_CLEAR_FLAGS(h, st);
     HIPCK(h, hipMemcpyAsync(h->d_T64.p, T_seed, row * 8, hipMemcpyDeviceToDevice, st));
@@ -1151,9 +1186,9 @@ static int sample_once(dedf_handle* h, int nT, const double* T_seed, const dedf_
     if (sched->n_steps > 0) {
         if (!h->d_tb_steps.ensure((size_t)sched->n_steps * tb_row * 4) || !h->d_time.ensure((size_t)std::max(nT, sched->n_steps) * 4))
             return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(time rows) failed");
-        h->h_tsteps.resize(sched->n_steps);
-        for (int s = 0; s < sched->n_steps; ++s) h->h_tsteps[s] = (float)sched->t[s];
-        HIPCK(h, hipMemcpyAsync(h->d_time.p, h->h_tsteps.data(), (size_t)sched->n_steps * 4, hipMemcpyHostToDevice, st));
+        float* pin_t = reinterpret_cast<float*>(h->h_pin) + 128;
+        for (int s = 0; s < sched->n_steps; ++s) pin_t[s] = (float)sched->t[s];
+        HIPCK(h, hipMemcpyAsync(h->d_time.p, pin_t, (size_t)sched->n_steps * 4, hipMemcpyHostToDevice, st));
         launch_time_bias(h, st, h->d_time.as<float>(), 1, sched->n_steps, h->d_tb_steps.as<float>());
         // Accuracy guard of the radial table, once per call: the table of the first, the middle and the last step (the time only shifts the
         // pre-linear's bias rows; what decides the interpolation error is the length encoder) is checked at EVERY interval midpoint of every
@@ -1214,15 +1249,19 @@ static int sample_once(dedf_handle* h, int nT, const double* T_seed, const dedf_
         if (use_async && s + R < sched->n_steps) { rc = gen_ahead(s + R, true); if (rc != DEDF_OK) return rc; }
     }
     HIPCK(h, hipMemcpyAsync(Ts_out + (size_t)(sched->n_steps + 1) * row, h->d_T64.p, row * 8, hipMemcpyDeviceToDevice, st));
-    HIPCK(h, hipStreamSynchronize(st));
     // sticky status words of the whole call: an overflow or a non-finite score in ANY step is reported (the trajectory then holds NaNs
-    // from that step on, never stale scores)
-    int flags[2] = {0, 0};
-    if (sched->n_steps > 0) HIPCK(h, hipMemcpy(flags, h->d_tile.as<int>() + kFlagOverflow, sizeof(flags), hipMemcpyDeviceToHost));
+    // from that step on, never stale scores).  They travel to pinned memory in front of the synchronisation.
+    memset(h->h_pin, 0, 72 * 4);
+    if (sched->n_steps > 0) {
+        HIPCK(h, hipMemcpyAsync(h->h_pin, h->d_tile.p, 64 * 4, hipMemcpyDeviceToHost, st));
+        if (h->d_rtab_err.p) HIPCK(h, hipMemcpyAsync(h->h_pin + 64, h->d_rtab_err.p, kMaxScales * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIPCK(h, hipStreamSynchronize(st));
+    h->stats_fresh = sched->n_steps > 0;
+    const int flags[2] = {h->h_pin[kFlagOverflow], h->h_pin[kFlagNonFinite]};
     if (flags[0]) { *overflowed = true; return fail(h, DEDF_ERR_RUNTIME, "edge workspace overflow: raise dedf_config.max_edges"); }
     if (h->edge16) {
-        int redo = 0;
-        HIPCK(h, hipMemcpy(&redo, h->d_tile.as<int>() + kFlagEdge16Redo, 4, hipMemcpyDeviceToHost));
+        const int redo = h->h_pin[kFlagEdge16Redo];
         if (redo) return fail(h, DEDF_ERR_RUNTIME, "DEDF_EDGE16: an edge tile lay outside the radial table (the 16-edge kernel has no per-edge front): unset DEDF_EDGE16");
     }
     if (flags[1]) return fail(h, DEDF_ERR_RUNTIME, "non-finite score: an activation left the fp16 operand range of the split-fp16 GEMMs "
@@ -1241,10 +1280,16 @@ int dedf_sample(dedf_handle* h, int nT, const double* T_seed, const dedf_schedul
         const int rcp = check_pending(h, true);
         if (rcp != DEDF_OK) return rcp;
     }
+    const int64_t per_dst_before = h ? h->auto_per_dst : 0;
     for (int attempt = 0;; ++attempt) {
         bool overflowed = false;
         const int rc = sample_once(h, nT, T_seed, sched, seed, first_pose_index, noise, Ts_out, stream, &overflowed);
-        if (!overflowed || h->cfg.max_edges > 0 || attempt >= 3) return rc;
+        if (h) h->sample_retries = attempt;
+        if (!overflowed || h->cfg.max_edges > 0 || attempt >= 3) {
+            if (rc == DEDF_OK) h->err.clear();                                   // (a repeat that succeeded leaves no stale "overflow" text behind)
+            else if (overflowed && h->cfg.max_edges <= 0) h->auto_per_dst = per_dst_before;      // every repeat failed: the capacity is not left 8x larger
+            return rc;
+        }
         h->auto_per_dst *= 2;
     }
 }
@@ -1441,15 +1486,22 @@ int dedf_get_stats(dedf_handle* h, dedf_stats* out) {
     memset(out, 0, sizeof(*out));
     h->flags_pending = false;      // the caller reads the verdict himself
     if (h->last_nT == 0) return DEDF_OK;
-    HIPCK(h, hipStreamSynchronize(h->last_stream));
     int ti[64];
-    HIPCK(h, hipMemcpy(ti, h->d_tile.p, sizeof(ti), hipMemcpyDeviceToHost));
+    const bool fresh = h->stats_fresh && h->h_pin;      // right behind a dedf_sample: its status block is on the host already
+    if (fresh) memcpy(ti, h->h_pin, sizeof(ti));
+    else {
+        HIPCK(h, hipStreamSynchronize(h->last_stream));
+        HIPCK(h, hipMemcpy(ti, h->d_tile.p, sizeof(ti), hipMemcpyDeviceToHost));
+    }
     out->n_dst = (int64_t)h->last_nT * h->nQ;
     for (int n = 0; n < h->cfg.n_scales; ++n) { out->n_edges[n] = ti[16 + n + 1] - ti[16 + n]; out->n_edges_total += out->n_edges[n]; }
     out->overflow = ti[40] | ti[kFlagOverflow];
     out->nonfinite = ti[kFlagNonFinite];
+    out->sample_retries = h->sample_retries;
+    out->edges_per_dst_capacity = h->cfg.max_edges > 0 ? 0 : (int)h->auto_per_dst;
     if (h->d_rtab_err.p) {
-        HIPCK(h, hipMemcpy(out->rtab_err, h->d_rtab_err.p, kMaxScales * 4, hipMemcpyDeviceToHost));
+        if (fresh) memcpy(out->rtab_err, h->h_pin + 64, kMaxScales * 4);
+        else HIPCK(h, hipMemcpy(out->rtab_err, h->d_rtab_err.p, kMaxScales * 4, hipMemcpyDeviceToHost));
         for (int n = 0; n < h->cfg.n_scales; ++n) if (!(out->rtab_err[n] <= radial_table_bound(h, n))) out->rtab_fallback |= 1 << n;
     }
     return DEDF_OK;
@@ -1527,6 +1579,11 @@ int dedf_debug_copy(dedf_handle* h, const char* name, void* host_dst, size_t max
     if (!host_dst) return DEDF_OK;
     if (n > max_bytes) return fail(h, DEDF_ERR_INVALID, "destination too small");
     if (n && src) HIPCK(h, hipMemcpy(host_dst, src, n, hipMemcpyDeviceToHost));
+    if (nm == "msg" && h->eo.msg_scale != 1.0f) {      // stored with a power-of-two scale (EdgeOffsets::msg_scale): the stage tests see the true message
+        float* v = static_cast<float*>(host_dst);
+        const float inv = 1.0f / h->eo.msg_scale;
+        for (size_t i = 0; i < n / 4; ++i) v[i] *= inv;
+    }
     return DEDF_OK;
 }
 

@@ -224,6 +224,17 @@ DEDF_DEV HL split8(const float (&x)[8]) {
     // the packed hi halves (the mixed-precision FMA converts the fp16 source on the fly; x - hi is exact in fp32, one rounding):
     // 3 instructions per pair instead of 6 (v_cvt_pk, 2 v_cvt_f32_f16, 2 v_sub, v_cvt_pk), bit-identical halves
     unsigned hp[4], lp[4];
+#if defined(DEDF_SPLIT_STAGED)
+    // the same twelve instructions stage by stage (4 x cvt, 4 x mixlo, 4 x mixhi) in ONE block: every instruction's producer is four issues back
+    // instead of the instruction before it (pair by pair the three of a pair wait for one another, and hipcc cannot reorder inside an asm block)
+    asm volatile("v_cvt_pk_f16_f32 %0, %8, %9\n\tv_cvt_pk_f16_f32 %1, %10, %11\n\tv_cvt_pk_f16_f32 %2, %12, %13\n\tv_cvt_pk_f16_f32 %3, %14, %15\n\t"
+                 "v_fma_mixlo_f16 %4, %0, -1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixlo_f16 %5, %1, -1.0, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                 "v_fma_mixlo_f16 %6, %2, -1.0, %12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixlo_f16 %7, %3, -1.0, %14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                 "v_fma_mixhi_f16 %4, %0, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %5, %1, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                 "v_fma_mixhi_f16 %6, %2, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %7, %3, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                 : "=&v"(hp[0]), "=&v"(hp[1]), "=&v"(hp[2]), "=&v"(hp[3]), "=&v"(lp[0]), "=&v"(lp[1]), "=&v"(lp[2]), "=&v"(lp[3])
+                 : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+#else
 #define DEDF_SPLIT_PAIR(Q)                                                                          \
     asm volatile("v_cvt_pk_f16_f32 %0, %2, %3\n\t"                                                   \
                  "v_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"             \
@@ -231,6 +242,7 @@ DEDF_DEV HL split8(const float (&x)[8]) {
                  : "=&v"(hp[Q]), "=&v"(lp[Q]) : "v"(x[2 * Q]), "v"(x[2 * Q + 1]))
     DEDF_SPLIT_PAIR(0); DEDF_SPLIT_PAIR(1); DEDF_SPLIT_PAIR(2); DEDF_SPLIT_PAIR(3);
 #undef DEDF_SPLIT_PAIR
+#endif
     r.hi = __builtin_bit_cast(h8, u32x4{hp[0], hp[1], hp[2], hp[3]});
     r.lo = __builtin_bit_cast(h8, u32x4{lp[0], lp[1], lp[2], lp[3]});
 #else

@@ -184,7 +184,7 @@ DEDF_DEV AItem load_item(const Wave& wv, int o_str) {
             const int lv = half_rows ? wv.lane16_r16 : wv.lane16;
             a.h[n] = bldw(wv, lv, (o_str + (it.slot + n) * 512) * 4);
             if constexpr (!HP) a.l[n] = bldw(wv, lv, (o_str + (it.slot + n) * 512 + 256) * 4);
-            if constexpr (acc_paired<L>(l3) && !S) {      // the same 16 rows once more, as rows 16-31 of the tile (odd components / second tile half)
+            if constexpr (acc_paired<L>(l3)) {      // the same 16 rows once more, as rows 16-31 of the tile (odd components / second tile half)
                 a.h[1] = bldw(wv, wv.lane16_r16up, (o_str + it.slot * 512) * 4);
                 if constexpr (!HP) a.l[1] = bldw(wv, wv.lane16_r16up, (o_str + it.slot * 512 + 256) * 4);
             }
@@ -204,17 +204,23 @@ DEDF_DEV void mfma_chunk(const Wave& wv, int o_str, AItem (&ring)[PD], const BOp
     if constexpr (S && l3 >= 1) {
         // edge-aligned frame (dedf_net.h::make_dtp_walk_so2): term t of the path is ONE product  acc[k_t] += A . B_t  with the chunk's single A slot
         // (the path's reference coefficient folded in); term-major like the general form, so that consecutive MFMAs hit different accumulators
-        static_assert(!acc_paired<L>(l3), "edge-frame form: one accumulator tile per output component");
+        // (paired tiles, lmax 3 / l3 >= 2: component K lives in rows 16 (K % 2) .. of tile K / 2 and takes the A operand placed there, see below)
         constexpr PathInfo pi = dtp_pos_path<L, S>(C);
         constexpr int NTm = kSo2NT[pi.l1][pi.l2][pi.l3];
+        constexpr bool PR = acc_paired<L>(l3);
         const AItem a = ring[I0 % PD];
         ring[I0 % PD] = load_item<L, NT0, I0 + PD, HP, S>(wv, o_str);
-        const h8 ah = __builtin_bit_cast(h8, a.h[0]), al = __builtin_bit_cast(h8, a.l[0]);
+        const h8 ah = __builtin_bit_cast(h8, a.h[0]), al = __builtin_bit_cast(h8, a.l[0]), bh = __builtin_bit_cast(h8, a.h[1]), bl = __builtin_bit_cast(h8, a.l[1]);
         auto& accm = [&]() -> auto& { if constexpr (l3 == 1) return acc1; else if constexpr (l3 == 2) return acc2; else return acc3; }();
-        static_for<NTm>([&]<int t>() { constexpr int K = kSo2K[pi.l1][pi.l2][pi.l3][t]; accm[K] = mfma_h(ah, bo.hi[t], accm[K]); });
+#if defined(DEDF_TIMING_SO2_NOMFMA1)
+        static_for<NTm>([&]<int t>() { constexpr int K = kSo2K[pi.l1][pi.l2][pi.l3][t]; accm[PR ? K / 2 : K][0] += __builtin_bit_cast(f32x4, bo.hi[t])[0] + __builtin_bit_cast(f32x4, bo.lo[t])[1] + __builtin_bit_cast(f32x4, ah)[0] + __builtin_bit_cast(f32x4, al)[0]; });
+        if constexpr (false)
+#else
+        static_for<NTm>([&]<int t>() { constexpr int K = kSo2K[pi.l1][pi.l2][pi.l3][t], T = PR ? K / 2 : K; accm[T] = mfma_h(PR && K % 2 ? bh : ah, bo.hi[t], accm[T]); });
+#endif
         if constexpr (!HP) {
-            static_for<NTm>([&]<int t>() { constexpr int K = kSo2K[pi.l1][pi.l2][pi.l3][t]; accm[K] = mfma_h(ah, bo.lo[t], accm[K]); });
-            static_for<NTm>([&]<int t>() { constexpr int K = kSo2K[pi.l1][pi.l2][pi.l3][t]; accm[K] = mfma_h(al, bo.hi[t], accm[K]); });
+            static_for<NTm>([&]<int t>() { constexpr int K = kSo2K[pi.l1][pi.l2][pi.l3][t], T = PR ? K / 2 : K; accm[T] = mfma_h(PR && K % 2 ? bh : ah, bo.lo[t], accm[T]); });
+            static_for<NTm>([&]<int t>() { constexpr int K = kSo2K[pi.l1][pi.l2][pi.l3][t], T = PR ? K / 2 : K; accm[T] = mfma_h(PR && K % 2 ? bl : al, bo.hi[t], accm[T]); });
         }
     } else
     if constexpr (dtp_pos_out<L, S>(C)) {
@@ -355,7 +361,7 @@ template <int L> struct Trig { float cg[L], sg[L], cb[L], sb[L]; };
 template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false, int MODE = 0, bool NW = false, bool SO2 = false>
 DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, int n_valid, GeoPre& geo, int e_next DEDF_PROF_ARG) {
     static_assert((H1 == 128 && H2 == 64) || (H1 == 32 && H2 == 32), "radial MLP widths of the shipped configs");
-    static_assert(!SO2 || (L <= 2 && !UN && !NW && MODE <= 1), "edge-frame form: the lmax <= 2 score-head kernels");
+    static_assert(!SO2 || (!UN && !NW && MODE <= 1), "edge-frame form: the score-head / critic / field kernels");
     static_assert(!UN || F0 == 64, "UNet layer: the radial MLP reads the 64 radial-basis channels");
     static_assert(MODE == 0 || !UN, "the radial table is the sampler's");
     static_assert(!NW || UN, "NW is a UNet-layer shape");
@@ -709,7 +715,10 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
 #ifndef DEDF_V_PDA_TAB
 #define DEDF_V_PDA_TAB 3
 #endif
-    constexpr int NCHK = WN / 16, PDA = L == 3 ? DEDF_PDA3 : ((L == 2 && MODE == 1 && F0 == 128) ? DEDF_PDA2_TAB : DEDF_PDA2);
+#ifndef DEDF_PDA_SO2
+#define DEDF_PDA_SO2 3      // edge-frame form: 3 against 5 (-2 %), 2 / 4 / 7 no better (profiles/r05c_so2_variants_ab.log, r05e_so2_timing_ab.log)
+#endif
+    constexpr int NCHK = WN / 16, PDA = SO2 ? DEDF_PDA_SO2 : (L == 3 ? DEDF_PDA3 : ((L == 2 && MODE == 1 && F0 == 128) ? DEDF_PDA2_TAB : DEDF_PDA2));
     struct XOps { f32x4 x[2][2 * L + 1]; f32x4 xd[UN ? 2 : 1][2 * L + 1]; };
     auto load_X = [&]<int C>() {      // this lane's 2 x 4 source-message rows of the chunk (contiguous runs in the reference layout)
         XOps o{};
@@ -739,18 +748,24 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             using Cg = CG<l1, l2, l3>;
             if constexpr (SO2 && l3 >= 1) {
                 // edge frame: B_t = (w . c_t / c_ref . cut-off) x'[i_t] for the terms (k_t, i_t, c_t) of the path (dedf_tables.h::kSo2*); c_ref rides on the A slot
-                constexpr bool newx = C == 0 || dtp_pos_l3<L, SO2>(C > 0 ? C - 1 : 0) == 0 || !dtp_pos_same_x<L, SO2>(C, C - 1);
+                constexpr bool newx = C == 0 || so2_group_of<L>(dtp_pos_l3<L, SO2>(C > 0 ? C - 1 : 0)) != so2_group_of<L>(l3) || !dtp_pos_same_x<L, SO2>(C, C - 1);
                 if constexpr (newx) static_for<2>([&]<int run>() { static_for<4>([&]<int j>() {
                     if constexpr (!pad_reg<L, NW>(l1, j)) {
                         float v[d1];
                         static_for<d1>([&]<int m>() { constexpr int el = j * d1 + m; v[m] = xo.x[run][el / 4][el % 4]; });
+#if !defined(DEDF_TIMING_SO2_NOROT)      // (timing experiments only, wrong results: DESIGN.md section 5.R5)
                         Rot<l1>::in(v, tg);
+#endif
                         static_for<d1>([&]<int m>() { xrot[4 * run + j][m] = v[m]; });
                     }
                 }); });
                 constexpr int NTm = kSo2NT[l1][l2][l3];
                 constexpr float ref = kSo2Ref[l1][l2][l3];
                 float wr[NTm][8];
+#if defined(DEDF_TIMING_SO2_NOB)
+                static_for<NTm>([&]<int t>() { o.hi[t] = __builtin_bit_cast(h8, xo.x[0][0]); o.lo[t] = __builtin_bit_cast(h8, xo.x[1][0]); });
+                if constexpr (false)
+#endif
                 static_for<NTm>([&]<int t>() {
                     constexpr float ratio = kSo2C[l1][l2][l3][t] / ref, ar = ratio < 0.0f ? -ratio : ratio;
                     constexpr int rp = [&]() { for (int q = 0; q < t; ++q) { const float rq = kSo2C[l1][l2][l3][q] / ref; if ((rq < 0.0f ? -rq : rq) == ar) return q; } return t; }();
@@ -1057,7 +1072,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         l3n = load_l3.template operator()<Ph + 1>();
         if constexpr ((Ph + 1) % 2 == 0) offn = load_off.template operator()<(Ph + 1) / 2>();
         // (SO2: every output degree >= 1 is live from the end of the scalar group to the end of the walk)
-        static_for<L + 1>([&]<int g>() { if constexpr (g >= 1 && C == dtp_group_end<L>(SO2 ? 0 : g - 1)) start_group.template operator()<g>(); });
+        static_for<L + 1>([&]<int g>() { if constexpr (g >= 1 && C == (SO2 ? so2_group_end<L>(so2_group_of<L>(g) - 1) : dtp_group_end<L>(g - 1))) start_group.template operator()<g>(); });
         sched_fence();
         if constexpr (Ph % 2 == 0) run_l3.template operator()<Ph>(l3c, offc, wbuf[T3 % 2]);
         else run_l3.template operator()<Ph>(l3c, wbuf[T3 % 2], wbuf[T3 % 2]);
@@ -1066,7 +1081,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         if constexpr (fin_out) static_for<acc_paired<L>(dtp_pos_l3<L, SO2>(C >= 1 ? C - 1 : 0)) ? 2 : 3>([&]<int a>() { gfin[a] = go[a]; });
         mfma_chunk<L, NR0, C, HP, PDA, SO2>(wv, o_S_lin, ring, b_cur, acc0, acc1, acc2, acc3, go);
         if constexpr (fin_out) contract_out.template operator()<C - 1>(gfin);
-        static_for<L + 1>([&]<int g>() { if constexpr (C == dtp_group_end<L>(g) && (!SO2 || g == 0)) finish_group.template operator()<g>(); });
+        static_for<L + 1>([&]<int g>() { if constexpr (C == (SO2 ? so2_group_end<L>(so2_group_of<L>(g)) : dtp_group_end<L>(g))) finish_group.template operator()<g>(); });
         // One MFMA per SGB1 VALU instructions inside the region.  hipcc's own schedule issues the region's 15-27 ready MFMAs in bursts, and a lone in-order
         // wave issues nothing while a burst drains (32 cycles per MFMA); spaced by the Clebsch-Gordan / split work of the next chunk they run under it.
         // Round 4, the sampler's two timed instantiations only (interleaved A/B at 2.37 M edges, profiles/r04z_sgb*_ab.log): lmax 2 2.697 -> 2.624 ms
@@ -1076,9 +1091,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         constexpr int SGB1 = DEDF_SGB;
 #else
 #ifndef DEDF_SGB_SO2
-#define DEDF_SGB_SO2 0
+#define DEDF_SGB_SO2 5      // (table-reading kernels only, like the general form: 3 / 4 / 5 / 7 -> -1 / -2 / -2 / -2 %, profiles/r05c_so2_variants_ab.log)
 #endif
-        constexpr int SGB1 = SO2 ? DEDF_SGB_SO2 : ((MODE == 1 && F0 == 128 && H1 == 128 && H2 == 64 && !HP && !UN) ? (L == 3 ? 7 : (L == 2 ? 5 : 0)) : 0);
+        constexpr int SGB1 = SO2 ? (MODE == 1 ? DEDF_SGB_SO2 : 0) : ((MODE == 1 && F0 == 128 && H1 == 128 && H2 == 64 && !HP && !UN) ? (L == 3 ? 7 : (L == 2 ? 5 : 0)) : 0);
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (SGB1 > 0) static_for<28>([&]<int i>() { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, SGB1, 0); });
@@ -1091,7 +1106,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         if constexpr (L == 3 && C + 1 == dtp_group_end<L>(2)) DEDF_STAMP(15);
     });
     if constexpr (dtp_pos_out<L, SO2>(NCHK - 1)) contract_out.template operator()<NCHK - 1>(go);
-    if constexpr (SO2) static_for<L>([&]<int g>() { finish_group.template operator()<g + 1>(); });
+    if constexpr (SO2) static_for<L>([&]<int g>() { if constexpr (so2_group_end<L>(so2_group_of<L>(g + 1)) == NCHK) finish_group.template operator()<g + 1>(); });
     else finish_group.template operator()<L>();
 #endif
     sched_fence();
@@ -1207,8 +1222,13 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     auto emit = [&]<int NS>(f32x4 (&xv)[NS], const int (&rec_off)[NS], const float (&inv)[NS]) {
         float x[NS][4];
         static_for<NS>([&]<int n>() { static_for<4>([&]<int q>() { x[n][q] = xv[n][q]; }); });
+#ifndef DEDF_SCAN_UNCOND
+#define DEDF_SCAN_UNCOND 0
+#endif
         static_for<4>([&]<int i>() {
-            if (i < n_steps) {
+            // (SO2 && DEDF_SCAN_UNCOND: every step always -- a step beyond the longest segment adds 0 x the shifted value --, so that the piece is
+            //  straight-line code the region's MFMAs can be spread over)
+            if ((SO2 && DEDF_SCAN_UNCOND) || i < n_steps) {
                 const float m = mkr(i) ? 1.0f : 0.0f;
                 static_for<NS>([&]<int n>() { scan_step.template operator()<i>(x[n], m); });
             }
@@ -1226,14 +1246,17 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
 #endif
 #endif
     };
-    auto store_group = [&]<int l3>() {       // value in internal layout [l][m][channel]; head of a channel = channel / (mul / 4)
+    // (K0, NK: the components K0 .. K0 + NK - 1 of the block only -- output tiles for l3 = 0 --, NK < 0: all of them.  The edge-frame value stage
+    //  emits a completed degree piece by piece under the GEMMs of the next one.)
+    auto store_group = [&]<int l3, int K0 = 0, int NKsel = -1>() {       // value in internal layout [l][m][channel]; head of a channel = channel / (mul / 4)
         const f32x4 pwv = pk[SPW * 64], ivv = pk[(SPW + 1) * 64];
         const float pw[kHeads] = {pwv[0], pwv[1], pwv[2], pwv[3]}, inv_s[kHeads] = {ivv[0], ivv[1], ivv[2], ivv[3]};
         float* const drec = drec_of();
+        constexpr int NKall = l3 == 0 ? 2 : 2 * l3 + 1, NK = NKsel < 0 ? NKall : NKsel;
         if constexpr (l3 == 0) {
-            f32x4 x[8]; int ro[8]; float iv[8];
-            static_for<2>([&]<int T>() { static_for<4>([&]<int g>() {
-                constexpr int hd = 2 * T + g / 2, n = 4 * T + g;
+            f32x4 x[4 * NK]; int ro[4 * NK]; float iv[4 * NK];
+            static_for<NK>([&]<int Tq>() { static_for<4>([&]<int g>() {
+                constexpr int T = K0 + Tq, hd = 2 * T + g / 2, n = 4 * Tq + g;
                 ro[n] = T * 32 + 8 * g + 4 * hi; iv[n] = inv_s[hd];
                 x[n] = f32x4{val0[T][4 * g], val0[T][4 * g + 1], val0[T][4 * g + 2], val0[T][4 * g + 3]};
                 if constexpr (DBG) { x[n] = x[n] * cv0; if (drec != nullptr && valid) st4(drec + ro[n], x[n]); x[n] = x[n] * pw[hd]; }
@@ -1248,9 +1271,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             }); });
             emit(x, ro, iv);
         } else if constexpr (l3 == 1) {
-            f32x4 x[12]; int ro[12]; float iv[12];
-            static_for<3>([&]<int K>() { static_for<4>([&]<int g>() {
-                constexpr int n = 4 * K + g;
+            f32x4 x[4 * NK]; int ro[4 * NK]; float iv[4 * NK];
+            static_for<NK>([&]<int Kq>() { static_for<4>([&]<int g>() {
+                constexpr int K = K0 + Kq, n = 4 * Kq + g;
                 ro[n] = blk_off(1) + K * mul_of(1) + 8 * g + 4 * hi; iv[n] = inv_s[g];
                 x[n] = f32x4{val1[K][4 * g], val1[K][4 * g + 1], val1[K][4 * g + 2], val1[K][4 * g + 3]};
                 if constexpr (DBG) { x[n] = x[n] * cv1; if (drec != nullptr && valid) st4(drec + ro[n], x[n]); x[n] = x[n] * pw[g]; }
@@ -1265,9 +1288,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             }); });
             emit(x, ro, iv);
         } else if constexpr (l3 == 2) {
-            f32x4 x[10]; int ro[10]; float iv[10];
-            static_for<5>([&]<int K>() { static_for<2>([&]<int g>() {        // 16 channels: head = 2 g + hi
-                constexpr int n = 2 * K + g;
+            f32x4 x[2 * NK]; int ro[2 * NK]; float iv[2 * NK];
+            static_for<NK>([&]<int Kq>() { static_for<2>([&]<int g>() {        // 16 channels: head = 2 g + hi
+                constexpr int K = K0 + Kq, n = 2 * Kq + g;
                 ro[n] = blk_off(2) + K * mul_of(2) + 8 * g + 4 * hi; iv[n] = hi ? inv_s[2 * g + 1] : inv_s[2 * g];
                 x[n] = f32x4{val2[K][4 * g], val2[K][4 * g + 1], val2[K][4 * g + 2], val2[K][4 * g + 3]};
                 if constexpr (DBG) { x[n] = x[n] * cv2; if (drec != nullptr && valid) st4(drec + ro[n], x[n]); x[n] = x[n] * (hi ? pw[2 * g + 1] : pw[2 * g]); }
@@ -1282,9 +1305,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             }); });
             emit(x, ro, iv);
         } else {
-            f32x4 x[14]; int ro[14]; float iv[14];
-            static_for<7>([&]<int K>() { static_for<2>([&]<int g>() {        // 16 (padded) channels: head = 2 g + hi
-                constexpr int n = 2 * K + g;
+            f32x4 x[2 * NK]; int ro[2 * NK]; float iv[2 * NK];
+            static_for<NK>([&]<int Kq>() { static_for<2>([&]<int g>() {        // 16 (padded) channels: head = 2 g + hi
+                constexpr int K = K0 + Kq, n = 2 * Kq + g;
                 ro[n] = blk_off(3) + K * mul_of(3) + 8 * g + 4 * hi; iv[n] = hi ? inv_s[2 * g + 1] : inv_s[2 * g];
                 x[n] = f32x4{val3[K][4 * g], val3[K][4 * g + 1], val3[K][4 * g + 2], val3[K][4 * g + 3]};
                 if constexpr (DBG) { x[n] = x[n] * cv3; if (drec != nullptr && valid) st4(drec + ro[n], x[n]); x[n] = x[n] * (hi ? pw[2 * g + 1] : pw[2 * g]); }
@@ -1308,18 +1331,24 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
 #ifndef DEDF_V_PDA_SO2
 #define DEDF_V_PDA_SO2 3
 #endif
-    constexpr int NVI = sval_num_items<L>(), PDV = DEDF_V_PDA_SO2, RS = 2 * (PDV + 1), NB = 2 * L + 1;
+    constexpr int NVI = sval_num_items<L>(), PDV = DEDF_V_PDA_SO2, RS = 2 * (PDV + 1), NB = sval_max_ops<L>();
     const int o_S_val = opaque_s(P.o_S_val);
-    struct ASlot { f32x4 h, l; };
+    struct ASlot { f32x4 h, l, hu, lu; };      // (hu, lu: the same 16 rows placed as rows 16-31 -- paired tiles, lmax 3)
     struct SB { f32x4 h[NB], l[NB]; };
     ASlot aring[RS];
     float tok = logit0;
-    int lane16_t = wv.lane16, lane16_r16_t = wv.lane16_r16, lane_t = wv.lane;
+    int lane16_t = wv.lane16, lane16_r16_t = wv.lane16_r16, lane16_r16up_t = wv.lane16_r16up, lane_t = wv.lane;
     auto load_A = [&]<int S>() {
         if constexpr (S < sval_num_slots<L>()) {
             const int lv = mul_of(sval_slot_l3<L>(S)) < 32 ? lane16_r16_t : lane16_t;      // rows 16-31 are padding: half the lanes fetch
-            aring[S % RS].h = bldw(wv, lv, (o_S_val + S * 512) * 4);
-            if constexpr (!HP) aring[S % RS].l = bldw(wv, lv, (o_S_val + S * 512 + 256) * 4);
+            if constexpr (sval_slot_needs<L>(S, false)) {
+                aring[S % RS].h = bldw(wv, lv, (o_S_val + S * 512) * 4);
+                if constexpr (!HP) aring[S % RS].l = bldw(wv, lv, (o_S_val + S * 512 + 256) * 4);
+            }
+            if constexpr (sval_slot_needs<L>(S, true)) {
+                aring[S % RS].hu = bldw(wv, lane16_r16up_t, (o_S_val + S * 512) * 4);
+                if constexpr (!HP) aring[S % RS].lu = bldw(wv, lane16_r16up_t, (o_S_val + S * 512 + 256) * 4);
+            }
         }
     };
     auto load_A_of = [&]<int I>() {
@@ -1331,8 +1360,14 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             constexpr SItem it = sval_item<L>(I);
             const f32x4* const pkt = park + lane_t;
             static_for<(it.l3 == 0 ? 1 : it.na)>([&]<int a>() {      // (scalar outputs: one B operand for both tiles)
+                if constexpr (park_packed<L>(it.bq[a])) {      // one slot: {hi(0,1), hi(4,5), lo(0,1), lo(4,5)}, the other registers are the zero padding of 8x3e
+                    const f32x4 sp = pkt[DEDF_PSLOT(park_phys<L>(it.bq[a])) * 64];
+                    o.h[a] = f32x4{sp[0], 0.0f, sp[1], 0.0f};
+                    if constexpr (!HP) o.l[a] = f32x4{sp[2], 0.0f, sp[3], 0.0f};
+                } else {
                 o.h[a] = pkt[DEDF_PSLOT(park_phys<L>(it.bq[a])) * 64];
                 if constexpr (!HP) o.l[a] = pkt[DEDF_PSLOT(park_phys<L>(it.bq[a]) + 1) * 64];
+                }
                 if constexpr (it.neg[a]) {
                     o.h[a] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, o.h[a]) ^ 0x80008000u);
                     if constexpr (!HP) o.l[a] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, o.l[a]) ^ 0x80008000u);
@@ -1341,18 +1376,18 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         }
         return o;
     };
-    f32x16 V0[2][2], V1[2][3], V2[2][5];
+    f32x16 V0[2][2], V1[2][3], V2[2][5], V3[2][4];      // (paired tiles, lmax 3: V2 uses three, V3 four)
     auto run_item = [&]<int I>(const SB& b) {
         constexpr SItem it = sval_item<L>(I);
-        auto& V = [&]() -> auto& { if constexpr (it.l3 == 0) return V0; else if constexpr (it.l3 == 1) return V1; else return V2; }();
+        auto& V = [&]() -> auto& { if constexpr (it.l3 == 0) return V0; else if constexpr (it.l3 == 1) return V1; else if constexpr (it.l3 == 2) return V2; else return V3; }();
         static_for<it.na>([&]<int a>() {
             f32x16 init = {};
             if constexpr (it.first[a] && it.l3 == 0 && it.set == 0) init = ldrows_lds(rows, hi, RL::val0, it.acc[a]);      // sep_value.lin's bias
-            V[it.set][it.acc[a]] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].h), __builtin_bit_cast(h8, b.h[it.l3 == 0 ? 0 : a]), it.first[a] ? init : V[it.set][it.acc[a]]);
+            V[it.set][it.tile[a]] = mfma_h(__builtin_bit_cast(h8, it.up[a] ? aring[it.aslot[a] % RS].hu : aring[it.aslot[a] % RS].h), __builtin_bit_cast(h8, b.h[it.l3 == 0 ? 0 : a]), it.first[a] ? init : V[it.set][it.tile[a]]);
         });
         if constexpr (!HP) {
-            static_for<it.na>([&]<int a>() { V[it.set][it.acc[a]] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].h), __builtin_bit_cast(h8, b.l[it.l3 == 0 ? 0 : a]), V[it.set][it.acc[a]]); });
-            static_for<it.na>([&]<int a>() { V[it.set][it.acc[a]] = mfma_h(__builtin_bit_cast(h8, aring[it.aslot[a] % RS].l), __builtin_bit_cast(h8, b.h[it.l3 == 0 ? 0 : a]), V[it.set][it.acc[a]]); });
+            static_for<it.na>([&]<int a>() { V[it.set][it.tile[a]] = mfma_h(__builtin_bit_cast(h8, it.up[a] ? aring[it.aslot[a] % RS].hu : aring[it.aslot[a] % RS].h), __builtin_bit_cast(h8, b.l[it.l3 == 0 ? 0 : a]), V[it.set][it.tile[a]]); });
+            static_for<it.na>([&]<int a>() { V[it.set][it.tile[a]] = mfma_h(__builtin_bit_cast(h8, it.up[a] ? aring[it.aslot[a] % RS].lu : aring[it.aslot[a] % RS].l), __builtin_bit_cast(h8, b.h[it.l3 == 0 ? 0 : a]), V[it.set][it.tile[a]]); });
         }
     };
     // a completed degree: set0 + cns . set1, back to the global frame, into val<l3> (what store_group reads)
@@ -1365,43 +1400,74 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             }); });
         } else {
             constexpr int d3 = 2 * l3 + 1, NR = mul_of(l3) >= 32 ? 16 : mul_of(l3) / 2;
-            auto& V = [&]() -> auto& { if constexpr (l3 == 1) return V1; else return V2; }();
+            constexpr bool PR = acc_paired<L>(l3);      // component K in rows 16 (K % 2) .. of tile K / 2
+            auto& V = [&]() -> auto& { if constexpr (l3 == 1) return V1; else if constexpr (l3 == 2) return V2; else return V3; }();
             static_for<NR>([&]<int R>() {
+                if constexpr (pad_reg<L, NW>(l3, R)) static_for<d3>([&]<int K>() { if constexpr (l3 == 3) val3[K][R] = 0.0f; else if constexpr (l3 == 2) val2[K][R] = 0.0f; else val1[K][R] = 0.0f; });
+                else {
                 float v[d3];
                 static_for<d3>([&]<int K>() {
+                    constexpr int T = PR ? K / 2 : K, Rr = PR ? 8 * (K % 2) + R : R;
                     float x = 0.0f;
-                    if constexpr (sval_acc_used<L>(l3, 0, K)) x = V[0][K][R];
-                    if constexpr (sval_acc_used<L>(l3, 1, K)) x += cns * V[1][K][R];
+                    if constexpr (sval_acc_used<L>(l3, 0, K)) x = V[0][T][Rr];
+                    if constexpr (sval_acc_used<L>(l3, 1, K)) x += cns * V[1][T][Rr];
                     v[K] = x;
                 });
                 Rot<l3>::out(v, tg);
-                static_for<d3>([&]<int K>() { if constexpr (l3 == 1) val1[K][R] = v[K]; else val2[K][R] = v[K]; });
-                if constexpr (R == NR - 1) tok = v[0];
+                static_for<d3>([&]<int K>() { if constexpr (l3 == 1) val1[K][R] = v[K]; else if constexpr (l3 == 2) val2[K][R] = v[K]; else val3[K][R] = v[K]; });
+                if constexpr (R == NR - 4 + pad_live<L, NW>(l3) - 1) tok = v[0];
+                }
             });
         }
     };
     static_for<PDV>([&]<int I>() { load_A_of.template operator()<I>(); });
     SB vb_cur = load_B.template operator()<0>();
-    static_for<NVI + 1>([&]<int I>() {
+    // A completed degree leaves in pieces, one per pipeline region, under the GEMMs of the degree that follows it in the walk (highest degree first,
+    // the scalars last): piece 0 = read the accumulators, set0 + cns . set1, rotate back (finish_value); piece q >= 1 = the segmented reduction and
+    // the record stores of component (output tile) q - 1 (store_group).  Region R carries item R and every piece that is due: piece q of degree g
+    // in region sval_group_last(g) + 1 + q.  Only the scalars' pieces are left without GEMMs beside them (the tail).
+    constexpr auto npieces = [](int l3) { return 1 + (l3 == 0 ? 2 : 2 * l3 + 1); };
+    constexpr int NTAIL = npieces(0);
+#ifndef DEDF_SGBV_SO2
+#define DEDF_SGBV_SO2 0
+#endif
+    static_for<NVI + NTAIL>([&]<int I>() {
         // (operand requests anchored to the stream: dedf_dev.h::tie on a word of the B operand this region's MFMAs read)
         if constexpr (I < NVI) tok = __builtin_bit_cast(f32x4, vb_cur.h[0])[0];
-        lane16_t = tie(wv.lane16, tok); lane16_r16_t = tie(wv.lane16_r16, tok); lane_t = tie(wv.lane, tok);
+        if constexpr (I + PDV < NVI) { lane16_t = tie(wv.lane16, tok); lane16_r16_t = tie(wv.lane16_r16, tok); if constexpr (L == 3) lane16_r16up_t = tie(wv.lane16_r16up, tok); }
+        if constexpr (I + 1 < NVI) lane_t = tie(wv.lane, tok);
         load_A_of.template operator()<I + PDV>();
         const SB b_nxt = load_B.template operator()<I + 1>();
         sched_fence();
+#if defined(DEDF_TIMING_SO2_NOMFMA2)
+        if constexpr (I < NVI) { constexpr SItem it = sval_item<L>(I); static_for<it.na>([&]<int a>() {
+            auto& V = [&]() -> auto& { if constexpr (it.l3 == 0) return V0; else if constexpr (it.l3 == 1) return V1; else if constexpr (it.l3 == 2) return V2; else return V3; }();
+            V[it.set][it.tile[a]][0] = (it.first[a] ? 0.0f : V[it.set][it.tile[a]][0]) + vb_cur.h[it.l3 == 0 ? 0 : a][0] + vb_cur.l[it.l3 == 0 ? 0 : a][1] + aring[it.aslot[a] % RS].h[0] + aring[it.aslot[a] % RS].l[1]; }); }
+#else
         if constexpr (I < NVI) run_item.template operator()<I>(vb_cur);
-        constexpr int F = I - 1;                         // item whose group (if it ended one) is finished in this region
-        if constexpr (F >= 0) {
-            constexpr int ge = sval_item<L>(F).group_end;
-            if constexpr (ge >= 0) {
-                finish_value.template operator()<ge>();
-                if constexpr (ge < L) store_group.template operator()<ge>();
+#endif
+        static_for<L + 1>([&]<int g>() {
+            constexpr int q = I - 1 - sval_group_last<L>(g);
+            if constexpr (q >= 0 && q < npieces(g)) {
+#if defined(DEDF_TIMING_SO2_NOFIN)
+                if constexpr (q == 0) {
+                    if constexpr (g == 0) static_for<2>([&]<int T>() { val0[T][0] = V0[0][T][0] + V0[1][T][1]; });
+                    if constexpr (g == 1) static_for<3>([&]<int K>() { val1[K][0] = V1[0][K][0] + V1[1][K][1]; });
+                    if constexpr (g == 2) static_for<5>([&]<int K>() { val2[K][0] = V2[0][K][0] + V2[1][K][1]; });
+                }
+#else
+                if constexpr (q == 0) finish_value.template operator()<g>();
+                else store_group.template operator()<g, q - 1, 1>();
+#endif
             }
-        }
+        });
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (DEDF_SGBV_SO2 > 0 && I < NVI) static_for<16>([&]<int i>() { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, DEDF_SGBV_SO2, 0); });
+#endif
         sched_fence();
         vb_cur = b_nxt;
-        if constexpr (F >= 0 && sval_item<L>(F >= 0 ? F : 0).group_end == 0) DEDF_STAMP(10);
-        if constexpr (L >= 2 && F >= 0 && sval_item<L>(F >= 0 ? F : 0).group_end == 1) DEDF_STAMP(13);
+        if constexpr (I == sval_group_last<L>(L) + 1) DEDF_STAMP(10);
+        if constexpr (L >= 2 && I == sval_group_last<L>(1) + 1) DEDF_STAMP(13);
     });
     } else {
     // Software pipeline over the work items: region I requests the A slots of item I + 2 and the parked B chunks of item I + 1,
@@ -1618,7 +1684,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     });
     }
     DEDF_STAMP(14);
-    store_group.template operator()<L>();
+    if constexpr (!SO2) store_group.template operator()<L>();
     if constexpr (DBG) if (P.dbg_out != nullptr && valid && hi == 0) st4(drec_of() + D, f32x4{logit[0], logit[1], logit[2], logit[3]});
     if constexpr (MODE == 1) {
         geo.ok = e_next >= 0; geo.src = nsrc; geo.dst = ndst;

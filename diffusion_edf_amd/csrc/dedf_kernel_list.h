@@ -62,5 +62,18 @@
     X(30, void k_edge<2, 64, true, 32, 32, true, 0, true>(EdgeParams))  \
     X(31, void k_edge<3, 64, true, 32, 32, true, 0, true>(EdgeParams))  \
     X(32, void k_edge<2, 128, false, 128, 64, false, 0, false, true>(EdgeParams)) \
-    X(33, void k_edge<2, 128, false, 128, 64, false, 1, false, true>(EdgeParams))
-constexpr int kKernelUnits = 34;
+    X(33, void k_edge<2, 128, false, 128, 64, false, 1, false, true>(EdgeParams)) \
+    X(34, void k_edge<2, 128, false, 32, 32, false, 0, false, true>(EdgeParams))  \
+    X(34, void k_edge<1, 128, false, 128, 64, false, 0, false, true>(EdgeParams)) \
+    X(35, void k_edge<2, 128, false, 32, 32, false, 1, false, true>(EdgeParams))  \
+    X(35, void k_edge<1, 64, false, 128, 64, false, 0, false, true>(EdgeParams))  \
+    X(36, void k_edge<2, 192, false, 128, 64, false, 0, false, true>(EdgeParams)) \
+    X(37, void k_edge<2, 192, false, 128, 64, false, 1, false, true>(EdgeParams)) \
+    X(38, void k_edge<2, 64, false, 128, 64, false, 0, false, true>(EdgeParams))  \
+    X(39, void k_edge<2, 64, false, 32, 32, false, 0, false, true>(EdgeParams))   \
+    X(39, void k_edge<1, 128, false, 32, 32, false, 0, false, true>(EdgeParams))  \
+    X(40, void k_edge<3, 128, false, 128, 64, false, 0, false, true>(EdgeParams)) \
+    X(41, void k_edge<3, 128, false, 128, 64, false, 1, false, true>(EdgeParams)) \
+    X(42, void k_edge<3, 64, false, 128, 64, false, 0, false, true>(EdgeParams))  \
+    X(43, void k_edge<3, 64, false, 32, 32, false, 0, false, true>(EdgeParams))
+constexpr int kKernelUnits = 44;

@@ -171,7 +171,9 @@ __global__ __launch_bounds__(256) void k_time_bias(TimeParams P) {
 template <int L, bool NORM = true, bool TRUE_IN = false>
 __global__ void k_src_message(const float* __restrict__ f, int n_pts, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                               const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ msg,
-                              int v0 = 0, int v1 = 0, int v2 = 0, int v3 = 0) {
+                              int v0 = 0, int v1 = 0, int v2 = 0, int v3 = 0, float out_scale = 1.0f) {
+    // out_scale: power of two the message is stored with (score heads: EdgeOffsets::msg_scale -- the activation-side exponent of the edge kernel's
+    // B operands  w x'  rides on the message, so that the last radial layer's weight image keeps its own, weight-side scale)
     constexpr int Din = TRUE_IN ? true_feat_dim<L>() : feat_dim<L>(), Dout = feat_dim<L>();
     auto m_in = [](int l) { return TRUE_IN ? true_mul(l) : mul_of(l); };
     auto off_in = [](int l) { return TRUE_IN ? true_blk_off(l) : blk_off(l); };
@@ -219,7 +221,7 @@ __global__ void k_src_message(const float* __restrict__ f, int n_pts, const floa
             const int w = i / d, k = i % d;
             float s = (l == 0 && bias != nullptr) ? bias[w] : 0.0f;
             for (int u = 0; u < m; ++u) s += W[woff + u * m + w] * x[off + u * d + k];
-            o[blk_off(l) + (TRUE_IN ? pad_pos(l, w) : w) * d + k] = s;
+            o[blk_off(l) + (TRUE_IN ? pad_pos(l, w) : w) * d + k] = s * out_scale;
         }
         woff += m * m;
     }

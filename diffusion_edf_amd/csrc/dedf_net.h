@@ -151,23 +151,21 @@ template <int L> DEDF_HD constexpr DtpWalk<L> make_dtp_walk() {
 // B operand = per-edge weight x rotated component, no Clebsch-Gordan sum, no output-side paths.  The scalar outputs (l3 = 0) are frame
 // independent and keep the general form; ALL chunks with l3 >= 1 form one group walked by (input degree, channel range), so that a chunk of
 // source rows is rotated once and serves every path that reads it (five at l1 = 1, 2 of lmax 2).  The l3 >= 1 accumulators are live together.
+// (lmax 3: two such groups, l3 in {1, 2} and l3 = 3 -- all three degrees at once are ten paired accumulator tiles, more than the stage has
+//  registers for; the source rows are then rotated once per group.)
+template <int L> DEDF_HD constexpr int so2_num_groups() { return L >= 3 ? 3 : 2; }
+template <int L> DEDF_HD constexpr int so2_group_of(int l3) { return l3 == 0 ? 0 : (L >= 3 && l3 == 3 ? 2 : 1); }
 template <int L> DEDF_HD constexpr DtpWalk<L> make_dtp_walk_so2() {
     DtpWalk<L> w{};
     int n = 0;
-    for (int l1 = 0; l1 <= L; ++l1)
-        for (int c = 0; c < mul_of(l1) / 16; ++c)
-            for (int q = 0; q < dtp_num_paths<L>(); ++q) {
-                const PathInfo pi = dtp_path<L>(q);
-                if (pi.l3 != 0 || pi.l1 != l1) continue;
-                w.chunk[n] = pi.wstart / 16 + c; w.path[n] = pi; ++n;
-            }
-    for (int l1 = 0; l1 <= L; ++l1)
-        for (int c = 0; c < mul_of(l1) / 16; ++c)
-            for (int q = 0; q < dtp_num_paths<L>(); ++q) {
-                const PathInfo pi = dtp_path<L>(q);
-                if (pi.l3 == 0 || pi.l1 != l1) continue;
-                w.chunk[n] = pi.wstart / 16 + c; w.path[n] = pi; ++n;
-            }
+    for (int g = 0; g < so2_num_groups<L>(); ++g)
+        for (int l1 = 0; l1 <= L; ++l1)
+            for (int c = 0; c < mul_of(l1) / 16; ++c)
+                for (int q = 0; q < dtp_num_paths<L>(); ++q) {
+                    const PathInfo pi = dtp_path<L>(q);
+                    if (so2_group_of<L>(pi.l3) != g || pi.l1 != l1) continue;
+                    w.chunk[n] = pi.wstart / 16 + c; w.path[n] = pi; ++n;
+                }
     w.n = n;
     for (int i = n; i < 64; ++i) { w.chunk[i] = dtp_wn<L>() / 16; w.path[i] = PathInfo{-1, -1, -1, 0, 0, 0, 0}; }
     return w;
@@ -224,6 +222,12 @@ template <int L, bool S = false> DEDF_HD constexpr int dtp_num_slots(int nt0) { 
 // (S: one A slot per chunk as in the general form -- the path's reference coefficient kSo2Ref is folded into the slot by the host packer, the
 //  kernel multiplies the per-edge weights by the compile-time ratios of the other terms)
 template <int L> DEDF_HD constexpr float so2_ref(const PathInfo& pi) { return kSo2Ref[pi.l1][pi.l2][pi.l3]; }
+// walk position one past the end of edge-frame group g
+template <int L> DEDF_HD constexpr int so2_group_end(int g) {
+    int n = 0;
+    for (int p = 0; p < dtp_wn<L>() / 16; ++p) if (so2_group_of<L>(kDtpWalk<L, true>.path[p].l3) <= g) ++n;
+    return n;
+}
 
 // ---- second depth-wise TP (attention value) in OUTPUT-SIDE form -----------------------------------------------------------
 // value[o,k] = sum_p sum_u W2[p,u,o] sum_ij C^p_ijk u[u,i] Y[j]  is evaluated as  G^p_i[o] = sum_u W2[p,u,o] u[u,i]  (a GEMM whose
@@ -423,20 +427,29 @@ struct SItem {
     int p, c;              // path (dtp_path), K-chunk of its input block
     int l3, set;           // output degree; accumulator set (0: l2 = 0, 1: l2 >= 1)
     int na;                // MFMA triples
-    int acc[7];            // accumulator inside (l3, set): output tile (l3 = 0) / output component k
+    int acc[7];            // output component k (l3 >= 1) / output tile (l3 = 0)
+    int tile[7];           // accumulator tile inside (l3, set): acc, or acc / 2 where two components share a tile (acc_paired: 16-row outputs at lmax 3)
+    bool up[7];            // paired tiles: the component lives in rows 16-31 (the A operand is fetched by the upper half of the lanes)
     int bq[7];             // parked chunk of the B operand (park_slot)
     bool neg[7];           // the B operand enters negated
     int aslot[7];
-    bool first[7];         // first accumulation into that accumulator
+    bool first[7];         // first accumulation into that tile
     int new_slots;
     int group_end;         // output degree completed by this item, or -1
     float coef;            // what the host folds into this item's A slot(s)
 };
-template <int L> struct SValWalk { SItem item[96]; int n, n_slots; };
+// operands one item may carry (they are all in registers while the item runs): a coefficient class with more terms is split into items that
+// share its A slot
+template <int L> DEDF_HD constexpr int sval_max_ops() { return L >= 3 ? 4 : 5; }
+template <int L> struct SValWalk { SItem item[128]; int n, n_slots; };
 template <int L> DEDF_HD constexpr SValWalk<L> make_sval_walk() {
     SValWalk<L> w{};
     int n = 0, slot = 0;
-    for (int l3 = 0; l3 <= L; ++l3) {
+    // Output degrees from the highest down to the scalars: the rotation back and the segmented reduction of a completed degree (dedf_edge.h:
+    // finish_value / store_group, VALU only) run under the GEMMs of the next one, and what is left exposed at the end is the cheapest degree.
+    for (int gi = 0; gi <= L; ++gi) {
+        const int l3 = gi < L ? L - gi : 0;
+        const bool PR = l3 >= 1 && acc_paired<L>(l3);
         bool seen[2][7] = {{false, false, false, false, false, false, false}, {false, false, false, false, false, false, false}};
         for (int set = 0; set < 2; ++set)
         for (int p = 0; p < dtp_num_paths<L>(); ++p) {
@@ -448,7 +461,7 @@ template <int L> DEDF_HD constexpr SValWalk<L> make_sval_walk() {
                     SItem it{};
                     it.p = p; it.c = c; it.l3 = 0; it.set = set; it.na = val_tiles<L>(0); it.group_end = -1; it.coef = kSo2C[pi.l1][pi.l2][0][0];
                     for (int a = 0; a < it.na; ++a) {
-                        it.acc[a] = a; it.bq[a] = park_slot<L>(pi.l1, kSo2I[pi.l1][pi.l2][0][0], c); it.neg[a] = false; it.aslot[a] = slot + a;
+                        it.acc[a] = a; it.tile[a] = a; it.up[a] = false; it.bq[a] = park_slot<L>(pi.l1, kSo2I[pi.l1][pi.l2][0][0], c); it.neg[a] = false; it.aslot[a] = slot + a;
                         it.first[a] = !seen[set][a]; seen[set][a] = true;
                     }
                     it.new_slots = it.na; slot += it.na;
@@ -464,10 +477,14 @@ template <int L> DEDF_HD constexpr SValWalk<L> make_sval_walk() {
                     for (int t = t0; t < nt; ++t) {
                         const float ct = kSo2C[pi.l1][pi.l2][pi.l3][t];
                         if (done[t] || !(ct == c0 || ct == -c0)) continue;
+                        if (it.na == sval_max_ops<L>()) {      // the class goes on in another item on the same A slot
+                            w.item[n++] = it;
+                            it.na = 0; it.new_slots = 0;
+                        }
                         done[t] = true;
-                        const int a = it.na++, k = kSo2K[pi.l1][pi.l2][pi.l3][t];
-                        it.acc[a] = k; it.bq[a] = park_slot<L>(pi.l1, kSo2I[pi.l1][pi.l2][pi.l3][t], c); it.neg[a] = ct != c0; it.aslot[a] = slot;
-                        it.first[a] = !seen[set][k]; seen[set][k] = true;
+                        const int a = it.na++, k = kSo2K[pi.l1][pi.l2][pi.l3][t], tl = PR ? k / 2 : k;
+                        it.acc[a] = k; it.tile[a] = tl; it.up[a] = PR && (k % 2 == 1); it.bq[a] = park_slot<L>(pi.l1, kSo2I[pi.l1][pi.l2][pi.l3][t], c); it.neg[a] = ct != c0; it.aslot[a] = slot;
+                        it.first[a] = !seen[set][tl]; seen[set][tl] = true;
                     }
                     slot += 1;
                     w.item[n++] = it;
@@ -489,18 +506,30 @@ template <int L> DEDF_HD constexpr int sval_slot_l3(int S) {
             if (kSValWalk<L>.item[i].aslot[a] == S) return kSValWalk<L>.item[i].l3;
     return 0;
 }
+// last item of output degree l3 in the walk
+template <int L> DEDF_HD constexpr int sval_group_last(int l3) {
+    for (int i = 0; i < kSValWalk<L>.n; ++i) if (kSValWalk<L>.item[i].group_end == l3) return i;
+    return -1;
+}
 template <int L> DEDF_HD constexpr int sval_item_slot0(int I) {
     int s = 0;
     for (int i = 0; i < I && i < kSValWalk<L>.n; ++i) s += kSValWalk<L>.item[i].new_slots;
     return s;
 }
-// set `set` of output degree l3 receives anything at all / accumulator `a` of it does
+// component k (output tile for l3 = 0) of set `set` of output degree l3 receives anything at all
 template <int L> DEDF_HD constexpr bool sval_acc_used(int l3, int set, int a) {
     for (int i = 0; i < kSValWalk<L>.n; ++i) {
         const SItem& it = kSValWalk<L>.item[i];
         if (it.l3 != l3 || it.set != set) continue;
         for (int q = 0; q < it.na; ++q) if (it.acc[q] == a) return true;
     }
+    return false;
+}
+// slot S is used by an operand that lives in rows 0-15 / in rows 16-31 of a paired tile
+template <int L> DEDF_HD constexpr bool sval_slot_needs(int S, bool up) {
+    for (int i = 0; i < kSValWalk<L>.n; ++i)
+        for (int a = 0; a < kSValWalk<L>.item[i].na; ++a)
+            if (kSValWalk<L>.item[i].aslot[a] == S && kSValWalk<L>.item[i].up[a] == up) return true;
     return false;
 }
 
@@ -609,7 +638,12 @@ template <int L> DEDF_HD constexpr NodeLayout<L> make_node_layout() {
 
 // accumulator -> true value of the node kernel's split-fp16 GEMMs (each weight matrix carries its own power-of-two scale,
 // the B operands a fixed 2^kNodeBShift; dedf_pack.h::pack_node)
-struct NodeScales { float proj[4], f1[4], f2[4], s[2][16], sl[2][2]; };
+struct NodeScales {
+    float proj[4], f1[4], f2[4], s[2][16], sl[2][2];
+    // B-operand multipliers (powers of two) per stage, chosen per handle from the weights (dedf_pack.h::act_exponent): aggregate z -> proj,
+    // normalised features -> fctp_1, hidden features of degree l -> fctp_2, field -> score TPs, contracted TP outputs -> final LinearRS
+    float bz, bn, bh[4], bf, bt[2];
+};
 // floats per pose record: raw q [0:4], D^1 [4:13], D^2 [16:41], D^3 [48:97]
 template <int L> DEDF_HD constexpr int pose_rec() { return L >= 3 ? 112 : 64; }
 constexpr int kNodeBShift = 5;      // activation-side operand: typical magnitude 2^5 (dedf_pack.h::kActHeadroomBits)

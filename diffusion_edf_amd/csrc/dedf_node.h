@@ -49,8 +49,7 @@ template <int L> struct Feat {                 // one node's features in row lay
 };
 // the same features as split-fp16 B operands: chunks of 16 channels (8 registers of a row-layout tile), scaled by 2^kNodeBShift
 template <int L> struct FeatH { HL s[4], v1[3][2], v2[5][1], v3[7][1]; };
-template <int L> DEDF_DEV FeatH<L> split_feat(const Feat<L>& f) {
-    constexpr float sc = (float)(1 << kNodeBShift);
+template <int L> DEDF_DEV FeatH<L> split_feat(const Feat<L>& f, const float sc) {
     FeatH<L> o;
     static_for<4>([&]<int c>() { float t[8]; static_for<8>([&]<int J>() { t[J] = f.s[c / 2][8 * (c % 2) + J]; }); o.s[c] = split8(t, sc); });
     if constexpr (L >= 1) static_for<3>([&]<int m>() { static_for<2>([&]<int c>() {
@@ -170,7 +169,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     // ---- proj: per-l dense matrix (+ bias on 0e); all GEMMs of this kernel are 3-term split-fp16 MFMA products -----------------
     Feat<L> emb;
     {
-        const FeatH<L> zh = split_feat<L>(z);
+        const FeatH<L> zh = split_feat<L>(z, opaque_s(P.sc.bz));
         f32x16 a0[2];
         static_for<2>([&]<int To>() { a0[To] = node_ldrows(rows, hi, NR::b_proj0, To); });
         dense_rot_hp<2, 4, 2, HP>(wv, O.A_proj[0], O.A_proj_l[0], a0, [&]<int c>() { return zh.s[c]; });
@@ -244,14 +243,13 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
     // ---- FFN: FCTP+SwishGate (D -> 336x0e+96x1e+48x2e) -> Gate -> FCTP (-> D), + residual (gnn_block.py:51-57, 210-216) ----
     Feat<L> fld;
     constexpr int NF1 = f1_rows0<L>() / 32 + (f1_rows0<L>() % 32 ? 1 : 0);     // 11 (L=2) / 9 (L=1) tiles of fctp_1's 0e rows
-    constexpr float kBS = (float)(1 << kNodeBShift);
     // split-fp16 B operands that are reused by several GEMMs are parked in LDS (this wave's 30 KB, slot = one h8 per lane):
     // first the normalised features (FFN), later the field (score tensor products); the registers go to the accumulators
     constexpr int FS1 = 8, FS2 = FS1 + 12, FS3 = FS2 + 10;
     __shared__ f32x4 fpark[(L >= 3 ? FS3 + 14 : FS2 + 10) * 64];
     f32x4* const fp = fpark + wv.lane;
-    auto park = [&](const Feat<L>& f) {
-        const FeatH<L> fh = split_feat<L>(f);
+    auto park = [&](const Feat<L>& f, const float bscale) {
+        const FeatH<L> fh = split_feat<L>(f, bscale);
         static_for<4>([&]<int c>() { fp[(2 * c) * 64] = __builtin_bit_cast(f32x4, fh.s[c].hi); fp[(2 * c + 1) * 64] = __builtin_bit_cast(f32x4, fh.s[c].lo); });
         if constexpr (L >= 1) static_for<3>([&]<int m>() { static_for<2>([&]<int c>() {
             fp[(FS1 + 4 * m + 2 * c) * 64] = __builtin_bit_cast(f32x4, fh.v1[m][c].hi);
@@ -273,7 +271,9 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         b.lo = __builtin_bit_cast(h8, fp[(slot + 1) * 64]);
         return b;
     };
-    park(nrm);
+    park(nrm, opaque_s(P.sc.bn));
+    const float bh0 = opaque_s(P.sc.bh[0]), bh1 = opaque_s(P.sc.bh[L >= 1 ? 1 : 0]), bh2 = opaque_s(P.sc.bh[L >= 2 ? 2 : 0]), bh3 = opaque_s(P.sc.bh[L >= 3 ? 3 : 0]);
+    (void)bh1; (void)bh2; (void)bh3;
     {   // l = 0: 192 hidden scalars (6 tiles) -> SiLU -> fctp_2
         f32x16 hs[6];
         static_for<6>([&]<int To>() { hs[To] = node_ldrows(rows, hi, NR::b_f1, To); });
@@ -285,7 +285,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         dense_rot_hp<2, 12, 2, HP>(wv, O.A_f2[0], O.A_f2_l[0], o0, [&]<int c>() {
             float t[8];
             static_for<8>([&]<int J>() { t[J] = hs[c / 2][8 * (c % 2) + J]; });
-            return split8(t, kBS);
+            return split8(t, bh0);
         });
         const float c2 = opaque_s(P.sc.f2[0]);
         static_for<2>([&]<int T>() { static_for<16>([&]<int R>() { fld.s[T][R] = o0[T][R] * c2 + emb.s[T][R]; }); });
@@ -312,7 +312,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         dense_shared_hp<3, 6, 2, HP>(wv, O.A_f2[1], O.A_f2_l[1], 6, 0, o, [&]<int m, int c>() {
             float t[8];
             static_for<8>([&]<int J>() { t[J] = hh[c / 2][m][8 * (c % 2) + J]; });
-            return split8(t, kBS);
+            return split8(t, bh1);
         });
         const float c2 = opaque_s(P.sc.f2[1]);
         static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { fld.v1[m][R] = o[m][R] * c2 + emb.v1[m][R]; }); });
@@ -330,7 +330,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         dense_shared_hp<5, 3, 2, HP>(wv, O.A_f2[2], O.A_f2_l[2], 3, 0, o, [&]<int m, int c>() {
             float t[8];
             static_for<8>([&]<int J>() { t[J] = hh[c / 2][m][8 * (c % 2) + J]; });
-            return split8(t, kBS);
+            return split8(t, bh2);
         });
         const float c2 = opaque_s(P.sc.f2[2]);
         static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { fld.v2[m][R] = o[m][R] * c2 + emb.v2[m][R]; }); });
@@ -348,7 +348,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         dense_shared_hp<7, 2, 2, HP>(wv, O.A_f2[3], O.A_f2_l[3], 2, 0, o, [&]<int m, int c>() {
             float t[8];
             static_for<8>([&]<int J>() { t[J] = hh[m][8 * c + J]; });
-            return split8(t, kBS);
+            return split8(t, bh3);
         });
         const float c2 = opaque_s(P.sc.f2[3]);
         static_for<7>([&]<int m>() { static_for<8>([&]<int R>() { fld.v3[m][R] = o[m][R] * c2 + emb.v3[m][R]; }); });
@@ -440,7 +440,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         return;
     }
     float res[2][3];                         // per TP: mean over the 32 gated 1e channels
-    park(fld);                               // the field as B operands, shared by every path of both tensor products
+    park(fld, opaque_s(P.sc.bf));            // the field as B operands, shared by every path of both tensor products
     static_for<2>([&]<int tp>() {
         f32x16 gacc = node_ldrows(rows, hi, tp == 0 ? NR::b_sl0 : NR::b_sl1, 0);
         f32x16 vacc[3];
@@ -487,7 +487,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
             constexpr int NCK = pi.mul2 / 16;             // K chunks over v
             constexpr int NCL = stp_k<L>(l3) / 16;        // chunks per row tile of the final LinearRS image
             using C = CG<l1, l2, l3>;
-            const float bsc = opaque_s(P.sc.s[tp][p]) * kBS;      // T accumulators -> true value, times the B-operand scale of stage 2
+            const float bsc = opaque_s(P.sc.s[tp][p]) * opaque_s(P.sc.bt[tp]);      // T accumulators -> true value, times the B-operand scale of stage 2
             static_for<cdiv(pi.mul1, 32)>([&]<int To>() {
                 constexpr int NC2 = imin(2, (pi.mul1 - 32 * To) / 16);      // 16-channel chunks of this row tile
                 // operands of the final LinearRS for this tile's chunks, requested before the first-stage GEMM

@@ -273,6 +273,9 @@ struct EdgeOffsets {
     float w_unscale;        // layer-3 output (per-edge TP weights) carries 2^s3; this is 2^-s3
     float u_scale;          // the gated features are parked as 2^su * u
     float c_lin[4], c_val[4];   // accumulator -> true value of the lin / value GEMMs, per output degree
+    float est_value;            // typical magnitude of the attention value (= of the aggregate z the node kernel reads), estimated from the weights
+    int s3, su;                 // the two activation-side exponents chosen for this handle (tests: DEDF_SCALE_DEBUG)
+    float msg_scale;            // power of two the source message is stored with (k_src_message): s3 = exponent of the weight image + log2(msg_scale)
 };
 struct NodeOffsets {
     int o_A_proj[4], o_b_proj0, o_ln_w[4], o_ln_b0, o_A_f1[4], o_b_f1, o_A_f2[4], o_b_f2;
@@ -287,6 +290,25 @@ struct NodeOffsets {
 // magnitude is placed near the geometric middle of that window (~2^5 ... 2^7: a factor ~1000 of headroom either way) instead of
 // the ~2^9 the weight images use.  kActHeadroomBits = how far below the weight-side target 2^8..2^9.
 constexpr int kActHeadroomBits = 3;
+// Round 5: the activation-side exponents are no longer constants.  Every activation that becomes a B operand sits behind a LayerNorm or is a
+// (bounded) function of one, times weights: its typical magnitude follows from the WEIGHTS of the handle -- rms row norms propagated from the
+// normalised inputs through the block (act_exponent below) --, so the exponent of every such operand is chosen at pack time to put the typical
+// value at 2^kActTarget = 8: x8 000 below the fp16 maximum, and an absolute rounding error of 2^-25 (the fp16 subnormal step of the residual half)
+// stays 2^-28 of the typical value.  A checkpoint whose edge linears are 100x larger than random init gets exponents 7 bits lower and the same
+// relative accuracy (tests/test_gpu_parity.py::test_fp16_operand_range_scaled_weights_and_features).  What stays data is the caller's features:
+// key features pass a LayerNorm first; the query features enter the score tensor products with x8 000 of room.
+constexpr int kActTarget = 3;
+inline int act_exponent(float typical, int lo = -40, int hi = 12) {
+    if (!(typical > 0.0f) || !std::isfinite(typical)) return 0;
+    const int e = kActTarget - (int)std::ceil(std::log2(typical));
+    return e < lo ? lo : (e > hi ? hi : e);
+}
+// rms over the rows of  sqrt(sum_k W(o, k)^2)
+template <class WAt> inline float rms_row_norm(int O, int K, WAt W) {
+    double acc = 0.0;
+    for (int o = 0; o < O; ++o) for (int k = 0; k < K; ++k) { const double w = W(o, k); acc += w * w; }
+    return O > 0 ? (float)std::sqrt(acc / O) : 0.0f;
+}
 inline float softplusf(float x) { return x > 20.0f ? x : std::log1p(std::exp(x)); }
 // exponent s such that 2^s * maxabs lands in [256, 512]: typical elements are then O(10..100), their fp16 residuals (2^-11 of
 // that) stay normal fp16 numbers, and the largest element is far from the fp16 maximum.  Scaling by 2^s is exact.
@@ -451,6 +473,7 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
     }
     auto rows = [&](int O, const float* v) { return pack_rows(O, [&](int i) { return v[i]; }); };
     int s3 = 0;
+    float est_we = 1.0f, est_msg = 0.0f;      // typical per-edge TP weight / source-message component (score heads; a UNet layer's features are not normalised: constants)
     const int H1 = c.fc_neurons[1], H2 = c.fc_neurons[2];      // hidden widths of the radial MLP: 128, 64 or 32, 32
     {
         std::vector<float> ih, il;
@@ -478,11 +501,41 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
         for (int i = 0; i < dtp_wn<L>() * H2; ++i) m3 = std::fmax(m3, std::fabs(W3[i]));
         for (int i = 0; i < dtp_wn<L>(); ++i) m3 = std::fmax(m3, std::fabs(off3[i]));
         s3 = pow2_scale(m3, -16, 8 + kActHeadroomBits) - kActHeadroomBits;
-        const float f3 = std::ldexp(1.0f, s3);
+        int s3img = s3;
+        o.msg_scale = 1.0f;
+        if (!un) {
+            // typical per-edge TP weight x typical source-message component (both follow from weights behind a LayerNorm) -> exponent of the
+            // B operands  w . x'  of the lin / sep_alpha GEMMs; never above what keeps the weight image itself in range
+            const float* g2 = S.get(B, rad + "net.4.weight"); const float* be2 = S.get(B, rad + "net.4.bias");
+            double q2 = 0.0;
+            for (int hh = 0; hh < H2; ++hh) q2 += (double)g2[hh] * g2[hh] + (double)be2[hh] * be2[hh];
+            q2 /= H2;
+            double acc = 0.0;
+            for (int r = 0; r < dtp_wn<L>(); ++r) { double rn = 0.0; for (int k = 0; k < H2; ++k) rn += (double)W3[r * H2 + k] * W3[r * H2 + k]; acc += rn * q2 + (double)off3[r] * off3[r]; }
+            est_we = (float)std::sqrt(acc / dtp_wn<L>());
+            const float* ws = S.get(B, blk + ".linear_src.tp.weight"); const float* aw = S.get(B, blk + ".prenorm_src.affine_weight");
+            const float* ab = S.get(B, blk + ".prenorm_src.affine_bias"); const float* bs = S.get(B, blk + ".linear_src.bias.0");
+            size_t wo = 0; int ao = 0;
+            for (int l = 0; l <= L; ++l) {
+                const int m = mul_of(l);
+                double a2 = 0.0;
+                for (int w = 0; w < m; ++w) for (int u = 0; u < m; ++u) { const double in2 = (double)aw[ao + u] * aw[ao + u] + (l == 0 ? (double)ab[u] * ab[u] : 0.0); a2 += (double)ws[wo + (size_t)u * m + w] * ws[wo + (size_t)u * m + w] * in2; }
+                if (l == 0) for (int w = 0; w < m; ++w) a2 += (double)bs[w] * bs[w];
+                est_msg = std::fmax(est_msg, (float)std::sqrt(a2 / m));
+                wo += (size_t)m * m; ao += m;
+            }
+            // (the exponent of the product is split: the weight image keeps the weight-side scale -- largest entry in [256, 512] like every A operand --,
+            //  the rest rides on the stored message: a 1000x larger linear_src must not push the layer-3 weights into the fp16 subnormals)
+            const int eB = act_exponent(est_we * est_msg * 2.3f);
+            s3img = pow2_scale(m3, -16, 20);
+            o.msg_scale = std::ldexp(1.0f, eB - s3img);
+            s3 = eB;
+        }
+        const float f3 = std::ldexp(1.0f, s3img);
         pack_A_h(dtp_wn<L>(), H2 / 16, [&](int oo, int k) { return W3[dtp_walk_row<L, SO2>(oo) * H2 + k] * f3; }, [&](int cc, int j, int h) { return chain_k(H2, cc, j, h); }, ih, il);
         o.o_A_r3 = im.push(ih); o.o_A_r3_l = im.push(il);
         o.o_off_r3 = im.push(pack_rows(dtp_wn<L>(), [&](int i) { return off3[dtp_walk_row<L, SO2>(i)] * f3; }));
-        o.w_unscale = std::ldexp(1.0f, -s3);
+        o.w_unscale = std::ldexp(1.0f, -s3img);
     }
     {   // sep_act.lin (+ sep_alpha on the l3 = 0 K-steps) and sep_value.lin (shared DTP weights folded in)
         const float* lw = S.get(B, ga + ".sep_act.lin.tp.weight");
@@ -524,7 +577,19 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
             if (SO2) { const PathInfo pi = path_of(l, k); m = 0.0f; for (int t = 0; t < kSo2NT[pi.l1][pi.l2][pi.l3]; ++t) m = std::fmax(m, std::fabs(kSo2C[pi.l1][pi.l2][pi.l3][t])); }
             return m;
         };
-        const int su = 8 - kActHeadroomBits;
+        int su = 8 - kActHeadroomBits;
+        o.est_value = 1.0f;
+        if (!un) {
+            // gated features u' = Gate(lin(w x')): typical magnitude from the rms row norms of lin; the value from those of the value linear
+            float eu = 0.0f;
+            const float eb = est_we * est_msg * (SO2 ? 1.0f : 1.5f);      // (edge frame: the path coefficient rides on lin_w already)
+            for (int l = 0; l <= L; ++l) eu = std::fmax(eu, 1.85f * eb * rms_row_norm(l == 0 ? O0 : mul_of(l), dtp_k<L>(l), [&](int oo, int k) { return lin_w(l, oo, k); }));
+            su = act_exponent(eu);
+            float ev = 0.0f;
+            for (int l = 0; l <= L; ++l) ev = std::fmax(ev, eu * rms_row_norm(mul_of(l), dtp_k<L>(l), [&](int oo, int k) { return val_w(l, oo, k) * so2_cmax(l, k); }));
+            o.est_value = ev;
+        }
+        o.s3 = s3; o.su = su;
         int sl[4] = {0, 0, 0, 0}, sv[4] = {0, 0, 0, 0};
         for (int l = 0; l <= L; ++l) {
             float ml = 0.0f, mv = 0.0f;
@@ -558,8 +623,9 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
     }
 }
 
+// est_z: typical magnitude of the aggregate the kernel reads (EdgeOffsets::est_value); <= 0: unknown (UNet layers) -> the fixed 2^kNodeBShift
 template <int L>
-inline void pack_node(const dedf_config& c, const ParamSpec& S, const float* B, Image& im, NodeOffsets& o) {
+inline void pack_node(const dedf_config& c, const ParamSpec& S, const float* B, Image& im, NodeOffsets& o, float est_z = 0.0f) {
     // Every GEMM of the node kernel runs on split-fp16 MFMAs: hi / lo images (dedf_layout.h::pack_A_h), each matrix scaled by
     // its own power of two (pow2_scale); biases carry the matrix scale times the fixed B-operand scale 2^kNodeBShift.
     const bool un = c.unet_layer != 0;
@@ -580,6 +646,30 @@ inline void pack_node(const dedf_config& c, const ParamSpec& S, const float* B, 
     };
     int s_proj0 = 0, s_f10 = 0, s_f20 = 0;
     size_t po = 0, lo = 0, f1o = 0, f2o = 0;
+    // B-operand exponents per stage from the weights (act_exponent): typical magnitudes propagated from the aggregate through proj, the LayerNorm
+    // (which resets the scale to its affine weights), the two FFN layers and the first stage of the score tensor products
+    const bool adaptive = !un && est_z > 0.0f;
+    int ez = kNodeBShift, en = kNodeBShift, eh[4] = {kNodeBShift, kNodeBShift, kNodeBShift, kNodeBShift}, ef = kNodeBShift, et[2] = {kNodeBShift, kNodeBShift};
+    float est_fld = 0.0f;
+    if (adaptive) {
+        ez = act_exponent(est_z);
+        const float* lnb = S.get(B, post + ".affine_bias");
+        double n2 = 0.0; int nn = 0;
+        for (int l = 0, q = 0; l <= L; ++l) for (int i = 0; i < mul_of(l); ++i, ++q) { n2 += (double)lnw[q] * lnw[q] + (l == 0 ? (double)lnb[i] * lnb[i] : 0.0); ++nn; }
+        const float est_n = (float)std::sqrt(n2 / nn);
+        en = act_exponent(est_n);
+        size_t po_ = 0, f1_ = 0, f2_ = 0;
+        for (int l = 0; l <= L; ++l) {
+            const int m = mul_of(l), O1 = (l == 0 ? f1_rows0<L>() : hid_of(l)), Kh = hid_of(l);
+            const float *Wp_ = pw + po_, *W1_ = f1w + f1_, *W2_ = f2w + f2_;
+            const float est_emb = est_z * rms_row_norm(m, m, [&](int oo, int k) { return Wp_[k * m + oo]; });
+            const float est_h = 1.85f * est_n * rms_row_norm(l == 0 ? hid_of(0) : O1, m, [&](int oo, int k) { return W1_[k * O1 + oo]; });
+            eh[l] = act_exponent(est_h);
+            est_fld = std::fmax(est_fld, est_emb + est_h * rms_row_norm(m, Kh, [&](int oo, int k) { return W2_[k * m + oo]; }));
+            po_ += (size_t)m * m; f1_ += (size_t)m * O1; f2_ += (size_t)Kh * m;
+        }
+        ef = act_exponent(est_fld);
+    }
     for (int l = 0; l <= L; ++l) {
         const int m = mul_of(l), O1 = (l == 0 ? f1_rows0<L>() : hid_of(l)), Kh = hid_of(l);
         const float* Wp = pw + po;
@@ -589,26 +679,35 @@ inline void pack_node(const dedf_config& c, const ParamSpec& S, const float* B, 
         const int s1 = push_h(O1, m, [&](int oo, int k) { return W1[k * O1 + oo]; }, o.o_A_f1[l], o.o_A_f1_l[l]);
         const float* W2 = f2w + f2o;
         const int s2 = push_h(m, Kh, [&](int oo, int k) { return W2[k * m + oo]; }, o.o_A_f2[l], o.o_A_f2_l[l]);
-        o.sc.proj[l] = std::ldexp(1.0f, -(sp + kNodeBShift));
-        o.sc.f1[l] = std::ldexp(1.0f, -(s1 + kNodeBShift));
-        o.sc.f2[l] = std::ldexp(1.0f, -(s2 + kNodeBShift));
+        o.sc.proj[l] = std::ldexp(1.0f, -(sp + ez));
+        o.sc.f1[l] = std::ldexp(1.0f, -(s1 + en));
+        o.sc.f2[l] = std::ldexp(1.0f, -(s2 + eh[l]));
         if (l == 0) { s_proj0 = sp; s_f10 = s1; s_f20 = s2; }
         po += (size_t)m * m; lo += m; f1o += (size_t)m * O1; f2o += (size_t)Kh * m;
     }
     auto rows_s = [&](int O, const float* v, int sh) { return pack_rows(O, [&](int i) { return std::ldexp(v[i], sh); }); };
-    o.o_b_proj0 = im.push(rows_s(mul_of(0), S.get(B, ga + ".proj.bias.0"), s_proj0 + kNodeBShift));
+    o.o_b_proj0 = im.push(rows_s(mul_of(0), S.get(B, ga + ".proj.bias.0"), s_proj0 + ez));
     o.o_ln_b0 = im.push(rows_s(mul_of(0), S.get(B, post + ".affine_bias"), 0));
-    o.o_b_f1 = im.push(rows_s(f1_rows0<L>(), S.get(B, blk + ".ffn.fctp_1.bias.0"), s_f10 + kNodeBShift));
-    o.o_b_f2 = im.push(rows_s(mul_of(0), S.get(B, blk + ".ffn.fctp_2.bias.0"), s_f20 + kNodeBShift));
+    o.o_b_f1 = im.push(rows_s(f1_rows0<L>(), S.get(B, blk + ".ffn.fctp_1.bias.0"), s_f10 + en));
+    o.o_b_f2 = im.push(rows_s(mul_of(0), S.get(B, blk + ".ffn.fctp_2.bias.0"), s_f20 + eh[0]));
     int tp = 0;
     if (!c.ebm && !un) for (const char* nm : {"lin_vel_tp", "ang_vel_tp"}) {
         const std::string p = std::string(nm);
         const float* dw = S.get(B, p + ".dtp.tp.weight");
+        if (adaptive) {      // contracted first-stage outputs (x the rotated query features, taken as O(1): they are the caller's data)
+            float est_t = 0.0f;
+            for (int q = 0; q < stp_num_paths<L>(); ++q) {
+                const PathInfo pi = stp_path<L>(q);
+                const float* W = dw + pi.wstart;
+                est_t = std::fmax(est_t, 1.5f * est_fld * rms_row_norm(pi.mul1, pi.mul2, [&](int u, int v) { return W[u * pi.mul2 + v]; }));
+            }
+            et[tp] = act_exponent(est_t);
+        }
         for (int q = 0; q < stp_num_paths<L>(); ++q) {
             const PathInfo pi = stp_path<L>(q);
             const float* W = dw + pi.wstart;
             const int sh = push_h(pi.mul1, pi.mul2, [&](int u, int v) { return W[u * pi.mul2 + v]; }, o.o_A_s[tp][q], o.o_A_s_l[tp][q]);
-            o.sc.s[tp][q] = std::ldexp(1.0f, -(sh + kNodeBShift));
+            o.sc.s[tp][q] = std::ldexp(1.0f, -(sh + ef));
         }
         // final LinearRS: K walks the 16-channel chunks of the TP output (stp_chunk_index), rows = the 32 gates (l3 = 0) / 32 1e channels
         const float* lw = S.get(B, p + ".lin.tp.weight");
@@ -629,12 +728,15 @@ inline void pack_node(const dedf_config& c, const ParamSpec& S, const float* B, 
             pack_A_h(n1, (int)base.size(), [&](int oo, int k) { return std::ldexp(Wat(oo, k), shl[l3]); },
                      [&](int cc, int j, int h) { return base[cc] + chunk_row(8 * h + j); }, ih, il);
             o.o_A_sl[tp][l3] = im.push(ih); o.o_A_sl_l[tp][l3] = im.push(il);
-            o.sc.sl[tp][l3] = std::ldexp(1.0f, -(shl[l3] + kNodeBShift));
+            o.sc.sl[tp][l3] = std::ldexp(1.0f, -(shl[l3] + et[tp]));
         }
         const float* lb = S.get(B, p + ".lin.bias.0");
-        o.o_b_sl[tp] = im.push(pack_rows(n1, [&](int i) { return std::ldexp(lb[1 + i], shl[0] + kNodeBShift); }));
+        o.o_b_sl[tp] = im.push(pack_rows(n1, [&](int i) { return std::ldexp(lb[1 + i], shl[0] + et[tp]); }));
         ++tp;
     }
+    o.sc.bz = std::ldexp(1.0f, ez); o.sc.bn = std::ldexp(1.0f, en); o.sc.bf = std::ldexp(1.0f, ef);
+    for (int l = 0; l < 4; ++l) o.sc.bh[l] = std::ldexp(1.0f, eh[l]);
+    o.sc.bt[0] = std::ldexp(1.0f, et[0]); o.sc.bt[1] = std::ldexp(1.0f, et[1]);
     // the kernel addresses the image through the compile-time layout: it must be what was just built
     constexpr NodeLayout<L> nl = kNodeLayout<L>;
     bool same = o.o_b_proj0 == nl.b_proj0 && o.o_ln_b0 == nl.ln_b0 && o.o_b_f1 == nl.b_f1 && o.o_b_f2 == nl.b_f2;

@@ -34,7 +34,8 @@ inline std::vector<float> halves_to_floats(const std::vector<uint16_t>& h) {
 }
 
 template <int L>
-inline void pack_edge16(const dedf_config& c, const ParamSpec& S, const float* B, Image& im, Edge16Offsets& o) {
+inline void pack_edge16(const dedf_config& c, const ParamSpec& S, const float* B, Image& im, Edge16Offsets& o, int msg_exp = 0) {
+    // msg_exp: log2 of the power of two the source message is stored with (EdgeOffsets::msg_scale): the lin accumulators carry it
     o.ok = false;
     if (c.unet_layer || c.half_gemm || c.fc_neurons[2] != 64) return;          // instantiated for the score heads with the [., 128, 64] radial MLP
     const std::string ga = "key_tensor_field.gnn_block_init.ga", rad = ga + ".sep_act.dtp_rad.";
@@ -98,7 +99,7 @@ inline void pack_edge16(const dedf_config& c, const ParamSpec& S, const float* B
             for (int oo = 0; oo < mul_of(l); ++oo) mv = std::fmax(mv, std::fabs(val_w(l, oo, k)));
         }
         sl[l] = pow2_scale(ml, 0, 20); sv[l] = pow2_scale(mv, 0, 20);
-        o.c_lin[l] = std::ldexp(1.0f, -(sl[l] + s3));
+        o.c_lin[l] = std::ldexp(1.0f, -(sl[l] + s3 + msg_exp));
         o.c_val[l] = std::ldexp(1.0f, -(sv[l] + su));
     }
     o.u_scale = std::ldexp(1.0f, su);
@@ -122,7 +123,7 @@ inline void pack_edge16(const dedf_config& c, const ParamSpec& S, const float* B
         o.o_S_lin = im.push(img);
         const float* lb = S.get(B, ga + ".sep_act.lin.bias.0");
         const float* ab = S.get(B, ga + ".sep_alpha.bias.0");
-        const float f0 = std::ldexp(1.0f, sl[0] + s3);
+        const float f0 = std::ldexp(1.0f, sl[0] + s3 + msg_exp);
         std::vector<float> b0(lin0_tiles16<L>() * 16);
         for (int i = 0; i < (int)b0.size(); ++i) b0[i] = (i < O0 ? lb[i] : ab[i - O0]) * f0;
         o.o_b0 = im.push(b0);

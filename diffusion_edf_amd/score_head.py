@@ -269,6 +269,7 @@ class ScoreModelHead(torch.nn.Module):
         _lib.raise_for(lib, self._handle, rc, "dedf_get_stats")
         return dict(n_dst=st.n_dst, n_edges=[st.n_edges[i] for i in range(self.n_scales)], n_edges_total=st.n_edges_total,
                     overflow=bool(st.overflow), nonfinite=bool(st.nonfinite),
+                    sample_retries=int(st.sample_retries), edges_per_dst_capacity=int(st.edges_per_dst_capacity),
                     # accuracy guard of the sampler's radial table: largest interpolation error per scale, scales that fell back to per-edge
                     rtab_err=[float(st.rtab_err[i]) for i in range(self.n_scales)],
                     rtab_fallback=[bool(st.rtab_fallback >> i & 1) for i in range(self.n_scales)])

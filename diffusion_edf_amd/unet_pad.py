@@ -6,7 +6,9 @@ layer is linear per channel, a gate / activation that maps 0 to 0, a LayerNorm, 
 EXACTLY a wide layer whose extra channels carry zeros, provided that
 
 * the true channels are placed so that the kernel's head assignment (head = channel // (mul / 4)) equals the reference's
-  (head = channel // (true_mul / 4)): channel c goes to ``(c // (m/4)) * (M/4) + c % (m/4)`` (``place``);
+  (head = channel // (true_mul / 4)) AND every group of four wide channels holds the same number of true ones (the lmax-3 and the narrow
+  instantiations of the kernels skip the lane-local work on the others): channel c goes to ``head * (M/4) + 4 * (k // q) + k % q`` with
+  ``k = c % (m/4)``, ``q = 4 m / M`` (``place``; half-filled blocks 0, 1, 4, 5, ..., quarter-filled 0, 4, 8, ...);
 * every weight touching a padded channel is zero (this module builds those parameter tensors, same names as the wide schema);
 * the LayerNorms take their statistics over the true channels only (told to the kernels: ``dedf_config.unet_valid / unet_fc_valid``);
 * the radial basis is normalised by sqrt(true num_basis).
@@ -48,7 +50,9 @@ def place(m: int, M: int) -> torch.Tensor:
     if m == M:
         return c
     q = 4 * m // M
-    assert m % HEADS == 0 and M % (4 * HEADS) == 0 and q in (1, 2) and 4 * m == q * M, (m, M)
+    if not (m % HEADS == 0 and M % (4 * HEADS) == 0 and q in (1, 2) and 4 * m == q * M):
+        raise ValueError(f"unet_pad.place: a block of {m} true channels cannot be embedded in {M} kernel channels; supported: m == M, m == M / 2, m == M / 4 "
+                         f"(with m a multiple of {HEADS} and M of {4 * HEADS})")
     k = c % (m // HEADS)
     return (c // (m // HEADS)) * (M // HEADS) + 4 * (k // q) + k % q
 

@@ -94,7 +94,10 @@ typedef struct dedf_config {
                                             configs/panda_mug/pick_lowres/score_model_configs.yaml:33-55) with every true channel c of a block of m in M kernel
                                             channels at head * (M / 4) + 4 * (k / q) + k % q, k = c % (m / 4), q = 4 m / M (diffusion_edf_amd/unet_pad.py::place):
                                             the narrow instantiations of the layer kernels skip the lane-local work on the structurally zero channels.
-                                            Requires unet_valid = {32, 16, 8 (, 4)}.  0: any zero-padded embedding (the padding is computed like data) */
+                                            Requires unet_valid = {32, 16, 8 (, 4)}.  0: any zero-padded embedding whose padded channels are exact zeros (the
+                                            padding is computed like data) -- EXCEPT the l = 3 block of an lmax-3 layer: every lmax-3 kernel skips the channels
+                                            p with p % 4 >= 2 of the 16x3e block, so the (at most 8) true 3e channels MUST sit at the positions of
+                                            unet_pad.py::place (8x3e: 0, 1, 4, 5, 8, 9, 12, 13; 4x3e: 0, 4, 8, 12) whatever this flag says */
 } dedf_config;
 
 typedef struct dedf_schedule {           /* host arrays, one entry per denoising step (score_model_base.py:146-171) */
@@ -118,6 +121,11 @@ typedef struct dedf_stats {
                                             call's first, middle and last diffusion time */
     int rtab_fallback;                   /* bit n set: scale n exceeded its bound (finite scales 1e-5, DEDF_RADIAL_TABLE_BOUND; all-pairs scale 2.4e-4, see
                                             dedf_set_radial_table) and evaluated its front per edge */
+    int sample_retries;                  /* ABI 5: how often the last dedf_sample call was repeated with a doubled automatic edge workspace (0-3); a
+                                            2-4x longer call is visible here */
+    int edges_per_dst_capacity;          /* ABI 5: edges per destination node the automatic workspace is sized for after that (96 or more); grown by
+                                            dedf_sample's repeats, kept for later calls on the same scene, reset by dedf_set_key_clouds, put back to its
+                                            value before the call when every repeat failed.  0 with an explicit dedf_config.max_edges */
 } dedf_stats;
 
 const char* dedf_version(void);
@@ -127,8 +135,9 @@ const char* dedf_version(void);
  * memory.  dedf_abi_version() is what the LOADED library was built with; dedf_struct_size(which) gives its sizeof of the struct
  * dedf_config [which = 0], dedf_schedule [1], dedf_stats [2], dedf_profile [3] for bindings that mirror the structs by hand (diffusion_edf_amd/_lib.py checks both).
  *   1  rounds 1-2.   2  round 3: dedf_config.unet_valid[4] (was [3]), dedf_stats.rtab_err / rtab_fallback, dedf_radius scratch arguments.
- *   3  round 4: dedf_abi_version / dedf_struct_size themselves; no struct change.   4  round 4: dedf_config.unet_narrow (appended). */
-#define DEDF_ABI_VERSION 4
+ *   3  round 4: dedf_abi_version / dedf_struct_size themselves; no struct change.   4  round 4: dedf_config.unet_narrow (appended).
+ *   5  round 5: dedf_stats.sample_retries / edges_per_dst_capacity (appended). */
+#define DEDF_ABI_VERSION 5
 int dedf_abi_version(void);
 size_t dedf_struct_size(int which);
 

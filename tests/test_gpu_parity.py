@@ -1063,13 +1063,16 @@ _RANGE_GROUPS = {
 }
 
 
-@pytest.mark.parametrize("factor", [30.0, 100.0])
+@pytest.mark.parametrize("factor", [30.0, 100.0, 1000.0, 0.01])
 @pytest.mark.parametrize("group", list(_RANGE_GROUPS) + ['all_of_them'])
 def test_fp16_operand_range_scaled_weights_and_features(group, factor):
-    """GEMM operands are fp16 hi + fp16 lo with power-of-two pre-scaling chosen for O(1) activations.  A trained
-    checkpoint may carry weights / features tens of times larger than random init.  Contract: with a group of weights or features
-    scaled x30 / x100 the result is EITHER within the 1e-4 tolerance of the fp64 oracle (same scaled inputs) OR the library says so
-    (non-finite flag in the stats, RuntimeError from `sample`) -- never a finite wrong score."""
+    """GEMM operands are fp16 hi + fp16 lo with power-of-two pre-scaling.  A trained checkpoint may carry weights / features tens of times
+    larger (or smaller) than random init.  Round 5: the activation-side exponents follow the handle's WEIGHTS (dedf_pack.h::act_exponent: typical
+    magnitudes propagated from the LayerNorms through the block), so with any group of weights -- or all of them at once -- scaled x30, x100
+    or x0.01 the score stays within the 1e-4 tolerance of the fp64 oracle on the same scaled inputs (or within 1.5x the fp32 restatement's own
+    error where the scaled model is ill-conditioned in fp32 itself), and never overflows.  Only from x1000 on (the caller's own
+    features, which no weight announces, or compounding groups) the old contract remains: within tolerance OR reported (non-finite flag in the
+    stats, RuntimeError from `sample`) -- never a finite wrong score."""
     kw, cfg, P, keys, query, Ts, time = SC.build_case(2, 6, 512, 60)
     names = [g for g in _RANGE_GROUPS if group in (g, 'all_of_them')]
     P = dict(P)
@@ -1092,6 +1095,7 @@ def test_fp16_operand_range_scaled_weights_and_features(group, factor):
     assert st['n_edges'] == d64['n_edges_per_scale']
     finite = bool(torch.isfinite(ang).all() and torch.isfinite(lin).all())
     if st['nonfinite'] or not finite:
+        assert factor >= 1000.0, (group, factor, st)                 # x30 / x100 / x0.01 are inside the window whatever the group
         assert st['nonfinite'] and not finite, (st, finite)          # flag and NaN/inf outputs go together
         dev = torch.device('cuda:0')
         gk, gq = _to_dev(keys, query, dev)
@@ -1100,7 +1104,12 @@ def test_fp16_operand_range_scaled_weights_and_features(group, factor):
         return          # outside the fp16 operand range, and reported as such
     scale = float(max(ang64.abs().max(), lin64.abs().max()))
     err = max(float((ang.double() - ang64).abs().max()), float((lin.double() - lin64).abs().max())) / scale
-    assert err < TOL, (group, factor, err)
+    # Some scaled models are ill-conditioned in fp32 itself (saturated softmax / gates: node_ffn x30 puts the fp32 RESTATEMENT 5e-4 from the fp64 one,
+    # profiles/r05k_range_floor.log): the bar is the stated tolerance or the fp32 restatement's own error on the same inputs, whichever is larger --
+    # x1.5 up to x100 (measured: HIP <= 1.2x the restatement everywhere), x6 at x1000 (22-bit operands against 24: measured 4.4x).
+    ang32, lin32, _, _ = SC.oracle_run(kw, P, keys, query, Ts, time, torch.float32)
+    floor = max(float((ang32.double() - ang64).abs().max()), float((lin32.double() - lin64).abs().max())) / scale
+    assert err < max(TOL, (6.0 if factor >= 1000.0 else 1.5) * floor), (group, factor, err, floor)
 
 
 def test_scene_cache_is_not_fooled_by_recycled_addresses():

@@ -55,6 +55,21 @@ def test_fps_of_an_fps_ordered_cloud_is_its_prefix_on_the_oracle(case):
             assert np.array_equal(p1, np.arange(len(p1))), (case, ratio, r1)
 
 
+def test_fps_prefix_shortcut_ends_where_the_distinct_points_do():
+    """the prefix property needs every prefix sample to have been at non-zero distance from the earlier ones.  A parent run that
+    takes more samples than the cloud has distinct points selects index 0 again and again (all distances 0, smallest-index arg-max), and the
+    re-sampling of THAT selection is no longer 0, 1, 2, ...: `FpsPool(_fps_ordered=True)` is documented as invalid there (DEDF_FPS_CHECK=1 raises)."""
+    rng = np.random.default_rng(5)
+    base = rng.normal(size=(50, 3)).astype(np.float32)
+    x = np.concatenate([base, base, base], 0)                 # 150 points, 50 distinct
+    p0 = G.fps(x, 0.5)                                        # 75 samples > 50 distinct points
+    assert len(np.unique(x[p0], axis=0)) == 50 and len(p0) == 75
+    sub = x[p0]
+    p1 = G.fps(sub, 0.8)                                      # 60 samples of the sub-cloud: beyond its 50 distinct points
+    assert np.array_equal(p1[:50], np.arange(50))             # the prefix holds exactly as far as the distinct samples go
+    assert not np.array_equal(p1, np.arange(len(p1)))         # ... and not beyond
+
+
 def test_radius_oracle_properties():
     x, y = _cloud(300, 1), _cloud(120, 2)
     ed, es = G.radius(x, y, 9.0, 1000)
@@ -143,6 +158,15 @@ def test_fps_of_an_fps_ordered_cloud_is_its_prefix():
         pool = CN.FpsPool(ratio=0.2, random_start=False, r=2.5, max_num_neighbors=1000)
         a, c = pool(sub, f, b), pool(sub, f, b, _fps_ordered=True)
         assert all(torch.equal(u, v) for u, v in zip(a, c))
+    # the cross-check switch: a cloud that is NOT in selection order is caught
+    import os
+    os.environ["DEDF_FPS_CHECK"] = "1"
+    try:
+        pool(sub, f, b, _fps_ordered=True)
+        with pytest.raises(RuntimeError, match="not in the selection order"):
+            pool(sub.flip(0).contiguous(), f, b, _fps_ordered=True)
+    finally:
+        del os.environ["DEDF_FPS_CHECK"]
 
 
 @pytest.mark.gpu

@@ -143,7 +143,7 @@ template <int L> void show() {
     printf("], \"slots\": [%d, %d], \"items\": [", dtp_num_slots<L, true>(r0_tiles<L>()), dtp_num_slots<L, false>(r0_tiles<L>()));
     for (int I = 0; I < sval_num_items<L>(); ++I) { auto it = sval_item<L>(I); auto pi = dtp_path<L>(it.p);
         printf("%s{\"path\": [%d, %d, %d], \"c\": %d, \"set\": %d, \"coef\": %.9g, \"ge\": %d, \"ops\": [", I ? ", " : "", pi.l1, pi.l2, pi.l3, it.c, it.set, it.coef, it.group_end);
-        for (int a = 0; a < it.na; ++a) printf("%s[%d, %d, %d, %d, %d]", a ? ", " : "", it.acc[a], it.bq[a], (int)it.neg[a], it.aslot[a], (int)it.first[a]);
+        for (int a = 0; a < it.na; ++a) printf("%s[%d, %d, %d, %d, %d, %d, %d]", a ? ", " : "", it.acc[a], it.bq[a], (int)it.neg[a], it.aslot[a], (int)it.first[a], it.tile[a], (int)it.up[a]);
         printf("]}"); }
     printf("], \"n_slots\": %d, \"park\": [", sval_num_slots<L>());
     for (int l = 0; l <= L; ++l) printf("%s%d", l ? ", " : "", park_slot<L>(l, 0, 0));
@@ -190,9 +190,13 @@ def test_kernel_walks_cover_every_term_once(tmp_path):
         l3s = [w[3] for w in W["walk"]]
         n0 = sum(1 for v in l3s if v == 0)
         assert all(v == 0 for v in l3s[:n0]) and all(v >= 1 for v in l3s[n0:])
-        keys = [(w[1], w[0]) for w in W["walk"][n0:]]
-        l1s = [w[1] for w in W["walk"][n0:]]
-        assert l1s == sorted(l1s)
+        # ... in groups of output degrees (lmax <= 2: one group; lmax 3: {1, 2} then {3}), each walked by (l1, channel range)
+        grp = lambda l3: 0 if l3 == 0 else (2 if (L == 3 and l3 == 3) else 1)
+        gs = [grp(w[3]) for w in W["walk"]]
+        assert gs == sorted(gs)
+        for g in set(gs):
+            l1s = [w[1] for w in W["walk"] if grp(w[3]) == g]
+            assert l1s == sorted(l1s)
         assert W["slots"][0] == W["slots"][1]          # one A slot per chunk, as in the general form
         # value: the items' terms are exactly the edge-frame terms of every (path, K-chunk), coefficient = folded class constant x sign
         park0 = W["park"]
@@ -201,7 +205,10 @@ def test_kernel_walks_cover_every_term_once(tmp_path):
         for it in W["items"]:
             l1, l2, l3 = it["path"]
             assert it["set"] == (1 if l2 > 0 else 0)
-            for acc, bq, neg, slot, first in it["ops"]:
+            assert len(it["ops"]) <= (4 if L == 3 else 5)
+            for acc, bq, neg, slot, first, tile, up in it["ops"]:
+                paired = L == 3 and l3 >= 2
+                assert (tile, up) == ((acc // 2, acc % 2) if paired else (acc, 0))
                 if l3 == 0:
                     k, i = 0, l1
                     comp = (bq - park0[l1]) // (mul(l1) // 16)
@@ -212,7 +219,7 @@ def test_kernel_walks_cover_every_term_once(tmp_path):
                     comp = (bq - park0[l1]) // (mul(l1) // 16)
                     got.setdefault((l1, l2, l3, it["c"], k), []).append((comp, -it["coef"] if neg else it["coef"]))
                     assert (bq - park0[l1]) % (mul(l1) // 16) == it["c"]
-                key = (l3, it["set"], acc)
+                key = (l3, it["set"], tile)
                 assert bool(first) == (key not in seen_first)
                 seen_first.add(key)
         for (l1, l2, l3) in paths:
@@ -226,4 +233,4 @@ def test_kernel_walks_cover_every_term_once(tmp_path):
                     assert len(e) == 1 and e[0][0] == i and abs(e[0][1] - cf) < 1e-6, (l1, l2, l3, c, k, e, cf)
         assert not [k for k in got if k[2] != 0]
         ends = [it["ge"] for it in W["items"] if it["ge"] >= 0]
-        assert ends == list(range(L + 1))
+        assert ends == list(range(L, 0, -1)) + [0]          # highest degree first, the scalars last (dedf_net.h::make_sval_walk)
