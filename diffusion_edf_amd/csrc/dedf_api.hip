@@ -125,6 +125,7 @@ struct dedf_handle {
                                       // records, aggregate, flags) this layer uses instead of its own
     std::vector<dedf_handle*> ws_borrowers;   // ... and, on the owner's side, the handles that currently borrow it (detached by dedf_destroy(owner))
     bool want_field = false;          // dedf_field: the node kernel also writes the field / emb of every node
+    DevBuf d_nspin;                   // [N_d][4]: the ang_spin half of the node kernel's output when it runs split (NodeParams::split)
     DevBuf d_Ts, d_time, d_tb, d_pose, d_qpos, d_cnt, d_off, d_blk, d_tile, d_esrc, d_edst, d_eout, d_z, d_nout, d_ang, d_lin, d_T64, d_dbgw, d_dbge, d_dbgf, d_dbgo, d_mask;
     int64_t edge_cap = 0;
     double est_degree = 0.0;          // dedf_set_key_clouds: sum over the scales of the key points' mean self-degree (k_self_degree) = the edges a query
@@ -778,6 +779,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     h->edge16_used = false;
     mark();
     // 6. node epilogue + score tensor products
+    const float* node_spin = nullptr;
     {
         NodeParams P{};
         P.z = h->d_z.as<float>(); P.z_bytes = (uint32_t)((size_t)Nd * D * 4);
@@ -801,6 +803,16 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         if ((h->debug || h->want_field) && h->d_dbge.ensure((size_t)Nd * D * 4) && h->d_dbgf.ensure((size_t)Nd * D * 4)) { P.dbg_emb = h->d_dbge.as<float>(); P.dbg_field = h->d_dbgf.as<float>(); }
         else if (h->want_field) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(field) failed");
         const int ntiles = (Nd + 31) / 32;
+        // small batches: two waves per node tile, one score tensor product each (dedf_node.h: NodeParams::split) while both fit the chip at once
+        static const bool split_on = [] { const char* e = getenv("DEDF_NODE_SPLIT"); return !(e && atoi(e) == 0); }();
+        if constexpr (!EBM) {
+            if (split_on && !h->cfg.half_gemm && !h->debug && !h->want_field && 2 * ntiles <= h->n_cu * 4 && h->d_nspin.ensure((size_t)Nd * 16)) {
+                P.split = 1; P.node_spin = h->d_nspin.as<float>(); node_spin = P.node_spin;
+            }
+        }
+        if (P.split) {
+            if constexpr (!EBM) DEDF_LAUNCH_PERSISTENT((k_node<L, EBM>), 2 * ntiles, st, P);
+        } else
         if constexpr (L == 3) {      // (balanced grid measured at lmax 3: 0.477 -> 0.482 ms, not used)
             if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_node<L, EBM, true>), ntiles, st, P);
             else DEDF_LAUNCH_PERSISTENT((k_node<L, EBM>), ntiles, st, P);
@@ -810,8 +822,8 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     mark();
     // 7. per-pose reduction
     if constexpr (EBM) hipLaunchKernelGGL(k_energy_reduce, dim3((nT + 127) / 128), dim3(128), 0, st, h->d_nout.as<float>(), nT, nQ, ang, h->d_tile.as<int>());
-    else if (h->fused_step) hipLaunchKernelGGL(k_reduce_langevin, dim3(nT), dim3(64), 0, st, h->d_nout.as<float>(), nQ, ang, lin, *h->fused_step, h->d_tile.as<int>());
-    else hipLaunchKernelGGL(k_pose_reduce, dim3(nT), dim3(64), 0, st, h->d_nout.as<float>(), nT, nQ, ang, lin, h->d_tile.as<int>());
+    else if (h->fused_step) hipLaunchKernelGGL(k_reduce_langevin, dim3(nT), dim3(64), 0, st, h->d_nout.as<float>(), nQ, ang, lin, *h->fused_step, h->d_tile.as<int>(), node_spin);
+    else hipLaunchKernelGGL(k_pose_reduce, dim3(nT), dim3(64), 0, st, h->d_nout.as<float>(), nT, nQ, ang, lin, h->d_tile.as<int>(), node_spin);
     mark();
     if (h->profile) { h->prof_evals += 1; h->prof_dst += Nd; }
     if (hipGetLastError() != hipSuccess) return fail(h, DEDF_ERR_RUNTIME, "kernel launch failed");

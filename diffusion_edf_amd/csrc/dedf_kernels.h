@@ -111,6 +111,12 @@ template <int L, bool EBM, bool HP = false, bool UN = false> __global__ __launch
     //  last node reduces it, found with one atomic counter per pose.  The device-scope release / acquire that the hand-over needs is an L2
     //  write-back on this multi-XCD part: k_node 0.29 -> 0.45 ms on C2, 56 -> 84 us at 16 poses, against one 5 us launch saved;
     //  profiles/r03g_fused_reduce_and_single_block_fill_small_batch.log.)
+    if constexpr (!EBM && !UN) {
+        if (P.split) {      // two waves per tile, one score tensor product each (dedf_node.h: NodeParams::split)
+            for (int t = blockIdx.x; t < 2 * ntiles; t += gridDim.x) node_tile<L, EBM, HP, UN>(P, wv, (t >> 1) * 32, t & 1);
+            return;
+        }
+    }
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) node_tile<L, EBM, HP, UN>(P, wv, t * 32);
 }
 

@@ -98,13 +98,20 @@ __device__ inline void langevin_update(const LangevinParams& P, int i, const flo
 }
 // Sum over the query points of pose t in k_pose_reduce's order (lanes stride over the query points, then a fixed butterfly: deterministic,
 // independent of nT) and the Langevin update of that pose; one WAVE, lane 0 carries the float64 update.
+// (node_spin: the ang_spin half when the node kernel ran split over two waves per tile -- NodeParams::split --, else null)
 __device__ inline void reduce_pose_and_step(const float* __restrict__ node_out, int nQ, int t, int lane, float* __restrict__ ang_out,
-                                            float* __restrict__ lin_out, const LangevinParams& P, int* __restrict__ flags) {
+                                            float* __restrict__ lin_out, const LangevinParams& P, int* __restrict__ flags,
+                                            const float* __restrict__ node_spin = nullptr) {
     float s[6] = {0, 0, 0, 0, 0, 0};
     for (int q = lane; q < nQ; q += 64) {
         const float* o = node_out + ((size_t)t * nQ + q) * 8;
         const f32x4 a = ld4(o), b = ld4(o + 4);
+        if (node_spin != nullptr) {
+            const f32x4 sp = ld4(node_spin + ((size_t)t * nQ + q) * 4);
+            s[0] += a[0]; s[1] += a[1]; s[2] += a[2]; s[3] += a[3] + sp[0]; s[4] += b[0] + sp[1]; s[5] += b[1] + sp[2];
+        } else {
         s[0] += a[0]; s[1] += a[1]; s[2] += a[2]; s[3] += a[3]; s[4] += b[0]; s[5] += b[1];
+        }
     }
     for (int m = 32; m >= 1; m >>= 1)
         for (int i = 0; i < 6; ++i) s[i] += __shfl_xor(s[i], m, 64);

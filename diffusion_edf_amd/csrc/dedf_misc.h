@@ -661,14 +661,19 @@ __global__ void k_aggregate(const float* __restrict__ edge_out, const int* __res
 
 // ------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_pose_reduce(const float* __restrict__ node_out, int nT, int nQ, float* __restrict__ ang, float* __restrict__ lin,
-                                                    int* __restrict__ flags) {
+                                                    int* __restrict__ flags, const float* __restrict__ node_spin = nullptr) {
     const int t = blockIdx.x, lane = threadIdx.x;
     if (t >= nT) return;
     float s[6] = {0, 0, 0, 0, 0, 0};
     for (int q = lane; q < nQ; q += 64) {
         const float* o = node_out + ((size_t)t * nQ + q) * 8;
         const f32x4 a = ld4(o), b = ld4(o + 4);
+        if (node_spin != nullptr) {      // (the node kernel ran split: NodeParams::split)
+            const f32x4 sp = ld4(node_spin + ((size_t)t * nQ + q) * 4);
+            s[0] += a[0]; s[1] += a[1]; s[2] += a[2]; s[3] += a[3] + sp[0]; s[4] += b[0] + sp[1]; s[5] += b[1] + sp[2];
+        } else {
         s[0] += a[0]; s[1] += a[1]; s[2] += a[2]; s[3] += a[3]; s[4] += b[0]; s[5] += b[1];
+        }
     }
     for (int m = 32; m >= 1; m >>= 1)
         for (int i = 0; i < 6; ++i) s[i] += __shfl_xor(s[i], m, 64);
@@ -682,10 +687,11 @@ __global__ __launch_bounds__(64) void k_pose_reduce(const float* __restrict__ no
 // Sampler: sum over the query points of one pose (k_pose_reduce's order, bit for bit) and the Langevin update of that pose in one
 // launch — one wave per pose, lane 0 carries the float64 update.
 __global__ __launch_bounds__(64) void k_reduce_langevin(const float* __restrict__ node_out, int nQ, float* __restrict__ ang_out,
-                                                        float* __restrict__ lin_out, LangevinParams P, int* __restrict__ flags) {
+                                                        float* __restrict__ lin_out, LangevinParams P, int* __restrict__ flags,
+                                                        const float* __restrict__ node_spin = nullptr) {
     const int t = blockIdx.x;
     if (t >= P.nT) return;
-    reduce_pose_and_step(node_out, nQ, t, (int)threadIdx.x, ang_out, lin_out, P, flags);
+    reduce_pose_and_step(node_out, nQ, t, (int)threadIdx.x, ang_out, lin_out, P, flags, node_spin);
 }
 
 }  // namespace dedf

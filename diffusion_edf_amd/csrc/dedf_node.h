@@ -37,6 +37,11 @@ struct NodeParams {
     float* feat_out;                           // UNet layer only: [N_d][D] output features, reference layout
     float ln_inv_n[4], ln_pad0;                // UNet layer only: 1 / (true multiplicity) per degree and the number of padded 0e channels (masked norm_2)
     float* node_out;                           // [N_d][8]: w*lin_vel (3), w*(ang_orbital + ang_spin) (3), 0, 0
+    // Small batches (round 5): a node tile's latency is the whole kernel, and its two score tensor products are independent.  With `split` the grid
+    // holds TWO waves per tile; both run the shared front (proj, LayerNorm, FFN), wave parity 0 the lin_vel product -> node_out = w*lin_vel,
+    // w*ang_orbital; parity 1 the ang_vel product -> node_spin = w*ang_spin.  The reductions add the two.
+    int split;
+    float* node_spin;                          // [N_d][4]
     float* dbg_emb;                            // optional [N_d][D] dumps (internal layout) of the proj output and of the field (tests)
     float* dbg_field;
 };
@@ -133,7 +138,7 @@ template <int L> DEDF_DEV void feat_store_ref(const Feat<L>& f, float* node_ptr,
 }
 
 template <int L, bool EBM, bool HP = false, bool UN = false>
-DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
+DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0, int tp_only = -1) {
     constexpr int D = feat_dim<L>();
     const int hi = wv.hi;
     constexpr NodeLayout<L> O = kNodeLayout<L>;      // weight-image offsets: compile-time constants (dedf_net.h)
@@ -439,9 +444,10 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         }
         return;
     }
-    float res[2][3];                         // per TP: mean over the 32 gated 1e channels
+    float res[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};      // per TP: mean over the 32 gated 1e channels
     park(fld, opaque_s(P.sc.bf));            // the field as B operands, shared by every path of both tensor products
     static_for<2>([&]<int tp>() {
+        if (tp_only >= 0 && tp_only != tp) return;      // (wave-uniform: the other product is the partner wave's, NodeParams::split)
         f32x16 gacc = node_ldrows(rows, hi, tp == 0 ? NR::b_sl0 : NR::b_sl1, 0);
         f32x16 vacc[3];
         static_for<3>([&]<int K>() { static_for<16>([&]<int R>() { vacc[K][R] = 0.0f; }); });
@@ -588,8 +594,14 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0) {
         const float o1 = x2 * rot[0][0] - x0 * rot[0][2];
         const float o2 = x0 * rot[0][1] - x1 * rot[0][0];
         float* out = P.node_out + (size_t)n * 8;
+        if (tp_only == 1) st4(P.node_spin + (size_t)n * 4, f32x4{w * rot[1][0], w * rot[1][1], w * rot[1][2], 0.0f});
+        else if (tp_only == 0) {
+            st4(out, f32x4{w * rot[0][0], w * rot[0][1], w * rot[0][2], w * o0});
+            st4(out + 4, f32x4{w * o1, w * o2, 0.0f, 0.0f});
+        } else {
         st4(out, f32x4{w * rot[0][0], w * rot[0][1], w * rot[0][2], w * o0 + w * rot[1][0]});
         st4(out + 4, f32x4{w * o1 + w * rot[1][1], w * o2 + w * rot[1][2], 0.0f, 0.0f});
+        }
     }
 }
 

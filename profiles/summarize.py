@@ -94,6 +94,16 @@ def main(tag):
             table_on = b["roofline"]["radial_table"].get("enabled", False)
             m_edge = {1: 105_536, 2: 193_344, 3: 338_304}[lmax] - (40_960 if table_on else 0)
             us = summary.get("edge_kernel_steady_avg_us_in_trace")
+            # the bench line's edge count is that of its TIMED steps: compare with the launches of those steps only (the warm-up steps before
+            # them start from the seeded poses and carry a different number of edges)
+            try:
+                d_all = rows.get(timed[-1], [])
+                k = int(b.get("steps", 0))
+                if k and len(d_all) >= k:
+                    us = sum(d_all[-k:]) / k
+                    summary["edge_kernel_timed_steps_avg_us_in_trace"] = us
+            except Exception:          # noqa: BLE001
+                pass
             if us:
                 gen = sum(summary.get("radial_table_steady_avg_us_in_trace", {}).values()) if table_on else 0.0
                 summary["edge_kernel_frac_executed_flop_from_trace"] = 2.0 * m_edge * edges / ((us + gen) * 1e-6) / (2.5e15 / 3.0)
