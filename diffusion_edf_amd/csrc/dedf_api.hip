@@ -268,7 +268,11 @@ template <int L> bool irreps_consistent(const IrrepsRT& K) {
 }
 // shapes with an edge-aligned-frame instantiation (dedf_kernel_list.h): the full-precision lmax-2 score head with the [128, 128, 64] radial network
 bool so2_instantiated(const dedf_config& c) {
-    if (c.unet_layer || c.half_gemm) return false;
+    if (c.half_gemm) return false;
+    if (c.unet_layer) {      // UNet layers (round 5): lmax 2 / 3 with the [64, 32, 32] radial network; DEDF_SO2_UNET=0 keeps them in the general form (A/B)
+        static const bool un_on = [] { const char* e = getenv("DEDF_SO2_UNET"); return !(e && atoi(e) == 0); }();
+        return un_on && c.lmax >= 2 && c.fc_neurons[0] == 64 && c.fc_neurons[1] == 32 && c.fc_neurons[2] == 32;
+    }
     const int F0 = c.fc_neurons[0];
     const bool wide = c.fc_neurons[1] == 128 && c.fc_neurons[2] == 64, narrow = c.fc_neurons[1] == 32 && c.fc_neurons[2] == 32;
     if (c.lmax == 3) return (F0 == 128 && wide) || (F0 == 64 && (wide || narrow));
@@ -1366,8 +1370,10 @@ int layer_forward_impl(dedf_handle* h, int n_src, const float* x_src, const floa
         static const bool nw_on = [] { const char* e = getenv("DEDF_UNET_NARROW"); return !(e && atoi(e) == 0); }();      // DEDF_UNET_NARROW=0: the general kernels (A/B)
         if (h->cfg.unet_narrow && nw_on) {      // narrow level: the instantiations that skip the structurally zero channels (dedf_net.h::pad_live)
             if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, true, 32, 32, true, 0, true>), 1 << 30, st, P);
+            else if (h->so2) DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, false, 32, 32, true, 0, true, true>), 1 << 30, st, P);      // edge-aligned frame (round 5)
             else DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, false, 32, 32, true, 0, true>), 1 << 30, st, P);
         } else if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, true, 32, 32, true>), 1 << 30, st, P);
+        else if (h->so2) DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, false, 32, 32, true, 0, false, true>), 1 << 30, st, P);
         else DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, false, 32, 32, true>), 1 << 30, st, P);
     }
     hipLaunchKernelGGL(k_aggregate<L>, dim3((n_dst + 3) / 4), dim3(256), 0, st, w->d_eout.as<float>(), w->d_cnt.as<int>(), w->d_off.as<int>(),

@@ -361,7 +361,7 @@ template <int L> struct Trig { float cg[L], sg[L], cb[L], sb[L]; };
 template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false, int MODE = 0, bool NW = false, bool SO2 = false>
 DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, int n_valid, GeoPre& geo, int e_next DEDF_PROF_ARG) {
     static_assert((H1 == 128 && H2 == 64) || (H1 == 32 && H2 == 32), "radial MLP widths of the shipped configs");
-    static_assert(!SO2 || (!UN && !NW && MODE <= 1), "edge-frame form: the score-head / critic / field kernels");
+    static_assert(!SO2 || MODE <= 1, "edge-frame form: the per-edge and the table-reading kernels");
     static_assert(!UN || F0 == 64, "UNet layer: the radial MLP reads the 64 radial-basis channels");
     static_assert(MODE == 0 || !UN, "the radial table is the sampler's");
     static_assert(!NW || UN, "NW is a UNet-layer shape");
@@ -439,7 +439,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         const float cut = 1.0f - soft_step((len - P.cut_begin[scale]) / P.cut_div[scale]);
         logit0 = logf(fmaxf(cut, 1e-12f));
     }
-    const float cns = UN ? 1.0f : soft_step((len - P.ns_lo) / P.ns_div);
+    // (UNet layer: no cut-off on the SH; what the edge frame still needs is the reference's SH of a zero-length edge -- 0 for l > 0, the normalised
+    //  zero vector -- which the general form gets from its unit vector (0, 0, 0): duplicate points of a cloud)
+    const float cns = UN ? ((SO2 && !(len > 0.0f)) ? 0.0f : 1.0f) : soft_step((len - P.ns_lo) / P.ns_div);
     SH<L> Y;
     {
         const float inv = 1.0f / fmaxf(len, 1e-12f);
@@ -752,7 +754,10 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 if constexpr (newx) static_for<2>([&]<int run>() { static_for<4>([&]<int j>() {
                     if constexpr (!pad_reg<L, NW>(l1, j)) {
                         float v[d1];
-                        static_for<d1>([&]<int m>() { constexpr int el = j * d1 + m; v[m] = xo.x[run][el / 4][el % 4]; });
+                        static_for<d1>([&]<int m>() {
+                            constexpr int el = j * d1 + m;
+                            if constexpr (UN) v[m] = xo.x[run][el / 4][el % 4] + xo.xd[run][el / 4][el % 4]; else v[m] = xo.x[run][el / 4][el % 4];
+                        });
 #if !defined(DEDF_TIMING_SO2_NOROT)      // (timing experiments only, wrong results: DESIGN.md section 5.R5)
                         Rot<l1>::in(v, tg);
 #endif
@@ -1377,25 +1382,29 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         return o;
     };
     f32x16 V0[2][2], V1[2][3], V2[2][5], V3[2][4];      // (paired tiles, lmax 3: V2 uses three, V3 four)
-    auto run_item = [&]<int I>(const SB& b) {
+    // ONE: every edge of the tile has cut-off factor 1 (no edge shorter than r_mincut_nonscalar_sh -- all but a handful of tiles): set 1 accumulates
+    // straight into set 0's tiles, and a completed degree is read once instead of twice (-240 VALU instructions per tile)
+    auto run_item = [&]<int I, bool ONE>(const SB& b) {
         constexpr SItem it = sval_item<L>(I);
+        constexpr int ST = ONE ? 0 : it.set;
         auto& V = [&]() -> auto& { if constexpr (it.l3 == 0) return V0; else if constexpr (it.l3 == 1) return V1; else if constexpr (it.l3 == 2) return V2; else return V3; }();
         static_for<it.na>([&]<int a>() {
+            constexpr bool fst = ONE ? it.first_one[a] : it.first[a];
             f32x16 init = {};
-            if constexpr (it.first[a] && it.l3 == 0 && it.set == 0) init = ldrows_lds(rows, hi, RL::val0, it.acc[a]);      // sep_value.lin's bias
-            V[it.set][it.tile[a]] = mfma_h(__builtin_bit_cast(h8, it.up[a] ? aring[it.aslot[a] % RS].hu : aring[it.aslot[a] % RS].h), __builtin_bit_cast(h8, b.h[it.l3 == 0 ? 0 : a]), it.first[a] ? init : V[it.set][it.tile[a]]);
+            if constexpr (fst && it.l3 == 0 && it.set == 0) init = ldrows_lds(rows, hi, RL::val0, it.acc[a]);      // sep_value.lin's bias
+            V[ST][it.tile[a]] = mfma_h(__builtin_bit_cast(h8, it.up[a] ? aring[it.aslot[a] % RS].hu : aring[it.aslot[a] % RS].h), __builtin_bit_cast(h8, b.h[it.l3 == 0 ? 0 : a]), fst ? init : V[ST][it.tile[a]]);
         });
         if constexpr (!HP) {
-            static_for<it.na>([&]<int a>() { V[it.set][it.tile[a]] = mfma_h(__builtin_bit_cast(h8, it.up[a] ? aring[it.aslot[a] % RS].hu : aring[it.aslot[a] % RS].h), __builtin_bit_cast(h8, b.l[it.l3 == 0 ? 0 : a]), V[it.set][it.tile[a]]); });
-            static_for<it.na>([&]<int a>() { V[it.set][it.tile[a]] = mfma_h(__builtin_bit_cast(h8, it.up[a] ? aring[it.aslot[a] % RS].lu : aring[it.aslot[a] % RS].l), __builtin_bit_cast(h8, b.h[it.l3 == 0 ? 0 : a]), V[it.set][it.tile[a]]); });
+            static_for<it.na>([&]<int a>() { V[ST][it.tile[a]] = mfma_h(__builtin_bit_cast(h8, it.up[a] ? aring[it.aslot[a] % RS].hu : aring[it.aslot[a] % RS].h), __builtin_bit_cast(h8, b.l[it.l3 == 0 ? 0 : a]), V[ST][it.tile[a]]); });
+            static_for<it.na>([&]<int a>() { V[ST][it.tile[a]] = mfma_h(__builtin_bit_cast(h8, it.up[a] ? aring[it.aslot[a] % RS].lu : aring[it.aslot[a] % RS].l), __builtin_bit_cast(h8, b.h[it.l3 == 0 ? 0 : a]), V[ST][it.tile[a]]); });
         }
     };
     // a completed degree: set0 + cns . set1, back to the global frame, into val<l3> (what store_group reads)
-    auto finish_value = [&]<int l3>() {
+    auto finish_value = [&]<int l3, bool ONE>() {
         if constexpr (l3 == 0) {
             static_for<2>([&]<int T>() { static_for<16>([&]<int R>() {
-                float v = sval_acc_used<L>(0, 0, T) ? V0[0][T][R] : 0.0f;
-                if constexpr (sval_acc_used<L>(0, 1, T)) v += cns * V0[1][T][R];
+                float v = (ONE || sval_acc_used<L>(0, 0, T)) ? V0[0][T][R] : 0.0f;
+                if constexpr (!ONE && sval_acc_used<L>(0, 1, T)) v += cns * V0[1][T][R];
                 val0[T][R] = v;
             }); });
         } else {
@@ -1409,8 +1418,11 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 static_for<d3>([&]<int K>() {
                     constexpr int T = PR ? K / 2 : K, Rr = PR ? 8 * (K % 2) + R : R;
                     float x = 0.0f;
+                    if constexpr (ONE) x = V[0][T][Rr];
+                    else {
                     if constexpr (sval_acc_used<L>(l3, 0, K)) x = V[0][T][Rr];
                     if constexpr (sval_acc_used<L>(l3, 1, K)) x += cns * V[1][T][Rr];
+                    }
                     v[K] = x;
                 });
                 Rot<l3>::out(v, tg);
@@ -1420,6 +1432,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             });
         }
     };
+    auto value_loop = [&]<bool ONE>() {
     static_for<PDV>([&]<int I>() { load_A_of.template operator()<I>(); });
     SB vb_cur = load_B.template operator()<0>();
     // A completed degree leaves in pieces, one per pipeline region, under the GEMMs of the degree that follows it in the walk (highest degree first,
@@ -1444,7 +1457,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             auto& V = [&]() -> auto& { if constexpr (it.l3 == 0) return V0; else if constexpr (it.l3 == 1) return V1; else if constexpr (it.l3 == 2) return V2; else return V3; }();
             V[it.set][it.tile[a]][0] = (it.first[a] ? 0.0f : V[it.set][it.tile[a]][0]) + vb_cur.h[it.l3 == 0 ? 0 : a][0] + vb_cur.l[it.l3 == 0 ? 0 : a][1] + aring[it.aslot[a] % RS].h[0] + aring[it.aslot[a] % RS].l[1]; }); }
 #else
-        if constexpr (I < NVI) run_item.template operator()<I>(vb_cur);
+        if constexpr (I < NVI) run_item.template operator()<I, ONE>(vb_cur);
 #endif
         static_for<L + 1>([&]<int g>() {
             constexpr int q = I - 1 - sval_group_last<L>(g);
@@ -1456,7 +1469,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                     if constexpr (g == 2) static_for<5>([&]<int K>() { val2[K][0] = V2[0][K][0] + V2[1][K][1]; });
                 }
 #else
-                if constexpr (q == 0) finish_value.template operator()<g>();
+                if constexpr (q == 0) finish_value.template operator()<g, ONE>();
                 else store_group.template operator()<g, q - 1, 1>();
 #endif
             }
@@ -1469,6 +1482,12 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         if constexpr (I == sval_group_last<L>(L) + 1) DEDF_STAMP(10);
         if constexpr (L >= 2 && I == sval_group_last<L>(1) + 1) DEDF_STAMP(13);
     });
+    };
+#ifndef DEDF_VAL_ONESET
+#define DEDF_VAL_ONESET 1
+#endif
+    if (DEDF_VAL_ONESET && __all(!valid || cns == 1.0f)) value_loop.template operator()<true>();
+    else value_loop.template operator()<false>();
     } else {
     // Software pipeline over the work items: region I requests the A slots of item I + 2 and the parked B chunks of item I + 1,
     // runs the MFMAs of item I and, beside them, the contraction of the accumulators item I - 1 completed.

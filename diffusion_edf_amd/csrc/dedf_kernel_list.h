@@ -75,5 +75,9 @@
     X(40, void k_edge<3, 128, false, 128, 64, false, 0, false, true>(EdgeParams)) \
     X(41, void k_edge<3, 128, false, 128, 64, false, 1, false, true>(EdgeParams)) \
     X(42, void k_edge<3, 64, false, 128, 64, false, 0, false, true>(EdgeParams))  \
-    X(43, void k_edge<3, 64, false, 32, 32, false, 0, false, true>(EdgeParams))
-constexpr int kKernelUnits = 44;
+    X(43, void k_edge<3, 64, false, 32, 32, false, 0, false, true>(EdgeParams))   \
+    X(44, void k_edge<2, 64, false, 32, 32, true, 0, false, true>(EdgeParams))    \
+    X(45, void k_edge<2, 64, false, 32, 32, true, 0, true, true>(EdgeParams))     \
+    X(46, void k_edge<3, 64, false, 32, 32, true, 0, false, true>(EdgeParams))    \
+    X(47, void k_edge<3, 64, false, 32, 32, true, 0, true, true>(EdgeParams))
+constexpr int kKernelUnits = 48;

@@ -434,6 +434,7 @@ struct SItem {
     bool neg[7];           // the B operand enters negated
     int aslot[7];
     bool first[7];         // first accumulation into that tile
+    bool first_one[7];     // ... when both sets share one tile (tiles whose edges all have cut-off factor 1: dedf_edge.h, value stage, ONE)
     int new_slots;
     int group_end;         // output degree completed by this item, or -1
     float coef;            // what the host folds into this item's A slot(s)
@@ -451,6 +452,7 @@ template <int L> DEDF_HD constexpr SValWalk<L> make_sval_walk() {
         const int l3 = gi < L ? L - gi : 0;
         const bool PR = l3 >= 1 && acc_paired<L>(l3);
         bool seen[2][7] = {{false, false, false, false, false, false, false}, {false, false, false, false, false, false, false}};
+        bool seen_one[7] = {false, false, false, false, false, false, false};
         for (int set = 0; set < 2; ++set)
         for (int p = 0; p < dtp_num_paths<L>(); ++p) {
             const PathInfo pi = dtp_path<L>(p);
@@ -463,6 +465,7 @@ template <int L> DEDF_HD constexpr SValWalk<L> make_sval_walk() {
                     for (int a = 0; a < it.na; ++a) {
                         it.acc[a] = a; it.tile[a] = a; it.up[a] = false; it.bq[a] = park_slot<L>(pi.l1, kSo2I[pi.l1][pi.l2][0][0], c); it.neg[a] = false; it.aslot[a] = slot + a;
                         it.first[a] = !seen[set][a]; seen[set][a] = true;
+                        it.first_one[a] = !seen_one[a]; seen_one[a] = true;
                     }
                     it.new_slots = it.na; slot += it.na;
                     w.item[n++] = it;
@@ -485,6 +488,7 @@ template <int L> DEDF_HD constexpr SValWalk<L> make_sval_walk() {
                         const int a = it.na++, k = kSo2K[pi.l1][pi.l2][pi.l3][t], tl = PR ? k / 2 : k;
                         it.acc[a] = k; it.tile[a] = tl; it.up[a] = PR && (k % 2 == 1); it.bq[a] = park_slot<L>(pi.l1, kSo2I[pi.l1][pi.l2][pi.l3][t], c); it.neg[a] = ct != c0; it.aslot[a] = slot;
                         it.first[a] = !seen[set][tl]; seen[set][tl] = true;
+                        it.first_one[a] = !seen_one[tl]; seen_one[tl] = true;
                     }
                     slot += 1;
                     w.item[n++] = it;

@@ -357,6 +357,51 @@ def test_tiny_batches(nT, n_grasp, static_kp):
     assert float((ang.double() - ang64).abs().max()) / scale < TOL and float((lin.double() - lin64).abs().max()) / scale < TOL
 
 
+@pytest.mark.parametrize("lmax", [1, 2, 3])
+def test_edge_frame_degenerate_directions(lmax):
+    """The edge-aligned frame of the edge kernels (dedf_edge.h: SO2; diffusion_edf_amd/so2.py) at the directions where its angles degenerate:
+    edges of length exactly 0 (a query point ON a key point: the frame is the identity, the non-scalar SH vanish), edges exactly along +-y
+    (rho = 0: gamma is free), along +-x / +-z, and lengths inside the non-scalar cut-off's ramp (0.06 .. 0.3) where cns is neither 0 nor 1.
+    The identity pose puts the transformed query points on the key coordinates bit for bit.  Also run on two of those handles as a sampler step
+    (table path) and in the general form (DEDF_SO2=0) -- the three must agree with the fp64 oracle."""
+    kw, cfg, P, keys, query, Ts, time = SC.build_case(lmax, 3, 300, 12, identity_pose=False)
+    q = query.x[:12].clone()
+    offs = []
+    for d in (0.0, 0.03, 0.1, 0.2, 0.29, 1.0, 3.0):
+        for ax in ((0., 1., 0.), (0., -1., 0.), (1., 0., 0.), (-1., 0., 0.), (0., 0., 1.), (0., 0., -1.), (1., 1., 0.), (0., 1., 1.)):
+            offs.append(torch.tensor(ax) * d)
+    extra = torch.cat([q[i % len(q)][None] + o[None] for i, o in enumerate(offs)]).to(keys[0].x.dtype)
+    g = torch.Generator().manual_seed(5)
+    keys = [k._replace(x=torch.cat([extra, k.x]), f=torch.cat([torch.randn(len(extra), k.f.shape[1], generator=g), k.f]),
+                       b=torch.zeros(len(extra) + len(k.x), dtype=torch.long)) for k in keys]
+    Ts = Ts.clone()
+    Ts[0] = torch.tensor([1., 0, 0, 0, 0., 0., 0.], dtype=torch.float64)          # identity: query points on their key twins
+    Ts[1] = torch.tensor([1., 0, 0, 0, 0., 0.5, 0.], dtype=torch.float64)         # shifted along y: more exact +-y edges
+    ang64, lin64, d64, _ = SC.oracle_run(kw, P, keys, query, Ts, time, torch.float64)
+    scale = float(max(ang64.abs().max(), lin64.abs().max()))
+    for so2 in ("1", "0"):
+        os.environ["DEDF_SO2"] = so2
+        try:
+            head, ang, lin = SC.gpu_run(kw, P, keys, query, Ts, time, debug=False)
+        finally:
+            del os.environ["DEDF_SO2"]
+        st = head.stats()
+        assert st['n_edges'] == d64['n_edges_per_scale'] and not st['nonfinite']
+        err = max(float((ang.double() - ang64).abs().max()), float((lin.double() - lin64).abs().max())) / scale
+        print(f"TOLPROBE degenerate directions lmax {lmax} SO2={so2}: {err:.2e}")
+        assert err < TOL, (lmax, so2, err)
+    if lmax >= 2:          # the table-reading instantiation on the same clouds: one sampler step at one time against the oracle's
+        dev = torch.device('cuda:0')
+        head = _gpu_head(kw, P, dev)
+        head.set_radial_table("always")
+        gk, gq = _to_dev(keys, query, dev)
+        out = ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[0.5, 0.5]], [1], [0.04], temperatures=0.0).cpu()
+        ok = [R.FeaturedPoints(k.x, k.f, k.b, None) for k in keys]
+        ref = R.sample(R.config_from_kwargs(kw), P, Ts, ok, R.FeaturedPoints(query.x, query.f, query.b, query.w), [[0.5, 0.5]], [1], [0.04], temperatures=0.0)
+        moved = float((ref[1] - ref[0]).abs().max())
+        assert float((out - ref).abs().max()) < 1e-4 * max(moved, 1e-3)
+
+
 @pytest.mark.parametrize("radii", [(6.,), (4., None), (3., 6., 9., 12., None)])
 def test_other_scale_counts(radii):
     kw, cfg, P, keys, query, Ts, time = SC.build_case(2, 5, 700, 60, radii=radii)
