@@ -268,16 +268,18 @@ template <int L> bool irreps_consistent(const IrrepsRT& K) {
 }
 // shapes with an edge-aligned-frame instantiation (dedf_kernel_list.h): the full-precision lmax-2 score head with the [128, 128, 64] radial network
 bool so2_instantiated(const dedf_config& c) {
-    if (c.half_gemm) return false;
-    if (c.unet_layer) {      // UNet layers (round 5): lmax 2 / 3 with the [64, 32, 32] radial network; DEDF_SO2_UNET=0 keeps them in the general form (A/B)
-        static const bool un_on = [] { const char* e = getenv("DEDF_SO2_UNET"); return !(e && atoi(e) == 0); }();
-        return un_on && c.lmax >= 2 && c.fc_neurons[0] == 64 && c.fc_neurons[1] == 32 && c.fc_neurons[2] == 32;
-    }
+    if (c.unet_layer)       // UNet layers (round 5): lmax 2 / 3 with the [64, 32, 32] radial network
+        return c.lmax >= 2 && c.fc_neurons[0] == 64 && c.fc_neurons[1] == 32 && c.fc_neurons[2] == 32;
     const int F0 = c.fc_neurons[0];
     const bool wide = c.fc_neurons[1] == 128 && c.fc_neurons[2] == 64, narrow = c.fc_neurons[1] == 32 && c.fc_neurons[2] == 32;
     if (c.lmax == 3) return (F0 == 128 && wide) || (F0 == 64 && (wide || narrow));
     if (c.lmax == 2) return ((F0 == 128 || F0 == 64) && (wide || narrow)) || (F0 == 192 && wide);
     return ((F0 == 128 || F0 == 64) && wide) || (F0 == 128 && narrow);
+}
+// the GENERAL form of the handle's full-precision edge kernels is instantiated too (so that DEDF_SO2=0 can select it): the headline shapes only
+bool general_instantiated(const dedf_config& c) {
+    if (c.half_gemm || c.unet_layer) return false;
+    return (c.lmax == 2 || c.lmax == 3) && c.fc_neurons[0] == 128 && c.fc_neurons[1] == 128 && c.fc_neurons[2] == 64;
 }
 template <int L> void pack_all(dedf_handle* h) {
     bool done = false;
@@ -444,19 +446,23 @@ inline int edge_wpc_limit() {      // experiments only: DEDF_EDGE_WAVES_PER_CU=1
 // Shapes with an edge-aligned-frame instantiation (dedf_kernel_list.h; dedf_edge.h: SO2): the full-precision score heads / critics / context-free
 // fields of lmax <= 2.  launch_edge picks it when the handle's image was packed for it (dedf_handle::so2).
 template <int L, int F0, bool HP, int H1, int H2, int MODE> constexpr bool so2_shape() {
-    if (HP) return false;
+    if (HP && MODE != 0) return false;      // (half precision evaluates per edge: no table-reading instantiation)
     if (L == 3) return MODE == 1 ? (F0 == 128 && H1 == 128) : ((F0 == 128 && H1 == 128) || F0 == 64);
     if (MODE == 1) return L == 2 && ((F0 == 128 && ((H1 == 128 && H2 == 64) || (H1 == 32 && H2 == 32))) || (F0 == 192 && H1 == 128 && H2 == 64));
     if (L == 2) return (F0 == 128 || F0 == 64) ? true : (F0 == 192 && H1 == 128);
     return (F0 == 128 || F0 == 64) && H1 == 128 ? true : (F0 == 128 && H1 == 32);      // lmax 1
 }
+// ... and the shapes whose GENERAL form is still instantiated: every half-precision one, and of the full-precision ones the headline shapes (A/B: DEDF_SO2=0)
+template <int L, int F0, bool HP, int H1, int H2, int MODE> constexpr bool general_shape() {
+    return (!so2_shape<L, F0, HP, H1, H2, MODE>()) || (!HP && (L == 2 || L == 3) && F0 == 128 && H1 == 128 && H2 == 64);
+}
 template <int L, int F0, bool HP, int H1, int H2, int MODE>
 void launch_edge(dedf_handle* h, hipStream_t st, const EdgeParams& P) {
     constexpr int kAll = 1 << 30;
     if constexpr (so2_shape<L, F0, HP, H1, H2, MODE>()) {
-        if (h->so2) { DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, HP, H1, H2, false, MODE, false, true>), kAll, st, P); return; }
+        if (h->so2 || !general_shape<L, F0, HP, H1, H2, MODE>()) { DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, HP, H1, H2, false, MODE, false, true>), kAll, st, P); return; }
     }
-    DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, HP, H1, H2, false, MODE>), kAll, st, P);
+    if constexpr (general_shape<L, F0, HP, H1, H2, MODE>()) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, HP, H1, H2, false, MODE>), kAll, st, P);
 }
 
 // parameters of the fused edge kernel for the current state of the handle
@@ -753,24 +759,24 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         } else if constexpr (L == 3) {          // lmax 3: full precision, [., 128, 64] (score head, EBM critic) or [64, 32, 32] (context-free fields)
             static_assert(F0 == 128 || F0 == 64, "lmax 3 instantiations");
             if constexpr (F0 == 64) {
-                if (narrow) { if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<3, 64, true, 32, 32>), kAll, st, P); else launch_edge<3, 64, false, 32, 32, 0>(h, st, P); }
-                else if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<3, 64, true>), kAll, st, P);
+                if (narrow) { if (hp) launch_edge<3, 64, true, 32, 32, 0>(h, st, P); else launch_edge<3, 64, false, 32, 32, 0>(h, st, P); }
+                else if (hp) launch_edge<3, 64, true, 128, 64, 0>(h, st, P);
                 else launch_edge<3, 64, false, 128, 64, 0>(h, st, P);
-            } else if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<3, 128, true>), kAll, st, P);
+            } else if (hp) launch_edge<3, 128, true, 128, 64, 0>(h, st, P);
             else launch_edge<3, 128, false, 128, 64, 0>(h, st, P);
         } else if constexpr (F0 == 128) {
             if (narrow) {         // narrow radial MLP (sapien place_*)
-                if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true, 32, 32>), kAll, st, P);
+                if (hp) launch_edge<L, F0, true, 32, 32, 0>(h, st, P);
                 else launch_edge<L, F0, false, 32, 32, 0>(h, st, P);
-            } else if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true>), kAll, st, P);
+            } else if (hp) launch_edge<L, F0, true, 128, 64, 0>(h, st, P);
             else if (L == 1 && h->edge_occ) {      // lmax 1: the two-waves-per-SIMD build of the same tile (dedf_kernels_occ.h)
                 if constexpr (L == 1) hipLaunchKernelGGL((k_edge_occ<1, 128, false>), dim3(h->n_cu * waves_per_cu<(k_edge_occ<1, 128, false>), 8>()), dim3(64), 0, st, P);
             } else launch_edge<L, F0, false, 128, 64, 0>(h, st, P);
         } else if constexpr (F0 == 64 && L == 2) {
-            if (narrow) { if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true, 32, 32>), kAll, st, P); else launch_edge<L, F0, false, 32, 32, 0>(h, st, P); }      // KeypointExtractor fields
-            else if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true>), kAll, st, P);
+            if (narrow) { if (hp) launch_edge<L, F0, true, 32, 32, 0>(h, st, P); else launch_edge<L, F0, false, 32, 32, 0>(h, st, P); }      // KeypointExtractor fields
+            else if (hp) launch_edge<L, F0, true, 128, 64, 0>(h, st, P);
             else launch_edge<L, F0, false, 128, 64, 0>(h, st, P);
-        } else if (hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, true>), kAll, st, P);
+        } else if (hp) launch_edge<L, F0, true, 128, 64, 0>(h, st, P);
         else launch_edge<L, F0, false, 128, 64, 0>(h, st, P);
     }
     mark();
@@ -912,7 +918,7 @@ int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, de
     if (const char* e = getenv("DEDF_EDGE_OCC")) h->edge_occ = atoi(e) != 0;
     if (const char* e = getenv("DEDF_EDGE16")) h->edge16 = atoi(e);
     h->so2 = so2_instantiated(*cfg) && !(cfg->lmax == 1 && h->edge_occ);
-    if (const char* e = getenv("DEDF_SO2")) h->so2 = h->so2 && atoi(e) != 0;
+    if (const char* e = getenv("DEDF_SO2")) h->so2 = h->so2 && (atoi(e) != 0 || !general_instantiated(*cfg));      // (A/B where both forms exist)
     const IrrepsRT T(h->L, cfg->unet_layer != 0), K(h->L, true);
     h->spec = build_spec(T, h->cfg);
     h->kspec = build_spec(K, h->cfg);
@@ -1369,12 +1375,10 @@ int layer_forward_impl(dedf_handle* h, int n_src, const float* x_src, const floa
         P.dbg_w = nullptr; P.dbg_out = nullptr; P.phase_prof = nullptr;
         static const bool nw_on = [] { const char* e = getenv("DEDF_UNET_NARROW"); return !(e && atoi(e) == 0); }();      // DEDF_UNET_NARROW=0: the general kernels (A/B)
         if (h->cfg.unet_narrow && nw_on) {      // narrow level: the instantiations that skip the structurally zero channels (dedf_net.h::pad_live)
-            if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, true, 32, 32, true, 0, true>), 1 << 30, st, P);
-            else if (h->so2) DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, false, 32, 32, true, 0, true, true>), 1 << 30, st, P);      // edge-aligned frame (round 5)
-            else DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, false, 32, 32, true, 0, true>), 1 << 30, st, P);
-        } else if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, true, 32, 32, true>), 1 << 30, st, P);
-        else if (h->so2) DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, false, 32, 32, true, 0, false, true>), 1 << 30, st, P);
-        else DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, false, 32, 32, true>), 1 << 30, st, P);
+            if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, true, 32, 32, true, 0, true, true>), 1 << 30, st, P);
+            else DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, false, 32, 32, true, 0, true, true>), 1 << 30, st, P);      // full precision: edge-aligned frame (round 5)
+        } else if (h->cfg.half_gemm) DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, true, 32, 32, true, 0, false, true>), 1 << 30, st, P);
+        else DEDF_LAUNCH_PERSISTENT((k_edge<L, 64, false, 32, 32, true, 0, false, true>), 1 << 30, st, P);
     }
     hipLaunchKernelGGL(k_aggregate<L>, dim3((n_dst + 3) / 4), dim3(256), 0, st, w->d_eout.as<float>(), w->d_cnt.as<int>(), w->d_off.as<int>(),
                        w->d_tile.as<int>(), n_dst, 1, w->d_z.as<float>());

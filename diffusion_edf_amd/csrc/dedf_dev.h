@@ -277,6 +277,27 @@ DEDF_DEV HL split8z(const float (&x)[8]) {
     return split8(y);
 #endif
 }
+// Half-precision mode (HP: every GEMM is ONE fp16 product): only the hi halves exist -- four conversions instead of twelve instructions.
+// (Round 5; until then the HP kernels formed the residual halves too and never used them.)
+DEDF_DEV HL split8_hi(const float (&x)[8]) {
+    HL r;
+#if defined(__HIP_DEVICE_COMPILE__) && DEDF_SPLIT_MIX
+    unsigned hp[4];
+    asm volatile("v_cvt_pk_f16_f32 %0, %4, %5\n\tv_cvt_pk_f16_f32 %1, %6, %7\n\tv_cvt_pk_f16_f32 %2, %8, %9\n\tv_cvt_pk_f16_f32 %3, %10, %11"
+                 : "=&v"(hp[0]), "=&v"(hp[1]), "=&v"(hp[2]), "=&v"(hp[3])
+                 : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+    r.hi = __builtin_bit_cast(h8, u32x4{hp[0], hp[1], hp[2], hp[3]});
+#else
+    static_for<8>([&]<int J>() { r.hi[J] = (_Float16)x[J]; });
+#endif
+    r.lo = h8{};
+    return r;
+}
+template <bool HP> DEDF_DEV HL split8x(const float (&x)[8]) { if constexpr (HP) return split8_hi(x); else return split8(x); }
+template <bool HP> DEDF_DEV HL split8zx(const float (&x)[8]) {
+    if constexpr (HP) { const float y[8] = {x[0], x[1], 0.0f, 0.0f, x[4], x[5], 0.0f, 0.0f}; return split8_hi(y); }
+    else return split8z(x);
+}
 // float(half HALF of `hi_pair`) + float(half HALF of `lo_pair`): a split value back in fp32 (exact: the sum of a hi / lo pair IS the 22-bit operand)
 // in ONE mixed-precision FMA -- hipcc turns (float)h + (float)l into two conversions and an add.
 template <int HALF> DEDF_DEV float unsplit(unsigned hi_pair, unsigned lo_pair) {
@@ -358,7 +379,7 @@ DEDF_DEV void dense_rot_h(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[NT
         sched_fence();
         float t[8];
         static_for<8>([&]<int J>() { t[J] = bsrc.template operator()<c, J>(); });
-        const HL b = split8(t);
+        const HL b = split8x<HP>(t);
         if constexpr (c + PD < NCH) {
             const int lv = tie(wv.lane16, __builtin_bit_cast(f32x4, b.hi)[0]);
             static_for<NTO>([&]<int To>() {
@@ -384,6 +405,11 @@ DEDF_DEV HL split8(const float (&x)[8], float scale) {
     float t[8];
     static_for<8>([&]<int J>() { t[J] = x[J] * scale; });
     return split8(t);
+}
+template <bool HP> DEDF_DEV HL split8sx(const float (&x)[8], float scale) {
+    float t[8];
+    static_for<8>([&]<int J>() { t[J] = x[J] * scale; });
+    return split8x<HP>(t);
 }
 // Same with the B chunks already split:  bh.operator()<chunk>() -> HL
 template <int NTO, int NCH, int PD = 2, bool HP = false, class BF>

@@ -299,11 +299,11 @@ DEDF_DEV void mfma_chunk(const Wave& wv, int o_str, AItem (&ring)[PD], const BOp
 }
 // split the chunk's fp32 products v[m][8] into B operands
 // (PADZ: elements 2, 3, 6, 7 are the zero padding of the chunk's input channels, dedf_net.h::pad_reg)
-template <int L, int l3, bool PADZ = false>
+template <int L, int l3, bool PADZ = false, bool HP = false>
 DEDF_DEV void split_chunk(const float (&v)[2 * l3 + 1][8], BOpsH<L>& o) {
     static_for<2 * l3 + 1>([&]<int K>() {
         HL sp;
-        if constexpr (PADZ) sp = split8z(v[K]); else sp = split8(v[K]);
+        if constexpr (PADZ) sp = split8zx<HP>(v[K]); else sp = split8x<HP>(v[K]);
         o.hi[K] = sp.hi; o.lo[K] = sp.lo;
     });
 }
@@ -685,7 +685,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             pk[DEDF_PSLOT(park_phys<L>(Q)) * 64] = split4pk(v4);
         } else {
             HL sp;
-            if constexpr (PADZ) sp = split8z(v); else sp = split8(v);
+            if constexpr (PADZ) sp = split8zx<HP>(v); else sp = split8x<HP>(v);
             pk[DEDF_PSLOT(park_phys<L>(Q)) * 64] = __builtin_bit_cast(f32x4, sp.hi);
             if constexpr (!HP) pk[DEDF_PSLOT(park_phys<L>(Q) + 1) * 64] = __builtin_bit_cast(f32x4, sp.lo);
         }
@@ -788,7 +788,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                         else v[jj] = wr[t][jj] * xrot[jj][I];
                     });
                     HL sp;
-                    if constexpr (pad_reg<L, NW>(l1, 2)) sp = split8z(v); else sp = split8(v);
+                    if constexpr (pad_reg<L, NW>(l1, 2)) sp = split8zx<HP>(v); else sp = split8x<HP>(v);
                     o.hi[t] = sp.hi; o.lo[t] = sp.lo;
                 });
             } else
@@ -806,7 +806,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                         }
                     }); });
                 });
-                static_for<d1>([&]<int I>() { HL sp; if constexpr (pad_reg<L, NW>(l1, 2)) sp = split8z(v[I]); else sp = split8(v[I]); o.hi[I] = sp.hi; o.lo[I] = sp.lo; });
+                static_for<d1>([&]<int I>() { HL sp; if constexpr (pad_reg<L, NW>(l1, 2)) sp = split8zx<HP>(v[I]); else sp = split8x<HP>(v[I]); o.hi[I] = sp.hi; o.lo[I] = sp.lo; });
             } else {
             float m[Cg::NM];
             Cg::make(Y.template get<l2>(), m);
@@ -825,7 +825,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                     }
                 });
             });
-            split_chunk<L, l3, pad_reg<L, NW>(l1, 2)>(v, o);
+            split_chunk<L, l3, pad_reg<L, NW>(l1, 2), HP>(v, o);
             }
         }
         return o;
@@ -1047,7 +1047,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         static_for<KC>([&]<int c>() {
             float t[8];
             static_for<8>([&]<int J>() { t[J] = r2[c / 2][8 * (c % 2) + J]; });
-            r2s[c] = split8(t);
+            r2s[c] = split8x<HP>(t);
             if constexpr (R2S_LDS) {
                 pk[DEDF_PSLOT(R2S_SLOT + 2 * c) * 64] = __builtin_bit_cast(f32x4, r2s[c].hi);
                 if constexpr (!HP) pk[DEDF_PSLOT(R2S_SLOT + 2 * c + 1) * 64] = __builtin_bit_cast(f32x4, r2s[c].lo);
@@ -1579,7 +1579,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 });
                 static_for<it.share_b ? 1 : it.na>([&]<int a>() {
                     HL sp;
-                    if constexpr (pad_reg<L, NW>(l1, 2)) sp = split8z(v[it.comp[a]]); else sp = split8(v[it.comp[a]]);
+                    if constexpr (pad_reg<L, NW>(l1, 2)) sp = split8zx<HP>(v[it.comp[a]]); else sp = split8x<HP>(v[it.comp[a]]);
                     o.h[a] = __builtin_bit_cast(f32x4, sp.hi);
                     if constexpr (!HP) o.l[a] = __builtin_bit_cast(f32x4, sp.lo);
                 });

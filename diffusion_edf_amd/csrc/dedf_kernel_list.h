@@ -2,21 +2,18 @@
 // edit of the list touches (a unit is rebuilt when its own lines or one of the kernel headers change, not when another unit's lines do).
 #pragma once
 // every instantiation the library launches: X(unit, declaration)
+// (Round 5: the full-precision kernels run in the edge-aligned frame -- the instantiations with the trailing `true`.  The GENERAL form of a
+//  full-precision shape is kept only where it serves the A/B switch DEDF_SO2=0: the headline shapes <2 | 3, 128, false, 128, 64> per edge and
+//  table-reading.  Half precision (HP) runs in the edge frame only.  Unit numbers of dropped instantiations are left unused.)
 #define DEDF_KERNEL_LIST(X)                                           \
     X(0, void k_edge<2, 128, false>(EdgeParams))                      \
-    X(1, void k_edge<2, 128, true>(EdgeParams))                       \
-    X(2, void k_edge<2, 64, false>(EdgeParams))                       \
-    X(3, void k_edge<2, 192, false>(EdgeParams))                      \
-    X(4, void k_edge<1, 64, false>(EdgeParams))                       \
-    X(4, void k_edge<1, 128, false>(EdgeParams))                      \
-    X(4, void k_edge<1, 128, true>(EdgeParams))                       \
-    X(7, void k_edge<2, 128, false, 32, 32>(EdgeParams))              \
-    X(7, void k_edge<1, 128, false, 32, 32>(EdgeParams))              \
-    X(8, void k_edge<2, 192, true>(EdgeParams))                       \
-    X(8, void k_edge<2, 64, true>(EdgeParams))                        \
-    X(9, void k_edge<2, 128, true, 32, 32>(EdgeParams))               \
-    X(9, void k_edge<1, 64, true>(EdgeParams))                        \
-    X(9, void k_edge<1, 128, true, 32, 32>(EdgeParams))               \
+    X(1, void k_edge<2, 128, true, 128, 64, false, 0, false, true>(EdgeParams)) \
+    X(4, void k_edge<1, 128, true, 128, 64, false, 0, false, true>(EdgeParams)) \
+    X(8, void k_edge<2, 192, true, 128, 64, false, 0, false, true>(EdgeParams)) \
+    X(8, void k_edge<2, 64, true, 128, 64, false, 0, false, true>(EdgeParams))  \
+    X(9, void k_edge<2, 128, true, 32, 32, false, 0, false, true>(EdgeParams))  \
+    X(9, void k_edge<1, 64, true, 128, 64, false, 0, false, true>(EdgeParams))  \
+    X(9, void k_edge<1, 128, true, 32, 32, false, 0, false, true>(EdgeParams))  \
     X(9, void k_node<2, true, true>(NodeParams))                      \
     X(9, void k_node<1, true, true>(NodeParams))                      \
     X(5, void k_node<2, false, false>(NodeParams))                    \
@@ -25,42 +22,33 @@
     X(6, void k_node<1, false, false>(NodeParams))                    \
     X(6, void k_node<1, false, true>(NodeParams))                     \
     X(6, void k_node<1, true, false>(NodeParams))                     \
-    X(10, void k_edge<2, 64, false, 32, 32, true>(EdgeParams))        \
     X(10, void k_node<2, false, false, true>(NodeParams))             \
-    X(11, void k_edge<2, 64, false, 32, 32>(EdgeParams))              \
     X(12, void k_edge<2, 128, false, 128, 64, false, 1>(EdgeParams))  \
     X(11, void k_radial_table<2, 128>(EdgeParams))                    \
     X(11, void k_radial_check<2, 128>(EdgeParams))                    \
-    X(13, void k_edge<2, 192, false, 128, 64, false, 1>(EdgeParams))  \
     X(10, void k_radial_table<2, 192>(EdgeParams))                    \
     X(10, void k_radial_check<2, 192>(EdgeParams))                    \
-    X(14, void k_edge<2, 128, false, 32, 32, false, 1>(EdgeParams))   \
     X(10, void k_radial_table<2, 128, false, 32, 32>(EdgeParams))     \
     X(10, void k_radial_check<2, 128, false, 32, 32>(EdgeParams))     \
-    X(15, void k_edge<2, 64, true, 32, 32, true>(EdgeParams))         \
+    X(15, void k_edge<2, 64, true, 32, 32, true, 0, false, true>(EdgeParams))   \
     X(15, void k_node<2, false, true, true>(NodeParams))               \
     X(16, void k_edge<3, 128, false>(EdgeParams))                     \
     X(17, void k_node<3, false, false>(NodeParams))                   \
-    X(18, void k_edge<3, 64, false>(EdgeParams))                      \
     X(17, void k_node<3, true, false>(NodeParams))                    \
-    X(19, void k_edge<3, 64, false, 32, 32, true>(EdgeParams))        \
     X(20, void k_node<3, false, false, true>(NodeParams))             \
-    X(21, void k_edge<3, 64, true, 32, 32, true>(EdgeParams))         \
+    X(21, void k_edge<3, 64, true, 32, 32, true, 0, false, true>(EdgeParams))   \
     X(20, void k_node<3, false, true, true>(NodeParams))              \
     X(22, void k_edge<3, 128, false, 128, 64, false, 1>(EdgeParams))  \
     X(23, void k_radial_table<3, 128>(EdgeParams))                    \
     X(23, void k_radial_check<3, 128>(EdgeParams))                    \
-    X(23, void k_edge<3, 64, false, 32, 32>(EdgeParams))              \
-    X(24, void k_edge<3, 128, true>(EdgeParams))                      \
-    X(25, void k_edge<3, 64, true>(EdgeParams))                       \
-    X(26, void k_edge<3, 64, true, 32, 32>(EdgeParams))               \
+    X(24, void k_edge<3, 128, true, 128, 64, false, 0, false, true>(EdgeParams)) \
+    X(25, void k_edge<3, 64, true, 128, 64, false, 0, false, true>(EdgeParams))  \
+    X(26, void k_edge<3, 64, true, 32, 32, false, 0, false, true>(EdgeParams))   \
     X(25, void k_node<3, false, true>(NodeParams))                    \
     X(26, void k_node<3, true, true>(NodeParams))                     \
-    X(27, void k_edge<2, 64, true, 32, 32>(EdgeParams))               \
-    X(28, void k_edge<2, 64, false, 32, 32, true, 0, true>(EdgeParams)) \
-    X(29, void k_edge<3, 64, false, 32, 32, true, 0, true>(EdgeParams)) \
-    X(30, void k_edge<2, 64, true, 32, 32, true, 0, true>(EdgeParams))  \
-    X(31, void k_edge<3, 64, true, 32, 32, true, 0, true>(EdgeParams))  \
+    X(27, void k_edge<2, 64, true, 32, 32, false, 0, false, true>(EdgeParams))   \
+    X(30, void k_edge<2, 64, true, 32, 32, true, 0, true, true>(EdgeParams))  \
+    X(31, void k_edge<3, 64, true, 32, 32, true, 0, true, true>(EdgeParams))  \
     X(32, void k_edge<2, 128, false, 128, 64, false, 0, false, true>(EdgeParams)) \
     X(33, void k_edge<2, 128, false, 128, 64, false, 1, false, true>(EdgeParams)) \
     X(34, void k_edge<2, 128, false, 32, 32, false, 0, false, true>(EdgeParams))  \

@@ -54,15 +54,15 @@ template <int L> struct Feat {                 // one node's features in row lay
 };
 // the same features as split-fp16 B operands: chunks of 16 channels (8 registers of a row-layout tile), scaled by 2^kNodeBShift
 template <int L> struct FeatH { HL s[4], v1[3][2], v2[5][1], v3[7][1]; };
-template <int L> DEDF_DEV FeatH<L> split_feat(const Feat<L>& f, const float sc) {
+template <int L, bool HP = false> DEDF_DEV FeatH<L> split_feat(const Feat<L>& f, const float sc) {
     FeatH<L> o;
-    static_for<4>([&]<int c>() { float t[8]; static_for<8>([&]<int J>() { t[J] = f.s[c / 2][8 * (c % 2) + J]; }); o.s[c] = split8(t, sc); });
+    static_for<4>([&]<int c>() { float t[8]; static_for<8>([&]<int J>() { t[J] = f.s[c / 2][8 * (c % 2) + J]; }); o.s[c] = split8sx<HP>(t, sc); });
     if constexpr (L >= 1) static_for<3>([&]<int m>() { static_for<2>([&]<int c>() {
-        float t[8]; static_for<8>([&]<int J>() { t[J] = f.v1[m][8 * c + J]; }); o.v1[m][c] = split8(t, sc); }); });
+        float t[8]; static_for<8>([&]<int J>() { t[J] = f.v1[m][8 * c + J]; }); o.v1[m][c] = split8sx<HP>(t, sc); }); });
     if constexpr (L >= 2) static_for<5>([&]<int m>() {
-        float t[8]; static_for<8>([&]<int J>() { t[J] = f.v2[m][J]; }); o.v2[m][0] = split8(t, sc); });
+        float t[8]; static_for<8>([&]<int J>() { t[J] = f.v2[m][J]; }); o.v2[m][0] = split8sx<HP>(t, sc); });
     if constexpr (L >= 3) static_for<7>([&]<int m>() {
-        float t[8]; static_for<8>([&]<int J>() { t[J] = f.v3[m][J]; }); o.v3[m][0] = split8(t, sc); });
+        float t[8]; static_for<8>([&]<int J>() { t[J] = f.v3[m][J]; }); o.v3[m][0] = split8sx<HP>(t, sc); });
     return o;
 }
 
@@ -174,7 +174,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0, int tp_only
     // ---- proj: per-l dense matrix (+ bias on 0e); all GEMMs of this kernel are 3-term split-fp16 MFMA products -----------------
     Feat<L> emb;
     {
-        const FeatH<L> zh = split_feat<L>(z, opaque_s(P.sc.bz));
+        const FeatH<L> zh = split_feat<L, HP>(z, opaque_s(P.sc.bz));
         f32x16 a0[2];
         static_for<2>([&]<int To>() { a0[To] = node_ldrows(rows, hi, NR::b_proj0, To); });
         dense_rot_hp<2, 4, 2, HP>(wv, O.A_proj[0], O.A_proj_l[0], a0, [&]<int c>() { return zh.s[c]; });
@@ -254,7 +254,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0, int tp_only
     __shared__ f32x4 fpark[(L >= 3 ? FS3 + 14 : FS2 + 10) * 64];
     f32x4* const fp = fpark + wv.lane;
     auto park = [&](const Feat<L>& f, const float bscale) {
-        const FeatH<L> fh = split_feat<L>(f, bscale);
+        const FeatH<L> fh = split_feat<L, HP>(f, bscale);
         static_for<4>([&]<int c>() { fp[(2 * c) * 64] = __builtin_bit_cast(f32x4, fh.s[c].hi); fp[(2 * c + 1) * 64] = __builtin_bit_cast(f32x4, fh.s[c].lo); });
         if constexpr (L >= 1) static_for<3>([&]<int m>() { static_for<2>([&]<int c>() {
             fp[(FS1 + 4 * m + 2 * c) * 64] = __builtin_bit_cast(f32x4, fh.v1[m][c].hi);
@@ -290,7 +290,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0, int tp_only
         dense_rot_hp<2, 12, 2, HP>(wv, O.A_f2[0], O.A_f2_l[0], o0, [&]<int c>() {
             float t[8];
             static_for<8>([&]<int J>() { t[J] = hs[c / 2][8 * (c % 2) + J]; });
-            return split8(t, bh0);
+            return split8sx<HP>(t, bh0);
         });
         const float c2 = opaque_s(P.sc.f2[0]);
         static_for<2>([&]<int T>() { static_for<16>([&]<int R>() { fld.s[T][R] = o0[T][R] * c2 + emb.s[T][R]; }); });
@@ -317,7 +317,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0, int tp_only
         dense_shared_hp<3, 6, 2, HP>(wv, O.A_f2[1], O.A_f2_l[1], 6, 0, o, [&]<int m, int c>() {
             float t[8];
             static_for<8>([&]<int J>() { t[J] = hh[c / 2][m][8 * (c % 2) + J]; });
-            return split8(t, bh1);
+            return split8sx<HP>(t, bh1);
         });
         const float c2 = opaque_s(P.sc.f2[1]);
         static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { fld.v1[m][R] = o[m][R] * c2 + emb.v1[m][R]; }); });
@@ -335,7 +335,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0, int tp_only
         dense_shared_hp<5, 3, 2, HP>(wv, O.A_f2[2], O.A_f2_l[2], 3, 0, o, [&]<int m, int c>() {
             float t[8];
             static_for<8>([&]<int J>() { t[J] = hh[c / 2][m][8 * (c % 2) + J]; });
-            return split8(t, bh2);
+            return split8sx<HP>(t, bh2);
         });
         const float c2 = opaque_s(P.sc.f2[2]);
         static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { fld.v2[m][R] = o[m][R] * c2 + emb.v2[m][R]; }); });
@@ -353,7 +353,7 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0, int tp_only
         dense_shared_hp<7, 2, 2, HP>(wv, O.A_f2[3], O.A_f2_l[3], 2, 0, o, [&]<int m, int c>() {
             float t[8];
             static_for<8>([&]<int J>() { t[J] = hh[m][8 * c + J]; });
-            return split8(t, bh3);
+            return split8sx<HP>(t, bh3);
         });
         const float c2 = opaque_s(P.sc.f2[3]);
         static_for<7>([&]<int m>() { static_for<8>([&]<int R>() { fld.v3[m][R] = o[m][R] * c2 + emb.v3[m][R]; }); });
@@ -541,12 +541,12 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0, int tp_only
                     });
                     const h8 ah = __builtin_bit_cast(h8, slh[cc]), al = __builtin_bit_cast(h8, sll[cc]);
                     if constexpr (l3 == 0) {
-                        const HL b = split8(a[0], bsc);
+                        const HL b = split8sx<HP>(a[0], bsc);
                         gacc = mfma_h(ah, b.hi, gacc);
                         if constexpr (!HP) { gacc = mfma_h(ah, b.lo, gacc); gacc = mfma_h(al, b.hi, gacc); }
                     } else {
                         HL b[3];
-                        static_for<3>([&]<int K>() { b[K] = split8(a[K], bsc); });
+                        static_for<3>([&]<int K>() { b[K] = split8sx<HP>(a[K], bsc); });
                         static_for<3>([&]<int K>() { vacc[K] = mfma_h(ah, b[K].hi, vacc[K]); });
                         if constexpr (!HP) {
                             static_for<3>([&]<int K>() { vacc[K] = mfma_h(ah, b[K].lo, vacc[K]); });

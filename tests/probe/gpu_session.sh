@@ -1,8 +1,8 @@
-mkdir -p gpurun_out
-T=r05t
-python -m pytest tests/test_unet.py tests/test_lmax3.py tests/test_keypoint_extractor.py tests/test_config5.py tests/test_agent.py -m gpu -q --durations=5 > gpurun_out/${T}_unet_suite.log 2>&1
-python tests/probe/unet_time.py > gpurun_out/${T}_unet_time.log 2>&1
-DEDF_SO2_UNET=0 python tests/probe/unet_time.py > gpurun_out/${T}_unet_time_general.log 2>&1
-python tests/probe/unet_time.py >> gpurun_out/${T}_unet_time.log 2>&1
-DEDF_SO2_UNET=0 python tests/probe/unet_time.py >> gpurun_out/${T}_unet_time_general.log 2>&1
-tail -6 gpurun_out/${T}_unet_suite.log; grep -v amdgpu gpurun_out/${T}_unet_time.log; echo general; grep -v amdgpu gpurun_out/${T}_unet_time_general.log
+#!/bin/bash
+# scratch driver for one gpurun call (rewritten per session)
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
+python -m pytest tests -x -q -m gpu -k "half" > gpurun_out/r05v_half_tests.log 2>&1; tail -3 gpurun_out/r05v_half_tests.log
+python bench.py --gpus 1 --steps 20 --warmup 5 --half > gpurun_out/r05v_half_bench.json 2> gpurun_out/r05v_half_bench.err; tail -c 600 gpurun_out/r05v_half_bench.json
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r05v_bench.json 2> gpurun_out/r05v_bench.err
+python bench.py --gpus 1 --steps 20 --warmup 5 --half --lmax 3 > gpurun_out/r05v_half_lmax3_bench.json 2>&1
+python -m pytest tests -x -q -m gpu --durations=5 > gpurun_out/r05v_gpu_suite.log 2>&1; tail -3 gpurun_out/r05v_gpu_suite.log
