@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("DEDF_LIB") or os.path.join(os.path.dirname(os.path.a
 MAX_SCALES = 8
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_RUNTIME = 0, 1, 2, 3
-ABI_VERSION = 5          # DEDF_ABI_VERSION of include/dedf.h this binding mirrors
+ABI_VERSION = 6          # DEDF_ABI_VERSION of include/dedf.h this binding mirrors
 
 SYMBOLS = [
     "dedf_version", "dedf_abi_version", "dedf_struct_size", "dedf_param_count", "dedf_param_name", "dedf_param_numel", "dedf_create", "dedf_destroy",
@@ -32,6 +32,7 @@ class DedfConfig(C.Structure):
         ("max_time", C.c_float), ("time_enc_n", C.c_float), ("lin_mult", C.c_float), ("ang_mult", C.c_float),
         ("max_neighbors", C.c_int), ("device", C.c_int), ("max_edges", C.c_int64), ("ebm", C.c_int), ("half_gemm", C.c_int), ("use_src_point_attn", C.c_int),
         ("unet_layer", C.c_int), ("unet_valid", C.c_int * 4), ("unet_fc_valid", C.c_int * 3), ("unet_narrow", C.c_int),
+        ("query_time_encoding", C.c_int),
     ]
 
 
@@ -151,6 +152,7 @@ def make_config(cfg: HeadConfig, device: int, max_edges: int = 0) -> DedfConfig:
     c.half_gemm = int(getattr(cfg, 'half_gemm', False))
     c.use_src_point_attn = int(getattr(cfg, 'use_src_point_attn', False))
     c.unet_layer = 0
+    c.query_time_encoding = int(getattr(cfg, 'query_time_encoding', False))
     return c
 
 

@@ -73,6 +73,7 @@ struct dedf_handle {
     // device: weights
     DevBuf d_edge_w, d_node_w, d_nat;     // d_nat: natural-layout weights for the small kernels
     size_t nat_tw1 = 0, nat_tb1 = 0, nat_tw2 = 0, nat_tb2 = 0, nat_wpre = 0, nat_bpre = 0, nat_lnw = 0, nat_lnb = 0, nat_wsrc = 0, nat_bsrc = 0, nat_tfreq = 0, nat_brows = 0, nat_wdst = 0, nat_bdst = 0;
+    size_t nat_qw1 = 0, nat_qb1 = 0, nat_qw2 = 0, nat_qb2 = 0, nat_qlnw = 0, nat_qlnb = 0, nat_qwdst = 0, nat_qbdst = 0, nat_qwskip = 0, nat_qbskip = 0;      // query_time_encoding
     DevBuf d_msg_dst;
     // device: scene / query
     DevBuf d_key_x, d_key_f, d_msg, d_qx, d_qf, d_qw;
@@ -82,6 +83,7 @@ struct dedf_handle {
     // device: per call
     DevBuf d_key_w; bool have_key_w = false;              // key-point attention weights (use_src_point_attn)
     const LangevinParams* fused_step = nullptr;           // dedf_sample: the per-pose reduction also carries this step's Langevin update
+    DevBuf d_qrows, d_qrows_steps;                        // query_time_encoding: time rows (dedf_misc.h::k_time_query) of the poses of a call / of ALL steps of dedf_sample
     DevBuf d_tb_steps; const float* tb_step = nullptr;    // dedf_sample: the time-bias rows of ALL steps are computed up front; tb_step = this step's rows
     std::vector<float> h_tsteps;
     // Pinned host block of dedf_sample (round 5: per-call overhead): [0, 64) ints = the tile_info block of the finished call, [64, 72) = the radial
@@ -247,6 +249,8 @@ int check_config(const dedf_config* c, std::string& why) {
     if (c->length_emb_dim != kLenEmb) { why = "length_emb_dim must be 64"; return DEDF_ERR_UNSUPPORTED; }
     if (c->irreps_mlp_mid != kMlpMid) { why = "irreps_mlp_mid must be 3"; return DEDF_ERR_UNSUPPORTED; }
     if (c->half_gemm && c->lmax == 1 && c->fc_neurons[0] == 192) { why = "lmax 1 with a 128-channel time embedding is not instantiated"; return DEDF_ERR_UNSUPPORTED; }
+    if (c->query_time_encoding && (c->ebm || c->half_gemm || c->lmax < 2 || c->fc_neurons[0] != 128 || !mlp_wide)) {
+        why = "query_time_encoding is instantiated for the score head with fc_neurons [128,128,64] at lmax 2 and 3, full precision"; return DEDF_ERR_UNSUPPORTED; }
     if (c->n_scales < 1 || c->n_scales > kMaxScales) { why = "n_scales out of range"; return DEDF_ERR_INVALID; }
     bool inf = false;
     for (int n = 0; n < c->n_scales; ++n) {
@@ -278,7 +282,7 @@ bool so2_instantiated(const dedf_config& c) {
 }
 // the GENERAL form of the handle's full-precision edge kernels is instantiated too (so that DEDF_SO2=0 can select it): the headline shapes only
 bool general_instantiated(const dedf_config& c) {
-    if (c.half_gemm || c.unet_layer) return false;
+    if (c.half_gemm || c.unet_layer || c.query_time_encoding) return false;
     return (c.lmax == 2 || c.lmax == 3) && c.fc_neurons[0] == 128 && c.fc_neurons[1] == 128 && c.fc_neurons[2] == 64;
 }
 template <int L> void pack_all(dedf_handle* h) {
@@ -346,7 +350,16 @@ int upload_weights(dedf_handle* h) {
     h->nat_lnw = put(S.get(B, blk + ".prenorm_src.affine_weight"), nirr);
     h->nat_lnb = put(S.get(B, blk + ".prenorm_src.affine_bias"), mul_of(0));
     h->nat_wsrc = put(S.get(B, blk + ".linear_src.tp.weight"), sq);
-    h->nat_bsrc = put(S.get(B, blk + ".linear_src.bias.0"), mul_of(0));
+    if (!c.query_time_encoding) h->nat_bsrc = put(S.get(B, blk + ".linear_src.bias.0"), mul_of(0));
+    else {      // use_dst_feature: linear_src has no bias (gnn_block.py:127); the query-side time MLP and the three small matrices the time rows go through
+        const std::vector<float> zero(mul_of(0), 0.0f);
+        h->nat_bsrc = put(zero.data(), zero.size());
+        h->nat_qw1 = put(S.get(B, "query_time_mlp.0.weight"), tH * tE); h->nat_qb1 = put(S.get(B, "query_time_mlp.0.bias"), tH);
+        h->nat_qw2 = put(S.get(B, "query_time_mlp.2.weight"), tT * tH); h->nat_qb2 = put(S.get(B, "query_time_mlp.2.bias"), tT);
+        h->nat_qlnw = put(S.get(B, blk + ".prenorm_dst.affine_weight"), tT); h->nat_qlnb = put(S.get(B, blk + ".prenorm_dst.affine_bias"), tT);
+        h->nat_qwdst = put(S.get(B, blk + ".linear_dst.tp.weight"), tT * mul_of(0)); h->nat_qbdst = put(S.get(B, blk + ".linear_dst.bias.0"), mul_of(0));
+        h->nat_qwskip = put(S.get(B, blk + ".skip_1.skip.tp.weight"), tT * mul_of(0)); h->nat_qbskip = put(S.get(B, blk + ".skip_1.skip.bias.0"), mul_of(0));
+    }
     {   // time-encoding frequencies, evaluated like torch: exp(float(k) * float(-ln(n)/127)) in float32
         const int half = c.time_emb_mlp[0] / 2;
         std::vector<float> fr(half);
@@ -398,6 +411,7 @@ int ensure_workspace(dedf_handle* h, int nT) {
         ok = ok && h->d_mask.ensure(words * Nd * 4);
     }
     if (ok && h->debug) ok = h->d_dbgw.ensure((size_t)cap * WN * 4);
+    if (ok && h->cfg.query_time_encoding) ok = h->d_qrows.ensure((size_t)nT * kQueryTimeRow * 4);
     if (!ok) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(workspace) failed");
     if (h->d_eout.bytes >= (1ull << 32) || h->d_z.bytes >= (1ull << 32))
         ;   // buffer descriptors address 4 GiB: z is read through one (see launch), eout is written with flat stores
@@ -415,6 +429,30 @@ void launch_time_bias(dedf_handle* h, hipStream_t st, const float* time, int tim
     tp.E = c.time_emb_mlp[0]; tp.H = c.time_emb_mlp[1]; tp.TE = c.time_emb_mlp[2];
     tp.max_time = c.max_time; tp.time_enc_n = c.time_enc_n; tp.tb = tb; tp.varies = varies;
     hipLaunchKernelGGL(k_time_bias, dim3(rows, c.n_scales), dim3(256), 0, st, tp);
+}
+
+// query_time_encoding: the time rows (dedf_misc.h::k_time_query) for `rows` times read at time[row * time_stride]
+void launch_time_query(dedf_handle* h, hipStream_t st, const float* time, int time_stride, int rows, float* out) {
+    const dedf_config& c = h->cfg;
+    const float* nat = h->d_nat.as<float>();
+    TimeQueryParams tp{};
+    tp.time = time; tp.time_stride = time_stride;
+    tp.w1 = nat + h->nat_qw1; tp.b1 = nat + h->nat_qb1; tp.w2 = nat + h->nat_qw2; tp.b2 = nat + h->nat_qb2;
+    tp.ln_w = nat + h->nat_qlnw; tp.ln_b = nat + h->nat_qlnb; tp.wdst = nat + h->nat_qwdst; tp.bdst = nat + h->nat_qbdst;
+    tp.wskip = nat + h->nat_qwskip; tp.bskip = nat + h->nat_qbskip; tp.tfreq = nat + h->nat_tfreq;
+    tp.E = c.time_emb_mlp[0]; tp.H = c.time_emb_mlp[1]; tp.TE = c.time_emb_mlp[2];
+    tp.max_time = c.max_time; tp.time_enc_n = c.time_enc_n; tp.out_scale = h->eo.msg_scale; tp.rows = out;
+    hipLaunchKernelGGL(k_time_query, dim3(rows), dim3(256), 0, st, tp);
+}
+// ... and where the current evaluation reads them: this step's row inside dedf_sample (h->tb_step names the step), else one row per pose / one shared row
+const float* query_time_rows(dedf_handle* h, int time_stride, int& pose_stride) {
+    if (h->tb_step != nullptr) {
+        const size_t step = (size_t)(h->tb_step - h->d_tb_steps.as<float>()) / ((size_t)h->cfg.n_scales * h->cfg.fc_neurons[0]);
+        pose_stride = 0;
+        return h->d_qrows_steps.as<float>() + step * kQueryTimeRow;
+    }
+    pose_stride = time_stride ? kQueryTimeRow : 0;
+    return h->d_qrows.as<float>();
 }
 
 // Persistent grids: as many waves per CU as are RESIDENT at once (4 for the 512-register kernels with <= 40 KB of LDS -- every k_edge / k_node
@@ -459,6 +497,10 @@ template <int L, int F0, bool HP, int H1, int H2, int MODE> constexpr bool gener
 template <int L, int F0, bool HP, int H1, int H2, int MODE>
 void launch_edge(dedf_handle* h, hipStream_t st, const EdgeParams& P) {
     constexpr int kAll = 1 << 30;
+    if (h->cfg.query_time_encoding) {      // (validate_config admits only these shapes)
+        if constexpr ((L == 2 || L == 3) && F0 == 128 && !HP && H1 == 128 && H2 == 64 && MODE <= 1) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, false, 128, 64, false, MODE, false, true, true>), kAll, st, P);
+        return;
+    }
     if constexpr (so2_shape<L, F0, HP, H1, H2, MODE>()) {
         if (h->so2 || !general_shape<L, F0, HP, H1, H2, MODE>()) { DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, HP, H1, H2, false, MODE, false, true>), kAll, st, P); return; }
     }
@@ -482,6 +524,11 @@ EdgeParams edge_params(dedf_handle* h, int nT, int time_stride) {
         P.tb = h->tb_step ? h->tb_step : h->d_tb.as<float>();
         P.tb_bytes = (uint32_t)((size_t)(time_stride && !h->tb_step ? nT : 1) * ns * F0 * 4);
         P.tb_pose_stride = time_stride && !h->tb_step ? ns * F0 : 0;
+    }
+    if (c.query_time_encoding) {
+        int ps = 0;
+        P.msg_dst = query_time_rows(h, time_stride, ps);
+        P.qd_pose_stride = ps; P.msg_dst_bytes = (uint32_t)((size_t)(ps ? nT : 1) * kQueryTimeRow * 4);
     }
     P.nQ = h->nQ; P.n_scales = ns;
     for (int n = 0; n < ns; ++n) {
@@ -663,6 +710,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         cnt_used = np.cnt;
         if constexpr (!EBM) {
             if (h->tb_step == nullptr) launch_time_bias(h, st, h->d_time.as<float>(), time_stride, time_stride ? nT : 1, h->d_tb.as<float>(), time_stride ? h->d_tile.as<int>() + kFlagTimeVaries : nullptr);
+            if (h->tb_step == nullptr && c.query_time_encoding) launch_time_query(h, st, h->d_time.as<float>(), time_stride, time_stride ? nT : 1, h->d_qrows.as<float>());
         }
         mark();
         const dim3 g(nblk, np.word_start[ns] + 1);
@@ -674,6 +722,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     // 2. time embedding -> pre-linear bias rows (EBM head: constant bias rows, uploaded once)
     if constexpr (!EBM) {
         if (h->tb_step == nullptr) launch_time_bias(h, st, h->d_time.as<float>(), time_stride, time_stride ? nT : 1, h->d_tb.as<float>(), time_stride ? h->d_tile.as<int>() + kFlagTimeVaries : nullptr);
+        if (h->tb_step == nullptr && c.query_time_encoding) launch_time_query(h, st, h->d_time.as<float>(), time_stride, time_stride ? nT : 1, h->d_qrows.as<float>());
     }
     mark();
     // 3. neighbour search
@@ -711,7 +760,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
                 } else {
                     if (!async_tab) launch_radial_table<L, F0, 128, 64>(h, P, st, false);
                     bool on16 = false;
-                    if constexpr (L == 2 && F0 == 128) on16 = h->edge16 != 0 && h->e16.ok && !c.use_src_point_attn;
+                    if constexpr (L == 2 && F0 == 128) on16 = h->edge16 != 0 && h->e16.ok && !c.use_src_point_attn && !c.query_time_encoding;
                     if (on16) {
                         if constexpr (L == 2 && F0 == 128) {
                             Edge16Params Q{};
@@ -809,6 +858,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
             P.o_A_sl[t][0] = o.o_A_sl[t][0]; P.o_A_sl[t][1] = o.o_A_sl[t][1]; P.o_b_sl[t] = o.o_b_sl[t];
             P.o_A_sl_l[t][0] = o.o_A_sl_l[t][0]; P.o_A_sl_l[t][1] = o.o_A_sl_l[t][1];
         }
+        if (c.query_time_encoding) { int ps = 0; P.skip1 = query_time_rows(h, time_stride, ps) + mul_of(0); P.skip1_stride = ps; }
         P.node_out = h->d_nout.as<float>();
         if ((h->debug || h->want_field) && h->d_dbge.ensure((size_t)Nd * D * 4) && h->d_dbgf.ensure((size_t)Nd * D * 4)) { P.dbg_emb = h->d_dbge.as<float>(); P.dbg_field = h->d_dbgf.as<float>(); }
         else if (h->want_field) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(field) failed");
@@ -1212,6 +1262,10 @@ static int sample_once(dedf_handle* h, int nT, const double* T_seed, const dedf_
         for (int s = 0; s < sched->n_steps; ++s) pin_t[s] = (float)sched->t[s];
         HIPCK(h, hipMemcpyAsync(h->d_time.p, pin_t, (size_t)sched->n_steps * 4, hipMemcpyHostToDevice, st));
         launch_time_bias(h, st, h->d_time.as<float>(), 1, sched->n_steps, h->d_tb_steps.as<float>());
+        if (h->cfg.query_time_encoding) {
+            if (!h->d_qrows_steps.ensure((size_t)sched->n_steps * kQueryTimeRow * 4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(time rows) failed");
+            launch_time_query(h, st, h->d_time.as<float>(), 1, sched->n_steps, h->d_qrows_steps.as<float>());
+        }
         // Accuracy guard of the radial table, once per call: the table of the first, the middle and the last step (the time only shifts the
         // pre-linear's bias rows; what decides the interpolation error is the length encoder) is checked at EVERY interval midpoint of every
         // scale against the exact evaluation; a scale whose largest deviation exceeds the bound evaluates its front per edge in this call.

@@ -26,8 +26,9 @@ struct EdgeParams {
     const int* tile_info;     // [0..n_scales] tile prefix, [16..16+n_scales] edge prefix
     const float* msg;         // [sum N_s][D]  source message (LN + LinearRS of key features), reference layout
     uint32_t msg_bytes;
-    const float* msg_dst;     // UNet layer only: [N_d][D] destination message (linear_dst), reference layout
-    uint32_t msg_dst_bytes;
+    const float* msg_dst;     // UNet layer: [N_d][D] destination message (linear_dst), reference layout.  Score head with query_time_encoding (QT): the
+    uint32_t msg_dst_bytes;   // time rows of dedf_misc.h::k_time_query -- [rows][kQueryTimeRow], the first 64 floats of a row join the 0e block of the message
+    int qd_pose_stride;       // QT: floats between the rows of consecutive poses; 0 when every pose shares the time (sampler)
     float ln_inv_n[2], ln_pad[2];   // UNet layer only: 1 / true width and number of padded channels of the radial MLP's two LayerNorms
     const float* tb;          // [(nT|1)][n_scales][F0] row-packed: W_pre[:,64:] c_t + b_pre  (b_pre alone when F0 = 64)
     uint32_t tb_bytes;
@@ -358,7 +359,7 @@ struct GeoPre { int ok, src, dst; float vx, vy, vz; };
 //      is rotated back (Rot<l>::out) before the segmented reduction.  Same result as the general form up to fp32 rounding; needs the image packed
 //      for it (dedf_pack.h::pack_edge<L, true>).
 template <int L> struct Trig { float cg[L], sg[L], cb[L], sb[L]; };
-template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false, int MODE = 0, bool NW = false, bool SO2 = false>
+template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false, int MODE = 0, bool NW = false, bool SO2 = false, bool QT = false>
 DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, int n_valid, GeoPre& geo, int e_next DEDF_PROF_ARG) {
     static_assert((H1 == 128 && H2 == 64) || (H1 == 32 && H2 == 32), "radial MLP widths of the shipped configs");
     static_assert(!SO2 || MODE <= 1, "edge-frame form: the per-edge and the table-reading kernels");
@@ -666,7 +667,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // wave's private 30 KB) until the second depth-wise TP reads them.
     f32x16 acc0[NR0], acc1[3], acc2[5], acc3[7];
     const Buf msgb = make_buf(P.msg, P.msg_bytes);
-    const Buf msgd = make_buf(P.msg_dst, P.msg_dst_bytes);      // UNet layer: the destination's message is added (block.py:155)
+    const Buf msgd = make_buf(P.msg_dst, P.msg_dst_bytes);      // UNet layer: the destination's message is added (block.py:155); QT: the pose's time row (0e only)
+    static_assert(!(UN && QT), "a UNet layer has no query time encoding");
     // per-l1 lane offsets of the 4 message rows this lane owns inside an 8-row group
 #if defined(DEDF_TIMING_X_SAME)      // timing experiment only (wrong results): every edge gathers the source rows of key 0 (L1-resident)
     const int srcx = 0;
@@ -674,7 +676,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     const int srcx = src;
 #endif
     const int mv0 = srcx * (D * 4) + hi * 16, mv1 = srcx * (D * 4) + hi * 48, mv2 = srcx * (D * 4) + hi * 80, mv3 = srcx * (D * 4) + hi * 112;
-    const int dv0 = dst * (D * 4) + hi * 16, dv1 = dst * (D * 4) + hi * 48, dv2 = dst * (D * 4) + hi * 80, dv3 = dst * (D * 4) + hi * 112;
+    const int dv0 = (QT ? pose * (P.qd_pose_stride * 4) : dst * (D * 4)) + hi * 16, dv1 = dst * (D * 4) + hi * 48, dv2 = dst * (D * 4) + hi * 80, dv3 = dst * (D * 4) + hi * 112;
     // LDS parking: the gated features wait here as READY-MADE B operands of the value GEMMs: one 16-byte slot per lane holds the
     // fp16 hi halves of a 16-channel chunk (8 accumulator registers), the next slot their fp16 residuals ([slot][lane][8 halves];
     // chunk q = dedf_net.h::park_slot(degree, component, chunk) -> slots 2q | 2q + 1), lane-private
@@ -721,7 +723,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
 #define DEDF_PDA_SO2 3      // edge-frame form: 3 against 5 (-2 %), 2 / 4 / 7 no better (profiles/r05c_so2_variants_ab.log, r05e_so2_timing_ab.log)
 #endif
     constexpr int NCHK = WN / 16, PDA = SO2 ? DEDF_PDA_SO2 : (L == 3 ? DEDF_PDA3 : ((L == 2 && MODE == 1 && F0 == 128) ? DEDF_PDA2_TAB : DEDF_PDA2));
-    struct XOps { f32x4 x[2][2 * L + 1]; f32x4 xd[UN ? 2 : 1][2 * L + 1]; };
+    struct XOps { f32x4 x[2][2 * L + 1]; f32x4 xd[UN ? 2 : 1][UN ? 2 * L + 1 : (QT ? 2 : 1)]; };      // (QT: xd[0][run], 0e chunks only)
     auto load_X = [&]<int C>() {      // this lane's 2 x 4 source-message rows of the chunk (contiguous runs in the reference layout)
         XOps o{};
         if constexpr (C < NCHK) {
@@ -737,6 +739,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                     o.xd[run][Q] = bld4(msgd, dv, (blk_off(l1) + (u0 + 8 * run) * d1 + 4 * Q) * 4);
                 }); });
             }
+            if constexpr (QT && l1 == 0) static_for<2>([&]<int run>() { o.xd[0][run] = bld4(msgd, dv0, (u0 + 8 * run) * 4); });
         }
         return o;
     };
@@ -756,7 +759,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                         float v[d1];
                         static_for<d1>([&]<int m>() {
                             constexpr int el = j * d1 + m;
-                            if constexpr (UN) v[m] = xo.x[run][el / 4][el % 4] + xo.xd[run][el / 4][el % 4]; else v[m] = xo.x[run][el / 4][el % 4];
+                            if constexpr (UN) v[m] = xo.x[run][el / 4][el % 4] + xo.xd[run][el / 4][el % 4];
+                            else if constexpr (QT && l1 == 0) v[m] = xo.x[run][0][el] + xo.xd[0][run][el];
+                            else v[m] = xo.x[run][el / 4][el % 4];
                         });
 #if !defined(DEDF_TIMING_SO2_NOROT)      // (timing experiments only, wrong results: DESIGN.md section 5.R5)
                         Rot<l1>::in(v, tg);
@@ -801,7 +806,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                         if constexpr (pad_reg<L, NW>(l1, ch)) v[cmp][4 * run + ch] = 0.0f;      // a zero-padding channel of the source rows
                         else {
                         float x;
-                        if constexpr (UN) x = xo.x[run][Q][i] + xo.xd[run][Q][i]; else x = xo.x[run][Q][i];
+                        if constexpr (UN) x = xo.x[run][Q][i] + xo.xd[run][Q][i];
+                        else if constexpr (QT && l1 == 0) x = xo.x[run][Q][i] + xo.xd[0][run][i];
+                        else x = xo.x[run][Q][i];
                         v[cmp][4 * run + ch] = x * wtile[8 * c2 + 4 * run + ch];
                         }
                     }); });
@@ -814,7 +821,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             static_for<2>([&]<int run>() {
                 float xr[4 * d1];
                 static_for<d1>([&]<int Q>() { static_for<4>([&]<int i>() {
-                    if constexpr (UN) xr[4 * Q + i] = xo.x[run][Q][i] + xo.xd[run][Q][i]; else xr[4 * Q + i] = xo.x[run][Q][i];
+                    if constexpr (UN) xr[4 * Q + i] = xo.x[run][Q][i] + xo.xd[run][Q][i];
+                    else if constexpr (QT && l1 == 0) xr[4 * Q + i] = xo.x[run][Q][i] + xo.xd[0][run][i];
+                    else xr[4 * Q + i] = xo.x[run][Q][i];
                 }); });
                 static_for<4>([&]<int j>() {
                     if constexpr (pad_reg<L, NW>(l1, j)) static_for<d3>([&]<int K>() { v[K][4 * run + j] = 0.0f; });      // a zero-padding channel of the source rows

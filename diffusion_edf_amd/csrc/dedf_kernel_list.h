@@ -67,5 +67,10 @@
     X(44, void k_edge<2, 64, false, 32, 32, true, 0, false, true>(EdgeParams))    \
     X(45, void k_edge<2, 64, false, 32, 32, true, 0, true, true>(EdgeParams))     \
     X(46, void k_edge<3, 64, false, 32, 32, true, 0, false, true>(EdgeParams))    \
-    X(47, void k_edge<3, 64, false, 32, 32, true, 0, true, true>(EdgeParams))
-constexpr int kKernelUnits = 48;
+    X(47, void k_edge<3, 64, false, 32, 32, true, 0, true, true>(EdgeParams))     \
+    X(48, void k_edge<2, 128, false, 128, 64, false, 0, false, true, true>(EdgeParams)) \
+    X(49, void k_edge<2, 128, false, 128, 64, false, 1, false, true, true>(EdgeParams)) \
+    X(50, void k_edge<3, 128, false, 128, 64, false, 0, false, true, true>(EdgeParams)) \
+    X(51, void k_edge<3, 128, false, 128, 64, false, 1, false, true, true>(EdgeParams))
+// (units 48-51: the score head with query_time_encoding -- trailing `true`: the pose's time row joins the 0e block of the gathered message)
+constexpr int kKernelUnits = 52;

@@ -159,6 +159,80 @@ __global__ __launch_bounds__(256) void k_time_bias(TimeParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// query_time_encoding (score_head.py:64-70, 168-173): every query point of a pose carries  e = query_time_mlp(sinusoid(time))  -- TE scalars -- as the
+// DESTINATION feature of the key field's block (use_dst_feature, gnn_block.py:109-130).  Everything the block does with it depends on the time alone,
+// so it is evaluated once per time row p (a pose of dedf_score, a step of dedf_sample) instead of once per (pose, query point):
+//   rows[p][0:64]   = out_scale * (linear_dst(prenorm_dst(e)) + bias)     joins the 0e block of every edge message of the pose (gnn_block.py:172-180;
+//                     natural channel order, scaled like the stored source message: dedf_pack.h::EdgeOffsets::msg_scale)
+//   rows[p][64:128] = skip_1(e) = LinearRS(e) + bias                      joins the 0e block of the attention output (gnn_block.py:111, 205-206;
+//                     row-packed like the node kernel's bias rows)
+// grid (rows), block 256.
+constexpr int kQueryTimeRow = 128;      // floats per time row
+struct TimeQueryParams {
+    const float* time; int time_stride;
+    const float *w1, *b1, *w2, *b2;                 // query_time_mlp: [H][E], [H], [TE][H], [TE]
+    const float *ln_w, *ln_b;                       // prenorm_dst affine [TE], [TE]
+    const float *wdst, *bdst, *wskip, *bskip;       // LinearRS 0e -> 0e: [TE][64] (in x out), [64]
+    const float* tfreq;
+    int E, H, TE;
+    float max_time, time_enc_n, out_scale;
+    float* rows;
+};
+__global__ __launch_bounds__(256) void k_time_query(TimeQueryParams P) {
+    __shared__ float enc[kTimeMaxEnc], hid[kTimeMaxHid], emb[kTimeMaxEmb], nrm[kTimeMaxEmb], red[2];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int E = P.E, H = P.H, TE = P.TE;
+    const float t = P.time[p * P.time_stride];
+    const float x = t / P.max_time * P.time_enc_n;
+    for (int i = tid; i < E / 2; i += blockDim.x) {
+        const float fr = P.tfreq[i];
+        enc[i] = sinf(x * fr);
+        enc[i + E / 2] = cosf(x * fr);
+    }
+    __syncthreads();
+    for (int i = tid; i < H; i += blockDim.x) {
+        const float* w = P.w1 + (size_t)i * E;
+        float s = P.b1[i];
+        for (int k = 0; k < E; ++k) s += w[k] * enc[k];
+        hid[i] = s / (1.0f + expf(-s));
+    }
+    __syncthreads();
+    for (int i = tid; i < TE; i += blockDim.x) {
+        const float* w = P.w2 + (size_t)i * H;
+        float s = P.b2[i];
+        for (int k = 0; k < H; ++k) s += w[k] * hid[k];
+        emb[i] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {      // EquivariantLayerNormV2 on TE x 0e (layer_norm.py:113-146): mean-free, 'component' norm over the block, eps 1e-5
+        float mean = 0.0f;
+        for (int k = 0; k < TE; ++k) mean += emb[k];
+        mean /= TE;
+        float v = 0.0f;
+        for (int k = 0; k < TE; ++k) { const float d = emb[k] - mean; v += d * d; }
+        red[0] = mean; red[1] = 1.0f / sqrtf(v / TE + 1e-5f);
+    }
+    __syncthreads();
+    for (int i = tid; i < TE; i += blockDim.x) nrm[i] = (emb[i] - red[0]) * (red[1] * P.ln_w[i]) + P.ln_b[i];
+    __syncthreads();
+    constexpr int M0 = mul_of(0);
+    float* const o = P.rows + (size_t)p * kQueryTimeRow;
+    for (int i = tid; i < 2 * M0; i += blockDim.x) {
+        const int w = i % M0;
+        if (i < M0) {
+            float s = P.bdst[w];
+            for (int u = 0; u < TE; ++u) s += P.wdst[u * M0 + w] * nrm[u];
+            o[w] = s * P.out_scale;
+        } else {
+            float s = P.bskip[w];
+            for (int u = 0; u < TE; ++u) s += P.wskip[u * M0 + w] * emb[u];
+            const int tile = w >> 5, row = w & 31;
+            o[M0 + (tile * 2 + row_hi(row)) * 16 + row_reg(row)] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // Source message (pose independent): EquivariantLayerNormV2 + LinearRS(bias) on every key point
 // (gnn_block.py:170-171, layer_norm.py:91-156, tensor_product_rescale.py:176-185).  One block (64 threads) per point.
 // NORM = false: LinearRS only, `bias` may be null (the linear_src / linear_dst of a UNet block: block.py:149-153 overwrites the

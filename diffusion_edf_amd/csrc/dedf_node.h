@@ -42,6 +42,8 @@ struct NodeParams {
     // w*ang_orbital; parity 1 the ang_vel product -> node_spin = w*ang_spin.  The reductions add the two.
     int split;
     float* node_spin;                          // [N_d][4]
+    const float* skip1; int skip1_stride;      // query_time_encoding: time rows of dedf_misc.h::k_time_query (their second, row-packed half): skip_1(destination
+                                               // feature) joins the 0e block of the attention output (gnn_block.py:111, 205-206); stride in floats between poses (0: shared)
     float* dbg_emb;                            // optional [N_d][D] dumps (internal layout) of the proj output and of the field (tests)
     float* dbg_field;
 };
@@ -201,6 +203,13 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0, int tp_only
     }
 
     if constexpr (UN) feat_add_ref<L>(emb, make_buf(P.f_dst, P.f_dst_bytes), n * (D * 4), hi);      // node_output = node_input_dst + ga(...)
+    if constexpr (!UN) if (P.skip1 != nullptr) {      // query_time_encoding: + skip_1(query_time_mlp(time of the pose))
+        const f32x4* const r = reinterpret_cast<const f32x4*>(P.skip1 + (size_t)pose * P.skip1_stride + hi * 16);
+        static_for<2>([&]<int T>() { static_for<4>([&]<int G>() {
+            const f32x4 t = r[T * 8 + G];
+            emb.s[T][4 * G] += t[0]; emb.s[T][4 * G + 1] += t[1]; emb.s[T][4 * G + 2] += t[2]; emb.s[T][4 * G + 3] += t[3];
+        }); });
+    }
 
     // ---- EquivariantLayerNormV2 (equiformer/layer_norm.py:91-156) ----------------------------------------------------------
     Feat<L> nrm;

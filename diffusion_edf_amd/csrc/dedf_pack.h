@@ -120,6 +120,10 @@ inline ParamSpec build_spec(const IrrepsRT& I, const dedf_config& c) {
         S.add(p + "0.weight", (size_t)te[1] * te[0]); S.add(p + "0.bias", te[1]);
         S.add(p + "2.weight", (size_t)te[2] * te[1]); S.add(p + "2.bias", te[2]);
     }
+    if (c.query_time_encoding) {      // score_head.py:64-70
+        S.add("query_time_mlp.0.weight", (size_t)te[1] * te[0]); S.add("query_time_mlp.0.bias", te[1]);
+        S.add("query_time_mlp.2.weight", (size_t)te[2] * te[1]); S.add("query_time_mlp.2.bias", te[2]);
+    }
     const std::string ktf = "key_tensor_field";
     const int F0 = c.fc_neurons[0], dimL = c.length_emb_dim;
     for (int n = 0; n < c.n_scales; ++n) {
@@ -132,7 +136,13 @@ inline ParamSpec build_spec(const IrrepsRT& I, const dedf_config& c) {
     }
     const std::string blk = ktf + ".gnn_block_init";
     S.add(blk + ".prenorm_src.affine_weight", I.sum_mul()); S.add(blk + ".prenorm_src.affine_bias", I.mul[0]);
-    S.add(blk + ".linear_src.tp.weight", I.sq()); S.add(blk + ".linear_src.bias.0", I.mul[0]);
+    S.add(blk + ".linear_src.tp.weight", I.sq());
+    if (!c.query_time_encoding) S.add(blk + ".linear_src.bias.0", I.mul[0]);
+    else {      // use_dst_feature = True with irreps_dst = te[2] x 0e (gnn_block.py:109-130; score_head.py:52, 81-83)
+        S.add(blk + ".skip_1.skip.tp.weight", (size_t)te[2] * I.mul[0]); S.add(blk + ".skip_1.skip.bias.0", I.mul[0]);
+        S.add(blk + ".prenorm_dst.affine_weight", te[2]); S.add(blk + ".prenorm_dst.affine_bias", te[2]);
+        S.add(blk + ".linear_dst.tp.weight", (size_t)te[2] * I.mul[0]); S.add(blk + ".linear_dst.bias.0", I.mul[0]);
+    }
     spec_block(S, I, c, blk, blk + ".post_norm");
     if (!c.ebm) for (const char* nm : {"lin_vel_tp", "ang_vel_tp"}) {
         const std::string p = std::string(nm);
@@ -514,13 +524,22 @@ inline void pack_edge(const dedf_config& c, const ParamSpec& S, const float* B, 
             for (int r = 0; r < dtp_wn<L>(); ++r) { double rn = 0.0; for (int k = 0; k < H2; ++k) rn += (double)W3[r * H2 + k] * W3[r * H2 + k]; acc += rn * q2 + (double)off3[r] * off3[r]; }
             est_we = (float)std::sqrt(acc / dtp_wn<L>());
             const float* ws = S.get(B, blk + ".linear_src.tp.weight"); const float* aw = S.get(B, blk + ".prenorm_src.affine_weight");
-            const float* ab = S.get(B, blk + ".prenorm_src.affine_bias"); const float* bs = S.get(B, blk + ".linear_src.bias.0");
+            const float* ab = S.get(B, blk + ".prenorm_src.affine_bias"); const float* bs = c.query_time_encoding ? nullptr : S.get(B, blk + ".linear_src.bias.0");
             size_t wo = 0; int ao = 0;
             for (int l = 0; l <= L; ++l) {
                 const int m = mul_of(l);
                 double a2 = 0.0;
                 for (int w = 0; w < m; ++w) for (int u = 0; u < m; ++u) { const double in2 = (double)aw[ao + u] * aw[ao + u] + (l == 0 ? (double)ab[u] * ab[u] : 0.0); a2 += (double)ws[wo + (size_t)u * m + w] * ws[wo + (size_t)u * m + w] * in2; }
-                if (l == 0) for (int w = 0; w < m; ++w) a2 += (double)bs[w] * bs[w];
+                if (l == 0 && bs != nullptr) for (int w = 0; w < m; ++w) a2 += (double)bs[w] * bs[w];
+                if (l == 0 && c.query_time_encoding) {      // + the destination message LinearRS(LayerNorm(time scalars)) that joins the 0e block (gnn_block.py:172-180)
+                    const int tq = c.time_emb_mlp[2];
+                    const float* wd = S.get(B, blk + ".linear_dst.tp.weight"); const float* bd = S.get(B, blk + ".linear_dst.bias.0");
+                    const float* dw = S.get(B, blk + ".prenorm_dst.affine_weight"); const float* db = S.get(B, blk + ".prenorm_dst.affine_bias");
+                    for (int w = 0; w < m; ++w) {
+                        a2 += (double)bd[w] * bd[w];
+                        for (int u = 0; u < tq; ++u) a2 += (double)wd[(size_t)u * m + w] * wd[(size_t)u * m + w] * ((double)dw[u] * dw[u] + (double)db[u] * db[u]);
+                    }
+                }
                 est_msg = std::fmax(est_msg, (float)std::sqrt(a2 / m));
                 wo += (size_t)m * m; ao += m;
             }

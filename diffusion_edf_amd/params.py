@@ -43,6 +43,7 @@ class HeadConfig:
     ebm: bool = False                    # EbmScoreModelHead (reference score_head_ebm.py): energy critic, no time encoding
     half_gemm: bool = False              # the reference's half_precision knob (agent.py:50-51): single-term fp16 GEMM products
     use_src_point_attn: bool = False     # PointAttentiveScoreModel (point_attentive_score_model.py:71-72): attention times the key points' weights
+    query_time_encoding: bool = False    # score_head.py:168-173: query_time_mlp(time) as the destination feature of the key field's block
 
     @property
     def n_scales(self) -> int:
@@ -74,9 +75,9 @@ class HeadConfig:
                 raise NotImplementedError(f"irreps must be mul_0 x0e + mul_1 x1e + ...: {irreps}")
         ebm = bool(k.get('ebm', False))
         ete, qte = bool(k.get('edge_time_encoding', False)), bool(k.get('query_time_encoding', True))
-        if qte or (ebm and ete) or (not ebm and not ete):
-            raise NotImplementedError("accelerated path: score head with edge_time_encoding=True / query_time_encoding=False, "
-                                      "or EBM critic head with both False (the only combinations in the shipped configs)")
+        if (ebm and (ete or qte)) or (not ebm and not ete):
+            raise NotImplementedError("accelerated path: score head with edge_time_encoding=True (the shipped configs; query_time_encoding on or "
+                                      "off), or EBM critic head with both False")
         if tf.get('n_layers', 1) != 1:
             raise NotImplementedError("n_layers != 1")
         if tf.get('cutoff_method', 'edge_attn') != 'edge_attn':
@@ -121,7 +122,7 @@ class HeadConfig:
                    max_time=float(k['max_time']), time_enc_n=float(k.get('time_enc_n', 10000.)),
                    lin_mult=float(k['lin_mult']), ang_mult=float(k['ang_mult']),
                    irreps_mlp_mid=int(tf.get('irreps_mlp_mid', 3)), ebm=ebm,
-                   use_src_point_attn=bool(tf.get('use_src_point_attn', False)))
+                   use_src_point_attn=bool(tf.get('use_src_point_attn', False)), query_time_encoding=qte)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -166,6 +167,13 @@ def param_spec(cfg: HeadConfig) -> List[Tuple[str, Tuple[int, ...], str, float]]
             S.append((f"time_mlps_multiscale.{n}.{li}.weight", (te[i], te[i - 1]), 'linear_w', te[i - 1]))
             S.append((f"time_mlps_multiscale.{n}.{li}.bias", (te[i],), 'linear_b', te[i - 1]))
             li += 2 if i != len(te) - 1 else 1
+    qte = cfg.query_time_encoding
+    if qte:                              # score_head.py:64-70: same shape as one time MLP
+        li = 0
+        for i in range(1, len(te)):
+            S.append((f"query_time_mlp.{li}.weight", (te[i], te[i - 1]), 'linear_w', te[i - 1]))
+            S.append((f"query_time_mlp.{li}.bias", (te[i],), 'linear_b', te[i - 1]))
+            li += 2 if i != len(te) - 1 else 1
     ktf = "key_tensor_field"
     F0 = cfg.fc_neurons[0]
     dimL = cfg.length_emb_dim
@@ -182,7 +190,16 @@ def param_spec(cfg: HeadConfig) -> List[Tuple[str, Tuple[int, ...], str, float]]
     S.append((f"{blk}.prenorm_src.affine_weight", (nirr,), 'ones', 0))
     S.append((f"{blk}.prenorm_src.affine_bias", (n0,), 'zeros', 0))
     S.append((f"{blk}.linear_src.tp.weight", (sum(m * m for m in muls),), 'tp_w:' + ','.join(f"{m*m}:{m}" for m in muls), 0))
-    S.append((f"{blk}.linear_src.bias.0", (n0,), 'zeros', 0))
+    if not qte:
+        S.append((f"{blk}.linear_src.bias.0", (n0,), 'zeros', 0))
+    else:                                # use_dst_feature=True (gnn_block.py:109-130): the destination features are the te[-1] time scalars
+        tq = te[-1]
+        S.append((f"{blk}.skip_1.skip.tp.weight", (tq * n0,), f'tp_w:{tq * n0}:{tq}', 0))
+        S.append((f"{blk}.skip_1.skip.bias.0", (n0,), 'zeros', 0))
+        S.append((f"{blk}.prenorm_dst.affine_weight", (tq,), 'ones', 0))
+        S.append((f"{blk}.prenorm_dst.affine_bias", (tq,), 'zeros', 0))
+        S.append((f"{blk}.linear_dst.tp.weight", (tq * n0,), f'tp_w:{tq * n0}:{tq}', 0))
+        S.append((f"{blk}.linear_dst.bias.0", (n0,), 'zeros', 0))
     ga = f"{blk}.ga"
     # radial profile
     sh_ls = list(range(cfg.lmax_sh + 1))

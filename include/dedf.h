@@ -98,6 +98,13 @@ typedef struct dedf_config {
                                             padding is computed like data) -- EXCEPT the l = 3 block of an lmax-3 layer: every lmax-3 kernel skips the channels
                                             p with p % 4 >= 2 of the 16x3e block, so the (at most 8) true 3e channels MUST sit at the positions of
                                             unet_pad.py::place (8x3e: 0, 1, 4, 5, 8, 9, 12, 13; 4x3e: 0, 4, 8, 12) whatever this flag says */
+    int query_time_encoding;             /* 1: ScoreModelHead(query_time_encoding=True) (score_head.py:64-70, 168-173): the query points carry
+                                            query_time_mlp(time) -- time_emb_mlp[2] scalars -- as the DESTINATION feature of the key field's block
+                                            (use_dst_feature, gnn_block.py:109-130, 170-180, 205-206): LayerNorm + LinearRS(bias) of it joins every edge's
+                                            message, linear_src has no bias, and its projection skip_1 joins the attention output before post_norm.  The
+                                            parameter list gains query_time_mlp.*, ...prenorm_dst.*, ...linear_dst.*, ...skip_1.skip.* and loses
+                                            ...linear_src.bias.0.  Together with edge time encoding (fc_neurons[0] = 64 + time_emb_mlp[2]); instantiated for
+                                            fc_neurons {128,128,64}, lmax 2 and 3, full precision.  0: default (every shipped config) */
 } dedf_config;
 
 typedef struct dedf_schedule {           /* host arrays, one entry per denoising step (score_model_base.py:146-171) */
@@ -136,8 +143,8 @@ const char* dedf_version(void);
  * dedf_config [which = 0], dedf_schedule [1], dedf_stats [2], dedf_profile [3] for bindings that mirror the structs by hand (diffusion_edf_amd/_lib.py checks both).
  *   1  rounds 1-2.   2  round 3: dedf_config.unet_valid[4] (was [3]), dedf_stats.rtab_err / rtab_fallback, dedf_radius scratch arguments.
  *   3  round 4: dedf_abi_version / dedf_struct_size themselves; no struct change.   4  round 4: dedf_config.unet_narrow (appended).
- *   5  round 5: dedf_stats.sample_retries / edges_per_dst_capacity (appended). */
-#define DEDF_ABI_VERSION 5
+ *   5  round 5: dedf_stats.sample_retries / edges_per_dst_capacity (appended).   6  round 5: dedf_config.query_time_encoding (appended). */
+#define DEDF_ABI_VERSION 6
 int dedf_abi_version(void);
 size_t dedf_struct_size(int which);
 

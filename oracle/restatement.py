@@ -525,6 +525,7 @@ class Config(NamedTuple):
     max_neighbors: int = 1000
     edge_time_encoding: bool = True
     use_src_point_attn: bool = False   # PointAttentiveScoreModel (point_attentive_score_model.py:71-72): alpha *= w_src after the softmax
+    query_time_encoding: bool = False  # score_head.py:168-173: the query points carry query_time_mlp(time) as the field's destination feature
 
 
 def config_from_kwargs(score_head_kwargs: dict) -> Config:
@@ -536,8 +537,9 @@ def config_from_kwargs(score_head_kwargs: dict) -> Config:
     assert parse_irreps(tf.get('irreps_input', tf['irreps_output'])) == irreps
     assert parse_irreps(k.get('irreps_query_edf', tf['irreps_output'])) == irreps
     ete = bool(k.get('edge_time_encoding', False))
-    assert not k.get('query_time_encoding', True)
-    assert ete or k.get('ebm', False), "No time encoding! Are you sure?"       # score_head.py:72-73 (the EBM head allows it)
+    qte = bool(k.get('query_time_encoding', True))
+    assert ete or qte or k.get('ebm', False), "No time encoding! Are you sure?"       # score_head.py:72-73 (the EBM head allows it)
+    assert not (qte and k.get('ebm', False))
     assert tf.get('n_layers', 1) == 1 and tf.get('cutoff_method', 'edge_attn') == 'edge_attn'
     if tf.get('use_dst_point_attn', False):
         raise NotImplementedError                                  # gnn_block.py:196-197
@@ -555,7 +557,7 @@ def config_from_kwargs(score_head_kwargs: dict) -> Config:
                   max_time=float(k['max_time']), time_enc_n=float(k.get('time_enc_n', 10000.)),
                   lin_mult=float(k['lin_mult']), ang_mult=float(k['ang_mult']),
                   irreps_mlp_mid=tf.get('irreps_mlp_mid', 3), edge_time_encoding=ete,
-                  use_src_point_attn=bool(tf.get('use_src_point_attn', False)))
+                  use_src_point_attn=bool(tf.get('use_src_point_attn', False)), query_time_encoding=qte)
 
 
 class FeaturedPoints(NamedTuple):
@@ -594,16 +596,38 @@ def time_embeddings(cfg: Config, P, time: Tensor) -> List[Tensor]:
     return outs
 
 
+def query_time_embedding(cfg: Config, P, time: Tensor) -> Tensor:
+    """score_head.py:64-70, 171: query_time_mlp (Linear, SiLU, ..., Linear) on the sinusoidal encoding -> (nT, time_emb_mlp[-1])."""
+    x = sinusoidal_embedding(time, cfg.time_emb_mlp[0], cfg.max_time, cfg.time_enc_n)
+    li = 0
+    for i in range(1, len(cfg.time_emb_mlp)):
+        x = x @ P[f"query_time_mlp.{li}.weight"].t() + P[f"query_time_mlp.{li}.bias"]
+        li += 1
+        if i != len(cfg.time_emb_mlp) - 1:
+            x = torch.nn.functional.silu(x)
+            li += 1
+    return x
+
+
 def equiformer_block(cfg: Config, P, blk: str, src_f: Tensor, edge_src: Tensor, edge_dst: Tensor, edge_attr: Tensor, edge_scalars: Tensor,
-                     edge_logits: Tensor, N_dst: int, src_w: Optional[Tensor] = None, irreps_output: Optional[Irreps] = None):
-    """EquiformerBlock.forward for ``use_dst_feature=False`` (gnn_block.py:164-218) + GraphAttentionMLP2.forward (graph_attention.py:218-273) on a
-    given bipartite graph: source features, edge lists and the per-edge attributes / scalars / pre-attention logits.  ``blk``: the block's prefix
-    in the state dict.  Returns (output features, intermediates)."""
+                     edge_logits: Tensor, N_dst: int, src_w: Optional[Tensor] = None, irreps_output: Optional[Irreps] = None,
+                     dst_f: Optional[Tensor] = None, irreps_dst: Optional[Irreps] = None):
+    """EquiformerBlock.forward (gnn_block.py:164-218) + GraphAttentionMLP2.forward (graph_attention.py:218-273) on a given bipartite graph: source
+    features, edge lists and the per-edge attributes / scalars / pre-attention logits.  ``blk``: the block's prefix in the state dict.
+    ``dst_f`` / ``irreps_dst``: the destination features of a ``use_dst_feature=True`` block (gnn_block.py:126-130: LayerNorm + LinearRS with bias on
+    them joins the message, linear_src loses its bias; :111: their projection skip_1 joins the attention output).  Returns (output features,
+    intermediates)."""
     irreps, irreps_sh, H = cfg.irreps, cfg.irreps_sh, cfg.num_heads
-    # ---- EquiformerBlock (use_dst_feature=False: no dst message, skip_1=None) --------------------
     msg_src = equivariant_layer_norm_v2(src_f, irreps, P, f"{blk}.prenorm_src")
-    msg_src = linear_rs(msg_src, irreps, irreps, P, f"{blk}.linear_src", bias=True)
-    message = msg_src[edge_src]
+    msg_dst = None
+    if dst_f is None:      # use_dst_feature=False: no dst message, skip_1=None
+        msg_src = linear_rs(msg_src, irreps, irreps, P, f"{blk}.linear_src", bias=True)
+        message = msg_src[edge_src]
+    else:
+        msg_src = linear_rs(msg_src, irreps, irreps, P, f"{blk}.linear_src", bias=False)
+        msg_dst = equivariant_layer_norm_v2(dst_f, irreps_dst, P, f"{blk}.prenorm_dst")
+        msg_dst = linear_rs(msg_dst, irreps_dst, irreps, P, f"{blk}.linear_dst", bias=True)
+        message = msg_src[edge_src] + msg_dst[edge_dst]
 
     # ---- GraphAttentionMLP2 ------------------------------------------------------------------------
     ga = f"{blk}.ga"
@@ -638,6 +662,11 @@ def equiformer_block(cfg: Config, P, blk: str, src_f: Tensor, edge_src: Tensor, 
     attn = torch.zeros((N_dst,) + attn.shape[1:], dtype=attn.dtype).index_add_(0, edge_dst, attn)
     attn = heads2vec(attn, irreps_head)
     emb = linear_rs(attn, irreps, irreps, P, f"{ga}.proj")
+    if dst_f is not None:                                         # skip_1 = ProjectIfMismatch(irreps_dst -> irreps_emb, layernorm=False), gnn_block.py:111, 205-206
+        if list(irreps_dst) == list(irreps):
+            emb = emb + dst_f
+        else:
+            emb = emb + linear_rs(dst_f, irreps_dst, irreps, P, f"{blk}.skip_1.skip", bias=True)
 
     # ---- post-norm + FFN + skip_2 (Identity) ----------------------------------------------------------
     out = equivariant_layer_norm_v2(emb, irreps, P, f"{blk}.post_norm")
@@ -657,17 +686,19 @@ def equiformer_block(cfg: Config, P, blk: str, src_f: Tensor, edge_src: Tensor, 
         o = o + emb                                               # skip_2 = Identity
     else:
         o = o + linear_rs(emb, irreps, ir_out, P, f"{blk}.skip_2.skip", bias=True)      # ProjectIfMismatch(layernorm=False)
-    return o, dict(msg_src=msg_src, dtp_weight=weight, log_alpha=log_alpha, value=value, attn=attn, emb=emb)
+    return o, dict(msg_src=msg_src, msg_dst=msg_dst, dtp_weight=weight, log_alpha=log_alpha, value=value, attn=attn, emb=emb)
 
 
 def key_tensor_field(cfg: Config, P, query_x: Tensor, key_pcd_multiscale: Sequence[FeaturedPoints],
                      context_emb: List[Tensor], dbg: Optional[Debug] = None, pre: str = "key_tensor_field",
-                     irreps_output: Optional[Irreps] = None) -> Tensor:
+                     irreps_output: Optional[Irreps] = None, query_f: Optional[Tensor] = None, irreps_query: Optional[Irreps] = None) -> Tensor:
     """MultiscaleTensorField.forward (multiscale_tensor_field.py:192-260) + EquiformerBlock.forward
     (gnn_block.py:164-218) + GraphAttentionMLP2.forward (graph_attention.py:218-273).
     ``pre``: where the module sits in the state dict (``tensor_field`` / ``weight_field`` inside a KeypointExtractor);
     ``irreps_output``: the field's output irreps when they differ from its input irreps (the KeypointExtractor's weight field,
-    keypoint_extractor.py:111-112): the FFN then ends in them and skip_2 is a LinearRS with bias (gnn_block.py:112)."""
+    keypoint_extractor.py:111-112): the FFN then ends in them and skip_2 is a LinearRS with bias (gnn_block.py:112);
+    ``query_f`` / ``irreps_query``: the query points' own features when the field is built with ``irreps_query`` (multiscale_tensor_field.py:49-51,
+    150-162: the block then runs with use_dst_feature=True)."""
     irreps, irreps_sh, H = cfg.irreps, cfg.irreps_sh, cfg.num_heads
     n_total = 0
     E_src, E_dst, E_attr, E_scal, E_logit, E_len = [], [], [], [], [], []
@@ -710,12 +741,13 @@ def key_tensor_field(cfg: Config, P, query_x: Tensor, key_pcd_multiscale: Sequen
         for kp in key_pcd_multiscale:
             assert isinstance(kp.w, Tensor)
         src_w = torch.cat([kp.w for kp in key_pcd_multiscale], dim=0)
-    o, mid_ = equiformer_block(cfg, P, f"{pre}.gnn_block_init", src_f, edge_src, edge_dst, edge_attr, edge_scalars, edge_logits, N_dst, src_w, irreps_output)
+    o, mid_ = equiformer_block(cfg, P, f"{pre}.gnn_block_init", src_f, edge_src, edge_dst, edge_attr, edge_scalars, edge_logits, N_dst, src_w, irreps_output,
+                               dst_f=query_f, irreps_dst=irreps_query)
     msg_src, weight, log_alpha, value, attn, emb = (mid_[k] for k in ("msg_src", "dtp_weight", "log_alpha", "value", "attn", "emb"))
     if dbg is not None:
         dbg.update(edge_src=edge_src, edge_dst=edge_dst, edge_attr=edge_attr, edge_scalars=edge_scalars,
                    edge_logits=edge_logits, edge_length=torch.cat(E_len), msg_src=msg_src, dtp_weight=weight,
-                   log_alpha=log_alpha, value=value, attn=attn, emb=emb, field=o,
+                   log_alpha=log_alpha, value=value, attn=attn, emb=emb, field=o, msg_dst=mid_["msg_dst"],
                    n_edges_per_scale=[len(e) for e in E_src])
     return o
 
@@ -727,11 +759,18 @@ def score_head_forward(cfg: Config, P, Ts: Tensor, key_pcd_multiscale: Sequence[
     assert time.ndim == 1 and len(time) == len(Ts)
     irreps = cfg.irreps
     nT, nQ = len(Ts), len(query_pcd.x)
-    tembs = [t.unsqueeze(-2).expand(-1, nQ, -1).reshape(nT * nQ, -1) for t in time_embeddings(cfg, P, time)]
+    tembs = None
+    if cfg.edge_time_encoding:
+        tembs = [t.unsqueeze(-2).expand(-1, nQ, -1).reshape(nT * nQ, -1) for t in time_embeddings(cfg, P, time)]
     f_t = transform_feature_quaternion(irreps, query_pcd.f, Ts[..., :4])        # (nT, nQ, F)
     x_t = transform_points(query_pcd.x, Ts)                                     # (nT, nQ, 3)
     qf = f_t.clone().reshape(nT * nQ, -1)
-    field = key_tensor_field(cfg, P, x_t.reshape(-1, 3), key_pcd_multiscale, tembs, dbg)
+    query_f, irreps_query = None, None
+    if cfg.query_time_encoding:                                                 # score_head.py:168-173
+        te = cfg.time_emb_mlp[-1]
+        query_f = query_time_embedding(cfg, P, time).unsqueeze(-2).expand(nT, nQ, te).reshape(nT * nQ, te)
+        irreps_query = [(te, 0)]                                                # score_head.py:52, 81-83
+    field = key_tensor_field(cfg, P, x_t.reshape(-1, 3), key_pcd_multiscale, tembs, dbg, query_f=query_f, irreps_query=irreps_query)
 
     n_pre = sum(m for m, l in irreps if l == 1)           # (query 1e + key 1e)//2 with equal irreps
     ir_out = [(1, 0), (n_pre, 1)]

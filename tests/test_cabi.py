@@ -61,9 +61,36 @@ def test_unsupported_configs_are_rejected(built_lib):
     with pytest.raises(ValueError):
         params.HeadConfig.from_kwargs(kw)
     kw = synthetic.score_head_kwargs(2)
-    kw['query_time_encoding'] = True
+    kw['query_time_encoding'], kw['edge_time_encoding'] = True, False          # query-side time encoding alone: not instantiated
+    kw['key_tensor_field_kwargs']['fc_neurons'] = [64, 128, 64]
     with pytest.raises(NotImplementedError):
         params.HeadConfig.from_kwargs(kw)
+    for bad in (dict(lmax=1), dict(half_gemm=1), dict(fc=(128, 32, 32))):       # query_time_encoding: lmax 2 / 3, full precision, [128,128,64] only
+        cfg = params.HeadConfig.from_kwargs(synthetic.score_head_kwargs(bad.get('lmax', 2), query_time_encoding=True))
+        cc = _lib.make_config(cfg, -1)
+        cc.half_gemm = bad.get('half_gemm', 0)
+        for i, v in enumerate(bad.get('fc', (128, 128, 64))):
+            cc.fc_neurons[i] = v
+        assert built_lib.dedf_param_count(C.byref(cc)) == -1, bad
+
+
+@pytest.mark.parametrize("lmax", [2, 3])
+def test_query_time_encoding_schema(built_lib, lmax):
+    """ScoreModelHead(query_time_encoding=True): the state dict gains the query-side time MLP (score_head.py:64-70) and the destination side of the
+    block -- prenorm_dst, linear_dst with bias, skip_1 (gnn_block.py:109-130) -- over irreps_dst = time_emb_mlp[-1] x 0e; linear_src has no bias"""
+    cfg = params.HeadConfig.from_kwargs(synthetic.score_head_kwargs(lmax, query_time_encoding=True))
+    assert cfg.query_time_encoding
+    cc = _lib.make_config(cfg, -1)
+    names = dict(_lib.param_names(cc))
+    assert list(names.items()) == [(n, int(np.prod(s))) for n, s, _, _ in params.param_spec(cfg)]
+    blk = "key_tensor_field.gnn_block_init."
+    assert blk + "linear_src.bias.0" not in names
+    assert names["query_time_mlp.0.weight"] == 128 * 256 and names["query_time_mlp.2.bias"] == 64
+    assert names[blk + "prenorm_dst.affine_weight"] == 64 and names[blk + "prenorm_dst.affine_bias"] == 64
+    assert names[blk + "linear_dst.tp.weight"] == 64 * 64 and names[blk + "linear_dst.bias.0"] == 64
+    assert names[blk + "skip_1.skip.tp.weight"] == 64 * 64 and names[blk + "skip_1.skip.bias.0"] == 64
+    plain = params.n_params(params.HeadConfig.from_kwargs(synthetic.score_head_kwargs(lmax)))
+    assert params.n_params(cfg) == plain - 64 + (128 * 256 + 128 + 64 * 128 + 64) + 2 * (64 * 64 + 64) + 128
 
 
 def _rowmap(r, hi):

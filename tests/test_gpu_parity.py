@@ -59,6 +59,54 @@ def test_score_parity_fake_input_style(lmax):
     _check(SC.stage_report(lmax=lmax, nT=5, n_scene=512, n_grasp=100, verbose=False))
 
 
+@pytest.mark.parametrize("lmax", [2, 3])
+def test_query_time_encoding(lmax):
+    """ScoreModelHead(query_time_encoding=True) (reference score_head.py:64-70, 168-173): the query points carry query_time_mlp(time) as the
+    destination feature of the key field's block -- its LayerNorm + LinearRS joins every edge message (gnn_block.py:172-180), linear_src has no
+    bias, skip_1 of it joins the attention output (:205-206).  Every stage against the fp64 oracle with a DIFFERENT time per pose (per-pose time
+    rows, per-edge radial front), then the sampler (one row per step, radial table) against the oracle's float64 Langevin loop."""
+    rep = SC.stage_report(lmax=lmax, nT=6, n_scene=512, n_grasp=100, verbose=False, query_time_encoding=True)
+    _check(rep)
+    kw, cfg, P, keys, query, Ts, time = SC.build_case(lmax, 8, 512, 100, query_time_encoding=True)
+    assert "key_tensor_field.gnn_block_init.linear_src.bias.0" not in P and "key_tensor_field.gnn_block_init.skip_1.skip.tp.weight" in P
+    ocfg = R.config_from_kwargs(kw)
+    assert ocfg.query_time_encoding
+    g = torch.Generator().manual_seed(9)
+    n_steps = [2, 2]
+    noise = torch.randn(sum(n_steps), 2, len(Ts), 3, generator=g, dtype=torch.float64)
+    sched = [[1.0, 0.5], [0.5, 0.2]]
+    ok = [R.FeaturedPoints(k.x, k.f, k.b) for k in keys]
+    oq = R.FeaturedPoints(query.x, query.f, query.b, query.w)
+    ref = R.sample(ocfg, P, Ts, ok, oq, sched, n_steps, [0.04, 0.02], temperatures=[1.0, 0.5], noise=noise)
+    dev = torch.device('cuda:0')
+    head = ScoreModelHead(**kw)
+    head.load_state_dict(P)
+    head.to(dev)
+    gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
+    gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
+    for table in (False, "always"):
+        head.set_radial_table(table)
+        out = ScoreModelBase(head).sample(Ts.to(dev), gk, gq, sched, n_steps, [0.04, 0.02], temperatures=[1.0, 0.5], noise=noise).cpu()
+        err = float((out - ref).abs().max())
+        print(f"TOLPROBE query-time sampler (table {table}): {err:.2e}")
+        assert err < 5e-5, (table, err)
+    # the time rows are really read: the same weights with the destination side zeroed give another score
+    ang0, lin0 = head(Ts.to(dev).float(), gk, gq, time.to(dev).float())
+    P2 = dict(P)
+    for k in ("linear_dst.tp.weight", "linear_dst.bias.0", "skip_1.skip.tp.weight", "skip_1.skip.bias.0"):
+        P2["key_tensor_field.gnn_block_init." + k] = torch.zeros_like(P["key_tensor_field.gnn_block_init." + k])
+    head.load_state_dict(P2)
+    ang1, lin1 = head(Ts.to(dev).float(), gk, gq, time.to(dev).float())
+    assert float((ang1 - ang0).abs().max()) > 1e-3 * float(ang0.abs().max())
+    # ... and with them zeroed the head IS the plain one (linear_src bias 0): the oracle of the plain configuration at the same weights
+    kw0 = synthetic.score_head_kwargs(lmax, query_time_encoding=False)
+    P0 = {k: v for k, v in P2.items() if not any(s in k for s in ("query_time_mlp", "prenorm_dst", "linear_dst", "skip_1"))}
+    P0["key_tensor_field.gnn_block_init.linear_src.bias.0"] = torch.zeros(64, dtype=torch.float64)
+    a64, l64, _, _ = SC.oracle_run(kw0, P0, keys, query, Ts, time, torch.float64)
+    scale = float(max(a64.abs().max(), l64.abs().max()))
+    assert float((ang1.cpu().double() - a64).abs().max()) / scale < TOL and float((lin1.cpu().double() - l64).abs().max()) / scale < TOL
+
+
 def test_score_parity_c0_plumbing():
     """BASELINE config C0: 4096-pt scene stand-in (820/164/33/7 key points), 2 static keypoints, 4 poses incl. the
     identity quaternion (YXY signed-zero quirk)"""

@@ -66,8 +66,8 @@ def test_radial_func_golden(gr):
 
 # ---------------------------------------------------------------------------------------------------------------------
 
-def _case(lmax, nT=5, n_scene=400, n_grasp=80, radii=(5., 10., 20., None)):
-    kw = synthetic.score_head_kwargs(lmax, radii=radii)
+def _case(lmax, nT=5, n_scene=400, n_grasp=80, radii=(5., 10., 20., None), query_time_encoding=False):
+    kw = synthetic.score_head_kwargs(lmax, radii=radii, query_time_encoding=query_time_encoding)
     cfgp = params.HeadConfig.from_kwargs(kw)
     cfg = R.config_from_kwargs(kw)
     P = params.init_params(cfgp, seed=2, randomize_all=True, dtype=torch.float64)
@@ -110,6 +110,50 @@ def test_right_equivariance(lmax):
     ang2, lin2 = R.score_head_forward(cfg, P, Ts2, keys, q2, time)
     assert (ang2 - R.quaternion_apply(hinv, ang)).abs().max() < 1e-11
     assert (lin2 - R.quaternion_apply(hinv, lin)).abs().max() < 1e-11
+
+
+def test_query_time_encoding_restatement():
+    """query_time_encoding=True (score_head.py:168-173; gnn_block.py:109-130, 170-180, 205-206).  (a) The destination feature is a set of time
+    scalars: both equivariances hold as before.  (b) It is read: another time changes the score through the destination side alone (edge time
+    embedding held fixed by zeroing the time MLPs' last layers).  (c) With linear_dst and skip_1 zeroed the block is the plain one with a zero
+    linear_src bias."""
+    cfg, P, keys, q, Ts, time = _case(2, query_time_encoding=True)
+    assert cfg.query_time_encoding and cfg.edge_time_encoding
+    dbg = R.Debug()
+    ang, lin = R.score_head_forward(cfg, P, Ts, keys, q, time, dbg)
+    nQ = len(q.x)
+    md = dbg['msg_dst'].reshape(len(Ts), nQ, -1)
+    assert (md[:, 0:1] - md).abs().max() == 0 and (md[0, 0] - md[1, 0]).abs().max() > 1e-3       # one row per pose, different times differ
+    assert md[..., 64:].abs().max() == 0                                                         # 0e channels only
+    g, gt = _rand_q(3), torch.tensor([1., -2., 0.5], dtype=torch.float64)
+    keys2 = [R.FeaturedPoints(x=R.quaternion_apply(g, k.x) + gt, f=R.transform_feature_quaternion(cfg.irreps, k.f, g[None])[0], b=k.b) for k in keys]
+    Ts2 = torch.cat([R.quaternion_raw_multiply(g.expand(len(Ts), 4), Ts[:, :4]), R.quaternion_apply(g, Ts[:, 4:]) + gt], -1)
+    ang2, lin2 = R.score_head_forward(cfg, P, Ts2, keys2, q, time)
+    assert (ang2 - ang).abs().max() < 1e-11 and (lin2 - lin).abs().max() < 1e-11
+    h = _rand_q(11)
+    hinv = R.quaternion_invert(h)
+    q2 = R.FeaturedPoints(x=R.quaternion_apply(hinv, q.x), f=R.transform_feature_quaternion(cfg.irreps, q.f, hinv[None])[0], b=q.b, w=q.w)
+    Ts3 = torch.cat([R.quaternion_raw_multiply(Ts[:, :4], h.expand(len(Ts), 4)), Ts[:, 4:]], -1)
+    ang3, lin3 = R.score_head_forward(cfg, P, Ts3, keys, q2, time)
+    assert (ang3 - R.quaternion_apply(hinv, ang)).abs().max() < 1e-11 and (lin3 - R.quaternion_apply(hinv, lin)).abs().max() < 1e-11
+    # (b)
+    Pb = dict(P)
+    for n in range(4):
+        Pb[f"time_mlps_multiscale.{n}.2.weight"] = torch.zeros_like(P[f"time_mlps_multiscale.{n}.2.weight"])
+    a1, _ = R.score_head_forward(cfg, Pb, Ts, keys, q, torch.full_like(time, 0.3))
+    a2, _ = R.score_head_forward(cfg, Pb, Ts, keys, q, torch.full_like(time, 0.8))
+    assert (a1 - a2).abs().max() > 1e-3 * a1.abs().max()
+    # (c)
+    blk = "key_tensor_field.gnn_block_init."
+    Pc = dict(P)
+    for k in ("linear_dst.tp.weight", "linear_dst.bias.0", "skip_1.skip.tp.weight", "skip_1.skip.bias.0"):
+        Pc[blk + k] = torch.zeros_like(P[blk + k])
+    ac, lc = R.score_head_forward(cfg, Pc, Ts, keys, q, time)
+    cfg0 = R.config_from_kwargs(synthetic.score_head_kwargs(2))
+    P0 = dict(Pc)
+    P0[blk + "linear_src.bias.0"] = torch.zeros(64, dtype=torch.float64)
+    a0, l0 = R.score_head_forward(cfg0, P0, Ts, keys, q, time)
+    assert (ac - a0).abs().max() < 1e-13 and (lc - l0).abs().max() < 1e-13 and (ac - ang).abs().max() > 1e-3
 
 
 def test_softmax_normalisation_and_empty_segments():
