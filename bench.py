@@ -438,7 +438,7 @@ def main():
         # path one product per output component instead of the Clebsch-Gordan sum, and no GEMM terms for components a path cannot reach.  `frac`
         # stays on the SAME constant as rounds 2-4 (SURVEY 8(d)'s algorithmic work minus what the table serves): it is the edge rate in fixed
         # units, comparable across rounds; what the pipes really did is `gemm_mac_per_edge_executed` / `frac_gemm_executed` and `frac_mfma_issued`.
-        so2_on = os.environ.get("DEDF_SO2", "1") != "0" and not args.half
+        so2_on = os.environ.get("DEDF_SO2", "1") != "0" or args.half      # (the half-precision mode has the edge-frame kernels only)
         gemm_general = M_EDGE[args.lmax] - M_EDGE_CG[args.lmax] - (M_EDGE_FRONT[args.lmax] if table_on else 0)      # (true shapes, as SURVEY counts them)
         gemm_exec = (edge_frame_gemm_mac(args.lmax) + (0 if table_on else M_EDGE_FRONT[args.lmax])) if so2_on else gemm_general
         flops_exec = 2.0 * e_per_launch * m_exec

@@ -1,17 +1,12 @@
 #!/bin/bash
 # scratch driver for one gpurun call (rewritten per session)
 ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out; mkdir -p $OUT; cd $ROOT; export TMPDIR=/tmp
-python tests/probe/small_batch.py 2 200 > $OUT/r05y_small_batch.log 2>&1
-python -m pytest tests -x -q -m gpu -k "tiny_batches or other_scale_counts or max_neighbors or sampler_parity or c2_bi_equi or workspace or eight_scales" > $OUT/r05y_tests.log 2>&1; tail -3 $OUT/r05y_tests.log
-COMMON="--no-cpu-baseline --no-extractors --no-small-batches --no-score-fwd"
-cd /tmp
-rocprofv3 --kernel-trace --stats -d $OUT/r05y_p16_trace -- python $ROOT/bench.py --poses-per-gpu 16 --steps 200 --warmup 5 $COMMON > $OUT/r05y_p16_trace_bench.json 2> $OUT/r05y_p16_trace.log
+python -m pytest tests -x -q -m gpu --durations=8 > $OUT/r05z_gpu_suite.log 2>&1; tail -3 $OUT/r05z_gpu_suite.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/r05z_smoke.log 2>&1; tail -1 $OUT/r05z_smoke.log
+bash profiles/collect.sh r05z "trace fetch write sq sq2 sq3 bench" > $OUT/r05z_collect.log 2>&1
 cd $ROOT
-python - <<PY > $OUT/r05y_p16_kernel_stats.txt
-import sqlite3, glob
-f = sorted(glob.glob("$OUT/r05y_p16_trace/*/*_results.db"))[-1]
-con = sqlite3.connect(f)
-for r in con.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
-    print(f"{r[0][:100]:100s} {r[1]:6d} {r[2]:14.1f} {r[3]:12.2f} {r[4]:6.2f}")
-PY
-rm -rf $OUT/r05y_p16_trace
+python bench.py --gpus 1 --steps 20 --warmup 5 --lmax 3 > $OUT/r05z_lmax3_bench.json 2>/dev/null
+python bench.py --gpus 1 --steps 20 --warmup 5 --half > $OUT/r05z_half_bench.json 2>/dev/null
+python bench.py --gpus 1 --steps 20 --warmup 5 --config5 > $OUT/r05z_config5_bench.json 2>/dev/null
+python bench.py --lmax 1 --scene 2048 --grasp 512 --poses-per-gpu 256 --steps 50 --warmup 5 --no-extractors > $OUT/r05z_c1_bench.json 2>/dev/null
+python bench.py --gpus 1 --steps 20 --warmup 5 --poses-per-gpu 8000 --no-extractors --no-small-batches > $OUT/r05z_poses8000_bench.json 2>/dev/null
