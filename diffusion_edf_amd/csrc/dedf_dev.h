@@ -411,13 +411,20 @@ template <bool HP> DEDF_DEV HL split8sx(const float (&x)[8], float scale) {
     static_for<8>([&]<int J>() { t[J] = x[J] * scale; });
     return split8x<HP>(t);
 }
-// Same with the B chunks already split:  bh.operator()<chunk>() -> HL
+// Same with the B chunks already split:  bh.operator()<chunk>() -> HL   (ring: the first PD chunks' operands, requested ahead -- dense_prefetch)
+template <int NTO, int NCH, int PD = 2, bool HP = false, class BF>
+DEDF_DEV void dense_rot_hp(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[NTO], BF&& bh, const DenseRing<NTO, PD>& ring);
 template <int NTO, int NCH, int PD = 2, bool HP = false, class BF>
 DEDF_DEV void dense_rot_hp(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[NTO], BF&& bh) {
-    f32x4 rh[PD][NTO], rl[PD][NTO] = {};
     sched_fence();
-    static_for<PD>([&]<int k>() { if constexpr (k < NCH) static_for<NTO>([&]<int To>() {
-        rh[k][To] = lda(wv, off_h, NCH, To, k); if constexpr (!HP) rl[k][To] = lda(wv, off_l, NCH, To, k); }); });
+    const DenseRing<NTO, PD> ring = dense_prefetch<NTO, NCH, PD, HP>(wv, off_h, off_l);
+    dense_rot_hp<NTO, NCH, PD, HP>(wv, off_h, off_l, acc, static_cast<BF&&>(bh), ring);
+}
+template <int NTO, int NCH, int PD, bool HP, class BF>
+DEDF_DEV void dense_rot_hp(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[NTO], BF&& bh, const DenseRing<NTO, PD>& ring) {
+    f32x4 rh[PD][NTO], rl[PD][NTO] = {};
+    static_for<PD>([&]<int k>() { static_for<NTO>([&]<int To>() { rh[k][To] = ring.h[k][To]; rl[k][To] = ring.l[k][To]; }); });
+    sched_fence();
     static_for<NCH>([&]<int c>() {
         f32x4 ch[NTO], cl[NTO];
         static_for<NTO>([&]<int To>() { ch[To] = rh[c % PD][To]; cl[To] = rl[c % PD][To]; });
@@ -440,12 +447,29 @@ DEDF_DEV void dense_rot_hp(const Wave& wv, int off_h, int off_l, f32x16 (&acc)[N
 }
 // One output tile (To, of a matrix with nCH chunks per tile) applied to NM right-hand sides that share the A operands
 // (e.g. the 2l+1 components of an l-block):   bh.operator()<m, chunk>() -> HL
+// (the first PD chunks' operands can be requested ahead of time -- shared_prefetch, e.g. before the VALU work that follows the PREVIOUS product: a lone
+//  wave has nothing else to hide the first requests of a product behind, and the node kernel runs ~45 of them per tile)
+template <int PD> struct SharedRing { f32x4 h[PD], l[PD]; };
+template <int NCH, int PD = 2, bool HP = false>
+DEDF_DEV SharedRing<PD> shared_prefetch(const Wave& wv, int off_h, int off_l, int nCH, int To) {
+    SharedRing<PD> r{};
+    static_for<PD>([&]<int k>() { if constexpr (k < NCH) {
+        r.h[k] = bldw(wv, wv.lane16, (off_h + (To * nCH + k) * 256) * 4); if constexpr (!HP) r.l[k] = bldw(wv, wv.lane16, (off_l + (To * nCH + k) * 256) * 4); } });
+    return r;
+}
+template <int NM, int NCH, int PD = 2, bool HP = false, class BF>
+DEDF_DEV void dense_shared_hp(const Wave& wv, int off_h, int off_l, int nCH, int To, f32x16 (&acc)[NM], BF&& bh, const SharedRing<PD>& ring);
 template <int NM, int NCH, int PD = 2, bool HP = false, class BF>
 DEDF_DEV void dense_shared_hp(const Wave& wv, int off_h, int off_l, int nCH, int To, f32x16 (&acc)[NM], BF&& bh) {
-    f32x4 rh[PD], rl[PD] = {};
     sched_fence();
-    static_for<PD>([&]<int k>() { if constexpr (k < NCH) {
-        rh[k] = bldw(wv, wv.lane16, (off_h + (To * nCH + k) * 256) * 4); if constexpr (!HP) rl[k] = bldw(wv, wv.lane16, (off_l + (To * nCH + k) * 256) * 4); } });
+    const SharedRing<PD> ring = shared_prefetch<NCH, PD, HP>(wv, off_h, off_l, nCH, To);
+    dense_shared_hp<NM, NCH, PD, HP>(wv, off_h, off_l, nCH, To, acc, static_cast<BF&&>(bh), ring);
+}
+template <int NM, int NCH, int PD, bool HP, class BF>
+DEDF_DEV void dense_shared_hp(const Wave& wv, int off_h, int off_l, int nCH, int To, f32x16 (&acc)[NM], BF&& bh, const SharedRing<PD>& ring) {
+    f32x4 rh[PD], rl[PD] = {};
+    static_for<PD>([&]<int k>() { rh[k] = ring.h[k]; rl[k] = ring.l[k]; });
+    sched_fence();
     static_for<NCH>([&]<int c>() {
         const h8 ch = __builtin_bit_cast(h8, rh[c % PD]), cl = __builtin_bit_cast(h8, rl[c % PD]);
         sched_fence();

@@ -139,6 +139,28 @@ template <int L> DEDF_DEV void feat_store_ref(const Feat<L>& f, float* node_ptr,
     });
 }
 
+// the (path, row tile) products of one score tensor product in the order node_tile walks them: grouped by input degree (the rotated query rows of a
+// degree serve all its paths), then path, then row tile -- so that every product can request the first operands of the NEXT one
+struct StpStep { int p, To; };
+template <int L> DEDF_HD constexpr int stp_num_steps() {
+    int n = 0;
+    for (int p = 0; p < stp_num_paths<L>(); ++p) n += cdiv(stp_path<L>(p).mul1, 32);
+    return n;
+}
+template <int L> DEDF_HD constexpr StpStep stp_step(int i) {
+    int n = 0;
+    for (int l1 = 0; l1 <= L; ++l1)
+        for (int p = 0; p < stp_num_paths<L>(); ++p) {
+            if (stp_path<L>(p).l1 != l1) continue;
+            for (int To = 0; To < cdiv(stp_path<L>(p).mul1, 32); ++To) { if (n == i) return StpStep{p, To}; ++n; }
+        }
+    return StpStep{-1, 0};
+}
+template <int L> DEDF_HD constexpr int stp_step_index(int p, int To) {
+    for (int i = 0; i < stp_num_steps<L>(); ++i) if (stp_step<L>(i).p == p && stp_step<L>(i).To == To) return i;
+    return -1;
+}
+
 template <int L, bool EBM, bool HP = false, bool UN = false>
 DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0, int tp_only = -1) {
     constexpr int D = feat_dim<L>();
@@ -150,6 +172,20 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0, int tp_only
     const int n = valid ? n0 + wv.col : n0;
     const int pose = n / P.nQ, q = n - pose * P.nQ;
 
+#ifndef DEDF_NODE_CARRY
+#define DEDF_NODE_CARRY 2    // 1: every (path, row tile) product of the score tensor products requests the first operands of the next one before it starts;
+                             // 2: the shared-operand products of proj / FFN too;  3: and their rotated-accumulator products (A/B: 0)
+#endif
+    constexpr bool CARRY2 = DEDF_NODE_CARRY >= 2 && L <= 2;      // (lmax 3: 300 -> 360 B of scratch with it)
+    constexpr bool CARRY3 = DEDF_NODE_CARRY >= 3 && L <= 2;
+    using SR = SharedRing<2>;
+    auto pf = [&]<int NCH>(int off_h, int off_l, int nCH, int To) -> SR {      // first operands of a later product, requested now
+        if constexpr (CARRY2) return shared_prefetch<NCH, 2, HP>(wv, off_h, off_l, nCH, To); else return SR{};
+    };
+    auto gemm_sh = [&]<int NM, int NCH>(int off_h, int off_l, int nCH, int To, f32x16 (&acc)[NM], auto&& bh, const SR& ring) {
+        if constexpr (CARRY2) dense_shared_hp<NM, NCH, 2, HP>(wv, off_h, off_l, nCH, To, acc, bh, ring);
+        else dense_shared_hp<NM, NCH, 2, HP>(wv, off_h, off_l, nCH, To, acc, bh);
+    };
     // ---- load aggregated attention values (internal layout [l][m][channel]) ---------------------------------------------
     Feat<L> z;
     {
@@ -176,27 +212,34 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0, int tp_only
     // ---- proj: per-l dense matrix (+ bias on 0e); all GEMMs of this kernel are 3-term split-fp16 MFMA products -----------------
     Feat<L> emb;
     {
+        SR rp1{}, rp2{}, rp3{};
+        DenseRing<2, 2> rp0{};
+        if constexpr (CARRY3) rp0 = dense_prefetch<2, 4, 2, HP>(wv, O.A_proj[0], O.A_proj_l[0]);
+        if constexpr (L >= 1) rp1 = pf.template operator()<2>(O.A_proj[1], O.A_proj_l[1], 2, 0);
         const FeatH<L> zh = split_feat<L, HP>(z, opaque_s(P.sc.bz));
         f32x16 a0[2];
         static_for<2>([&]<int To>() { a0[To] = node_ldrows(rows, hi, NR::b_proj0, To); });
-        dense_rot_hp<2, 4, 2, HP>(wv, O.A_proj[0], O.A_proj_l[0], a0, [&]<int c>() { return zh.s[c]; });
+        if constexpr (CARRY3) dense_rot_hp<2, 4, 2, HP>(wv, O.A_proj[0], O.A_proj_l[0], a0, [&]<int c>() { return zh.s[c]; }, rp0);
+        else dense_rot_hp<2, 4, 2, HP>(wv, O.A_proj[0], O.A_proj_l[0], a0, [&]<int c>() { return zh.s[c]; });
         const float c0 = opaque_s(P.sc.proj[0]);
         static_for<2>([&]<int To>() { static_for<16>([&]<int R>() { emb.s[To][R] = a0[To][R] * c0; }); });
         if constexpr (L >= 1) {
             f32x16 a[3] = {{0}, {0}, {0}};
-            dense_shared_hp<3, 2, 2, HP>(wv, O.A_proj[1], O.A_proj_l[1], 2, 0, a, [&]<int m, int c>() { return zh.v1[m][c]; });
+            if constexpr (L >= 2) rp2 = pf.template operator()<1>(O.A_proj[2], O.A_proj_l[2], 1, 0);
+            gemm_sh.template operator()<3, 2>(O.A_proj[1], O.A_proj_l[1], 2, 0, a, [&]<int m, int c>() { return zh.v1[m][c]; }, rp1);
             const float c1 = opaque_s(P.sc.proj[1]);
             static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { emb.v1[m][R] = a[m][R] * c1; }); });
         }
         if constexpr (L >= 2) {
             f32x16 a[5] = {{0}, {0}, {0}, {0}, {0}};
-            dense_shared_hp<5, 1, 2, HP>(wv, O.A_proj[2], O.A_proj_l[2], 1, 0, a, [&]<int m, int c>() { return zh.v2[m][c]; });
+            if constexpr (L >= 3) rp3 = pf.template operator()<1>(O.A_proj[3], O.A_proj_l[3], 1, 0);
+            gemm_sh.template operator()<5, 1>(O.A_proj[2], O.A_proj_l[2], 1, 0, a, [&]<int m, int c>() { return zh.v2[m][c]; }, rp2);
             const float c2 = opaque_s(P.sc.proj[2]);
             static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { emb.v2[m][R] = a[m][R] * c2; }); });
         }
         if constexpr (L >= 3) {
             f32x16 a[7] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}};
-            dense_shared_hp<7, 1, 2, HP>(wv, O.A_proj[3], O.A_proj_l[3], 1, 0, a, [&]<int m, int c>() { return zh.v3[m][c]; });
+            gemm_sh.template operator()<7, 1>(O.A_proj[3], O.A_proj_l[3], 1, 0, a, [&]<int m, int c>() { return zh.v3[m][c]; }, rp3);
             const float c3 = opaque_s(P.sc.proj[3]);
             static_for<7>([&]<int m>() { static_for<8>([&]<int R>() { emb.v3[m][R] = a[m][R] * c3; }); });
         }
@@ -285,22 +328,32 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0, int tp_only
         b.lo = __builtin_bit_cast(h8, fp[(slot + 1) * 64]);
         return b;
     };
+    DenseRing<6, 1> rf10{};
+    if constexpr (CARRY3) rf10 = dense_prefetch<6, 4, 1, HP>(wv, O.A_f1[0], O.A_f1_l[0]);      // under the split + parking of the normalised features
     park(nrm, opaque_s(P.sc.bn));
     const float bh0 = opaque_s(P.sc.bh[0]), bh1 = opaque_s(P.sc.bh[L >= 1 ? 1 : 0]), bh2 = opaque_s(P.sc.bh[L >= 2 ? 2 : 0]), bh3 = opaque_s(P.sc.bh[L >= 3 ? 3 : 0]);
     (void)bh1; (void)bh2; (void)bh3;
+    constexpr int NGT0 = NF1 - 6;
+    DenseRing<NGT0, 1> rg{};      // first operands of the gate rows' product: requested when the hidden scalars' registers are free (behind fctp_2's l = 0 product)
     {   // l = 0: 192 hidden scalars (6 tiles) -> SiLU -> fctp_2
         f32x16 hs[6];
         static_for<6>([&]<int To>() { hs[To] = node_ldrows(rows, hi, NR::b_f1, To); });
-        dense_rot_hp<6, 4, 1, HP>(wv, O.A_f1[0], O.A_f1_l[0], hs, [&]<int c>() { return parked.template operator()<0, 0, c>(); });
+        DenseRing<2, 2> rf20{};
+        if constexpr (CARRY3) rf20 = dense_prefetch<2, 12, 2, HP>(wv, O.A_f2[0], O.A_f2_l[0]);
+        if constexpr (CARRY3) dense_rot_hp<6, 4, 1, HP>(wv, O.A_f1[0], O.A_f1_l[0], hs, [&]<int c>() { return parked.template operator()<0, 0, c>(); }, rf10);
+        else dense_rot_hp<6, 4, 1, HP>(wv, O.A_f1[0], O.A_f1_l[0], hs, [&]<int c>() { return parked.template operator()<0, 0, c>(); });
         const float c1 = opaque_s(P.sc.f1[0]);
         static_for<6>([&]<int To>() { static_for<16>([&]<int R>() { hs[To][R] = silu_n(hs[To][R] * c1); }); });
         f32x16 o0[2];
         static_for<2>([&]<int T>() { o0[T] = node_ldrows(rows, hi, NR::b_f2, T); });
-        dense_rot_hp<2, 12, 2, HP>(wv, O.A_f2[0], O.A_f2_l[0], o0, [&]<int c>() {
+        auto bh_f2 = [&]<int c>() {
             float t[8];
             static_for<8>([&]<int J>() { t[J] = hs[c / 2][8 * (c % 2) + J]; });
             return split8sx<HP>(t, bh0);
-        });
+        };
+        if constexpr (CARRY3) dense_rot_hp<2, 12, 2, HP>(wv, O.A_f2[0], O.A_f2_l[0], o0, bh_f2, rf20);
+        else dense_rot_hp<2, 12, 2, HP>(wv, O.A_f2[0], O.A_f2_l[0], o0, bh_f2);
+        if constexpr (CARRY3) rg = dense_prefetch<NGT0, 4, 1, HP>(wv, O.A_f1[0] + 6 * 4 * 256, O.A_f1_l[0] + 6 * 4 * 256);
         const float c2 = opaque_s(P.sc.f2[0]);
         static_for<2>([&]<int T>() { static_for<16>([&]<int R>() { fld.s[T][R] = o0[T][R] * c2 + emb.s[T][R]; }); });
     }
@@ -308,8 +361,12 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0, int tp_only
     constexpr int NGT = NF1 - 6;
     f32x16 gt[NGT];
     static_for<NGT>([&]<int t>() { gt[t] = node_ldrows(rows, hi, NR::b_f1, 6 + t); });
+    SR rf1{};       // carried from product to product through the rest of the FFN
+    if constexpr (L >= 1) rf1 = pf.template operator()<2>(O.A_f1[1], O.A_f1_l[1], 2, 0);
     {
         // the gate tiles start at tile 6 of the same matrix (4 chunks per tile) -> shift the image offsets
+        if constexpr (CARRY3) dense_rot_hp<NGT, 4, 1, HP>(wv, O.A_f1[0] + 6 * 4 * 256, O.A_f1_l[0] + 6 * 4 * 256, gt, [&]<int c>() { return parked.template operator()<0, 0, c>(); }, rg);
+        else
         dense_rot_hp<NGT, 4, 1, HP>(wv, O.A_f1[0] + 6 * 4 * 256, O.A_f1_l[0] + 6 * 4 * 256, gt, [&]<int c>() { return parked.template operator()<0, 0, c>(); });
         const float c1 = opaque_s(P.sc.f1[0]);
         static_for<NGT>([&]<int t>() { static_for<16>([&]<int R>() { gt[t][R] = sigmoid_n(gt[t][R] * c1); }); });
@@ -319,15 +376,20 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0, int tp_only
         const float c1 = opaque_s(P.sc.f1[1]);
         static_for<3>([&]<int t>() {
             static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] = 0.0f; }); });
-            dense_shared_hp<3, 2, 2, HP>(wv, O.A_f1[1], O.A_f1_l[1], 2, t, hh[t], [&]<int m, int c>() { return parked.template operator()<1, m, c>(); });
+            const SR cur = rf1;
+            if constexpr (t < 2) rf1 = pf.template operator()<2>(O.A_f1[1], O.A_f1_l[1], 2, t + 1);
+            else rf1 = pf.template operator()<6>(O.A_f2[1], O.A_f2_l[1], 6, 0);
+            gemm_sh.template operator()<3, 2>(O.A_f1[1], O.A_f1_l[1], 2, t, hh[t], [&]<int m, int c>() { return parked.template operator()<1, m, c>(); }, cur);
             static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] *= gt[t][R] * c1; }); });
         });
         f32x16 o[3] = {{0}, {0}, {0}};
-        dense_shared_hp<3, 6, 2, HP>(wv, O.A_f2[1], O.A_f2_l[1], 6, 0, o, [&]<int m, int c>() {
+        const SR cur1 = rf1;
+        if constexpr (L >= 2) rf1 = pf.template operator()<1>(O.A_f1[2], O.A_f1_l[2], 1, 0);
+        gemm_sh.template operator()<3, 6>(O.A_f2[1], O.A_f2_l[1], 6, 0, o, [&]<int m, int c>() {
             float t[8];
             static_for<8>([&]<int J>() { t[J] = hh[c / 2][m][8 * (c % 2) + J]; });
             return split8sx<HP>(t, bh1);
-        });
+        }, cur1);
         const float c2 = opaque_s(P.sc.f2[1]);
         static_for<3>([&]<int m>() { static_for<16>([&]<int R>() { fld.v1[m][R] = o[m][R] * c2 + emb.v1[m][R]; }); });
     }
@@ -336,16 +398,21 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0, int tp_only
         const float c1 = opaque_s(P.sc.f1[2]);
         static_for<2>([&]<int t>() {
             static_for<5>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] = 0.0f; }); });
-            dense_shared_hp<5, 1, 2, HP>(wv, O.A_f1[2], O.A_f1_l[2], 1, t, hh[t], [&]<int m, int c>() { return parked.template operator()<2, m, c>(); });
+            const SR cur = rf1;
+            if constexpr (t < 1) rf1 = pf.template operator()<1>(O.A_f1[2], O.A_f1_l[2], 1, t + 1);
+            else rf1 = pf.template operator()<3>(O.A_f2[2], O.A_f2_l[2], 3, 0);
+            gemm_sh.template operator()<5, 1>(O.A_f1[2], O.A_f1_l[2], 1, t, hh[t], [&]<int m, int c>() { return parked.template operator()<2, m, c>(); }, cur);
             static_for<5>([&]<int m>() { static_for<16>([&]<int R>() { hh[t][m][R] *= gt[3 + t][R] * c1; }); });
         });
         f32x16 o[5] = {{0}, {0}, {0}, {0}, {0}};
         // K = 48: chunks 0, 1 read hidden tile 0, chunk 2 the valid half of tile 1
-        dense_shared_hp<5, 3, 2, HP>(wv, O.A_f2[2], O.A_f2_l[2], 3, 0, o, [&]<int m, int c>() {
+        const SR cur2 = rf1;
+        if constexpr (L >= 3) rf1 = pf.template operator()<1>(O.A_f1[3], O.A_f1_l[3], 1, 0);
+        gemm_sh.template operator()<5, 3>(O.A_f2[2], O.A_f2_l[2], 3, 0, o, [&]<int m, int c>() {
             float t[8];
             static_for<8>([&]<int J>() { t[J] = hh[c / 2][m][8 * (c % 2) + J]; });
             return split8sx<HP>(t, bh2);
-        });
+        }, cur2);
         const float c2 = opaque_s(P.sc.f2[2]);
         static_for<5>([&]<int m>() { static_for<8>([&]<int R>() { fld.v2[m][R] = o[m][R] * c2 + emb.v2[m][R]; }); });
     }
@@ -354,16 +421,18 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0, int tp_only
         f32x16 hh[7];
         const float c1 = opaque_s(P.sc.f1[3]);
         static_for<7>([&]<int m>() { static_for<16>([&]<int R>() { hh[m][R] = 0.0f; }); });
-        dense_shared_hp<7, 1, 2, HP>(wv, O.A_f1[3], O.A_f1_l[3], 1, 0, hh, [&]<int m, int c>() { return parked.template operator()<3, m, c>(); });
+        const SR cur3 = rf1;
+        rf1 = pf.template operator()<2>(O.A_f2[3], O.A_f2_l[3], 2, 0);
+        gemm_sh.template operator()<7, 1>(O.A_f1[3], O.A_f1_l[3], 1, 0, hh, [&]<int m, int c>() { return parked.template operator()<3, m, c>(); }, cur3);
         static_for<7>([&]<int m>() { static_for<16>([&]<int R>() {
             if constexpr (R < 8) hh[m][R] *= gt[4][R + 8] * c1; else hh[m][R] *= gt[5][R - 8] * c1;
         }); });
         f32x16 o[7] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}};
-        dense_shared_hp<7, 2, 2, HP>(wv, O.A_f2[3], O.A_f2_l[3], 2, 0, o, [&]<int m, int c>() {
+        gemm_sh.template operator()<7, 2>(O.A_f2[3], O.A_f2_l[3], 2, 0, o, [&]<int m, int c>() {
             float t[8];
             static_for<8>([&]<int J>() { t[J] = hh[m][8 * c + J]; });
             return split8sx<HP>(t, bh3);
-        });
+        }, rf1);
         const float c2 = opaque_s(P.sc.f2[3]);
         static_for<7>([&]<int m>() { static_for<8>([&]<int R>() { fld.v3[m][R] = o[m][R] * c2 + emb.v3[m][R]; }); });
     }
@@ -457,12 +526,19 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0, int tp_only
     park(fld, opaque_s(P.sc.bf));            // the field as B operands, shared by every path of both tensor products
     static_for<2>([&]<int tp>() {
         if (tp_only >= 0 && tp_only != tp) return;      // (wave-uniform: the other product is the partner wave's, NodeParams::split)
-        f32x16 gacc = node_ldrows(rows, hi, tp == 0 ? NR::b_sl0 : NR::b_sl1, 0);
-        f32x16 vacc[3];
-        static_for<3>([&]<int K>() { static_for<16>([&]<int R>() { vacc[K][R] = 0.0f; }); });
 #ifndef DEDF_NODE_SPD
 #define DEDF_NODE_SPD 2      // operand prefetch depth of the score tensor products' first-stage GEMMs (experiments: 3, 4)
 #endif
+        // first operands of the walk's first product (stp_step): in flight under the accumulator setup and the first rotation of query rows
+        SharedRing<DEDF_NODE_SPD> nxt{};
+        if constexpr (DEDF_NODE_CARRY) {
+            constexpr StpStep s0 = stp_step<L>(0);
+            constexpr int NCK0 = stp_path<L>(s0.p).mul2 / 16;
+            nxt = shared_prefetch<NCK0, DEDF_NODE_SPD, HP>(wv, O.A_s[tp][s0.p], O.A_s_l[tp][s0.p], NCK0, s0.To);
+        }
+        f32x16 gacc = node_ldrows(rows, hi, tp == 0 ? NR::b_sl0 : NR::b_sl1, 0);
+        f32x16 vacc[3];
+        static_for<3>([&]<int K>() { static_for<16>([&]<int R>() { vacc[K][R] = 0.0f; }); });
 #ifndef DEDF_NODE_HOIST_ROT
 #define DEDF_NODE_HOIST_ROT 1
 #endif
@@ -514,6 +590,17 @@ DEDF_DEV void node_tile(const NodeParams& P, const Wave& wv, int n0, int tp_only
                 });
                 f32x16 T[d2];
                 static_for<d2>([&]<int j>() { static_for<16>([&]<int R>() { T[j][R] = 0.0f; }); });
+                if constexpr (DEDF_NODE_CARRY && DEDF_NODE_HOIST_ROT) {
+                    const SharedRing<DEDF_NODE_SPD> cur = nxt;
+                    constexpr int si = stp_step_index<L>(p, To);
+                    static_assert(si >= 0, "score TP walk");
+                    if constexpr (si + 1 < stp_num_steps<L>()) {
+                        constexpr StpStep sn = stp_step<L>(si + 1);
+                        constexpr int NCKn = stp_path<L>(sn.p).mul2 / 16;
+                        nxt = shared_prefetch<NCKn, DEDF_NODE_SPD, HP>(wv, O.A_s[tp][sn.p], O.A_s_l[tp][sn.p], NCKn, sn.To);
+                    }
+                    dense_shared_hp<d2, NCK, DEDF_NODE_SPD, HP>(wv, O.A_s[tp][p], O.A_s_l[tp][p], NCK, To, T, [&]<int j, int c>() { return parked.template operator()<l2, j, c>(); }, cur);
+                } else
                 dense_shared_hp<d2, NCK, DEDF_NODE_SPD, HP>(wv, O.A_s[tp][p], O.A_s_l[tp][p], NCK, To, T, [&]<int j, int c>() { return parked.template operator()<l2, j, c>(); });
                 static_for<NC2>([&]<int cc>() {
                     constexpr int u0 = 32 * To + 16 * cc;
