@@ -715,7 +715,9 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         mark();
         const dim3 g(nblk, np.word_start[ns] + 1);
         hipLaunchKernelGGL(k_nbr_masks_small<L>, g, dim3(kNbrBlock), 0, st, np, h->d_Ts.as<float>(), T64, h->d_qx.as<float>(), nQ, nT, h->d_pose.as<float>(), h->d_qpos.as<float>());
-        hipLaunchKernelGGL(k_neighbors<true>, dim3(nblk), dim3(kNbrBlock), 0, st, np);
+        // (few destination blocks: the fill pass's bit walk is split over G blocks per destination block, dedf_misc.h)
+        const int G = std::max(1, std::min(16, (2 * h->n_cu) / std::max(1, nblk)));
+        hipLaunchKernelGGL(k_neighbors<true>, dim3(nblk, G), dim3(kNbrBlock), 0, st, np);
     } else {
     // 1. poses: Wigner-D + transformed query positions
     hipLaunchKernelGGL(k_pose_prep<L>, dim3(nT), dim3(64), 0, st, h->d_Ts.as<float>(), T64, h->d_qx.as<float>(), nQ, h->d_pose.as<float>(), h->d_qpos.as<float>());

@@ -400,9 +400,12 @@ __device__ inline int block_exclusive_scan_256(int v, int* total) {
 
 // Count pass: every destination tests every key of every scale (keys staged in LDS as float4: one broadcast ds_read_b128 per
 // key), counts its neighbours and leaves a bit mask of them ([word][dst], coalesced).  Fill pass: walks the set bits only.
+constexpr int kFillStage = 4096;      // edges of one scale a block stages in LDS (2 x 16 KB: 16 per destination; C2 has ~20 over all four scales)
 template <bool FILL>
 __global__ __launch_bounds__(kNbrBlock) void k_neighbors(NbrParams P) {
-    __shared__ f32x4 kx[kNbrChunk];
+    __shared__ f32x4 kx[FILL ? 2 * kFillStage / 4 : kNbrChunk];      // count pass: the key chunk; fill pass: the staging run (src | dst)
+    int* const st_src = reinterpret_cast<int*>(kx);
+    int* const st_dst = st_src + kFillStage;
     const int d = blockIdx.x * kNbrBlock + threadIdx.x;
     const bool act = d < P.n_dst;
     float px = 0, py = 0, pz = 0;
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(kNbrBlock) void k_neighbors(NbrParams P) {
             if ((threadIdx.x & 63) == 0) { atomicAdd(&s_tot[n], tot); atomicAdd(&s_pre[n], pre); }      // integers: order-independent
         }
         __syncthreads();
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
             int tiles = 0;
             int64_t edges = 0;
             P.tile_info[0] = 0; P.tile_info[16] = 0;
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(kNbrBlock) void k_neighbors(NbrParams P) {
         const int w0 = P.word_start[n], nw = P.word_start[n + 1] - w0;
         if (FILL) {
             const int mine = act ? P.cnt[(size_t)n * P.n_dst + d] : 0;
-            if (P.zero_cnt != nullptr) {
+            if (P.zero_cnt != nullptr && blockIdx.y == 0) {
                 if (act) P.zero_cnt[(size_t)n * P.n_dst + d] = 0;
                 if (blockIdx.x == 0) for (int i = threadIdx.x; i < (int)gridDim.x; i += kNbrBlock) P.zero_blk[(size_t)n * gridDim.x + i] = 0;
             }
@@ -455,9 +458,54 @@ __global__ __launch_bounds__(kNbrBlock) void k_neighbors(NbrParams P) {
             const int ex = block_exclusive_scan_256(mine, &total);
             const int o = s_pre[n] + ex;
             const int64_t base = scale_base + o;
+            const int64_t blk_base = scale_base + s_pre[n];      // first edge of this block's destinations in the scale
             scale_base += s_tot[n];
+            if (act && blockIdx.y == 0) P.off[(size_t)n * P.n_dst + d] = o;
+            // Small batches (gridDim.y = G > 1): a handful of blocks would walk ~150 divergent bit-loop iterations each while the chip idles (16 of
+            // the pass's 23.5 us at 16 poses: timing builds, profiles/r05zc_fill_timing.txt).  The mask WORDS are split over G blocks per destination
+            // block: every one of them repeats the cheap part (counts, scans, the popcounts of the words before its own) and walks only its share.
+            if (gridDim.y > 1) {
+                if (!act) continue;
+                const int nW = P.word_start[P.n_scales];
+                const int gw0 = (int)((int64_t)blockIdx.y * nW / gridDim.y), gw1 = (int)((int64_t)(blockIdx.y + 1) * nW / gridDim.y);
+                if (w0 >= gw1 || w0 + nw <= gw0) continue;          // none of this scale's words are mine
+                int c = 0;
+                for (int g = 0; g < nw && w0 + g < gw1; ++g) {
+                    uint32_t word = P.mask[(size_t)(w0 + g) * P.n_dst + d];
+                    if (w0 + g < gw0) { c += __builtin_popcount(word); continue; }
+                    while (word) {
+                        const int bit = __builtin_ctz(word);
+                        word &= word - 1;
+                        if (base + c < P.cap) { P.edge_src[base + c] = s0 + 32 * g + bit; P.edge_dst[base + c] = d; }
+                        ++c;
+                    }
+                }
+                continue;
+            }
+            // The edges of the block's 256 destinations are ONE contiguous run of the list.  Written straight from the bit walk every store
+            // instruction scatters 64 lanes over 64 cache lines (~20 edges apart) and the walk issues two of them per iteration.  So the walk fills a
+            // staging run in LDS (ex = this destination's offset inside the block) and the block copies it out with coalesced stores (C2: 38.6 ->
+            // 30.9 us, profiles/r05zd_fill_timing.txt); a block whose run does not fit writes directly.
+            if (total <= kFillStage) {
+                if (act) {
+                    int c = ex;
+                    for (int g = 0; g < nw; ++g) {
+                        uint32_t word = P.mask[(size_t)(w0 + g) * P.n_dst + d];
+                        while (word) {
+                            const int bit = __builtin_ctz(word);
+                            word &= word - 1;
+                            st_src[c] = s0 + 32 * g + bit; st_dst[c] = d;
+                            ++c;
+                        }
+                    }
+                }
+                __syncthreads();
+                for (int i = threadIdx.x; i < total; i += kNbrBlock)
+                    if (blk_base + i < P.cap) { P.edge_src[blk_base + i] = st_src[i]; P.edge_dst[blk_base + i] = st_dst[i]; }
+                __syncthreads();
+                continue;
+            }
             if (!act) continue;
-            P.off[(size_t)n * P.n_dst + d] = o;
             int c = 0;
             for (int g = 0; g < nw; ++g) {
                 uint32_t word = P.mask[(size_t)(w0 + g) * P.n_dst + d];
