@@ -724,7 +724,10 @@ __global__ void k_aggregate(const float* __restrict__ edge_out, const int* __res
     f32x4 acc[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) acc[p] = f32x4{0, 0, 0, 0};
-    constexpr int U = 4;          // records per iteration: all their loads are in flight together
+#ifndef DEDF_AGG_U
+#define DEDF_AGG_U 4
+#endif
+    constexpr int U = DEDF_AGG_U;          // records per iteration: all their loads are in flight together (2 / 8: see profiles/r05zl_aggregate_u.txt)
     for (int j0 = 0; j0 < total; j0 += 64) {
         // lane k holds the edge index of record j0 + k of the flattened list
         const int k = j0 + lane;
