@@ -16,8 +16,8 @@ Extra objects on the JSON line:
                 (fp32-equivalent algorithmic FLOP).  Every dense GEMM of the kernel (163 584 of the 193 344
                 MAC/edge) runs as a 3-term split-fp16 product (hi*hi + hi*lo + lo*hi, fp32 accumulate) on the 2.5 PFLOP/s dense
                 fp16 MFMAs of MI355X_MICROARCH.md, so the hardware MFMA peak of this arithmetic is peak = 2500 / 3 TFLOP/s
-                fp32-equivalent and frac = achieved / peak.  The kernel is limited by VALU issue (one wave per SIMD), not by
-                the matrix pipes: "bound" says so.  Since round 3 `achieved` / `frac` count the FLOP the kernel EXECUTES per edge (152 384 MAC
+                fp32-equivalent and frac = achieved / peak ("bound": "mfma" names that roof, as the bench contract asks).  What limits the
+                kernel is VALU issue (one wave per SIMD), not the matrix pipes: "limiter" says so.  Since round 3 `achieved` / `frac` count the FLOP the kernel EXECUTES per edge (152 384 MAC
                 with the sampler's radial table); the algorithmic count is reported beside them as `achieved_algorithmic` / `frac_algorithmic`,
                 and `frac_mfma_issued` is the MFMA issue fraction from the PMC counters of the newest profile.  `mix_bound` is the secondary figure that also prices the lane-local
                 Clebsch-Gordan contractions (29 760 MAC/edge in the dense-CG convention) on the 157.3 TFLOP/s fp32 vector peak, in
@@ -458,7 +458,8 @@ def main():
                        "poses_total": n_total, "parallelism": f"pose-parallel dp{world}, one RCCL all-gather at the end",
                        "edges_per_step_rank0": e_per_launch, "full_trajectories_per_s_at_50_steps": n_total * args.steps / el / 50.0,
                        "score_fwd_ms_at_t0.5": fixed, "feature_extractors_ms": extract, "small_batches_50_steps": small},
-            "roofline": {"kernel": "k_edge (fused per-edge pipeline)", "bound": "valu-issue", "achieved": achieved_exec, "peak": peak,
+            "roofline": {"kernel": "k_edge (fused per-edge pipeline)", "bound": "mfma", "limiter": "valu-issue (one wave per SIMD: VALU and MFMA time add up, DESIGN.md section 5.R5)",
+                         "achieved": achieved_exec, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved_exec / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "frac_definition": f"2 x {m_exec} MAC per edge (the constant of rounds 2-4" + (f": {M_EDGE[args.lmax]} algorithmic - 40 960 that the sampler's radial table evaluates per grid node" if table_on else "") + "; what the general form of the kernel executes) x edges of the launch / its HIP-event duration / peak -- with the edge-frame kernels an edge RATE in fixed units, see frac_gemm_executed for the executed GEMM work",
                          "achieved_algorithmic": achieved, "frac_algorithmic": achieved / peak,
