@@ -65,7 +65,7 @@ def test_unsupported_configs_are_rejected(built_lib):
     kw['key_tensor_field_kwargs']['fc_neurons'] = [64, 128, 64]
     with pytest.raises(NotImplementedError):
         params.HeadConfig.from_kwargs(kw)
-    for bad in (dict(lmax=1), dict(half_gemm=1), dict(lmax=3, fc=(128, 32, 32))):       # query_time_encoding: lmax 2 / 3, full precision; lmax 3 with [128,128,64] only
+    for bad in (dict(lmax=1), dict(lmax=3, half_gemm=1), dict(lmax=3, fc=(128, 32, 32))):       # query_time_encoding: lmax 2 / 3; lmax 3 with [128,128,64], full precision only
         cfg = params.HeadConfig.from_kwargs(synthetic.score_head_kwargs(bad.get('lmax', 2), query_time_encoding=True))
         cc = _lib.make_config(cfg, -1)
         cc.half_gemm = bad.get('half_gemm', 0)

@@ -145,6 +145,19 @@ def test_query_time_encoding_other_shapes(shape):
     assert 0.0 < dev_on_off < 1e-5, (shape, dev_on_off)
 
 
+def test_query_time_encoding_half_precision():
+    """model.half() (agent.py:50-51) of a head with query_time_encoding: the half-precision tolerance (5e-3) against the fp64 oracle, and really
+    another arithmetic than the default mode"""
+    kw, cfg, P, keys, query, Ts, time = SC.build_case(2, 6, 512, 100, query_time_encoding=True)
+    a64, l64, _, _ = SC.oracle_run(kw, P, keys, query, Ts, time, torch.float64)
+    scale = float(max(a64.abs().max(), l64.abs().max()))
+    errs = []
+    for half in (False, True):
+        head, ang, lin = SC.gpu_run(kw, P, keys, query, Ts, time, debug=False, half=half)
+        errs.append(max(float((ang.double() - a64).abs().max()), float((lin.double() - l64).abs().max())) / scale)
+    assert errs[0] < TOL and 3e-5 < errs[1] < 5e-3, errs
+
+
 def test_score_parity_c0_plumbing():
     """BASELINE config C0: 4096-pt scene stand-in (820/164/33/7 key points), 2 static keypoints, 4 poses incl. the
     identity quaternion (YXY signed-zero quirk)"""
