@@ -1,6 +1,5 @@
 #!/bin/bash
 # scratch driver for one gpurun call (rewritten per session)
 ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out; mkdir -p $OUT; cd $ROOT; export TMPDIR=/tmp
-python -m pytest tests -x -q -m gpu --durations=5 > $OUT/r05zu_gpu_suite.log 2>&1; tail -3 $OUT/r05zu_gpu_suite.log
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/r05zu_smoke.log 2>&1; tail -1 $OUT/r05zu_smoke.log
-python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/r05zu_bench.json 2> $OUT/r05zu_bench.err
+export DEDF_STRESS_LMAX3=1
+TAG=case23 python tests/probe/stress_case.py 505 23 > $OUT/r05zw_case23_resolved.log 2>&1; grep -E "RESULT|binding|fp32" $OUT/r05zw_case23_resolved.log | cut -c1-400

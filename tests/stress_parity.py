@@ -117,6 +117,21 @@ def run_case(i, rng):
         print(f"   (fp32 restatement vs fp64: {gap:.2e}; kernel vs fp32 restatement: {e32:.2e})")
         if e32 < 2e-5 and gap > 0.5 * err:
             err = e32
+    if err >= 1e-4 and edges_ok and any(r is not None and len(k.x) > max_nb for k, r in zip(keys, cfg.radii)):
+        # a key within fp32 rounding of a radius UNDER A BINDING NEIGHBOUR CAP?  Whether that pair is a neighbour is decided by the last bit of an fp32
+        # distance (the reference's torch_cluster kernel has the same ambiguity); without a cap it would only add or drop an edge of weight ~0, with
+        # the cap it decides whether ANOTHER, fully weighted key takes the 17th place -- same edge count, other edge set (seen once in 120 cases:
+        # seed 505 case 23, a key at r (1 - 1.7e-7); tests/probe/stress_edges.py lists the pairs).  The oracle with the radii moved by 3e-7 either
+        # way decides: the kernel must agree with one of them.
+        for f in (1.0 - 3e-7, 1.0 + 3e-7):
+            oc2 = ocfg._replace(r_cluster_multiscale=[None if r is None else r * f for r in ocfg.r_cluster_multiscale])
+            a2, l2 = R.score_head_forward(oc2, Pd, Ts, ok, oq, time)
+            s2 = float(max(a2.abs().max(), l2.abs().max()))
+            e2 = max(float((ang.cpu().double() - a2).abs().max()), float((lin.cpu().double() - l2).abs().max())) / s2
+            print(f"   (binding neighbour cap; oracle with the radii x {f}: kernel {e2:.2e} from it)")
+            if e2 < 1e-4:
+                err = e2
+                break
     print(f"case {i:3d} err {err:.2e} edges_ok {edges_ok}  {desc}", flush=True)
     return err, edges_ok, desc
 
