@@ -166,6 +166,9 @@ def run_sample_case(i, rng):
     move = float((ref[-1] - ref[0]).abs().max())
     ok_ = out.shape == ref.shape and err < 1e-3 and bool(torch.isfinite(out).all())
     print(f"sample {i:3d} |dT| {err:.2e} (poses moved {move:.2e}) steps {n_steps} nT {len(Ts)} lmax {cfg.lmax} radii {cfg.radii} cap {cfg.max_neighbors}", flush=True)
+    if err > 2e-4:      # where along the trajectory the difference appears: a step that starts it, or growth from the rounding level (a sampler amplifies)
+        print("   per step:", [f"{float((out[k] - ref[k]).abs().max()):.1e}" for k in range(len(out))],
+              "worst pose per step:", [int((out[k] - ref[k]).abs().amax(dim=-1).argmax()) for k in range(len(out))], flush=True)
     return err, ok_, ""
 
 
