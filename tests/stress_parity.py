@@ -169,6 +169,17 @@ def run_sample_case(i, rng):
     if err > 2e-4:      # where along the trajectory the difference appears: a step that starts it, or growth from the rounding level (a sampler amplifies)
         print("   per step:", [f"{float((out[k] - ref[k]).abs().max()):.1e}" for k in range(len(out))],
               "worst pose per step:", [int((out[k] - ref[k]).abs().amax(dim=-1).argmax()) for k in range(len(out))], flush=True)
+        # ... and the score itself at the SEED poses (first step's time): kernel against the fp64 restatement, beside the fp32 restatement's own distance
+        t0 = torch.full((len(Ts),), sched[0][0], dtype=torch.float64)
+        k64 = [R.FeaturedPoints(k.x.double(), k.f.double(), k.b, None if k.w is None else k.w.double()) for k in keys]
+        q64 = R.FeaturedPoints(query.x.double(), query.f.double(), query.b, query.w.double())
+        a64, l64 = R.score_head_forward(ocfg, R.cast_params(P, torch.float64), Ts, k64, q64, t0)
+        a32, l32 = R.score_head_forward(ocfg, R.cast_params(P, torch.float32), Ts.float(), ok, oq, t0.float())
+        ag, lg = head(Ts.to(dev).float(), gk, gq, t0.to(dev).float())
+        sc = float(max(a64.abs().max(), l64.abs().max()))
+        print(f"   score at the seed poses: kernel {max(float((ag.cpu().double() - a64).abs().max()), float((lg.cpu().double() - l64).abs().max())) / sc:.2e}, "
+              f"fp32 restatement {max(float((a32.double() - a64).abs().max()), float((l32.double() - l64).abs().max())) / sc:.2e} from the fp64 restatement; "
+              f"per pose (kernel): {[f'{float(max((ag.cpu().double() - a64)[p].abs().max(), (lg.cpu().double() - l64)[p].abs().max())) / sc:.1e}' for p in range(len(Ts))]}", flush=True)
     return err, ok_, ""
 
 
