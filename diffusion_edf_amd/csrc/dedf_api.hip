@@ -17,16 +17,11 @@
 using namespace dedf;
 
 #include "dedf_kernels.h"
-#include "dedf_kernels_occ.h"
-#include "dedf_edge16.h"
-#include "dedf_pack16.h"
 #include "dedf_graph.h"
 #if !defined(DEDF_SINGLE_TU)
 #define DEDF_DECL(unit, ...) extern template __global__ __VA_ARGS__;
 DEDF_KERNEL_LIST(DEDF_DECL)
 #undef DEDF_DECL
-extern template __global__ void k_edge_occ<1, 128, false>(EdgeParams);
-extern template __global__ void dedf::k_edge16<2>(Edge16Params);
 #endif
 __global__ void k_energy_reduce(const float* __restrict__ node_out, int nT, int nQ, float* __restrict__ energy, int* __restrict__ flags) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -108,10 +103,8 @@ struct dedf_handle {
     int tab_slot = -1;            // >= 0 inside dedf_sample's loop: the ring slot that holds THIS step's table
     bool rtab_async = false;      // DEDF_RTAB_ASYNC=1 turns the side-stream generation on (A/B)
     DevBuf d_cnt2, d_blk2; int small_parity = 0; int64_t small_layout = -1;      // the two alternating count sets of the small-batch neighbour path
-    Image edge16_img; Edge16Offsets e16{}; DevBuf d_edge16_w;      // the 16-edge tile's weight image (dedf_pack16.h), lmax-2 score heads
-    int edge16 = 0;                   // DEDF_EDGE16=1: the sampler's table path on the 16-edge / two-waves-per-SIMD kernel (dedf_edge16.h)
-    bool edge16_used = false;
-    bool edge_occ = false;            // DEDF_EDGE_OCC=1: lmax-1 score head on the two-waves-per-SIMD build of the edge kernel (A/B)
+    DevBuf d_tot;                     // destination-major edge list: [2][N_d] per-destination totals / first edges (NbrParams::cnt_tot / off_tot)
+    int dst_major = 0;                // DEDF_DST_MAJOR=1: the destination-major edge list + mixed-scale table kernels (built and measured in round 6: k_aggregate -32 us, k_edge +100 us at C2 -- profiles/r06g_dst_major_ab3.log -- hence opt-in)
     // Verdict of the last dedf_score / dedf_energy call (they never synchronise): the status words are copied to pinned host memory behind the
     // call's kernels; the NEXT entry point of this handle looks at them (check_pending) and fails if the call overflowed its edge workspace or
     // produced a non-finite result -- so that a caller who never reads dedf_get_stats does not keep working with NaN scores.
@@ -320,10 +313,6 @@ int upload_weights(dedf_handle* h) {
         return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(weights) failed");
     HIPCK(h, hipMemcpy(h->d_edge_w.p, h->edge_img.data.data(), h->edge_img.data.size() * 4, hipMemcpyHostToDevice));
     HIPCK(h, hipMemcpy(h->d_node_w.p, h->node_img.data.data(), h->node_img.data.size() * 4, hipMemcpyHostToDevice));
-    if (h->e16.ok) {
-        if (!h->d_edge16_w.ensure(h->edge16_img.data.size() * 4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(weights) failed");
-        HIPCK(h, hipMemcpy(h->d_edge16_w.p, h->edge16_img.data.data(), h->edge16_img.data.size() * 4, hipMemcpyHostToDevice));
-    }
     // natural-layout weights for the small kernels
     std::vector<float> nat;
     auto put = [&](const float* p, size_t n) { size_t o = nat.size(); nat.insert(nat.end(), p, p + n); return o; };
@@ -508,6 +497,10 @@ void launch_edge(dedf_handle* h, hipStream_t st, const EdgeParams& P) {
         constexpr bool qt_hp = HP && MODE == 0 && L == 2 && F0 == 128 && H1 == 128 && H2 == 64;
         if constexpr (qt || qt_hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, HP, H1, H2, false, MODE, false, true, true>), kAll, st, P);
         return;
+    }
+    if constexpr (MODE == 1 && so2_shape<L, F0, HP, H1, H2, MODE>()) {
+        // destination-major edge list (score_impl: `mixed`): the instantiation whose tiles mix scales
+        if (P.mixed) { DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, HP, H1, H2, false, MODE, false, true, false, true>), kAll, st, P); return; }
     }
     if constexpr (so2_shape<L, F0, HP, H1, H2, MODE>()) {
         if (h->so2 || !general_shape<L, F0, HP, H1, H2, MODE>()) { DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, HP, H1, H2, false, MODE, false, true>), kAll, st, P); return; }
@@ -695,6 +688,17 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     for (int n = 0; n < ns; ++n) np.word_start[n + 1] = np.word_start[n] + (h->scale_start[n + 1] - h->scale_start[n] + 31) / 32;
     np.mask = h->d_mask.as<uint32_t>();
     np.edge_hist = h->profile ? h->d_hist.as<long long>() : nullptr;
+    // The sampler's table-reading edge kernel takes a DESTINATION-major edge list (dedf_misc.h::NbrParams::dst_major): decided here, before the
+    // fill pass is enqueued, from the same host-side facts as `use_tab` below.
+    bool want_tab = false;
+    if constexpr (has_radial_table<L, F0>())
+        want_tab = table_instantiated<L, F0>(h) && h->radial_table != 0 && (EBM || !(time_stride && !h->tb_step)) && !h->debug &&
+                   (Nd >= kRtabMinNodes || h->radial_table == 2 || h->tab_slot >= 0);
+    const bool mixed = want_tab && h->dst_major != 0 && h->so2 && !c.query_time_encoding;      // (the edge-frame table kernels without query time: units 57-60)
+    if (mixed) {
+        if (!h->d_tot.ensure((size_t)2 * Nd * 4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(workspace) failed");
+        np.dst_major = 1; np.cnt_tot = h->d_tot.as<int>(); np.off_tot = h->d_tot.as<int>() + Nd;
+    }
     // small batches: pose preparation + word-parallel masks in one launch, single-workgroup count / scan / fill (dedf_misc.h)
     static const int small_max = [] { const char* e = getenv("DEDF_SMALL_BATCH_MAX"); return e ? atoi(e) : kNbrSmallMax; }();      // (experiments)
     bool small = Nd <= small_max && h->small_batch_path;
@@ -754,7 +758,10 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
             // (worth its 34 us generator launch from ~6 rounds of edge tiles on: ~20 edges per destination node -> 8 192 nodes)
             const bool async_tab = h->tab_slot >= 0;      // dedf_sample: this step's table was generated on the side stream (ring slot h->tab_slot)
             use_tab = table_instantiated<L, F0>(h) && h->radial_table != 0 && P.tb_pose_stride == 0 && !h->debug && (Nd >= kRtabMinNodes || h->radial_table == 2 || async_tab);
+            if (use_tab != want_tab) return fail(h, DEDF_ERR_RUNTIME, "internal: the edge list was ordered for the other edge kernel");
             if (use_tab) {
+                P.mixed = mixed ? 1 : 0;
+                for (int n = 0; n <= ns; ++n) P.scale_start[n] = h->scale_start[n];
                 int rc = radial_table_setup(h, P);
                 if (rc != DEDF_OK) return rc;
                 if (async_tab) {
@@ -769,21 +776,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
                     }
                 } else {
                     if (!async_tab) launch_radial_table<L, F0, 128, 64>(h, P, st, false);
-                    bool on16 = false;
-                    if constexpr (L == 2 && F0 == 128) on16 = h->edge16 != 0 && h->e16.ok && !c.use_src_point_attn && !c.query_time_encoding;
-                    if (on16) {
-                        if constexpr (L == 2 && F0 == 128) {
-                            Edge16Params Q{};
-                            Q.E = P; Q.W = h->d_edge16_w.as<float>(); Q.W_bytes = (uint32_t)h->d_edge16_w.bytes;
-                            const Edge16Offsets& o = h->e16;
-                            Q.o_A3 = o.o_A3; Q.o_A3_l = o.o_A3_l; Q.o_off3 = o.o_off3; Q.o_S_lin = o.o_S_lin; Q.o_b0 = o.o_b0; Q.o_S_val = o.o_S_val;
-                            Q.o_bval0 = o.o_bval0; Q.o_adot = o.o_adot; Q.w_unscale = o.w_unscale; Q.u_scale = o.u_scale;
-                            for (int l = 0; l < 4; ++l) { Q.c_lin[l] = o.c_lin[l]; Q.c_val[l] = o.c_val[l]; }
-                            Q.redo = h->d_tile.as<int>() + kFlagEdge16Redo;
-                            hipLaunchKernelGGL((k_edge16<2>), dim3(h->n_cu * waves_per_cu<(k_edge16<2>), 8>()), dim3(64), 0, st, Q);
-                            h->edge16_used = true;
-                        }
-                    } else launch_edge<L, F0, false, 128, 64, 1>(h, st, P);
+                    launch_edge<L, F0, false, 128, 64, 1>(h, st, P);
                 }
                 if (async_tab) HIPCK(h, hipEventRecord(h->rt_used[h->tab_slot], st));      // the slot may be refilled once this edge kernel is done
             }
@@ -828,9 +821,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
                 if (hp) launch_edge<L, F0, true, 32, 32, 0>(h, st, P);
                 else launch_edge<L, F0, false, 32, 32, 0>(h, st, P);
             } else if (hp) launch_edge<L, F0, true, 128, 64, 0>(h, st, P);
-            else if (L == 1 && h->edge_occ) {      // lmax 1: the two-waves-per-SIMD build of the same tile (dedf_kernels_occ.h)
-                if constexpr (L == 1) hipLaunchKernelGGL((k_edge_occ<1, 128, false>), dim3(h->n_cu * waves_per_cu<(k_edge_occ<1, 128, false>), 8>()), dim3(64), 0, st, P);
-            } else launch_edge<L, F0, false, 128, 64, 0>(h, st, P);
+            else launch_edge<L, F0, false, 128, 64, 0>(h, st, P);
         } else if constexpr (F0 == 64 && L == 2) {
             if (narrow) { if (hp) launch_edge<L, F0, true, 32, 32, 0>(h, st, P); else launch_edge<L, F0, false, 32, 32, 0>(h, st, P); }      // KeypointExtractor fields
             else if (hp) launch_edge<L, F0, true, 128, 64, 0>(h, st, P);
@@ -840,12 +831,12 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     }
     mark();
     // 5. joint softmax + aggregation
-    if (h->edge16_used) hipLaunchKernelGGL((k_aggregate<L, 16>), dim3((Nd + 3) / 4), dim3(256), 0, st, h->d_eout.as<float>(), cnt_used, h->d_off.as<int>(),
-                                           h->d_tile.as<int>(), Nd, ns, h->d_z.as<float>());
+    // (destination-major list: a destination's edges over all scales are ONE run -- the merge sees one "scale" with the per-destination totals)
+    if (mixed) hipLaunchKernelGGL(k_aggregate<L>, dim3((Nd + 3) / 4), dim3(256), 0, st, h->d_eout.as<float>(), np.cnt_tot, np.off_tot,
+                                  h->d_tile.as<int>(), Nd, 1, h->d_z.as<float>());
     else
     hipLaunchKernelGGL(k_aggregate<L>, dim3((Nd + 3) / 4), dim3(256), 0, st, h->d_eout.as<float>(), cnt_used, h->d_off.as<int>(),
                        h->d_tile.as<int>(), Nd, ns, h->d_z.as<float>());
-    h->edge16_used = false;
     mark();
     // 6. node epilogue + score tensor products
     const float* node_spin = nullptr;
@@ -975,9 +966,8 @@ int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, de
     if (const char* e = getenv("DEDF_RTAB_ASYNC")) h->rtab_async = atoi(e) != 0;
     if (const char* e = getenv("DEDF_RTAB_FIN")) h->rtab_fin = std::max(64, atoi(e));
     if (const char* e = getenv("DEDF_RTAB_INF")) h->rtab_inf = std::max(64, atoi(e));
-    if (const char* e = getenv("DEDF_EDGE_OCC")) h->edge_occ = atoi(e) != 0;
-    if (const char* e = getenv("DEDF_EDGE16")) h->edge16 = atoi(e);
-    h->so2 = so2_instantiated(*cfg) && !(cfg->lmax == 1 && h->edge_occ);
+    h->so2 = so2_instantiated(*cfg);
+    if (const char* e = getenv("DEDF_DST_MAJOR")) h->dst_major = atoi(e);
     if (const char* e = getenv("DEDF_SO2")) h->so2 = h->so2 && (atoi(e) != 0 || !general_instantiated(*cfg));      // (A/B where both forms exist)
     const IrrepsRT T(h->L, cfg->unet_layer != 0), K(h->L, true);
     h->spec = build_spec(T, h->cfg);
@@ -994,7 +984,6 @@ int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, de
     try {
         h->kparams = pad_params(h->cfg, T, h->spec, K, h->kspec, h->params.data());
         if (h->L == 1) pack_all<1>(h.get()); else if (h->L == 2) pack_all<2>(h.get()); else pack_all<3>(h.get());
-        if (h->L == 2 && !cfg->unet_layer && !cfg->ebm && cfg->fc_neurons[0] == 128) pack_edge16<2>(h->cfg, h->kspec, h->kparams.data(), h->edge16_img, h->e16, (int)std::lround(std::log2(h->eo.msg_scale)));
     } catch (const std::exception& e) {
         fprintf(stderr, "dedf_create: %s\n", e.what());
         return DEDF_ERR_INVALID;
@@ -1346,10 +1335,6 @@ static int sample_once(dedf_handle* h, int nT, const double* T_seed, const dedf_
     h->stats_fresh = sched->n_steps > 0;
     const int flags[2] = {h->h_pin[kFlagOverflow], h->h_pin[kFlagNonFinite]};
     if (flags[0]) { *overflowed = true; return fail(h, DEDF_ERR_RUNTIME, "edge workspace overflow: raise dedf_config.max_edges"); }
-    if (h->edge16) {
-        const int redo = h->h_pin[kFlagEdge16Redo];
-        if (redo) return fail(h, DEDF_ERR_RUNTIME, "DEDF_EDGE16: an edge tile lay outside the radial table (the 16-edge kernel has no per-edge front): unset DEDF_EDGE16");
-    }
     if (flags[1]) return fail(h, DEDF_ERR_RUNTIME, "non-finite score: an activation left the fp16 operand range of the split-fp16 GEMMs "
                                                    "(or the inputs / poses were not finite)");
     return DEDF_OK;
@@ -1580,7 +1565,7 @@ int dedf_get_stats(dedf_handle* h, dedf_stats* out) {
         HIPCK(h, hipMemcpy(ti, h->d_tile.p, sizeof(ti), hipMemcpyDeviceToHost));
     }
     out->n_dst = (int64_t)h->last_nT * h->nQ;
-    for (int n = 0; n < h->cfg.n_scales; ++n) { out->n_edges[n] = ti[16 + n + 1] - ti[16 + n]; out->n_edges_total += out->n_edges[n]; }
+    for (int n = 0; n < h->cfg.n_scales; ++n) { out->n_edges[n] = ti[kEdgeCountWord + n]; out->n_edges_total += out->n_edges[n]; }
     out->overflow = ti[40] | ti[kFlagOverflow];
     out->nonfinite = ti[kFlagNonFinite];
     out->sample_retries = h->sample_retries;

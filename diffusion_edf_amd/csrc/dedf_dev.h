@@ -127,6 +127,19 @@ DEDF_DEV f32x4 bld4(const Buf& b, int voff_bytes, int soff_bytes) {
 }
 
 
+// Copy of N floats (compile-time count) from global memory into a wave's LDS in two phases -- every request first, then every store --, so that
+// a prologue costs ONE round trip to memory.  (`for (i = lane; i < n; i += 64) dst[i] = src[i]` has a lane-dependent trip count: hipcc keeps it
+// a loop of load -> wait -> store round trips, ~22 of them in k_edge's prologue: several microseconds of a launch whose waves run ONE tile,
+// the deployment regime of 10-20 poses.)
+template <int N> struct RowRegs { float v[(N + 63) / 64]; };
+template <int N> DEDF_DEV RowRegs<N> rows_request(const float* src, int lane) {
+    RowRegs<N> r;
+    static_for<(N + 63) / 64>([&]<int k>() { const int i = lane + 64 * k; r.v[k] = src[(N % 64 == 0 || i < N) ? i : N - 1]; });
+    return r;
+}
+template <int N> DEDF_DEV void rows_store(float* dst, const RowRegs<N>& r, int lane) {
+    static_for<(N + 63) / 64>([&]<int k>() { const int i = lane + 64 * k; if (N % 64 == 0 || i < N) dst[i] = r.v[k]; });
+}
 struct Wave {            // per-lane constants of the transposed-GEMM layout
     int lane, col, hi;
     int lane16;          // byte offset of this lane inside a packed-A group (64 lanes x 16 B)
@@ -135,9 +148,6 @@ struct Wave {            // per-lane constants of the transposed-GEMM layout
                          // are padding are then fetched by half the lanes only (an out-of-range buffer load returns 0 without a fetch)
     int lane16_r16up;    // the same 16 rows placed as rows 16-31 of the tile: lanes of rows 16-31 fetch what the lane 16 below them would
     Buf w;               // all packed weights / row vectors of the launch
-#if defined(DEDF_TIMING_W_NONE)
-    f32x4 dummy;         // timing experiment: stands in for every weight operand
-#endif
 };
 DEDF_DEV Wave make_wave(const void* wbuf, uint32_t wbytes) {
     Wave wv;
@@ -146,28 +156,10 @@ DEDF_DEV Wave make_wave(const void* wbuf, uint32_t wbytes) {
     wv.lane16_r16 = wv.col < 16 ? wv.lane16 : 0x7ffffff0;
     wv.lane16_r16up = wv.col >= 16 ? wv.lane16 - 256 : 0x7ffffff0;
     wv.w = make_buf(wbuf, wbytes);
-#if defined(DEDF_TIMING_W_NONE) && defined(__HIP_DEVICE_COMPILE__)
-    wv.dummy = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
-    asm volatile("" : "+v"(wv.dummy));
-#endif
     return wv;
 }
-// A operand of the fused stage's weight streams (layer 3, lin / sep_alpha, value).  Two timing-only builds (wrong results) bound what ANY redesign
-// of the weight path could gain: DEDF_TIMING_W_SAME -- every request reads the first KiB of the image (same instruction count, same bytes
-// through the vector L1, no L2 -> L1 traffic); DEDF_TIMING_W_NONE -- no request at all, the operand is a register the wave already holds.
-DEDF_DEV f32x4 bldw(const Wave& wv, int voff_bytes, int soff_bytes) {
-#if defined(DEDF_TIMING_W_NONE) && defined(__HIP_DEVICE_COMPILE__)
-    (void)voff_bytes; (void)soff_bytes;
-    return wv.dummy;
-#elif defined(DEDF_TIMING_W_SAME) && defined(__HIP_DEVICE_COMPILE__)
-    int z = 0;
-    asm volatile("" : "+s"(z));      // (opaque: the requests must not be merged)
-    (void)soff_bytes;
-    return bld4(wv.w, voff_bytes, z);
-#else
-    return bld4(wv.w, voff_bytes, soff_bytes);
-#endif
-}
+// A operand of the fused stage's weight streams (layer 3, lin / sep_alpha, value)
+DEDF_DEV f32x4 bldw(const Wave& wv, int voff_bytes, int soff_bytes) { return bld4(wv.w, voff_bytes, soff_bytes); }
 // A operands of 4 consecutive K-steps (group g) of out tile To; matrix at float offset `off`, nG groups per tile
 DEDF_DEV f32x4 lda(const Wave& wv, int off, int nG, int To, int g) {
     return bldw(wv, wv.lane16, (off + (To * nG + g) * 256) * 4);
@@ -224,17 +216,6 @@ DEDF_DEV HL split8(const float (&x)[8]) {
     // the packed hi halves (the mixed-precision FMA converts the fp16 source on the fly; x - hi is exact in fp32, one rounding):
     // 3 instructions per pair instead of 6 (v_cvt_pk, 2 v_cvt_f32_f16, 2 v_sub, v_cvt_pk), bit-identical halves
     unsigned hp[4], lp[4];
-#if defined(DEDF_SPLIT_STAGED)
-    // the same twelve instructions stage by stage (4 x cvt, 4 x mixlo, 4 x mixhi) in ONE block: every instruction's producer is four issues back
-    // instead of the instruction before it (pair by pair the three of a pair wait for one another, and hipcc cannot reorder inside an asm block)
-    asm volatile("v_cvt_pk_f16_f32 %0, %8, %9\n\tv_cvt_pk_f16_f32 %1, %10, %11\n\tv_cvt_pk_f16_f32 %2, %12, %13\n\tv_cvt_pk_f16_f32 %3, %14, %15\n\t"
-                 "v_fma_mixlo_f16 %4, %0, -1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixlo_f16 %5, %1, -1.0, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-                 "v_fma_mixlo_f16 %6, %2, -1.0, %12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixlo_f16 %7, %3, -1.0, %14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-                 "v_fma_mixhi_f16 %4, %0, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %5, %1, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-                 "v_fma_mixhi_f16 %6, %2, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %7, %3, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-                 : "=&v"(hp[0]), "=&v"(hp[1]), "=&v"(hp[2]), "=&v"(hp[3]), "=&v"(lp[0]), "=&v"(lp[1]), "=&v"(lp[2]), "=&v"(lp[3])
-                 : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
-#else
 #define DEDF_SPLIT_PAIR(Q)                                                                          \
     asm volatile("v_cvt_pk_f16_f32 %0, %2, %3\n\t"                                                   \
                  "v_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"             \
@@ -242,7 +223,6 @@ DEDF_DEV HL split8(const float (&x)[8]) {
                  : "=&v"(hp[Q]), "=&v"(lp[Q]) : "v"(x[2 * Q]), "v"(x[2 * Q + 1]))
     DEDF_SPLIT_PAIR(0); DEDF_SPLIT_PAIR(1); DEDF_SPLIT_PAIR(2); DEDF_SPLIT_PAIR(3);
 #undef DEDF_SPLIT_PAIR
-#endif
     r.hi = __builtin_bit_cast(h8, u32x4{hp[0], hp[1], hp[2], hp[3]});
     r.lo = __builtin_bit_cast(h8, u32x4{lp[0], lp[1], lp[2], lp[3]});
 #else

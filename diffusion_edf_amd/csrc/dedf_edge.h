@@ -81,6 +81,12 @@ struct EdgeParams {
     // without reading the times back; the one that does not apply returns at once.
     const int* gate;
     int gate_want;
+    // Destination-major edge list (table-reading kernels, MODE 1; dedf_misc.h::NbrParams::dst_major): the list is ordered (dst, scale, src), a tile
+    // mixes scales and its softmax segments run across them.  A lane then takes its scale from its key index (the key clouds are concatenated:
+    // scale_start) and the per-scale constants by lane; a tile that cannot take the radial table (a length beyond it, a scale whose table failed its
+    // accuracy guard) evaluates the per-edge front once per scale PRESENT in it and keeps, per lane, the result of its own scale.
+    int mixed;
+    int scale_start[kMaxScales + 1];
 };
 DEDF_DEV bool edge_gate_closed(const EdgeParams& P) { return P.gate != nullptr && (*P.gate != 0) != (P.gate_want != 0); }
 
@@ -213,12 +219,7 @@ DEDF_DEV void mfma_chunk(const Wave& wv, int o_str, AItem (&ring)[PD], const BOp
         ring[I0 % PD] = load_item<L, NT0, I0 + PD, HP, S>(wv, o_str);
         const h8 ah = __builtin_bit_cast(h8, a.h[0]), al = __builtin_bit_cast(h8, a.l[0]), bh = __builtin_bit_cast(h8, a.h[1]), bl = __builtin_bit_cast(h8, a.l[1]);
         auto& accm = [&]() -> auto& { if constexpr (l3 == 1) return acc1; else if constexpr (l3 == 2) return acc2; else return acc3; }();
-#if defined(DEDF_TIMING_SO2_NOMFMA1)
-        static_for<NTm>([&]<int t>() { constexpr int K = kSo2K[pi.l1][pi.l2][pi.l3][t]; accm[PR ? K / 2 : K][0] += __builtin_bit_cast(f32x4, bo.hi[t])[0] + __builtin_bit_cast(f32x4, bo.lo[t])[1] + __builtin_bit_cast(f32x4, ah)[0] + __builtin_bit_cast(f32x4, al)[0]; });
-        if constexpr (false)
-#else
         static_for<NTm>([&]<int t>() { constexpr int K = kSo2K[pi.l1][pi.l2][pi.l3][t], T = PR ? K / 2 : K; accm[T] = mfma_h(PR && K % 2 ? bh : ah, bo.hi[t], accm[T]); });
-#endif
         if constexpr (!HP) {
             static_for<NTm>([&]<int t>() { constexpr int K = kSo2K[pi.l1][pi.l2][pi.l3][t], T = PR ? K / 2 : K; accm[T] = mfma_h(PR && K % 2 ? bh : ah, bo.lo[t], accm[T]); });
             static_for<NTm>([&]<int t>() { constexpr int K = kSo2K[pi.l1][pi.l2][pi.l3][t], T = PR ? K / 2 : K; accm[T] = mfma_h(PR && K % 2 ? bl : al, bo.hi[t], accm[T]); });
@@ -309,18 +310,31 @@ DEDF_DEV void split_chunk(const float (&v)[2 * l3 + 1][8], BOpsH<L>& o) {
     });
 }
 
-// once per wave, before its first tile: copy the row vectors into LDS
+// once per wave, before its first tile: copy the row vectors into LDS (all requests, then all stores: dedf_dev.h::rows_request)
 template <int L, int H1 = 128, int H2 = 64, bool FRONT = true>
 DEDF_DEV void edge_rows_to_lds(const EdgeParams& P, const Wave& wv) {
     using RL = RowsLds<L, FRONT>;
     float* rows = rows_lds<L, FRONT>();
-    auto cp = [&](int dst, int src, int n) { for (int i = wv.lane; i < n; i += 64) rows[dst + i] = P.W[src + i]; };
+    const float* const W = P.W;
+    const int lane = wv.lane;
+    constexpr int NO3 = RL::BIG ? rup(dtp_wn<L>(), 32) : 64, NB0 = RL::BIG ? r0_tiles<L>() * 32 : 64;
+    RowRegs<H1> f1[3];
+    RowRegs<H2> f2[3];
+    RowRegs<NO3> o3;
+    RowRegs<NB0> b0;
     if constexpr (FRONT) {
-        cp(RL::b1, P.o_b_r1, H1); cp(RL::g1, P.o_g_r1, H1); cp(RL::be1, P.o_be_r1, H1);
-        cp(RL::b2, P.o_b_r2, H2); cp(RL::g2, P.o_g_r2, H2); cp(RL::be2, P.o_be_r2, H2);
+        f1[0] = rows_request<H1>(W + P.o_b_r1, lane); f1[1] = rows_request<H1>(W + P.o_g_r1, lane); f1[2] = rows_request<H1>(W + P.o_be_r1, lane);
+        f2[0] = rows_request<H2>(W + P.o_b_r2, lane); f2[1] = rows_request<H2>(W + P.o_g_r2, lane); f2[2] = rows_request<H2>(W + P.o_be_r2, lane);
     }
-    if constexpr (RL::BIG) { cp(RL::off3, P.o_off_r3, rup(dtp_wn<L>(), 32)); cp(RL::b0, P.o_b_r0, r0_tiles<L>() * 32); }
-    cp(RL::val0, P.o_b_val0, 64); cp(RL::adot, P.o_alpha_dot, 64);
+    if constexpr (RL::BIG) { o3 = rows_request<NO3>(W + P.o_off_r3, lane); b0 = rows_request<NB0>(W + P.o_b_r0, lane); }
+    const RowRegs<64> v0 = rows_request<64>(W + P.o_b_val0, lane), ad = rows_request<64>(W + P.o_alpha_dot, lane);
+    sched_fence();
+    if constexpr (FRONT) {
+        rows_store<H1>(rows + RL::b1, f1[0], lane); rows_store<H1>(rows + RL::g1, f1[1], lane); rows_store<H1>(rows + RL::be1, f1[2], lane);
+        rows_store<H2>(rows + RL::b2, f2[0], lane); rows_store<H2>(rows + RL::g2, f2[1], lane); rows_store<H2>(rows + RL::be2, f2[2], lane);
+    }
+    if constexpr (RL::BIG) { rows_store<NO3>(rows + RL::off3, o3, lane); rows_store<NB0>(rows + RL::b0, b0, lane); }
+    rows_store<64>(rows + RL::val0, v0, lane); rows_store<64>(rows + RL::adot, ad, lane);
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 }
@@ -330,7 +344,8 @@ template <int L, bool FRONT = true>
 DEDF_DEV void edge_enc_to_lds(const EdgeParams& P, const Wave& wv, int scale) {
     if constexpr (FRONT) {
         float* rows = rows_lds<L, FRONT>();
-        for (int i = wv.lane; i < 192; i += 64) rows[RowsLds<L, FRONT>::enc + i] = P.W[P.o_enc + scale * 192 + i];
+        const RowRegs<192> e = rows_request<192>(P.W + P.o_enc + scale * 192, wv.lane);
+        rows_store<192>(rows + RowsLds<L, FRONT>::enc, e, wv.lane);
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
@@ -340,9 +355,6 @@ DEDF_DEV void edge_enc_to_lds(const EdgeParams& P, const Wave& wv, int scale) {
 // UN: the edge pipeline of a UNet layer (block.EquiformerBlock + GraphAttentionMLP, block.py:141-174, graph_attention.py:84-122):
 //     message = linear_src(f_src)[src] + linear_dst(f_dst)[dst], the radial MLP reads the radial basis directly (no pre-linear, no
 //     time), GaussianRadialBasisLayerFiniteCutoff instead of GaussianRadialBasis, SH without the non-scalar cut-off, no edge logit
-#ifndef DEDF_RTAB_COALESCED
-#define DEDF_RTAB_COALESCED 0      // measured: 2.45-2.47 ms against 2.47-2.51 ms for the per-lane requests: within noise, kept for reference
-#endif
 // Geometry of the NEXT tile, carried across the persistent tile loop by the table-reading kernel (MODE 1): with the radial network's front
 // gone, a tile would otherwise start with three dependent round trips to memory (edge indices -> coordinates -> table rows) and nothing to
 // put under them.  The indices are requested at the top of the previous tile, the coordinates in its middle.
@@ -359,12 +371,13 @@ struct GeoPre { int ok, src, dst; float vx, vy, vz; };
 //      is rotated back (Rot<l>::out) before the segmented reduction.  Same result as the general form up to fp32 rounding; needs the image packed
 //      for it (dedf_pack.h::pack_edge<L, true>).
 template <int L> struct Trig { float cg[L], sg[L], cb[L], sb[L]; };
-template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false, int MODE = 0, bool NW = false, bool SO2 = false, bool QT = false>
+template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false, int MODE = 0, bool NW = false, bool SO2 = false, bool QT = false, bool MX = false>
 DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, int n_valid, GeoPre& geo, int e_next DEDF_PROF_ARG) {
     static_assert((H1 == 128 && H2 == 64) || (H1 == 32 && H2 == 32), "radial MLP widths of the shipped configs");
     static_assert(!SO2 || MODE <= 1, "edge-frame form: the per-edge and the table-reading kernels");
     static_assert(!UN || F0 == 64, "UNet layer: the radial MLP reads the 64 radial-basis channels");
     static_assert(MODE == 0 || !UN, "the radial table is the sampler's");
+    static_assert(!MX || MODE == 1, "mixed-scale tiles (destination-major edge list): the table-reading kernel");
     static_assert(!NW || UN, "NW is a UNet-layer shape");
     // activation stage on the registers of a run that hold true channels only (the others are structural zeros and stay 0)
     auto on_live = [&]<int l, int N, class St>(float (&v)[N], St&& st) {
@@ -404,20 +417,28 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     } else if constexpr (MODE < 2) { src = P.edge_src[e]; dst = P.edge_dst[e]; pose = dst / P.nQ; }
     int nsrc = 0, ndst = 0;            // MODE 1: the next tile's indices, requested now
     if constexpr (MODE == 1) { if (e_next >= 0) { nsrc = P.edge_src[e_next]; ndst = P.edge_dst[e_next]; } }
+    // destination-major list (EdgeParams::mixed): this lane's scale from its key index; per-scale constants by lane (select chains: a kernel
+    // argument array indexed by a VGPR would go through scratch)
+    // (MX is a template parameter -- its own instantiations -- so that the scale-major kernels compile to exactly what they were)
+    int ls = scale;
+    if constexpr (MX) { ls = 0; static_for<kMaxScales - 1>([&]<int n>() { if (n + 1 < P.n_scales && src >= P.scale_start[n + 1]) ls = n + 1; }); }
+    auto by_lane = [&](const auto (&a)[kMaxScales]) { auto v = a[0]; static_for<kMaxScales - 1>([&]<int n>() { v = ls > n ? a[n + 1] : v; }); return v; };
+    int fs = scale;                 // the scale whose per-edge front is being evaluated (wave-uniform; == scale unless the list is mixed)
 
     // operands of the edge pre-linear (first K-chunks) and its per-pose bias rows: requested before the geometry / length-encoding
     // VALU work, which hides their latency
     constexpr int NH = F0 / 32;      // pre-linear width: 128 (length + time embedding) or 64 (EBM critic: length only)
     constexpr int NT1 = H1 / 32, NT2 = H2 / 32;
     f32x16 h[NH];
-    const int oA_pre = opaque_s(P.o_A_pre + scale * (NH * 4 * 256)), oAl_pre = opaque_s(P.o_A_pre_l + scale * (NH * 4 * 256));
+    int oA_pre = 0, oAl_pre = 0;
     DenseRing<NH, 2> ring_pre{};
     DenseRing<NT1, 2> ring_r1u{};
     auto front_requests = [&]() {
         if constexpr (!UN) {
+            oA_pre = opaque_s(P.o_A_pre + fs * (NH * 4 * 256)); oAl_pre = opaque_s(P.o_A_pre_l + fs * (NH * 4 * 256));
             const Buf tbb = make_buf(P.tb, P.tb_bytes);
             const int tvoff = (pose * P.tb_pose_stride) * 4 + wv.hi64;
-            static_for<NH>([&]<int To>() { h[To] = ldrows(tbb, tvoff, scale * F0, To); });
+            static_for<NH>([&]<int To>() { h[To] = ldrows(tbb, tvoff, fs * F0, To); });
             ring_pre = dense_prefetch<NH, 4, 2, HP>(wv, oA_pre, oAl_pre);
         } else ring_r1u = dense_prefetch<NT1, 4, 2, HP>(wv, o_A_r1, o_A_r1_l);
     };
@@ -436,7 +457,11 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     }
     const float radius = P.radius[scale];
     float logit0 = 0.0f;
-    if (!UN && radius > 0.0f) {
+    if constexpr (MX) {      // per lane: its scale's cut-off (all-pairs scale: no cut-off, radius <= 0)
+        const float rl = by_lane(P.radius), cb = by_lane(P.cut_begin), cd = by_lane(P.cut_div);
+        const float cut = 1.0f - soft_step((len - cb) / (rl > 0.0f ? cd : 1.0f));
+        logit0 = rl > 0.0f ? logf(fmaxf(cut, 1e-12f)) : 0.0f;
+    } else if (!UN && radius > 0.0f) {
         const float cut = 1.0f - soft_step((len - P.cut_begin[scale]) / P.cut_div[scale]);
         logit0 = logf(fmaxf(cut, 1e-12f));
     }
@@ -491,18 +516,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         });
     }
 
-    // Timing experiments only (wrong results, same instruction stream; DESIGN.md section 5.R4, "two waves per SIMD, costed"):
-    //   -DDEDF_TIMING_LDS_ALIAS   every parked operand lands in one of six LDS slots, so that a wave needs 8 KB instead of 32 KB and EIGHT waves fit a CU
-    //   -DDEDF_TIMING_STAGE1      the tile ends after the first depth-wise TP + lin / alpha stage (no value stage, no records): the "producer wave"
-    //   -DDEDF_TIMING_STAGE2      the first stage's chunk loop is skipped (the value stage reads whatever the LDS holds): the "consumer wave"
-    //   -DDEDF_EDGE_WPS=2         __launch_bounds__(64, 2): at most 256 registers per wave (dedf_kernels.h)
-#if defined(DEDF_TIMING_LDS_ALIAS)
-#define DEDF_PSLOT(s) ((s) % 6)
-    constexpr int SPW = 6, NSLOT = 8;
-#else
-#define DEDF_PSLOT(s) (s)
     constexpr int SPW = park_phys_slots<L>(), NSLOT = SPW + 2;      // SPW: segment softmax weights / normalisers
-#endif
     __shared__ f32x4 park[NSLOT * 64];         // (declared here: the table path stages its rows in it before the parking starts)
     f32x16 r2[NT2];
     f32x4 trow[MODE == 1 ? 4 : 1][8];      // MODE 1: this lane's halves of the four table rows around its length (16 * NT2 floats of the 32 are used:
@@ -511,9 +525,19 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     bool tab = false;          // wave-uniform: this tile takes the radial network's front from the table
     if constexpr (MODE == 1) {
         DEDF_STAMP(0);
-        const float pos = len * P.rtab_inv_step[scale];
-        const bool accurate = __builtin_bit_cast(float, P.rtab_err[scale]) <= P.rtab_err_bound[scale];      // (wave-uniform; NaN compares false)
-        tab = accurate && __all(!valid || pos < (float)P.rtab_n[scale]) != 0;
+        float inv_step, tn;
+        int row0;
+        bool accurate;                                    // (wave-uniform; NaN compares false)
+        if constexpr (MX) {
+            inv_step = by_lane(P.rtab_inv_step); tn = (float)by_lane(P.rtab_n); row0 = by_lane(P.rtab_row0);
+            accurate = true;
+            for (int n = 0; n < P.n_scales; ++n) accurate = accurate && __builtin_bit_cast(float, P.rtab_err[n]) <= P.rtab_err_bound[n];
+        } else {
+            inv_step = P.rtab_inv_step[scale]; tn = (float)P.rtab_n[scale]; row0 = P.rtab_row0[scale];
+            accurate = __builtin_bit_cast(float, P.rtab_err[scale]) <= P.rtab_err_bound[scale];
+        }
+        const float pos = len * inv_step;
+        tab = accurate && __all(!valid || pos < tn) != 0;
         if (tab) {
             const float ps = valid ? pos : 0.0f;
             const int i0 = (int)ps;
@@ -522,47 +546,24 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             const float um = u - 1.0f, up = u + 1.0f, u2 = u - 2.0f;
             const float w0 = -(1.0f / 6) * u * um * u2, w1 = 0.5f * up * um * u2, w2 = -0.5f * up * u * u2, w3 = (1.0f / 6) * up * u * um;
             const Buf rtb = make_buf(P.rtab, P.rtab_bytes);
-            const int rv = ((P.rtab_row0[scale] + i0) * 2 + hi) * 128;
-#if DEDF_RTAB_COALESCED
-            // Coalesced form: an edge's four rows are 1 KB of consecutive memory, but in the operand layout a lane owns 128 bytes of each row
-            // of ITS edge -- 32 requests per lane in which all 64 lanes touch different lines (2 048 sixteen-byte lane requests per tile,
-            // bound by the address path).  Instead 16 consecutive lanes fetch one row of one edge (256 contiguous bytes), four edges per
-            // request, the wave's private LDS turns the rows round to the per-edge ownership, and the combine reads them back.
-            (void)rv;
-            const int rowoff = (P.rtab_row0[scale] + i0) * 256;
-            int eoff[8];
-            static_for<8>([&]<int T>() { eoff[T] = __shfl(rowoff, 4 * T + (wv.lane >> 4), 64) + (wv.lane & 15) * 16; });
-            f32x4* const stg_w = park + (wv.lane >> 4) * 17 + (wv.lane & 15);        // [edge][17]: one pad slot per edge against bank conflicts
-            const f32x4* const stg_r = park + wv.col * 17 + hi * 8;
-            static_for<4>([&]<int K>() { static_for<8>([&]<int T>() { trow[K][T] = bld4(rtb, eoff[T], K * 256); }); });      // all 32 requests first
-            const float twv[4] = {w0, w1, w2, w3};
-            static_for<4>([&]<int K>() {
-                static_for<8>([&]<int T>() { stg_w[(4 * T) * 17] = trow[K][T]; });
-                static_for<4 * NT2>([&]<int Q>() {
-                    const f32x4 a = stg_r[Q];
-                    static_for<4>([&]<int J>() {
-                        if constexpr (K == 0) r2[Q / 4][4 * (Q % 4) + J] = twv[0] * a[J];
-                        else r2[Q / 4][4 * (Q % 4) + J] += twv[K] * a[J];
-                    });
-                });
-            });
-#else
+            const int rv = ((row0 + i0) * 2 + hi) * 128;
             // the four rows are only REQUESTED here; they are combined in the prologue of the fused stage, under its operand requests
             static_for<4>([&]<int K>() { static_for<4 * NT2>([&]<int Q>() { trow[K][Q] = bld4(rtb, rv, K * 256 + Q * 16); }); });
             tw[0] = w0; tw[1] = w1; tw[2] = w2; tw[3] = w3;
-#endif
-        } else front_requests();
+        } else if constexpr (!MX) front_requests();
         DEDF_STAMP(1);
     }
-    if (!tab) {
+    // The per-edge front of scale `fs` (-> r2, before layer 2's LayerNorm).  One pass with fs = scale -- except for a tile of the destination-major
+    // list (MX) that cannot take the table: one pass per scale PRESENT in it, every lane keeps the activations of its own scale.
+    auto front_body = [&](const float radius) {
         // ---- length embedding: this lane's 32 of the 64 channels (k = s + 32*hi) ------------------------------------------
         float eb[32];
         {
-            const f32x4* const enc = reinterpret_cast<const f32x4*>(FRONT ? rows + RL::enc : P.W + P.o_enc + scale * 192);       // this scale's constants (edge_enc_to_lds)
+            const f32x4* const enc = reinterpret_cast<const f32x4*>(FRONT ? rows + RL::enc : P.W + P.o_enc + fs * 192);       // this scale's constants (edge_enc_to_lds)
             if (radius > 0.0f) {           // GaussianRadialBasis, radial_func.py:208-227
                 // UNet layer (GaussianRadialBasisLayerFiniteCutoff, radial_func.py:262-278): t = (len - offset) / (cutoff - offset); the host
                 // passes cutoff - offset as `radius` and the offset as `cut_begin`
-                const float t = UN ? (len - P.cut_begin[scale]) / radius : len / radius;
+                const float t = UN ? (len - P.cut_begin[fs]) / radius : len / radius;
                 static_for<2>([&]<int Hf>() {      // 16 channels at a time, stage by stage (see sigmoid_stage)
                     float z[16], wv16[16];
                     static_for<4>([&]<int G4>() {
@@ -625,6 +626,21 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         static_for<NT2>([&]<int To>() { r2[To] = ldrows_lds(r_b2, hi, 0, To); });
         dense_rot_h<NT2, H1 / 16, 2, HP>(wv, o_A_r2, o_A_r2_l, r2, [&]<int c, int j>() { return r1[c / 2][8 * (c % 2) + j]; }, ring_r2);
         DEDF_STAMP(4);
+    };
+    if constexpr (!MX) { if (!tab) front_body(radius); }
+    else if (!tab) {
+        f32x16 r2keep[NT2];
+        static_for<NT2>([&]<int T>() { static_for<16>([&]<int R>() { r2keep[T][R] = 0.0f; }); });
+        for (fs = 0; fs < P.n_scales; ++fs) {
+            if (__any(valid && ls == fs) == 0) continue;
+            edge_enc_to_lds<L, FRONT>(P, wv, fs);      // (wave-private rows; the table path never reads them)
+            front_requests();
+            front_body(P.radius[fs]);
+            const bool mine = ls == fs;
+            // (values, not lvalues: a ternary on two lvalues selects an ADDRESS and sends both arrays through scratch)
+            static_for<NT2>([&]<int T>() { to_vgpr(r2[T]); static_for<16>([&]<int R>() { const float mn = r2[T][R], kp = r2keep[T][R]; r2keep[T][R] = mine ? mn : kp; }); });
+        }
+        static_for<NT2>([&]<int T>() { r2[T] = r2keep[T]; });
     }
     if constexpr (MODE == 3) {      // accuracy check: exact activations at the interval midpoint against the interpolation of table rows e .. e + 3
         static_for<NT2>([&]<int To>() { to_vgpr(r2[To]); });
@@ -670,11 +686,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     const Buf msgd = make_buf(P.msg_dst, P.msg_dst_bytes);      // UNet layer: the destination's message is added (block.py:155); QT: the pose's time row (0e only)
     static_assert(!(UN && QT), "a UNet layer has no query time encoding");
     // per-l1 lane offsets of the 4 message rows this lane owns inside an 8-row group
-#if defined(DEDF_TIMING_X_SAME)      // timing experiment only (wrong results): every edge gathers the source rows of key 0 (L1-resident)
-    const int srcx = 0;
-#else
     const int srcx = src;
-#endif
     const int mv0 = srcx * (D * 4) + hi * 16, mv1 = srcx * (D * 4) + hi * 48, mv2 = srcx * (D * 4) + hi * 80, mv3 = srcx * (D * 4) + hi * 112;
     const int dv0 = (QT ? pose * (P.qd_pose_stride * 4) : dst * (D * 4)) + hi * 16, dv1 = dst * (D * 4) + hi * 48, dv2 = dst * (D * 4) + hi * 80, dv3 = dst * (D * 4) + hi * 112;
     // LDS parking: the gated features wait here as READY-MADE B operands of the value GEMMs: one 16-byte slot per lane holds the
@@ -684,12 +696,12 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     auto park_chunk = [&]<int Q, bool PADZ = false>(const float (&v)[8]) {
         if constexpr (park_packed<L>(Q)) {      // registers 2, 3, 6, 7 are the zero padding of 8x3e: hi and lo of the other four in one slot
             const float v4[4] = {v[0], v[1], v[4], v[5]};
-            pk[DEDF_PSLOT(park_phys<L>(Q)) * 64] = split4pk(v4);
+            pk[(park_phys<L>(Q)) * 64] = split4pk(v4);
         } else {
             HL sp;
             if constexpr (PADZ) sp = split8zx<HP>(v); else sp = split8x<HP>(v);
-            pk[DEDF_PSLOT(park_phys<L>(Q)) * 64] = __builtin_bit_cast(f32x4, sp.hi);
-            if constexpr (!HP) pk[DEDF_PSLOT(park_phys<L>(Q) + 1) * 64] = __builtin_bit_cast(f32x4, sp.lo);
+            pk[(park_phys<L>(Q)) * 64] = __builtin_bit_cast(f32x4, sp.hi);
+            if constexpr (!HP) pk[(park_phys<L>(Q) + 1) * 64] = __builtin_bit_cast(f32x4, sp.lo);
         }
     };
 
@@ -763,19 +775,13 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                             else if constexpr (QT && l1 == 0) v[m] = xo.x[run][0][el] + xo.xd[0][run][el];
                             else v[m] = xo.x[run][el / 4][el % 4];
                         });
-#if !defined(DEDF_TIMING_SO2_NOROT)      // (timing experiments only, wrong results: DESIGN.md section 5.R5)
                         Rot<l1>::in(v, tg);
-#endif
                         static_for<d1>([&]<int m>() { xrot[4 * run + j][m] = v[m]; });
                     }
                 }); });
                 constexpr int NTm = kSo2NT[l1][l2][l3];
                 constexpr float ref = kSo2Ref[l1][l2][l3];
                 float wr[NTm][8];
-#if defined(DEDF_TIMING_SO2_NOB)
-                static_for<NTm>([&]<int t>() { o.hi[t] = __builtin_bit_cast(h8, xo.x[0][0]); o.lo[t] = __builtin_bit_cast(h8, xo.x[1][0]); });
-                if constexpr (false)
-#endif
                 static_for<NTm>([&]<int t>() {
                     constexpr float ratio = kSo2C[l1][l2][l3][t] / ref, ar = ratio < 0.0f ? -ratio : ratio;
                     constexpr int rp = [&]() { for (int q = 0; q < t; ++q) { const float rq = kSo2C[l1][l2][l3][q] / ref; if ((rq < 0.0f ? -rq : rq) == ar) return q; } return t; }();
@@ -880,8 +886,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 const h8 ah = __builtin_bit_cast(h8, a.h[k]), al = __builtin_bit_cast(h8, a.l[k]);
                 HL b;
                 if constexpr (R2S_LDS) {
-                    b.hi = __builtin_bit_cast(h8, pk[DEDF_PSLOT(R2S_SLOT + 2 * (c0 + k)) * 64]);
-                    if constexpr (!HP) b.lo = __builtin_bit_cast(h8, pk[DEDF_PSLOT(R2S_SLOT + 2 * (c0 + k) + 1) * 64]);
+                    b.hi = __builtin_bit_cast(h8, pk[(R2S_SLOT + 2 * (c0 + k)) * 64]);
+                    if constexpr (!HP) b.lo = __builtin_bit_cast(h8, pk[(R2S_SLOT + 2 * (c0 + k) + 1) * 64]);
                 } else b = r2s[c0 + k];
                 t = mfma_h(ah, b.hi, t);
                 if constexpr (!HP) { t = mfma_h(ah, b.lo, t); t = mfma_h(al, b.hi, t); }
@@ -893,11 +899,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     // Debug hooks (stage tests): compiled into the per-edge instantiations only.  The table-reading kernel (MODE 1) is never launched in debug mode
     // (dedf_api.hip: use_tab requires !debug); there the hooks were 15 exec-masked store blocks in the hot loop and 4 in the value stage, each a
     // basic-block boundary in the middle of a pipeline region.
-#if defined(DEDF_NO_DBG)      // (experiment: what the stage tests' hooks cost the per-edge instantiations)
-    constexpr bool DBG = false;
-#else
     constexpr bool DBG = MODE != 1 && !UN;
-#endif      // (UNet layers are never run in debug mode either: dedf_api.hip::layer_forward_impl)
     auto dump_w = [&]<int Tw>(const f32x16& w) {      // debug only: back to the e3nn weight order
         if constexpr (DBG) if (P.dbg_w != nullptr && valid)
             static_for<16>([&]<int R>() {
@@ -1029,9 +1031,6 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     };
 
     DEDF_STAMP(6);
-#if defined(DEDF_TIMING_STAGE2)      // consumer-only timing build: no first stage; the value stage reads whatever the LDS holds
-    static_for<kHeads>([&]<int hd>() { logit[hd] = logit0 + r2[0][hd]; });
-#else
     // prologue: weight tile 0 and the first half of tile 1, source rows of chunks 0 / 1, B operands of chunk 0
     f32x16 wbuf[2];
     XOps x_nxt = load_X.template operator()<1>();
@@ -1047,7 +1046,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         if (!tab) {
             static_for<NT2>([&]<int To>() { to_vgpr(r2[To]); });
             ln_silu<NT2, UN>(r2, wv, r_g2, r_be2, P.ln_inv_n[1], P.ln_pad[1]);
-        } else if constexpr (MODE == 1 && !DEDF_RTAB_COALESCED) {
+        } else if constexpr (MODE == 1) {
             static_for<4 * NT2>([&]<int Q>() { static_for<4>([&]<int J>() {
                 r2[Q / 4][4 * (Q % 4) + J] = (tw[0] * trow[0][Q][J] + tw[1] * trow[1][Q][J]) + (tw[2] * trow[2][Q][J] + tw[3] * trow[3][Q][J]);
             }); });
@@ -1058,8 +1057,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             static_for<8>([&]<int J>() { t[J] = r2[c / 2][8 * (c % 2) + J]; });
             r2s[c] = split8x<HP>(t);
             if constexpr (R2S_LDS) {
-                pk[DEDF_PSLOT(R2S_SLOT + 2 * c) * 64] = __builtin_bit_cast(f32x4, r2s[c].hi);
-                if constexpr (!HP) pk[DEDF_PSLOT(R2S_SLOT + 2 * c + 1) * 64] = __builtin_bit_cast(f32x4, r2s[c].lo);
+                pk[(R2S_SLOT + 2 * c) * 64] = __builtin_bit_cast(f32x4, r2s[c].hi);
+                if constexpr (!HP) pk[(R2S_SLOT + 2 * c + 1) * 64] = __builtin_bit_cast(f32x4, r2s[c].lo);
             }
         });
         static_for<NR0>([&]<int T>() {      // accumulator init: lin / sep_alpha biases
@@ -1101,14 +1100,10 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         // Round 4, the sampler's two timed instantiations only (interleaved A/B at 2.37 M edges, profiles/r04z_sgb*_ab.log): lmax 2 2.697 -> 2.624 ms
         // with 5 (3 / 4: slower, 6 - 8: 2.64 - 2.68), lmax 3 5.53 -> 5.27 ms with 7 (5: 5.30, 9: 5.35, 12: 5.32); the per-edge lmax-2 kernel spills
         // 224 B with it, the value stage's regions gain nothing (their bursts have no VALU partner).
-#if defined(DEDF_SGB)
-        constexpr int SGB1 = DEDF_SGB;
-#else
 #ifndef DEDF_SGB_SO2
 #define DEDF_SGB_SO2 5      // (table-reading kernels only, like the general form: 3 / 4 / 5 / 7 -> -1 / -2 / -2 / -2 %, profiles/r05c_so2_variants_ab.log)
 #endif
         constexpr int SGB1 = SO2 ? (MODE == 1 ? DEDF_SGB_SO2 : 0) : ((MODE == 1 && F0 == 128 && H1 == 128 && H2 == 64 && !HP && !UN) ? (L == 3 ? 7 : (L == 2 ? 5 : 0)) : 0);
-#endif
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (SGB1 > 0) static_for<28>([&]<int i>() { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, SGB1, 0); });
 #endif
@@ -1122,15 +1117,8 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     if constexpr (dtp_pos_out<L, SO2>(NCHK - 1)) contract_out.template operator()<NCHK - 1>(go);
     if constexpr (SO2) static_for<L>([&]<int g>() { if constexpr (so2_group_end<L>(so2_group_of<L>(g + 1)) == NCHK) finish_group.template operator()<g + 1>(); });
     else finish_group.template operator()<L>();
-#endif
     sched_fence();
     DEDF_STAMP(12);
-#if defined(DEDF_TIMING_STAGE1)
-    // the producer's tile ends here (the value stage is not compiled); one word could leave so that the logits are not dead
-    if (P.nQ == 0x7ffffff0) P.out[e] = (logit[0] + logit[1]) + (logit[2] + logit[3]);
-    if constexpr (MODE == 1) geo.ok = 0;
-    return;
-#endif
     float nk[3] = {0.0f, 0.0f, 0.0f}, nq[3] = {0.0f, 0.0f, 0.0f};       // MODE 1: the next tile's coordinates, requested here
     if constexpr (MODE == 1) {
         if (e_next >= 0) {
@@ -1250,15 +1238,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         const float cross = (col >= 16 && seg_start < 16) ? 1.0f : 0.0f;
         static_for<NS>([&]<int n>() { scan_step.template operator()<4>(x[n], cross); });
         float* const orec = orec_of();
-#if defined(DEDF_TIMING_NO_RECORDS)      // timing experiment only (wrong results): everything is computed, no segment record leaves the kernel
-        if (seg_last && P.nQ < 0) static_for<NS>([&]<int n>() { st4(orec + rec_off[n], f32x4{x[n][0], x[n][1], x[n][2], x[n][3]} * inv[n]); });
-#else
-#if defined(DEDF_NO_PK)      // experiment: four scalar products instead of the packed pair hipcc makes of `f32x4 * float`
-        if (seg_last) static_for<NS>([&]<int n>() { st4(orec + rec_off[n], f32x4{x[n][0] * inv[n], x[n][1] * inv[n], x[n][2] * inv[n], x[n][3] * inv[n]}); });
-#else
         if (seg_last) static_for<NS>([&]<int n>() { st4(orec + rec_off[n], f32x4{x[n][0], x[n][1], x[n][2], x[n][3]} * inv[n]); });
-#endif
-#endif
     };
     // (K0, NK: the components K0 .. K0 + NK - 1 of the block only -- output tiles for l3 = 0 --, NK < 0: all of them.  The edge-frame value stage
     //  emits a completed degree piece by piece under the GEMMs of the next one.)
@@ -1276,11 +1256,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 if constexpr (DBG) { x[n] = x[n] * cv0; if (drec != nullptr && valid) st4(drec + ro[n], x[n]); x[n] = x[n] * pw[hd]; }
                 else {
                     const float sc_ = cv0 * pw[hd];
-#if defined(DEDF_NO_PK)
-                    x[n] = f32x4{x[n][0] * sc_, x[n][1] * sc_, x[n][2] * sc_, x[n][3] * sc_};
-#else
                     x[n] = x[n] * sc_;
-#endif
                 }          // (one product per value: the power-of-two operand scale folds into the softmax weight exactly)
             }); });
             emit(x, ro, iv);
@@ -1293,11 +1269,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 if constexpr (DBG) { x[n] = x[n] * cv1; if (drec != nullptr && valid) st4(drec + ro[n], x[n]); x[n] = x[n] * pw[g]; }
                 else {
                     const float sc_ = cv1 * pw[g];
-#if defined(DEDF_NO_PK)
-                    x[n] = f32x4{x[n][0] * sc_, x[n][1] * sc_, x[n][2] * sc_, x[n][3] * sc_};
-#else
                     x[n] = x[n] * sc_;
-#endif
                 }
             }); });
             emit(x, ro, iv);
@@ -1310,11 +1282,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 if constexpr (DBG) { x[n] = x[n] * cv2; if (drec != nullptr && valid) st4(drec + ro[n], x[n]); x[n] = x[n] * (hi ? pw[2 * g + 1] : pw[2 * g]); }
                 else {
                     const float sc_ = cv2 * (hi ? pw[2 * g + 1] : pw[2 * g]);
-#if defined(DEDF_NO_PK)
-                    x[n] = f32x4{x[n][0] * sc_, x[n][1] * sc_, x[n][2] * sc_, x[n][3] * sc_};
-#else
                     x[n] = x[n] * sc_;
-#endif
                 }
             }); });
             emit(x, ro, iv);
@@ -1327,11 +1295,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 if constexpr (DBG) { x[n] = x[n] * cv3; if (drec != nullptr && valid) st4(drec + ro[n], x[n]); x[n] = x[n] * (hi ? pw[2 * g + 1] : pw[2 * g]); }
                 else {
                     const float sc_ = cv3 * (hi ? pw[2 * g + 1] : pw[2 * g]);
-#if defined(DEDF_NO_PK)
-                    x[n] = f32x4{x[n][0] * sc_, x[n][1] * sc_, x[n][2] * sc_, x[n][3] * sc_};
-#else
                     x[n] = x[n] * sc_;
-#endif
                 }
             }); });
             emit(x, ro, iv);
@@ -1375,12 +1339,12 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             const f32x4* const pkt = park + lane_t;
             static_for<(it.l3 == 0 ? 1 : it.na)>([&]<int a>() {      // (scalar outputs: one B operand for both tiles)
                 if constexpr (park_packed<L>(it.bq[a])) {      // one slot: {hi(0,1), hi(4,5), lo(0,1), lo(4,5)}, the other registers are the zero padding of 8x3e
-                    const f32x4 sp = pkt[DEDF_PSLOT(park_phys<L>(it.bq[a])) * 64];
+                    const f32x4 sp = pkt[(park_phys<L>(it.bq[a])) * 64];
                     o.h[a] = f32x4{sp[0], 0.0f, sp[1], 0.0f};
                     if constexpr (!HP) o.l[a] = f32x4{sp[2], 0.0f, sp[3], 0.0f};
                 } else {
-                o.h[a] = pkt[DEDF_PSLOT(park_phys<L>(it.bq[a])) * 64];
-                if constexpr (!HP) o.l[a] = pkt[DEDF_PSLOT(park_phys<L>(it.bq[a]) + 1) * 64];
+                o.h[a] = pkt[(park_phys<L>(it.bq[a])) * 64];
+                if constexpr (!HP) o.l[a] = pkt[(park_phys<L>(it.bq[a]) + 1) * 64];
                 }
                 if constexpr (it.neg[a]) {
                     o.h[a] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, o.h[a]) ^ 0x80008000u);
@@ -1461,26 +1425,12 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         load_A_of.template operator()<I + PDV>();
         const SB b_nxt = load_B.template operator()<I + 1>();
         sched_fence();
-#if defined(DEDF_TIMING_SO2_NOMFMA2)
-        if constexpr (I < NVI) { constexpr SItem it = sval_item<L>(I); static_for<it.na>([&]<int a>() {
-            auto& V = [&]() -> auto& { if constexpr (it.l3 == 0) return V0; else if constexpr (it.l3 == 1) return V1; else if constexpr (it.l3 == 2) return V2; else return V3; }();
-            V[it.set][it.tile[a]][0] = (it.first[a] ? 0.0f : V[it.set][it.tile[a]][0]) + vb_cur.h[it.l3 == 0 ? 0 : a][0] + vb_cur.l[it.l3 == 0 ? 0 : a][1] + aring[it.aslot[a] % RS].h[0] + aring[it.aslot[a] % RS].l[1]; }); }
-#else
         if constexpr (I < NVI) run_item.template operator()<I, ONE>(vb_cur);
-#endif
         static_for<L + 1>([&]<int g>() {
             constexpr int q = I - 1 - sval_group_last<L>(g);
             if constexpr (q >= 0 && q < npieces(g)) {
-#if defined(DEDF_TIMING_SO2_NOFIN)
-                if constexpr (q == 0) {
-                    if constexpr (g == 0) static_for<2>([&]<int T>() { val0[T][0] = V0[0][T][0] + V0[1][T][1]; });
-                    if constexpr (g == 1) static_for<3>([&]<int K>() { val1[K][0] = V1[0][K][0] + V1[1][K][1]; });
-                    if constexpr (g == 2) static_for<5>([&]<int K>() { val2[K][0] = V2[0][K][0] + V2[1][K][1]; });
-                }
-#else
                 if constexpr (q == 0) finish_value.template operator()<g, ONE>();
                 else store_group.template operator()<g, q - 1, 1>();
-#endif
             }
         });
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1545,7 +1495,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 constexpr VItem prev = val_item<L>(I - 1);
                 if constexpr (!(prev.in_side && dtp_path<L>(prev.p >= 0 ? prev.p : 0).l1 == 3 && I >= 1)) {
                     static_for<7>([&]<int i>() {
-                        const u32x4 s = __builtin_bit_cast(u32x4, pkt[DEDF_PSLOT(park_phys<L>(park_slot<L>(3, i, 0))) * 64]);      // {hi(0,1), hi(4,5), lo(0,1), lo(4,5)}
+                        const u32x4 s = __builtin_bit_cast(u32x4, pkt[(park_phys<L>(park_slot<L>(3, i, 0))) * 64]);      // {hi(0,1), hi(4,5), lo(0,1), lo(4,5)}
                         static_for<4>([&]<int c>() { uin[i][c] = unsplit<c % 2>(s[c / 2], s[2 + c / 2]); });
                     });
                 }
@@ -1569,10 +1519,10 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
                 constexpr int KCH = mul_of(l1) / 16;      // park_slot(l, i, c) = park_slot(l, 0, c) + i * KCH
                 float u[d1][8];
                 static_for<d1>([&]<int i>() {
-                    const h8 hh = __builtin_bit_cast(h8, pkt[DEDF_PSLOT(park_phys<L>(it.bq[0] + i * KCH)) * 64]);
+                    const h8 hh = __builtin_bit_cast(h8, pkt[(park_phys<L>(it.bq[0] + i * KCH)) * 64]);
                     if constexpr (HP) static_for<8>([&]<int r>() { u[i][r] = (float)hh[r]; });
                     else {
-                        const u32x4 hw = __builtin_bit_cast(u32x4, hh), lw = __builtin_bit_cast(u32x4, pkt[DEDF_PSLOT(park_phys<L>(it.bq[0] + i * KCH) + 1) * 64]);
+                        const u32x4 hw = __builtin_bit_cast(u32x4, hh), lw = __builtin_bit_cast(u32x4, pkt[(park_phys<L>(it.bq[0] + i * KCH) + 1) * 64]);
                         static_for<8>([&]<int r>() { if constexpr (!pad_reg<L, NW>(l1, r)) u[i][r] = unsplit<r % 2>(hw[r / 2], lw[r / 2]); else u[i][r] = 0.0f; });
                     }
                 });
@@ -1598,12 +1548,12 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             const f32x4* const pkt = park + lane_t;
             static_for<it.share_b ? 1 : it.na>([&]<int a>() {
                 if constexpr (park_packed<L>(it.bq[a])) {      // one slot: {hi(0,1), hi(4,5), lo(0,1), lo(4,5)}, the other registers are zeros
-                    const f32x4 s = pkt[DEDF_PSLOT(park_phys<L>(it.bq[a])) * 64];
+                    const f32x4 s = pkt[(park_phys<L>(it.bq[a])) * 64];
                     o.h[a] = f32x4{s[0], 0.0f, s[1], 0.0f};
                     if constexpr (!HP) o.l[a] = f32x4{s[2], 0.0f, s[3], 0.0f};
                 } else {
-                    o.h[a] = pkt[DEDF_PSLOT(park_phys<L>(it.bq[a])) * 64];
-                    if constexpr (!HP) o.l[a] = pkt[DEDF_PSLOT(park_phys<L>(it.bq[a]) + 1) * 64];
+                    o.h[a] = pkt[(park_phys<L>(it.bq[a])) * 64];
+                    if constexpr (!HP) o.l[a] = pkt[(park_phys<L>(it.bq[a]) + 1) * 64];
                 }
             });
         }
@@ -1695,15 +1645,6 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             constexpr int ge = val_item<L>(F).group_end;
             if constexpr (ge >= 0 && ge < L) store_group.template operator()<ge>();
         }
-#if defined(DEDF_SGB_CHAIN) && defined(__HIP_DEVICE_COMPILE__)      // experiment: the MFMAs of a chained item one by one between the VALU work that forms the next item's operand
-        if constexpr (I < NVI) { if constexpr (val_item<L>(I < NVI ? I : 0).chain) static_for<9>([&]<int i>() { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, DEDF_SGB_CHAIN, 0); }); }
-#endif
-#if defined(DEDF_SGB) && !defined(DEDF_SGBV)
-#define DEDF_SGBV DEDF_SGB
-#endif
-#if defined(DEDF_SGBV) && DEDF_SGBV > 0 && defined(__HIP_DEVICE_COMPILE__)
-        static_for<10>([&]<int i>() { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, DEDF_SGBV, 0); });
-#endif
         sched_fence();
         vb_cur = b_nxt;
         if constexpr (F >= 0 && val_item<L>(F).group_end == 0) DEDF_STAMP(10);

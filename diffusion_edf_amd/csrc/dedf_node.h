@@ -82,13 +82,25 @@ DEDF_DEV void node_rows_to_lds(const NodeParams& P, const Wave& wv) {
     using RL = NodeRowsLds<L>;
     constexpr NodeLayout<L> O = kNodeLayout<L>;
     float* rows = node_rows_lds<L>();
-    auto cp = [&](int dst, int src, int n) { for (int i = wv.lane; i < n; i += 64) rows[dst + i] = P.W[src + i]; };
-    cp(RL::b_proj0, O.b_proj0, 64); cp(RL::ln_w0, O.ln_w[0], 64); cp(RL::ln_b0, O.ln_b0, 64);
-    if constexpr (L >= 1) cp(RL::ln_w1, O.ln_w[1], 32);
-    if constexpr (L >= 2) cp(RL::ln_w2, O.ln_w[2], 32);
-    if constexpr (L >= 3) cp(RL::ln_w3, O.ln_w[3], 32);
-    cp(RL::b_f1, O.b_f1, cdiv(f1_rows0<L>(), 32) * 32); cp(RL::b_f2, O.b_f2, 64);
-    if constexpr (!EBM) { cp(RL::b_sl0, O.b_sl[0], 32); cp(RL::b_sl1, O.b_sl[1], 32); }
+    // (all requests, then all stores: dedf_dev.h::rows_request)
+    const float* const W = P.W;
+    const int lane = wv.lane;
+    constexpr int NF1 = cdiv(f1_rows0<L>(), 32) * 32;
+    const RowRegs<64> bp = rows_request<64>(W + O.b_proj0, lane), w0 = rows_request<64>(W + O.ln_w[0], lane), lb = rows_request<64>(W + O.ln_b0, lane),
+                      bf2 = rows_request<64>(W + O.b_f2, lane);
+    RowRegs<32> w1, w2, w3, s0, s1;
+    if constexpr (L >= 1) w1 = rows_request<32>(W + O.ln_w[1], lane);
+    if constexpr (L >= 2) w2 = rows_request<32>(W + O.ln_w[2], lane);
+    if constexpr (L >= 3) w3 = rows_request<32>(W + O.ln_w[3], lane);
+    const RowRegs<NF1> bf1 = rows_request<NF1>(W + O.b_f1, lane);
+    if constexpr (!EBM) { s0 = rows_request<32>(W + O.b_sl[0], lane); s1 = rows_request<32>(W + O.b_sl[1], lane); }
+    sched_fence();
+    rows_store<64>(rows + RL::b_proj0, bp, lane); rows_store<64>(rows + RL::ln_w0, w0, lane); rows_store<64>(rows + RL::ln_b0, lb, lane);
+    if constexpr (L >= 1) rows_store<32>(rows + RL::ln_w1, w1, lane);
+    if constexpr (L >= 2) rows_store<32>(rows + RL::ln_w2, w2, lane);
+    if constexpr (L >= 3) rows_store<32>(rows + RL::ln_w3, w3, lane);
+    rows_store<NF1>(rows + RL::b_f1, bf1, lane); rows_store<64>(rows + RL::b_f2, bf2, lane);
+    if constexpr (!EBM) { rows_store<32>(rows + RL::b_sl0, s0, lane); rows_store<32>(rows + RL::b_sl1, s1, lane); }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 }

@@ -16,6 +16,6 @@ wait
 OBJS="$APIO $C/_obj/k${UNIT}_$NAME.o"
 NU=$(grep -o "kKernelUnits = [0-9]*" $C/dedf_kernel_list.h | grep -o "[0-9]*$")
 for u in $(seq 0 $((NU - 1))); do if [ $u != $UNIT ]; then OBJS="$OBJS $C/_obj/k$u.o"; fi; done
-OBJS="$OBJS $C/_obj/kocc.o $C/_obj/k16e.o"      # the A/B instantiations that live outside the unit list
+
 hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $C/libdedf_$NAME.so
 echo built $C/libdedf_$NAME.so

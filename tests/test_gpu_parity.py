@@ -129,11 +129,12 @@ def test_query_time_encoding_other_shapes(shape):
     scale = float(max(a64.abs().max(), l64.abs().max()))
     err = max(float((ang.double() - a64).abs().max()), float((lin.double() - l64).abs().max())) / scale
     # (these random-init weights with a time-dependent destination message are harsher than the plain head: the fp32 RESTATEMENT itself sits
-    #  4.6e-5 / 7.9e-5 from the fp64 one here, and the kernels land on that floor -- the bar is the stated 1e-4, or 1.5 x the floor where it is higher)
+    #  4.6e-5 / 7.9e-5 from the fp64 one here and the kernels land on that floor -- measured 8.2e-5 / 4.6e-5, inside the stated 1e-4, which is the bar;
+    #  the restatement's own error is printed as a diagnostic only)
     a32, l32, _, _ = SC.oracle_run(kw, P, keys, query, Ts, time, torch.float32)
     floor = max(float((a32.double() - a64).abs().max()), float((l32.double() - l64).abs().max())) / scale
     print(f"TOLPROBE query-time {shape}: {err:.2e} (fp32 restatement {floor:.2e})")
-    assert err < max(TOL, 1.5 * floor), (shape, err, floor)
+    assert err < TOL, (shape, err, floor)
     gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
     gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
     outs = []
@@ -270,26 +271,44 @@ def test_radial_table_of_the_sampler_against_the_per_edge_evaluation():
                 assert e_on < 1e-4 and e_on < e_off + 5e-6, (t, e_on, e_off)
 
 
-def test_sixteen_edge_tile_of_the_sampler_against_the_oracle(monkeypatch):
-    """DEDF_EDGE16=1: the sampler's table path on the 16-edge tile (v_mfma_f32_16x16x32_f16, two waves per SIMD; csrc/dedf_edge16.h) -- an A/B
-    build of the same arithmetic (it is slower: profiles/r03j16_*).  One noise-free step against the fp64 oracle (1e-4 of the displacement
-    scale, rotation and translation) and against the 32-edge kernel (same 3-term products in another summation order: 1e-5), finite scales
-    and the all-pairs scale, partial tiles included (edge counts are not multiples of 16).  Lengths beyond the table are an error in this
-    mode (the tile has no per-edge front), not a silent fallback."""
+@pytest.mark.parametrize("lmax", [2, 3])
+def test_destination_major_edge_list_of_the_table_path(monkeypatch, lmax):
+    """Round 6: the sampler's table-reading edge kernel works on a DESTINATION-major edge list -- (dst, scale, src) instead of (scale, dst, src),
+    dedf_misc.h::NbrParams::dst_major -- so that a destination's softmax segments merge across scales (the joint softmax of reference
+    graph_attention.py:253-268 is over all scales' edges of a destination anyway).  Checked: the list itself (same edge SET as the scale-major list,
+    sorted by destination, inside a destination by scale and key index; same per-scale counts), one noise-free step against the scale-major run of
+    the same library (DEDF_DST_MAJOR=0: other summation order only, 1e-5 of the displacement) and against the fp64 oracle (1e-4); and the case a mixed
+    tile cannot take the table -- poses far from the scene: all-pairs lengths beyond the table -- where every scale present in the tile is evaluated
+    per edge."""
     dev = torch.device('cuda:0')
-    for radii, nT in (((5., 10., 20., None), 12), ((3.5, 5., 6.5, 8.), 40)):
-        kw, cfg, P, keys, query, Ts, _ = SC.build_case(2, nT, 1024, 128, radii=radii)
+    radii = (5., 10., 20., None)
+    for far in (False, True):
+        kw, cfg, P, keys, query, Ts, _ = SC.build_case(lmax, 14, 1024, 128, radii=radii)
+        if far:
+            Ts = Ts.clone(); Ts[::3, 4:] += torch.tensor([120.0, 60.0, 40.0], dtype=Ts.dtype)
         gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
         gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
-        t, outs = 0.5, {}
-        for e16 in (0, 1):
-            monkeypatch.setenv("DEDF_EDGE16", str(e16))          # read by dedf_create
+        t, outs, lists, counts = 0.5, {}, {}, {}
+        for dm in (1, 0):
+            monkeypatch.setenv("DEDF_DST_MAJOR", str(dm))          # read by dedf_create
             head = ScoreModelHead(**kw); head.load_state_dict(P); head.to(dev); head.set_radial_table("always")
-            outs[e16] = ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[t, t]], [1], [0.04], temperatures=0.0).cpu()
-        d0, d1 = outs[0][1] - outs[0][0], outs[1][1] - outs[1][0]
-        sq, sx = float(d0[:, :4].abs().max()), float(d0[:, 4:].abs().max())
-        dq, dx = float((d1 - d0)[:, :4].abs().max()) / sq, float((d1 - d0)[:, 4:].abs().max()) / sx
-        assert 0.0 < max(dq, dx) < 1e-5, (radii, dq, dx)         # (> 0: the other kernel really ran)
+            outs[dm] = ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[t, t]], [1], [0.04], temperatures=0.0).cpu()
+            counts[dm] = head.stats()['n_edges']
+            lists[dm] = (head.debug_buffer("edge_src", torch.int32).long(), head.debug_buffer("edge_dst", torch.int32).long())
+        assert counts[1] == counts[0] and sum(counts[1]) == len(lists[1][0]) == len(lists[0][0]), (counts, len(lists[1][0]))
+        src, dst = lists[1]
+        start = torch.tensor([0] + [len(k.x) for k in keys]).cumsum(0)
+        scale = torch.bucketize(src, start[1:], right=True)
+        key1 = (dst * 16 + scale) * (int(start[-1]) + 1) + src
+        assert bool((key1[1:] > key1[:-1]).all()), "destination-major list: not sorted by (dst, scale, src)"
+        s0, d0 = lists[0]
+        key0 = (d0 * 16 + torch.bucketize(s0, start[1:], right=True)) * (int(start[-1]) + 1) + s0
+        assert torch.equal(key1, key0.sort().values), "the two orders hold different edge sets"
+        assert [int((scale == n).sum()) for n in range(len(keys))] == list(counts[1])
+        d1, d0_ = outs[1][1] - outs[1][0], outs[0][1] - outs[0][0]
+        sq, sx = float(d0_[:, :4].abs().max()), float(d0_[:, 4:].abs().max())
+        dq, dx = float((d1 - d0_)[:, :4].abs().max()) / sq, float((d1 - d0_)[:, 4:].abs().max()) / sx
+        assert max(dq, dx) < 1e-5, (far, dq, dx)
         ocfg = R.config_from_kwargs(kw)
         k64 = [R.FeaturedPoints(k.x.double(), k.f.double(), k.b, None) for k in keys]
         q64 = R.FeaturedPoints(query.x.double(), query.f.double(), query.b, query.w.double())
@@ -297,16 +316,8 @@ def test_sixteen_edge_tile_of_the_sampler_against_the_oracle(monkeypatch):
         z = torch.zeros(len(Ts), 3, dtype=torch.float64)
         dr = R.langevin_step(ocfg, Ts, ang, lin, t, 0.04, 0.0, 0.5, 0.5, z, z) - Ts
         eq, ex = float((d1 - dr)[:, :4].abs().max()) / sq, float((d1 - dr)[:, 4:].abs().max()) / sx
-        assert eq < 1e-4 and ex < 1e-4, (radii, eq, ex)
-    # far poses: all-pairs lengths leave the table -> reported
-    monkeypatch.setenv("DEDF_EDGE16", "1")
-    kw, cfg, P, keys, query, Ts, _ = SC.build_case(2, 12, 1024, 128, radii=(5., 10., 20., None))
-    Ts = Ts.clone(); Ts[::3, 4:] += torch.tensor([120.0, 60.0, 40.0], dtype=Ts.dtype)
-    head = ScoreModelHead(**kw); head.load_state_dict(P); head.to(dev); head.set_radial_table("always")
-    gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
-    gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
-    with pytest.raises(RuntimeError, match="DEDF_EDGE16"):
-        ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[0.5, 0.5]], [1], [0.04], temperatures=0.0)
+        print(f"TOLPROBE dst-major lmax {lmax} far {far}: against the scale-major run {max(dq, dx):.2e}, against the fp64 oracle {max(eq, ex):.2e}")
+        assert eq < 1e-4 and ex < 1e-4, (far, eq, ex)
 
 
 @pytest.mark.parametrize("shape", ["time_emb_128", "narrow_radial_mlp"])
@@ -857,8 +868,9 @@ def test_randomised_shapes_and_sizes():
     """a short run of tests/stress_parity.py (model shape, scales, radii, cap, cloud sizes, poses all drawn at random; 490 such cases
     were run clean on the GPU box during round 1): final score within the tolerance and identical edge counts in every case"""
     import stress_parity
-    # (in the suite: 8 cases; DEDF_FULL_SWEEPS=1 runs the 16 of rounds 1-4 -- the long sweeps live in tests/stress_parity.py with their logs under profiles/)
-    assert stress_parity.run_cases(16 if os.environ.get("DEDF_FULL_SWEEPS") else 8, seed=2) == []
+    # (in the suite: the 16 cases of rounds 1-4 again -- round 5 had cut them to 8; DEDF_SHORT_SWEEPS=1 runs 8; the long sweeps live in tests/stress_parity.py
+    #  with their logs under profiles/)
+    assert stress_parity.run_cases(8 if os.environ.get("DEDF_SHORT_SWEEPS") else 16, seed=2) == []
 
 
 def test_randomised_sampler_critic_and_half_precision_cases():
@@ -866,7 +878,7 @@ def test_randomised_sampler_critic_and_half_precision_cases():
     noise against the oracle's float64 loop, the EBM critic's energies, and the score head in half-precision GEMM mode at its stated 5e-3"""
     import numpy as np
     import stress_parity
-    n_each = 5 if os.environ.get("DEDF_FULL_SWEEPS") else 3
+    n_each = 3 if os.environ.get("DEDF_SHORT_SWEEPS") else 5
     for fn, n, seed in ((stress_parity.run_sample_case, n_each, 11), (stress_parity.run_ebm_case, n_each, 12), (stress_parity.run_half_case, n_each, 13)):
         rng = np.random.default_rng(seed)
         res = [fn(i, rng) for i in range(n)]
@@ -1207,14 +1219,27 @@ _RANGE_GROUPS = {
 }
 
 
+# The cases whose bar is above the stated 1e-4, by name.  Measured on the round-5 library (profiles/r05k_range_floor.log: error of the fp32 restatement of the
+# reference / of the HIP path, both against the fp64 restatement, in units of the largest score): the first three are ill-conditioned in fp32 ITSELF -- the
+# restatement in the reference's own precision is outside 1e-4 or at it --, the two x1000 rows are where 22-bit operands (3-term split fp16) show against
+# 24-bit ones.  Bar = 1.5 x the larger of the two measured errors.  Every other (group, factor) asserts 1e-4.
+_RANGE_BARS = {
+    ('node_ffn', 30.0): 7.6e-4,               # fp32 restatement 5.06e-4, HIP 4.51e-4
+    ('query_features', 1000.0): 2.8e-4,       # fp32 restatement 1.81e-4, HIP 1.72e-4
+    ('edge_linears', 100.0): 1.7e-4,          # fp32 restatement 9.87e-5, HIP 1.11e-4
+    ('src_message', 1000.0): 6.4e-4,          # fp32 restatement 9.60e-5, HIP 4.26e-4 (x1000: "within this bar OR reported")
+    ('radial_last_layer', 1000.0): 6.4e-4,    # fp32 restatement 9.65e-5, HIP 4.24e-4
+}
+
+
 @pytest.mark.parametrize("factor", [30.0, 100.0, 1000.0, 0.01])
 @pytest.mark.parametrize("group", list(_RANGE_GROUPS) + ['all_of_them'])
 def test_fp16_operand_range_scaled_weights_and_features(group, factor):
     """GEMM operands are fp16 hi + fp16 lo with power-of-two pre-scaling.  A trained checkpoint may carry weights / features tens of times
     larger (or smaller) than random init.  Round 5: the activation-side exponents follow the handle's WEIGHTS (dedf_pack.h::act_exponent: typical
     magnitudes propagated from the LayerNorms through the block), so with any group of weights -- or all of them at once -- scaled x30, x100
-    or x0.01 the score stays within the 1e-4 tolerance of the fp64 oracle on the same scaled inputs (or within 1.5x the fp32 restatement's own
-    error where the scaled model is ill-conditioned in fp32 itself), and never overflows.  Only from x1000 on (the caller's own
+    or x0.01 the score stays within the 1e-4 tolerance of the fp64 oracle on the same scaled inputs (the named exceptions of _RANGE_BARS: models that
+    are ill-conditioned in fp32 itself), and never overflows.  Only from x1000 on (the caller's own
     features, which no weight announces, or compounding groups) the old contract remains: within tolerance OR reported (non-finite flag in the
     stats, RuntimeError from `sample`) -- never a finite wrong score."""
     kw, cfg, P, keys, query, Ts, time = SC.build_case(2, 6, 512, 60)
@@ -1248,12 +1273,13 @@ def test_fp16_operand_range_scaled_weights_and_features(group, factor):
         return          # outside the fp16 operand range, and reported as such
     scale = float(max(ang64.abs().max(), lin64.abs().max()))
     err = max(float((ang.double() - ang64).abs().max()), float((lin.double() - lin64).abs().max())) / scale
-    # Some scaled models are ill-conditioned in fp32 itself (saturated softmax / gates: node_ffn x30 puts the fp32 RESTATEMENT 5e-4 from the fp64 one,
-    # profiles/r05k_range_floor.log): the bar is the stated tolerance or the fp32 restatement's own error on the same inputs, whichever is larger --
-    # x1.5 up to x100 (measured: HIP <= 1.2x the restatement everywhere), x6 at x1000 (22-bit operands against 24: measured 4.4x).
+    # Every (group, factor) asserts the stated 1e-4 EXCEPT the named cases of _RANGE_BARS: scaled models that are ill-conditioned in fp32 itself
+    # (saturated softmax / gates), each with the error its fp32 RESTATEMENT has on the same inputs (profiles/r05k_range_floor.log).
     ang32, lin32, _, _ = SC.oracle_run(kw, P, keys, query, Ts, time, torch.float32)
     floor = max(float((ang32.double() - ang64).abs().max()), float((lin32.double() - lin64).abs().max())) / scale
-    assert err < max(TOL, (6.0 if factor >= 1000.0 else 1.5) * floor), (group, factor, err, floor)
+    bar = _RANGE_BARS.get((group, factor), TOL)
+    print(f"TOLPROBE fp16 range {group} x{factor:g}: {err:.2e} (fp32 restatement {floor:.2e}, bar {bar:.1e})")
+    assert err < bar, (group, factor, err, floor, bar)
 
 
 def test_scene_cache_is_not_fooled_by_recycled_addresses():
