@@ -29,7 +29,7 @@ __global__ void k_energy_reduce(const float* __restrict__ node_out, int nT, int 
     float s = 0.0f;
     for (int q = 0; q < nQ; ++q) s += node_out[((size_t)t * nQ + q) * 8];
     if (flags[kFlagOverflow]) s = __builtin_nanf("");              // see dedf_misc.h::reduce_status
-    else if (!(fabsf(s) <= 3.0e38f)) flags[kFlagNonFinite] = 1;
+    else if (!(fabsf(s) <= 3.0e38f)) { flags[kFlagNonFinite] = 1; flags[kFlagNonFiniteSeen] = 1; }
     energy[t] = s;
 }
 
@@ -103,14 +103,13 @@ struct dedf_handle {
     int tab_slot = -1;            // >= 0 inside dedf_sample's loop: the ring slot that holds THIS step's table
     bool rtab_async = false;      // DEDF_RTAB_ASYNC=1 turns the side-stream generation on (A/B)
     DevBuf d_cnt2, d_blk2; int small_parity = 0; int64_t small_layout = -1;      // the two alternating count sets of the small-batch neighbour path
-    DevBuf d_tot;                     // destination-major edge list: [2][N_d] per-destination totals / first edges (NbrParams::cnt_tot / off_tot)
-    int dst_major = 0;                // DEDF_DST_MAJOR=1: the destination-major edge list + mixed-scale table kernels (built and measured in round 6: k_aggregate -32 us, k_edge +100 us at C2 -- profiles/r06g_dst_major_ab3.log -- hence opt-in)
     // Verdict of the last dedf_score / dedf_energy call (they never synchronise): the status words are copied to pinned host memory behind the
     // call's kernels; the NEXT entry point of this handle looks at them (check_pending) and fails if the call overflowed its edge workspace or
     // produced a non-finite result -- so that a caller who never reads dedf_get_stats does not keep working with NaN scores.
     int* h_flags = nullptr;           // pinned, 64 ints (the tile_info block)
     hipEvent_t ev_flags = nullptr;
     bool flags_pending = false;
+    bool clear_seen = false;          // the host has consumed a sticky verdict (kFlagOverflowSeen / kFlagNonFiniteSeen): clear the words at the next call
     bool so2 = false;                 // the edge kernels of this handle run both depth-wise TPs in the edge-aligned frame (dedf_edge.h: SO2; its own
                                       // packed image, dedf_pack.h::pack_edge<L, true>).  DEDF_SO2=0 keeps the general form (A/B, tests)
     bool small_batch_path = true;     // N_d <= kNbrSmallMax (32 768): word-parallel neighbour masks + fused pose preparation (DEDF_SMALL_BATCH=0 turns it off: A/B, tests)
@@ -161,7 +160,11 @@ struct DeviceGuard {
     DeviceGuard dev_guard__((h)->cfg.device);              \
     if (!dev_guard__.ok) return fail(h, DEDF_ERR_RUNTIME, "hipSetDevice failed")
 // clears the sticky status words (overflow, non-finite) at the start of an API call
-#define DEDF_CLEAR_FLAGS(h, st) HIPCK(h, hipMemsetAsync((h)->d_tile.as<int>() + kFlagOverflow, 0, (kFlagTimeVaries + 1 - kFlagOverflow) * sizeof(int), st))
+#define DEDF_CLEAR_FLAGS(h, st)                                                                                                              \
+    do {                                                                                                                                     \
+        HIPCK(h, hipMemsetAsync((h)->d_tile.as<int>() + kFlagOverflow, 0, (kFlagTimeVaries + 1 - kFlagOverflow) * sizeof(int), st));          \
+        if ((h)->clear_seen) { HIPCK(h, hipMemsetAsync((h)->d_tile.as<int>() + kFlagOverflowSeen, 0, 2 * sizeof(int), st)); (h)->clear_seen = false; } \
+    } while (0)
 
 int fail(dedf_handle* h, int code, const std::string& msg) {
     if (h) h->err = msg;
@@ -190,11 +193,14 @@ int check_pending(dedf_handle* h, bool block) {
     if (block) HIPCK(h, hipEventSynchronize(h->ev_flags));
     else if (hipEventQuery(h->ev_flags) != hipSuccess) return DEDF_OK;
     h->flags_pending = false;
-    if (h->h_flags[40] | h->h_flags[kFlagOverflow])
-        return fail(h, DEDF_ERR_RUNTIME, "the previous dedf_score / dedf_energy call overflowed its edge workspace: its outputs are NaN (dedf_config.max_edges, or let "
+    // (the "seen" words are sticky on the device until consumed here: a verdict of ANY call since the last look, not only of the latest one)
+    const bool ovf = (h->h_flags[40] | h->h_flags[kFlagOverflow] | h->h_flags[kFlagOverflowSeen]) != 0, nonfin = (h->h_flags[kFlagNonFinite] | h->h_flags[kFlagNonFiniteSeen]) != 0;
+    if (ovf || nonfin) h->clear_seen = true;      // the next call of the handle clears them on its stream, in front of its kernels
+    if (ovf)
+        return fail(h, DEDF_ERR_RUNTIME, "a previous dedf_score / dedf_energy call (since this handle's status was last looked at) overflowed its edge workspace: its outputs are NaN (dedf_config.max_edges, or let "
                                          "dedf_sample grow the automatic workspace); reported by the next call because dedf_score never synchronises");
-    if (h->h_flags[kFlagNonFinite])
-        return fail(h, DEDF_ERR_RUNTIME, "the previous dedf_score / dedf_energy call produced a non-finite result (an operand left the fp16 window of the split GEMMs, "
+    if (nonfin)
+        return fail(h, DEDF_ERR_RUNTIME, "a previous dedf_score / dedf_energy call (since this handle's status was last looked at) produced a non-finite result (an operand left the fp16 window of the split GEMMs, "
                                          "or the inputs were not finite): its outputs are NaN; reported by the next call because dedf_score never synchronises");
     return DEDF_OK;
 }
@@ -393,6 +399,7 @@ int ensure_workspace(dedf_handle* h, int nT) {
     cap = std::min<int64_t>(cap, 0x7fffffff - 64);
     cap = std::max<int64_t>(cap, 64);
     h->edge_cap = cap;
+    const bool new_tile = h->d_tile.p == nullptr;      // (the status block starts from zero: its "seen" words are only ever cleared once consumed)
     bool ok = h->d_Ts.ensure((size_t)nT * 7 * 4) && h->d_time.ensure((size_t)nT * 4) && h->d_tb.ensure((size_t)nT * ns * 256 * 4) &&
               h->d_pose.ensure((size_t)nT * pose_rec_rt(L) * 4) && h->d_qpos.ensure(Nd * 3 * 4) && h->d_cnt.ensure(Nd * ns * 4) &&
               h->d_off.ensure(Nd * ns * 4) && h->d_blk.ensure(((Nd + kNbrBlock - 1) / kNbrBlock) * ns * 4 + 64) && h->d_tile.ensure(64 * 4) && h->d_esrc.ensure((size_t)cap * 4) &&
@@ -404,6 +411,7 @@ int ensure_workspace(dedf_handle* h, int nT) {
         for (int n = 0; n < ns; ++n) words += (size_t)(h->scale_start[n + 1] - h->scale_start[n] + 31) / 32;
         ok = ok && h->d_mask.ensure(words * Nd * 4);
     }
+    if (ok && new_tile) ok = hipMemset(h->d_tile.p, 0, 64 * 4) == hipSuccess;
     if (ok && h->debug) ok = h->d_dbgw.ensure((size_t)cap * WN * 4);
     if (ok && h->cfg.query_time_encoding) ok = h->d_qrows.ensure((size_t)nT * kQueryTimeRow * 4);
     if (!ok) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(workspace) failed");
@@ -497,10 +505,6 @@ void launch_edge(dedf_handle* h, hipStream_t st, const EdgeParams& P) {
         constexpr bool qt_hp = HP && MODE == 0 && L == 2 && F0 == 128 && H1 == 128 && H2 == 64;
         if constexpr (qt || qt_hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, HP, H1, H2, false, MODE, false, true, true>), kAll, st, P);
         return;
-    }
-    if constexpr (MODE == 1 && so2_shape<L, F0, HP, H1, H2, MODE>()) {
-        // destination-major edge list (score_impl: `mixed`): the instantiation whose tiles mix scales
-        if (P.mixed) { DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, HP, H1, H2, false, MODE, false, true, false, true>), kAll, st, P); return; }
     }
     if constexpr (so2_shape<L, F0, HP, H1, H2, MODE>()) {
         if (h->so2 || !general_shape<L, F0, HP, H1, H2, MODE>()) { DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, HP, H1, H2, false, MODE, false, true>), kAll, st, P); return; }
@@ -688,17 +692,6 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     for (int n = 0; n < ns; ++n) np.word_start[n + 1] = np.word_start[n] + (h->scale_start[n + 1] - h->scale_start[n] + 31) / 32;
     np.mask = h->d_mask.as<uint32_t>();
     np.edge_hist = h->profile ? h->d_hist.as<long long>() : nullptr;
-    // The sampler's table-reading edge kernel takes a DESTINATION-major edge list (dedf_misc.h::NbrParams::dst_major): decided here, before the
-    // fill pass is enqueued, from the same host-side facts as `use_tab` below.
-    bool want_tab = false;
-    if constexpr (has_radial_table<L, F0>())
-        want_tab = table_instantiated<L, F0>(h) && h->radial_table != 0 && (EBM || !(time_stride && !h->tb_step)) && !h->debug &&
-                   (Nd >= kRtabMinNodes || h->radial_table == 2 || h->tab_slot >= 0);
-    const bool mixed = want_tab && h->dst_major != 0 && h->so2 && !c.query_time_encoding;      // (the edge-frame table kernels without query time: units 57-60)
-    if (mixed) {
-        if (!h->d_tot.ensure((size_t)2 * Nd * 4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(workspace) failed");
-        np.dst_major = 1; np.cnt_tot = h->d_tot.as<int>(); np.off_tot = h->d_tot.as<int>() + Nd;
-    }
     // small batches: pose preparation + word-parallel masks in one launch, single-workgroup count / scan / fill (dedf_misc.h)
     static const int small_max = [] { const char* e = getenv("DEDF_SMALL_BATCH_MAX"); return e ? atoi(e) : kNbrSmallMax; }();      // (experiments)
     bool small = Nd <= small_max && h->small_batch_path;
@@ -758,10 +751,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
             // (worth its 34 us generator launch from ~6 rounds of edge tiles on: ~20 edges per destination node -> 8 192 nodes)
             const bool async_tab = h->tab_slot >= 0;      // dedf_sample: this step's table was generated on the side stream (ring slot h->tab_slot)
             use_tab = table_instantiated<L, F0>(h) && h->radial_table != 0 && P.tb_pose_stride == 0 && !h->debug && (Nd >= kRtabMinNodes || h->radial_table == 2 || async_tab);
-            if (use_tab != want_tab) return fail(h, DEDF_ERR_RUNTIME, "internal: the edge list was ordered for the other edge kernel");
             if (use_tab) {
-                P.mixed = mixed ? 1 : 0;
-                for (int n = 0; n <= ns; ++n) P.scale_start[n] = h->scale_start[n];
                 int rc = radial_table_setup(h, P);
                 if (rc != DEDF_OK) return rc;
                 if (async_tab) {
@@ -831,10 +821,6 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     }
     mark();
     // 5. joint softmax + aggregation
-    // (destination-major list: a destination's edges over all scales are ONE run -- the merge sees one "scale" with the per-destination totals)
-    if (mixed) hipLaunchKernelGGL(k_aggregate<L>, dim3((Nd + 3) / 4), dim3(256), 0, st, h->d_eout.as<float>(), np.cnt_tot, np.off_tot,
-                                  h->d_tile.as<int>(), Nd, 1, h->d_z.as<float>());
-    else
     hipLaunchKernelGGL(k_aggregate<L>, dim3((Nd + 3) / 4), dim3(256), 0, st, h->d_eout.as<float>(), cnt_used, h->d_off.as<int>(),
                        h->d_tile.as<int>(), Nd, ns, h->d_z.as<float>());
     mark();
@@ -967,7 +953,6 @@ int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, de
     if (const char* e = getenv("DEDF_RTAB_FIN")) h->rtab_fin = std::max(64, atoi(e));
     if (const char* e = getenv("DEDF_RTAB_INF")) h->rtab_inf = std::max(64, atoi(e));
     h->so2 = so2_instantiated(*cfg);
-    if (const char* e = getenv("DEDF_DST_MAJOR")) h->dst_major = atoi(e);
     if (const char* e = getenv("DEDF_SO2")) h->so2 = h->so2 && (atoi(e) != 0 || !general_instantiated(*cfg));      // (A/B where both forms exist)
     const IrrepsRT T(h->L, cfg->unet_layer != 0), K(h->L, true);
     h->spec = build_spec(T, h->cfg);
@@ -1334,6 +1319,7 @@ static int sample_once(dedf_handle* h, int nT, const double* T_seed, const dedf_
     HIPCK(h, hipStreamSynchronize(st));
     h->stats_fresh = sched->n_steps > 0;
     const int flags[2] = {h->h_pin[kFlagOverflow], h->h_pin[kFlagNonFinite]};
+    h->clear_seen = true;      // (the sampler consumes its own verdicts -- an overflow it repeats with more room is not news for the next dedf_score)
     if (flags[0]) { *overflowed = true; return fail(h, DEDF_ERR_RUNTIME, "edge workspace overflow: raise dedf_config.max_edges"); }
     if (flags[1]) return fail(h, DEDF_ERR_RUNTIME, "non-finite score: an activation left the fp16 operand range of the split-fp16 GEMMs "
                                                    "(or the inputs / poses were not finite)");
@@ -1556,6 +1542,7 @@ int dedf_get_stats(dedf_handle* h, dedf_stats* out) {
     if (h->host_only) return fail(h, DEDF_ERR_RUNTIME, "host-only handle");
     memset(out, 0, sizeof(*out));
     h->flags_pending = false;      // the caller reads the verdict himself
+    h->clear_seen = true;
     if (h->last_nT == 0) return DEDF_OK;
     int ti[64];
     const bool fresh = h->stats_fresh && h->h_pin;      // right behind a dedf_sample: its status block is on the host already

@@ -81,12 +81,6 @@ struct EdgeParams {
     // without reading the times back; the one that does not apply returns at once.
     const int* gate;
     int gate_want;
-    // Destination-major edge list (table-reading kernels, MODE 1; dedf_misc.h::NbrParams::dst_major): the list is ordered (dst, scale, src), a tile
-    // mixes scales and its softmax segments run across them.  A lane then takes its scale from its key index (the key clouds are concatenated:
-    // scale_start) and the per-scale constants by lane; a tile that cannot take the radial table (a length beyond it, a scale whose table failed its
-    // accuracy guard) evaluates the per-edge front once per scale PRESENT in it and keeps, per lane, the result of its own scale.
-    int mixed;
-    int scale_start[kMaxScales + 1];
 };
 DEDF_DEV bool edge_gate_closed(const EdgeParams& P) { return P.gate != nullptr && (*P.gate != 0) != (P.gate_want != 0); }
 
@@ -371,13 +365,12 @@ struct GeoPre { int ok, src, dst; float vx, vy, vz; };
 //      is rotated back (Rot<l>::out) before the segmented reduction.  Same result as the general form up to fp32 rounding; needs the image packed
 //      for it (dedf_pack.h::pack_edge<L, true>).
 template <int L> struct Trig { float cg[L], sg[L], cb[L], sb[L]; };
-template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false, int MODE = 0, bool NW = false, bool SO2 = false, bool QT = false, bool MX = false>
+template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false, int MODE = 0, bool NW = false, bool SO2 = false, bool QT = false>
 DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, int n_valid, GeoPre& geo, int e_next DEDF_PROF_ARG) {
     static_assert((H1 == 128 && H2 == 64) || (H1 == 32 && H2 == 32), "radial MLP widths of the shipped configs");
     static_assert(!SO2 || MODE <= 1, "edge-frame form: the per-edge and the table-reading kernels");
     static_assert(!UN || F0 == 64, "UNet layer: the radial MLP reads the 64 radial-basis channels");
     static_assert(MODE == 0 || !UN, "the radial table is the sampler's");
-    static_assert(!MX || MODE == 1, "mixed-scale tiles (destination-major edge list): the table-reading kernel");
     static_assert(!NW || UN, "NW is a UNet-layer shape");
     // activation stage on the registers of a run that hold true channels only (the others are structural zeros and stay 0)
     auto on_live = [&]<int l, int N, class St>(float (&v)[N], St&& st) {
@@ -417,28 +410,20 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     } else if constexpr (MODE < 2) { src = P.edge_src[e]; dst = P.edge_dst[e]; pose = dst / P.nQ; }
     int nsrc = 0, ndst = 0;            // MODE 1: the next tile's indices, requested now
     if constexpr (MODE == 1) { if (e_next >= 0) { nsrc = P.edge_src[e_next]; ndst = P.edge_dst[e_next]; } }
-    // destination-major list (EdgeParams::mixed): this lane's scale from its key index; per-scale constants by lane (select chains: a kernel
-    // argument array indexed by a VGPR would go through scratch)
-    // (MX is a template parameter -- its own instantiations -- so that the scale-major kernels compile to exactly what they were)
-    int ls = scale;
-    if constexpr (MX) { ls = 0; static_for<kMaxScales - 1>([&]<int n>() { if (n + 1 < P.n_scales && src >= P.scale_start[n + 1]) ls = n + 1; }); }
-    auto by_lane = [&](const auto (&a)[kMaxScales]) { auto v = a[0]; static_for<kMaxScales - 1>([&]<int n>() { v = ls > n ? a[n + 1] : v; }); return v; };
-    int fs = scale;                 // the scale whose per-edge front is being evaluated (wave-uniform; == scale unless the list is mixed)
 
     // operands of the edge pre-linear (first K-chunks) and its per-pose bias rows: requested before the geometry / length-encoding
     // VALU work, which hides their latency
     constexpr int NH = F0 / 32;      // pre-linear width: 128 (length + time embedding) or 64 (EBM critic: length only)
     constexpr int NT1 = H1 / 32, NT2 = H2 / 32;
     f32x16 h[NH];
-    int oA_pre = 0, oAl_pre = 0;
+    const int oA_pre = opaque_s(P.o_A_pre + scale * (NH * 4 * 256)), oAl_pre = opaque_s(P.o_A_pre_l + scale * (NH * 4 * 256));
     DenseRing<NH, 2> ring_pre{};
     DenseRing<NT1, 2> ring_r1u{};
     auto front_requests = [&]() {
         if constexpr (!UN) {
-            oA_pre = opaque_s(P.o_A_pre + fs * (NH * 4 * 256)); oAl_pre = opaque_s(P.o_A_pre_l + fs * (NH * 4 * 256));
             const Buf tbb = make_buf(P.tb, P.tb_bytes);
             const int tvoff = (pose * P.tb_pose_stride) * 4 + wv.hi64;
-            static_for<NH>([&]<int To>() { h[To] = ldrows(tbb, tvoff, fs * F0, To); });
+            static_for<NH>([&]<int To>() { h[To] = ldrows(tbb, tvoff, scale * F0, To); });
             ring_pre = dense_prefetch<NH, 4, 2, HP>(wv, oA_pre, oAl_pre);
         } else ring_r1u = dense_prefetch<NT1, 4, 2, HP>(wv, o_A_r1, o_A_r1_l);
     };
@@ -457,11 +442,7 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     }
     const float radius = P.radius[scale];
     float logit0 = 0.0f;
-    if constexpr (MX) {      // per lane: its scale's cut-off (all-pairs scale: no cut-off, radius <= 0)
-        const float rl = by_lane(P.radius), cb = by_lane(P.cut_begin), cd = by_lane(P.cut_div);
-        const float cut = 1.0f - soft_step((len - cb) / (rl > 0.0f ? cd : 1.0f));
-        logit0 = rl > 0.0f ? logf(fmaxf(cut, 1e-12f)) : 0.0f;
-    } else if (!UN && radius > 0.0f) {
+    if (!UN && radius > 0.0f) {
         const float cut = 1.0f - soft_step((len - P.cut_begin[scale]) / P.cut_div[scale]);
         logit0 = logf(fmaxf(cut, 1e-12f));
     }
@@ -525,19 +506,9 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
     bool tab = false;          // wave-uniform: this tile takes the radial network's front from the table
     if constexpr (MODE == 1) {
         DEDF_STAMP(0);
-        float inv_step, tn;
-        int row0;
-        bool accurate;                                    // (wave-uniform; NaN compares false)
-        if constexpr (MX) {
-            inv_step = by_lane(P.rtab_inv_step); tn = (float)by_lane(P.rtab_n); row0 = by_lane(P.rtab_row0);
-            accurate = true;
-            for (int n = 0; n < P.n_scales; ++n) accurate = accurate && __builtin_bit_cast(float, P.rtab_err[n]) <= P.rtab_err_bound[n];
-        } else {
-            inv_step = P.rtab_inv_step[scale]; tn = (float)P.rtab_n[scale]; row0 = P.rtab_row0[scale];
-            accurate = __builtin_bit_cast(float, P.rtab_err[scale]) <= P.rtab_err_bound[scale];
-        }
-        const float pos = len * inv_step;
-        tab = accurate && __all(!valid || pos < tn) != 0;
+        const float pos = len * P.rtab_inv_step[scale];
+        const bool accurate = __builtin_bit_cast(float, P.rtab_err[scale]) <= P.rtab_err_bound[scale];      // (wave-uniform; NaN compares false)
+        tab = accurate && __all(!valid || pos < (float)P.rtab_n[scale]) != 0;
         if (tab) {
             const float ps = valid ? pos : 0.0f;
             const int i0 = (int)ps;
@@ -546,24 +517,22 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
             const float um = u - 1.0f, up = u + 1.0f, u2 = u - 2.0f;
             const float w0 = -(1.0f / 6) * u * um * u2, w1 = 0.5f * up * um * u2, w2 = -0.5f * up * u * u2, w3 = (1.0f / 6) * up * u * um;
             const Buf rtb = make_buf(P.rtab, P.rtab_bytes);
-            const int rv = ((row0 + i0) * 2 + hi) * 128;
+            const int rv = ((P.rtab_row0[scale] + i0) * 2 + hi) * 128;
             // the four rows are only REQUESTED here; they are combined in the prologue of the fused stage, under its operand requests
             static_for<4>([&]<int K>() { static_for<4 * NT2>([&]<int Q>() { trow[K][Q] = bld4(rtb, rv, K * 256 + Q * 16); }); });
             tw[0] = w0; tw[1] = w1; tw[2] = w2; tw[3] = w3;
-        } else if constexpr (!MX) front_requests();
+        } else front_requests();
         DEDF_STAMP(1);
     }
-    // The per-edge front of scale `fs` (-> r2, before layer 2's LayerNorm).  One pass with fs = scale -- except for a tile of the destination-major
-    // list (MX) that cannot take the table: one pass per scale PRESENT in it, every lane keeps the activations of its own scale.
-    auto front_body = [&](const float radius) {
+    if (!tab) {
         // ---- length embedding: this lane's 32 of the 64 channels (k = s + 32*hi) ------------------------------------------
         float eb[32];
         {
-            const f32x4* const enc = reinterpret_cast<const f32x4*>(FRONT ? rows + RL::enc : P.W + P.o_enc + fs * 192);       // this scale's constants (edge_enc_to_lds)
+            const f32x4* const enc = reinterpret_cast<const f32x4*>(FRONT ? rows + RL::enc : P.W + P.o_enc + scale * 192);       // this scale's constants (edge_enc_to_lds)
             if (radius > 0.0f) {           // GaussianRadialBasis, radial_func.py:208-227
                 // UNet layer (GaussianRadialBasisLayerFiniteCutoff, radial_func.py:262-278): t = (len - offset) / (cutoff - offset); the host
                 // passes cutoff - offset as `radius` and the offset as `cut_begin`
-                const float t = UN ? (len - P.cut_begin[fs]) / radius : len / radius;
+                const float t = UN ? (len - P.cut_begin[scale]) / radius : len / radius;
                 static_for<2>([&]<int Hf>() {      // 16 channels at a time, stage by stage (see sigmoid_stage)
                     float z[16], wv16[16];
                     static_for<4>([&]<int G4>() {
@@ -626,21 +595,6 @@ DEDF_DEV void edge_tile(const EdgeParams& P, const Wave& wv, int scale, int e0, 
         static_for<NT2>([&]<int To>() { r2[To] = ldrows_lds(r_b2, hi, 0, To); });
         dense_rot_h<NT2, H1 / 16, 2, HP>(wv, o_A_r2, o_A_r2_l, r2, [&]<int c, int j>() { return r1[c / 2][8 * (c % 2) + j]; }, ring_r2);
         DEDF_STAMP(4);
-    };
-    if constexpr (!MX) { if (!tab) front_body(radius); }
-    else if (!tab) {
-        f32x16 r2keep[NT2];
-        static_for<NT2>([&]<int T>() { static_for<16>([&]<int R>() { r2keep[T][R] = 0.0f; }); });
-        for (fs = 0; fs < P.n_scales; ++fs) {
-            if (__any(valid && ls == fs) == 0) continue;
-            edge_enc_to_lds<L, FRONT>(P, wv, fs);      // (wave-private rows; the table path never reads them)
-            front_requests();
-            front_body(P.radius[fs]);
-            const bool mine = ls == fs;
-            // (values, not lvalues: a ternary on two lvalues selects an ADDRESS and sends both arrays through scratch)
-            static_for<NT2>([&]<int T>() { to_vgpr(r2[T]); static_for<16>([&]<int R>() { const float mn = r2[T][R], kp = r2keep[T][R]; r2keep[T][R] = mine ? mn : kp; }); });
-        }
-        static_for<NT2>([&]<int T>() { r2[T] = r2keep[T]; });
     }
     if constexpr (MODE == 3) {      // accuracy check: exact activations at the interval midpoint against the interpolation of table rows e .. e + 3
         static_for<NT2>([&]<int To>() { to_vgpr(r2[To]); });

@@ -76,12 +76,7 @@
     X(53, void k_edge<2, 128, false, 32, 32, false, 1, false, true, true>(EdgeParams))  \
     X(54, void k_edge<2, 192, false, 128, 64, false, 0, false, true, true>(EdgeParams)) \
     X(55, void k_edge<2, 192, false, 128, 64, false, 1, false, true, true>(EdgeParams)) \
-    X(56, void k_edge<2, 128, true, 128, 64, false, 0, false, true, true>(EdgeParams)) \
-    X(57, void k_edge<2, 128, false, 128, 64, false, 1, false, true, false, true>(EdgeParams)) \
-    X(58, void k_edge<3, 128, false, 128, 64, false, 1, false, true, false, true>(EdgeParams)) \
-    X(59, void k_edge<2, 128, false, 32, 32, false, 1, false, true, false, true>(EdgeParams))  \
-    X(60, void k_edge<2, 192, false, 128, 64, false, 1, false, true, false, true>(EdgeParams))
+    X(56, void k_edge<2, 128, true, 128, 64, false, 0, false, true, true>(EdgeParams))
 // (units 48-55: the score head with query_time_encoding -- trailing `true`: the pose's time row joins the 0e block of the gathered message;
-//  52-55: the two other lmax-2 score-head shapes the reference ships, radial MLP [128,32,32] and the 192-wide pre-linear; 56: half precision;
-//  57-60: the table-reading kernels on the DESTINATION-major edge list of the sampler -- last `true`: tiles mix scales, dedf_edge.h::EdgeParams::mixed)
-constexpr int kKernelUnits = 61;
+//  52-55: the two other lmax-2 score-head shapes the reference ships, radial MLP [128,32,32] and the 192-wide pre-linear; 56: half precision)
+constexpr int kKernelUnits = 57;

@@ -8,7 +8,7 @@
 
 using namespace dedf;
 
-template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false, int MODE = 0, bool NW = false, bool SO2 = false, bool QT = false, bool MX = false> __global__ __launch_bounds__(64, 1) void k_edge(EdgeParams P) {
+template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = false, int MODE = 0, bool NW = false, bool SO2 = false, bool QT = false> __global__ __launch_bounds__(64, 1) void k_edge(EdgeParams P) {
     if (edge_gate_closed(P)) return;
     const int* ti = P.tile_info;
     const int ntiles = ti[P.n_scales];
@@ -37,9 +37,9 @@ template <int L, int F0, bool HP = false, int H1 = 128, int H2 = 64, bool UN = f
             }
         }
 #if defined(DEDF_PHASE_PROF)
-        edge_tile<L, F0, HP, H1, H2, UN, MODE, NW, SO2, QT, MX>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k), geo, e_next, pacc);
+        edge_tile<L, F0, HP, H1, H2, UN, MODE, NW, SO2, QT>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k), geo, e_next, pacc);
 #else
-        edge_tile<L, F0, HP, H1, H2, UN, MODE, NW, SO2, QT, MX>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k), geo, e_next);
+        edge_tile<L, F0, HP, H1, H2, UN, MODE, NW, SO2, QT>(P, wv, scale, ebase + 32 * k, min(32, En - 32 * k), geo, e_next);
 #endif
     }
 #if defined(DEDF_PHASE_PROF)

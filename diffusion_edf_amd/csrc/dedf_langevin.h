@@ -5,7 +5,10 @@
 
 namespace dedf {
 
-constexpr int kFlagOverflow = 41, kFlagNonFinite = 42;      // words of tile_info
+constexpr int kFlagOverflow = 41, kFlagNonFinite = 42;      // words of tile_info: sticky within ONE API call (cleared at its start)
+// ... and the same two verdicts, sticky until the HOST has consumed them (dedf_api.hip::check_pending): a dedf_score / dedf_energy call never
+// synchronises, so in a loop of back-to-back calls the per-call words of an earlier call are cleared before anyone has looked at them
+constexpr int kFlagOverflowSeen = 56, kFlagNonFiniteSeen = 57;
 
 // Sum over the query points of one pose (score_head.py:207-209), fixed order.
 // One wave per pose: lanes stride over the query points, then a fixed butterfly (deterministic, independent of nT).
@@ -17,7 +20,7 @@ __device__ inline bool reduce_status(int* flags, float (&s)[6]) {
     if (ovf) for (int i = 0; i < 6; ++i) s[i] = __builtin_nanf("");
     bool fin = true;
     for (int i = 0; i < 6; ++i) fin = fin && (fabsf(s[i]) <= 3.0e38f);
-    if (!fin && !ovf) flags[kFlagNonFinite] = 1;
+    if (!fin && !ovf) { flags[kFlagNonFinite] = 1; flags[kFlagNonFiniteSeen] = 1; }
     return ovf;
 }
 // ------------------------------------------------------------------------------------------------------------------------

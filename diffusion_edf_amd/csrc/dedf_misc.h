@@ -357,7 +357,7 @@ __global__ void k_keypoint_weight(const float* __restrict__ field, const float* 
 // ------------------------------------------------------------------------------------------------------------------------
 // Radius neighbour search (torch_cluster.radius as used at graph_parser.py:339; all pairs for the infinite scale,
 // graph_parser.py:279-281).  Keys are tiny (<= a few thousand points) and static, queries move every step: brute force with
-// the key cloud streamed through LDS, one thread per destination node.  Edge order: scale, then dst, then src ascending (NbrParams::dst_major: dst, scale, src).
+// the key cloud streamed through LDS, one thread per destination node.  Edge order: scale, then dst, then src ascending.
 //   pass 1 (count):  cnt[n][d], neighbour bit masks and per-block totals;
 //   pass 2 (fill):   block-local exclusive scan of cnt + block offset -> off[n][d], then the edge lists.
 struct NbrParams {
@@ -378,15 +378,8 @@ struct NbrParams {
     int *zero_cnt, *zero_blk;             // small-batch path only: the OTHER parity's count / block-total arrays, cleared by the fill pass for the next step
     uint32_t* mask;                       // [word][n_dst]: neighbour bit masks written by the count pass, 32 keys per word
     int word_start[kMaxScales + 1];       // first mask word of every scale (scale n has ceil(n_keys_n / 32) words)
-    // Destination-major edge list (round 6; the table-reading edge kernel of the sampler): order (dst, scale, src) instead of (scale, dst, src).  All
-    // edges of a destination are then ONE run of the list -- its softmax segments inside a 32-edge tile merge across scales (~1.6 segment records per
-    // destination instead of ~4.6: less record traffic, a shorter k_aggregate) -- and a tile mixes scales (dedf_edge.h: EdgeParams::mixed).
-    // cnt_tot[d] / off_tot[d]: the destination's edge count over all scales and the index of its first edge (what k_aggregate reads, as ONE scale);
-    // off[n][d] then holds the GLOBAL index of the first edge of (d, n).  The tile table says "one scale": every tile prefix = ceil(E / 32).
-    int dst_major;
-    int* cnt_tot; int* off_tot;
 };
-constexpr int kEdgeCountWord = 48;        // tile_info[48 + n]: edges of scale n of the last neighbour search (statistics; valid in both edge orders)
+constexpr int kEdgeCountWord = 48;        // tile_info[48 + n]: edges of scale n of the last neighbour search (statistics)
 constexpr int kNbrChunk = 1024;
 constexpr int kNbrBlock = 256;
 
@@ -407,7 +400,7 @@ __device__ inline int block_exclusive_scan_256(int v, int* total) {
 
 // Count pass: every destination tests every key of every scale (keys staged in LDS as float4: one broadcast ds_read_b128 per
 // key), counts its neighbours and leaves a bit mask of them ([word][dst], coalesced).  Fill pass: walks the set bits only.
-constexpr int kFillStage = 8192;      // edges a block stages in LDS (2 x 32 KB: 32 per destination; C2 has ~23 over all four scales -- the destination-major order stages all scales at once)
+constexpr int kFillStage = 4096;      // edges of one scale a block stages in LDS (2 x 16 KB: 16 per destination; C2 has ~20 over all four scales)
 template <bool FILL>
 __global__ __launch_bounds__(kNbrBlock) void k_neighbors(NbrParams P) {
     __shared__ f32x4 kx[FILL ? 2 * kFillStage / 4 : kNbrChunk];      // count pass: the key chunk; fill pass: the staging run (src | dst)
@@ -445,81 +438,12 @@ __global__ __launch_bounds__(kNbrBlock) void k_neighbors(NbrParams P) {
                 P.tile_info[16 + n + 1] = (int)min(edges, (int64_t)0x7fffffff);
                 P.tile_info[kEdgeCountWord + n] = s_tot[n];
             }
-            if (P.dst_major) {      // one list of mixed-scale tiles: every tile belongs to "scale 0", which holds all the edges
-                const int e_all = (int)min(edges, (int64_t)0x7fffffff);
-                tiles = (int)((edges + 31) / 32);
-                for (int n = 0; n < P.n_scales; ++n) { P.tile_info[n + 1] = tiles; P.tile_info[16 + n + 1] = e_all; }
-            }
             const int ovf = edges > P.cap ? 1 : 0;
             P.tile_info[40] = ovf;
-            if (ovf) P.tile_info[kFlagOverflow] = 1;       // sticky within one dedf_score / dedf_energy / dedf_sample call
+            if (ovf) { P.tile_info[kFlagOverflow] = 1; P.tile_info[kFlagOverflowSeen] = 1; }      // sticky within one API call / until the host has seen it
             if (P.edge_hist) *P.edge_hist += edges;
             if (ovf) for (int n = 0; n <= P.n_scales; ++n) P.tile_info[n] = 0;     // no tiles: downstream kernels do nothing
         }
-    }
-    if (FILL && P.dst_major) {
-        // ---- destination-major fill: the edges of this block's 256 destinations, all scales, are one contiguous run of the list ----------------
-        int cn[kMaxScales];
-        int tot = 0;
-        int64_t pre_all = 0;
-        for (int n = 0; n < P.n_scales; ++n) {
-            cn[n] = act ? P.cnt[(size_t)n * P.n_dst + d] : 0;
-            tot += cn[n];
-            pre_all += s_pre[n];
-            if (P.zero_cnt != nullptr && blockIdx.y == 0) {
-                if (act) P.zero_cnt[(size_t)n * P.n_dst + d] = 0;
-                if (blockIdx.x == 0) for (int i = threadIdx.x; i < (int)gridDim.x; i += kNbrBlock) P.zero_blk[(size_t)n * gridDim.x + i] = 0;
-            }
-        }
-        int total;
-        const int ex = block_exclusive_scan_256(tot, &total);
-        const int64_t base = pre_all + ex;            // first edge of this destination
-        if (act && blockIdx.y == 0) { P.cnt_tot[d] = tot; P.off_tot[d] = (int)min(base, (int64_t)0x7fffffff); }
-        const bool staged = gridDim.y == 1 && total <= kFillStage;
-        int run = 0;                                   // edges of this destination in front of the scale being walked
-        for (int n = 0; n < P.n_scales; ++n) {
-            const int s0 = P.scale_start[n];
-            const int w0 = P.word_start[n], nw = P.word_start[n + 1] - w0;
-            if (act && blockIdx.y == 0) P.off[(size_t)n * P.n_dst + d] = (int)min(base + run, (int64_t)0x7fffffff);
-            if (act) {
-                if (gridDim.y > 1) {      // small batches: the mask words are split over gridDim.y blocks per destination block (see below)
-                    const int nW = P.word_start[P.n_scales];
-                    const int gw0 = (int)((int64_t)blockIdx.y * nW / gridDim.y), gw1 = (int)((int64_t)(blockIdx.y + 1) * nW / gridDim.y);
-                    if (!(w0 >= gw1 || w0 + nw <= gw0)) {
-                        int c = run;
-                        for (int g = 0; g < nw && w0 + g < gw1; ++g) {
-                            uint32_t word = P.mask[(size_t)(w0 + g) * P.n_dst + d];
-                            if (w0 + g < gw0) { c += __builtin_popcount(word); continue; }
-                            while (word) {
-                                const int bit = __builtin_ctz(word);
-                                word &= word - 1;
-                                if (base + c < P.cap) { P.edge_src[base + c] = s0 + 32 * g + bit; P.edge_dst[base + c] = d; }
-                                ++c;
-                            }
-                        }
-                    }
-                } else {
-                    int c = run;
-                    for (int g = 0; g < nw; ++g) {
-                        uint32_t word = P.mask[(size_t)(w0 + g) * P.n_dst + d];
-                        while (word) {
-                            const int bit = __builtin_ctz(word);
-                            word &= word - 1;
-                            if (staged) { st_src[ex + c] = s0 + 32 * g + bit; st_dst[ex + c] = d; }
-                            else if (base + c < P.cap) { P.edge_src[base + c] = s0 + 32 * g + bit; P.edge_dst[base + c] = d; }
-                            ++c;
-                        }
-                    }
-                }
-            }
-            run += cn[n];
-        }
-        if (staged) {      // (wave-uniform over the block: `total` is the same for every thread)
-            __syncthreads();
-            for (int i = threadIdx.x; i < total; i += kNbrBlock)
-                if (pre_all + i < P.cap) { P.edge_src[pre_all + i] = st_src[i]; P.edge_dst[pre_all + i] = st_dst[i]; }
-        }
-        return;
     }
     int64_t scale_base = 0;
     for (int n = 0; n < P.n_scales; ++n) {

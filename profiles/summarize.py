@@ -106,10 +106,17 @@ def main(tag):
                 pass
             if us:
                 gen = sum(summary.get("radial_table_steady_avg_us_in_trace", {}).values()) if table_on else 0.0
-                summary["edge_kernel_frac_executed_flop_from_trace"] = 2.0 * m_edge * edges / ((us + gen) * 1e-6) / (2.5e15 / 3.0)
-                summary["edge_kernel_frac_executed_flop_from_trace_definition"] = ("2 x executed MAC per edge x edges per launch of the traced bench line / (steady-state average "
-                                                                                   "duration of the timed kernel + its table generator) / (2.5 PFLOP/s / 3)")
+                m_alg = {1: 105_536, 2: 193_344, 3: 338_304}[lmax]
+                # roofline.frac of the bench line (round 6: ONE definition, SURVEY 8(d)'s algorithmic constant) recomputed from THIS trace
+                summary["edge_kernel_frac_from_trace"] = 2.0 * m_alg * edges / ((us + gen) * 1e-6) / (2.5e15 / 3.0)
+                summary["edge_kernel_frac_from_trace_definition"] = ("2 x algorithmic MAC per edge (SURVEY 8(d)) x edges per launch of the traced bench line / (average duration of the "
+                                                                     "timed kernel over the timed steps + its table generator) / (2.5 PFLOP/s / 3)")
                 summary["traced_bench_line_frac"] = b["roofline"]["frac"]
+                summary["edge_kernel_frac_round2_4_units_from_trace"] = 2.0 * m_edge * edges / ((us + gen) * 1e-6) / (2.5e15 / 3.0)
+                summary["traced_bench_line_frac_round2_4_units"] = b["roofline"].get("frac_round2_4_units")
+                summary["traced_bench_line_edges_per_step"] = edges
+                summary["traced_bench_line_gemm_mac_per_edge_executed"] = b["roofline"].get("gemm_mac_per_edge_executed")
+                summary["traced_bench_line_frac_gemm_executed"] = b["roofline"].get("frac_gemm_executed")
         except Exception as e:          # noqa: BLE001
             summary["trace_bench_line_error"] = str(e)
     for name, c in pmc.items():
@@ -119,6 +126,12 @@ def main(tag):
                 summary["edge_kernel_mfma_insts_per_launch"] = n_mfma
                 us = summary.get("edge_kernel_steady_avg_us_in_trace") or summary["edge_kernel_avg_us_in_trace"]
                 summary["edge_kernel_frac_mfma_issued"] = n_mfma * 32768.0 / (us * 1e-6) / 2.5e15
+                # MFMAs per edge and the GEMM multiply-adds they amount to (three MFMAs of 32 x 32 x 16 per GEMM term and 32 edges): what
+                # bench.py::edge_frame_gemm_mac() must reproduce.  (Edges: the timed steps of the traced bench line; the counter average is over
+                # ALL launches of the command incl. its warm-up steps, whose edge counts differ by a few per cent.)
+                if summary.get("traced_bench_line_edges_per_step"):
+                    summary["edge_kernel_mfma_per_edge"] = n_mfma / summary["traced_bench_line_edges_per_step"]
+                    summary["edge_kernel_gemm_mac_per_edge_from_counters"] = n_mfma / summary["traced_bench_line_edges_per_step"] / 3.0 * 512.0
     # the four ratios of the issue profile of the timed kernel (round-4 review: computed by hand until now)
     for name, c in pmc.items():
         if timed and name == timed[-1]:

@@ -271,55 +271,6 @@ def test_radial_table_of_the_sampler_against_the_per_edge_evaluation():
                 assert e_on < 1e-4 and e_on < e_off + 5e-6, (t, e_on, e_off)
 
 
-@pytest.mark.parametrize("lmax", [2, 3])
-def test_destination_major_edge_list_of_the_table_path(monkeypatch, lmax):
-    """Round 6: the sampler's table-reading edge kernel works on a DESTINATION-major edge list -- (dst, scale, src) instead of (scale, dst, src),
-    dedf_misc.h::NbrParams::dst_major -- so that a destination's softmax segments merge across scales (the joint softmax of reference
-    graph_attention.py:253-268 is over all scales' edges of a destination anyway).  Checked: the list itself (same edge SET as the scale-major list,
-    sorted by destination, inside a destination by scale and key index; same per-scale counts), one noise-free step against the scale-major run of
-    the same library (DEDF_DST_MAJOR=0: other summation order only, 1e-5 of the displacement) and against the fp64 oracle (1e-4); and the case a mixed
-    tile cannot take the table -- poses far from the scene: all-pairs lengths beyond the table -- where every scale present in the tile is evaluated
-    per edge."""
-    dev = torch.device('cuda:0')
-    radii = (5., 10., 20., None)
-    for far in (False, True):
-        kw, cfg, P, keys, query, Ts, _ = SC.build_case(lmax, 14, 1024, 128, radii=radii)
-        if far:
-            Ts = Ts.clone(); Ts[::3, 4:] += torch.tensor([120.0, 60.0, 40.0], dtype=Ts.dtype)
-        gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
-        gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
-        t, outs, lists, counts = 0.5, {}, {}, {}
-        for dm in (1, 0):
-            monkeypatch.setenv("DEDF_DST_MAJOR", str(dm))          # read by dedf_create
-            head = ScoreModelHead(**kw); head.load_state_dict(P); head.to(dev); head.set_radial_table("always")
-            outs[dm] = ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[t, t]], [1], [0.04], temperatures=0.0).cpu()
-            counts[dm] = head.stats()['n_edges']
-            lists[dm] = (head.debug_buffer("edge_src", torch.int32).long(), head.debug_buffer("edge_dst", torch.int32).long())
-        assert counts[1] == counts[0] and sum(counts[1]) == len(lists[1][0]) == len(lists[0][0]), (counts, len(lists[1][0]))
-        src, dst = lists[1]
-        start = torch.tensor([0] + [len(k.x) for k in keys]).cumsum(0)
-        scale = torch.bucketize(src, start[1:], right=True)
-        key1 = (dst * 16 + scale) * (int(start[-1]) + 1) + src
-        assert bool((key1[1:] > key1[:-1]).all()), "destination-major list: not sorted by (dst, scale, src)"
-        s0, d0 = lists[0]
-        key0 = (d0 * 16 + torch.bucketize(s0, start[1:], right=True)) * (int(start[-1]) + 1) + s0
-        assert torch.equal(key1, key0.sort().values), "the two orders hold different edge sets"
-        assert [int((scale == n).sum()) for n in range(len(keys))] == list(counts[1])
-        d1, d0_ = outs[1][1] - outs[1][0], outs[0][1] - outs[0][0]
-        sq, sx = float(d0_[:, :4].abs().max()), float(d0_[:, 4:].abs().max())
-        dq, dx = float((d1 - d0_)[:, :4].abs().max()) / sq, float((d1 - d0_)[:, 4:].abs().max()) / sx
-        assert max(dq, dx) < 1e-5, (far, dq, dx)
-        ocfg = R.config_from_kwargs(kw)
-        k64 = [R.FeaturedPoints(k.x.double(), k.f.double(), k.b, None) for k in keys]
-        q64 = R.FeaturedPoints(query.x.double(), query.f.double(), query.b, query.w.double())
-        ang, lin = R.score_head_forward(ocfg, R.cast_params(P, torch.float64), Ts, k64, q64, torch.full((len(Ts),), t, dtype=torch.float64))
-        z = torch.zeros(len(Ts), 3, dtype=torch.float64)
-        dr = R.langevin_step(ocfg, Ts, ang, lin, t, 0.04, 0.0, 0.5, 0.5, z, z) - Ts
-        eq, ex = float((d1 - dr)[:, :4].abs().max()) / sq, float((d1 - dr)[:, 4:].abs().max()) / sx
-        print(f"TOLPROBE dst-major lmax {lmax} far {far}: against the scale-major run {max(dq, dx):.2e}, against the fp64 oracle {max(eq, ex):.2e}")
-        assert eq < 1e-4 and ex < 1e-4, (far, eq, ex)
-
-
 @pytest.mark.parametrize("shape", ["time_emb_128", "narrow_radial_mlp"])
 def test_radial_table_other_score_head_shapes(shape):
     """the table path of the two other lmax-2 score-head shapes the reference ships: pre-linear 192 wide (time_emb_mlp [512,256,128], sapien
@@ -1050,6 +1001,24 @@ def test_automatic_edge_workspace_follows_the_scene_density_and_grows_on_overflo
     torch.cuda.synchronize()
     assert torch.isfinite(ang2).all()
     silent.set_query(gq)                                                                                   # nothing pending: no error
+    # back to back, the normal asynchronous loop: a bad call FOLLOWED by a good one before anyone looks -- the good call clears the per-call words, the
+    # verdict of the bad one survives in the words that stay set until the host has consumed them (round 6)
+    loop = _gpu_head(kw, P, dev)
+    T_far = Ts.clone(); T_far[:, 4:] += torch.tensor([60.0, 0.0, 0.0], dtype=Ts.dtype)        # 60 cm from the clump: a handful of grid points in reach, no overflow
+    T_bad, T_ok, t_dev = Ts.to(dev).float(), T_far.to(dev).float(), time.to(dev).float()
+    loop.set_key_clouds(gk); loop.set_query(gq)
+    torch.cuda.synchronize()
+    torch.cuda._sleep(int(4e8))                  # ~0.2 s of stream time in front: both calls below are enqueued before either has run
+    a_bad, _ = loop(T_bad, gk, gq, t_dev)
+    a_ok, _ = loop(T_ok, gk, gq, t_dev)          # (same scene tensors: no set_key_clouds, nothing synchronises, and the first verdict is not in yet)
+    torch.cuda.synchronize()
+    assert torch.isnan(a_bad).all() and torch.isfinite(a_ok).all()
+    with pytest.raises(RuntimeError, match="overflowed its edge workspace"):
+        loop(T_ok, gk, gq, t_dev)
+    a_ok2, _ = loop(T_ok, gk, gq, t_dev)         # (reported once)
+    torch.cuda.synchronize()
+    loop.set_query(gq)
+    assert torch.isfinite(a_ok2).all()
     # a pinned workspace that is too small is reported, never grown (an explicit max_edges is the caller's decision)
     small = _gpu_head(kw, P, dev, max_edges=5000)
     with pytest.raises(RuntimeError, match="overflow"):
