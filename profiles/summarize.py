@@ -129,9 +129,13 @@ def main(tag):
                 # MFMAs per edge and the GEMM multiply-adds they amount to (three MFMAs of 32 x 32 x 16 per GEMM term and 32 edges): what
                 # bench.py::edge_frame_gemm_mac() must reproduce.  (Edges: the timed steps of the traced bench line; the counter average is over
                 # ALL launches of the command incl. its warm-up steps, whose edge counts differ by a few per cent.)
-                if summary.get("traced_bench_line_edges_per_step"):
-                    summary["edge_kernel_mfma_per_edge"] = n_mfma / summary["traced_bench_line_edges_per_step"]
-                    summary["edge_kernel_gemm_mac_per_edge_from_counters"] = n_mfma / summary["traced_bench_line_edges_per_step"] / 3.0 * 512.0
+                if summary.get("traced_bench_line_edges_per_step") and summary.get("edge_kernel_timed_steps_avg_us_in_trace") and summary.get("edge_kernel_steady_avg_us_in_trace"):
+                    # edges per launch averaged over the launches the counters average over (warm-up steps carry more edges than the timed ones): the
+                    # timed steps' edge count scaled by the ratio of the average durations (the kernel's time is proportional to its edges)
+                    e_est = summary["traced_bench_line_edges_per_step"] * summary["edge_kernel_steady_avg_us_in_trace"] / summary["edge_kernel_timed_steps_avg_us_in_trace"]
+                    summary["edge_kernel_edges_per_launch_estimate"] = e_est
+                    summary["edge_kernel_mfma_per_32_edge_tile"] = n_mfma / e_est * 32.0
+                    summary["edge_kernel_gemm_mac_per_edge_from_counters"] = n_mfma / e_est * 32.0 / 3.0 * 512.0      # three MFMAs per GEMM term, 512 MAC per edge and term
     # the four ratios of the issue profile of the timed kernel (round-4 review: computed by hand until now)
     for name, c in pmc.items():
         if timed and name == timed[-1]:
