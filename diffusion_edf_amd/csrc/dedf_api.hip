@@ -251,9 +251,10 @@ int check_config(const dedf_config* c, std::string& why) {
     if (c->query_time_encoding) {
         const bool ok2 = c->lmax == 2 && ((c->fc_neurons[0] == 128 && (mlp_wide || mlp_narrow)) || (c->fc_neurons[0] == 192 && mlp_wide));
         const bool ok3 = c->lmax == 3 && c->fc_neurons[0] == 128 && mlp_wide;
+        const bool ok1 = c->lmax == 1 && c->fc_neurons[0] == 128 && mlp_wide;
         const bool okh = !c->half_gemm || (c->lmax == 2 && c->fc_neurons[0] == 128 && mlp_wide);
-        if (c->ebm || !(ok2 || ok3) || !okh) {
-            why = "query_time_encoding is instantiated for the score head: lmax 2 with fc_neurons [128,128,64] (also in half precision) / [128,32,32] / [192,128,64], lmax 3 with [128,128,64]"; return DEDF_ERR_UNSUPPORTED; }
+        if (c->ebm || !(ok1 || ok2 || ok3) || !okh) {
+            why = "query_time_encoding is instantiated for the score head: lmax 2 with fc_neurons [128,128,64] (also in half precision) / [128,32,32] / [192,128,64], lmax 1 and 3 with [128,128,64]"; return DEDF_ERR_UNSUPPORTED; }
     }
     if (c->n_scales < 1 || c->n_scales > kMaxScales) { why = "n_scales out of range"; return DEDF_ERR_INVALID; }
     bool inf = false;
@@ -500,7 +501,7 @@ template <int L, int F0, bool HP, int H1, int H2, int MODE>
 void launch_edge(dedf_handle* h, hipStream_t st, const EdgeParams& P) {
     constexpr int kAll = 1 << 30;
     if (h->cfg.query_time_encoding) {      // (validate_config admits only these shapes)
-        constexpr bool qt = !HP && MODE <= 1 && (((L == 2 || L == 3) && F0 == 128 && H1 == 128 && H2 == 64) || (L == 2 && F0 == 128 && H1 == 32 && H2 == 32) ||
+        constexpr bool qt = !HP && MODE <= 1 && (((L == 2 || L == 3 || (L == 1 && MODE == 0)) && F0 == 128 && H1 == 128 && H2 == 64) || (L == 2 && F0 == 128 && H1 == 32 && H2 == 32) ||
                                                  (L == 2 && F0 == 192 && H1 == 128 && H2 == 64));
         constexpr bool qt_hp = HP && MODE == 0 && L == 2 && F0 == 128 && H1 == 128 && H2 == 64;
         if constexpr (qt || qt_hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, HP, H1, H2, false, MODE, false, true, true>), kAll, st, P);

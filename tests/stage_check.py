@@ -174,6 +174,7 @@ def stage_report_case(kw, cfg, P, keys, query, Ts, time, verbose=True, half=Fals
         for l, m in enumerate(muls):
             nn = m * (2 * l + 1)
             rep[f'{nm}_l{l}'] = rel(g[:, off:off + nn], d64[nm][:, off:off + nn])
+            rep[f'o32_{nm}_l{l}'] = rel(d32[nm][:, off:off + nn], d64[nm][:, off:off + nn])      # the fp32 restatement's own distance (diagnostic)
             off += nn
     no = head.debug_buffer('node_out').reshape(nT, nQ, 8)
     w = query.w.double()

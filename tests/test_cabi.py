@@ -65,13 +65,14 @@ def test_unsupported_configs_are_rejected(built_lib):
     kw['key_tensor_field_kwargs']['fc_neurons'] = [64, 128, 64]
     with pytest.raises(NotImplementedError):
         params.HeadConfig.from_kwargs(kw)
-    for bad in (dict(lmax=1), dict(lmax=3, half_gemm=1), dict(lmax=3, fc=(128, 32, 32))):       # query_time_encoding: lmax 2 / 3; lmax 3 with [128,128,64], full precision only
+    for bad in (dict(lmax=1, half_gemm=1), dict(lmax=1, fc=(128, 32, 32)), dict(lmax=3, half_gemm=1), dict(lmax=3, fc=(128, 32, 32))):       # query_time_encoding at lmax 1 / 3: [128,128,64], full precision only
         cfg = params.HeadConfig.from_kwargs(synthetic.score_head_kwargs(bad.get('lmax', 2), query_time_encoding=True))
         cc = _lib.make_config(cfg, -1)
         cc.half_gemm = bad.get('half_gemm', 0)
         for i, v in enumerate(bad.get('fc', (128, 128, 64))):
             cc.fc_neurons[i] = v
         assert built_lib.dedf_param_count(C.byref(cc)) == -1, bad
+    assert built_lib.dedf_param_count(C.byref(_lib.make_config(params.HeadConfig.from_kwargs(synthetic.score_head_kwargs(1, query_time_encoding=True)), -1))) > 0      # lmax 1: round 6
     kw = synthetic.score_head_kwargs(2, query_time_encoding=True)          # ... and the two other lmax-2 shapes the reference ships are instantiated
     kw['key_tensor_field_kwargs']['fc_neurons'] = [-1, 32, 32]
     assert built_lib.dedf_param_count(C.byref(_lib.make_config(params.HeadConfig.from_kwargs(kw), -1))) > 0
