@@ -104,7 +104,7 @@ typedef struct dedf_config {
                                             message, linear_src has no bias, and its projection skip_1 joins the attention output before post_norm.  The
                                             parameter list gains query_time_mlp.*, ...prenorm_dst.*, ...linear_dst.*, ...skip_1.skip.* and loses
                                             ...linear_src.bias.0.  Together with edge time encoding (fc_neurons[0] = 64 + time_emb_mlp[2]); instantiated
-                                            for lmax 2 with fc_neurons {128,128,64} (half_gemm too) / {128,32,32} / {192,128,64} and lmax 3 with {128,128,64}.
+                                            for lmax 2 with fc_neurons {128,128,64} (half_gemm too) / {128,32,32} / {192,128,64} and lmax 1 / 3 with {128,128,64}.
                                             0: default (every shipped config) */
 } dedf_config;
 
