@@ -967,6 +967,28 @@ int dedf_create(const dedf_config* cfg, const float* params, size_t n_params, de
         return DEDF_ERR_INVALID;
     }
     h->params.assign(params, params + n_params);
+    if (cfg->unet_layer && h->L == 3) {
+        // The lmax-3 layer kernels skip the lane-local work on the channels p with p % 4 >= q of the 16x3e block (q = 2; 1 for the narrow
+        // instantiations, unet_narrow) -- include/dedf.h.  A blob whose true 3e channels sit anywhere else gives silently wrong
+        // features: refuse it.  Checked on the tensors whose l = 3 block is addressable by name -- the three 16 x 16 LinearRS blocks and the
+        // post-norm's per-channel weights; unet_pad.py::place puts every tensor's channels at the same positions.
+        const int q = cfg->unet_narrow ? 1 : 2;      // (what the instantiation that will run skips: dedf_net.h::pad_reg)
+        auto live = [&](int p) { return p % 4 < q; };
+        const char* bad = nullptr;
+        for (const char* nm : {"gnn.linear_src.tp.weight", "gnn.linear_dst.tp.weight", "gnn.ga.proj.tp.weight"}) {
+            const float* w = h->spec.get(params, nm) + (64 * 64 + 32 * 32 + 16 * 16);
+            for (int u = 0; u < 16 && !bad; ++u) for (int v = 0; v < 16; ++v) if (!(live(u) && live(v)) && w[u * 16 + v] != 0.0f) { bad = nm; break; }
+        }
+        {
+            const float* a = h->spec.get(params, "gnn.norm_2.affine_weight") + (64 + 32 + 16);
+            for (int p = 0; p < 16 && !bad; ++p) if (!live(p) && a[p] != 0.0f) bad = "gnn.norm_2.affine_weight";
+        }
+        if (bad) {
+            fprintf(stderr, "dedf_create: UNet layer at lmax 3: %s is non-zero on a channel p with p %% 4 >= %d of the 16x3e block -- the true 3e channels must sit at the "
+                            "positions of diffusion_edf_amd/unet_pad.py::place (8x3e: 0, 1, 4, 5, 8, 9, 12, 13; 4x3e: 0, 4, 8, 12), the kernels skip the others\n", bad, q);
+            return DEDF_ERR_INVALID;
+        }
+    }
     try {
         h->kparams = pad_params(h->cfg, T, h->spec, K, h->kspec, h->params.data());
         if (h->L == 1) pack_all<1>(h.get()); else if (h->L == 2) pack_all<2>(h.get()); else pack_all<3>(h.get());

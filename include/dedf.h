@@ -97,7 +97,9 @@ typedef struct dedf_config {
                                             Requires unet_valid = {32, 16, 8 (, 4)}.  0: any zero-padded embedding whose padded channels are exact zeros (the
                                             padding is computed like data) -- EXCEPT the l = 3 block of an lmax-3 layer: every lmax-3 kernel skips the channels
                                             p with p % 4 >= 2 of the 16x3e block, so the (at most 8) true 3e channels MUST sit at the positions of
-                                            unet_pad.py::place (8x3e: 0, 1, 4, 5, 8, 9, 12, 13; 4x3e: 0, 4, 8, 12) whatever this flag says */
+                                            unet_pad.py::place (8x3e: 0, 1, 4, 5, 8, 9, 12, 13; 4x3e: 0, 4, 8, 12) whatever this flag says.  dedf_create checks it (round 6) on the
+                                            tensors whose l = 3 block is addressable by name -- linear_src / linear_dst / proj, norm_2 -- and returns
+                                            DEDF_ERR_INVALID for a blob with a non-zero weight on a skipped channel */
     int query_time_encoding;             /* 1: ScoreModelHead(query_time_encoding=True) (score_head.py:64-70, 168-173): the query points carry
                                             query_time_mlp(time) -- time_emb_mlp[2] scalars -- as the DESTINATION feature of the key field's block
                                             (use_dst_feature, gnn_block.py:109-130, 170-180, 205-206): LayerNorm + LinearRS(bias) of it joins every edge's

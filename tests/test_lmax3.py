@@ -121,6 +121,41 @@ def test_lmax3_layer_equals_its_zero_padded_kernel_shape_embedding(muls, muls_sr
     assert wide.shape[1] == 352 and float(wide[:, ~mask_true].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("muls,muls_src,fc", [([64, 32, 16, 8], [64, 32, 16, 8], [64, 32, 32]), ([32, 16, 8, 4], [32, 16, 8, 4], [32, 16, 16]),
+                                               ([64, 32, 16, 8], [32, 16, 8, 4], [64, 32, 32]), ([32, 16, 8, 4], [64, 32, 16, 8], [64, 32, 32])])
+def test_lmax3_layer_blob_with_misplaced_3e_channels_is_refused(built_lib, muls, muls_src, fc):
+    """the lmax-3 layer kernels skip the channels p with p % 4 >= 2 (narrow instantiations: >= 1) of the 16x3e block, so a C-ABI
+    caller that zero-pads 8x3e differently from unet_pad.place would get silently wrong features.  dedf_create checks the placement on the tensors
+    whose l = 3 block is addressable by name: the blobs unet_pad builds are accepted (wide, narrow and both mixed layers), the same blob with a true
+    3e channel moved to a skipped position is DEDF_ERR_INVALID."""
+    from diffusion_edf_amd import unet_pad as UP
+    irr, irr_s = [(m, l) for l, m in enumerate(muls)], [(m, l) for l, m in enumerate(muls_src)]
+    P = params.init_from_spec(params.unet_layer_param_spec(irr, fc, irreps_src=irr_s), seed=9, randomize_all=True)
+    Q = UP.expand_layer_params(P, muls, fc, muls_src)
+    nw = list(muls) == list(muls_src) == list(UP.NARROW3)
+    cc = _lib.make_unet_layer_config(9.0, -1, UP.WIDE_FC, tuple(UP.WIDE3), 4, valid=tuple(muls), fc_valid=tuple(fc) if list(fc) != list(UP.WIDE_FC) else None, narrow=nw)
+    def create(state):
+        blob = _lib.pack_params(cc, state)
+        h = C.c_void_p()
+        rc = built_lib.dedf_create(C.byref(cc), blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, C.byref(h))
+        if rc == _lib.OK:
+            built_lib.dedf_destroy(h)
+        return rc
+    assert create(Q) == _lib.OK
+    for name in ("gnn.linear_src.tp.weight", "gnn.ga.proj.tp.weight", "gnn.norm_2.affine_weight"):
+        bad = {k: v.clone() for k, v in Q.items()}
+        w = bad[name].reshape(-1)
+        if name.endswith("affine_weight"):
+            blk = w[64 + 32 + 16:]                       # the 16 per-channel weights of the 3e block
+            assert float(blk[0]) != 0.0 and float(blk[3]) == 0.0
+            blk[3] = blk[0]; blk[0] = 0.0                # channel 0 -> position 3 (p % 4 = 3: skipped by every lmax-3 kernel)
+        else:
+            blk = w[64 * 64 + 32 * 32 + 16 * 16:].reshape(16, 16)       # [in channel][out channel] of the l = 3 block
+            assert float(blk[0].abs().max()) > 0.0 and float(blk[:, 3].abs().max()) == 0.0
+            blk[:, 3] = blk[:, 0]; blk[:, 0] = 0.0       # output channel 0 -> position 3
+        assert create(bad) == _lib.ERR_INVALID, name
+
+
 # ---- GPU: score head ------------------------------------------------------------------------------------------------------------------
 
 def _gpu_head(kw, P, dev, cls=None):
