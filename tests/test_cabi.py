@@ -145,3 +145,14 @@ def test_packed_radial_layer_replays_as_dense_linear(built_lib):
                     k = 32 * (c // 2) + _rowmap(8 * (c % 2) + j, lane >> 5)
                     got[32 * To + (lane & 31)] += (hi[To, c, lane, j] + lo[To, c, lane, j]) * x[k]
     assert np.abs(got - W @ x).max() < 1e-5
+
+
+def test_shipped_library_is_built_from_these_sources(built_lib):
+    """libdedf.so travels to the GPU box as a binary (its objects do not): build() writes the signature of ALL its sources beside it and loads a
+    library only when the signature matches -- so must the one these tests just loaded"""
+    import os
+    import __graft_entry__ as G
+    sig = os.path.join(G.CSRC, "libdedf.so.sig")
+    assert os.path.exists(sig), "build() writes libdedf.so.sig"
+    assert open(sig).read() == G.library_signature()
+
