@@ -281,10 +281,10 @@ def _sched_piece(piece: list, gap: float, stats: dict) -> list:
     if not any(x.kind == "mfma" for x in piece):
         return piece
     res = schedule_block(piece, gap)
-    res = pad_hazards(res, stats)
     stats["blocks"] += 1
     stats["mfma"] += sum(1 for x in piece if x.kind == "mfma")
-    stats["moved"] += sum(1 for a, b in zip(piece, [r for r in res if r.line != "" or True]) if a is not b and a.kind == "mfma")
+    stats["moved"] += sum(1 for a, b in zip(piece, res) if a is not b and a.kind == "mfma")      # (before the pads are inserted: same length)
+    res = pad_hazards(res, stats)
     b, sb = model_cycles(piece)
     a, sa = model_cycles(res)
     stats["model_before"] += b
