@@ -153,7 +153,10 @@ __global__ __launch_bounds__(BLOCK) void k_fps(const float* __restrict__ x, int 
 // Measured (tests/probe/fps_bucket_probe.hip, synthetic scene, ratio 0.2): 16 384 points 6.4 -> 4.2 ms (set-up 0.09 ms; late in the run 5 of
 // the 128 buckets are active per sample and a sample costs 1.2 us: 0.4 us test + exchange, 0.1 us the wave's best bucket, the rest the
 // active buckets of the busiest wave at ~0.3 us each -- a serial chain of ~70 dependent instructions per bucket on a lone wave).  At 8 000
-// points it ties with the exhaustive kernel (1.97 against 2.05 ms), at 4 096 it loses (1.03 against 0.88 ms): dedf_fps uses it above 8 192.
+// points it ties with the exhaustive kernel (1.97 against 2.05 ms), at 4 096 it loses (1.03 against 0.88 ms).
+// BATCH = true (round 6, what dedf_fps launches): the ~1 us round trip through the workgroup is paid once per BATCH of up to 64 samples
+// instead of once per sample -- see "batches" inside.  16 384 points: 4.2 -> 1.7 ms (8 waves), 8 192: 2.1 -> 0.87, 3 277: 0.61 -> 0.36 ms,
+// ahead of the exhaustive kernel from ~1 100 points on (profiles/r06p_fps_*.log); still bit-identical to the exhaustive arg-max.
 __device__ __forceinline__ float wave_max_f32(float v) {
     auto step = [&]<int CTRL, int ROW_MASK>() {
         const int b = __float_as_int(v);
@@ -210,17 +213,29 @@ __device__ __forceinline__ unsigned morton5(unsigned v) {      // 5 bits -> ever
     return v;
 }
 
-#ifndef DEDF_FPS_TIE_BALLOT
-#define DEDF_FPS_TIE_BALLOT 0      // (measured, round 4: the index of a unique maximum by one v_readlane instead of the second reduction -- 4.196 against 4.20 ms at 16 384 points, bit-exact, no gain: profiles/r04r_fps_time.log)
-#endif
 constexpr int kFpsBucketBlock = 256;
-template <int PPT>      // points per thread: the cloud has at most 256 * PPT points (PPT = 16, 32, 64)
-__global__ __launch_bounds__(kFpsBucketBlock) void k_fps_bucketed(const float* __restrict__ x, int n, int n_samples, int start, int* __restrict__ idx_out) {
+// the better of the exchange slots [LO, LO + N): larger minimum, then smaller original index (straight-line selects)
+struct FpsSlot { float4 e; int i; };
+template <int LO, int N, int NW> __device__ __forceinline__ FpsSlot fps_knock_out(const float4 (&e)[NW], const int (&ei)[NW]) {
+    if constexpr (N == 1) return FpsSlot{e[LO], ei[LO]};
+    else {
+        const FpsSlot a = fps_knock_out<LO, N / 2, NW>(e, ei), b = fps_knock_out<LO + N / 2, N / 2, NW>(e, ei);
+        const int am = __float_as_int(a.e.x), bm = __float_as_int(b.e.x);
+        const bool sb = bm > am || (bm == am && b.i < a.i);
+        return FpsSlot{float4{sb ? b.e.x : a.e.x, sb ? b.e.y : a.e.y, sb ? b.e.z : a.e.z, sb ? b.e.w : a.e.w}, sb ? b.i : a.i};
+    }
+}
+constexpr int kFpsBatchStart = 32;         // samples taken one by one before the first batch (early samples lower every running minimum)
+constexpr int kFpsCandPerLane = 4;          // candidate list of a batch: 64 lanes x this many points
+constexpr int kFpsBatchedFrom = 1024;       // dedf_fps: clouds above this many points take the bucketed + batched kernel (measured, tests/probe/fps_time.py: 0.167 against 0.227 ms at 1 100 points, a tie at 656)
+template <int PPT, int BLOCK = kFpsBucketBlock, bool BATCH = false>      // points per thread: the cloud has at most BLOCK * PPT points
+__global__ __launch_bounds__(BLOCK) void k_fps_bucketed(const float* __restrict__ x, int n, int n_samples, int start, int* __restrict__ idx_out) {
 #pragma clang fp contract(off)
-    constexpr int BLOCK = kFpsBucketBlock, NW = BLOCK / 64, NP = PPT / 2, NPAD = BLOCK * PPT;
+    constexpr int NW = BLOCK / 64, NP = PPT / 2, NPAD = BLOCK * PPT;
     static_assert(NP <= 32 && NPAD <= 16384, "bucket masks are 32 bits wide; original indices are kept in 16 bits");
     constexpr int kBins = 32768;
-    __shared__ unsigned s_hist[kBins / 2];                  // set-up only: cell counters / offsets, two 16-bit halves per word
+    __shared__ __align__(16) unsigned s_hist[kBins / 2];    // set-up: cell counters / offsets, two 16-bit halves per word; afterwards the candidate list of a batch
+    __shared__ int s_cnt[4];                                // candidate counters, one per collection attempt (rotating)
     __shared__ unsigned short s_perm[NPAD];                 // set-up only: original index of sorted position p
     __shared__ unsigned s_part[BLOCK];
     __shared__ float4 s_cand[NW][NP];                       // per bucket: coordinates (+ original index) of the point with the largest minimum
@@ -240,6 +255,7 @@ __global__ __launch_bounds__(kFpsBucketBlock) void k_fps_bucketed(const float* _
         if (lane == 0) { s_box[0][wave][k] = lo[k]; s_box[1][wave][k] = hi[k]; }
     }
     for (int i = tid; i < kBins / 2; i += BLOCK) s_hist[i] = 0u;
+    if (tid < 4) s_cnt[tid] = 0;
     __syncthreads();
     float qs[3];
     for (int k = 0; k < 3; ++k) {
@@ -296,6 +312,8 @@ __global__ __launch_bounds__(kFpsBucketBlock) void k_fps_bucketed(const float* _
         px[j] = fps_f2{x[3 * i0], x[3 * i1]}; py[j] = fps_f2{x[3 * i0 + 1], x[3 * i1 + 1]}; pz[j] = fps_f2{x[3 * i0 + 2], x[3 * i1 + 2]};
         md[j] = fps_f2{v0 ? INFINITY : -1.0f, v1 ? INFINITY : -1.0f};
         pidx[j] = (unsigned)i0 | ((unsigned)i1 << 16);
+        // (opaque: the pairs are what stays in registers -- otherwise hipcc also keeps the loaded (x, y, z) triples alive for every scalar use)
+        asm volatile("" : "+v"(px[j]), "+v"(py[j]), "+v"(pz[j]));
     }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
@@ -316,33 +334,189 @@ __global__ __launch_bounds__(kFpsBucketBlock) void k_fps_bucketed(const float* _
     // the wave's best bucket, kept while no bucket of the wave changes
     int wmd = __float_as_int(-1.0f), widx = 0x7fffffff;
     float wx = 0.0f, wy = 0.0f, wz = 0.0f;
-    for (int s = 0; s < n_samples; ++s) {
+    // BATCH (round 6): see "batches" below; these are wave-uniform
+    [[maybe_unused]] int curm = __float_as_int(INFINITY);            // bits of the running minimum of `cur` (the largest one)
+    [[maybe_unused]] int single_until = BATCH ? min(n_samples, kFpsBatchStart) : n_samples, flushed = 0, attempt = 0, it = 0;
+    [[maybe_unused]] float frac = 0.9f;
+    for (int s = 0; s < n_samples;) {
+        int n_adv = 1;                                      // samples this iteration settles
+        bool single = true;
+        if constexpr (BATCH) {
+            // ---- batches -------------------------------------------------------------------------------------------------------------------
+            // Once a few dozen samples exist the running minima form a plateau: many points within a few per cent of the largest one, far
+            // apart from each other.  Let tau <= the largest minimum and C = {points whose minimum is >= tau}.  Every other point is below tau
+            // and can only fall, so AS LONG AS the best point of C (minima of C kept exact against the samples drawn meanwhile) is >= tau, it is
+            // the next sample of the exhaustive algorithm -- found by ONE wave inside its registers (<= 256 candidates, 4 per lane), no barrier,
+            // no LDS: ~0.2 us per sample against ~1.2 us for a sample that goes round the workgroup.  The samples of a batch (<= 64: lane i keeps
+            // sample i) are then applied to the buckets in one pass (a bucket is touched once per BATCH: one pair of reductions for all its
+            // hits), the bucket maxima are exact again and the exchange below names the first sample of the next batch.  Every wave runs the
+            // same batch redundantly (same instructions, same data: same result), so nothing has to be broadcast.
+            // tau = frac * largest minimum; frac rises when the candidates overflow the list and falls when a batch ends because the list ran dry.
+            single = s < single_until;
+            constexpr int C = kFpsCandPerLane, CAP = 64 * C;
+            // (component by component: a float4 per candidate would make hipcc keep a second, (x, y, z, -)-shaped copy of every point in registers)
+            float* const s_cx = reinterpret_cast<float*>(s_hist), * const s_cy = s_cx + CAP, * const s_cz = s_cy + CAP, * const s_cm = s_cz + CAP;
+            int* const s_ci = reinterpret_cast<int*>(s_cm + CAP);
+            float tau = 0.0f;
+            int cnt = 0;
+            if (!single) {
+                bool ok = false;
+                const float M = __int_as_float(__builtin_amdgcn_readfirstlane(curm));        // (read from LDS: uniform, but not to the compiler)
+                for (int t = 0; t < 3 && !ok; ++t) {
+                    tau = M * frac;
+                    if (!(tau > 0.0f) || !(tau < INFINITY)) break;
+                    int* const c_now = &s_cnt[attempt & 3];
+                    if (tid == 0) s_cnt[(attempt + 2) & 3] = 0;          // (last read two barriers ago)
+                    ++attempt;
+                    int nw = 0;
+#pragma unroll
+                    for (int j = 0; j < NP; ++j)
+                        nw += __builtin_popcountll(__ballot(md[j].x >= tau)) + __builtin_popcountll(__ballot(md[j].y >= tau));
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(c_now, nw);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base + nw <= CAP) {
+#pragma unroll
+                        for (int j = 0; j < NP; ++j) {
+                            const bool c0 = md[j].x >= tau, c1 = md[j].y >= tau;
+                            const unsigned long long b0 = __ballot(c0), b1 = __ballot(c1);
+                            if (b0 | b1) {
+                                const int n0 = __builtin_popcountll(b0);
+                                const int p0 = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b0, 0u));
+                                const int p1 = base + n0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0u));
+                                unsigned pj = pidx[j];
+                                asm volatile("" : "+v"(pj));          // (else the 2 x NP unpacked indices are hoisted out of the sample loop into registers)
+                                if (c0) { s_cx[p0] = px[j].x; s_cy[p0] = py[j].x; s_cz[p0] = pz[j].x; s_cm[p0] = md[j].x; s_ci[p0] = (int)(pj & 0xffffu); }
+                                if (c1) { s_cx[p1] = px[j].y; s_cy[p1] = py[j].y; s_cz[p1] = pz[j].y; s_cm[p1] = md[j].y; s_ci[p1] = (int)(pj >> 16); }
+                                base += n0 + __builtin_popcountll(b1);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    cnt = __builtin_amdgcn_readfirstlane(*c_now);
+                    if (cnt <= CAP) ok = true;
+                    else frac = 0.5f * (1.0f + frac);
+                }
+                if (!ok) { single_until = min(n_samples, s + 4); single = true; }          // (ties / duplicates / the first samples: one by one for a while)
+            }
+            if (!single) {
+                if (flushed < s) {                              // samples still waiting in the ring
+                    if (flushed + tid < s) idx_out[flushed + tid] = s_out[0][(flushed + tid) & (BLOCK - 1)];
+                }
+                // the candidates, C per lane as C / 2 pairs (minimum -1: none)
+                static_assert(C % 2 == 0, "candidates are processed in pairs");
+                fps_f2 qx[C / 2], qy[C / 2], qz[C / 2], qm[C / 2];
+                int qi[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const int k = lane + 64 * c;
+                    const bool valid = k < cnt;
+                    const int kk = valid ? k : 0;
+                    const float vx = s_cx[kk], vy = s_cy[kk], vz = s_cz[kk], vm = valid ? s_cm[kk] : -1.0f;
+                    if (c & 1) { qx[c / 2].y = vx; qy[c / 2].y = vy; qz[c / 2].y = vz; qm[c / 2].y = vm; }
+                    else { qx[c / 2].x = vx; qy[c / 2].x = vy; qz[c / 2].x = vz; qm[c / 2].x = vm; }
+                    qi[c] = valid ? s_ci[kk] : 0x7fffffff;
+                }
+                const int m_max = min(64, n_samples - s), tau_bits = __builtin_amdgcn_readfirstlane(__float_as_int(tau));
+                float sx = 0.0f, sy = 0.0f, sz = 0.0f;          // lane i: sample i of the batch
+                int si = 0;
+                int m = 0;
+                bool dry = false;
+                for (; m < m_max; ++m) {
+                    // the lane's best candidate (larger minimum, then smaller index; minima are >= 0 or -1: they order like their bits)
+                    int bm = __float_as_int(qm[0].x), bi = qi[0];
+                    float bx = qx[0].x, by = qy[0].x, bz = qz[0].x;
+#pragma unroll
+                    for (int c = 1; c < C; ++c) {
+                        const int cm = __float_as_int((c & 1) ? qm[c / 2].y : qm[c / 2].x);
+                        const bool t = (cm > bm) | ((cm == bm) & (qi[c] < bi));          // (no short circuit: that would be branches)
+                        bm = t ? cm : bm; bi = t ? qi[c] : bi;
+                        bx = t ? ((c & 1) ? qx[c / 2].y : qx[c / 2].x) : bx; by = t ? ((c & 1) ? qy[c / 2].y : qy[c / 2].x) : by;
+                        bz = t ? ((c & 1) ? qz[c / 2].y : qz[c / 2].x) : bz;
+                    }
+                    const int wmi = wave_max_i32(bm);
+                    if (wmi < tau_bits) { dry = true; break; }
+                    // the lane that holds it: one lane unless two candidates tie exactly (then the smaller index, by a second reduction)
+                    const unsigned long long tied = __ballot(bm == wmi);
+                    int wl = __builtin_ctzll(tied);
+                    if (__builtin_expect((tied & (tied - 1ull)) != 0ull, 0)) {
+                        const int wi = wave_min_i32_dpp(bm == wmi ? bi : 0x7fffffff);
+                        wl = __builtin_ctzll(__ballot(bm == wmi && bi == wi));
+                    }
+                    const int win = __builtin_amdgcn_readlane(bi, wl);
+                    const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx), wl)),
+                                oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(by), wl)),
+                                oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bz), wl));
+                    if (lane == m) { sx = ox; sy = oy; sz = oz; si = win; }
+                    const fps_f2 c_x = fps_f2{ox, ox}, c_y = fps_f2{oy, oy}, c_z = fps_f2{oz, oz};
+#pragma unroll
+                    for (int c = 0; c < C / 2; ++c) {
+                        const fps_f2 dx = qx[c] - c_x, dy = qy[c] - c_y, dz = qz[c] - c_z;
+                        const fps_f2 d2 = (dx * dx + dy * dy) + dz * dz;
+                        // (minimum of the bit patterns: both are >= 0 or the padding value -1, which stays)
+                        qm[c].x = __int_as_float(min(__float_as_int(qm[c].x), __float_as_int(d2.x)));
+                        qm[c].y = __int_as_float(min(__float_as_int(qm[c].y), __float_as_int(d2.y)));
+                    }
+                }
+                if (dry && m < 48) frac = fmaxf(0.3f, frac * 0.95f);
+                if (m == 0) single_until = min(n_samples, s + 4);          // (cannot happen: `cur` is a candidate; never spin)
+                if (lane < m) s_out[wave][(s + lane) & (BLOCK - 1)] = si;
+                if (wave == 0 && lane < m) idx_out[s + lane] = si;
+                flushed = s + m;
+                n_adv = m;
+                // the batch against the buckets: slot by slot, lane i tests sample i against the slot's box
+#pragma unroll
+                for (int J = 0; J < NP; ++J) {
+                    auto at = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), J)); };
+                    const float l0 = at(blo[0]), l1 = at(blo[1]), l2 = at(blo[2]), h0 = at(bhi[0]), h1 = at(bhi[1]), h2 = at(bhi[2]), bmJ = at(bmax);
+                    const float ddx = fmaxf(fmaxf(l0 - sx, sx - h0), 0.0f), ddy = fmaxf(fmaxf(l1 - sy, sy - h1), 0.0f), ddz = fmaxf(fmaxf(l2 - sz, sz - h2), 0.0f);
+                    const float lb2 = ((ddx * ddx + ddy * ddy) + ddz * ddz) * (1.0f - 4e-6f);
+                    unsigned long long hit = __ballot(lane < m && !(lb2 >= bmJ));
+                    if (hit) {
+                        fps_f2 mm = md[J];
+                        do {
+                            const int i = __builtin_ctzll(hit);
+                            hit &= hit - 1ull;
+                            const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sx), i)),
+                                        oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sy), i)),
+                                        oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sz), i));
+                            const fps_f2 c_x = fps_f2{ox, ox}, c_y = fps_f2{oy, oy}, c_z = fps_f2{oz, oz};
+                            const fps_f2 dx = px[J] - c_x, dy = py[J] - c_y, dz = pz[J] - c_z;
+                            const fps_f2 d2 = (dx * dx + dy * dy) + dz * dz;
+                            mm.x = __int_as_float(min(__float_as_int(mm.x), __float_as_int(d2.x)));
+                            mm.y = __int_as_float(min(__float_as_int(mm.y), __float_as_int(d2.y)));
+                        } while (hit);
+                        md[J] = mm;
+                        const int b0 = __float_as_int(mm.x), b1 = __float_as_int(mm.y);
+                        unsigned pj = pidx[J];
+                        asm volatile("" : "+v"(pj));
+                        const int i0 = (int)(pj & 0xffffu), i1 = (int)(pj >> 16);
+                        const bool sel1 = (b1 > b0) | ((b1 == b0) & (i1 < i0));
+                        const int lb = sel1 ? b1 : b0, li = sel1 ? i1 : i0;
+                        const float4 lc = float4{sel1 ? px[J].y : px[J].x, sel1 ? py[J].y : py[J].x, sel1 ? pz[J].y : pz[J].x, 0.0f};
+                        const int wmi = wave_max_i32(lb);
+                        const unsigned long long tied = __ballot(lb == wmi);
+                        int win;
+                        if (__builtin_expect((tied & (tied - 1ull)) != 0ull, 0)) win = wave_min_i32_dpp(lb == wmi ? li : 0x7fffffff);
+                        else win = __builtin_amdgcn_readlane(li, __builtin_ctzll(tied));
+                        if (li == win && lb == wmi && wmi >= 0) s_cand[wave][J] = lc;
+                        if (lane == J) { bmax = __int_as_float(wmi); bidx = win; }
+                    }
+                }
+            }
+        }
+        if (single) {
         if (lane == 0) s_out[wave][s & (BLOCK - 1)] = cur;
-#if defined(DEDF_FPS_STATS)
-        const long long tk0 = __builtin_readcyclecounter();
-#endif
         // 1. which buckets of this wave can change
         const float ddx = fmaxf(fmaxf(blo[0] - cx, cx - bhi[0]), 0.0f), ddy = fmaxf(fmaxf(blo[1] - cy, cy - bhi[1]), 0.0f),
                     ddz = fmaxf(fmaxf(blo[2] - cz, cz - bhi[2]), 0.0f);
         const float lb2 = ((ddx * ddx + ddy * ddy) + ddz * ddz) * (1.0f - 4e-6f);      // below every distance the update would compute
         unsigned mask = (unsigned)__ballot(lane < NP && !(lb2 >= bmax));
         // 2. active buckets
-#if defined(DEDF_FPS_STATS)
-        if (lane == 0) { atomicAdd(&g_fps_stats[0], (unsigned long long)__builtin_popcount(mask)); atomicAdd(&g_fps_stats[1], mask != 0u ? 1ull : 0ull); }
-        const long long tk05 = __builtin_readcyclecounter();
-        if (tid == 64) { atomicAdd(&g_fps_stats[7], (unsigned long long)(tk05 - tk0)); }
-#endif
-#if defined(DEDF_FPS_SKIP) && DEDF_FPS_SKIP >= 1
-        if (s > 0) mask = 0u;          // timing experiment (wrong results): no bucket updates after the first sample
-#endif
         while (mask) {
             const int ja = __builtin_ctz(mask);
             mask &= mask - 1u;
-#if defined(DEDF_FPS_SKIP) && DEDF_FPS_SKIP == 3
-            fps_dispatch<1>(ja & 0, [&]<int J>() {      // timing experiment (wrong results): every active bucket runs slot 0's code
-#else
             fps_dispatch<NP>(ja, [&]<int J>() {
-#endif
                 // (opaque copy of the sample: hipcc otherwise hoists the distance arithmetic of ALL slots out of the dispatch and computes it
                 // for every sample -- the exhaustive update again)
                 float ox = cx, oy = cy, oz = cz;
@@ -354,7 +528,9 @@ __global__ __launch_bounds__(kFpsBucketBlock) void k_fps_bucketed(const float* _
                 m.x = fminf(m.x, d2.x); m.y = fminf(m.y, d2.y);
                 md[J] = m;
                 const int b0 = __float_as_int(m.x), b1 = __float_as_int(m.y);
-                const int i0 = (int)(pidx[J] & 0xffffu), i1 = (int)(pidx[J] >> 16);
+                unsigned pj = pidx[J];
+                asm volatile("" : "+v"(pj));          // (else the 2 x NP unpacked indices are hoisted out of the sample loop into registers)
+                const int i0 = (int)(pj & 0xffffu), i1 = (int)(pj >> 16);
                 // the lane's better point (larger minimum, then smaller original index) and its coordinates: independent of the reduction
                 const bool sel1 = b1 > b0 || (b1 == b0 && i1 < i0);
                 const int lb = sel1 ? b1 : b0, li = sel1 ? i1 : i0;
@@ -362,82 +538,44 @@ __global__ __launch_bounds__(kFpsBucketBlock) void k_fps_bucketed(const float* _
                 const int wmi = wave_max_i32(lb);                                         // wave-uniform
                 const float wm = __int_as_float(wmi);
                 // (a taken branch costs a lone wave about as much as fifteen instructions: ties are resolved by a second reduction, always)
-#if DEDF_FPS_TIE_BALLOT
-                // ties are rare: when exactly one lane holds the maximum (the fall-through path) its index comes from one v_readlane instead of a
-                // second six-step reduction; exact ties take the reduction (round 4)
-                const unsigned long long tied = __ballot(lb == wmi);
-                int win;
-                if (__builtin_expect(__builtin_popcountll(tied) == 1, 1)) win = __builtin_amdgcn_readlane(li, __builtin_ctzll(tied));
-                else win = wave_min_i32_dpp(lb == wmi ? li : 0x7fffffff);
-#else
                 const int win = wave_min_i32_dpp(lb == wmi ? li : 0x7fffffff);
-#endif
                 if (li == win && lb == wmi && wmi >= 0) s_cand[wave][J] = lc;
                 if (lane == J) { bmax = wm; bidx = win; }
             });
         }
-#if defined(DEDF_FPS_STATS)
-        const long long tk1 = __builtin_readcyclecounter();
-#endif
+        }
         // 3. best bucket of the wave: largest minimum, ties to the smaller original index (recomputed every sample: cheaper than branching
         //    around it, and a wave without work is not the one the others wait for)
-#if defined(DEDF_FPS_SKIP) && DEDF_FPS_SKIP >= 2
-        if (s == 0)
-#endif
         {
             const int kb = lane < NP ? __float_as_int(bmax) : -1;
             const int best = wave_max_i32(kb);
-#if DEDF_FPS_TIE_BALLOT
-            const unsigned long long tiedb = __ballot(kb == best);
-            int bi, jb;
-            if (__builtin_expect(__builtin_popcountll(tiedb) == 1, 1)) { jb = __builtin_ctzll(tiedb); bi = __builtin_amdgcn_readlane(bidx, jb); }
-            else { bi = wave_min_i32_dpp(kb == best ? bidx : 0x7fffffff); jb = __builtin_ctzll(__ballot(kb == best && bidx == bi)); }
-#else
             const int bi = wave_min_i32_dpp(kb == best ? bidx : 0x7fffffff);
             const int jb = __builtin_ctzll(__ballot(kb == best && bidx == bi));
-#endif
             wmd = best; widx = bi;
             const float4 c = s_cand[wave][jb < NP ? jb : 0];
             wx = c.x; wy = c.y; wz = c.z;
         }
-        const int buf = s & 1;
+        const int buf = (BATCH ? it++ : s) & 1;
         if (lane == 0) { s_exch[buf][wave] = float4{__int_as_float(wmd), wx, wy, wz}; s_exch_idx[buf][wave] = widx; }
-#if defined(DEDF_FPS_STATS)
-        const long long tk2 = __builtin_readcyclecounter();
-#endif
         __syncthreads();
-#if defined(DEDF_FPS_STATS)
-        const long long tk3 = __builtin_readcyclecounter();
-#endif
-        if (__builtin_expect((s & (BLOCK - 1)) == BLOCK - 1 || s == n_samples - 1, 0)) {
+        if (__builtin_expect(single && ((s & (BLOCK - 1)) == BLOCK - 1 || s == n_samples - 1), 0)) {
             const int base = s & ~(BLOCK - 1);
             if (base + tid <= s) idx_out[base + tid] = s_out[0][tid];
+            flushed = s + 1;
         }
         // all four slots are read before anything is compared (left to itself hipcc reads them one by one behind branches: four LDS
         // round trips in a row), then a two-level knock-out without branches
-        static_assert(NW == 4, "the knock-out below is written for four waves");
+        static_assert(NW == 4 || NW == 8, "the knock-out below is written for four or eight waves");
         float4 e[NW]; int ei[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w) { e[w] = s_exch[buf][w]; ei[w] = s_exch_idx[buf][w]; }
         asm volatile("" : "+v"(e[0].x), "+v"(e[1].x), "+v"(e[2].x), "+v"(e[3].x), "+v"(ei[0]), "+v"(ei[1]), "+v"(ei[2]), "+v"(ei[3]));
-        auto better = [](const float4& a, int ai, const float4& b, int bi) {      // is b ahead of a
-            const int am = __float_as_int(a.x), bm = __float_as_int(b.x);
-            return bm > am || (bm == am && bi < ai);
-        };
-        const bool s01 = better(e[0], ei[0], e[1], ei[1]), s23 = better(e[2], ei[2], e[3], ei[3]);
-        const float4 a01 = float4{s01 ? e[1].x : e[0].x, s01 ? e[1].y : e[0].y, s01 ? e[1].z : e[0].z, s01 ? e[1].w : e[0].w};
-        const float4 a23 = float4{s23 ? e[3].x : e[2].x, s23 ? e[3].y : e[2].y, s23 ? e[3].z : e[2].z, s23 ? e[3].w : e[2].w};
-        const int i01 = s01 ? ei[1] : ei[0], i23 = s23 ? ei[3] : ei[2];
-        const bool sf = better(a01, i01, a23, i23);
-        cur = sf ? i23 : i01;
-        cx = sf ? a23.y : a01.y; cy = sf ? a23.z : a01.z; cz = sf ? a23.w : a01.w;
-#if defined(DEDF_FPS_STATS)
-        if (tid == 64) {      // wave 1
-            const long long tk4 = __builtin_readcyclecounter();
-            atomicAdd(&g_fps_stats[3], (unsigned long long)(tk1 - tk0)); atomicAdd(&g_fps_stats[4], (unsigned long long)(tk2 - tk1));
-            atomicAdd(&g_fps_stats[5], (unsigned long long)(tk3 - tk2)); atomicAdd(&g_fps_stats[6], (unsigned long long)(tk4 - tk3));
-        }
-#endif
+        if constexpr (NW == 8) asm volatile("" : "+v"(e[4].x), "+v"(e[5].x), "+v"(e[6].x), "+v"(e[7].x), "+v"(ei[4]), "+v"(ei[5]), "+v"(ei[6]), "+v"(ei[7]));
+        const FpsSlot won = fps_knock_out<0, NW, NW>(e, ei);
+        cur = won.i;
+        curm = __float_as_int(won.e.x);
+        cx = won.e.y; cy = won.e.z; cz = won.e.w;
+        s += n_adv;
     }
 }
 

@@ -1,12 +1,11 @@
-// Timing + bucket statistics of the bucketed FPS kernel (dedf_graph.h) on the synthetic scene (60 % plane, 40 % cylinder):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++20 -DDEDF_FPS_STATS -I diffusion_edf_amd/csrc tests/probe/fps_bucket_probe.hip -o tests/probe/fps_bucket_probe
+// Timing of the FPS kernels (dedf_graph.h) on the synthetic scene (60 % plane, 40 % cylinder): exhaustive, bucketed, bucketed + batched
+//   hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-slp-vectorize -I diffusion_edf_amd/csrc tests/probe/fps_bucket_probe.hip -o tests/probe/fps_bucket_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
 #include <vector>
 #include <random>
-__device__ unsigned long long g_fps_stats[8];
 #include "dedf_graph.h"
 using namespace dedf;
 __global__ __launch_bounds__(256) void k_poison_lds(int* sink) {      // leaves garbage in the CU's LDS (a fresh process finds zeros there)
@@ -39,27 +38,49 @@ int main(int argc, char** argv) {
             if (n <= 4096) hipLaunchKernelGGL((k_fps<16, true, 256>), dim3(1), dim3(256), 0, 0, dx, n, ks, 0, out);
             else if (n <= 8192) hipLaunchKernelGGL((k_fps<16, true, 512>), dim3(1), dim3(512), 0, 0, dx, n, ks, 0, out);
             else hipLaunchKernelGGL((k_fps<32, true, 512>), dim3(1), dim3(512), 0, 0, dx, n, ks, 0, out);
-        } else {
+        } else if (which == 1) {
             if (n <= 4096) hipLaunchKernelGGL((k_fps_bucketed<16>), dim3(1), dim3(256), 0, 0, dx, n, ks, 0, out);
             else if (n <= 8192) hipLaunchKernelGGL((k_fps_bucketed<32>), dim3(1), dim3(256), 0, 0, dx, n, ks, 0, out);
             else hipLaunchKernelGGL((k_fps_bucketed<64>), dim3(1), dim3(256), 0, 0, dx, n, ks, 0, out);
+        } else if (which == 2) {
+#ifndef PROBE_NO_BATCH
+            if (n <= 4096) hipLaunchKernelGGL((k_fps_bucketed<16, 256, true>), dim3(1), dim3(256), 0, 0, dx, n, ks, 0, out);
+            else if (n <= 8192) hipLaunchKernelGGL((k_fps_bucketed<32, 256, true>), dim3(1), dim3(256), 0, 0, dx, n, ks, 0, out);
+            else hipLaunchKernelGGL((k_fps_bucketed<64, 256, true>), dim3(1), dim3(256), 0, 0, dx, n, ks, 0, out);
+#endif
         }
+#ifdef PROBE_X8
+        if (which == 3) {
+            if (n <= 4096) hipLaunchKernelGGL((k_fps_bucketed<8, 512, true>), dim3(1), dim3(512), 0, 0, dx, n, ks, 0, out);
+            else if (n <= 8192) hipLaunchKernelGGL((k_fps_bucketed<16, 512, true>), dim3(1), dim3(512), 0, 0, dx, n, ks, 0, out);
+            else hipLaunchKernelGGL((k_fps_bucketed<32, 512, true>), dim3(1), dim3(512), 0, 0, dx, n, ks, 0, out);
+        }
+#endif
     };
-    for (int which = 0; which < 2; ++which) {
+    #ifdef PROBE_X8
+    constexpr int NV = 4;
+#else
+    constexpr int NV = 3;
+#endif
+    const char* names[4] = {"plain      ", "bucketed x4", "batched    ", "batched x8 "};
+    std::vector<int> h[4];
+    for (int which = 0; which < NV; ++which) {
         int* out = which ? d1 : d0;
         run(which, out, k); hipDeviceSynchronize();
         for (int ks : {1, k / 8, k / 2, k}) {
-            unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_fps_stats), z, sizeof(z));
-            hipEventRecord(a); run(which, out, ks); hipEventRecord(b); hipEventSynchronize(b);
-            float ms; hipEventElapsedTime(&ms, a, b);
-            hipMemcpyFromSymbol(z, HIP_SYMBOL(g_fps_stats), sizeof(z));
-            printf("%s n=%d samples=%d: %.3f ms (%.2f us/sample)  active buckets %llu, waves with work %llu, slow ties %llu; wave-1 clocks (100 MHz): test+buckets %llu, wave best %llu, barrier %llu, after %llu, test only (incl. 2 atomics) %llu\n", which ? "bucketed" : "plain   ", n, ks, ms, ms * 1e3 / ks, z[0], z[1], z[2], z[3], z[4], z[5], z[6], z[7]);
+            float best = 1e9f;
+            for (int rep = 0; rep < 3; ++rep) {
+                hipEventRecord(a); run(which, out, ks); hipEventRecord(b); hipEventSynchronize(b);
+                float ms; hipEventElapsedTime(&ms, a, b); best = std::min(best, ms);
+            }
+            printf("%s n=%d samples=%d: %.3f ms (%.2f us/sample)\n", names[which], n, ks, best, best * 1e3 / ks);
         }
+        h[which].resize(k);
+        hipMemcpy(h[which].data(), out, k * 4, hipMemcpyDeviceToHost);
     }
-    std::vector<int> h0(k), h1(k);
-    run(0, d0, k); run(1, d1, k); hipDeviceSynchronize();
-    hipMemcpy(h0.data(), d0, k * 4, hipMemcpyDeviceToHost); hipMemcpy(h1.data(), d1, k * 4, hipMemcpyDeviceToHost);
-    int bad = -1; for (int i = 0; i < k; ++i) if (h0[i] != h1[i]) { bad = i; break; }
-    printf("first difference: %d\n", bad);
+    for (int which = 1; which < NV; ++which) {
+        int bad = -1; for (int i = 0; i < k; ++i) if (h[0][i] != h[which][i]) { bad = i; break; }
+        printf("%s against plain, first difference: %d\n", names[which], bad);
+    }
     return 0;
 }

@@ -99,19 +99,15 @@ def test_fps_bit_exact(n, ratio):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["grid_ties", "duplicates", "n1025", "n4097", "n8192", "n12000_padding", "n16383", "line", "start_mid"])
+@pytest.mark.parametrize("case", ["grid_ties", "duplicates", "n1025", "n2049", "n4097", "n8192", "n12000_padding", "n16383", "line", "start_mid",
+                                  "everything_n3000", "everything_n9000", "ten_distinct", "two_clusters", "grid_large"])
 def test_fps_bucketed_kernel_bit_exact(case):
-    """the bucketed kernel (Morton buckets skipped when the sample cannot lower any of their minima, dedf_graph.h::k_fps_bucketed; default
-    above 8 192 points, here forced from 1 025 points on in a subprocess so that every register layout -- 16 / 32 / 64 points per thread --
-    runs): identical to the exhaustive arg-max of the oracle, exact ties (grid, duplicated points), padding in the last bucket, degenerate
-    extents, a start point in the middle"""
-    import os, subprocess, sys
-    if os.environ.get("DEDF_FPS_BUCKETED") != "2":
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", f"{os.path.abspath(__file__)}::test_fps_bucketed_kernel_bit_exact[{case}]"],
-                           cwd=root, env=dict(os.environ, DEDF_FPS_BUCKETED="2"), capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-        return
+    """the bucketed + batched kernel (dedf_graph.h::k_fps_bucketed: Morton buckets skipped when the sample cannot lower any of their minima;
+    from the 33rd sample on, batches of up to 64 samples drawn by one wave from the candidates above a threshold and applied to the buckets in
+    one pass; what dedf_fps runs from 1 025 to 16 384 points: every register layout -- 16 / 32 points per thread, 4 / 8 waves -- is
+    among the cases): identical to the exhaustive arg-max of the oracle.  Exact ties (grids, duplicated points: the batch's
+    tie path and its fall-back to single samples when more points tie at the top than the candidate list holds), sampling EVERY point (the
+    largest minimum reaches 0: no threshold below it), padding in the last bucket, degenerate extents, a start point in the middle."""
     from diffusion_edf_amd import connectivity as K
     from diffusion_edf_amd import _lib
     rng = np.random.default_rng(5)
@@ -125,6 +121,15 @@ def test_fps_bucketed_kernel_bit_exact(case):
         x = np.zeros((3000, 3), np.float32); x[:, 1] = rng.permutation(3000).astype(np.float32) * 0.25      # zero extent in two axes
     elif case == "start_mid":
         x = _cloud(6000, 9); start = 4321
+    elif case.startswith("everything"):
+        x = _cloud(int(case.split("_n")[1]), 21); ratio = 1.0
+    elif case == "ten_distinct":
+        x = _cloud(10, 4)[rng.integers(0, 10, 6000)]; ratio = 0.05    # 300 samples of 10 distinct points: from the 11th on every minimum is 0
+    elif case == "two_clusters":
+        x = np.concatenate([_cloud(7000, 1) * 0.01, _cloud(7000, 2) * 0.01 + 500.0]).astype(np.float32); ratio = 0.1
+    elif case == "grid_large":
+        x = np.stack(np.meshgrid(np.arange(32.), np.arange(32.), np.arange(16.), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+        x = x[rng.permutation(len(x))]; ratio = 0.25                   # 16 384 lattice points: hundreds of exact ties at every level
     else:
         n = int(case[1:].split("_")[0])
         x = _cloud(n, n)
@@ -137,6 +142,23 @@ def test_fps_bucketed_kernel_bit_exact(case):
         assert lib.dedf_fps(xd.data_ptr(), len(x), len(ref), start, out.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
         got = out.cpu().numpy().astype(np.int64)
     assert np.array_equal(got, ref), (case, int(np.argmax(got != ref)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [3000, 8192, 16383])
+def test_fps_exhaustive_kernel_bit_exact(n):
+    """DEDF_FPS_BUCKETED=0 (read once per process: a subprocess): the exhaustive kernel at the sizes the batched one has taken over"""
+    import os, subprocess, sys
+    if os.environ.get("DEDF_FPS_BUCKETED") != "0":
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", f"{os.path.abspath(__file__)}::test_fps_exhaustive_kernel_bit_exact[{n}]"],
+                           cwd=root, env=dict(os.environ, DEDF_FPS_BUCKETED="0"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        return
+    from diffusion_edf_amd import connectivity as K
+    x = _cloud(n, n)
+    got = K.fps(torch.from_numpy(x).cuda(), None, ratio=0.2, random_start=False).cpu().numpy()
+    assert np.array_equal(got, G.fps(x, 0.2))
 
 
 @pytest.mark.gpu
