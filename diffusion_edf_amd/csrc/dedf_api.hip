@@ -1704,13 +1704,14 @@ int dedf_fps(const float* x, int n, int n_samples, int start, int* idx_out, void
     // 1 025 .. 16 384 points: Morton buckets + batches (dedf_graph.h::k_fps_bucketed<.., BATCH>): a sample only updates the buckets it can change,
     // and once the running minima form a plateau the samples are drawn 30-60 at a time by one wave from a candidate list, the buckets being
     // updated once per batch -- bit-identical to the exhaustive arg-max.  16 384 points, ratio 0.2: 6.3 ms exhaustive, 4.1 ms with buckets
-    // (round 3), 1.7 ms with batches (round 6; profiles/r06p_*); it wins from ~1 100 points on.  DEDF_FPS_BUCKETED=0: the exhaustive kernel everywhere.
+    // (round 3), 1.5 ms with batches (round 6; profiles/r06p_*, r06r_*); it wins from ~1 100 points on.  DEDF_FPS_BUCKETED=0: the exhaustive kernel everywhere.
     // Below and above that range the exhaustive kernel: workgroup size by cloud size (tests/probe/fps_time.py: a sample costs a fixed part
     // that grows with the number of waves -- 0.43 / 0.79 / 1.95 us for 4 / 8 / 16 waves -- plus 0.04 us per point held by a thread).
     static const int bucketed = [] { const char* e = getenv("DEDF_FPS_BUCKETED"); return e ? atoi(e) : 1; }();
     if (bucketed != 0 && n <= 16384 && n > kFpsBatchedFrom && n_samples > kFpsBatchStart) {
-        if (n <= 4096) hipLaunchKernelGGL((k_fps_bucketed<16, 256, true>), dim3(1), dim3(256), 0, st, x, n, n_samples, start, idx_out);
-        else if (n <= 8192) hipLaunchKernelGGL((k_fps_bucketed<32, 256, true>), dim3(1), dim3(256), 0, st, x, n, n_samples, start, idx_out);
+        // (8 waves at every size: waves 0-3 draw the batch, one per SIMD, the other four share in collecting and applying it)
+        if (n <= 4096) hipLaunchKernelGGL((k_fps_bucketed<8, 512, true>), dim3(1), dim3(512), 0, st, x, n, n_samples, start, idx_out);
+        else if (n <= 8192) hipLaunchKernelGGL((k_fps_bucketed<16, 512, true>), dim3(1), dim3(512), 0, st, x, n, n_samples, start, idx_out);
         else hipLaunchKernelGGL((k_fps_bucketed<32, 512, true>), dim3(1), dim3(512), 0, st, x, n, n_samples, start, idx_out);
         return hipGetLastError() == hipSuccess ? DEDF_OK : DEDF_ERR_RUNTIME;
     }

@@ -155,8 +155,8 @@ __global__ __launch_bounds__(BLOCK) void k_fps(const float* __restrict__ x, int 
 // active buckets of the busiest wave at ~0.3 us each -- a serial chain of ~70 dependent instructions per bucket on a lone wave).  At 8 000
 // points it ties with the exhaustive kernel (1.97 against 2.05 ms), at 4 096 it loses (1.03 against 0.88 ms).
 // BATCH = true (round 6, what dedf_fps launches): the ~1 us round trip through the workgroup is paid once per BATCH of up to 64 samples
-// instead of once per sample -- see "batches" inside.  16 384 points: 4.2 -> 1.7 ms (8 waves), 8 192: 2.1 -> 0.87, 3 277: 0.61 -> 0.36 ms,
-// ahead of the exhaustive kernel from ~1 100 points on (profiles/r06p_fps_*.log); still bit-identical to the exhaustive arg-max.
+// instead of once per sample -- see "batches" inside.  16 384 points: 4.2 -> 1.5 ms, 8 192: 2.1 -> 0.69, 3 277: 0.61 -> 0.28 ms (8 waves,
+// kernel time), ahead of the exhaustive kernel from ~1 100 points on (profiles/r06p_fps_*.log, r06r_*); still bit-identical to the exhaustive arg-max.
 __device__ __forceinline__ float wave_max_f32(float v) {
     auto step = [&]<int CTRL, int ROW_MASK>() {
         const int b = __float_as_int(v);
@@ -236,6 +236,8 @@ __global__ __launch_bounds__(BLOCK) void k_fps_bucketed(const float* __restrict_
     constexpr int kBins = 32768;
     __shared__ __align__(16) unsigned s_hist[kBins / 2];    // set-up: cell counters / offsets, two 16-bit halves per word; afterwards the candidate list of a batch
     __shared__ int s_cnt[4];                                // candidate counters, one per collection attempt (rotating)
+    __shared__ float4 s_batch[64];                          // 8 waves: the batch drawn by wave 0 for the waves that do not draw
+    __shared__ int s_batch_m;
     __shared__ unsigned short s_perm[NPAD];                 // set-up only: original index of sorted position p
     __shared__ unsigned s_part[BLOCK];
     __shared__ float4 s_cand[NW][NP];                       // per bucket: coordinates (+ original index) of the point with the largest minimum
@@ -349,8 +351,9 @@ __global__ __launch_bounds__(BLOCK) void k_fps_bucketed(const float* __restrict_
             // the next sample of the exhaustive algorithm -- found by ONE wave inside its registers (<= 256 candidates, 4 per lane), no barrier,
             // no LDS: ~0.2 us per sample against ~1.2 us for a sample that goes round the workgroup.  The samples of a batch (<= 64: lane i keeps
             // sample i) are then applied to the buckets in one pass (a bucket is touched once per BATCH: one pair of reductions for all its
-            // hits), the bucket maxima are exact again and the exchange below names the first sample of the next batch.  Every wave runs the
-            // same batch redundantly (same instructions, same data: same result), so nothing has to be broadcast.
+            // hits), the bucket maxima are exact again and the exchange below names the first sample of the next batch.  With 4 waves every
+            // wave draws the same batch redundantly (same instructions, same data: same result: nothing to broadcast); with 8 only waves 0-3
+            // do, one per SIMD at full speed, and the other four read the batch from LDS behind a barrier.
             // tau = frac * largest minimum; frac rises when the candidates overflow the list and falls when a batch ends because the list ran dry.
             single = s < single_until;
             constexpr int C = kFpsCandPerLane, CAP = 64 * C;
@@ -403,59 +406,77 @@ __global__ __launch_bounds__(BLOCK) void k_fps_bucketed(const float* __restrict_
                 if (flushed < s) {                              // samples still waiting in the ring
                     if (flushed + tid < s) idx_out[flushed + tid] = s_out[0][(flushed + tid) & (BLOCK - 1)];
                 }
-                // the candidates, C per lane as C / 2 pairs (minimum -1: none)
-                static_assert(C % 2 == 0, "candidates are processed in pairs");
-                fps_f2 qx[C / 2], qy[C / 2], qz[C / 2], qm[C / 2];
-                int qi[C];
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const int k = lane + 64 * c;
-                    const bool valid = k < cnt;
-                    const int kk = valid ? k : 0;
-                    const float vx = s_cx[kk], vy = s_cy[kk], vz = s_cz[kk], vm = valid ? s_cm[kk] : -1.0f;
-                    if (c & 1) { qx[c / 2].y = vx; qy[c / 2].y = vy; qz[c / 2].y = vz; qm[c / 2].y = vm; }
-                    else { qx[c / 2].x = vx; qy[c / 2].x = vy; qz[c / 2].x = vz; qm[c / 2].x = vm; }
-                    qi[c] = valid ? s_ci[kk] : 0x7fffffff;
-                }
                 const int m_max = min(64, n_samples - s), tau_bits = __builtin_amdgcn_readfirstlane(__float_as_int(tau));
                 float sx = 0.0f, sy = 0.0f, sz = 0.0f;          // lane i: sample i of the batch
                 int si = 0;
                 int m = 0;
                 bool dry = false;
-                for (; m < m_max; ++m) {
-                    // the lane's best candidate (larger minimum, then smaller index; minima are >= 0 or -1: they order like their bits)
-                    int bm = __float_as_int(qm[0].x), bi = qi[0];
-                    float bx = qx[0].x, by = qy[0].x, bz = qz[0].x;
+                // with 8 waves two share a SIMD: only waves 0-3 draw (one per SIMD, at full speed), the others get the batch through LDS
+                constexpr bool SPLIT = NW == 8;
+                const bool draws = !SPLIT || __builtin_amdgcn_readfirstlane(wave) < 4;
+                if (draws) {
+                    // the candidates, C per lane as C / 2 pairs (minimum -1: none)
+                    static_assert(C % 2 == 0, "candidates are processed in pairs");
+                    fps_f2 qx[C / 2], qy[C / 2], qz[C / 2], qm[C / 2];
+                    int qi[C];
 #pragma unroll
-                    for (int c = 1; c < C; ++c) {
-                        const int cm = __float_as_int((c & 1) ? qm[c / 2].y : qm[c / 2].x);
-                        const bool t = (cm > bm) | ((cm == bm) & (qi[c] < bi));          // (no short circuit: that would be branches)
-                        bm = t ? cm : bm; bi = t ? qi[c] : bi;
-                        bx = t ? ((c & 1) ? qx[c / 2].y : qx[c / 2].x) : bx; by = t ? ((c & 1) ? qy[c / 2].y : qy[c / 2].x) : by;
-                        bz = t ? ((c & 1) ? qz[c / 2].y : qz[c / 2].x) : bz;
+                    for (int c = 0; c < C; ++c) {
+                        const int k = lane + 64 * c;
+                        const bool valid = k < cnt;
+                        const int kk = valid ? k : 0;
+                        const float vx = s_cx[kk], vy = s_cy[kk], vz = s_cz[kk], vm = valid ? s_cm[kk] : -1.0f;
+                        if (c & 1) { qx[c / 2].y = vx; qy[c / 2].y = vy; qz[c / 2].y = vz; qm[c / 2].y = vm; }
+                        else { qx[c / 2].x = vx; qy[c / 2].x = vy; qz[c / 2].x = vz; qm[c / 2].x = vm; }
+                        qi[c] = valid ? s_ci[kk] : 0x7fffffff;
                     }
-                    const int wmi = wave_max_i32(bm);
-                    if (wmi < tau_bits) { dry = true; break; }
-                    // the lane that holds it: one lane unless two candidates tie exactly (then the smaller index, by a second reduction)
-                    const unsigned long long tied = __ballot(bm == wmi);
-                    int wl = __builtin_ctzll(tied);
-                    if (__builtin_expect((tied & (tied - 1ull)) != 0ull, 0)) {
-                        const int wi = wave_min_i32_dpp(bm == wmi ? bi : 0x7fffffff);
-                        wl = __builtin_ctzll(__ballot(bm == wmi && bi == wi));
-                    }
-                    const int win = __builtin_amdgcn_readlane(bi, wl);
-                    const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx), wl)),
-                                oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(by), wl)),
-                                oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bz), wl));
-                    if (lane == m) { sx = ox; sy = oy; sz = oz; si = win; }
-                    const fps_f2 c_x = fps_f2{ox, ox}, c_y = fps_f2{oy, oy}, c_z = fps_f2{oz, oz};
+                    for (; m < m_max; ++m) {
+                        // the lane's best candidate (larger minimum, then smaller index; minima are >= 0 or -1: they order like their bits)
+                        int bm = __float_as_int(qm[0].x), bi = qi[0];
+                        float bx = qx[0].x, by = qy[0].x, bz = qz[0].x;
 #pragma unroll
-                    for (int c = 0; c < C / 2; ++c) {
-                        const fps_f2 dx = qx[c] - c_x, dy = qy[c] - c_y, dz = qz[c] - c_z;
-                        const fps_f2 d2 = (dx * dx + dy * dy) + dz * dz;
-                        // (minimum of the bit patterns: both are >= 0 or the padding value -1, which stays)
-                        qm[c].x = __int_as_float(min(__float_as_int(qm[c].x), __float_as_int(d2.x)));
-                        qm[c].y = __int_as_float(min(__float_as_int(qm[c].y), __float_as_int(d2.y)));
+                        for (int c = 1; c < C; ++c) {
+                            const int cm = __float_as_int((c & 1) ? qm[c / 2].y : qm[c / 2].x);
+                            const bool t = (cm > bm) | ((cm == bm) & (qi[c] < bi));          // (no short circuit: that would be branches)
+                            bm = t ? cm : bm; bi = t ? qi[c] : bi;
+                            bx = t ? ((c & 1) ? qx[c / 2].y : qx[c / 2].x) : bx; by = t ? ((c & 1) ? qy[c / 2].y : qy[c / 2].x) : by;
+                            bz = t ? ((c & 1) ? qz[c / 2].y : qz[c / 2].x) : bz;
+                        }
+                        const int wmi = wave_max_i32(bm);
+                        if (wmi < tau_bits) { dry = true; break; }
+                        // the lane that holds it: one lane unless two candidates tie exactly (then the smaller index, by a second reduction)
+                        const unsigned long long tied = __ballot(bm == wmi);
+                        int wl = __builtin_ctzll(tied);
+                        if (__builtin_expect((tied & (tied - 1ull)) != 0ull, 0)) {
+                            const int wi = wave_min_i32_dpp(bm == wmi ? bi : 0x7fffffff);
+                            wl = __builtin_ctzll(__ballot(bm == wmi && bi == wi));
+                        }
+                        const int win = __builtin_amdgcn_readlane(bi, wl);
+                        const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx), wl)),
+                                    oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(by), wl)),
+                                    oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bz), wl));
+                        if (lane == m) { sx = ox; sy = oy; sz = oz; si = win; }
+                        const fps_f2 c_x = fps_f2{ox, ox}, c_y = fps_f2{oy, oy}, c_z = fps_f2{oz, oz};
+#pragma unroll
+                        for (int c = 0; c < C / 2; ++c) {
+                            const fps_f2 dx = qx[c] - c_x, dy = qy[c] - c_y, dz = qz[c] - c_z;
+                            const fps_f2 d2 = (dx * dx + dy * dy) + dz * dz;
+                            // (minimum of the bit patterns: both are >= 0 or the padding value -1, which stays)
+                            qm[c].x = __int_as_float(min(__float_as_int(qm[c].x), __float_as_int(d2.x)));
+                            qm[c].y = __int_as_float(min(__float_as_int(qm[c].y), __float_as_int(d2.y)));
+                        }
+                    }
+                    if (SPLIT && wave == 0) {
+                        if (lane < m) s_batch[lane] = float4{sx, sy, sz, __int_as_float(si)};
+                        if (lane == 0) s_batch_m = m | (dry ? 256 : 0);
+                    }
+                }
+                if constexpr (SPLIT) {
+                    __syncthreads();
+                    if (!draws) {
+                        const int mm = __builtin_amdgcn_readfirstlane(s_batch_m);
+                        m = mm & 255; dry = (mm & 256) != 0;
+                        const float4 v = s_batch[lane];
+                        sx = v.x; sy = v.y; sz = v.z; si = __float_as_int(v.w);
                     }
                 }
                 if (dry && m < 48) frac = fmaxf(0.3f, frac * 0.95f);
