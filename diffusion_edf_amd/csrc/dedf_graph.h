@@ -225,7 +225,7 @@ template <int LO, int N, int NW> __device__ __forceinline__ FpsSlot fps_knock_ou
         return FpsSlot{float4{sb ? b.e.x : a.e.x, sb ? b.e.y : a.e.y, sb ? b.e.z : a.e.z, sb ? b.e.w : a.e.w}, sb ? b.i : a.i};
     }
 }
-constexpr int kFpsBatchStart = 32;         // samples taken one by one before the first batch (early samples lower every running minimum)
+constexpr int kFpsBatchStart = 16;         // samples taken one by one before the first batch (early samples lower every running minimum)
 constexpr int kFpsCandPerLane = 4;          // candidate list of a batch: 64 lanes x this many points
 constexpr int kFpsBatchedFrom = 1024;       // dedf_fps: clouds above this many points take the bucketed + batched kernel (measured, tests/probe/fps_time.py: 0.167 against 0.227 ms at 1 100 points, a tie at 656)
 template <int PPT, int BLOCK = kFpsBucketBlock, bool BATCH = false>      // points per thread: the cloud has at most BLOCK * PPT points
