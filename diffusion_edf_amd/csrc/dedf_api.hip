@@ -239,8 +239,13 @@ int check_config(const dedf_config* c, std::string& why) {
     if (!t_small && !t_big) { why = "time_emb_mlp must be [256,128,64] or [512,256,128]"; return DEDF_ERR_UNSUPPORTED; }
     const bool mlp_wide = c->fc_neurons[1] == kFc1 && c->fc_neurons[2] == kFc2;
     const bool mlp_narrow = c->fc_neurons[1] == 32 && c->fc_neurons[2] == 32;       // sapien place_* score heads
-    if (c->fc_neurons[0] != (c->ebm ? kLenEmb : kLenEmb + c->time_emb_mlp[2]) || !(mlp_wide || mlp_narrow)) {
-        why = "fc_neurons must resolve to [64 + time_emb, 128, 64] or [64 + time_emb, 32, 32] (score head), or [64,128,64] / [64,32,32] (EBM head / context-free field, no time encoding)"; return DEDF_ERR_UNSUPPORTED; }
+    // (a score head WITHOUT edge_time_encoding -- the reference constructor's default, score_head.py:40-41 -- has the 64-wide pre-linear of the EBM
+    //  head and takes its time through query_time_encoding alone: instantiated for fc_neurons [64, 128, 64], full precision)
+    const bool no_edge_time = !c->ebm && c->fc_neurons[0] == kLenEmb && c->query_time_encoding;
+    if ((c->fc_neurons[0] != (c->ebm ? kLenEmb : kLenEmb + c->time_emb_mlp[2]) && !no_edge_time) || !(mlp_wide || mlp_narrow)) {
+        why = "fc_neurons must resolve to [64 + time_emb, 128, 64] or [64 + time_emb, 32, 32] (score head with edge_time_encoding), [64, 128, 64] (score head with query_time_encoding only), or [64,128,64] / [64,32,32] (EBM head / context-free field, no time encoding)"; return DEDF_ERR_UNSUPPORTED; }
+    if (no_edge_time && (!mlp_wide || c->half_gemm)) {
+        why = "the score head without edge_time_encoding is instantiated for fc_neurons [64, 128, 64] in full precision"; return DEDF_ERR_UNSUPPORTED; }
     if (mlp_narrow && c->ebm && c->lmax < 2) {
         why = "the context-free field with the 32-wide radial MLP (KeypointExtractor) is instantiated for lmax 2 and 3"; return DEDF_ERR_UNSUPPORTED; }
     if (mlp_narrow && !c->ebm && c->fc_neurons[0] != 128) {
@@ -249,12 +254,12 @@ int check_config(const dedf_config* c, std::string& why) {
     if (c->irreps_mlp_mid != kMlpMid) { why = "irreps_mlp_mid must be 3"; return DEDF_ERR_UNSUPPORTED; }
     if (c->half_gemm && c->lmax == 1 && c->fc_neurons[0] == 192) { why = "lmax 1 with a 128-channel time embedding is not instantiated"; return DEDF_ERR_UNSUPPORTED; }
     if (c->query_time_encoding) {
-        const bool ok2 = c->lmax == 2 && ((c->fc_neurons[0] == 128 && (mlp_wide || mlp_narrow)) || (c->fc_neurons[0] == 192 && mlp_wide));
-        const bool ok3 = c->lmax == 3 && c->fc_neurons[0] == 128 && mlp_wide;
-        const bool ok1 = c->lmax == 1 && c->fc_neurons[0] == 128 && mlp_wide;
+        const bool ok2 = c->lmax == 2 && ((c->fc_neurons[0] == 128 && (mlp_wide || mlp_narrow)) || (c->fc_neurons[0] == 192 && mlp_wide) || no_edge_time);
+        const bool ok3 = c->lmax == 3 && (c->fc_neurons[0] == 128 || no_edge_time) && mlp_wide;
+        const bool ok1 = c->lmax == 1 && (c->fc_neurons[0] == 128 || no_edge_time) && mlp_wide;
         const bool okh = !c->half_gemm || (c->lmax == 2 && c->fc_neurons[0] == 128 && mlp_wide);
         if (c->ebm || !(ok1 || ok2 || ok3) || !okh) {
-            why = "query_time_encoding is instantiated for the score head: lmax 2 with fc_neurons [128,128,64] (also in half precision) / [128,32,32] / [192,128,64], lmax 1 and 3 with [128,128,64]"; return DEDF_ERR_UNSUPPORTED; }
+            why = "query_time_encoding is instantiated for the score head: lmax 2 with fc_neurons [128,128,64] (also in half precision) / [128,32,32] / [192,128,64], lmax 1 and 3 with [128,128,64]; without edge_time_encoding [64,128,64] at lmax 1-3"; return DEDF_ERR_UNSUPPORTED; }
     }
     if (c->n_scales < 1 || c->n_scales > kMaxScales) { why = "n_scales out of range"; return DEDF_ERR_INVALID; }
     bool inf = false;
@@ -368,7 +373,7 @@ int upload_weights(dedf_handle* h) {
         for (int k = 0; k < half; ++k) fr[k] = std::exp((float)k * (float)(-step));
         h->nat_tfreq = put(fr.data(), half);
     }
-    if (c.ebm) {   // no time encoding: the pre-linear "time rows" are just its bias, row-packed once
+    if (c.fc_neurons[0] == kLenEmb) {   // no edge time encoding (EBM head, score head with query_time_encoding only): the pre-linear "time rows" are just its bias, row-packed once
         std::vector<float> rows;
         for (int n = 0; n < ns; ++n) {
             const float* b = S.get(B, "key_tensor_field.edge_scalars_pre_linears." + std::to_string(n) + ".0.bias");
@@ -502,7 +507,7 @@ void launch_edge(dedf_handle* h, hipStream_t st, const EdgeParams& P) {
     constexpr int kAll = 1 << 30;
     if (h->cfg.query_time_encoding) {      // (validate_config admits only these shapes)
         constexpr bool qt = !HP && MODE <= 1 && (((L == 2 || L == 3 || (L == 1 && MODE == 0)) && F0 == 128 && H1 == 128 && H2 == 64) || (L == 2 && F0 == 128 && H1 == 32 && H2 == 32) ||
-                                                 (L == 2 && F0 == 192 && H1 == 128 && H2 == 64));
+                                                 (L == 2 && F0 == 192 && H1 == 128 && H2 == 64) || (MODE == 0 && F0 == 64 && H1 == 128 && H2 == 64));
         constexpr bool qt_hp = HP && MODE == 0 && L == 2 && F0 == 128 && H1 == 128 && H2 == 64;
         if constexpr (qt || qt_hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, HP, H1, H2, false, MODE, false, true, true>), kAll, st, P);
         return;
@@ -516,7 +521,7 @@ void launch_edge(dedf_handle* h, hipStream_t st, const EdgeParams& P) {
 // parameters of the fused edge kernel for the current state of the handle
 template <int L, int F0>
 EdgeParams edge_params(dedf_handle* h, int nT, int time_stride) {
-    constexpr bool EBM = F0 == kLenEmb;
+    constexpr bool NOTIME = F0 == kLenEmb;      // no edge time encoding: constant pre-linear bias rows
     constexpr int D = feat_dim<L>();
     const dedf_config& c = h->cfg;
     const int ns = c.n_scales;
@@ -524,7 +529,7 @@ EdgeParams edge_params(dedf_handle* h, int nT, int time_stride) {
     EdgeParams P{};
     P.key_x = h->d_key_x.as<float>(); P.qpos = h->d_qpos.as<float>(); P.edge_src = h->d_esrc.as<int>(); P.edge_dst = h->d_edst.as<int>();
     P.tile_info = h->d_tile.as<int>(); P.msg = h->d_msg.as<float>(); P.msg_bytes = (uint32_t)((size_t)h->n_keys * D * 4);
-    if constexpr (EBM) {
+    if constexpr (NOTIME) {
         P.tb = nat + h->nat_brows; P.tb_bytes = (uint32_t)((size_t)ns * F0 * 4); P.tb_pose_stride = 0;
     } else {
         P.tb = h->tb_step ? h->tb_step : h->d_tb.as<float>();
@@ -667,9 +672,12 @@ int radial_table_check_dispatch(dedf_handle* h, hipStream_t st) {
 }
 
 // one evaluation of the score head on poses already in h->d_Ts (f32) with times in h->d_time
-template <int L, int F0>
+template <int L, int F0, bool EBM = (F0 == kLenEmb)>
 int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, hipStream_t st) {
-    constexpr bool EBM = F0 == kLenEmb;           // 64: EBM critic (no time encoding); 128 / 192: score head with 64 / 128 time channels
+    // F0 = 64: no edge time encoding -- the EBM critic (no time at all) or, EBM = false, the score head whose time comes through
+    // query_time_encoding alone; 128 / 192: score head with 64 / 128 time channels in the pre-linear
+    constexpr bool NOTIME = F0 == kLenEmb;
+    static_assert(!EBM || NOTIME, "the EBM head has no time encoding");
     const dedf_config& c = h->cfg;
     const int ns = c.n_scales, nQ = h->nQ;
     const int Nd = nT * nQ;
@@ -715,7 +723,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
         h->small_parity = 1 - par;
         cnt_used = np.cnt;
         if constexpr (!EBM) {
-            if (h->tb_step == nullptr) launch_time_bias(h, st, h->d_time.as<float>(), time_stride, time_stride ? nT : 1, h->d_tb.as<float>(), time_stride ? h->d_tile.as<int>() + kFlagTimeVaries : nullptr);
+            if constexpr (!NOTIME) if (h->tb_step == nullptr) launch_time_bias(h, st, h->d_time.as<float>(), time_stride, time_stride ? nT : 1, h->d_tb.as<float>(), time_stride ? h->d_tile.as<int>() + kFlagTimeVaries : nullptr);
             if (h->tb_step == nullptr && c.query_time_encoding) launch_time_query(h, st, h->d_time.as<float>(), time_stride, time_stride ? nT : 1, h->d_qrows.as<float>());
         }
         mark();
@@ -729,7 +737,7 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
     hipLaunchKernelGGL(k_pose_prep<L>, dim3(nT), dim3(64), 0, st, h->d_Ts.as<float>(), T64, h->d_qx.as<float>(), nQ, h->d_pose.as<float>(), h->d_qpos.as<float>());
     // 2. time embedding -> pre-linear bias rows (EBM head: constant bias rows, uploaded once)
     if constexpr (!EBM) {
-        if (h->tb_step == nullptr) launch_time_bias(h, st, h->d_time.as<float>(), time_stride, time_stride ? nT : 1, h->d_tb.as<float>(), time_stride ? h->d_tile.as<int>() + kFlagTimeVaries : nullptr);
+        if constexpr (!NOTIME) if (h->tb_step == nullptr) launch_time_bias(h, st, h->d_time.as<float>(), time_stride, time_stride ? nT : 1, h->d_tb.as<float>(), time_stride ? h->d_tile.as<int>() + kFlagTimeVaries : nullptr);
         if (h->tb_step == nullptr && c.query_time_encoding) launch_time_query(h, st, h->d_time.as<float>(), time_stride, time_stride ? nT : 1, h->d_qrows.as<float>());
     }
     mark();
@@ -884,16 +892,16 @@ int score_impl(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, 
 int score_dispatch(dedf_handle* h, int nT, int time_stride, float* ang, float* lin, hipStream_t st) {
     const int F0 = h->cfg.fc_neurons[0];
     if (h->L == 1) {
-        if (F0 == 64) return score_impl<1, 64>(h, nT, time_stride, ang, lin, st);
+        if (F0 == 64) return h->cfg.ebm ? score_impl<1, 64, true>(h, nT, time_stride, ang, lin, st) : score_impl<1, 64, false>(h, nT, time_stride, ang, lin, st);
         if (F0 == 128) return score_impl<1, 128>(h, nT, time_stride, ang, lin, st);
         return fail(h, DEDF_ERR_UNSUPPORTED, "lmax 1 with a 128-channel time embedding is not instantiated");
     }
     if (h->L == 3) {
-        if (F0 == 64) return score_impl<3, 64>(h, nT, time_stride, ang, lin, st);
+        if (F0 == 64) return h->cfg.ebm ? score_impl<3, 64, true>(h, nT, time_stride, ang, lin, st) : score_impl<3, 64, false>(h, nT, time_stride, ang, lin, st);
         if (F0 == 128) return score_impl<3, 128>(h, nT, time_stride, ang, lin, st);
         return fail(h, DEDF_ERR_UNSUPPORTED, "lmax 3 with a 128-channel time embedding is not instantiated");
     }
-    if (F0 == 64) return score_impl<2, 64>(h, nT, time_stride, ang, lin, st);
+    if (F0 == 64) return h->cfg.ebm ? score_impl<2, 64, true>(h, nT, time_stride, ang, lin, st) : score_impl<2, 64, false>(h, nT, time_stride, ang, lin, st);
     if (F0 == 128) return score_impl<2, 128>(h, nT, time_stride, ang, lin, st);
     return score_impl<2, 192>(h, nT, time_stride, ang, lin, st);
 }
@@ -1268,7 +1276,8 @@ static int sample_once(dedf_handle* h, int nT, const double* T_seed, const dedf_
         float* pin_t = reinterpret_cast<float*>(h->h_pin) + 128;
         for (int s = 0; s < sched->n_steps; ++s) pin_t[s] = (float)sched->t[s];
         HIPCK(h, hipMemcpyAsync(h->d_time.p, pin_t, (size_t)sched->n_steps * 4, hipMemcpyHostToDevice, st));
-        launch_time_bias(h, st, h->d_time.as<float>(), 1, sched->n_steps, h->d_tb_steps.as<float>());
+        // (without edge time encoding the rows are constants: h->tb_step then only names the step for query_time_rows)
+        if (h->cfg.fc_neurons[0] != kLenEmb) launch_time_bias(h, st, h->d_time.as<float>(), 1, sched->n_steps, h->d_tb_steps.as<float>());
         if (h->cfg.query_time_encoding) {
             if (!h->d_qrows_steps.ensure((size_t)sched->n_steps * kQueryTimeRow * 4)) return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(time rows) failed");
             launch_time_query(h, st, h->d_time.as<float>(), 1, sched->n_steps, h->d_qrows_steps.as<float>());

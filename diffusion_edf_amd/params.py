@@ -75,9 +75,9 @@ class HeadConfig:
                 raise NotImplementedError(f"irreps must be mul_0 x0e + mul_1 x1e + ...: {irreps}")
         ebm = bool(k.get('ebm', False))
         ete, qte = bool(k.get('edge_time_encoding', False)), bool(k.get('query_time_encoding', True))
-        if (ebm and (ete or qte)) or (not ebm and not ete):
-            raise NotImplementedError("accelerated path: score head with edge_time_encoding=True (the shipped configs; query_time_encoding on or "
-                                      "off), or EBM critic head with both False")
+        if (ebm and (ete or qte)) or (not ebm and not ete and not qte):
+            raise NotImplementedError("accelerated path: score head with edge_time_encoding and / or query_time_encoding (the reference "
+                                      "constructor's default is query_time_encoding alone), or EBM critic head with both False")
         if tf.get('n_layers', 1) != 1:
             raise NotImplementedError("n_layers != 1")
         if tf.get('cutoff_method', 'edge_attn') != 'edge_attn':

@@ -23,14 +23,14 @@ def ebm_head_kwargs(lmax: int = 2, radii=(3.5, 5., 6.5, 8.)) -> dict:
     return kw
 
 
-def score_head_kwargs(lmax: int = 2, radii=(5., 10., 20., None), query_time_encoding: bool = False) -> dict:
+def score_head_kwargs(lmax: int = 2, radii=(5., 10., 20., None), query_time_encoding: bool = False, edge_time_encoding: bool = True) -> dict:
     """The `score_head_kwargs` block of reference configs/panda_mug/pick_lowres/score_model_configs.yaml:3-25
     (+ the keys multiscale_score_model.py:79-85 injects), with irreps truncated at `lmax`."""
     irr = '+'.join(['64x0e', '32x1e', '16x2e', '8x3e'][:lmax + 1])
     sh = '+'.join(['1x0e', '1x1e', '1x2e', '1x3e'][:lmax + 1])
     return dict(
         max_time=1., time_emb_mlp=[256, 128, 64], ang_mult=2.5, lin_mult=15.,
-        edge_time_encoding=True, query_time_encoding=query_time_encoding,
+        edge_time_encoding=edge_time_encoding, query_time_encoding=query_time_encoding,
         key_tensor_field_kwargs=dict(
             irreps_input=irr, irreps_output=irr, irreps_sh=sh, num_heads=4, fc_neurons=[-1, 128, 64],
             length_emb_dim=64, r_cluster_multiscale=list(radii), n_layers=1, irreps_mlp_mid=3,

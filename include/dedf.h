@@ -57,7 +57,8 @@ typedef struct dedf_config {
                                             reference's shapes: features are (N, 296), parameters as the reference's state dict has them) */
     int mul[4];                          /* must equal {64,32,16,8}[0..lmax] (every reference config) */
     int num_heads;                       /* 4 */
-    int fc_neurons[3];                   /* {64 + time_emb_mlp[2],128,64} ({64,128,64} for the EBM head), {128,32,32} (sapien place_* score heads), or
+    int fc_neurons[3];                   /* {64 + time_emb_mlp[2],128,64} ({64,128,64} for the EBM head and for the score head WITHOUT edge time
+                                            encoding -- ebm = 0, query_time_encoding = 1, the reference constructor's default), {128,32,32} (sapien place_* score heads), or
                                             {64,32,32} with ebm = 1 (the context-free fields of KeypointExtractor, lmax 2 only):
                                             fc_neurons after the -1 is resolved (multiscale_tensor_field.py:63-67) */
     int length_emb_dim;                  /* 64 */
@@ -105,8 +106,10 @@ typedef struct dedf_config {
                                             (use_dst_feature, gnn_block.py:109-130, 170-180, 205-206): LayerNorm + LinearRS(bias) of it joins every edge's
                                             message, linear_src has no bias, and its projection skip_1 joins the attention output before post_norm.  The
                                             parameter list gains query_time_mlp.*, ...prenorm_dst.*, ...linear_dst.*, ...skip_1.skip.* and loses
-                                            ...linear_src.bias.0.  Together with edge time encoding (fc_neurons[0] = 64 + time_emb_mlp[2]); instantiated
+                                            ...linear_src.bias.0.  Together with edge time encoding (fc_neurons[0] = 64 + time_emb_mlp[2]): instantiated
                                             for lmax 2 with fc_neurons {128,128,64} (half_gemm too) / {128,32,32} / {192,128,64} and lmax 1 / 3 with {128,128,64}.
+                                            ALONE (edge_time_encoding=False, score_head.py:183-186: the pre-linears see the length embedding only,
+                                            fc_neurons[0] = 64): instantiated for lmax 1-3 with fc_neurons {64,128,64}, full precision.
                                             0: default (every shipped config) */
 } dedf_config;
 

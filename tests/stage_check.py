@@ -69,8 +69,8 @@ def rel(a, b):
 
 
 def build_case(lmax=2, nT=6, n_scene=512, n_grasp=100, seed=0, radii=(5., 10., 20., None), static_kp=False, identity_pose=True,
-               near=True, query_time_encoding=False):
-    kw = synthetic.score_head_kwargs(lmax, radii=radii, query_time_encoding=query_time_encoding)
+               near=True, query_time_encoding=False, edge_time_encoding=True):
+    kw = synthetic.score_head_kwargs(lmax, radii=radii, query_time_encoding=query_time_encoding, edge_time_encoding=edge_time_encoding)
     cfg = params.HeadConfig.from_kwargs(kw)
     P = params.init_params(cfg, seed=2, randomize_all=True)
     keys = synthetic.make_key_clouds(cfg, n_scene, seed=seed)

@@ -61,8 +61,24 @@ def test_unsupported_configs_are_rejected(built_lib):
     with pytest.raises(ValueError):
         params.HeadConfig.from_kwargs(kw)
     kw = synthetic.score_head_kwargs(2)
-    kw['query_time_encoding'], kw['edge_time_encoding'] = True, False          # query-side time encoding alone: not instantiated
+    kw['query_time_encoding'], kw['edge_time_encoding'] = False, False         # no time encoding at all: the reference refuses it too (score_head.py:77-78)
     kw['key_tensor_field_kwargs']['fc_neurons'] = [64, 128, 64]
+    with pytest.raises(NotImplementedError):
+        params.HeadConfig.from_kwargs(kw)
+    # query-side time encoding ALONE (the reference constructor's default, score_head.py:40-41): instantiated in round 6 for lmax 1-3 with the
+    # radial MLP [64, 128, 64] in full precision; the narrow radial MLP and half precision are not
+    for lmax in (1, 2, 3):
+        cfg = params.HeadConfig.from_kwargs(synthetic.score_head_kwargs(lmax, query_time_encoding=True, edge_time_encoding=False))
+        assert cfg.fc_neurons == [64, 128, 64] and not cfg.ebm
+        cc = _lib.make_config(cfg, -1)
+        assert built_lib.dedf_param_count(C.byref(cc)) > 0, lmax
+        cc.half_gemm = 1
+        assert built_lib.dedf_param_count(C.byref(cc)) == -1, lmax
+        cc.half_gemm = 0
+        cc.fc_neurons[1], cc.fc_neurons[2] = 32, 32
+        assert built_lib.dedf_param_count(C.byref(cc)) == -1, lmax
+    kw = synthetic.score_head_kwargs(2, query_time_encoding=True, edge_time_encoding=False)
+    kw['key_tensor_field_kwargs']['fc_neurons'] = [-1, 32, 32]
     with pytest.raises(NotImplementedError):
         params.HeadConfig.from_kwargs(kw)
     for bad in (dict(lmax=1, half_gemm=1), dict(lmax=1, fc=(128, 32, 32)), dict(lmax=3, half_gemm=1), dict(lmax=3, fc=(128, 32, 32))):       # query_time_encoding at lmax 1 / 3: [128,128,64], full precision only

@@ -114,6 +114,43 @@ def test_query_time_encoding(lmax):
     assert float((ang1.cpu().double() - a64).abs().max()) / scale < TOL and float((lin1.cpu().double() - l64).abs().max()) / scale < TOL
 
 
+@pytest.mark.parametrize("lmax", [1, 2, 3])
+def test_query_time_encoding_without_edge_time_encoding(lmax):
+    """ScoreModelHead(edge_time_encoding=False, query_time_encoding=True) -- the reference constructor's DEFAULT (score_head.py:40-41): the
+    pre-linears see the length embedding alone (fc_neurons [64, 128, 64], context_emb = None, :183-186) and the time reaches the field only
+    through the destination feature.  Every stage against the fp64 oracle with a different time per pose, then the sampler (per-edge radial
+    front: without a time in it there is no per-step table) against the oracle's float64 Langevin loop, and the time really matters."""
+    rep = SC.stage_report(lmax=lmax, nT=6, n_scene=512, n_grasp=100, verbose=False, query_time_encoding=True, edge_time_encoding=False)
+    print("TOLPROBE query-time-only stages:", {k: f"{v:.1e}" for k, v in rep.items() if isinstance(v, float)})
+    _check(rep, named_bars={'field_l1': 1.5e-4} if lmax == 1 else None)
+    kw, cfg, P, keys, query, Ts, time = SC.build_case(lmax, 8, 512, 100, query_time_encoding=True, edge_time_encoding=False)
+    assert cfg.fc_neurons == [64, 128, 64] and "key_tensor_field.edge_scalars_pre_linears.0.0.weight" in P and tuple(P["key_tensor_field.edge_scalars_pre_linears.0.0.weight"].shape) == (64, 64)
+    ocfg = R.config_from_kwargs(kw)
+    assert ocfg.query_time_encoding and not ocfg.edge_time_encoding
+    g = torch.Generator().manual_seed(11)
+    n_steps = [2, 2]
+    noise = torch.randn(sum(n_steps), 2, len(Ts), 3, generator=g, dtype=torch.float64)
+    sched = [[1.0, 0.5], [0.5, 0.2]]
+    ok = [R.FeaturedPoints(k.x, k.f, k.b) for k in keys]
+    oq = R.FeaturedPoints(query.x, query.f, query.b, query.w)
+    ref = R.sample(ocfg, P, Ts, ok, oq, sched, n_steps, [0.04, 0.02], temperatures=[1.0, 0.5], noise=noise)
+    dev = torch.device('cuda:0')
+    head = ScoreModelHead(**kw)
+    head.load_state_dict(P)
+    head.to(dev)
+    gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
+    gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
+    out = ScoreModelBase(head).sample(Ts.to(dev), gk, gq, sched, n_steps, [0.04, 0.02], temperatures=[1.0, 0.5], noise=noise).cpu()
+    err = float((out - ref).abs().max())
+    print(f"TOLPROBE query-time-only sampler: {err:.2e}")
+    assert err < 5e-5, err
+    # the time is really read: another time, another score
+    t0 = time.to(dev).float()
+    ang0, _ = head(Ts.to(dev).float(), gk, gq, t0)
+    ang1, _ = head(Ts.to(dev).float(), gk, gq, (t0 * 0.5).contiguous())
+    assert float((ang1 - ang0).abs().max()) > 1e-3 * float(ang0.abs().max())
+
+
 @pytest.mark.parametrize("shape", ["time_emb_128", "narrow_radial_mlp"])
 def test_query_time_encoding_other_shapes(shape):
     """query_time_encoding on the two other lmax-2 score-head shapes the reference ships (pre-linear 192 wide with a 128-channel time embedding --
