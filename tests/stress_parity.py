@@ -20,18 +20,24 @@ from diffusion_edf_amd.gnn_data import FeaturedPoints
 LMAX_HI = 4 if os.environ.get("DEDF_STRESS_LMAX3") else 3
 
 
-def draw_case(rng: np.random.Generator, max_lmax: int = 3):
+# DEDF_STRESS_QT=1: every third case carries query_time_encoding beside the edge time encoding, every third one query_time_encoding ALONE (the
+# reference constructor's default); decided by the case index, so that the random stream -- and with it every earlier seed's cases -- is unchanged
+STRESS_QT = bool(os.environ.get("DEDF_STRESS_QT"))
+
+
+def draw_case(rng: np.random.Generator, max_lmax: int = 3, index: int = 0):
     lmax = min(int(rng.integers(1, LMAX_HI)), max_lmax)
     ns = int(rng.integers(1, 6))
     radii = sorted(float(r) for r in rng.uniform(2.0, 14.0, size=ns))
     inf_last = bool(rng.integers(0, 2))
     if inf_last:
         radii[-1] = None
-    kw = synthetic.score_head_kwargs(lmax, radii=tuple(radii))
+    qt_mode = index % 3 if STRESS_QT else 0          # 1: query + edge time encoding, 2: query time encoding alone
+    kw = synthetic.score_head_kwargs(lmax, radii=tuple(radii), query_time_encoding=qt_mode != 0, edge_time_encoding=qt_mode != 2)
     tf = kw['key_tensor_field_kwargs']
     tf['length_enc_max_r'] = 100. if inf_last else None
     shape = int(rng.integers(0, 4))
-    if lmax == 3:
+    if lmax == 3 or (qt_mode and lmax != 2) or (qt_mode == 2 and shape == 2):          # (the shapes instantiated with query_time_encoding)
         shape = 0
     if shape == 1 and lmax == 2:
         kw['time_emb_mlp'] = [512, 256, 128]
@@ -70,8 +76,11 @@ def draw_case(rng: np.random.Generator, max_lmax: int = 3):
     return kw, cfg, P, keys, query, Ts, time
 
 
+AT_FP32_FLOOR = []          # DEDF_STRESS_QT: (case, kernel error, fp32 restatement error) of the query-time cases above 1e-4 whose fp32 restatement is too
+
+
 def run_case(i, rng):
-    kw, cfg, P, keys, query, Ts, time = draw_case(rng)
+    kw, cfg, P, keys, query, Ts, time = draw_case(rng, index=i)
     max_nb = cfg.max_neighbors
     kw_o = dict(kw)
     ocfg_patch = {'max_neighbors': max_nb}
@@ -117,6 +126,11 @@ def run_case(i, rng):
         print(f"   (fp32 restatement vs fp64: {gap:.2e}; kernel vs fp32 restatement: {e32:.2e})")
         if e32 < 2e-5 and gap > 0.5 * err:
             err = e32
+        elif kw.get('query_time_encoding') and err < 1.25 * gap:
+            # query_time_encoding with randomised weights: the reference's OWN fp32 arithmetic is outside 1e-4 of fp64 here (the time-dependent destination
+            # message, tests/test_gpu_parity.py::test_query_time_encoding) and the kernel is no farther than it.  Counted separately, never as "within 1e-4".
+            AT_FP32_FLOOR.append((i, err, gap))
+            print(f"   (query-time case at the fp32 restatement's own floor: kernel {err:.2e}, restatement {gap:.2e} from fp64)")
     if err >= 1e-4 and edges_ok and any(r is not None and len(k.x) > max_nb for k, r in zip(keys, cfg.radii)):
         # a key within fp32 rounding of a radius UNDER A BINDING NEIGHBOUR CAP?  Whether that pair is a neighbour is decided by the last bit of an fp32
         # distance (the reference's torch_cluster kernel has the same ambiguity); without a cap it would only add or drop an edge of weight ~0, with
@@ -138,7 +152,7 @@ def run_case(i, rng):
 
 def run_sample_case(i, rng):
     """ScoreModelBase.sample (3-5 Langevin steps, injected noise) against the oracle's float64 loop with an fp32 score"""
-    kw, cfg, P, keys, query, Ts, time = draw_case(rng)
+    kw, cfg, P, keys, query, Ts, time = draw_case(rng, index=i)
     import oracle.restatement as R
     from diffusion_edf_amd.score_head import ScoreModelHead
     from diffusion_edf_amd.score_model_base import ScoreModelBase
@@ -176,7 +190,14 @@ def run_sample_case(i, rng):
     sc = float(max(a64.abs().max(), l64.abs().max()))
     seed_err = max(float((ag.cpu().double() - a64).abs().max()), float((lg.cpu().double() - l64).abs().max())) / sc
     step1 = float((out[1] - ref[1]).abs().max())
-    ok_ = out.shape == ref.shape and bool(torch.isfinite(out).all()) and seed_err < 1e-4 and step1 < 1e-4
+    seed_bar = 1e-4
+    if seed_err >= 1e-4 and kw.get('query_time_encoding'):      # (DEDF_STRESS_QT) the reference's own fp32 arithmetic as the floor, as in run_case -- and said so
+        a32, l32 = R.score_head_forward(ocfg, R.cast_params(P, torch.float32), Ts.float(), ok, oq, t0.float())
+        gap = max(float((a32.double() - a64).abs().max()), float((l32.double() - l64).abs().max())) / sc
+        print(f"   (query-time case: fp32 restatement {gap:.2e} from fp64 at the seed poses, kernel {seed_err:.2e})")
+        if seed_err < 1.25 * gap:
+            AT_FP32_FLOOR.append((i, seed_err, gap)); seed_bar = 1.25 * gap
+    ok_ = out.shape == ref.shape and bool(torch.isfinite(out).all()) and seed_err < seed_bar and step1 < 1e-4
     print(f"sample {i:3d} score at the seed poses {seed_err:.2e}, after step 1 {step1:.2e}; after all steps |dT| {err:.2e} (poses moved {move:.2e}) steps {n_steps} nT {len(Ts)} "
           f"lmax {cfg.lmax} radii {cfg.radii} cap {cfg.max_neighbors}", flush=True)
     if err > 2e-4:      # where along the trajectory the difference appears: a step that starts it, or growth from the rounding level
@@ -267,15 +288,17 @@ def main():
         rng = np.random.default_rng(seed)
         res = [fn(i, rng) for i in range(n)]
         nbad = sum(1 for r in res if not r[1])
-        print("FAILED" if nbad else "ALL OK", nbad, "of", n, "largest difference", max(r[0] for r in res))
+        print("FAILED" if nbad else "ALL OK", nbad, "of", n, "largest difference", max(r[0] for r in res),
+              f"({len(AT_FP32_FLOOR)} query-time cases at the fp32 restatement's own floor: {[(i, float(f'{e:.2e}'), float(f'{g:.2e}')) for i, e, g in AT_FP32_FLOOR]})" if AT_FP32_FLOOR else "")
         sys.exit(1 if nbad else 0)
     rng = np.random.default_rng(seed)
     bad = []
     for i in range(n):
         err, eok, desc = run_case(i, rng)
-        if not (err < 1e-4 and eok):
+        if not (err < 1e-4 and eok) and not any(f[0] == i for f in AT_FP32_FLOOR):
             bad.append((i, err, eok, desc))
-    print("FAILED" if bad else "ALL OK", len(bad), "of", n)
+    print("FAILED" if bad else "ALL OK", len(bad), "of", n, f"({n - len(bad) - len(AT_FP32_FLOOR)} within 1e-4, {len(AT_FP32_FLOOR)} query-time cases at the fp32 restatement's own floor: "
+          f"{[(i, float(f'{e:.2e}'), float(f'{g:.2e}')) for i, e, g in AT_FP32_FLOOR]})" if AT_FP32_FLOOR else "")
     for b in bad:
         print(b)
     sys.exit(1 if bad else 0)
