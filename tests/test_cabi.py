@@ -81,6 +81,10 @@ def test_unsupported_configs_are_rejected(built_lib):
     kw['key_tensor_field_kwargs']['fc_neurons'] = [-1, 32, 32]
     with pytest.raises(NotImplementedError):
         params.HeadConfig.from_kwargs(kw)
+    kw = synthetic.score_head_kwargs(2)                       # neither keyword given: the constructor's defaults ARE this shape
+    del kw['query_time_encoding'], kw['edge_time_encoding']
+    cfg = params.HeadConfig.from_kwargs(kw)
+    assert cfg.query_time_encoding and cfg.fc_neurons == [64, 128, 64] and built_lib.dedf_param_count(C.byref(_lib.make_config(cfg, -1))) > 0
     for bad in (dict(lmax=1, half_gemm=1), dict(lmax=1, fc=(128, 32, 32)), dict(lmax=3, half_gemm=1), dict(lmax=3, fc=(128, 32, 32))):       # query_time_encoding at lmax 1 / 3: [128,128,64], full precision only
         cfg = params.HeadConfig.from_kwargs(synthetic.score_head_kwargs(bad.get('lmax', 2), query_time_encoding=True))
         cc = _lib.make_config(cfg, -1)
