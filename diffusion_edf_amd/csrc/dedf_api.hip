@@ -67,7 +67,7 @@ struct dedf_handle {
     int n_cu = 256;
     // device: weights
     DevBuf d_edge_w, d_node_w, d_nat;     // d_nat: natural-layout weights for the small kernels
-    size_t nat_tw1 = 0, nat_tb1 = 0, nat_tw2 = 0, nat_tb2 = 0, nat_wpre = 0, nat_bpre = 0, nat_lnw = 0, nat_lnb = 0, nat_wsrc = 0, nat_bsrc = 0, nat_tfreq = 0, nat_brows = 0, nat_wdst = 0, nat_bdst = 0;
+    size_t nat_tw1 = 0, nat_tb1 = 0, nat_tw2 = 0, nat_tb2 = 0, nat_wpre = 0, nat_bpre = 0, nat_lnw = 0, nat_lnb = 0, nat_wsrc = 0, nat_bsrc = 0, nat_brows = 0, nat_wdst = 0, nat_bdst = 0;
     size_t nat_qw1 = 0, nat_qb1 = 0, nat_qw2 = 0, nat_qb2 = 0, nat_qlnw = 0, nat_qlnb = 0, nat_qwdst = 0, nat_qbdst = 0, nat_qwskip = 0, nat_qbskip = 0;      // query_time_encoding
     DevBuf d_msg_dst;
     // device: scene / query
@@ -366,13 +366,6 @@ int upload_weights(dedf_handle* h) {
         h->nat_qwdst = put(S.get(B, blk + ".linear_dst.tp.weight"), tT * mul_of(0)); h->nat_qbdst = put(S.get(B, blk + ".linear_dst.bias.0"), mul_of(0));
         h->nat_qwskip = put(S.get(B, blk + ".skip_1.skip.tp.weight"), tT * mul_of(0)); h->nat_qbskip = put(S.get(B, blk + ".skip_1.skip.bias.0"), mul_of(0));
     }
-    {   // time-encoding frequencies, evaluated like torch: exp(float(k) * float(-ln(n)/127)) in float32
-        const int half = c.time_emb_mlp[0] / 2;
-        std::vector<float> fr(half);
-        const double step = std::log((double)c.time_enc_n) / (half - 1);
-        for (int k = 0; k < half; ++k) fr[k] = std::exp((float)k * (float)(-step));
-        h->nat_tfreq = put(fr.data(), half);
-    }
     if (c.fc_neurons[0] == kLenEmb) {   // no edge time encoding (EBM head, score head with query_time_encoding only): the pre-linear "time rows" are just its bias, row-packed once
         std::vector<float> rows;
         for (int n = 0; n < ns; ++n) {
@@ -433,7 +426,7 @@ void launch_time_bias(dedf_handle* h, hipStream_t st, const float* time, int tim
     TimeParams tp{};
     tp.time = time; tp.time_stride = time_stride;
     tp.w1 = nat + h->nat_tw1; tp.b1 = nat + h->nat_tb1; tp.w2 = nat + h->nat_tw2; tp.b2 = nat + h->nat_tb2;
-    tp.wpre = nat + h->nat_wpre; tp.bpre = nat + h->nat_bpre; tp.tfreq = nat + h->nat_tfreq;
+    tp.wpre = nat + h->nat_wpre; tp.bpre = nat + h->nat_bpre;
     tp.E = c.time_emb_mlp[0]; tp.H = c.time_emb_mlp[1]; tp.TE = c.time_emb_mlp[2];
     tp.max_time = c.max_time; tp.time_enc_n = c.time_enc_n; tp.tb = tb; tp.varies = varies;
     hipLaunchKernelGGL(k_time_bias, dim3(rows, c.n_scales), dim3(256), 0, st, tp);
@@ -447,7 +440,7 @@ void launch_time_query(dedf_handle* h, hipStream_t st, const float* time, int ti
     tp.time = time; tp.time_stride = time_stride;
     tp.w1 = nat + h->nat_qw1; tp.b1 = nat + h->nat_qb1; tp.w2 = nat + h->nat_qw2; tp.b2 = nat + h->nat_qb2;
     tp.ln_w = nat + h->nat_qlnw; tp.ln_b = nat + h->nat_qlnb; tp.wdst = nat + h->nat_qwdst; tp.bdst = nat + h->nat_qbdst;
-    tp.wskip = nat + h->nat_qwskip; tp.bskip = nat + h->nat_qbskip; tp.tfreq = nat + h->nat_tfreq;
+    tp.wskip = nat + h->nat_qwskip; tp.bskip = nat + h->nat_qbskip;
     tp.E = c.time_emb_mlp[0]; tp.H = c.time_emb_mlp[1]; tp.TE = c.time_emb_mlp[2];
     tp.max_time = c.max_time; tp.time_enc_n = c.time_enc_n; tp.out_scale = h->eo.msg_scale; tp.rows = out;
     hipLaunchKernelGGL(k_time_query, dim3(rows), dim3(256), 0, st, tp);
@@ -1273,6 +1266,8 @@ static int sample_once(dedf_handle* h, int nT, const double* T_seed, const dedf_
     if (sched->n_steps > 0) {
         if (!h->d_tb_steps.ensure((size_t)sched->n_steps * tb_row * 4) || !h->d_time.ensure((size_t)std::max(nT, sched->n_steps) * 4))
             return fail(h, DEDF_ERR_RUNTIME, "hipMalloc(time rows) failed");
+        // (the score head sees the step's time as FLOAT32, like the reference's: score_model_base.py:177 `time = t.repeat(len(T)).type(dtype)`;
+        //  the Langevin update below uses the float64 value)
         float* pin_t = reinterpret_cast<float*>(h->h_pin) + 128;
         for (int s = 0; s < sched->n_steps; ++s) pin_t[s] = (float)sched->t[s];
         HIPCK(h, hipMemcpyAsync(h->d_time.p, pin_t, (size_t)sched->n_steps * 4, hipMemcpyHostToDevice, st));

@@ -113,7 +113,6 @@ struct TimeParams {
     const float* time; int time_stride;             // stride 0: one shared time
     const float *w1, *b1, *w2, *b2;                 // [n_scales][H][E], [H], [TE][H], [TE]
     const float *wpre, *bpre;                       // [n_scales][F0][F0], [F0]   (F0 = 64 + TE)
-    const float* tfreq;                             // [E/2] exp(k * -(ln n / (E/2 - 1))) evaluated on the host like torch does
     int E, H, TE;                                   // time_emb_mlp = [E, H, TE]: [256,128,64] or [512,256,128]
     float max_time, time_enc_n;
     float* tb;
@@ -121,40 +120,47 @@ struct TimeParams {
 };
 constexpr int kFlagTimeVaries = 45;      // word of tile_info, cleared at the start of every API call
 constexpr int kTimeMaxEnc = 512, kTimeMaxHid = 256, kTimeMaxEmb = 128;
+// The time path runs in FLOAT64 (round 6).  The sinusoid's argument reaches time_enc_n = 10 000 rad, where a float32 has an ulp of 1e-3 rad: in
+// float32 -- the reference's own arithmetic included -- the high-frequency channels carry an error of ~5e-4, which query_time_encoding passes
+// straight into every edge message (the fp32 restatement's destination message sits 6.6e-5 from the fp64 one; with edge time encoding alone the
+// pre-linear averages it down to 7e-6).  One row per pose / per step and ~50 k multiply-adds per row: float64 costs nothing here, and the rows are
+// exact functions of the float32 `time` the caller hands over (the reference's `time` tensor is float32 too, score_model_base.py:177).
+__device__ __forceinline__ void time_sinusoid(double t, double max_time, double n, int E, double* enc) {      // radial_func.py:291-316, exactly
+    const double x = t / max_time * n, step = log(n) / (double)(E / 2 - 1);
+    for (int i = threadIdx.x; i < E / 2; i += blockDim.x) {
+        const double a = x * exp(-(double)i * step);
+        enc[i] = sin(a);
+        enc[i + E / 2] = cos(a);
+    }
+}
 __global__ __launch_bounds__(256) void k_time_bias(TimeParams P) {
-    __shared__ float enc[kTimeMaxEnc], hid[kTimeMaxHid], emb[kTimeMaxEmb];
+    __shared__ double enc[kTimeMaxEnc], hid[kTimeMaxHid], emb[kTimeMaxEmb];
     const int p = blockIdx.x, n = blockIdx.y, n_scales = gridDim.y, tid = threadIdx.x;
     const int E = P.E, H = P.H, TE = P.TE, F0 = kLenEmb + TE;
-    const float t = P.time[p * P.time_stride];
-    if (P.varies != nullptr && n == 0 && tid == 0 && !(t == P.time[0])) *P.varies = 1;       // (a NaN time reads as "varies")
-    // SinusoidalPositionEmbeddings(dim E, max_val, n) — radial_func.py:305-316
-    const float x = t / P.max_time * P.time_enc_n;
-    for (int i = tid; i < E / 2; i += blockDim.x) {
-        const float fr = P.tfreq[i];
-        enc[i] = sinf(x * fr);
-        enc[i + E / 2] = cosf(x * fr);
-    }
+    const double t = (double)P.time[p * P.time_stride];
+    if (P.varies != nullptr && n == 0 && tid == 0 && !(t == (double)P.time[0])) *P.varies = 1;       // (a NaN time reads as "varies")
+    time_sinusoid(t, (double)P.max_time, (double)P.time_enc_n, E, enc);
     __syncthreads();
     for (int i = tid; i < H; i += blockDim.x) {
         const float* w = P.w1 + ((size_t)n * H + i) * E;
-        float s = P.b1[n * H + i];
-        for (int k = 0; k < E; ++k) s += w[k] * enc[k];
-        hid[i] = s / (1.0f + expf(-s));
+        double s = P.b1[n * H + i];
+        for (int k = 0; k < E; ++k) s += (double)w[k] * enc[k];
+        hid[i] = s / (1.0 + exp(-s));
     }
     __syncthreads();
     for (int i = tid; i < TE; i += blockDim.x) {
         const float* w = P.w2 + ((size_t)n * TE + i) * H;
-        float s = P.b2[n * TE + i];
-        for (int k = 0; k < H; ++k) s += w[k] * hid[k];
+        double s = P.b2[n * TE + i];
+        for (int k = 0; k < H; ++k) s += (double)w[k] * hid[k];
         emb[i] = s;
     }
     __syncthreads();
     for (int i = tid; i < F0; i += blockDim.x) {
         const float* w = P.wpre + ((size_t)n * F0 + i) * F0 + kLenEmb;
-        float s = P.bpre[n * F0 + i];
-        for (int k = 0; k < TE; ++k) s += w[k] * emb[k];
+        double s = P.bpre[n * F0 + i];
+        for (int k = 0; k < TE; ++k) s += (double)w[k] * emb[k];
         const int tile = i >> 5, row = i & 31;
-        P.tb[((size_t)p * n_scales + n) * F0 + (tile * 2 + row_hi(row)) * 16 + row_reg(row)] = s;
+        P.tb[((size_t)p * n_scales + n) * F0 + (tile * 2 + row_hi(row)) * 16 + row_reg(row)] = (float)s;
     }
 }
 
@@ -173,61 +179,55 @@ struct TimeQueryParams {
     const float *w1, *b1, *w2, *b2;                 // query_time_mlp: [H][E], [H], [TE][H], [TE]
     const float *ln_w, *ln_b;                       // prenorm_dst affine [TE], [TE]
     const float *wdst, *bdst, *wskip, *bskip;       // LinearRS 0e -> 0e: [TE][64] (in x out), [64]
-    const float* tfreq;
     int E, H, TE;
     float max_time, time_enc_n, out_scale;
     float* rows;
 };
-__global__ __launch_bounds__(256) void k_time_query(TimeQueryParams P) {
-    __shared__ float enc[kTimeMaxEnc], hid[kTimeMaxHid], emb[kTimeMaxEmb], nrm[kTimeMaxEmb], red[2];
+__global__ __launch_bounds__(256) void k_time_query(TimeQueryParams P) {      // (float64 like k_time_bias: see there)
+    __shared__ double enc[kTimeMaxEnc], hid[kTimeMaxHid], emb[kTimeMaxEmb], nrm[kTimeMaxEmb], red[2];
     const int p = blockIdx.x, tid = threadIdx.x;
     const int E = P.E, H = P.H, TE = P.TE;
-    const float t = P.time[p * P.time_stride];
-    const float x = t / P.max_time * P.time_enc_n;
-    for (int i = tid; i < E / 2; i += blockDim.x) {
-        const float fr = P.tfreq[i];
-        enc[i] = sinf(x * fr);
-        enc[i + E / 2] = cosf(x * fr);
-    }
+    const double t = (double)P.time[p * P.time_stride];
+    time_sinusoid(t, (double)P.max_time, (double)P.time_enc_n, E, enc);
     __syncthreads();
     for (int i = tid; i < H; i += blockDim.x) {
         const float* w = P.w1 + (size_t)i * E;
-        float s = P.b1[i];
-        for (int k = 0; k < E; ++k) s += w[k] * enc[k];
-        hid[i] = s / (1.0f + expf(-s));
+        double s = P.b1[i];
+        for (int k = 0; k < E; ++k) s += (double)w[k] * enc[k];
+        hid[i] = s / (1.0 + exp(-s));
     }
     __syncthreads();
     for (int i = tid; i < TE; i += blockDim.x) {
         const float* w = P.w2 + (size_t)i * H;
-        float s = P.b2[i];
-        for (int k = 0; k < H; ++k) s += w[k] * hid[k];
+        double s = P.b2[i];
+        for (int k = 0; k < H; ++k) s += (double)w[k] * hid[k];
         emb[i] = s;
     }
     __syncthreads();
     if (tid == 0) {      // EquivariantLayerNormV2 on TE x 0e (layer_norm.py:113-146): mean-free, 'component' norm over the block, eps 1e-5
-        float mean = 0.0f;
+        double mean = 0.0;
         for (int k = 0; k < TE; ++k) mean += emb[k];
         mean /= TE;
-        float v = 0.0f;
-        for (int k = 0; k < TE; ++k) { const float d = emb[k] - mean; v += d * d; }
-        red[0] = mean; red[1] = 1.0f / sqrtf(v / TE + 1e-5f);
+        double v = 0.0;
+        for (int k = 0; k < TE; ++k) { const double d = emb[k] - mean; v += d * d; }
+        red[0] = mean; red[1] = 1.0 / sqrt(v / TE + 1e-5);
     }
     __syncthreads();
-    for (int i = tid; i < TE; i += blockDim.x) nrm[i] = (emb[i] - red[0]) * (red[1] * P.ln_w[i]) + P.ln_b[i];
+    for (int i = tid; i < TE; i += blockDim.x) nrm[i] = (emb[i] - red[0]) * (red[1] * (double)P.ln_w[i]) + (double)P.ln_b[i];
     __syncthreads();
     constexpr int M0 = mul_of(0);
     float* const o = P.rows + (size_t)p * kQueryTimeRow;
     for (int i = tid; i < 2 * M0; i += blockDim.x) {
         const int w = i % M0;
         if (i < M0) {
-            float s = P.bdst[w];
-            for (int u = 0; u < TE; ++u) s += P.wdst[u * M0 + w] * nrm[u];
-            o[w] = s * P.out_scale;
+            double s = P.bdst[w];
+            for (int u = 0; u < TE; ++u) s += (double)P.wdst[u * M0 + w] * nrm[u];
+            o[w] = (float)(s * (double)P.out_scale);
         } else {
-            float s = P.bskip[w];
-            for (int u = 0; u < TE; ++u) s += P.wskip[u * M0 + w] * emb[u];
+            double s = P.bskip[w];
+            for (int u = 0; u < TE; ++u) s += (double)P.wskip[u * M0 + w] * emb[u];
             const int tile = w >> 5, row = w & 31;
-            o[M0 + (tile * 2 + row_hi(row)) * 16 + row_reg(row)] = s;
+            o[M0 + (tile * 2 + row_hi(row)) * 16 + row_reg(row)] = (float)s;
         }
     }
 }

@@ -78,7 +78,9 @@ def build_case(lmax=2, nT=6, n_scene=512, n_grasp=100, seed=0, radii=(5., 10., 2
     Ts = synthetic.make_poses(nT, seed=1, near_object=near)
     if identity_pose and nT > 1:
         Ts[0] = torch.tensor([1., 0, 0, 0, 0., 0., 12.], dtype=torch.float64)     # notebook seed quaternion (YXY quirk)
-    time = torch.linspace(0.2, 1.0, nT, dtype=torch.float64)
+    # (float32-representable: the C ABI takes the diffusion time as float32 -- the reference's `time` tensor -- and the sinusoidal encoding multiplies
+    #  it by time_enc_n = 10 000: an oracle evaluated at the UNROUNDED float64 value would sit 3e-4 rad away in the high-frequency channels)
+    time = torch.linspace(0.2, 1.0, nT, dtype=torch.float64).float().double()
     return kw, cfg, P, keys, query, Ts, time
 
 
@@ -88,7 +90,7 @@ def oracle_run(kw, P, keys, query, Ts, time, dtype):
     okeys = [R.FeaturedPoints(k.x.to(dtype), k.f.to(dtype), k.b, None if k.w is None else k.w.to(dtype)) for k in keys]
     oq = R.FeaturedPoints(query.x.to(dtype), query.f.to(dtype), query.b, query.w.to(dtype))
     dbg = R.Debug()
-    ang, lin = R.score_head_forward(ocfg, Pd, Ts.to(dtype), okeys, oq, time.to(dtype), dbg)
+    ang, lin = R.score_head_forward(ocfg, Pd, Ts.to(dtype), okeys, oq, time.float().to(dtype), dbg)      # (the time as the C ABI receives it: float32)
     return ang, lin, dbg, ocfg
 
 

@@ -73,6 +73,7 @@ def draw_case(rng: np.random.Generator, max_lmax: int = 3, index: int = 0):
         Ts = Ts[: max(1, len(Ts) // 2)]
     nT = len(Ts)
     time = torch.rand(nT, dtype=torch.float64, generator=torch.Generator().manual_seed(seed)) * 0.95 * kw['max_time'] + 0.02 * kw['max_time']
+    time = time.float().double()          # (float32-representable: the time as the C ABI receives it, tests/stage_check.py::build_case)
     return kw, cfg, P, keys, query, Ts, time
 
 
