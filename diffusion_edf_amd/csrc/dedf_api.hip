@@ -487,7 +487,8 @@ inline int edge_wpc_limit() {      // experiments only: DEDF_EDGE_WAVES_PER_CU=1
 template <int L, int F0, bool HP, int H1, int H2, int MODE> constexpr bool so2_shape() {
     if (HP && MODE != 0) return false;      // (half precision evaluates per edge: no table-reading instantiation)
     if (L == 3) return MODE == 1 ? (F0 == 128 && H1 == 128) : ((F0 == 128 && H1 == 128) || F0 == 64);
-    if (MODE == 1) return L == 2 && ((F0 == 128 && ((H1 == 128 && H2 == 64) || (H1 == 32 && H2 == 32))) || (F0 == 192 && H1 == 128 && H2 == 64));
+    if (MODE == 1) return (L == 2 && ((F0 == 128 && ((H1 == 128 && H2 == 64) || (H1 == 32 && H2 == 32))) || (F0 == 192 && H1 == 128 && H2 == 64))) ||
+                          (L == 1 && F0 == 128 && H1 == 128 && H2 == 64);
     if (L == 2) return (F0 == 128 || F0 == 64) ? true : (F0 == 192 && H1 == 128);
     return (F0 == 128 || F0 == 64) && H1 == 128 ? true : (F0 == 128 && H1 == 32);      // lmax 1
 }
@@ -499,7 +500,7 @@ template <int L, int F0, bool HP, int H1, int H2, int MODE>
 void launch_edge(dedf_handle* h, hipStream_t st, const EdgeParams& P) {
     constexpr int kAll = 1 << 30;
     if (h->cfg.query_time_encoding) {      // (validate_config admits only these shapes)
-        constexpr bool qt = !HP && MODE <= 1 && (((L == 2 || L == 3 || (L == 1 && MODE == 0)) && F0 == 128 && H1 == 128 && H2 == 64) || (L == 2 && F0 == 128 && H1 == 32 && H2 == 32) ||
+        constexpr bool qt = !HP && MODE <= 1 && (((L == 1 || L == 2 || L == 3) && F0 == 128 && H1 == 128 && H2 == 64) || (L == 2 && F0 == 128 && H1 == 32 && H2 == 32) ||
                                                  (L == 2 && F0 == 192 && H1 == 128 && H2 == 64) || (MODE == 0 && F0 == 64 && H1 == 128 && H2 == 64));
         constexpr bool qt_hp = HP && MODE == 0 && L == 2 && F0 == 128 && H1 == 128 && H2 == 64;
         if constexpr (qt || qt_hp) DEDF_LAUNCH_PERSISTENT((k_edge<L, F0, HP, H1, H2, false, MODE, false, true, true>), kAll, st, P);
@@ -563,8 +564,8 @@ EdgeParams edge_params(dedf_handle* h, int nT, int time_stride) {
 }
 
 // ---- the sampler's radial table (dedf_edge.h: EdgeParams::rtab) ------------------------------------------------------------------------
-// instantiated for the score heads: lmax 2 with fc_neurons {128|192, 128, 64} and {128, 32, 32}; lmax 3 with {128, 128, 64}; full precision
-template <int L, int F0> constexpr bool has_radial_table() { return (L == 2 && (F0 == 128 || F0 == 192)) || (L == 3 && F0 == 128); }
+// instantiated for the score heads: lmax 2 with fc_neurons {128|192, 128, 64} and {128, 32, 32}; lmax 1 (round 6: config C1) and 3 with {128, 128, 64}; full precision
+template <int L, int F0> constexpr bool has_radial_table() { return (L == 2 && (F0 == 128 || F0 == 192)) || ((L == 1 || L == 3) && F0 == 128); }
 template <int L, int F0> bool table_instantiated(const dedf_handle* h) {
     const bool narrow = h->cfg.fc_neurons[1] == 32;
     return !h->cfg.half_gemm && !h->cfg.ebm && !(narrow && !(L == 2 && F0 == 128));
@@ -631,6 +632,7 @@ int radial_table_async(dedf_handle* h, int slot) {
 }
 int radial_table_async_dispatch(dedf_handle* h, int slot) {
     const int F0 = h->cfg.fc_neurons[0];
+    if (h->L == 1 && F0 == 128) return radial_table_async<1, 128>(h, slot);
     if (h->L == 2 && F0 == 128) return radial_table_async<2, 128>(h, slot);
     if (h->L == 2 && F0 == 192) return radial_table_async<2, 192>(h, slot);
     if (h->L == 3 && F0 == 128) return radial_table_async<3, 128>(h, slot);
@@ -639,6 +641,7 @@ int radial_table_async_dispatch(dedf_handle* h, int slot) {
 bool radial_table_instantiated_rt(const dedf_handle* h) {
     const int F0 = h->cfg.fc_neurons[0];
     if (h->L == 2 && F0 == 128) return table_instantiated<2, 128>(h);
+    if (h->L == 1 && F0 == 128) return table_instantiated<1, 128>(h);
     if (h->L == 2 && F0 == 192) return table_instantiated<2, 192>(h);
     if (h->L == 3 && F0 == 128) return table_instantiated<3, 128>(h);
     return false;
@@ -658,6 +661,7 @@ int radial_table_check(dedf_handle* h, hipStream_t st) {
 }
 int radial_table_check_dispatch(dedf_handle* h, hipStream_t st) {
     const int F0 = h->cfg.fc_neurons[0];
+    if (h->L == 1 && F0 == 128) return radial_table_check<1, 128>(h, st);
     if (h->L == 2 && F0 == 128) return radial_table_check<2, 128>(h, st);
     if (h->L == 2 && F0 == 192) return radial_table_check<2, 192>(h, st);
     if (h->L == 3 && F0 == 128) return radial_table_check<3, 128>(h, st);

@@ -80,8 +80,13 @@
     X(57, void k_edge<1, 128, false, 128, 64, false, 0, false, true, true>(EdgeParams)) \
     X(58, void k_edge<2, 64, false, 128, 64, false, 0, false, true, true>(EdgeParams))  \
     X(59, void k_edge<3, 64, false, 128, 64, false, 0, false, true, true>(EdgeParams))  \
-    X(60, void k_edge<1, 64, false, 128, 64, false, 0, false, true, true>(EdgeParams))
+    X(60, void k_edge<1, 64, false, 128, 64, false, 0, false, true, true>(EdgeParams))  \
+    X(61, void k_edge<1, 128, false, 128, 64, false, 1, false, true>(EdgeParams))       \
+    X(61, void k_radial_table<1, 128>(EdgeParams))                                      \
+    X(61, void k_radial_check<1, 128>(EdgeParams))                                      \
+    X(62, void k_edge<1, 128, false, 128, 64, false, 1, false, true, true>(EdgeParams))
 // (units 48-55: the score head with query_time_encoding -- trailing `true`: the pose's time row joins the 0e block of the gathered message;
 //  52-55: the two other lmax-2 score-head shapes the reference ships, radial MLP [128,32,32] and the 192-wide pre-linear; 56: half precision; 57: lmax 1, round 6;
-//  58-60: query_time_encoding WITHOUT edge_time_encoding -- the reference constructor's default -- at lmax 2 / 3 / 1: the 64-wide pre-linear of the EBM shapes)
-constexpr int kKernelUnits = 61;
+//  58-60: query_time_encoding WITHOUT edge_time_encoding -- the reference constructor's default -- at lmax 2 / 3 / 1: the 64-wide pre-linear of the EBM shapes;
+//  61-62: the sampler's radial table at lmax 1 -- BASELINE config C1 -- plain and with query_time_encoding)
+constexpr int kKernelUnits = 63;

@@ -315,6 +315,37 @@ def test_radial_table_of_the_sampler_against_the_per_edge_evaluation():
                 assert e_on < 1e-4 and e_on < e_off + 5e-6, (t, e_on, e_off)
 
 
+def test_radial_table_at_lmax_1():
+    """the sampler's radial table at lmax 1 (BASELINE config C1's degree; instantiated in round 6): one noise-free step with the table against the
+    per-edge evaluation (1e-5 of the displacement) and against the fp64 oracle (no farther from it than the per-edge path plus 5e-6)"""
+    dev = torch.device('cuda:0')
+    kw, cfg, P, keys, query, Ts, time = SC.build_case(1, 12, 1024, 128)
+    head = ScoreModelHead(**kw)
+    head.load_state_dict(P)
+    head.to(dev)
+    gk = [FeaturedPoints(k.x.to(dev), k.f.to(dev), k.b.to(dev)) for k in keys]
+    gq = FeaturedPoints(query.x.to(dev), query.f.to(dev), query.b.to(dev), query.w.to(dev))
+    ocfg = R.config_from_kwargs(kw)
+    k64 = [R.FeaturedPoints(k.x.double(), k.f.double(), k.b, None) for k in keys]
+    q64 = R.FeaturedPoints(query.x.double(), query.f.double(), query.b, query.w.double())
+    for t in (0.75, 0.0625):                      # (float32-representable: the head sees the step's time as float32)
+        outs = []
+        for on in ("always", False):
+            head.set_radial_table(on)
+            outs.append(ScoreModelBase(head).sample(Ts.to(dev), gk, gq, [[t, t]], [1], [0.04], temperatures=0.0).cpu())
+        d_on, d_off = (outs[0][1] - outs[0][0])[:, 4:], (outs[1][1] - outs[1][0])[:, 4:]
+        scale = float(d_off.abs().max())
+        assert scale > 1e-3
+        dev_on_off = float((d_on - d_off).abs().max()) / scale
+        assert 0.0 < dev_on_off < 1e-5, (t, dev_on_off)              # (> 0: the table path really ran)
+        ang, lin = R.score_head_forward(ocfg, R.cast_params(P, torch.float64), Ts, k64, q64, torch.full((len(Ts),), t, dtype=torch.float64))
+        z = torch.zeros(len(Ts), 3, dtype=torch.float64)
+        d_ref = (R.langevin_step(ocfg, Ts, ang, lin, t, 0.04, 0.0, 0.5, 0.5, z, z) - Ts)[:, 4:]
+        e_on, e_off = float((d_on - d_ref).abs().max()) / scale, float((d_off - d_ref).abs().max()) / scale
+        print(f"TOLPROBE lmax-1 radial table t={t}: table vs per-edge {dev_on_off:.1e}; vs oracle: table {e_on:.1e}, per-edge {e_off:.1e}")
+        assert e_on < 1e-4 and e_on < e_off + 5e-6, (t, e_on, e_off)
+
+
 @pytest.mark.parametrize("shape", ["time_emb_128", "narrow_radial_mlp"])
 def test_radial_table_other_score_head_shapes(shape):
     """the table path of the two other lmax-2 score-head shapes the reference ships: pre-linear 192 wide (time_emb_mlp [512,256,128], sapien
@@ -1192,11 +1223,19 @@ def test_full_size_c1_anchored_on_the_oracle_and_sharded_sampling():
     head = _gpu_head(kw, P, dev)
     sel = torch.tensor([0, 1, 2, 31, 32, 63, 100, 127, 128, 200, 254, 255], device=dev)
     t_all = torch.full((256,), 0.5, device=dev)
+    # (pose independence is a statement about ONE arithmetic: since round 6 the 256-pose batch -- 13 312 nodes, one shared time -- reads the radial table
+    #  at lmax 1 too, the 12-pose subset evaluates the front per edge; the table is switched off for this comparison and on again for the oracle's)
+    head.set_radial_table(False)
     ang_all, lin_all = head(Ts.float(), keys, query, t_all)
     assert head.stats()['n_edges_total'] > 100_000 and not head.stats()['overflow']
     ang_s, lin_s = head(Ts[sel].float(), keys, query, t_all[:len(sel)])
     scale = float(max(ang_all.abs().max(), lin_all.abs().max()))
     assert float((ang_all[sel] - ang_s).abs().max()) / scale < 2e-6 and float((lin_all[sel] - lin_s).abs().max()) / scale < 2e-6
+    head.set_radial_table(True)
+    ang_tab, lin_tab = head(Ts.float(), keys, query, t_all)
+    d_tab = max(float((ang_tab - ang_all).abs().max()), float((lin_tab - lin_all).abs().max())) / scale
+    assert 0.0 < d_tab < 1e-5, d_tab                                 # the table path ran, within its bound of the per-edge evaluation
+    ang_all, lin_all = ang_tab, lin_tab
     ocfg = R.config_from_kwargs(kw)
     ok = [R.FeaturedPoints(k.x.cpu().double(), k.f.cpu().double(), k.b.cpu()) for k in keys]
     oq = R.FeaturedPoints(query.x.cpu().double(), query.f.cpu().double(), query.b.cpu(), query.w.cpu().double())
